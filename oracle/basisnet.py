@@ -1,0 +1,102 @@
+"""Oracle (test infrastructure): BasisNet / LearningFilters forward pieces, restated functionally.
+
+Reference: /root/reference/LearningFilters/ign.py:29-39 (IGN2to1.forward), :117-128 (layer_2_to_1),
+:203-214 (layer_1_to_1), :344-374 / :404-417 (contractions); signbasisnet.py:11-41 (SignPlus,
+IGNBasisInv); models.py:58-113 (EqDeepSetsEncoder); training.py:47-73,119-126 (eigenspace grouping
+and the basis_inv feature assembly).
+
+IGN2to1 equivariant coefficients are NOT in the module's state_dict when the module is built on a
+non-default device, so they are passed explicitly: `eq` is a list of
+(coeffs [D,S,B], bias [1,S,1]) for the three equivariant layers.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+def _bn_cn(sd, pfx, x, training):
+    """BatchNorm1d on [b, C, n] (stats over b*n)."""
+    if training or (pfx + ".running_mean") not in sd:
+        return F.batch_norm(x, None, None, sd[pfx + ".weight"], sd[pfx + ".bias"], True, 0.0, BN_EPS)
+    return F.batch_norm(x, sd[pfx + ".running_mean"], sd[pfx + ".running_var"],
+                        sd[pfx + ".weight"], sd[pfx + ".bias"], False, 0.0, BN_EPS)
+
+
+def contractions_2_to_1(X):
+    """ign.py:344-374 with normalization='inf'.  X [b,D,n,n] -> [b,D,5,n]."""
+    n = X.shape[-1]
+    diag = torch.diagonal(X, dim1=2, dim2=3)
+    tr = diag.sum(2, keepdim=True).expand(-1, -1, n) / n
+    rows = X.sum(3) / n
+    cols = X.sum(2) / n
+    tot = X.sum((2, 3)).unsqueeze(2).expand(-1, -1, n) / (n ** 2)
+    return torch.stack([diag, tr, rows, cols, tot], dim=2)
+
+
+def contractions_1_to_1(h):
+    """ign.py:404-417.  h [b,D,n] -> [b,D,2,n]."""
+    n = h.shape[-1]
+    return torch.stack([h, h.sum(2, keepdim=True).expand(-1, -1, n) / n], dim=2)
+
+
+def ign2to1(sd, eq, X, training=False, pfx=""):
+    """IGN2to1.forward — ign.py:29-39 (ReLU BEFORE BatchNorm)."""
+    (c0, b0), (c1, b1), (c2, b2) = eq
+    h = torch.einsum("dsb,ndbi->nsi", c0, contractions_2_to_1(X)) + b0
+    h = _bn_cn(sd, pfx + "bns.0", torch.relu(h), training)
+    h = torch.einsum("dsb,ndbi->nsi", c1, contractions_1_to_1(h)) + b1
+    h = _bn_cn(sd, pfx + "bns.1", torch.relu(h), training)
+    h = torch.einsum("dsb,ndbi->nsi", c2, contractions_1_to_1(h)) + b2
+    h = _bn_cn(sd, pfx + "bns.2", torch.relu(h), training)
+    h = h.transpose(2, 1)
+    h = torch.relu(F.linear(h, sd[pfx + "fc1.weight"], sd[pfx + "fc1.bias"]))
+    h = F.linear(h, sd[pfx + "fc2.weight"], sd[pfx + "fc2.bias"])
+    return h.transpose(2, 1)
+
+
+def eq_deepsets(sd, x, num_layers, use_bn, pfx=""):
+    """EqDeepSetsEncoder.forward — models.py:91-113.  BN has track_running_stats=False, so it
+    always normalises with batch statistics (models.py:74,80)."""
+    for i in range(num_layers - 1):
+        x1 = F.linear(x, sd[f"{pfx}lins1.{i}.weight"], sd[f"{pfx}lins1.{i}.bias"])
+        x2 = F.linear(x.mean(dim=-2, keepdim=True), sd[f"{pfx}lins2.{i}.weight"], sd[f"{pfx}lins2.{i}.bias"])
+        x = torch.relu(x1 + x2)
+        if use_bn:
+            w, b = sd[f"{pfx}bns.{i}.weight"], sd[f"{pfx}bns.{i}.bias"]
+            if x.dim() == 2:
+                x = F.batch_norm(x, None, None, w, b, True, 0.0, BN_EPS)
+            else:
+                x = F.batch_norm(x.transpose(2, 1), None, None, w, b, True, 0.0, BN_EPS).transpose(2, 1)
+    i = num_layers - 1
+    x1 = F.linear(x, sd[f"{pfx}lins1.{i}.weight"], sd[f"{pfx}lins1.{i}.bias"])
+    x2 = F.linear(x.mean(dim=-2, keepdim=True), sd[f"{pfx}lins2.{i}.weight"], sd[f"{pfx}lins2.{i}.bias"])
+    return x1 + x2
+
+
+def sign_plus_deepsets(sd, v, num_layers, use_bn, pfx="model."):
+    """SignPlus.forward — signbasisnet.py:16-18 with an EqDeepSetsEncoder inside."""
+    return eq_deepsets(sd, v, num_layers, use_bn, pfx) + eq_deepsets(sd, -v, num_layers, use_bn, pfx)
+
+
+def group_eigenspaces(eigvals, eigvecs, decimals=5):
+    """training.py:47-73: round eigenvalues, group eigenvectors by rounded value, P = V V^T,
+    stack by multiplicity.  Returns {mult: [b,1,N,N]} in ascending-eigenvalue order."""
+    N = eigvecs.shape[0]
+    rounded = torch.round(eigvals * 10 ** decimals) / (10 ** decimals)
+    _, counts = rounded.unique(return_counts=True)
+    sections = torch.cumsum(counts, 0)
+    spaces = torch.tensor_split(eigvecs, sections, dim=1)[:-1]
+    groups = {}
+    for V, c in zip(spaces, counts.tolist()):
+        groups.setdefault(c, []).append((V @ V.T).reshape(1, 1, N, N))
+    return {m: torch.cat(ps, 0) for m, ps in sorted(groups.items())}, counts
+
+
+def basis_inv_features(phi_outs, eigvals, N):
+    """training.py:119-123: `phi_out.reshape(N, -1)` (a plain reshape of [b,mult,N], as the
+    reference does) concatenated, then eigvals tiled [N,N] appended -> [N, 2N]."""
+    feats = torch.cat([p.reshape(N, -1) for p in phi_outs], dim=-1)
+    return torch.cat([feats, eigvals.unsqueeze(0).repeat(N, 1)], dim=-1)

@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/*.npz.  BUILD-CONTAINER ONLY.
+
+Imports the reference's own module code from /root/reference (unmodified) with the
+third-party graph ops it needs (absent from the image) supplied by tests/golden/ref_shim/,
+runs it on tiny seeded batches and stores inputs, the full state_dict and the outputs.
+The fixtures are plain arrays; nothing of the reference's source travels with them.
+
+    python tests/golden/make_golden.py          # rewrites every fixture
+
+The GPU box never runs this (it has no /root/reference).
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+SHIM = os.path.join(HERE, "ref_shim")
+sys.path.insert(0, ROOT)
+
+from signnet_basisnet_amd import synth  # noqa: E402
+
+
+def _fresh_import(tree, names):
+    """Import reference modules from one tree with the shim ahead of everything."""
+    for m in list(sys.modules):
+        if m.split(".")[0] in ("sign_net", "core", "layers", "nets", "ign", "signbasisnet", "models"):
+            del sys.modules[m]
+    sys.path[:0] = [SHIM, os.path.join(REF, tree)]
+    try:
+        return [importlib.import_module(n) for n in names]
+    finally:
+        del sys.path[:2]
+
+
+def randomise(model, seed):
+    """Make BN running stats / affines and GIN eps non-trivial so eval-mode BN is not the identity."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, mod in model.named_modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                if mod.running_mean is not None:
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                mod.weight.copy_(1 + 0.2 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+            if isinstance(mod, torch.nn.LayerNorm):
+                mod.weight.copy_(1 + 0.2 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+        for name, p in model.named_parameters():
+            if name.endswith(".eps"):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+
+
+_SKIP = re.compile(r"(embeddings\.[1-9]\.|phi\.edge_encoders\.|\.layer\.nn\.)")
+
+
+def sd_arrays(model):
+    """State dict as arrays.  To keep fixtures small the tensors that never influence the forward
+    (embedding tables of feature columns 1..9 — ZINC has one column; GNN3d.edge_encoders — unused,
+    core/sign_net.py:22,40; the second registration of each GINE MLP under `.layer.nn.`,
+    pyg_gnn_wrapper.py:22-23) are listed by key+shape only (`meta/sd_keys`, `meta/sd_shapes`)."""
+    sd = model.state_dict()
+    out = {"sd/" + k: v.detach().cpu().clone().numpy() for k, v in sd.items() if not _SKIP.search(k)}
+    out["meta/sd_keys"] = np.array(list(sd.keys()))
+    out["meta/sd_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+    return out
+
+
+def data_arrays(data):
+    return {"in/" + k: v.numpy() for k, v in vars(data).items() if torch.is_tensor(v)} | {
+        "in/sizes": np.array(data.sizes, dtype=np.int64)}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays")
+
+
+# ------------------------------------------------------------------ PyG trees
+def pyg_case(name, variant, ctor_args, sizes, features, seed):
+    tree, modname = ("Alchemy", "sign_net.sign_net") if variant == "alchemy" else ("GINESignNetPyG", "core.sign_net")
+    (mod,) = _fresh_import(tree, [modname])
+    torch.manual_seed(seed)
+    model = mod.SignNetGNN(*ctor_args)
+    randomise(model, seed + 1)
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes, features=features)
+    cap = {}
+    hooks = [
+        model.sign_net.phi.register_forward_hook(lambda m, i, o: cap.setdefault("phi_calls", []).append(o.detach().clone())),
+        model.sign_net.register_forward_hook(lambda m, i, o: cap.__setitem__("pos", o.detach().clone())),
+    ]
+    for l, conv in enumerate(model.gnn.convs):
+        hooks.append(conv.register_forward_hook(
+            lambda m, i, o, l=l: cap.__setitem__(f"gine_conv{l}", o.detach().clone())))
+    arrays = {**sd_arrays(model), **data_arrays(data),
+              "meta/ctor": np.array([-1 if a is None else a for a in ctor_args], dtype=np.int64),
+              "meta/variant": np.array(variant)}
+    model.eval()
+    with torch.no_grad():
+        y = model(data)
+    arrays.update({"out/eval/y": y.numpy(), "out/eval/pos": cap["pos"].numpy(),
+                   "out/eval/phi_plus": cap["phi_calls"][0].numpy(),
+                   "out/eval/phi_minus": cap["phi_calls"][1].numpy()})
+    for l in range(len(model.gnn.convs)):
+        arrays[f"out/eval/gine_conv{l}"] = cap[f"gine_conv{l}"].numpy()
+    # train-mode forward (batch-stat BN).  The attention dropout p=0.1 that survives in train mode
+    # (transformer_module.py:46) is switched off so the fixture is deterministic.
+    cap.clear()
+    model.train()
+    for layer in model.sign_net.rho.transformer_layers:
+        layer.slf_attn.attention.dropout.p = 0.0
+    with torch.no_grad():
+        yt = model(data)
+    arrays.update({"out/train/y": yt.numpy(), "out/train/pos": cap["pos"].numpy()})
+    for h in hooks:
+        h.remove()
+    save(name, **arrays)
+
+
+# ------------------------------------------------------------------ DGL tree
+def dgl_case(name, kind, hidden, c, layers, k, sizes, seed):
+    mods = _fresh_import("GraphPrediction", ["nets.ZINC_graph_regression.sign_inv_net"])
+    import dgl  # the shim
+    params = dict(sign_inv_net=kind, hidden_dim=hidden, phi_out_dim=c, sign_inv_layers=layers,
+                  pos_enc_dim=k, dropout=0.0, sign_inv_activation="relu", device="cpu")
+    torch.manual_seed(seed)
+    net = mods[0].get_sign_inv_net(params)
+    randomise(net, seed + 1)
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes)
+    pe = synth.dgl_pos_enc(data, k)
+    g = dgl.Graph(data.edge_index[0], data.edge_index[1], torch.tensor(data.sizes))
+    x = pe.unsqueeze(-1)
+    arrays = {**sd_arrays(net), **data_arrays(data), "in/pos_enc": pe.numpy(),
+              "meta/params": np.array([hidden, c, layers, k], dtype=np.int64), "meta/kind": np.array(kind)}
+    net.eval()
+    with torch.no_grad():
+        arrays["out/eval/y"] = net(g, x.clone()).numpy()
+    net.train()
+    with torch.no_grad():
+        arrays["out/train/y"] = net(g, x.clone()).numpy()
+    save(name, **arrays)
+
+
+# ------------------------------------------------------------------ LearningFilters
+def basisnet_case(name, side, hidden, seed):
+    ign, sbn, models = _fresh_import("LearningFilters", ["ign", "signbasisnet", "models"])
+    from oracle import basisnet as ob
+    ei, N = synth.grid_graph(side)
+    D, V = synth.sym_laplacian_eigh(ei, N)
+    groups, counts = ob.group_eigenspaces(D, V)        # restates training.py:47-73 (module-level code)
+    mults = sorted(groups)
+    torch.manual_seed(seed)
+    # IGNBasisInv builds IGN2to1 with device='cuda' (signbasisnet.py:33) -> build the pieces on CPU
+    encs = [ign.IGN2to1(1, hidden, m, num_layers=2, device="cpu") for m in mults]
+    rho = models.EqDeepSetsEncoder(2 * N, hidden_channels=10, out_channels=8, num_layers=3, use_bn=True)
+    sign = sbn.SignPlus(models.EqDeepSetsEncoder(1, num_layers=3, use_bn=True))
+    for i, e in enumerate(encs):
+        randomise(e, seed + 10 + i)
+    randomise(rho, seed + 2)
+    randomise(sign, seed + 3)
+    arrays = {"in/eigvals": D.numpy(), "in/eigvecs": V.numpy(), "in/edge_index": ei,
+              "meta/mults": np.array(mults, dtype=np.int64), "meta/hidden": np.array(hidden)}
+    for mode in ("eval", "train"):
+        outs = []
+        for m, e in zip(mults, encs):
+            e.train(mode == "train")
+            with torch.no_grad():
+                outs.append(e(groups[m]))
+            arrays[f"out/{mode}/phi_m{m}"] = outs[-1].numpy()
+        feats = ob.basis_inv_features(outs, D, N)       # restates training.py:119-123
+        rho.train(mode == "train")
+        with torch.no_grad():
+            arrays[f"out/{mode}/rho"] = rho(feats).numpy()
+    for m, e in zip(mults, encs):
+        for k, v in e.state_dict().items():
+            arrays[f"sd/enc{m}/{k}"] = v.numpy()
+        for li, layer in enumerate(e.equi_layers):
+            arrays[f"eq/enc{m}/{li}/coeffs"] = layer.coeffs.detach().numpy()
+            arrays[f"eq/enc{m}/{li}/bias"] = layer.bias.detach().numpy()
+    for k, v in rho.state_dict().items():
+        arrays["sd/rho/" + k] = v.numpy()
+    for k, v in sign.state_dict().items():
+        arrays["sd/sign/" + k] = v.numpy()
+    sign.eval()
+    with torch.no_grad():
+        arrays["out/eval/signplus"] = sign(V.transpose(1, 0).unsqueeze(-1)).numpy()   # training.py:101-102
+    save(name, **arrays)
+
+
+def main():
+    # GINESignNetPyG: SignNetGNN(None, None, n_hid, n_out, nl_signnet, nl_gnn)
+    pyg_case("gine_d16", "gine", (None, None, 16, 1, 3, 2), [5, 7, 6, 9], "zinc", 11)
+    pyg_case("gine_d44_ragged", "gine", (None, None, 44, 3, 2, 2), [1, 2, 12, 4, 3], "zinc", 12)
+    pyg_case("gine_d32_deep", "gine", (None, None, 32, 1, 4, 6), [9, 17, 11, 20, 10, 13], "zinc", 13)
+    # Alchemy: SignNetGNN(node_feat, edge_feat, n_hid, n_out, nl_signnet, nl_gnn)  (nl_rho fixed at 4)
+    pyg_case("alchemy_d12", "alchemy", (6, 4, 12, 5, 3, 3), [6, 9, 7, 8], "alchemy", 21)
+    pyg_case("alchemy_d36", "alchemy", (6, 4, 36, 12, 2, 3), [10, 6, 14, 9, 11], "alchemy", 22)
+    # DGL sign-inv nets
+    dgl_case("dgl_gin_k8", "gin", 24, 4, 3, 8, [5, 9, 12, 7], 31)
+    dgl_case("dgl_masked_k10", "masked_gin", 20, 20, 3, 10, [5, 13, 8, 11], 32)
+    # BasisNet on a small grid
+    basisnet_case("basisnet_grid6", 6, 8, 41)
+
+
+if __name__ == "__main__":
+    main()

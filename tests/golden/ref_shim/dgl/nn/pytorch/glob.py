@@ -1,0 +1,6 @@
+import torch
+
+
+class SetTransformerEncoder(torch.nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()

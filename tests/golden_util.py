@@ -1,0 +1,55 @@
+"""Load tests/golden/*.npz fixtures (made by tests/golden/make_golden.py from the reference)."""
+import os
+import types
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    sd, inp, out, meta, eq = {}, {}, {}, {}, {}
+    for k in z.files:
+        grp, rest = k.split("/", 1)
+        a = z[k]
+        if grp == "sd":
+            sd[rest] = torch.from_numpy(a)
+        elif grp == "in":
+            inp[rest] = torch.from_numpy(a) if a.dtype.kind in "fiu" else a
+        elif grp == "out":
+            out[rest] = torch.from_numpy(a)
+        elif grp == "eq":
+            eq[rest] = torch.from_numpy(a)
+        else:
+            meta[rest] = a
+    return types.SimpleNamespace(sd=sd, inp=inp, out=out, meta=meta, eq=eq)
+
+
+def as_data(inp):
+    d = types.SimpleNamespace(**{k: v for k, v in inp.items() if k != "sizes"})
+    d.sizes = [int(s) for s in inp["sizes"]]
+    d.num_graphs = len(d.sizes)
+    d.num_nodes = int(sum(d.sizes))
+    return d
+
+
+def full_state_dict(fx):
+    """Reference-keyed state_dict with the skipped (forward-irrelevant) tensors zero-filled."""
+    sd = dict(fx.sd)
+    for k, shp in zip(fx.meta["sd_keys"], fx.meta["sd_shapes"]):
+        k = str(k)
+        if k not in sd:
+            shape = tuple(int(s) for s in str(shp).split(",") if s)
+            sd[k] = torch.zeros(shape, dtype=torch.long if k.endswith("num_batches_tracked") else torch.float32)
+    return sd
+
+
+PYG_CASES = ["gine_d16", "gine_d44_ragged", "gine_d32_deep", "alchemy_d12", "alchemy_d36"]
+
+
+def pyg_cfg(fx):
+    from oracle import pyg_signnet as O
+    c = [None if v < 0 else int(v) for v in fx.meta["ctor"]]
+    return O.make_cfg(str(fx.meta["variant"]), *c)

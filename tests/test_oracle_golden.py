@@ -1,0 +1,71 @@
+"""The oracle (oracle/*.py) against the golden fixtures produced by the reference's own module code."""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import basisnet as OB
+from oracle import dgl_deepsigns as OD
+from oracle import pyg_signnet as O
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+# batch-stat BN sums in a different order than the reference's transpose(2,1) layout -> fp32 noise
+TOL_BS = dict(rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", G.PYG_CASES)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_pyg_signnet_gnn(name, mode):
+    fx = G.load(name)
+    cfg, data = G.pyg_cfg(fx), G.as_data(fx.inp)
+    out = {}
+    y = O.signnet_gnn(fx.sd, cfg, data, training=(mode == "train"), out=out)
+    torch.testing.assert_close(out["pos"], fx.out[f"{mode}/pos"], **TOL)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL)
+    if mode == "eval":
+        torch.testing.assert_close(out["phi_plus_layers"][-1], fx.out["eval/phi_plus"], **TOL)
+        torch.testing.assert_close(out["phi_minus_layers"][-1], fx.out["eval/phi_minus"], **TOL)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gin_deepsigns(mode):
+    fx = G.load("dgl_gin_k8")
+    hidden, c, layers, k = (int(v) for v in fx.meta["params"])
+    ei = fx.inp["edge_index"]
+    y = OD.gin_deepsigns(fx.sd, ei[0], ei[1], fx.inp["pos_enc"].unsqueeze(-1), layers, k, training=(mode == "train"))
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_masked_gin_deepsigns(mode):
+    fx = G.load("dgl_masked_k10")
+    hidden, c, layers, k = (int(v) for v in fx.meta["params"])
+    ei = fx.inp["edge_index"]
+    y = OD.masked_gin_deepsigns(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["pos_enc"].unsqueeze(-1), layers, k,
+                                training=(mode == "train"))
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_basisnet(mode):
+    fx = G.load("basisnet_grid6")
+    D, V = fx.inp["eigvals"], fx.inp["eigvecs"]
+    N = V.shape[0]
+    groups, _ = OB.group_eigenspaces(D, V)
+    assert sorted(groups) == [int(m) for m in fx.meta["mults"]]
+    outs = []
+    for m in sorted(groups):
+        sd = {k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith(f"enc{m}/")}
+        eq = [(fx.eq[f"enc{m}/{i}/coeffs"], fx.eq[f"enc{m}/{i}/bias"]) for i in range(3)]
+        o = OB.ign2to1(sd, eq, groups[m], training=(mode == "train"))
+        torch.testing.assert_close(o, fx.out[f"{mode}/phi_m{m}"], rtol=1e-4, atol=1e-5)
+        outs.append(o)
+    feats = OB.basis_inv_features(outs, D, N)
+    rho_sd = {k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith("rho/")}
+    torch.testing.assert_close(OB.eq_deepsets(rho_sd, feats, 3, True), fx.out[f"{mode}/rho"], rtol=1e-4, atol=1e-5)
+
+
+def test_signplus_deepsets():
+    fx = G.load("basisnet_grid6")
+    sd = {k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith("sign/")}
+    v = fx.inp["eigvecs"].transpose(1, 0).unsqueeze(-1)
+    torch.testing.assert_close(OB.sign_plus_deepsets(sd, v, 3, True), fx.out["eval/signplus"], rtol=1e-4, atol=1e-5)
