@@ -171,6 +171,16 @@ def basisnet_case(name, side, hidden, seed):
     randomise(sign, seed + 3)
     arrays = {"in/eigvals": D.numpy(), "in/eigvecs": V.numpy(), "in/edge_index": ei,
               "meta/mults": np.array(mults, dtype=np.int64), "meta/hidden": np.array(hidden)}
+    for m, e in zip(mults, encs):
+        for k, v in e.state_dict().items():
+            arrays[f"sd/enc{m}/{k}"] = v.clone().numpy()
+        for li, layer in enumerate(e.equi_layers):
+            arrays[f"eq/enc{m}/{li}/coeffs"] = layer.coeffs.detach().clone().numpy()
+            arrays[f"eq/enc{m}/{li}/bias"] = layer.bias.detach().clone().numpy()
+    for k, v in rho.state_dict().items():
+        arrays["sd/rho/" + k] = v.clone().numpy()
+    for k, v in sign.state_dict().items():
+        arrays["sd/sign/" + k] = v.clone().numpy()
     for mode in ("eval", "train"):
         outs = []
         for m, e in zip(mults, encs):
@@ -182,16 +192,6 @@ def basisnet_case(name, side, hidden, seed):
         rho.train(mode == "train")
         with torch.no_grad():
             arrays[f"out/{mode}/rho"] = rho(feats).numpy()
-    for m, e in zip(mults, encs):
-        for k, v in e.state_dict().items():
-            arrays[f"sd/enc{m}/{k}"] = v.numpy()
-        for li, layer in enumerate(e.equi_layers):
-            arrays[f"eq/enc{m}/{li}/coeffs"] = layer.coeffs.detach().numpy()
-            arrays[f"eq/enc{m}/{li}/bias"] = layer.bias.detach().numpy()
-    for k, v in rho.state_dict().items():
-        arrays["sd/rho/" + k] = v.numpy()
-    for k, v in sign.state_dict().items():
-        arrays["sd/sign/" + k] = v.numpy()
     sign.eval()
     with torch.no_grad():
         arrays["out/eval/signplus"] = sign(V.transpose(1, 0).unsqueeze(-1)).numpy()   # training.py:101-102
