@@ -1,0 +1,88 @@
+"""ctypes binding of libsignnet_hip.so (the C ABI declared in include/signnet_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, the op raises.
+PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsignnet_hip.so")
+
+EPI_BIAS, EPI_RELU_PRE, EPI_AFFINE, EPI_RELU, EPI_RESIDUAL = 1, 2, 4, 8, 16
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (restype int unless noted).  Must mirror include/signnet_hip.h exactly;
+# tests/test_abi.py cross-checks the symbol list against the header.
+SIGNATURES = {
+    "sn_version": [],
+    "sn_device_info": [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "sn_pack_eig_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
+    "sn_pack_weight_f32": [_p, _i, _i, _i, _p, _p],
+    "sn_gin_aggregate_f32": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
+    "sn_gin_aggregate_slab_f32": [_p, _p, _l, _i, _l, _p, _p, _p, _p, _i, _p],
+    "sn_gine_aggregate_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p],
+    "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
+    "sn_colstats_blocks": [_l],
+    "sn_masked_colstats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _p],
+    "sn_masked_affine_f32": [_p, _i, _l, _i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
+    "sn_masked_layernorm_f32": [_p, _p, _l, _i, _p, _p, _f, _p, _i, _p, _p],
+    "sn_set_attention_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
+    "sn_slot_sum_f32": [_p, _l, _i, _i, _p, _p],
+    "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), _i, _p, _p],
+    "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
+}
+_SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m signnet_basisnet_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU/PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        L.sn_last_error.argtypes = []
+        L.sn_last_error.restype = C.c_char_p
+        L.sn_packed_weight_floats.argtypes = [_i, _i]
+        L.sn_packed_weight_floats.restype = C.c_int64
+        if L.sn_version() != 1:
+            raise RuntimeError("libsignnet_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().sn_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("signnet_basisnet_amd ops run on the GPU only (tensor is on %s); "
+                               "there is no CPU fallback" % t.device)

@@ -1,0 +1,660 @@
+// ops.hip — the layer-at-a-time kernels behind the C ABI (include/signnet_hip.h).
+// One kernel per op class the reference's forward inherits from PyG / torch_scatter / DGL / ATen
+// (SURVEY.md §2.1).  The fused whole-stage kernels (fused_*.hip) reuse the same GEMM convention.
+#include "common.hpp"
+
+namespace sn {
+
+// ============================================================================ weight packing
+__global__ void k_pack_weight(const float* __restrict__ W, int d_out, int d_in, int ldw, int nto, int nti,
+                              float* __restrict__ Wp) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = (int64_t)nto * nti * 256;
+  if (idx >= total) return;
+  int t = idx & 3;
+  int lane = (idx >> 2) & 63;
+  int64_t blk = idx >> 8;
+  int kk = (int)(blk % nti), ot = (int)(blk / nti);
+  int o = 16 * ot + (lane & 15);
+  int k = 16 * kk + 4 * (lane >> 4) + t;
+  Wp[idx] = (o < d_out && k < d_in) ? W[(int64_t)o * ldw + k] : 0.f;
+}
+
+// ============================================================================ masked linear
+struct LinArgs {
+  const float* x; int ldx; int64_t R; int d_in;
+  const float4* wp; int nti; int d_out; int nto;
+  const float* bias; const int32_t* nvalid; int K; int flags;
+  const float* scale; const float* shift; const float* res; int ldr;
+  float* y; int ldy;
+};
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c0, int C) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    if (c0 < C) { float4 t = *reinterpret_cast<const float4*>(p + c0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (c0 + r < C) v[r] = p[c0 + r];
+  }
+  return v;
+}
+template <bool VEC>
+__device__ __forceinline__ void store4(float* __restrict__ p, int c0, int C, f32x4 v) {
+  if (VEC) {
+    if (c0 < C) *reinterpret_cast<float4*>(p + c0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (c0 + r < C) p[c0 + r] = v[r];
+  }
+}
+
+// XV: x rows 16-byte aligned with d_in % 4 == 0.  YV: every per-channel vector and y/res rows
+// 16-byte aligned with d_out % 4 == 0.
+template <bool XV, bool YV>
+__global__ __launch_bounds__(256) void k_linear(LinArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile * 16 >= a.R) return;  // wave-uniform
+  const int64_t row = tile * 16 + (lane & 15);
+  const int g = lane >> 4;
+  const bool inr = row < a.R;
+  bool valid = inr;
+  if (inr && a.nvalid) {
+    int64_t node = row / a.K;
+    valid = (int)(row - node * a.K) < a.nvalid[node];
+  }
+  const float* xr = a.x + row * a.ldx;
+  float* yr = a.y + row * a.ldy;
+  if (__ballot(valid) == 0ull) {  // nothing valid in this tile: zeros
+    if (inr) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      for (int ot = 0; ot < a.nto; ++ot) store4<YV>(yr, 16 * ot + 4 * g, a.d_out, z);
+    }
+    return;
+  }
+  f32x4 in[8];
+  const bool single = a.nti <= 8;
+  if (single) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kk < a.nti && valid) in[kk] = load4<XV>(xr, 16 * kk + 4 * g, a.d_in);
+    }
+  }
+  for (int ot = 0; ot < a.nto; ++ot) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float4* wo = a.wp + (int64_t)ot * a.nti * 64;
+    for (int kc = 0; kc < a.nti; kc += 8) {
+      if (!single) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (kc + kk < a.nti && valid) in[kk] = load4<XV>(xr, 16 * (kc + kk) + 4 * g, a.d_in);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        if (kc + kk < a.nti) {
+          float4 w = wo[(kc + kk) * 64 + lane];
+          acc = mfma16(w.x, in[kk][0], acc);
+          acc = mfma16(w.y, in[kk][1], acc);
+          acc = mfma16(w.z, in[kk][2], acc);
+          acc = mfma16(w.w, in[kk][3], acc);
+        }
+      }
+    }
+    // ---- epilogue on Y[row][o0 .. o0+3]
+    const int o0 = 16 * ot + 4 * g;
+    f32x4 v = acc;
+    if (!valid) {
+      v = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      if (a.flags & SN_EPI_BIAS) v += load4<YV>(a.bias, o0, a.d_out);
+      if (a.flags & SN_EPI_RELU_PRE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.flags & SN_EPI_AFFINE) {
+        f32x4 sc = load4<YV>(a.scale, o0, a.d_out), sh = load4<YV>(a.shift, o0, a.d_out);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      }
+      if (a.flags & SN_EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.flags & SN_EPI_RESIDUAL) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
+    }
+    if (inr) store4<YV>(yr, o0, a.d_out, v);
+  }
+}
+
+template <typename VT>
+__device__ __forceinline__ VT vzero();
+template <>
+__device__ __forceinline__ float vzero<float>() { return 0.f; }
+template <>
+__device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ============================================================================ GIN aggregate (gather)
+// out[i,f] = sum_{e in in(i)} x[col[e], f]  +  (1+eps) * x[i,f]      (neighbours first, in edge-id
+// order, then the self term: the order PyG's propagate + `out += (1+eps)*x_r` produces)
+template <typename VT>
+__global__ __launch_bounds__(256) void k_gin_gather(const VT* __restrict__ x, VT* __restrict__ out, int64_t N,
+                                                    int FV, int P, const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col,
+                                                    const float* __restrict__ eps, int negate) {
+  const int64_t L = xcd_remap(blockIdx.x, 32 * P);
+  const int64_t node = L / P;
+  const int part = (int)(L - node * P);
+  if (node >= N) return;
+  const int f = part * 256 + threadIdx.x;
+  if (f >= FV) return;
+  const float sc = 1.f + (eps ? *eps : 0.f);
+  const int lo = rowptr[node], hi = rowptr[node + 1];
+  const VT zero = vzero<VT>();
+  VT acc = zero;
+  for (int e = lo; e < hi; ++e) acc = acc + x[(int64_t)col[e] * FV + f];
+  acc = acc + x[node * FV + f] * sc;
+  out[node * FV + f] = negate ? zero - acc : acc;
+}
+
+// ============================================================================ GIN aggregate (LDS slab)
+// One workgroup per (graph, chunk of CH vector columns).  The graph's rows of this chunk and its
+// CSR slice are staged in LDS; every feature row is read from HBM exactly once (coalesced), every
+// output row written once.  Graphs that do not fit the LDS budget fall back to the gather form.
+template <typename VT>
+__global__ __launch_bounds__(256) void k_gin_slab(const VT* __restrict__ x, VT* __restrict__ out, int FV, int CH,
+                                                  int nchunk, const int32_t* __restrict__ graph_ptr,
+                                                  const int32_t* __restrict__ rowptr,
+                                                  const int32_t* __restrict__ col, const float* __restrict__ eps,
+                                                  int negate, int lds_bytes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int g = blockIdx.x / nchunk, c = blockIdx.x - g * nchunk;
+  const int gs = graph_ptr[g], n = graph_ptr[g + 1] - gs;
+  if (n <= 0) return;
+  const int c0 = c * CH;
+  const int cw = (FV - c0) < CH ? (FV - c0) : CH;  // vector columns in this chunk
+  const int e0 = rowptr[gs], ne = rowptr[gs + n] - e0;
+  const float sc = 1.f + (eps ? *eps : 0.f);
+  const int64_t need = (int64_t)n * cw * sizeof(VT) + (int64_t)(n + 1 + ne) * 4;
+  const int tid = threadIdx.x;
+  if (need <= lds_bytes) {
+    VT* slab = reinterpret_cast<VT*>(smem);
+    int* lrow = reinterpret_cast<int*>(smem + (size_t)n * cw * sizeof(VT));
+    int* lcol = lrow + n + 1;
+    for (int i = tid; i < n * cw; i += 256) {
+      int r = i / cw, f = i - r * cw;
+      slab[i] = x[(int64_t)(gs + r) * FV + c0 + f];
+    }
+    for (int i = tid; i <= n; i += 256) lrow[i] = rowptr[gs + i] - e0;
+    for (int i = tid; i < ne; i += 256) lcol[i] = col[e0 + i] - gs;
+    __syncthreads();
+    for (int i = tid; i < n * cw; i += 256) {
+      int r = i / cw, f = i - r * cw;
+      VT self = slab[i];
+      const VT zero = vzero<VT>();
+      VT acc = zero;
+      for (int e = lrow[r]; e < lrow[r + 1]; ++e) acc = acc + slab[lcol[e] * cw + f];
+      acc = acc + self * sc;
+      out[(int64_t)(gs + r) * FV + c0 + f] = negate ? zero - acc : acc;
+    }
+  } else {
+    for (int i = tid; i < n * cw; i += 256) {
+      int r = i / cw, f = i - r * cw;
+      VT self = x[(int64_t)(gs + r) * FV + c0 + f];
+      const VT zero = vzero<VT>();
+      VT acc = zero;
+      for (int e = rowptr[gs + r]; e < rowptr[gs + r + 1]; ++e) acc = acc + x[(int64_t)col[e] * FV + c0 + f];
+      acc = acc + self * sc;
+      out[(int64_t)(gs + r) * FV + c0 + f] = negate ? zero - acc : acc;
+    }
+  }
+}
+
+// ============================================================================ GINE aggregate
+template <typename VT>
+__device__ __forceinline__ VT vrelu(VT v);
+template <>
+__device__ __forceinline__ float vrelu<float>(float v) { return fmaxf(v, 0.f); }
+template <>
+__device__ __forceinline__ float4 vrelu<float4>(float4 v) {
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_gine_gather(const VT* __restrict__ x, const VT* __restrict__ ea,
+                                                     VT* __restrict__ out, int64_t N, int CV,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ eperm,
+                                                     const float* __restrict__ eps) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * CV) return;
+  int64_t node = idx / CV;
+  int f = (int)(idx - node * CV);
+  const float sc = 1.f + (eps ? *eps : 0.f);
+  VT self = x[idx];
+  VT acc = vzero<VT>();
+  for (int e = rowptr[node]; e < rowptr[node + 1]; ++e)
+    acc = acc + vrelu<VT>(x[(int64_t)col[e] * CV + f] + ea[(int64_t)eperm[e] * CV + f]);
+  out[idx] = acc + self * sc;
+}
+
+// ============================================================================ masked column statistics
+// pass 0: per-block partial sums of x over valid rows; pass 1: partial sums of (x-mean)^2.
+__global__ __launch_bounds__(256) void k_colstats_partial(const float* __restrict__ x, int ldx, int64_t R, int C,
+                                                          const int32_t* __restrict__ nvalid, int K,
+                                                          const float* __restrict__ mean, int pass,
+                                                          int64_t rows_per_block, float* __restrict__ part,
+                                                          float* __restrict__ cnt_part) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f, m = pass ? mean[c] : 0.f;
+    int cnt = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+      bool ok = true;
+      if (nvalid) { int64_t node = r / K; ok = (int)(r - node * K) < nvalid[node]; }
+      if (ok) {
+        float v = x[r * ldx + c] - m;
+        s += pass ? v * v : v;
+        ++cnt;
+      }
+    }
+    part[(int64_t)blockIdx.x * C + c] = s;
+    if (c == 0 && cnt_part) cnt_part[blockIdx.x] = (float)cnt;
+  }
+}
+__global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict__ part, const float* __restrict__ cnt_part,
+                                                        int nblk, int C, float* __restrict__ outv,
+                                                        float* __restrict__ count, int pass) {
+  __shared__ float tot;
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    if (pass == 0) { for (int b = 0; b < nblk; ++b) t += cnt_part[b]; *count = t; }
+    else t = *count;
+    tot = t;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * C + c];
+    outv[c] = tot > 0.f ? s / tot : 0.f;
+  }
+}
+
+// ============================================================================ masked affine (un-fused BN apply)
+__global__ __launch_bounds__(256) void k_affine(const float* __restrict__ x, int ldx, int64_t R, int C,
+                                                const int32_t* __restrict__ nvalid, int K, int flags,
+                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                const float* __restrict__ res, int ldr, float* __restrict__ y,
+                                                int ldy) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * C) return;
+  int64_t r = idx / C;
+  int c = (int)(idx - r * C);
+  bool ok = true;
+  if (nvalid) { int64_t node = r / K; ok = (int)(r - node * K) < nvalid[node]; }
+  float v = 0.f;
+  if (ok) {
+    v = x[r * ldx + c];
+    if (flags & SN_EPI_RELU_PRE) v = fmaxf(v, 0.f);
+    if (flags & SN_EPI_AFFINE) v = v * scale[c] + shift[c];
+    if (flags & SN_EPI_RELU) v = fmaxf(v, 0.f);
+    if (flags & SN_EPI_RESIDUAL) v += res[r * ldr + c];
+  }
+  y[r * ldy + c] = v;
+}
+
+// ============================================================================ masked LayerNorm
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ res,
+                                                   int64_t R, int C, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps,
+                                                   const int32_t* __restrict__ nvalid, int K,
+                                                   float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  bool ok = true;
+  if (nvalid) { int64_t node = row / K; ok = (int)(row - node * K) < nvalid[node]; }
+  const float* xr = x + row * C;
+  const float* rr = res ? res + row * C : nullptr;
+  float* yr = y + row * C;
+  if (!ok) {
+    for (int c = lane; c < C; c += 64) yr[c] = 0.f;
+    return;
+  }
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { float d = xr[c] + (rr ? rr[c] : 0.f) - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  for (int c = lane; c < C; c += 64) {
+    float v = xr[c] + (rr ? rr[c] : 0.f);
+    yr[c] = (v - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+
+// ============================================================================ per-node set attention
+// One wave per (node, head).  q,k,v rows are [N*K, H*dk]; head h owns columns [h*dk, (h+1)*dk).
+__global__ __launch_bounds__(64) void k_set_attention(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, int K, int H, int dk,
+                                                      const int32_t* __restrict__ nvalid, float* __restrict__ out) {
+  extern __shared__ float sm[];
+  const int node = blockIdx.x / H, h = blockIdx.x - node * H;
+  const int lane = threadIdx.x;
+  const int kv = nvalid ? nvalid[node] : K;
+  const int D = H * dk;
+  float* sq = sm;                // [K][dk]   (q / sqrt(dk))
+  float* sk = sq + K * dk;       // [K][dk]
+  float* sv = sk + K * dk;       // [K][dk]
+  float* sp = sv + K * dk;       // [K][K+1]
+  const float temp = sqrtf((float)dk);
+  const int64_t base = (int64_t)node * K * D + (int64_t)h * dk;
+  for (int i = lane; i < kv * dk; i += 64) {
+    int r = i / dk, c = i - r * dk;
+    int64_t o = base + (int64_t)r * D + c;
+    sq[i] = q[o] / temp;
+    sk[i] = k[o];
+    sv[i] = v[o];
+  }
+  __syncthreads();
+  for (int i = lane; i < kv * kv; i += 64) {
+    int a = i / kv, b = i - a * kv;
+    float s = 0.f;
+    for (int c = 0; c < dk; ++c) s += sq[a * dk + c] * sk[b * dk + c];
+    sp[a * (K + 1) + b] = s;
+  }
+  __syncthreads();
+  for (int a = lane; a < kv; a += 64) {
+    float m = -INFINITY;
+    for (int b = 0; b < kv; ++b) m = fmaxf(m, sp[a * (K + 1) + b]);
+    float z = 0.f;
+    for (int b = 0; b < kv; ++b) { float e = expf(sp[a * (K + 1) + b] - m); sp[a * (K + 1) + b] = e; z += e; }
+    for (int b = 0; b < kv; ++b) sp[a * (K + 1) + b] /= z;
+  }
+  __syncthreads();
+  for (int i = lane; i < K * dk; i += 64) {
+    int a = i / dk, c = i - a * dk;
+    float s = 0.f;
+    if (a < kv)
+      for (int b = 0; b < kv; ++b) s += sp[a * (K + 1) + b] * sv[b * dk + c];
+    out[base + (int64_t)a * D + c] = s;
+  }
+}
+
+// ============================================================================ small reductions / gathers
+__global__ __launch_bounds__(256) void k_slot_sum(const float* __restrict__ x, int64_t N, int K, int C,
+                                                  float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * C) return;
+  int64_t n = idx / C;
+  int c = (int)(idx - n * C);
+  const float* p = x + n * K * C + c;
+  float s = 0.f;
+  for (int j = 0; j < K; ++j) s += p[(int64_t)j * C];
+  out[idx] = s;
+}
+
+struct TablePtrs { const float* t[10]; };
+
+__global__ __launch_bounds__(256) void k_embedding_sum(const int64_t* __restrict__ idx, int ldi, int nf, int64_t R,
+                                                       TablePtrs tp, int C, float* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * C) return;
+  int64_t r = i / C;
+  int c = (int)(i - r * C);
+  float s = 0.f;
+  for (int f = 0; f < nf; ++f) s += tp.t[f][idx[r * ldi + f] * C + c];
+  out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void k_segment_pool(const float* __restrict__ x, int C,
+                                                      const int32_t* __restrict__ graph_ptr, int mode,
+                                                      float* __restrict__ out) {
+  const int g = blockIdx.x;
+  const int lo = graph_ptr[g], hi = graph_ptr[g + 1];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int i = lo; i < hi; ++i) s += x[(int64_t)i * C + c];
+    if (mode == 1) { int n = hi - lo; s = s / (float)(n > 0 ? n : 1); }
+    out[(int64_t)g * C + c] = s;
+  }
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int sn_version(void) { return SN_ABI_VERSION; }
+extern "C" const char* sn_last_error(void) { return sn::err_buf(); }
+
+extern "C" int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(SN_ERR_LAUNCH, "sn_device_info: no HIP device");
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return fail(SN_ERR_LAUNCH, "sn_device_info: query failed");
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+  if (clock_khz) *clock_khz = p.clockRate;
+  return SN_OK;
+}
+
+extern "C" int64_t sn_packed_weight_floats(int d_out, int d_in) {
+  return (int64_t)cdiv(d_out, 16) * cdiv(d_in, 16) * 256;
+}
+
+extern "C" int sn_pack_weight_f32(const float* W, int d_out, int d_in, int ldw, float* Wp, void* stream) {
+  SN_REQUIRE(W && Wp && d_out > 0 && d_in > 0 && ldw >= d_in, "sn_pack_weight_f32: bad arguments");
+  int nto = (int)cdiv(d_out, 16), nti = (int)cdiv(d_in, 16);
+  int64_t total = (int64_t)nto * nti * 256;
+  hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, d_out,
+                     d_in, ldw, nto, nti, Wp);
+  SN_CHECK_LAUNCH("sn_pack_weight_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
+                                    const float* bias, const int32_t* nvalid, int K, int flags,
+                                    const float* scale, const float* shift, const float* residual, int ldr,
+                                    float* y, int ldy, void* stream) {
+  SN_REQUIRE(x && Wp && y && R >= 0 && d_in > 0 && d_out > 0, "sn_masked_linear_f32: bad arguments");
+  SN_REQUIRE(ldx >= d_in && ldy >= d_out, "sn_masked_linear_f32: leading dimension too small");
+  SN_REQUIRE(!(flags & SN_EPI_BIAS) || bias, "sn_masked_linear_f32: BIAS without bias");
+  SN_REQUIRE(!(flags & SN_EPI_AFFINE) || (scale && shift), "sn_masked_linear_f32: AFFINE without scale/shift");
+  SN_REQUIRE(!(flags & SN_EPI_RESIDUAL) || (residual && ldr >= d_out), "sn_masked_linear_f32: RESIDUAL without residual");
+  SN_REQUIRE(!nvalid || K > 0, "sn_masked_linear_f32: nvalid needs K > 0");
+  SN_REQUIRE(al16(Wp), "sn_masked_linear_f32: Wp must be 16-byte aligned");
+  if (R == 0) return SN_OK;
+  LinArgs a{x, ldx, R, d_in, reinterpret_cast<const float4*>(Wp), (int)cdiv(d_in, 16), d_out, (int)cdiv(d_out, 16),
+            bias, nvalid, K, flags, scale, shift, residual, ldr, y, ldy};
+  const bool xv = (d_in % 4 == 0) && (ldx % 4 == 0) && al16(x);
+  const bool yv = (d_out % 4 == 0) && (ldy % 4 == 0) && al16(y) && (!bias || al16(bias)) && (!scale || al16(scale)) &&
+                  (!shift || al16(shift)) && (!residual || (al16(residual) && ldr % 4 == 0));
+  dim3 grid((unsigned)cdiv(R, 64)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (xv && yv) hipLaunchKernelGGL((k_linear<true, true>), grid, block, 0, st, a);
+  else if (xv) hipLaunchKernelGGL((k_linear<true, false>), grid, block, 0, st, a);
+  else if (yv) hipLaunchKernelGGL((k_linear<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_linear<false, false>), grid, block, 0, st, a);
+  SN_CHECK_LAUNCH("sn_masked_linear_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gin_aggregate_f32(const float* x, float* out, int64_t N, int F, const int32_t* rowptr,
+                                    const int32_t* col, const float* eps, int negate, void* stream) {
+  SN_REQUIRE(x && out && rowptr && N >= 0 && F > 0, "sn_gin_aggregate_f32: bad arguments");
+  SN_REQUIRE(x != out, "sn_gin_aggregate_f32: in-place aggregation is not supported");
+  if (N == 0) return SN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (F % 4 == 0 && al16(x) && al16(out)) {
+    int FV = F / 4, P = (int)cdiv(FV, 256);
+    int64_t grp = (int64_t)8 * 32 * P;
+    int64_t nblk = cdiv(N * P, grp) * grp;
+    hipLaunchKernelGGL((k_gin_gather<float4>), dim3((unsigned)nblk), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), N, FV, P, rowptr, col, eps,
+                       negate);
+  } else {
+    int P = (int)cdiv(F, 256);
+    int64_t grp = (int64_t)8 * 32 * P;
+    int64_t nblk = cdiv(N * P, grp) * grp;
+    hipLaunchKernelGGL((k_gin_gather<float>), dim3((unsigned)nblk), dim3(256), 0, st, x, out, N, F, P, rowptr, col, eps,
+                       negate);
+  }
+  SN_CHECK_LAUNCH("sn_gin_aggregate_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gin_aggregate_slab_f32(const float* x, float* out, int64_t N, int F, int64_t B,
+                                         const int32_t* graph_ptr, const int32_t* rowptr, const int32_t* col,
+                                         const float* eps, int negate, void* stream) {
+  SN_REQUIRE(x && out && rowptr && graph_ptr && N >= 0 && F > 0 && B >= 0, "sn_gin_aggregate_slab_f32: bad arguments");
+  SN_REQUIRE(x != out, "sn_gin_aggregate_slab_f32: in-place aggregation is not supported");
+  if (N == 0 || B == 0) return SN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 64 * 1024;  // 2 workgroups per CU
+  if (F % 4 == 0 && al16(x) && al16(out)) {
+    int FV = F / 4;
+    int CH = FV < 64 ? FV : 64;
+    int nchunk = (int)cdiv(FV, CH);
+    hipLaunchKernelGGL((k_gin_slab<float4>), dim3((unsigned)(B * nchunk)), dim3(256), lds, st,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), FV, CH, nchunk, graph_ptr,
+                       rowptr, col, eps, negate, lds);
+  } else {
+    int CH = F < 256 ? F : 256;
+    int nchunk = (int)cdiv(F, CH);
+    hipLaunchKernelGGL((k_gin_slab<float>), dim3((unsigned)(B * nchunk)), dim3(256), lds, st, x, out, F, CH, nchunk,
+                       graph_ptr, rowptr, col, eps, negate, lds);
+  }
+  SN_CHECK_LAUNCH("sn_gin_aggregate_slab_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gine_aggregate_f32(const float* x, const float* ea, float* out, int64_t N, int C,
+                                     const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                                     const float* eps, void* stream) {
+  SN_REQUIRE(x && ea && out && rowptr && N >= 0 && C > 0, "sn_gine_aggregate_f32: bad arguments");
+  SN_REQUIRE(x != out, "sn_gine_aggregate_f32: in-place aggregation is not supported");
+  if (N == 0) return SN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0 && al16(x) && al16(ea) && al16(out)) {
+    int CV = C / 4;
+    hipLaunchKernelGGL((k_gine_gather<float4>), dim3((unsigned)cdiv(N * CV, 256)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(ea),
+                       reinterpret_cast<float4*>(out), N, CV, rowptr, col, eperm, eps);
+  } else {
+    hipLaunchKernelGGL((k_gine_gather<float>), dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, st, x, ea, out, N, C,
+                       rowptr, col, eperm, eps);
+  }
+  SN_CHECK_LAUNCH("sn_gine_aggregate_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_colstats_blocks(int64_t R) {
+  int64_t b = cdiv(R, 256);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int sn_masked_colstats_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K,
+                                      float* mean, float* var, float* count, float* scratch, void* stream) {
+  SN_REQUIRE(x && mean && var && count && scratch && C > 0 && R >= 0 && ldx >= C, "sn_masked_colstats_f32: bad arguments");
+  SN_REQUIRE(!nvalid || K > 0, "sn_masked_colstats_f32: nvalid needs K > 0");
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = sn_colstats_blocks(R);
+  int64_t rpb = cdiv(R > 0 ? R : 1, nblk);
+  float* part = scratch;
+  float* cnt = scratch + (int64_t)nblk * C;
+  hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)nullptr, 0,
+                     rpb, part, cnt);
+  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, part, cnt, nblk, C, mean, count, 0);
+  hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)mean, 1,
+                     rpb, part, (float*)nullptr);
+  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, part, cnt, nblk, C, var, count, 1);
+  SN_CHECK_LAUNCH("sn_masked_colstats_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_masked_affine_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K,
+                                    int flags, const float* scale, const float* shift, const float* residual,
+                                    int ldr, float* y, int ldy, void* stream) {
+  SN_REQUIRE(x && y && C > 0 && R >= 0 && ldx >= C && ldy >= C, "sn_masked_affine_f32: bad arguments");
+  SN_REQUIRE(!(flags & SN_EPI_AFFINE) || (scale && shift), "sn_masked_affine_f32: AFFINE without scale/shift");
+  SN_REQUIRE(!(flags & SN_EPI_RESIDUAL) || (residual && ldr >= C), "sn_masked_affine_f32: RESIDUAL without residual");
+  SN_REQUIRE(!nvalid || K > 0, "sn_masked_affine_f32: nvalid needs K > 0");
+  if (R == 0) return SN_OK;
+  hipLaunchKernelGGL(k_affine, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, R, C,
+                     nvalid, K, flags, scale, shift, residual, ldr, y, ldy);
+  SN_CHECK_LAUNCH("sn_masked_affine_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_masked_layernorm_f32(const float* x, const float* residual, int64_t R, int C, const float* gamma,
+                                       const float* beta, float eps, const int32_t* nvalid, int K, float* y,
+                                       void* stream) {
+  SN_REQUIRE(x && y && gamma && beta && C > 0 && R >= 0, "sn_masked_layernorm_f32: bad arguments");
+  SN_REQUIRE(!nvalid || K > 0, "sn_masked_layernorm_f32: nvalid needs K > 0");
+  if (R == 0) return SN_OK;
+  hipLaunchKernelGGL(k_layernorm, dim3((unsigned)cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, R, C,
+                     gamma, beta, eps, nvalid, K, y);
+  SN_CHECK_LAUNCH("sn_masked_layernorm_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_set_attention_f32(const float* q, const float* k, const float* v, int64_t N, int K, int heads,
+                                    int dk, const int32_t* nvalid, float* out, void* stream) {
+  SN_REQUIRE(q && k && v && out && N >= 0 && K > 0 && heads > 0 && dk > 0, "sn_set_attention_f32: bad arguments");
+  size_t lds = ((size_t)3 * K * dk + (size_t)K * (K + 1)) * sizeof(float);
+  SN_REQUIRE(lds <= 160 * 1024, "sn_set_attention_f32: K=%d dk=%d needs %zu B of LDS (> 160 KiB)", K, dk, lds);
+  if (N == 0) return SN_OK;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_set_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return fail(SN_ERR_LAUNCH, "sn_set_attention_f32: cannot raise dynamic LDS limit");
+  }
+  hipLaunchKernelGGL(k_set_attention, dim3((unsigned)(N * heads)), dim3(64), lds, (hipStream_t)stream, q, k, v, K, heads,
+                     dk, nvalid, out);
+  SN_CHECK_LAUNCH("sn_set_attention_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* out, void* stream) {
+  SN_REQUIRE(x && out && N >= 0 && K > 0 && C > 0, "sn_slot_sum_f32: bad arguments");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_slot_sum, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, x, N, K, C, out);
+  SN_CHECK_LAUNCH("sn_slot_sum_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_embedding_sum_f32(const int64_t* idx, int ldi, int nf, int64_t R, const float* const* tables,
+                                    int C, float* out, void* stream) {
+  SN_REQUIRE(idx && tables && out && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && R >= 0,
+             "sn_embedding_sum_f32: bad arguments");
+  if (R == 0) return SN_OK;
+  TablePtrs tp;
+  for (int f = 0; f < 10; ++f) tp.t[f] = f < nf ? tables[f] : nullptr;
+  hipLaunchKernelGGL(k_embedding_sum, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, ldi, nf,
+                     R, tp, C, out);
+  SN_CHECK_LAUNCH("sn_embedding_sum_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32_t* graph_ptr, int mode, float* out,
+                                   void* stream) {
+  SN_REQUIRE(x && out && graph_ptr && B >= 0 && C > 0 && (mode == 0 || mode == 1), "sn_segment_pool_f32: bad arguments");
+  if (B == 0) return SN_OK;
+  hipLaunchKernelGGL(k_segment_pool, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, x, C, graph_ptr, mode, out);
+  SN_CHECK_LAUNCH("sn_segment_pool_f32");
+  return SN_OK;
+}

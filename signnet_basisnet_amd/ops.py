@@ -1,0 +1,256 @@
+"""Thin Python wrappers over the C ABI (one per entry point of include/signnet_hip.h).
+
+Each wrapper validates dtype/contiguity, allocates the output with torch (device memory is
+PyTorch's job here), and launches on torch's current stream.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, check, lib, ptr,
+                   require_cuda, stream)
+
+__all__ = ["GraphPlan", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
+           "masked_linear", "masked_colstats", "masked_affine", "masked_layernorm", "set_attention",
+           "slot_sum", "embedding_sum", "segment_pool", "PackedLinear",
+           "EPI_BIAS", "EPI_RELU_PRE", "EPI_AFFINE", "EPI_RELU", "EPI_RESIDUAL"]
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+@dataclass
+class GraphPlan:
+    """Device-resident structure of one batch (built once per batch by `build_plan`)."""
+    N: int
+    B: int
+    E: int
+    kmax: int
+    graph_ptr: torch.Tensor   # int32 [B+1]
+    node_graph: torch.Tensor  # int32 [N]
+    nvalid: torch.Tensor      # int32 [N]   valid eigenvector slots per node
+    evoff: torch.Tensor       # int64 [B+1] offset of each graph's n_b x n_b eigenvector block
+    rowptr: torch.Tensor      # int32 [N+1] dst-sorted CSR
+    col: torch.Tensor         # int32 [E]   source node of each in-edge
+    eperm: torch.Tensor       # int32 [E]   original edge id of each CSR slot
+    status: torch.Tensor      # int32 [4]   [err bits, max nodes/graph, max in-degree, -]
+
+    def check(self):
+        """Synchronising validity check (raises on malformed batches)."""
+        st = self.status.tolist()
+        if st[0]:
+            bits = [n for b, n in ((1, "batch not sorted"), (2, "graph id out of range"),
+                                   (4, "edge endpoint out of range"), (8, "edge crosses graphs")) if st[0] & b]
+            raise ValueError("malformed graph batch: " + ", ".join(bits))
+        return st
+
+
+def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0) -> GraphPlan:
+    require_cuda(batch, edge_index)
+    if batch.dtype != torch.int64 or edge_index.dtype != torch.int64:
+        raise ValueError("build_plan: batch and edge_index must be int64 (the reference's index dtype)")
+    batch = batch.contiguous()
+    edge_index = edge_index.contiguous()
+    N, E, B = batch.numel(), edge_index.shape[1] if edge_index.numel() else 0, int(num_graphs)
+    dev = batch.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    # one int32 arena, carved into the plan arrays (single allocation per batch)
+    sizes = [B + 1, N, N, N + 1, E, E, 4, N + 8]
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + ((s + 3) // 4) * 4)
+    arena = torch.empty(offs[-1], **i32)
+    graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, scratch = (
+        arena[offs[i]:offs[i] + sizes[i]] for i in range(8))
+    evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
+                              ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
+                              ptr(scratch), stream()), "sn_batch_plan")
+    return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status)
+
+
+def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: bool):
+    require_cuda(eigen_vectors)
+    ev = _f32c(eigen_vectors, "eigen_vectors")
+    x0 = torch.empty(plan.N, K, dtype=torch.float32, device=ev.device)
+    s0 = torch.empty_like(x0) if want_values else None
+    es = _f32c(eigen_values, "eigen_values") if want_values else None
+    check(lib().sn_pack_eig_f32(ptr(ev), ptr(es), ptr(plan.graph_ptr), ptr(plan.node_graph), ptr(plan.nvalid),
+                                ptr(plan.evoff), plan.N, K, ptr(x0), ptr(s0), stream()), "sn_pack_eig_f32")
+    return x0, s0
+
+
+def packed_floats(d_out: int, d_in: int) -> int:
+    return int(lib().sn_packed_weight_floats(d_out, d_in))
+
+
+def pack_weight(W: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """nn.Linear weight [d_out, d_in] -> MFMA fragment order (see csrc/common.hpp)."""
+    require_cuda(W)
+    if W.dtype != torch.float32 or W.dim() != 2 or W.stride(1) != 1:
+        raise ValueError("pack_weight: expected a float32 [d_out, d_in] matrix with unit inner stride")
+    d_out, d_in = W.shape
+    n = packed_floats(d_out, d_in)
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=W.device)
+    check(lib().sn_pack_weight_f32(ptr(W), d_out, d_in, W.stride(0), ptr(out), stream()), "sn_pack_weight_f32")
+    return out
+
+
+@dataclass
+class PackedLinear:
+    wp: torch.Tensor
+    d_out: int
+    d_in: int
+    bias: torch.Tensor | None = None
+
+
+def gin_aggregate(x, plan: GraphPlan, eps=None, negate=False, slab=False):
+    """x [N, ...] -> (1+eps) x_i + sum_{j->i} x_j over the node axis (trailing dims flattened)."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    N = x.shape[0]
+    F = x.numel() // max(N, 1)
+    out = torch.empty_like(x)
+    if slab:
+        check(lib().sn_gin_aggregate_slab_f32(ptr(x), ptr(out), N, F, plan.B, ptr(plan.graph_ptr), ptr(plan.rowptr),
+                                              ptr(plan.col), ptr(eps), int(negate), stream()),
+              "sn_gin_aggregate_slab_f32")
+    else:
+        check(lib().sn_gin_aggregate_f32(ptr(x), ptr(out), N, F, ptr(plan.rowptr), ptr(plan.col), ptr(eps),
+                                         int(negate), stream()), "sn_gin_aggregate_f32")
+    return out
+
+
+def gine_aggregate(x, ea, plan: GraphPlan, eps=None):
+    require_cuda(x, ea)
+    x, ea = _f32c(x, "x"), _f32c(ea, "edge_attr")
+    if ea.shape != (plan.E, x.shape[1]):
+        raise ValueError("gine_aggregate: edge features must be [E, C] with C == x.shape[1]")
+    out = torch.empty_like(x)
+    check(lib().sn_gine_aggregate_f32(ptr(x), ptr(ea), ptr(out), x.shape[0], x.shape[1], ptr(plan.rowptr),
+                                      ptr(plan.col), ptr(plan.eperm), ptr(eps), stream()), "sn_gine_aggregate_f32")
+    return out
+
+
+def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False,
+                  residual=None, use_bias=True, out=None):
+    """y = epilogue(x @ W^T); x is a row matrix [..., d_in] (leading dims flattened to rows)."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    if x.shape[-1] != pl.d_in:
+        raise ValueError(f"masked_linear: x has {x.shape[-1]} channels, weight expects {pl.d_in}")
+    R = x.numel() // pl.d_in
+    flags = 0
+    bias = pl.bias if use_bias else None
+    if bias is not None:
+        flags |= EPI_BIAS
+    if relu_pre:
+        flags |= EPI_RELU_PRE
+    if scale is not None:
+        flags |= EPI_AFFINE
+    if relu:
+        flags |= EPI_RELU
+    if residual is not None:
+        flags |= EPI_RESIDUAL
+        residual = _f32c(residual, "residual")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], pl.d_out, dtype=torch.float32, device=x.device)
+    check(lib().sn_masked_linear_f32(ptr(x), pl.d_in, R, pl.d_in, ptr(pl.wp), pl.d_out, ptr(bias), ptr(nvalid),
+                                     int(K), flags, ptr(scale), ptr(shift), ptr(residual), pl.d_out, ptr(out),
+                                     pl.d_out, stream()), "sn_masked_linear_f32")
+    return out
+
+
+def masked_colstats(x, nvalid=None, K=0):
+    """Per-channel mean / biased variance over the valid rows of a row matrix [..., C]."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    nb = int(lib().sn_colstats_blocks(R))
+    mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    count = torch.empty(1, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(nb * Cc + nb, dtype=torch.float32, device=x.device)
+    check(lib().sn_masked_colstats_f32(ptr(x), Cc, R, Cc, ptr(nvalid), int(K), ptr(mean), ptr(var), ptr(count),
+                                       ptr(scratch), stream()), "sn_masked_colstats_f32")
+    return mean, var, count
+
+
+def masked_affine(x, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False, residual=None):
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    flags = (EPI_RELU_PRE if relu_pre else 0) | (EPI_AFFINE if scale is not None else 0) | \
+            (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0)
+    out = torch.empty_like(x)
+    check(lib().sn_masked_affine_f32(ptr(x), Cc, R, Cc, ptr(nvalid), int(K), flags, ptr(scale), ptr(shift),
+                                     ptr(residual), Cc, ptr(out), Cc, stream()), "sn_masked_affine_f32")
+    return out
+
+
+def masked_layernorm(x, residual, gamma, beta, eps, nvalid=None, K=0):
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    check(lib().sn_masked_layernorm_f32(ptr(x), ptr(residual), x.numel() // Cc, Cc, ptr(gamma), ptr(beta),
+                                        float(eps), ptr(nvalid), int(K), ptr(out), stream()),
+          "sn_masked_layernorm_f32")
+    return out
+
+
+def set_attention(q, k, v, N, K, heads, nvalid=None):
+    require_cuda(q, k, v)
+    q, k, v = _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
+    D = q.shape[-1]
+    out = torch.empty_like(q)
+    check(lib().sn_set_attention_f32(ptr(q), ptr(k), ptr(v), N, K, heads, D // heads, ptr(nvalid), ptr(out),
+                                     stream()), "sn_set_attention_f32")
+    return out
+
+
+def slot_sum(x, N, K):
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    out = torch.empty(N, Cc, dtype=torch.float32, device=x.device)
+    check(lib().sn_slot_sum_f32(ptr(x), N, K, Cc, ptr(out), stream()), "sn_slot_sum_f32")
+    return out
+
+
+def embedding_sum(idx, tables):
+    """sum_f tables[f][idx[:, f]] — DiscreteEncoder; idx int64 [R] or [R, F]."""
+    require_cuda(idx)
+    if idx.dtype != torch.int64:
+        raise ValueError("embedding_sum: integer features must be int64")
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(1)
+    idx = idx.contiguous()
+    R, nf = idx.shape
+    if nf > len(tables):
+        raise ValueError("embedding_sum: more feature columns than embedding tables")
+    tabs = [_f32c(t, "embedding table") for t in tables[:nf]]
+    Cc = tabs[0].shape[1]
+    arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs])
+    out = torch.empty(R, Cc, dtype=torch.float32, device=idx.device)
+    check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, Cc, ptr(out), stream()), "sn_embedding_sum_f32")
+    return out
+
+
+def segment_pool(x, plan: GraphPlan, mode="add"):
+    require_cuda(x)
+    x = _f32c(x, "x")
+    out = torch.empty(plan.B, x.shape[1], dtype=torch.float32, device=x.device)
+    check(lib().sn_segment_pool_f32(ptr(x), plan.B, x.shape[1], ptr(plan.graph_ptr), 1 if mode == "mean" else 0,
+                                    ptr(out), stream()), "sn_segment_pool_f32")
+    return out

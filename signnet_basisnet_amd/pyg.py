@@ -1,0 +1,413 @@
+"""PyG-tree SignNet + GINE modules (drop-in `nn.Module` surface, HIP forward).
+
+Mirrors the operator boundary of the reference's two PyG trees:
+  Alchemy/sign_net/sign_net.py:120-132         SignNetGNN(node_feat, edge_feat, n_hid, n_out,
+                                                nl_signnet, nl_gnn, nl_rho=4, ignore_eigval, gnn_type)
+  GINESignNetPyG/core/sign_net.py:122-134      SignNetGNN(node_feat, edge_feat, n_hid, n_out,
+                                                nl_signnet, nl_gnn)
+Same constructor arguments, same `forward(data) -> [B, n_out]`, same `state_dict` keys
+ so reference-trained weights load unchanged.  The module classes below only
+hold parameters; all arithmetic runs in the HIP kernels of libsignnet_hip.so through
+`signnet_basisnet_amd.ops` / the fused engine.  There is no CPU path: tensors must be on the GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+N_HEAD = 4          # TransformerEncoderLayer(nhid, n_head=4): sign_net.py:50 / core/sign_net.py:57
+LN_EPS = 1e-6       # masked_layers.py:25
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class MaskedBN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(c)
+
+    def reset_parameters(self):
+        self.bn.reset_parameters()
+
+
+class MaskedLN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.ln = nn.LayerNorm(c, eps=LN_EPS)
+
+    def reset_parameters(self):
+        self.ln.reset_parameters()
+
+
+class _Identity(nn.Module):
+    def reset_parameters(self):
+        pass
+
+
+def _mlp_layers(nin, nout, nlayer, final_act, with_norm, bias, nhid):
+    """Layer widths / bias rule shared by MaskedMLP (masked_layers.py:35-47) and MLP (elements.py:40-51)."""
+    h = nin if nhid is None else nhid
+    dims = [(nin if i == 0 else h, h if i < nlayer - 1 else nout) for i in range(nlayer)]
+    has_bias = [bool((i == nlayer - 1 and not final_act and bias) or (not with_norm)) for i in range(nlayer)]
+    return dims, has_bias
+
+
+class MaskedMLP(nn.Module):
+    def __init__(self, nin, nout, nlayer=2, with_final_activation=True, with_norm=True, bias=True, nhid=None):
+        super().__init__()
+        dims, hb = _mlp_layers(nin, nout, nlayer, with_final_activation, with_norm, bias, nhid)
+        self.layers = nn.ModuleList([nn.Linear(a, b, bias=h) for (a, b), h in zip(dims, hb)])
+        self.norms = nn.ModuleList([MaskedBN(b) if with_norm else _Identity() for a, b in dims])
+        self.nlayer, self.with_final_activation = nlayer, with_final_activation
+
+    def reset_parameters(self):
+        for l, n in zip(self.layers, self.norms):
+            l.reset_parameters()
+            n.reset_parameters()
+
+
+class MLP(nn.Module):
+    def __init__(self, nin, nout, nlayer=2, with_final_activation=True, with_norm=True, bias=True, nhid=None):
+        super().__init__()
+        dims, hb = _mlp_layers(nin, nout, nlayer, with_final_activation, with_norm, bias, nhid)
+        self.layers = nn.ModuleList([nn.Linear(a, b, bias=h) for (a, b), h in zip(dims, hb)])
+        self.norms = nn.ModuleList([nn.BatchNorm1d(b) if with_norm else _Identity() for a, b in dims])
+        self.nlayer, self.with_final_activation = nlayer, with_final_activation
+
+    def reset_parameters(self):
+        for l, n in zip(self.layers, self.norms):
+            l.reset_parameters()
+            n.reset_parameters()
+
+
+class DiscreteEncoder(nn.Module):
+    def __init__(self, hidden, max_num_features=10, max_num_values=500):
+        super().__init__()
+        self.embeddings = nn.ModuleList([nn.Embedding(max_num_values, hidden) for _ in range(max_num_features)])
+
+    def reset_parameters(self):
+        for e in self.embeddings:
+            e.reset_parameters()
+
+
+class _GINEps(nn.Module):
+    """Holder of PyG GINConv/GINEConv's `eps` (train_eps=True, initial 0) and, for GINE, the MLP
+    that PyG registers a second time under `.layer.nn` (pyg_gnn_wrapper.py:22-23)."""
+    def __init__(self, mlp=None):
+        super().__init__()
+        if mlp is not None:
+            self.nn = mlp
+        self.eps = nn.Parameter(torch.zeros(1))
+
+    def reset_parameters(self):
+        self.eps.data.fill_(0.0)
+
+
+class MaskedGINConv(nn.Module):
+    def __init__(self, nin, nout, bias=True, nhid=None):
+        super().__init__()
+        self.nn = MaskedMLP(nin, nout, 2, False, bias=bias, nhid=nhid)
+        self.layer = _GINEps()
+
+    def reset_parameters(self):
+        self.nn.reset_parameters()
+        self.layer.reset_parameters()
+
+
+class GINEConv(nn.Module):
+    def __init__(self, nin, nout, bias=True):
+        super().__init__()
+        self.nn = MLP(nin, nout, 2, False, bias=bias)
+        self.layer = _GINEps(self.nn)
+
+    def reset_parameters(self):
+        self.nn.reset_parameters()
+        self.layer.reset_parameters()
+
+
+class GNN3d(nn.Module):
+    def __init__(self, n_in, n_out, n_layer, variant):
+        super().__init__()
+        if variant == "alchemy":   # sign_net.py:20
+            self.convs = nn.ModuleList([MaskedGINConv(n_in if i == 0 else n_out, n_out, bias=True, nhid=n_out)
+                                        for i in range(n_layer)])
+        else:                      # core/sign_net.py:20
+            self.convs = nn.ModuleList([MaskedGINConv(n_in if i == 0 else n_out, n_out, bias=False)
+                                        for i in range(n_layer)])
+        self.norms = nn.ModuleList([MaskedBN(n_out) for _ in range(n_layer)])
+        if variant != "alchemy":   # registered but never used by the reference (core/sign_net.py:22,40)
+            self.edge_encoders = nn.ModuleList([DiscreteEncoder(n_in if i == 0 else n_out) for i in range(n_layer)])
+
+    def reset_parameters(self):
+        for m in list(self.convs) + list(self.norms) + list(getattr(self, "edge_encoders", [])):
+            m.reset_parameters()
+
+
+class _MHA(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.w_qs = nn.Linear(d, d, bias=False)
+        self.w_ks = nn.Linear(d, d, bias=False)
+        self.w_vs = nn.Linear(d, d, bias=False)
+        self.fc = nn.Linear(d, d, bias=False)
+        self.norm = MaskedLN(d)
+
+
+class _FFN(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.w_1 = nn.Linear(d, d)
+        self.w_2 = nn.Linear(d, d)
+        self.norm = MaskedLN(d)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        if d % N_HEAD:
+            raise ValueError(f"hidden width {d} must be divisible by the {N_HEAD} attention heads")
+        self.slf_attn = _MHA(d)
+        self.pos_ffn = _FFN(d)
+
+
+class SetTransformer(nn.Module):
+    def __init__(self, nhid, nlayer, variant):
+        super().__init__()
+        if variant != "alchemy":   # unused parameter of the reference (core/sign_net.py:54)
+            self.pos_encoder = MaskedMLP(1, nhid, nlayer=2)
+        self.transformer_layers = nn.ModuleList(TransformerEncoderLayer(nhid) for _ in range(nlayer))
+        self.out = nn.Sequential(nn.Linear(nhid, nhid, bias=False), nn.BatchNorm1d(nhid))
+
+    def reset_parameters(self):
+        if hasattr(self, "pos_encoder"):
+            self.pos_encoder.reset_parameters()
+
+
+class SignNet(nn.Module):
+    def __init__(self, n_hid, nl_phi, nl_rho, variant, ignore_eigval=False):
+        super().__init__()
+        self.variant = variant
+        self.phi = GNN3d(1, n_hid, nl_phi, variant)
+        self.rho = SetTransformer(n_hid, nl_rho, variant)
+        self.ignore_eigval = ignore_eigval
+        if variant == "alchemy":
+            if not ignore_eigval:
+                self.eigen_encoder = MaskedMLP(1, n_hid, nlayer=2)
+        else:
+            self.eigen_encoder1 = MaskedMLP(1, n_hid, nlayer=1)
+            self.eigen_encoder2 = MaskedMLP(1, n_hid, nlayer=2)
+
+    def reset_parameters(self):
+        self.phi.reset_parameters()
+        self.rho.reset_parameters()
+        for n in ("eigen_encoder", "eigen_encoder1", "eigen_encoder2"):
+            if hasattr(self, n):
+                getattr(self, n).reset_parameters()
+
+
+class GNN(nn.Module):
+    def __init__(self, nfeat_node, nfeat_edge, nhid, nout, nlayer, variant, pooling="add"):
+        super().__init__()
+        nv = 6 if variant == "alchemy" else 500      # elements.py:22
+        self.input_encoder = DiscreteEncoder(nhid, max_num_values=nv) if nfeat_node is None else MLP(nfeat_node, nhid, 1)
+        self.edge_encoders = nn.ModuleList([DiscreteEncoder(nhid, max_num_values=nv) if nfeat_edge is None
+                                            else MLP(nfeat_edge, nhid, 1) for _ in range(nlayer)])
+        self.convs = nn.ModuleList([GINEConv(nhid, nhid, bias=False) for _ in range(nlayer)])
+        self.norms = nn.ModuleList([nn.BatchNorm1d(nhid) for _ in range(nlayer)])
+        self.output_encoder = MLP(nhid, nout, nlayer=2, with_final_activation=False,
+                                  with_norm=False if pooling == "mean" else True)
+        if variant != "alchemy":   # core/model.py:18
+            self.size_embedder = nn.Embedding(200, nhid)
+        self.linear = nn.Linear(2 * nhid, nhid)
+        self.pooling = pooling
+
+    def reset_parameters(self):
+        self.input_encoder.reset_parameters()
+        self.output_encoder.reset_parameters()
+        if hasattr(self, "size_embedder"):
+            self.size_embedder.reset_parameters()
+        self.linear.reset_parameters()
+        for e, c, n in zip(self.edge_encoders, self.convs, self.norms):
+            e.reset_parameters()
+            c.reset_parameters()
+            n.reset_parameters()
+
+
+# ----------------------------------------------------------------------------- prepared (packed) parameters
+def _bn_affine(bn: nn.BatchNorm1d):
+    """Eval-mode BatchNorm as y = x*scale + shift (running statistics)."""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+def _pack(lin: nn.Linear) -> ops.PackedLinear:
+    w = lin.weight.detach()
+    return ops.PackedLinear(ops.pack_weight(w), w.shape[0], w.shape[1],
+                            None if lin.bias is None else lin.bias.detach().contiguous())
+
+
+class SignNetGNN(nn.Module):
+    """HIP SignNet + GINE.  `variant` selects which reference tree's semantics are reproduced.
+
+    Extra keyword (not in the reference): `max_k` — use only the first `max_k` eigenvectors
+    (BASELINE.json's "k=16" reading); None = all eigenvectors as the reference does.
+    """
+
+    def __init__(self, node_feat, edge_feat, n_hid, n_out, nl_signnet, nl_gnn, nl_rho=4, ignore_eigval=False,
+                 gnn_type="GINEConv", *, variant="alchemy", max_k=None):
+        super().__init__()
+        if gnn_type != "GINEConv":
+            raise ValueError("only gnn_type='GINEConv' is on the SignNet hot path (SURVEY.md §2 row 3)")
+        if variant not in ("alchemy", "gine"):
+            raise ValueError("variant must be 'alchemy' or 'gine'")
+        self.variant, self.max_k = variant, max_k
+        self.cfg = dict(node_feat=node_feat, edge_feat=edge_feat, n_hid=n_hid, n_out=n_out,
+                        nl_signnet=nl_signnet, nl_gnn=nl_gnn)
+        # nl_rho is fixed by the reference constructors (sign_net.py:123 ignores the argument)
+        self.nl_rho = 4 if variant == "alchemy" else 1
+        self.sign_net = SignNet(n_hid, nl_signnet, self.nl_rho, variant, ignore_eigval)
+        self.gnn = GNN(node_feat, edge_feat, n_hid, n_out, nl_gnn, variant)
+        self._prep = None
+
+    def reset_parameters(self):
+        self.sign_net.reset_parameters()
+        self.gnn.reset_parameters()
+        self._prep = None
+
+    # cache invalidation: packed weights depend on parameters, buffers, device and mode
+    def train(self, mode=True):
+        self._prep = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def invalidate(self):
+        """Call after modifying parameters in place while in eval mode."""
+        self._prep = None
+
+    # ------------------------------------------------------------------ prepare
+    def _prepare(self):
+        P = {}
+        sn, g = self.sign_net, self.gnn
+        P["phi"] = []
+        for conv, norm in zip(sn.phi.convs, sn.phi.norms):
+            P["phi"].append(dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0].bn),
+                                 l1=_pack(conv.nn.layers[1]), bn=_bn_affine(norm.bn)))
+        if self.variant == "alchemy" and not sn.ignore_eigval:
+            ee = sn.eigen_encoder
+            P["eig"] = dict(l0=_pack(ee.layers[0]), bn0=_bn_affine(ee.norms[0].bn), l1=_pack(ee.layers[1]),
+                            bn1=_bn_affine(ee.norms[1].bn))
+        P["rho"] = []
+        for tl in sn.rho.transformer_layers:
+            a, f = tl.slf_attn, tl.pos_ffn
+            P["rho"].append(dict(q=_pack(a.w_qs), k=_pack(a.w_ks), v=_pack(a.w_vs), fc=_pack(a.fc),
+                                 ln1=(a.norm.ln.weight.detach(), a.norm.ln.bias.detach()),
+                                 w1=_pack(f.w_1), w2=_pack(f.w_2),
+                                 ln2=(f.norm.ln.weight.detach(), f.norm.ln.bias.detach())))
+        P["rho_out"] = dict(l=_pack(sn.rho.out[0]), bn=_bn_affine(sn.rho.out[1]))
+        if isinstance(g.input_encoder, DiscreteEncoder):
+            P["in_tabs"] = [e.weight.detach() for e in g.input_encoder.embeddings]
+        else:
+            P["in_mlp"] = dict(l=_pack(g.input_encoder.layers[0]), bn=_bn_affine(g.input_encoder.norms[0]))
+        P["lin"] = _pack(g.linear)
+        P["gine"] = []
+        for enc, conv, norm in zip(g.edge_encoders, g.convs, g.norms):
+            d = dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0]),
+                     l1=_pack(conv.nn.layers[1]), bn=_bn_affine(norm))
+            if isinstance(enc, DiscreteEncoder):
+                d["tabs"] = [e.weight.detach() for e in enc.embeddings]
+            else:
+                d["emlp"] = dict(l=_pack(enc.layers[0]), bn=_bn_affine(enc.norms[0]))
+            P["gine"].append(d)
+        oe = g.output_encoder
+        P["head"] = dict(l0=_pack(oe.layers[0]), bn0=_bn_affine(oe.norms[0]), l1=_pack(oe.layers[1]))
+        return P
+
+    # ------------------------------------------------------------------ forward (layer-at-a-time HIP path)
+    def forward(self, data, return_stages=False):
+        if self.training:
+            raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+        ops.require_cuda(data.edge_index, data.batch, data.eigen_vectors)
+        if self._prep is None:
+            self._prep = self._prepare()
+        P = self._prep
+        B = int(data.num_graphs)
+        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0)
+        if self.max_k:
+            K = int(self.max_k)
+            plan.check() if return_stages else None
+        else:
+            K = plan.check()[1]          # N_max: one host sync, as the reference's to_dense_EVD does
+        N, d = plan.N, self.cfg["n_hid"]
+        nv = plan.nvalid
+        want_vals = "eig" in P
+        x0, s0 = ops.pack_eig(plan, data.eigen_vectors, data.eigen_values if want_vals else None, K, want_vals)
+        stages = {}
+
+        # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)
+        phis = []
+        for sign in (0, 1):
+            x, prev = x0, None
+            for l, L in enumerate(P["phi"]):
+                a = ops.gin_aggregate(x.view(N, -1), plan, L["eps"], negate=(sign == 1 and l == 0))
+                h = ops.masked_linear(a.view(N * K, -1), L["l0"], nv, K, scale=L["bn0"][0], shift=L["bn0"][1], relu=True)
+                x = ops.masked_linear(h, L["l1"], nv, K, scale=L["bn"][0], shift=L["bn"][1], relu=True, residual=prev)
+                prev = x
+            phis.append(x)
+        x = ops.masked_affine(phis[0], nv, K, residual=phis[1])          # phi(x) + phi(-x)
+        if return_stages:
+            stages.update(phi_plus=phis[0].view(N, K, d), phi_minus=phis[1].view(N, K, d))
+        # ---- rho                    (SetTransformer.forward, sign_net.py:60-72)
+        if want_vals:
+            E_ = P["eig"]
+            p = ops.masked_linear(s0.view(N * K, 1), E_["l0"], nv, K, scale=E_["bn0"][0], shift=E_["bn0"][1], relu=True)
+            p = ops.masked_linear(p, E_["l1"], nv, K, scale=E_["bn1"][0], shift=E_["bn1"][1], relu=True)
+            x = ops.masked_affine(x, nv, K, residual=p)
+        for L in P["rho"]:
+            q = ops.masked_linear(x, L["q"], nv, K)
+            k = ops.masked_linear(x, L["k"], nv, K)
+            v = ops.masked_linear(x, L["v"], nv, K)
+            o = ops.set_attention(q, k, v, N, K, N_HEAD, nv)
+            o = ops.masked_linear(o, L["fc"], nv, K)
+            y = ops.masked_layernorm(o, x, L["ln1"][0], L["ln1"][1], LN_EPS, nv, K)
+            z = ops.masked_linear(y, L["w1"], nv, K, relu=True)
+            z = ops.masked_linear(z, L["w2"], nv, K)
+            x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
+        s = ops.slot_sum(x, N, K)
+        pe = ops.masked_linear(s, P["rho_out"]["l"], scale=P["rho_out"]["bn"][0], shift=P["rho_out"]["bn"][1])
+        if return_stages:
+            stages["pos"] = pe
+        # ---- GINE network           (GNN.forward, model.py:36-64)
+        xin = data.x.squeeze() if data.x.dim() > 1 and data.x.shape[-1] == 1 else data.x
+        if "in_tabs" in P:
+            h = ops.embedding_sum(xin, P["in_tabs"])
+        else:
+            h = ops.masked_linear(xin.contiguous(), P["in_mlp"]["l"], scale=P["in_mlp"]["bn"][0],
+                                  shift=P["in_mlp"]["bn"][1], relu=True)
+        h = ops.masked_linear(torch.cat([h, pe], dim=-1), P["lin"])
+        for l, L in enumerate(P["gine"]):
+            if "tabs" in L:
+                e = ops.embedding_sum(data.edge_attr, L["tabs"])
+            else:
+                e = ops.masked_linear(data.edge_attr.contiguous(), L["emlp"]["l"], scale=L["emlp"]["bn"][0],
+                                      shift=L["emlp"]["bn"][1], relu=True)
+            u = ops.gine_aggregate(h, e, plan, L["eps"])
+            u = ops.masked_linear(u, L["l0"], scale=L["bn0"][0], shift=L["bn0"][1], relu=True)
+            h = ops.masked_linear(u, L["l1"], scale=L["bn"][0], shift=L["bn"][1], relu=True, residual=h)
+            if return_stages:
+                stages[f"gine{l}"] = h
+        pooled = ops.segment_pool(h, plan, self.gnn.pooling)
+        y = ops.masked_linear(pooled, P["head"]["l0"], scale=P["head"]["bn0"][0], shift=P["head"]["bn0"][1], relu=True)
+        y = ops.masked_linear(y, P["head"]["l1"])
+        if return_stages:
+            stages["y"] = y
+            return y, stages
+        return y

@@ -1,0 +1,214 @@
+"""-m gpu: every C-ABI op against a plain torch fp32/fp64 restatement on the same seeded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from signnet_basisnet_amd import synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def batch(dev):
+    from signnet_basisnet_amd import ops
+    data = synth.make_batch(12, seed=5, sizes=[1, 2, 5, 9, 37, 23, 16, 17, 3, 30, 8, 12])
+    d = synth.batch_to(data, dev)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 0)
+    plan.check()
+    return data, d, plan
+
+
+def dense_adj(data, dtype=torch.float64):
+    N = data.batch.numel()
+    A = torch.zeros(N, N, dtype=dtype)
+    A.index_put_((data.edge_index[1], data.edge_index[0]), torch.ones(data.edge_index.shape[1], dtype=dtype), accumulate=True)
+    return A
+
+
+def test_plan(batch):
+    data, d, plan = batch
+    n = torch.tensor(data.sizes)
+    gp = torch.cat([torch.zeros(1, dtype=torch.long), n.cumsum(0)])
+    assert plan.graph_ptr.cpu().tolist() == gp.tolist()
+    assert plan.node_graph.cpu().tolist() == data.batch.tolist()
+    assert plan.nvalid.cpu().tolist() == n[data.batch].tolist()
+    assert plan.evoff.cpu().tolist() == torch.cat([torch.zeros(1, dtype=torch.long), (n * n).cumsum(0)]).tolist()
+    st = plan.status.cpu().tolist()
+    assert st[0] == 0 and st[1] == max(data.sizes)
+    # CSR: in-edges of every node, ordered by edge id
+    rowptr, col, eperm = plan.rowptr.cpu(), plan.col.cpu(), plan.eperm.cpu()
+    src, dst = data.edge_index
+    for i in range(plan.N):
+        ids = torch.nonzero(dst == i).flatten()
+        seg = slice(int(rowptr[i]), int(rowptr[i + 1]))
+        assert eperm[seg].tolist() == ids.tolist()
+        assert col[seg].tolist() == src[ids].tolist()
+
+
+def test_plan_kmax_and_errors(dev):
+    from signnet_basisnet_amd import ops
+    data = synth.make_batch(4, seed=2, sizes=[3, 20, 7, 12])
+    d = synth.batch_to(data, dev)
+    plan = ops.build_plan(d.batch, d.edge_index, 4, 8)
+    assert plan.nvalid.cpu().tolist() == torch.tensor(data.sizes).clamp(max=8)[data.batch].tolist()
+    bad = d.batch.flip(0).contiguous()
+    with pytest.raises(ValueError):
+        ops.build_plan(bad, d.edge_index, 4, 0).check()
+    ei = d.edge_index.clone()
+    ei[0, 0] = data.batch.numel() - 1      # edge from the last graph into the first
+    with pytest.raises(ValueError):
+        ops.build_plan(d.batch, ei, 4, 0).check()
+
+
+def test_pack_eig(batch):
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    K = max(data.sizes)
+    x0, s0 = ops.pack_eig(plan, d.eigen_vectors, d.eigen_values, K, True)
+    es, ev, mask = O.to_dense_list_evd(data.eigen_values, data.eigen_vectors, data.batch)
+    assert torch.equal(x0.cpu(), ev) and torch.equal(s0.cpu(), es)     # pure data movement: bit exact
+
+
+@pytest.mark.parametrize("F", [1, 37, 64, 16 * 128])
+@pytest.mark.parametrize("slab", [False, True])
+def test_gin_aggregate(batch, dev, F, slab):
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    g = torch.Generator().manual_seed(F)
+    x = torch.randn(plan.N, F, generator=g)
+    eps = torch.tensor([0.37])
+    ref = O.gin_aggregate(x, data.edge_index, eps, node_dim=0)
+    out = ops.gin_aggregate(x.to(dev), plan, eps.to(dev), slab=slab)
+    assert torch.equal(out.cpu(), ref)                       # same summation order -> bit exact
+    outn = ops.gin_aggregate(x.to(dev), plan, eps.to(dev), negate=True, slab=slab)
+    assert torch.equal(outn.cpu(), O.gin_aggregate(-x, data.edge_index, eps, node_dim=0))
+    # independent check: dense fp64 adjacency product
+    ref64 = dense_adj(data) @ x.double() + (1 + eps.double()) * x.double()
+    torch.testing.assert_close(out.cpu().double(), ref64, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C", [20, 128])
+def test_gine_aggregate(batch, dev, C):
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    g = torch.Generator().manual_seed(C)
+    x, e = torch.randn(plan.N, C, generator=g), torch.randn(plan.E, C, generator=g)
+    eps = torch.tensor([-0.2])
+    out = ops.gine_aggregate(x.to(dev), e.to(dev), plan, eps.to(dev))
+    assert torch.equal(out.cpu(), O.gine_aggregate(x, data.edge_index, e, eps))
+
+
+@pytest.mark.parametrize("d_in,d_out", [(1, 1), (1, 128), (128, 128), (108, 108), (6, 44), (256, 128), (95, 4), (300, 70)])
+def test_masked_linear(batch, dev, d_in, d_out):
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    K = 19
+    nv = torch.tensor(data.sizes).clamp(max=K)[data.batch]
+    mask = torch.arange(K)[None, :] < nv[:, None]
+    g = torch.Generator().manual_seed(d_in * 1000 + d_out)
+    x = torch.randn(plan.N, K, d_in, generator=g)
+    W, b = torch.randn(d_out, d_in, generator=g) / d_in ** 0.5, torch.randn(d_out, generator=g)
+    sc, sh = torch.rand(d_out, generator=g) + 0.5, torch.randn(d_out, generator=g)
+    res = torch.randn(plan.N, K, d_out, generator=g)
+    pl = ops.PackedLinear(ops.pack_weight(W.to(dev)), d_out, d_in, b.to(dev))
+    nvd = nv.to(dev).int()
+    # plain
+    y = ops.masked_linear(x.to(dev), pl, use_bias=False)
+    ref = (x.double() @ W.double().T)
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    # full epilogue, PyG order: bias -> mask -> affine -> relu -> residual
+    y = ops.masked_linear(x.to(dev), pl, nvd, K, scale=sc.to(dev), shift=sh.to(dev), relu=True, residual=res.to(dev))
+    ref = torch.relu((x.double() @ W.double().T + b.double()) * sc.double() + sh.double()) + res.double()
+    ref = ref * mask.unsqueeze(-1)
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    # DGL order: bias -> relu -> affine
+    y = ops.masked_linear(x.to(dev), pl, scale=sc.to(dev), shift=sh.to(dev), relu_pre=True)
+    ref = torch.relu(x.double() @ W.double().T + b.double()) * sc.double() + sh.double()
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+    # fp32 torch agreement (the tolerance north_star states: 1e-5 relative)
+    y32 = F.linear(x, W)
+    yk = ops.masked_linear(x.to(dev), pl, use_bias=False).cpu()
+    assert (yk - y32).abs().max() <= 1e-5 * max(1.0, y32.abs().max().item())
+
+
+def test_colstats_affine(batch, dev):
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    K, C = 11, 44
+    nv = torch.tensor(data.sizes).clamp(max=K)[data.batch]
+    mask = torch.arange(K)[None, :] < nv[:, None]
+    x = torch.randn(plan.N, K, C, generator=torch.Generator().manual_seed(3)) * 2 + 5
+    mean, var, cnt = ops.masked_colstats(x.to(dev), nv.to(dev).int(), K)
+    rows = x[mask].double()
+    assert cnt.item() == rows.shape[0]
+    torch.testing.assert_close(mean.cpu().double(), rows.mean(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(var.cpu().double(), rows.var(0, unbiased=False), rtol=1e-5, atol=1e-5)
+    sc, sh = torch.rand(C) + 0.5, torch.randn(C)
+    y = ops.masked_affine(x.to(dev), nv.to(dev).int(), K, scale=sc.to(dev), shift=sh.to(dev), relu=True)
+    ref = torch.relu(x * sc + sh) * mask.unsqueeze(-1)
+    torch.testing.assert_close(y.cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("C", [12, 108, 128])
+def test_layernorm(batch, dev, C):
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    K = 9
+    nv = torch.tensor(data.sizes).clamp(max=K)[data.batch]
+    mask = torch.arange(K)[None, :] < nv[:, None]
+    g = torch.Generator().manual_seed(C)
+    x, r = torch.randn(plan.N, K, C, generator=g), torch.randn(plan.N, K, C, generator=g)
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    y = ops.masked_layernorm(x.to(dev), r.to(dev), w.to(dev), b.to(dev), 1e-6, nv.to(dev).int(), K)
+    ref = F.layer_norm((x + r).double(), (C,), w.double(), b.double(), 1e-6) * mask.unsqueeze(-1)
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,D", [(9, 12), (16, 128), (37, 108)])
+def test_set_attention(batch, dev, K, D):
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    H, dk = 4, D // 4
+    nv = torch.tensor(data.sizes).clamp(max=K)[data.batch]
+    mask = (torch.arange(K)[None, :] < nv[:, None])
+    g = torch.Generator().manual_seed(K * D)
+    q, k, v = (torch.randn(plan.N, K, D, generator=g) * mask.unsqueeze(-1) for _ in range(3))
+    out = ops.set_attention(q.to(dev), k.to(dev), v.to(dev), plan.N, K, H, nv.to(dev).int())
+    pair = (mask.unsqueeze(1) * mask.unsqueeze(2)).unsqueeze(1)
+    sp = lambda t: t.double().view(plan.N, K, H, dk).transpose(1, 2)
+    att = torch.matmul(sp(q) / dk ** 0.5, sp(k).transpose(2, 3)).masked_fill(pair == 0, -1e10)
+    att = torch.softmax(att, -1) * pair
+    ref = torch.matmul(att, sp(v)).transpose(1, 2).reshape(plan.N, K, D)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_small_ops(batch, dev):
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(plan.N, 7, 20, generator=g)
+    torch.testing.assert_close(ops.slot_sum(x.to(dev), plan.N, 7).cpu(), x.sum(1), rtol=1e-6, atol=1e-6)
+    tabs = [torch.randn(30, 20, generator=g) for _ in range(3)]
+    idx = torch.randint(0, 30, (plan.N, 3), generator=g)
+    ref = sum(tabs[f][idx[:, f]] for f in range(3))
+    torch.testing.assert_close(ops.embedding_sum(idx.to(dev), [t.to(dev) for t in tabs]).cpu(), ref, rtol=1e-6, atol=1e-6)
+    assert torch.equal(ops.embedding_sum(idx[:, 0].contiguous().to(dev), [tabs[0].to(dev)]).cpu(), tabs[0][idx[:, 0]])
+    h = torch.randn(plan.N, 20, generator=g)
+    ref = torch.zeros(plan.B, 20).index_add_(0, data.batch, h)
+    torch.testing.assert_close(ops.segment_pool(h.to(dev), plan).cpu(), ref, rtol=1e-6, atol=1e-6)
+    cnt = torch.tensor(data.sizes).float().unsqueeze(1)
+    torch.testing.assert_close(ops.segment_pool(h.to(dev), plan, "mean").cpu(), ref / cnt, rtol=1e-6, atol=1e-6)
+
+
+def test_cpu_tensors_are_rejected():
+    from signnet_basisnet_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.pack_weight(torch.randn(4, 4))

@@ -1,0 +1,73 @@
+"""-m gpu: the HIP SignNetGNN modules against the golden fixtures (reference outputs) and the oracle."""
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5     # north_star: outputs within 1e-5 relative fp32 of the CPU path
+
+
+def close(a, b, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= REL * scale * 4, f"{what}: max|diff| {err:.3e} vs scale {scale:.3e}"
+
+
+def build(fx, max_k=None):
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    c = [None if v < 0 else int(v) for v in fx.meta["ctor"]]
+    variant = str(fx.meta["variant"])
+    m = SignNetGNN(*c, variant=variant, max_k=max_k)
+    sd = G.full_state_dict(fx)
+    assert sorted(m.state_dict().keys()) == sorted(sd.keys()), "state_dict key layout differs from the reference"
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", G.PYG_CASES)
+def test_golden(name):
+    from signnet_basisnet_amd import synth
+    fx = G.load(name)
+    model = build(fx)
+    data = synth.batch_to(G.as_data(fx.inp), "cuda:0")
+    y, st = model(data, return_stages=True)
+    close(st["phi_plus"], fx.out["eval/phi_plus"], "phi(+x)")
+    close(st["phi_minus"], fx.out["eval/phi_minus"], "phi(-x)")
+    close(st["pos"], fx.out["eval/pos"], "sign_net output")
+    close(y, fx.out["eval/y"], "model output")
+
+
+@pytest.mark.parametrize("variant,ctor,feat,max_k", [
+    ("gine", (None, None, 128, 1, 4, 6), "zinc", 16),
+    ("gine", (None, None, 64, 1, 4, 6), "zinc", 8),
+    ("gine", (None, None, 128, 1, 4, 6), "zinc", None),
+    ("alchemy", (6, 4, 108, 12, 3, 4), "alchemy", None),
+])
+def test_vs_oracle_real_widths(variant, ctor, feat, max_k):
+    """Reference-sized widths on a seeded synthetic batch: HIP vs the CPU oracle (same weights)."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    model = SignNetGNN(*ctor, variant=variant, max_k=max_k)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    lo, hi = (6, 14) if variant == "alchemy" else (9, 37)
+    data = synth.make_batch(16, seed=77, n_lo=lo, n_hi=hi, features=feat)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    cfg = O.make_cfg(variant, *ctor)
+    out = {}
+    yref = O.signnet_gnn(sd, cfg, data, training=False, max_k=max_k, out=out)
+    model = model.cuda().eval()
+    y, st = model(synth.batch_to(data, "cuda:0"), return_stages=True)
+    close(st["pos"], out["pos"], "sign_net output")
+    close(y, yref, "model output")
