@@ -138,6 +138,18 @@ __device__ __forceinline__ float vzero<float>() { return 0.f; }
 template <>
 __device__ __forceinline__ float4 vzero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// acc + x*s with the product rounded separately (no FMA contraction), so the result is bit-identical
+// to the reference's `out += (1 + eps) * x` evaluated as two fp32 ops.
+__device__ __forceinline__ float self_term(float acc, float x, float s) {
+#pragma clang fp contract(off)
+  float p = x * s;
+  return acc + p;
+}
+__device__ __forceinline__ float4 self_term(float4 acc, float4 x, float s) {
+  return make_float4(self_term(acc.x, x.x, s), self_term(acc.y, x.y, s), self_term(acc.z, x.z, s),
+                     self_term(acc.w, x.w, s));
+}
+
 // ============================================================================ GIN aggregate (gather)
 // out[i,f] = sum_{e in in(i)} x[col[e], f]  +  (1+eps) * x[i,f]      (neighbours first, in edge-id
 // order, then the self term: the order PyG's propagate + `out += (1+eps)*x_r` produces)
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gin_gather(const VT* __restrict__ x, VT
   const VT zero = vzero<VT>();
   VT acc = zero;
   for (int e = lo; e < hi; ++e) acc = acc + x[(int64_t)col[e] * FV + f];
-  acc = acc + x[node * FV + f] * sc;
+  acc = self_term(acc, x[node * FV + f], sc);
   out[node * FV + f] = negate ? zero - acc : acc;
 }
 
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gin_slab(const VT* __restrict__ x, VT* 
       const VT zero = vzero<VT>();
       VT acc = zero;
       for (int e = lrow[r]; e < lrow[r + 1]; ++e) acc = acc + slab[lcol[e] * cw + f];
-      acc = acc + self * sc;
+      acc = self_term(acc, self, sc);
       out[(int64_t)(gs + r) * FV + c0 + f] = negate ? zero - acc : acc;
     }
   } else {
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256) void k_gin_slab(const VT* __restrict__ x, VT* 
       const VT zero = vzero<VT>();
       VT acc = zero;
       for (int e = rowptr[gs + r]; e < rowptr[gs + r + 1]; ++e) acc = acc + x[(int64_t)col[e] * FV + c0 + f];
-      acc = acc + self * sc;
+      acc = self_term(acc, self, sc);
       out[(int64_t)(gs + r) * FV + c0 + f] = negate ? zero - acc : acc;
     }
   }
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256) void k_gine_gather(const VT* __restrict__ x, c
   VT acc = vzero<VT>();
   for (int e = rowptr[node]; e < rowptr[node + 1]; ++e)
     acc = acc + vrelu<VT>(x[(int64_t)col[e] * CV + f] + ea[(int64_t)eperm[e] * CV + f]);
-  out[idx] = acc + self * sc;
+  out[idx] = self_term(acc, self, sc);
 }
 
 // ============================================================================ masked column statistics

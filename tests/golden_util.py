@@ -40,6 +40,8 @@ def full_state_dict(fx):
     sd = dict(fx.sd)
     for k, shp in zip(fx.meta["sd_keys"], fx.meta["sd_shapes"]):
         k = str(k)
+        if k not in sd and ".layer.nn." in k:      # second registration of the same GINE MLP tensors
+            sd[k] = sd[k.replace(".layer.nn.", ".nn.")]
         if k not in sd:
             shape = tuple(int(s) for s in str(shp).split(",") if s)
             sd[k] = torch.zeros(shape, dtype=torch.long if k.endswith("num_batches_tracked") else torch.float32)
