@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py — graphs/sec of the SignNet+GINE forward (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one eval-mode forward of `SignNetGNN(None, None, 128, 1, 4, 6)` (GINESignNetPyG
+defaults, core/config.py:30,53-57) over one synthetic ZINC-like batch of 128 graphs with the
+first k=16 eigenvectors (BASELINE.json configs[1]), inputs resident in HBM.  Multi-GPU: the batch
+of 128*N graphs is sharded by graph, 128 per rank, no data-path collective (weak scaling).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (f32 in / f32 acc) dense peak
+
+WORKLOAD = dict(name="ZINC SignNet k=16 hidden=128 batch=128 (GINESignNetPyG SignNetGNN(None,None,128,1,4,6))",
+                B=128, k=16, hidden=128, nl_signnet=4, nl_rho=1, nl_gnn=6, n_out=1)
+
+
+def build_model(dev):
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    m = SignNetGNN(None, None, WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"],
+                   variant="gine", max_k=WORKLOAD["k"])
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():          # eval-BN must not be the identity
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    return m.to(dev).eval()
+
+
+def algorithmic_flops(data, k, d, L_phi, L_rho, L_g):
+    """Dense-contraction flops of one forward on this batch (SURVEY.md §8(d) formulas, valid rows only)."""
+    n = torch.tensor(data.sizes, dtype=torch.float64)
+    M = float((n * torch.clamp(n, max=k)).sum())          # valid (node, slot) rows
+    N = float(n.sum())
+    phi = 2 * (L_phi - 1) * 2 * 2 * M * d * d + 2 * 2 * M * d           # hidden layers, both signs (+ tiny first layer)
+    rho = L_rho * (6 * 2 * M * d * d + 4 * float((n * torch.clamp(n, max=k) ** 2).sum()) * d) + 2 * N * d * d
+    gnn = 2 * N * 2 * d * d + L_g * 2 * 2 * N * d * d + 2 * len(data.sizes) * d * d
+    return dict(phi=phi, rho=rho, gnn=gnn, total=phi + rho + gnn, M=M, N=N)
+
+
+def cpu_baseline(data, model_cpu_sd, budget_s=20.0):
+    """The oracle (CPU restatement of the reference) timed on this host's cores on the same batch."""
+    from oracle import pyg_signnet as O
+    cfg = O.make_cfg("gine", None, None, WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"])
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.signnet_gnn(model_cpu_sd, cfg, data, training=False, max_k=WORKLOAD["k"])     # warm-up
+        first = time.perf_counter() - t0
+        iters = max(1, min(10, int(budget_s / max(first, 1e-3)) - 1))
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            O.signnet_gnn(model_cpu_sd, cfg, data, training=False, max_k=WORKLOAD["k"])
+            ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return dict(value=len(data.sizes) / med, unit="graphs/s", cores=cores, kind="port",
+                sample=f"{iters} forward(s) of the same {len(data.sizes)}-graph batch, median; oracle/pyg_signnet.py "
+                       f"(torch CPU fp32, {cores} threads)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 and world == 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist = dist_
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from signnet_basisnet_amd import ops, synth
+    # each rank owns its shard of the global batch: graphs [rank*B, (rank+1)*B)
+    host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2 + 1000 * rank)
+    data = synth.batch_to(host, dev)
+    model = build_model(dev)
+    fl = algorithmic_flops(host, WORKLOAD["k"], WORKLOAD["hidden"], WORKLOAD["nl_signnet"], WORKLOAD["nl_rho"], WORKLOAD["nl_gnn"])
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            model(data)
+        rec = ops.KernelTimer()
+        sync_all()
+        t0 = time.perf_counter()
+        with rec:
+            for _ in range(args.steps):
+                model(data)
+        sync_all()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        total_graphs = WORKLOAD["B"] * world * args.steps
+        ktimes = rec.summary()                       # {kernel: (launches, mean_ms)}
+        dom = max(ktimes.items(), key=lambda kv: kv[1][0] * kv[1][1]) if ktimes else None
+        roof = None
+        if dom is not None:
+            name, (launches, mean_ms) = dom
+            per_step = launches / args.steps
+            info = ops.KERNEL_ROOFLINE.get(name, None)
+            if info is not None:
+                roof = info(fl, WORKLOAD, host, mean_ms, per_step)
+        out = {
+            "metric": "graphs/sec SignNet+GINE forward, ZINC batch=128 k=16",
+            "value": total_graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD["name"], "graphs_per_gpu": WORKLOAD["B"], "global_batch": WORKLOAD["B"] * world,
+                       "nodes": int(fl["N"]), "valid_rows": int(fl["M"]), "parallelism": f"graph-sharded dp{world}, no collective",
+                       "gflop_per_step": fl["total"] / 1e9},
+            "roofline": roof,
+            "kernels": {k: {"launches_per_step": v[0] / args.steps, "mean_us": 1e3 * v[1]} for k, v in ktimes.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            out["cpu_baseline"] = cpu_baseline(host, sd)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,10 +14,75 @@ from . import _lib
 from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, check, lib, ptr,
                    require_cuda, stream)
 
-__all__ = ["GraphPlan", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
+__all__ = ["KernelTimer", "KERNEL_ROOFLINE", "GraphPlan", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
            "masked_linear", "masked_colstats", "masked_affine", "masked_layernorm", "set_attention",
            "slot_sum", "embedding_sum", "segment_pool", "PackedLinear",
            "EPI_BIAS", "EPI_RELU_PRE", "EPI_AFFINE", "EPI_RELU", "EPI_RESIDUAL"]
+
+
+# ----------------------------------------------------------------------------- kernel timing (bench.py)
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOSPAN = _NoSpan()
+_active_timer = None
+
+
+class _Span:
+    __slots__ = ("timer", "name", "e0")
+
+    def __init__(self, timer, name):
+        self.timer, self.name = timer, name
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()          # torch's current stream == the stream the kernel is launched on
+        return self
+
+    def __exit__(self, *a):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.timer.spans.append((self.name, self.e0, e1))
+        return False
+
+
+class KernelTimer:
+    """HIP-event timing of C-ABI launches on torch's current stream (the stream every launch uses).
+    `only` restricts recording to the named entry points so the timed region is barely perturbed."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only else None
+        self.spans = []
+
+    def __enter__(self):
+        global _active_timer
+        _active_timer = self
+        return self
+
+    def __exit__(self, *a):
+        global _active_timer
+        _active_timer = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        acc = {}
+        for name, e0, e1 in self.spans:
+            n, t = acc.get(name, (0, 0.0))
+            acc[name] = (n + 1, t + e0.elapsed_time(e1))
+        return {k: (n, t / n) for k, (n, t) in acc.items()}
+
+
+def _span(name):
+    t = _active_timer
+    if t is None or (t.only is not None and name not in t.only):
+        return _NOSPAN
+    return _Span(t, name)
 
 
 def _f32c(t, name):
@@ -70,9 +135,10 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, scratch = (
         arena[offs[i]:offs[i] + sizes[i]] for i in range(8))
     evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
-    check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
-                              ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
-                              ptr(scratch), stream()), "sn_batch_plan")
+    with _span("sn_batch_plan"):
+        check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
+                                  ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
+                                  ptr(scratch), stream()), "sn_batch_plan")
     return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status)
 
 
@@ -82,8 +148,9 @@ def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: 
     x0 = torch.empty(plan.N, K, dtype=torch.float32, device=ev.device)
     s0 = torch.empty_like(x0) if want_values else None
     es = _f32c(eigen_values, "eigen_values") if want_values else None
-    check(lib().sn_pack_eig_f32(ptr(ev), ptr(es), ptr(plan.graph_ptr), ptr(plan.node_graph), ptr(plan.nvalid),
-                                ptr(plan.evoff), plan.N, K, ptr(x0), ptr(s0), stream()), "sn_pack_eig_f32")
+    with _span("sn_pack_eig_f32"):
+        check(lib().sn_pack_eig_f32(ptr(ev), ptr(es), ptr(plan.graph_ptr), ptr(plan.node_graph), ptr(plan.nvalid),
+                                    ptr(plan.evoff), plan.N, K, ptr(x0), ptr(s0), stream()), "sn_pack_eig_f32")
     return x0, s0
 
 
@@ -120,12 +187,14 @@ def gin_aggregate(x, plan: GraphPlan, eps=None, negate=False, slab=False):
     F = x.numel() // max(N, 1)
     out = torch.empty_like(x)
     if slab:
-        check(lib().sn_gin_aggregate_slab_f32(ptr(x), ptr(out), N, F, plan.B, ptr(plan.graph_ptr), ptr(plan.rowptr),
-                                              ptr(plan.col), ptr(eps), int(negate), stream()),
-              "sn_gin_aggregate_slab_f32")
+        with _span("sn_gin_aggregate_slab_f32"):
+            check(lib().sn_gin_aggregate_slab_f32(ptr(x), ptr(out), N, F, plan.B, ptr(plan.graph_ptr), ptr(plan.rowptr),
+                                                  ptr(plan.col), ptr(eps), int(negate), stream()),
+                  "sn_gin_aggregate_slab_f32")
     else:
-        check(lib().sn_gin_aggregate_f32(ptr(x), ptr(out), N, F, ptr(plan.rowptr), ptr(plan.col), ptr(eps),
-                                         int(negate), stream()), "sn_gin_aggregate_f32")
+        with _span("sn_gin_aggregate_f32"):
+            check(lib().sn_gin_aggregate_f32(ptr(x), ptr(out), N, F, ptr(plan.rowptr), ptr(plan.col), ptr(eps),
+                                             int(negate), stream()), "sn_gin_aggregate_f32")
     return out
 
 
@@ -135,8 +204,9 @@ def gine_aggregate(x, ea, plan: GraphPlan, eps=None):
     if ea.shape != (plan.E, x.shape[1]):
         raise ValueError("gine_aggregate: edge features must be [E, C] with C == x.shape[1]")
     out = torch.empty_like(x)
-    check(lib().sn_gine_aggregate_f32(ptr(x), ptr(ea), ptr(out), x.shape[0], x.shape[1], ptr(plan.rowptr),
-                                      ptr(plan.col), ptr(plan.eperm), ptr(eps), stream()), "sn_gine_aggregate_f32")
+    with _span("sn_gine_aggregate_f32"):
+        check(lib().sn_gine_aggregate_f32(ptr(x), ptr(ea), ptr(out), x.shape[0], x.shape[1], ptr(plan.rowptr),
+                                          ptr(plan.col), ptr(plan.eperm), ptr(eps), stream()), "sn_gine_aggregate_f32")
     return out
 
 
@@ -163,9 +233,10 @@ def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=No
         residual = _f32c(residual, "residual")
     if out is None:
         out = torch.empty(*x.shape[:-1], pl.d_out, dtype=torch.float32, device=x.device)
-    check(lib().sn_masked_linear_f32(ptr(x), pl.d_in, R, pl.d_in, ptr(pl.wp), pl.d_out, ptr(bias), ptr(nvalid),
-                                     int(K), flags, ptr(scale), ptr(shift), ptr(residual), pl.d_out, ptr(out),
-                                     pl.d_out, stream()), "sn_masked_linear_f32")
+    with _span("sn_masked_linear_f32"):
+        check(lib().sn_masked_linear_f32(ptr(x), pl.d_in, R, pl.d_in, ptr(pl.wp), pl.d_out, ptr(bias), ptr(nvalid),
+                                         int(K), flags, ptr(scale), ptr(shift), ptr(residual), pl.d_out, ptr(out),
+                                         pl.d_out, stream()), "sn_masked_linear_f32")
     return out
 
 
@@ -193,8 +264,9 @@ def masked_affine(x, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False
     flags = (EPI_RELU_PRE if relu_pre else 0) | (EPI_AFFINE if scale is not None else 0) | \
             (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0)
     out = torch.empty_like(x)
-    check(lib().sn_masked_affine_f32(ptr(x), Cc, R, Cc, ptr(nvalid), int(K), flags, ptr(scale), ptr(shift),
-                                     ptr(residual), Cc, ptr(out), Cc, stream()), "sn_masked_affine_f32")
+    with _span("sn_masked_affine_f32"):
+        check(lib().sn_masked_affine_f32(ptr(x), Cc, R, Cc, ptr(nvalid), int(K), flags, ptr(scale), ptr(shift),
+                                         ptr(residual), Cc, ptr(out), Cc, stream()), "sn_masked_affine_f32")
     return out
 
 
@@ -203,9 +275,10 @@ def masked_layernorm(x, residual, gamma, beta, eps, nvalid=None, K=0):
     x = _f32c(x, "x")
     Cc = x.shape[-1]
     out = torch.empty_like(x)
-    check(lib().sn_masked_layernorm_f32(ptr(x), ptr(residual), x.numel() // Cc, Cc, ptr(gamma), ptr(beta),
-                                        float(eps), ptr(nvalid), int(K), ptr(out), stream()),
-          "sn_masked_layernorm_f32")
+    with _span("sn_masked_layernorm_f32"):
+        check(lib().sn_masked_layernorm_f32(ptr(x), ptr(residual), x.numel() // Cc, Cc, ptr(gamma), ptr(beta),
+                                            float(eps), ptr(nvalid), int(K), ptr(out), stream()),
+              "sn_masked_layernorm_f32")
     return out
 
 
@@ -214,8 +287,9 @@ def set_attention(q, k, v, N, K, heads, nvalid=None):
     q, k, v = _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
     D = q.shape[-1]
     out = torch.empty_like(q)
-    check(lib().sn_set_attention_f32(ptr(q), ptr(k), ptr(v), N, K, heads, D // heads, ptr(nvalid), ptr(out),
-                                     stream()), "sn_set_attention_f32")
+    with _span("sn_set_attention_f32"):
+        check(lib().sn_set_attention_f32(ptr(q), ptr(k), ptr(v), N, K, heads, D // heads, ptr(nvalid), ptr(out),
+                                         stream()), "sn_set_attention_f32")
     return out
 
 
@@ -224,7 +298,8 @@ def slot_sum(x, N, K):
     x = _f32c(x, "x")
     Cc = x.shape[-1]
     out = torch.empty(N, Cc, dtype=torch.float32, device=x.device)
-    check(lib().sn_slot_sum_f32(ptr(x), N, K, Cc, ptr(out), stream()), "sn_slot_sum_f32")
+    with _span("sn_slot_sum_f32"):
+        check(lib().sn_slot_sum_f32(ptr(x), N, K, Cc, ptr(out), stream()), "sn_slot_sum_f32")
     return out
 
 
@@ -243,7 +318,8 @@ def embedding_sum(idx, tables):
     Cc = tabs[0].shape[1]
     arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs])
     out = torch.empty(R, Cc, dtype=torch.float32, device=idx.device)
-    check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, Cc, ptr(out), stream()), "sn_embedding_sum_f32")
+    with _span("sn_embedding_sum_f32"):
+        check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, Cc, ptr(out), stream()), "sn_embedding_sum_f32")
     return out
 
 
@@ -251,6 +327,21 @@ def segment_pool(x, plan: GraphPlan, mode="add"):
     require_cuda(x)
     x = _f32c(x, "x")
     out = torch.empty(plan.B, x.shape[1], dtype=torch.float32, device=x.device)
-    check(lib().sn_segment_pool_f32(ptr(x), plan.B, x.shape[1], ptr(plan.graph_ptr), 1 if mode == "mean" else 0,
-                                    ptr(out), stream()), "sn_segment_pool_f32")
+    with _span("sn_segment_pool_f32"):
+        check(lib().sn_segment_pool_f32(ptr(x), plan.B, x.shape[1], ptr(plan.graph_ptr), 1 if mode == "mean" else 0,
+                                        ptr(out), stream()), "sn_segment_pool_f32")
     return out
+
+
+# ----------------------------------------------------------------------------- roofline accounting (bench.py)
+def _roof_linear(fl, wl, host, mean_ms, per_step):
+    """All dense contractions of the layer-at-a-time path go through sn_masked_linear_f32
+    (attention's K x K part excepted): achieved = contraction flops per step / time per step in it."""
+    flops = fl["total"] - wl["nl_rho"] * 4 * sum(n * min(n, wl["k"]) ** 2 for n in host.sizes) * wl["hidden"]
+    t = mean_ms * per_step * 1e-3
+    ach = flops / t / 1e12
+    return {"kernel": "sn_masked_linear_f32 (k_linear, all launches of a step)", "bound": "mfma", "achieved": ach,
+            "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None}
+
+
+KERNEL_ROOFLINE = {"sn_masked_linear_f32": _roof_linear}
