@@ -117,6 +117,14 @@ int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const flo
                          const float* scale, const float* shift, const float* residual, int ldr,
                          float* y, int ldy, void* stream);
 
+/* Eval-mode BatchNorm1d folded to an affine (nn.BatchNorm1d.forward with running statistics,
+ * used at masked_layers.py:19, model.py:50, elements.py:64, sign_net.py:50):
+ *   scale[c] = weight[c] / sqrt(running_var[c] + eps),  shift[c] = bias[c] - running_mean[c]*scale[c]
+ * for c < C, 0 for C <= c < C_pad.  weight/bias may be NULL (affine=False). */
+int sn_bn_fold_f32(const float* weight, const float* bias, const float* running_mean,
+                   const float* running_var, float eps, int C, int C_pad, float* scale, float* shift,
+                   void* stream);
+
 /* Per-channel masked statistics for train-mode BatchNorm (MaskedBN on the compacted valid rows,
  * masked_layers.py:19; nn.BatchNorm1d model.py:50): mean[c], biased var[c] over valid rows,
  * count written to *count.  scratch: float[2*C*nblocks] (nblocks = sn_colstats_blocks(R)). */
@@ -154,6 +162,65 @@ int sn_embedding_sum_f32(const int64_t* idx, int ldi, int nf, int64_t R, const f
  * mode 0 = add, 1 = mean. */
 int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32_t* graph_ptr, int mode,
                         float* out, void* stream);
+
+/* ==========================================================================================
+ * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).
+ *
+ * Work is cut into *bins* of R activation rows that one workgroup keeps on chip for a whole
+ * stage.  A bin holds whole *units* — the sets of rows that exchange data inside the stage:
+ *   kind 0 (phi): unit = one (graph, eigenvector slot) slab, n_graph rows   (GIN aggregation)
+ *   kind 1 (rho): unit = one node, its nvalid slot rows                     (attention over slots)
+ *   kind 2 (gnn): unit = one graph, n_graph rows                            (GINE aggregation + pooling)
+ * sn_plan_bins packs units into bins (next-fit in graph order, on the device, no host sync):
+ *   bin_node[b*R + r], bin_slot[b*R + r] = node id / slot of bin row r (-1 = padding)
+ *   meta[0] = number of bins, meta[1] != 0 if some unit exceeds R rows (stage cannot run fused),
+ *   meta[2] = number of real rows.  max_bins bounds the arrays: use sn_bins_bound(rows_bound, R).
+ */
+int64_t sn_bins_bound(int64_t rows_upper_bound, int R);
+int sn_plan_bins(const int32_t* graph_ptr, int64_t B, int kmax, int kind, int R, int64_t max_bins,
+                 int32_t* bin_node, int32_t* bin_slot, int32_t* meta, void* stream);
+
+/* phi(x) + phi(-x) for every valid (node, slot) row, all L layers in one launch.
+ * Replaces the whole of GNN3d.forward called twice (sign_net.py:28-44,113 /
+ * core/sign_net.py:30-48,115): per layer GINConv aggregate (masked_layers.py:75) -> MaskedMLP
+ * (:54-64) -> mask -> MaskedBN -> ReLU -> +previous.  Activations never leave the CU between
+ * layers: the slab rows live in registers (MFMA operand layout) and are exchanged through LDS for
+ * the neighbour sums.  All per-channel vectors are zero-padded to d_pad = 16*ceil(d/16) floats;
+ * weight matrices are in sn_pack_weight_f32 order.
+ *   layer 0 takes the scalar eigenvector entry: Linear(1 -> hid0) [BN, ReLU] Linear(hid0 -> d)
+ *   with hid0 == 1 (GINESignNetPyG, core/sign_net.py:20) or hid0 == d (Alchemy, sign_net.py:20).
+ * out: [N*K, d] rows (row = node*K + slot); only valid rows are written. */
+typedef struct {
+  const float* w1p;        /* packed [d, d] */
+  const float* bn0_scale;  /* MaskedMLP.norms[0] folded */
+  const float* bn0_shift;
+  const float* w2p;        /* packed [d, d] */
+  const float* bias2;      /* may be NULL */
+  const float* bn_scale;   /* GNN3d.norms[l] folded */
+  const float* bn_shift;
+  const float* eps;        /* device scalar */
+} sn_phi_layer;
+
+#define SN_PHI_MAX_LAYERS 16
+typedef struct {
+  int d, n_layers, hid0, reserved;
+  const float* l0_w1;        /* [hid0_pad] : Linear(1 -> hid0).weight[:, 0] */
+  const float* l0_bn0_scale; /* [hid0_pad] */
+  const float* l0_bn0_shift;
+  const float* l0_w2;        /* hid0 == 1: [d_pad] = Linear(1 -> d).weight[:, 0]; else packed [d, d] */
+  const float* l0_bias2;     /* may be NULL */
+  const float* l0_bn_scale;
+  const float* l0_bn_shift;
+  const float* l0_eps;
+  sn_phi_layer layers[SN_PHI_MAX_LAYERS - 1]; /* layers 1 .. n_layers-1 */
+} sn_phi_params;
+
+#define SN_PHI_BIN_ROWS 64
+int sn_phi_fused_f32(const sn_phi_params* params /* host struct of device pointers */,
+                     const float* eigen_vectors, const int32_t* graph_ptr, const int32_t* node_graph,
+                     const int64_t* evoff, const int32_t* rowptr, const int32_t* col,
+                     const int32_t* bin_node, const int32_t* bin_slot, const int32_t* meta,
+                     int64_t max_bins, int K, float* out, void* stream);
 
 #ifdef __cplusplus
 }

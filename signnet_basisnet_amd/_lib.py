@@ -29,7 +29,10 @@ SIGNATURES = {
     "sn_gin_aggregate_slab_f32": [_p, _p, _l, _i, _l, _p, _p, _p, _p, _i, _p],
     "sn_gine_aggregate_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p],
     "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
+    "sn_bn_fold_f32": [_p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "sn_colstats_blocks": [_l],
+    "sn_plan_bins": [_p, _l, _i, _i, _i, _l, _p, _p, _p, _p],
+    "sn_phi_fused_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p],
     "sn_masked_colstats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "sn_masked_affine_f32": [_p, _i, _l, _i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     "sn_masked_layernorm_f32": [_p, _p, _l, _i, _p, _p, _f, _p, _i, _p, _p],
@@ -60,6 +63,8 @@ def lib():
         L.sn_last_error.restype = C.c_char_p
         L.sn_packed_weight_floats.argtypes = [_i, _i]
         L.sn_packed_weight_floats.restype = C.c_int64
+        L.sn_bins_bound.argtypes = [_l, _i]
+        L.sn_bins_bound.restype = C.c_int64
         if L.sn_version() != 1:
             raise RuntimeError("libsignnet_hip.so ABI version mismatch")
         _lib = L

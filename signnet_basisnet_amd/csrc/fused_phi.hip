@@ -1,0 +1,334 @@
+// fused_phi.hip — phi(x) + phi(-x) for every valid (node, eigenvector slot) row, all layers in ONE launch.
+//
+// Replaces GNN3d.forward applied to x and -x (Alchemy/sign_net/sign_net.py:28-44,113;
+// GINESignNetPyG/core/sign_net.py:30-48,115) in eval mode.  Why one kernel: with BatchNorm folded to
+// an affine, every op of every phi layer is local to one (graph, slot, sign) slab of n_graph <= 64
+// rows, so the [rows, d] activations never need to touch HBM between layers.
+//
+// Mapping (SN_PHI_BIN_ROWS = 64 rows per workgroup, 4 waves):
+//   * a bin (sn_plan_bins kind 0) holds whole slabs; wave w owns bin rows [16w, 16w+16) for BOTH signs;
+//   * a row tile lives in registers in the MFMA operand layout of common.hpp
+//     (lane = (row = l&15, g = l>>4) holds channels 16*kk + 4*g + t), so the accumulators of one GEMM
+//     are directly the operand of the next — no LDS round trip between the two Linears of a MaskedMLP;
+//   * the GIN neighbour sum goes through LDS: every wave writes its rows (both signs) to X[sign][row][ch],
+//     one barrier, then each lane gathers its CSR neighbours' rows (ds_read_b128) — the reference's
+//     [K,E,d] gather + scatter_add (masked_layers.py:75) becomes LDS traffic; the residual `+ previous_x`
+//     (sign_net.py:42) is re-read from the same LDS image;
+//   * weights are streamed from L2 in pre-packed fragment order (1 KiB coalesced per wave-load), each
+//     fragment feeding 8 MFMAs (4 k-steps x 2 signs).
+// Bound: fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s chip peak); algorithmic flops per valid row:
+// 2 signs * (L-1) layers * 2 GEMMs * 2*d*d.
+#include "common.hpp"
+
+namespace sn {
+
+constexpr int PHI_R = SN_PHI_BIN_ROWS;  // rows per bin / workgroup
+constexpr int PHI_WAVES = PHI_R / 16;
+
+struct PhiStruct {
+  const float* ev;
+  const int32_t* graph_ptr;
+  const int32_t* node_graph;
+  const int64_t* evoff;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const int32_t* bin_node;
+  const int32_t* bin_slot;
+  const int32_t* meta;
+  int64_t max_bins;
+  int K;
+  float* out;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  return f32x4{t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ f32x4 lds_ld4(const float* p) {
+  float4 t = *reinterpret_cast<const float4*>(p);
+  return f32x4{t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ void lds_st4(float* p, f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Weight fragments are fetched with buffer loads: descriptor in SGPRs (wave-uniform base), one VGPR of
+// per-lane offset (lane*16) and an immediate/SGPR fragment offset — no 64-bit address VGPR per fragment.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* p, unsigned bytes) {
+  unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 wfrag(__amdgpu_buffer_rsrc_t rs, int voff, int frag) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, frag * 1024, 0);
+  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
+// out{P,M}[ot] = W (packed) x in{P,M}  — both signs share every weight fragment.
+// The weight fragments of output tile ot+1 are fetched (NT x 1 KiB coalesced wave-loads from L2) while the
+// 8*NT MFMAs of tile ot run; sched_barrier keeps the compiler from hoisting all NT*NT loads to the top
+// (which spills: 64 fragments = 256 VGPRs at NT = 8).
+template <int NT>
+__device__ __forceinline__ void gemm_pm(const float* __restrict__ wp, const f32x4 (&inP)[NT], const f32x4 (&inM)[NT],
+                                        f32x4 (&oP)[NT], f32x4 (&oM)[NT], int lane) {
+  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, NT * NT * 1024);
+  const int voff = lane * 16;
+  float4 wc[NT], wn[NT];
+#pragma unroll
+  for (int kk = 0; kk < NT; ++kk) wc[kk] = wfrag(rs, voff, kk);
+#pragma unroll
+  for (int ot = 0; ot < NT; ++ot) {
+    if (ot + 1 < NT) {
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) wn[kk] = wfrag(rs, voff, (ot + 1) * NT + kk);
+    }
+    f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NT; ++kk) {
+      const float4 w = wc[kk];
+      aP = mfma16(w.x, inP[kk][0], aP);
+      aM = mfma16(w.x, inM[kk][0], aM);
+      aP = mfma16(w.y, inP[kk][1], aP);
+      aM = mfma16(w.y, inM[kk][1], aM);
+      aP = mfma16(w.z, inP[kk][2], aP);
+      aM = mfma16(w.z, inM[kk][2], aM);
+      aP = mfma16(w.w, inP[kk][3], aP);
+      aM = mfma16(w.w, inM[kk][3], aM);
+    }
+    oP[ot] = aP;
+    oM[ot] = aM;
+    __builtin_amdgcn_sched_barrier(0);
+    if (ot + 1 < NT) {
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) wc[kk] = wn[kk];
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_params P) {
+  constexpr int D = 16 * NT;
+  constexpr int LD = D + 4;  // +4 floats: conflict-free ds_write_b128 of 8 consecutive rows
+  extern __shared__ __align__(16) float lds[];
+  float* X = lds;                         // [2][PHI_R][LD]
+  float* xs = lds + 2 * PHI_R * LD;       // [PHI_R] scalar eigenvector entries (layer 0)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = wave * 16 + (lane & 15), g = lane >> 4;
+  const int nbins = S.meta[0];
+  if (S.meta[1] != 0) return;  // a unit does not fit a bin: the host falls back to the layer path
+
+  for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
+    // ---------------------------------------------------------------- my row
+    const int node = S.bin_node[(int64_t)bin * PHI_R + r];
+    const int slot = S.bin_slot[(int64_t)bin * PHI_R + r];
+    const bool valid = node >= 0;
+    int gs = 0, row0 = 0, e_lo = 0, e_hi = 0;
+    float xval = 0.f;
+    if (valid) {
+      const int gi = S.node_graph[node];
+      gs = S.graph_ptr[gi];
+      const int n = S.graph_ptr[gi + 1] - gs;
+      const int li = node - gs;
+      row0 = r - li;
+      e_lo = S.rowptr[node];
+      e_hi = S.rowptr[node + 1];
+      xval = S.ev[S.evoff[gi] + (int64_t)li * n + slot];
+    }
+    float* XP = X + r * LD;                 // my row, sign +
+    float* XM = X + (PHI_R + r) * LD;       // my row, sign -
+    // ---------------------------------------------------------------- layer 0 (scalar input)
+    if (g == 0) xs[r] = xval;
+    __syncthreads();
+    float a0 = 0.f;
+    for (int e = e_lo; e < e_hi; ++e) a0 += xs[row0 + S.col[e] - gs];
+    {
+#pragma clang fp contract(off)
+      const float sc = 1.f + *P.l0_eps;
+      const float self = xval * sc;
+      a0 = a0 + self;
+    }
+    __syncthreads();  // xs may be rewritten by the next bin
+    f32x4 inP[NT], inM[NT], oP[NT], oM[NT];
+    if (P.hid0 == 1) {
+      // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
+      const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
+      const float tP = fmaxf((a0 * w1) * s0 + h0, 0.f);
+      const float tM = fmaxf(((-a0) * w1) * s0 + h0, 0.f);
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 w2 = ld4(P.l0_w2 + c), s1 = ld4(P.l0_bn_scale + c), h1 = ld4(P.l0_bn_shift + c);
+        f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
+        if (P.l0_bias2) b2 = ld4(P.l0_bias2 + c);
+        inP[kk] = relu4((tP * w2 + b2) * s1 + h1);
+        inM[kk] = relu4((tM * w2 + b2) * s1 + h1);
+      }
+    } else {
+      // Linear(1->d) . BN . ReLU . Linear(d->d) [+b] . BN . ReLU           (Alchemy sign_net.py:20)
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 w1 = ld4(P.l0_w1 + c), s0 = ld4(P.l0_bn0_scale + c), h0 = ld4(P.l0_bn0_shift + c);
+        oP[kk] = relu4((a0 * w1) * s0 + h0);
+        oM[kk] = relu4(((-a0) * w1) * s0 + h0);
+      }
+      gemm_pm<NT>(P.l0_w2, oP, oM, inP, inM, lane);
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 s1 = ld4(P.l0_bn_scale + c), h1 = ld4(P.l0_bn_shift + c);
+        f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
+        if (P.l0_bias2) b2 = ld4(P.l0_bias2 + c);
+        inP[kk] = relu4((inP[kk] + b2) * s1 + h1);
+        inM[kk] = relu4((inM[kk] + b2) * s1 + h1);
+      }
+    }
+    if (!valid) {
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) { inP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; inM[kk] = inP[kk]; }
+    }
+    // ---------------------------------------------------------------- layers 1 .. L-1
+    for (int l = 1; l < P.n_layers; ++l) {
+      const sn_phi_layer& Lp = P.layers[l - 1];
+      // publish x_l (both signs) for the neighbour sums and the residual
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        lds_st4(XP + 16 * kk + 4 * g, inP[kk]);
+        lds_st4(XM + 16 * kk + 4 * g, inM[kk]);
+      }
+      __syncthreads();
+      // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) { oP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; oM[kk] = oP[kk]; }
+      for (int e = e_lo; e < e_hi; ++e) {
+        const int nb = row0 + S.col[e] - gs;
+        const float* nP = X + nb * LD + 4 * g;
+        const float* nM = nP + PHI_R * LD;
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) {
+          oP[kk] += lds_ld4(nP + 16 * kk);
+          oM[kk] += lds_ld4(nM + 16 * kk);
+        }
+      }
+      {
+#pragma clang fp contract(off)
+        const float sc = 1.f + *Lp.eps;
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) {
+          const f32x4 sP = inP[kk] * sc, sM = inM[kk] * sc;
+          inP[kk] = oP[kk] + sP;
+          inM[kk] = oM[kk] + sM;
+        }
+      }
+      // MaskedMLP: Linear . BN . ReLU . Linear [+b]
+      gemm_pm<NT>(Lp.w1p, inP, inM, oP, oM, lane);
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 s0 = ld4(Lp.bn0_scale + c), h0 = ld4(Lp.bn0_shift + c);
+        oP[kk] = relu4(oP[kk] * s0 + h0);
+        oM[kk] = relu4(oM[kk] * s0 + h0);
+      }
+      gemm_pm<NT>(Lp.w2p, oP, oM, inP, inM, lane);
+      // GNN3d: mask . BN . ReLU . + previous_x
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 s1 = ld4(Lp.bn_scale + c), h1 = ld4(Lp.bn_shift + c);
+        f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
+        if (Lp.bias2) b2 = ld4(Lp.bias2 + c);
+        inP[kk] = relu4((inP[kk] + b2) * s1 + h1) + lds_ld4(XP + c);
+        inM[kk] = relu4((inM[kk] + b2) * s1 + h1) + lds_ld4(XM + c);
+      }
+      if (!valid) {
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) { inP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; inM[kk] = inP[kk]; }
+      }
+      __syncthreads();  // everyone is done reading X before it is overwritten
+    }
+    // ---------------------------------------------------------------- phi(x) + phi(-x) -> out[node*K + slot, :]
+    if (valid) {
+      float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 v = inP[kk] + inM[kk];
+        if ((P.d & 3) == 0) {
+          if (c < P.d) *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (c + t < P.d) orow[c + t] = v[t];
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
+  constexpr int LD = 16 * NT + 4;
+  const size_t lds = (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float);
+  static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
+  if (cus == 0) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_phi_fused<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return fail(SN_ERR_LAUNCH, "sn_phi_fused_f32: cannot raise the dynamic LDS limit to %zu", lds);
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  int64_t grid = S.max_bins < (int64_t)2 * cus ? S.max_bins : (int64_t)2 * cus;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_phi_fused<NT>), dim3((unsigned)grid), dim3(PHI_R * 4), lds, st, S, P);
+  return SN_OK;
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_vectors, const int32_t* graph_ptr,
+                                const int32_t* node_graph, const int64_t* evoff, const int32_t* rowptr,
+                                const int32_t* col, const int32_t* bin_node, const int32_t* bin_slot,
+                                const int32_t* meta, int64_t max_bins, int K, float* out, void* stream) {
+  SN_REQUIRE(params && eigen_vectors && graph_ptr && node_graph && evoff && rowptr && bin_node && bin_slot && meta && out,
+             "sn_phi_fused_f32: null pointer");
+  const sn_phi_params& P = *params;
+  SN_REQUIRE(P.d > 0 && P.d <= 128, "sn_phi_fused_f32: hidden width %d not in (0, 128]", P.d);
+  SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS, "sn_phi_fused_f32: %d layers unsupported", P.n_layers);
+  SN_REQUIRE(P.hid0 == 1 || P.hid0 == P.d, "sn_phi_fused_f32: first hidden width must be 1 or d");
+  SN_REQUIRE(P.l0_w1 && P.l0_bn0_scale && P.l0_bn0_shift && P.l0_w2 && P.l0_bn_scale && P.l0_bn_shift && P.l0_eps,
+             "sn_phi_fused_f32: layer-0 parameters missing");
+  for (int l = 1; l < P.n_layers; ++l) {
+    const sn_phi_layer& L = P.layers[l - 1];
+    SN_REQUIRE(L.w1p && L.bn0_scale && L.bn0_shift && L.w2p && L.bn_scale && L.bn_shift && L.eps,
+               "sn_phi_fused_f32: layer %d parameters missing", l);
+  }
+  SN_REQUIRE(K > 0 && max_bins >= 0, "sn_phi_fused_f32: bad K / max_bins");
+  if (max_bins == 0) return SN_OK;
+  PhiStruct S{eigen_vectors, graph_ptr, node_graph, evoff, rowptr, col, bin_node, bin_slot, meta, max_bins, K, out};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = SN_OK;
+  switch ((P.d + 15) / 16) {
+    case 1: rc = launch_phi<1>(S, P, st); break;
+    case 2: rc = launch_phi<2>(S, P, st); break;
+    case 3: rc = launch_phi<3>(S, P, st); break;
+    case 4: rc = launch_phi<4>(S, P, st); break;
+    case 5: rc = launch_phi<5>(S, P, st); break;
+    case 6: rc = launch_phi<6>(S, P, st); break;
+    case 7: rc = launch_phi<7>(S, P, st); break;
+    default: rc = launch_phi<8>(S, P, st); break;
+  }
+  if (rc != SN_OK) return rc;
+  SN_CHECK_LAUNCH("sn_phi_fused_f32");
+  return SN_OK;
+}

@@ -20,6 +20,22 @@ __global__ void k_pack_weight(const float* __restrict__ W, int d_out, int d_in, 
   Wp[idx] = (o < d_out && k < d_in) ? W[(int64_t)o * ldw + k] : 0.f;
 }
 
+// ============================================================================ BatchNorm(eval) folding
+// scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale; zero padded to Cp.
+__global__ void k_bn_fold(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ rm,
+                          const float* __restrict__ rv, float eps, int C, int Cp, float* __restrict__ scale,
+                          float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  float sc = 0.f, sh = 0.f;
+  if (c < C) {
+    sc = (w ? w[c] : 1.f) / sqrtf(rv[c] + eps);
+    sh = (b ? b[c] : 0.f) - rm[c] * sc;
+  }
+  scale[c] = sc;
+  shift[c] = sh;
+}
+
 // ============================================================================ masked linear
 struct LinArgs {
   const float* x; int ldx; int64_t R; int d_in;
@@ -475,6 +491,16 @@ extern "C" int sn_pack_weight_f32(const float* W, int d_out, int d_in, int ldw, 
   hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, d_out,
                      d_in, ldw, nto, nti, Wp);
   SN_CHECK_LAUNCH("sn_pack_weight_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_bn_fold_f32(const float* weight, const float* bias, const float* running_mean,
+                              const float* running_var, float eps, int C, int C_pad, float* scale, float* shift,
+                              void* stream) {
+  SN_REQUIRE(running_mean && running_var && scale && shift && C > 0 && C_pad >= C, "sn_bn_fold_f32: bad arguments");
+  hipLaunchKernelGGL(k_bn_fold, dim3((unsigned)cdiv(C_pad, 128)), dim3(128), 0, (hipStream_t)stream, weight, bias,
+                     running_mean, running_var, eps, C, C_pad, scale, shift);
+  SN_CHECK_LAUNCH("sn_bn_fold_f32");
   return SN_OK;
 }
 

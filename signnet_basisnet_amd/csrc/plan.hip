@@ -185,6 +185,92 @@ __global__ void k_pack_eig(const float* __restrict__ ev, const float* __restrict
   if (s0) s0[idx] = s;
 }
 
+
+// ---------------------------------------------------------------------------- bins for the fused stages
+// Units of graph g: kind 0 -> K_g slabs of n_g rows; kind 1 -> n_g nodes of K_g rows; kind 2 -> 1 graph of n_g rows
+// (K_g = min(n_g, kmax)).  Next-fit packing in graph order into bins of R rows.
+__device__ __forceinline__ void unit_shape(int kind, int n, int kg, int& usize, int& ucount) {
+  if (kind == 0) { usize = n; ucount = kg; }
+  else if (kind == 1) { usize = kg; ucount = n; }
+  else { usize = n; ucount = n > 0 ? 1 : 0; }
+}
+
+__global__ __launch_bounds__(1024) void k_plan_bins(const int32_t* __restrict__ graph_ptr, int64_t B, int kmax,
+                                                    int kind, int R, int64_t max_bins,
+                                                    int32_t* __restrict__ bin_node, int32_t* __restrict__ bin_slot,
+                                                    int32_t* __restrict__ meta) {
+  extern __shared__ int sh[];   // [B] bin0, [B] fill0  (start state of every graph)
+  int* bin0 = sh;
+  int* fill0 = sh + B;
+  __shared__ int s_err, s_nbins, s_rows;
+  const int t = threadIdx.x, T = blockDim.x;
+  if (t == 0) {
+    int bin = 0, fill = 0, err = 0, rows = 0;
+    for (int64_t g = 0; g < B; ++g) {
+      int n = graph_ptr[g + 1] - graph_ptr[g];
+      int kg = (kmax > 0 && n > kmax) ? kmax : n;
+      int us, uc;
+      unit_shape(kind, n, kg, us, uc);
+      bin0[g] = bin;
+      fill0[g] = fill;
+      if (us <= 0 || uc <= 0) continue;
+      if (us > R) { err = 1; continue; }
+      rows += us * uc;
+      int a = (R - fill) / us;
+      if (a > uc) a = uc;
+      fill += a * us;
+      int rem = uc - a;
+      if (rem > 0) {
+        int per = R / us;
+        int nb = (rem + per - 1) / per;
+        bin += nb;
+        fill = (rem - (nb - 1) * per) * us;
+      }
+    }
+    s_err = err;
+    s_nbins = (fill > 0 || bin > 0) ? bin + (fill > 0 ? 1 : 0) : 0;
+    // `bin` is the index of the currently open bin; it is counted once it holds rows
+    if (fill == 0 && bin > 0) s_nbins = bin;  // cannot happen (a new bin is opened only to hold a unit) — kept for safety
+    s_rows = rows;
+  }
+  __syncthreads();
+  const int nbins = s_nbins;
+  if (t == 0) {
+    meta[0] = nbins;
+    meta[1] = s_err | (nbins > max_bins ? 2 : 0);
+    meta[2] = s_rows;
+  }
+  if (nbins > max_bins) return;
+  // padding rows = -1
+  for (int64_t i = t; i < (int64_t)nbins * R; i += T) { bin_node[i] = -1; bin_slot[i] = -1; }
+  __syncthreads();
+  // expansion: one thread per (graph, unit, row) — loop graphs, spread (unit,row) over threads
+  for (int64_t g = 0; g < B; ++g) {
+    const int gs = graph_ptr[g];
+    const int n = graph_ptr[g + 1] - gs;
+    const int kg = (kmax > 0 && n > kmax) ? kmax : n;
+    int us, uc;
+    unit_shape(kind, n, kg, us, uc);
+    if (us <= 0 || uc <= 0 || us > R) continue;
+    int a = (R - fill0[g]) / us;
+    if (a > uc) a = uc;
+    const int per = R / us;
+    for (int i = t; i < us * uc; i += T) {
+      int u = i / us, r = i - u * us;
+      int bin, row0;
+      if (u < a) { bin = bin0[g]; row0 = fill0[g] + u * us; }
+      else { int v = u - a; bin = bin0[g] + 1 + v / per; row0 = (v % per) * us; }
+      int node, slot;
+      if (kind == 0) { node = gs + r; slot = u; }
+      else if (kind == 1) { node = gs + u; slot = r; }
+      else { node = gs + r; slot = 0; }
+      int64_t o = (int64_t)bin * R + row0 + r;
+      bin_node[o] = node;
+      bin_slot[o] = slot;
+    }
+  }
+}
+
 }  // namespace sn
 
 using namespace sn;
@@ -231,5 +317,23 @@ extern "C" int sn_pack_eig_f32(const float* eigen_vectors, const float* eigen_va
   hipLaunchKernelGGL(k_pack_eig, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, (hipStream_t)stream,
                      eigen_vectors, eigen_values, graph_ptr, node_graph, nvalid, evoff, N, K, x0, s0);
   SN_CHECK_LAUNCH("sn_pack_eig_f32");
+  return SN_OK;
+}
+
+extern "C" int64_t sn_bins_bound(int64_t rows_upper_bound, int R) {
+  // next-fit: two consecutive bins always hold more than R rows together
+  if (R <= 0) return 0;
+  return 2 * cdiv(rows_upper_bound > 0 ? rows_upper_bound : 0, R) + 2;
+}
+
+extern "C" int sn_plan_bins(const int32_t* graph_ptr, int64_t B, int kmax, int kind, int R, int64_t max_bins,
+                            int32_t* bin_node, int32_t* bin_slot, int32_t* meta, void* stream) {
+  SN_REQUIRE(graph_ptr && bin_node && bin_slot && meta && B >= 0 && R > 0 && max_bins >= 0 && kind >= 0 && kind <= 2,
+             "sn_plan_bins: bad arguments");
+  SN_REQUIRE(B <= 16000, "sn_plan_bins: B=%lld graphs exceed the single-workgroup planner (16000)", (long long)B);
+  size_t lds = (size_t)2 * (B > 0 ? B : 1) * sizeof(int);
+  hipLaunchKernelGGL(k_plan_bins, dim3(1), dim3(1024), lds, (hipStream_t)stream, graph_ptr, B, kmax, kind, R, max_bins,
+                     bin_node, bin_slot, meta);
+  SN_CHECK_LAUNCH("sn_plan_bins");
   return SN_OK;
 }

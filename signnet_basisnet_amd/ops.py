@@ -154,6 +154,54 @@ def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: 
     return x0, s0
 
 
+PHI_BIN_ROWS = 64     # SN_PHI_BIN_ROWS
+
+
+@dataclass
+class Bins:
+    kind: int
+    R: int
+    max_bins: int
+    node: torch.Tensor   # int32 [max_bins*R]
+    slot: torch.Tensor   # int32 [max_bins*R]
+    meta: torch.Tensor   # int32 [4]: nbins, error flag, rows
+
+
+def plan_bins(plan: GraphPlan, kind: int, R: int, rows_upper_bound: int) -> Bins:
+    """Pack the stage's units (kind 0: (graph,slot) slabs; 1: nodes; 2: graphs) into bins of R rows."""
+    max_bins = int(lib().sn_bins_bound(int(rows_upper_bound), R))
+    dev = plan.graph_ptr.device
+    arena = torch.empty(2 * max_bins * R + 4, dtype=torch.int32, device=dev)
+    node, slot, meta = arena[:max_bins * R], arena[max_bins * R:2 * max_bins * R], arena[2 * max_bins * R:]
+    with _span("sn_plan_bins"):
+        check(lib().sn_plan_bins(ptr(plan.graph_ptr), plan.B, plan.kmax, kind, R, max_bins, ptr(node), ptr(slot),
+                                 ptr(meta), stream()), "sn_plan_bins")
+    return Bins(kind, R, max_bins, node, slot, meta)
+
+
+def bn_fold(bn, c_pad=None):
+    """Eval-mode nn.BatchNorm1d -> (scale, shift), zero padded to c_pad channels."""
+    Cc = bn.num_features
+    cp = Cc if c_pad is None else int(c_pad)
+    dev = bn.running_mean.device
+    require_cuda(bn.running_mean)
+    scale = torch.empty(cp, dtype=torch.float32, device=dev)
+    shift = torch.empty(cp, dtype=torch.float32, device=dev)
+    w = bn.weight.detach() if bn.affine else None
+    b = bn.bias.detach() if bn.affine else None
+    check(lib().sn_bn_fold_f32(ptr(w), ptr(b), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps), Cc, cp,
+                               ptr(scale), ptr(shift), stream()), "sn_bn_fold_f32")
+    return scale, shift
+
+
+def pad_vec(v, c_pad):
+    """Zero-pad a per-channel vector to c_pad floats (a copy, no arithmetic)."""
+    v = v.detach().reshape(-1)
+    out = torch.zeros(c_pad, dtype=torch.float32, device=v.device)
+    out[:v.numel()].copy_(v)
+    return out
+
+
 def packed_floats(d_out: int, d_in: int) -> int:
     return int(lib().sn_packed_weight_floats(d_out, d_in))
 

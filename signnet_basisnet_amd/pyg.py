@@ -15,7 +15,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fused, ops
 
 N_HEAD = 4          # TransformerEncoderLayer(nhid, n_head=4): sign_net.py:50 / core/sign_net.py:57
 LN_EPS = 1e-6       # masked_layers.py:25
@@ -236,10 +236,8 @@ class GNN(nn.Module):
 
 # ----------------------------------------------------------------------------- prepared (packed) parameters
 def _bn_affine(bn: nn.BatchNorm1d):
-    """Eval-mode BatchNorm as y = x*scale + shift (running statistics)."""
-    scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
-    shift = bn.bias.detach() - bn.running_mean * scale
-    return scale.contiguous(), shift.contiguous()
+    """Eval-mode BatchNorm as y = x*scale + shift (running statistics), folded on the device."""
+    return ops.bn_fold(bn)
 
 
 def _pack(lin: nn.Linear) -> ops.PackedLinear:
@@ -267,6 +265,7 @@ class SignNetGNN(nn.Module):
                         nl_signnet=nl_signnet, nl_gnn=nl_gnn)
         # nl_rho is fixed by the reference constructors (sign_net.py:123 ignores the argument)
         self.nl_rho = 4 if variant == "alchemy" else 1
+        self.use_fused = True       # whole-stage kernels (eval mode); False = layer-at-a-time kernels only
         self.sign_net = SignNet(n_hid, nl_signnet, self.nl_rho, variant, ignore_eigval)
         self.gnn = GNN(node_feat, edge_feat, n_hid, n_out, nl_gnn, variant)
         self._prep = None
@@ -297,6 +296,8 @@ class SignNetGNN(nn.Module):
     def _prepare(self):
         P = {}
         sn, g = self.sign_net, self.gnn
+        d = self.cfg["n_hid"]
+        P["phi_fused"] = fused.PhiPlan(sn.phi) if (self.use_fused and d <= 128 and len(sn.phi.convs) <= 16) else None
         P["phi"] = []
         for conv, norm in zip(sn.phi.convs, sn.phi.norms):
             P["phi"].append(dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0].bn),
@@ -353,18 +354,28 @@ class SignNetGNN(nn.Module):
         stages = {}
 
         # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)
-        phis = []
-        for sign in (0, 1):
-            x, prev = x0, None
-            for l, L in enumerate(P["phi"]):
-                a = ops.gin_aggregate(x.view(N, -1), plan, L["eps"], negate=(sign == 1 and l == 0))
-                h = ops.masked_linear(a.view(N * K, -1), L["l0"], nv, K, scale=L["bn0"][0], shift=L["bn0"][1], relu=True)
-                x = ops.masked_linear(h, L["l1"], nv, K, scale=L["bn"][0], shift=L["bn"][1], relu=True, residual=prev)
-                prev = x
-            phis.append(x)
-        x = ops.masked_affine(phis[0], nv, K, residual=phis[1])          # phi(x) + phi(-x)
+        phis = None
+        if P["phi_fused"] is not None and not return_stages:
+            rows_ub = min(N * K, data.eigen_vectors.numel())
+            bins = ops.plan_bins(plan, 0, ops.PHI_BIN_ROWS, rows_ub)
+            x = P["phi_fused"].run(plan, bins, data.eigen_vectors, K).view(N * K, d)
+        else:
+            phis = []
+            for sign in (0, 1):
+                x, prev = x0, None
+                for l, L in enumerate(P["phi"]):
+                    a = ops.gin_aggregate(x.view(N, -1), plan, L["eps"], negate=(sign == 1 and l == 0))
+                    h = ops.masked_linear(a.view(N * K, -1), L["l0"], nv, K, scale=L["bn0"][0], shift=L["bn0"][1], relu=True)
+                    x = ops.masked_linear(h, L["l1"], nv, K, scale=L["bn"][0], shift=L["bn"][1], relu=True, residual=prev)
+                    prev = x
+                phis.append(x)
+            x = ops.masked_affine(phis[0], nv, K, residual=phis[1])          # phi(x) + phi(-x)
         if return_stages:
-            stages.update(phi_plus=phis[0].view(N, K, d), phi_minus=phis[1].view(N, K, d))
+            stages.update(phi_plus=phis[0].view(N, K, d), phi_minus=phis[1].view(N, K, d), phi=x.view(N, K, d))
+            if P["phi_fused"] is not None:      # cross-check target for the fused kernel
+                bins = ops.plan_bins(plan, 0, ops.PHI_BIN_ROWS, min(N * K, data.eigen_vectors.numel()))
+                stages["phi_fused"] = P["phi_fused"].run(plan, bins, data.eigen_vectors, K)
+                stages["phi_bins_meta"] = bins.meta
         # ---- rho                    (SetTransformer.forward, sign_net.py:60-72)
         if want_vals:
             E_ = P["eig"]
