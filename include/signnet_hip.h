@@ -52,13 +52,23 @@ int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz);
  *   evoff[B+1]      prefix of n_b^2   (offset of graph b's eigenvector block, int64)
  *   rowptr[N+1], col[E] (source node of each in-edge), eperm[E] (edge id, for edge_attr)
  *     — in-edges of a node are ordered by edge id (deterministic summation order)
- *   status[4]       status[0] != 0 -> malformed batch (unsorted batch, edge across graphs, ...)
- * scratch: int32[N + 8].
+ *   status[4]       status[0] != 0 -> malformed batch (unsorted batch, edge across graphs, ...);
+ *                   status[1] = max nodes per graph, status[2] = max in-degree
+ *   bins[3] / bins_meta[12]  work bins of the fused stages (may be NULL) — see "Fused stages" below
+ * scratch: int32[4*ceil(N/4) + 6*B + 8].  Five launches, no host synchronisation.
  */
+typedef struct {
+  int R;            /* rows per bin */
+  int64_t max_bins; /* capacity of node/slot in bins: use sn_bins_bound(rows_upper_bound, R) */
+  int32_t* node;    /* [max_bins*R] node id of each bin row, -1 = padding; NULL = kind not requested */
+  int32_t* slot;    /* [max_bins*R] eigenvector slot of each bin row */
+} sn_bins_out;
+
 int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index, int64_t E,
                   int kmax, int32_t* graph_ptr, int32_t* node_graph, int32_t* nvalid, int64_t* evoff,
-                  int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* status, int32_t* scratch,
-                  void* stream);
+                  int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* status,
+                  const sn_bins_out* bins /* [3] or NULL */, int32_t* bins_meta /* [12] */,
+                  int32_t* scratch, void* stream);
 
 /* Eigen-data packing.  Replaces to_dense_list_EVD (transform.py:52-61): x0[node, j] = V_b[local, j]
  * and s0[node, j] = D_b[j] for j < nvalid[node], else 0.  K = slots per node in the output. */
@@ -171,14 +181,12 @@ int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32_t* graph_p
  *   kind 0 (phi): unit = one (graph, eigenvector slot) slab, n_graph rows   (GIN aggregation)
  *   kind 1 (rho): unit = one node, its nvalid slot rows                     (attention over slots)
  *   kind 2 (gnn): unit = one graph, n_graph rows                            (GINE aggregation + pooling)
- * sn_plan_bins packs units into bins (next-fit in graph order, on the device, no host sync):
- *   bin_node[b*R + r], bin_slot[b*R + r] = node id / slot of bin row r (-1 = padding)
- *   meta[0] = number of bins, meta[1] != 0 if some unit exceeds R rows (stage cannot run fused),
- *   meta[2] = number of real rows.  max_bins bounds the arrays: use sn_bins_bound(rows_bound, R).
+ * sn_batch_plan packs the units into bins (next-fit in graph order, on the device, no host sync):
+ *   bins[kind].node[b*R + r], .slot[b*R + r] = node id / slot of bin row r (-1 = padding)
+ *   bins_meta[4*kind + 0] = number of bins, [+1] != 0 if some unit exceeds R rows (the stage cannot
+ *   run fused) or the bins overflow max_bins, [+2] = number of real rows, [+3] = R.
  */
 int64_t sn_bins_bound(int64_t rows_upper_bound, int R);
-int sn_plan_bins(const int32_t* graph_ptr, int64_t B, int kmax, int kind, int R, int64_t max_bins,
-                 int32_t* bin_node, int32_t* bin_slot, int32_t* meta, void* stream);
 
 /* phi(x) + phi(-x) for every valid (node, slot) row, all L layers in one launch.
  * Replaces the whole of GNN3d.forward called twice (sign_net.py:28-44,113 /

@@ -22,7 +22,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "sn_version": [],
     "sn_device_info": [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
-    "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_pack_eig_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
     "sn_pack_weight_f32": [_p, _i, _i, _i, _p, _p],
     "sn_gin_aggregate_f32": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
@@ -31,7 +31,6 @@ SIGNATURES = {
     "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     "sn_bn_fold_f32": [_p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "sn_colstats_blocks": [_l],
-    "sn_plan_bins": [_p, _l, _i, _i, _i, _l, _p, _p, _p, _p],
     "sn_phi_fused_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p],
     "sn_masked_colstats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "sn_masked_affine_f32": [_p, _i, _l, _i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],

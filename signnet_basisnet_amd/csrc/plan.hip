@@ -10,47 +10,125 @@ namespace sn {
 enum { ST_ERR = 0, ST_NMAX = 1, ST_DEGMAX = 2 };
 enum { ERR_UNSORTED = 1, ERR_GRAPH_ID = 2, ERR_EDGE_RANGE = 4, ERR_EDGE_CROSS = 8 };
 
-// K1: per node — graph id, graph boundaries; zero the in-degree counters.
+struct BinsOut {           // device-side view of sn_bins_out[3]
+  int R[3];
+  long long max_bins[3];
+  int32_t* node[3];
+  int32_t* slot[3];
+};
+
+// K1: per node — graph id, graph boundaries; zero the in-degree counters and the status words; mark every
+// bin row as padding (-1).  Nothing here is read by another thread of this launch.
 __global__ void k_plan_nodes(const int64_t* __restrict__ batch, int64_t N, int64_t B,
                              int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
-                             int32_t* __restrict__ deg, int32_t* __restrict__ status) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                             int32_t* __restrict__ deg, int32_t* __restrict__ status, BinsOut bo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int k = 0; k < 3; ++k) {
+    if (!bo.node[k]) continue;
+    const int64_t tot = bo.max_bins[k] * bo.R[k];
+    for (int64_t j = i; j < tot; j += stride) { bo.node[k][j] = -1; bo.slot[k][j] = -1; }
+  }
+  if (i < 4) status[i] = 0;
   if (i == 0) graph_ptr[B] = (int32_t)N;
   if (i >= N) return;
   int64_t g = batch[i];
   deg[i] = 0;
-  if (g < 0 || g >= B) {
-    atomicOr(&status[ST_ERR], ERR_GRAPH_ID);
-    node_graph[i] = 0;
-    return;
-  }
+  if (g < 0 || g >= B) { node_graph[i] = 0; return; }   // reported by k_plan_degree
   node_graph[i] = (int32_t)g;
   int64_t gp = (i == 0) ? -1 : batch[i - 1];
-  if (gp > g) atomicOr(&status[ST_ERR], ERR_UNSORTED);
-  if (gp != g) {
+  if (gp < -1) gp = -1;
+  if (gp != g && gp < g) {
     // every graph id in (gp, g] starts here (ids in between are empty graphs)
-    for (int64_t t = (gp < 0 ? 0 : gp + 1); t <= g; ++t) graph_ptr[t] = (int32_t)i;
+    for (int64_t t = gp + 1; t <= g; ++t) graph_ptr[t] = (int32_t)i;
   }
   if (i == N - 1)
     for (int64_t t = g + 1; t < B; ++t) graph_ptr[t] = (int32_t)N;
 }
 
-// K2: per edge — validate, count in-degree.
-__global__ void k_plan_degree(const int64_t* __restrict__ ei, int64_t E, int64_t N,
-                              const int32_t* __restrict__ node_graph, int32_t* __restrict__ deg,
-                              int32_t* __restrict__ status) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  int64_t s = ei[e], d = ei[E + e];
+// K2: validation (per node and per edge) and in-degree counting.
+__global__ void k_plan_degree(const int64_t* __restrict__ batch, const int64_t* __restrict__ ei, int64_t E,
+                              int64_t N, int64_t B, int32_t* __restrict__ deg, int32_t* __restrict__ status) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < N) {
+    int64_t g = batch[t];
+    if (g < 0 || g >= B) atomicOr(&status[ST_ERR], ERR_GRAPH_ID);
+    if (t > 0 && batch[t - 1] > g) atomicOr(&status[ST_ERR], ERR_UNSORTED);
+  }
+  if (t >= E) return;
+  int64_t s = ei[t], d = ei[E + t];
   if (s < 0 || s >= N || d < 0 || d >= N) {
     atomicOr(&status[ST_ERR], ERR_EDGE_RANGE);
     return;
   }
-  if (node_graph[s] != node_graph[d]) atomicOr(&status[ST_ERR], ERR_EDGE_CROSS);
+  if (batch[s] != batch[d]) atomicOr(&status[ST_ERR], ERR_EDGE_CROSS);
   atomicAdd(&deg[d], 1);
 }
 
-// K3: one workgroup — exclusive scans: deg -> rowptr (and cursor copy), n_b^2 -> evoff; nvalid; maxima.
+// Units of graph g: kind 0 -> K_g slabs of n_g rows; kind 1 -> n_g nodes of K_g rows; kind 2 -> 1 graph of n_g rows
+// (K_g = min(n_g, kmax)).  Next-fit packing in graph order into bins of R rows.
+__device__ __forceinline__ void unit_shape(int kind, int n, int kg, int& usize, int& ucount) {
+  if (kind == 0) { usize = n; ucount = kg; }
+  else if (kind == 1) { usize = kg; ucount = n; }
+  else { usize = n; ucount = n > 0 ? 1 : 0; }
+}
+
+// Next-fit over the graphs, one wave per stage kind: the per-graph unit shapes are computed by all 64 lanes
+// into LDS, then lane 0 walks the graphs (closed form per graph, small-integer divisions done with exact
+// float reciprocals) recording the (bin, fill) state every graph starts from.
+__device__ __forceinline__ int idiv_small(int a, int b) {   // exact for 0 <= a, 0 < b <= 2^20
+  int q = (int)(((float)a + 0.5f) / (float)b);
+  return q;
+}
+__device__ void bins_scan(int kind, int R, long long max_bins, int kmax, const int32_t* __restrict__ graph_ptr, int64_t B,
+                          int32_t* __restrict__ bin0, int32_t* __restrict__ fill0, int32_t* __restrict__ meta,
+                          int* sh_us, int* sh_uc, int chunk) {
+  const int lane = threadIdx.x & 63;
+  int bin = 0, fill = 0, err = 0, rows = 0;
+  for (int64_t base = 0; base < B; base += chunk) {
+    const int cnt = (int)((B - base) < chunk ? (B - base) : chunk);
+    for (int i = lane; i < cnt; i += 64) {
+      int n = graph_ptr[base + i + 1] - graph_ptr[base + i];
+      int kg = (kmax > 0 && n > kmax) ? kmax : n;
+      int us, uc;
+      unit_shape(kind, n, kg, us, uc);
+      sh_us[i] = us;
+      sh_uc[i] = uc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to lane 0
+    if (lane == 0) {
+      for (int i = 0; i < cnt; ++i) {
+        const int us = sh_us[i], uc = sh_uc[i];
+        bin0[base + i] = bin;
+        fill0[base + i] = fill;
+        if (us <= 0 || uc <= 0) continue;
+        if (us > R) { err = 1; continue; }
+        rows += us * uc;
+        int a = idiv_small(R - fill, us);
+        if (a > uc) a = uc;
+        fill += a * us;
+        const int rem = uc - a;
+        if (rem > 0) {
+          const int per = idiv_small(R, us);
+          const int nb = idiv_small(rem + per - 1, per);
+          bin += nb;                         // the open bin is closed, nb new ones are used, the last stays open
+          fill = (rem - (nb - 1) * per) * us;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    const int nbins = fill > 0 ? bin + 1 : bin;
+    meta[0] = nbins;
+    meta[1] = err | (nbins > max_bins ? 2 : 0);
+    meta[2] = rows;
+    meta[3] = R;
+  }
+}
+
+// K3: one workgroup — exclusive scans: deg -> rowptr (and cursor copy), n_b^2 -> evoff; nvalid; maxima; bin states.
 __global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int kmax,
                                                     const int32_t* __restrict__ graph_ptr,
                                                     const int32_t* __restrict__ node_graph,
@@ -58,13 +136,25 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int km
                                                     int32_t* __restrict__ rowptr,
                                                     int32_t* __restrict__ nvalid,
                                                     int64_t* __restrict__ evoff,
-                                                    int32_t* __restrict__ status) {
+                                                    int32_t* __restrict__ status, BinsOut bo,
+                                                    int32_t* __restrict__ binstate /* [3][2][B] */,
+                                                    int32_t* __restrict__ bins_meta /* [3][4] */) {
   __shared__ long long part[1024];
-  __shared__ long long carry_s;
   __shared__ int maxs[2];
   const int T = blockDim.x, t = threadIdx.x;
-  if (t == 0) { carry_s = 0; maxs[0] = 0; maxs[1] = 0; }
+  if (t == 0) { maxs[0] = 0; maxs[1] = 0; }
   __syncthreads();
+  // ---- block 1: the three sequential bin scans (one lane of three waves), concurrent with block 0's scans
+  if (blockIdx.x == 1) {
+    __shared__ int sh_shape[3][2][1024];
+    if ((t >> 6) < 3 && bins_meta) {
+      const int k = t >> 6;
+      if (bo.node[k]) bins_scan(k, bo.R[k], bo.max_bins[k], kmax, graph_ptr, B, binstate + (2 * k) * B,
+                                binstate + (2 * k + 1) * B, bins_meta + 4 * k, sh_shape[k][0], sh_shape[k][1], 1024);
+      else if ((t & 63) == 0) { bins_meta[4 * k] = 0; bins_meta[4 * k + 1] = 0; bins_meta[4 * k + 2] = 0; bins_meta[4 * k + 3] = 0; }
+    }
+    return;
+  }
   // ---- rowptr = exclusive scan of deg (chunked: each thread owns a contiguous run)
   {
     int64_t per = (N + T - 1) / T;
@@ -75,8 +165,7 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int km
     part[t] = s;
     atomicMax(&maxs[1], dmax);
     __syncthreads();
-    // Hillis-Steele inclusive scan over the T partials
-    for (int off = 1; off < T; off <<= 1) {
+    for (int off = 1; off < T; off <<= 1) {   // Hillis-Steele inclusive scan over the T partials
       long long v = (t >= off) ? part[t - off] : 0;
       __syncthreads();
       part[t] += v;
@@ -130,20 +219,56 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int km
   if (t == 0) { status[ST_NMAX] = maxs[0]; status[ST_DEGMAX] = maxs[1]; }
 }
 
-// K4: per edge — scatter into its destination's segment (arrival order is arbitrary here ...)
-__global__ void k_plan_fill(const int64_t* __restrict__ ei, int64_t E, int64_t N,
-                            int32_t* __restrict__ cursor, int32_t* __restrict__ col,
-                            int32_t* __restrict__ eperm) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  int64_t s = ei[e], d = ei[E + e];
-  if (s < 0 || s >= N || d < 0 || d >= N) return;
-  int p = atomicAdd(&cursor[d], 1);
-  col[p] = (int32_t)s;
-  eperm[p] = (int32_t)e;
+// K4: blocks [0, eblocks): per edge — scatter into its destination's segment (arrival order arbitrary, fixed
+// by k_plan_sort);  blocks [eblocks, eblocks + B): one graph each — write its bin rows for the three stage kinds.
+__global__ __launch_bounds__(256) void k_plan_fill(const int64_t* __restrict__ ei, int64_t E, int64_t N, int eblocks,
+                                                   int32_t* __restrict__ cursor, int32_t* __restrict__ col,
+                                                   int32_t* __restrict__ eperm, const int32_t* __restrict__ graph_ptr,
+                                                   int64_t B, int kmax, BinsOut bo,
+                                                   const int32_t* __restrict__ binstate,
+                                                   const int32_t* __restrict__ bins_meta) {
+  if ((int)blockIdx.x < eblocks) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t s = ei[e], d = ei[E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) return;
+    int p = atomicAdd(&cursor[d], 1);
+    col[p] = (int32_t)s;
+    eperm[p] = (int32_t)e;
+    return;
+  }
+  const int64_t g = (int64_t)blockIdx.x - eblocks;
+  if (g >= B) return;
+  const int gs = graph_ptr[g];
+  const int n = graph_ptr[g + 1] - gs;
+  const int kg = (kmax > 0 && n > kmax) ? kmax : n;
+  for (int kind = 0; kind < 3; ++kind) {
+    if (!bo.node[kind] || bins_meta[4 * kind + 1] != 0) continue;
+    const int R = bo.R[kind];
+    int us, uc;
+    unit_shape(kind, n, kg, us, uc);
+    if (us <= 0 || uc <= 0 || us > R) continue;
+    const int b0 = binstate[(2 * kind) * B + g], f0 = binstate[(2 * kind + 1) * B + g];
+    int a = (R - f0) / us;
+    if (a > uc) a = uc;
+    const int per = R / us;
+    for (int i = threadIdx.x; i < us * uc; i += blockDim.x) {
+      int u = i / us, r = i - u * us;
+      int bin, row0;
+      if (u < a) { bin = b0; row0 = f0 + u * us; }
+      else { int v = u - a; bin = b0 + 1 + v / per; row0 = (v % per) * us; }
+      int node, slot;
+      if (kind == 0) { node = gs + r; slot = u; }
+      else if (kind == 1) { node = gs + u; slot = r; }
+      else { node = gs + r; slot = 0; }
+      const int64_t o = (int64_t)bin * R + row0 + r;
+      bo.node[kind][o] = node;
+      bo.slot[kind][o] = slot;
+    }
+  }
 }
 
-// K5: per node — ... so sort each segment by edge id (insertion sort; molecular degrees are <= 4).
+// K5: per node — sort each CSR segment by edge id (insertion sort; molecular degrees are <= 4).
 // The in-edge order, and therefore the fp32 summation order of every aggregation, is deterministic.
 __global__ void k_plan_sort(int64_t N, const int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
                             int32_t* __restrict__ eperm) {
@@ -186,91 +311,6 @@ __global__ void k_pack_eig(const float* __restrict__ ev, const float* __restrict
 }
 
 
-// ---------------------------------------------------------------------------- bins for the fused stages
-// Units of graph g: kind 0 -> K_g slabs of n_g rows; kind 1 -> n_g nodes of K_g rows; kind 2 -> 1 graph of n_g rows
-// (K_g = min(n_g, kmax)).  Next-fit packing in graph order into bins of R rows.
-__device__ __forceinline__ void unit_shape(int kind, int n, int kg, int& usize, int& ucount) {
-  if (kind == 0) { usize = n; ucount = kg; }
-  else if (kind == 1) { usize = kg; ucount = n; }
-  else { usize = n; ucount = n > 0 ? 1 : 0; }
-}
-
-__global__ __launch_bounds__(1024) void k_plan_bins(const int32_t* __restrict__ graph_ptr, int64_t B, int kmax,
-                                                    int kind, int R, int64_t max_bins,
-                                                    int32_t* __restrict__ bin_node, int32_t* __restrict__ bin_slot,
-                                                    int32_t* __restrict__ meta) {
-  extern __shared__ int sh[];   // [B] bin0, [B] fill0  (start state of every graph)
-  int* bin0 = sh;
-  int* fill0 = sh + B;
-  __shared__ int s_err, s_nbins, s_rows;
-  const int t = threadIdx.x, T = blockDim.x;
-  if (t == 0) {
-    int bin = 0, fill = 0, err = 0, rows = 0;
-    for (int64_t g = 0; g < B; ++g) {
-      int n = graph_ptr[g + 1] - graph_ptr[g];
-      int kg = (kmax > 0 && n > kmax) ? kmax : n;
-      int us, uc;
-      unit_shape(kind, n, kg, us, uc);
-      bin0[g] = bin;
-      fill0[g] = fill;
-      if (us <= 0 || uc <= 0) continue;
-      if (us > R) { err = 1; continue; }
-      rows += us * uc;
-      int a = (R - fill) / us;
-      if (a > uc) a = uc;
-      fill += a * us;
-      int rem = uc - a;
-      if (rem > 0) {
-        int per = R / us;
-        int nb = (rem + per - 1) / per;
-        bin += nb;
-        fill = (rem - (nb - 1) * per) * us;
-      }
-    }
-    s_err = err;
-    s_nbins = (fill > 0 || bin > 0) ? bin + (fill > 0 ? 1 : 0) : 0;
-    // `bin` is the index of the currently open bin; it is counted once it holds rows
-    if (fill == 0 && bin > 0) s_nbins = bin;  // cannot happen (a new bin is opened only to hold a unit) — kept for safety
-    s_rows = rows;
-  }
-  __syncthreads();
-  const int nbins = s_nbins;
-  if (t == 0) {
-    meta[0] = nbins;
-    meta[1] = s_err | (nbins > max_bins ? 2 : 0);
-    meta[2] = s_rows;
-  }
-  if (nbins > max_bins) return;
-  // padding rows = -1
-  for (int64_t i = t; i < (int64_t)nbins * R; i += T) { bin_node[i] = -1; bin_slot[i] = -1; }
-  __syncthreads();
-  // expansion: one thread per (graph, unit, row) — loop graphs, spread (unit,row) over threads
-  for (int64_t g = 0; g < B; ++g) {
-    const int gs = graph_ptr[g];
-    const int n = graph_ptr[g + 1] - gs;
-    const int kg = (kmax > 0 && n > kmax) ? kmax : n;
-    int us, uc;
-    unit_shape(kind, n, kg, us, uc);
-    if (us <= 0 || uc <= 0 || us > R) continue;
-    int a = (R - fill0[g]) / us;
-    if (a > uc) a = uc;
-    const int per = R / us;
-    for (int i = t; i < us * uc; i += T) {
-      int u = i / us, r = i - u * us;
-      int bin, row0;
-      if (u < a) { bin = bin0[g]; row0 = fill0[g] + u * us; }
-      else { int v = u - a; bin = bin0[g] + 1 + v / per; row0 = (v % per) * us; }
-      int node, slot;
-      if (kind == 0) { node = gs + r; slot = u; }
-      else if (kind == 1) { node = gs + u; slot = r; }
-      else { node = gs + r; slot = 0; }
-      int64_t o = (int64_t)bin * R + row0 + r;
-      bin_node[o] = node;
-      bin_slot[o] = slot;
-    }
-  }
-}
-
 }  // namespace sn
 
 using namespace sn;
@@ -278,30 +318,42 @@ using namespace sn;
 extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index,
                              int64_t E, int kmax, int32_t* graph_ptr, int32_t* node_graph,
                              int32_t* nvalid, int64_t* evoff, int32_t* rowptr, int32_t* col,
-                             int32_t* eperm, int32_t* status, int32_t* scratch, void* stream) {
+                             int32_t* eperm, int32_t* status, const sn_bins_out* bins, int32_t* bins_meta,
+                             int32_t* scratch, void* stream) {
   SN_REQUIRE(N >= 0 && B >= 0 && E >= 0, "sn_batch_plan: negative size");
   SN_REQUIRE(N < (1ll << 31) && E < (1ll << 31), "sn_batch_plan: N/E exceed int32");
   SN_REQUIRE(graph_ptr && node_graph && nvalid && evoff && rowptr && status && scratch,
              "sn_batch_plan: null output");
   SN_REQUIRE(N == 0 || batch, "sn_batch_plan: null batch");
   SN_REQUIRE(E == 0 || (edge_index && col && eperm), "sn_batch_plan: null edge arrays");
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st) != hipSuccess)
-    return fail(SN_ERR_LAUNCH, "sn_batch_plan: memset failed");
-  int32_t* deg = scratch;
-  const int T = 256;
-  hipLaunchKernelGGL(k_plan_nodes, dim3((unsigned)cdiv(N > 0 ? N : 1, T)), dim3(T), 0, st, batch, N, B,
-                     graph_ptr, node_graph, deg, status);
-  if (E > 0)
-    hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(E, T)), dim3(T), 0, st, edge_index, E, N,
-                       node_graph, deg, status);
-  hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(1024), 0, st, N, B, kmax, graph_ptr, node_graph, deg,
-                     rowptr, nvalid, evoff, status);
-  if (E > 0) {
-    hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)cdiv(E, T)), dim3(T), 0, st, edge_index, E, N, deg,
-                       col, eperm);
-    hipLaunchKernelGGL(k_plan_sort, dim3((unsigned)cdiv(N, T)), dim3(T), 0, st, N, rowptr, col, eperm);
+  BinsOut bo;
+  for (int k = 0; k < 3; ++k) {
+    bo.R[k] = 0; bo.max_bins[k] = 0; bo.node[k] = nullptr; bo.slot[k] = nullptr;
+    if (bins && bins[k].node) {
+      SN_REQUIRE(bins[k].slot && bins[k].R > 0 && bins[k].max_bins >= 0 && bins_meta, "sn_batch_plan: bad bins[%d]", k);
+      bo.R[k] = bins[k].R; bo.max_bins[k] = bins[k].max_bins; bo.node[k] = bins[k].node; bo.slot[k] = bins[k].slot;
+    }
   }
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* deg = scratch;                       // [N]
+  int32_t* binstate = scratch + ((N + 3) / 4) * 4;  // [3][2][B]
+  const int T = 256;
+  const bool any_bins = bo.node[0] || bo.node[1] || bo.node[2];
+  int64_t nb1 = cdiv(N > 0 ? N : 1, T);
+  if (nb1 < 64) nb1 = 64;                       // enough threads to clear the bin arrays quickly
+  hipLaunchKernelGGL(k_plan_nodes, dim3((unsigned)nb1), dim3(T), 0, st, batch, N, B, graph_ptr, node_graph, deg, status, bo);
+  const int64_t ne = N > E ? N : E;
+  hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(ne > 0 ? ne : 1, T)), dim3(T), 0, st, batch, edge_index, E, N, B, deg,
+                     status);
+  hipLaunchKernelGGL(k_plan_scan, dim3(any_bins ? 2 : 1), dim3(1024), 0, st, N, B, kmax, graph_ptr, node_graph, deg, rowptr, nvalid, evoff,
+                     status, bo, binstate, bins_meta);
+  const int eblocks = (int)cdiv(E, T);
+  const int64_t gblocks = any_bins ? B : 0;
+  if (eblocks + gblocks > 0)
+    hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)(eblocks + gblocks)), dim3(T), 0, st, edge_index, E, N, eblocks, deg, col,
+                       eperm, graph_ptr, B, kmax, bo, binstate, bins_meta);
+  if (E > 0)
+    hipLaunchKernelGGL(k_plan_sort, dim3((unsigned)cdiv(N, T)), dim3(T), 0, st, N, rowptr, col, eperm);
   SN_CHECK_LAUNCH("sn_batch_plan");
   return SN_OK;
 }
@@ -326,14 +378,3 @@ extern "C" int64_t sn_bins_bound(int64_t rows_upper_bound, int R) {
   return 2 * cdiv(rows_upper_bound > 0 ? rows_upper_bound : 0, R) + 2;
 }
 
-extern "C" int sn_plan_bins(const int32_t* graph_ptr, int64_t B, int kmax, int kind, int R, int64_t max_bins,
-                            int32_t* bin_node, int32_t* bin_slot, int32_t* meta, void* stream) {
-  SN_REQUIRE(graph_ptr && bin_node && bin_slot && meta && B >= 0 && R > 0 && max_bins >= 0 && kind >= 0 && kind <= 2,
-             "sn_plan_bins: bad arguments");
-  SN_REQUIRE(B <= 16000, "sn_plan_bins: B=%lld graphs exceed the single-workgroup planner (16000)", (long long)B);
-  size_t lds = (size_t)2 * (B > 0 ? B : 1) * sizeof(int);
-  hipLaunchKernelGGL(k_plan_bins, dim3(1), dim3(1024), lds, (hipStream_t)stream, graph_ptr, B, kmax, kind, R, max_bins,
-                     bin_node, bin_slot, meta);
-  SN_CHECK_LAUNCH("sn_plan_bins");
-  return SN_OK;
-}

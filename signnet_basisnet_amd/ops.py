@@ -92,6 +92,17 @@ def _f32c(t, name):
 
 
 @dataclass
+class Bins:
+    """Work bins of one fused stage (kind 0: (graph,slot) slabs; 1: nodes; 2: graphs)."""
+    kind: int
+    R: int
+    max_bins: int
+    node: torch.Tensor   # int32 [max_bins*R]  node id per bin row, -1 = padding
+    slot: torch.Tensor   # int32 [max_bins*R]
+    meta: torch.Tensor   # int32 [4]: nbins, error flag, real rows, R
+
+
+@dataclass
 class GraphPlan:
     """Device-resident structure of one batch (built once per batch by `build_plan`)."""
     N: int
@@ -106,6 +117,7 @@ class GraphPlan:
     col: torch.Tensor         # int32 [E]   source node of each in-edge
     eperm: torch.Tensor       # int32 [E]   original edge id of each CSR slot
     status: torch.Tensor      # int32 [4]   [err bits, max nodes/graph, max in-degree, -]
+    bins: dict                # kind -> Bins
 
     def check(self):
         """Synchronising validity check (raises on malformed batches)."""
@@ -117,7 +129,12 @@ class GraphPlan:
         return st
 
 
-def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0) -> GraphPlan:
+class _BinsOut(C.Structure):
+    _fields_ = [("R", C.c_int), ("max_bins", C.c_int64), ("node", C.c_void_p), ("slot", C.c_void_p)]
+
+
+def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins=None) -> GraphPlan:
+    """bins: optional {kind: (R, rows_upper_bound)} — work bins for the fused stages, built in the same launches."""
     require_cuda(batch, edge_index)
     if batch.dtype != torch.int64 or edge_index.dtype != torch.int64:
         raise ValueError("build_plan: batch and edge_index must be int64 (the reference's index dtype)")
@@ -125,21 +142,34 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     edge_index = edge_index.contiguous()
     N, E, B = batch.numel(), edge_index.shape[1] if edge_index.numel() else 0, int(num_graphs)
     dev = batch.device
-    i32 = dict(dtype=torch.int32, device=dev)
+    bins = bins or {}
+    specs = []
+    for kind in range(3):
+        if kind in bins:
+            R, ub = bins[kind]
+            specs.append((kind, int(R), int(lib().sn_bins_bound(int(ub), int(R)))))
     # one int32 arena, carved into the plan arrays (single allocation per batch)
-    sizes = [B + 1, N, N, N + 1, E, E, 4, N + 8]
+    sizes = [B + 1, N, N, N + 1, E, E, 4, 12, 4 * ((N + 3) // 4) + 6 * B + 8]
+    for _, R, mb in specs:
+        sizes += [mb * R, mb * R]
     offs = [0]
     for s in sizes:
         offs.append(offs[-1] + ((s + 3) // 4) * 4)
-    arena = torch.empty(offs[-1], **i32)
-    graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, scratch = (
-        arena[offs[i]:offs[i] + sizes[i]] for i in range(8))
+    arena = torch.empty(offs[-1], dtype=torch.int32, device=dev)
+    parts = [arena[offs[i]:offs[i] + sizes[i]] for i in range(len(sizes))]
+    graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, bmeta, scratch = parts[:9]
     evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    bo = (_BinsOut * 3)()
+    bdict = {}
+    for j, (kind, R, mb) in enumerate(specs):
+        node, slot = parts[9 + 2 * j], parts[10 + 2 * j]
+        bo[kind].R, bo[kind].max_bins, bo[kind].node, bo[kind].slot = R, mb, node.data_ptr(), slot.data_ptr()
+        bdict[kind] = Bins(kind, R, mb, node, slot, bmeta[4 * kind:4 * kind + 4])
     with _span("sn_batch_plan"):
         check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
                                   ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
-                                  ptr(scratch), stream()), "sn_batch_plan")
-    return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status)
+                                  bo if specs else None, ptr(bmeta), ptr(scratch), stream()), "sn_batch_plan")
+    return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bdict)
 
 
 def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: bool):
@@ -155,28 +185,6 @@ def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: 
 
 
 PHI_BIN_ROWS = 64     # SN_PHI_BIN_ROWS
-
-
-@dataclass
-class Bins:
-    kind: int
-    R: int
-    max_bins: int
-    node: torch.Tensor   # int32 [max_bins*R]
-    slot: torch.Tensor   # int32 [max_bins*R]
-    meta: torch.Tensor   # int32 [4]: nbins, error flag, rows
-
-
-def plan_bins(plan: GraphPlan, kind: int, R: int, rows_upper_bound: int) -> Bins:
-    """Pack the stage's units (kind 0: (graph,slot) slabs; 1: nodes; 2: graphs) into bins of R rows."""
-    max_bins = int(lib().sn_bins_bound(int(rows_upper_bound), R))
-    dev = plan.graph_ptr.device
-    arena = torch.empty(2 * max_bins * R + 4, dtype=torch.int32, device=dev)
-    node, slot, meta = arena[:max_bins * R], arena[max_bins * R:2 * max_bins * R], arena[2 * max_bins * R:]
-    with _span("sn_plan_bins"):
-        check(lib().sn_plan_bins(ptr(plan.graph_ptr), plan.B, plan.kmax, kind, R, max_bins, ptr(node), ptr(slot),
-                                 ptr(meta), stream()), "sn_plan_bins")
-    return Bins(kind, R, max_bins, node, slot, meta)
 
 
 def bn_fold(bn, c_pad=None):

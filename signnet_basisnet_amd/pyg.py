@@ -341,7 +341,12 @@ class SignNetGNN(nn.Module):
             self._prep = self._prepare()
         P = self._prep
         B = int(data.num_graphs)
-        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0)
+        use_phi_fused = P["phi_fused"] is not None
+        rows_ub = data.eigen_vectors.numel()
+        if self.max_k:
+            rows_ub = min(rows_ub, data.batch.numel() * int(self.max_k))
+        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0,
+                              bins={0: (ops.PHI_BIN_ROWS, rows_ub)} if use_phi_fused else None)
         if self.max_k:
             K = int(self.max_k)
             plan.check() if return_stages else None
@@ -355,10 +360,8 @@ class SignNetGNN(nn.Module):
 
         # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)
         phis = None
-        if P["phi_fused"] is not None and not return_stages:
-            rows_ub = min(N * K, data.eigen_vectors.numel())
-            bins = ops.plan_bins(plan, 0, ops.PHI_BIN_ROWS, rows_ub)
-            x = P["phi_fused"].run(plan, bins, data.eigen_vectors, K).view(N * K, d)
+        if use_phi_fused and not return_stages:
+            x = P["phi_fused"].run(plan, plan.bins[0], data.eigen_vectors, K).view(N * K, d)
         else:
             phis = []
             for sign in (0, 1):
@@ -373,9 +376,8 @@ class SignNetGNN(nn.Module):
         if return_stages:
             stages.update(phi_plus=phis[0].view(N, K, d), phi_minus=phis[1].view(N, K, d), phi=x.view(N, K, d))
             if P["phi_fused"] is not None:      # cross-check target for the fused kernel
-                bins = ops.plan_bins(plan, 0, ops.PHI_BIN_ROWS, min(N * K, data.eigen_vectors.numel()))
-                stages["phi_fused"] = P["phi_fused"].run(plan, bins, data.eigen_vectors, K)
-                stages["phi_bins_meta"] = bins.meta
+                stages["phi_fused"] = P["phi_fused"].run(plan, plan.bins[0], data.eigen_vectors, K)
+                stages["phi_bins_meta"] = plan.bins[0].meta
         # ---- rho                    (SetTransformer.forward, sign_net.py:60-72)
         if want_vals:
             E_ = P["eig"]

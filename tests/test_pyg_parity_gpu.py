@@ -53,12 +53,14 @@ def test_plan_bins():
     data = synth.make_batch(40, seed=9)
     d = synth.batch_to(data, "cuda:0")
     for kmax in (0, 16, 5):
-        plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax)
         n = torch.tensor(data.sizes)
         kg = n.clamp(max=kmax) if kmax else n
+        ubs = {0: int((n * kg).sum()), 1: int((n * kg).sum()), 2: int(n.sum())}
+        plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins={k: (64, ubs[k]) for k in range(3)})
+        assert plan.check()[0] == 0
         for kind, R in ((0, 64), (1, 64), (2, 64)):
-            rows_ub = int((n * kg).sum()) if kind < 2 else int(n.sum())
-            bins = ops.plan_bins(plan, kind, R, rows_ub)
+            rows_ub = ubs[kind]
+            bins = plan.bins[kind]
             nb, err, rows = bins.meta.cpu().tolist()[:3]
             assert err == 0 and rows == rows_ub and nb <= bins.max_bins
             node = bins.node.cpu()[:nb * R].view(nb, R)
