@@ -230,6 +230,40 @@ int sn_phi_fused_f32(const sn_phi_params* params /* host struct of device pointe
                      const int32_t* bin_node, const int32_t* bin_slot, const int32_t* meta,
                      int64_t max_bins, int K, float* out, void* stream);
 
+/* rho: the set-transformer encoder layers over each node's valid slots and the sum over slots, one launch.
+ * Replaces SetTransformer.forward up to torch.sum(x, dim=1) (sign_net.py:60-70 / core/sign_net.py:64-75)
+ * with its TransformerEncoderLayer stack (transformer_module.py:27-127, 4 heads, post-LN, eps 1e-6) and,
+ * when has_pos, the eigenvalue encoder MaskedMLP(1->1->d) added to x (Alchemy sign_net.py:86,108,62).
+ * Weight matrices packed (sn_pack_weight_f32), vectors zero-padded to d_pad.  Bins: kind 1, R = 64.
+ *   x:       [N*K, d] = phi(x)+phi(-x) (row = node*K + slot; only valid rows are read)
+ *   out_sum: [N, d]   sum over the node's valid slots of the last encoder layer's output            */
+typedef struct {
+  const float *wq, *wk, *wv, *wfc; /* packed [d,d], no bias (transformer_module.py:67-70) */
+  const float *ln1_g, *ln1_b;      /* slf_attn.norm.ln */
+  const float *w1, *b1, *w2, *b2;  /* pos_ffn.w_1 / w_2 */
+  const float *ln2_g, *ln2_b;      /* pos_ffn.norm.ln */
+} sn_rho_layer;
+
+#define SN_RHO_MAX_LAYERS 8
+#define SN_RHO_BIN_ROWS 64
+typedef struct {
+  int d, n_layers, heads, has_pos;
+  float ln_eps;
+  int reserved;
+  const float* pe_w1;        /* [>=1]  eigen_encoder.layers.0.weight */
+  const float* pe_bn0_scale; /* [>=1] */
+  const float* pe_bn0_shift;
+  const float* pe_w2;        /* [d_pad] eigen_encoder.layers.1.weight[:, 0] */
+  const float* pe_bn1_scale; /* [d_pad] */
+  const float* pe_bn1_shift;
+  sn_rho_layer layers[SN_RHO_MAX_LAYERS];
+} sn_rho_params;
+
+int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* eigen_values,
+                     const int32_t* graph_ptr, const int32_t* node_graph, const int32_t* nvalid,
+                     const int32_t* bin_node, const int32_t* bin_slot, const int32_t* meta,
+                     int64_t max_bins, int K, float* out_sum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

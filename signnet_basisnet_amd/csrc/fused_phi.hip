@@ -18,7 +18,7 @@
 //     fragment feeding 8 MFMAs (4 k-steps x 2 signs).
 // Bound: fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s chip peak); algorithmic flops per valid row:
 // 2 signs * (L-1) layers * 2 GEMMs * 2*d*d.
-#include "common.hpp"
+#include "fused_common.hpp"
 
 namespace sn {
 
@@ -39,37 +39,6 @@ struct PhiStruct {
   int K;
   float* out;
 };
-
-__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) {
-  float4 t = *reinterpret_cast<const float4*>(p);
-  return f32x4{t.x, t.y, t.z, t.w};
-}
-__device__ __forceinline__ f32x4 lds_ld4(const float* p) {
-  float4 t = *reinterpret_cast<const float4*>(p);
-  return f32x4{t.x, t.y, t.z, t.w};
-}
-__device__ __forceinline__ void lds_st4(float* p, f32x4 v) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ f32x4 relu4(f32x4 v) {
-  return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-}
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Weight fragments are fetched with buffer loads: descriptor in SGPRs (wave-uniform base), one VGPR of
-// per-lane offset (lane*16) and an immediate/SGPR fragment offset — no 64-bit address VGPR per fragment.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* p, unsigned bytes) {
-  unsigned long long a = reinterpret_cast<unsigned long long>(p);
-  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-  return __builtin_amdgcn_make_buffer_rsrc(q, 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 wfrag(__amdgpu_buffer_rsrc_t rs, int voff, int frag) {
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, frag * 1024, 0);
-  return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-}
 
 // out{P,M}[ot] = W (packed) x in{P,M}  — both signs share every weight fragment.
 // The weight fragments of output tile ot+1 are fetched (NT x 1 KiB coalesced wave-loads from L2) while the

@@ -85,3 +85,67 @@ class PhiPlan:
                                          ptr(bins.slot), ptr(bins.meta), bins.max_bins, K, ptr(out), stream()),
                   "sn_phi_fused_f32")
         return out
+
+
+RHO_MAX_LAYERS = 8
+RHO_BIN_ROWS = 64
+
+
+class _RhoLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "wk", "wv", "wfc", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+
+
+class _RhoParams(C.Structure):
+    _fields_ = [("d", C.c_int), ("n_layers", C.c_int), ("heads", C.c_int), ("has_pos", C.c_int),
+                ("ln_eps", C.c_float), ("reserved", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("pe_w1", "pe_bn0_scale", "pe_bn0_shift", "pe_w2", "pe_bn1_scale", "pe_bn1_shift")] + \
+               [("layers", _RhoLayer * RHO_MAX_LAYERS)]
+
+
+class RhoPlan:
+    """Packed parameters of a SetTransformer (rho) for sn_rho_fused_f32."""
+
+    def __init__(self, rho_module, eigen_encoder, heads, ln_eps):
+        tls = rho_module.transformer_layers
+        d = rho_module.out[0].weight.shape[1]
+        if not (0 < d <= 128 and len(tls) <= RHO_MAX_LAYERS and heads == 4 and d % heads == 0):
+            raise ValueError("fused rho supports hidden width <= 128 (divisible by 4 heads) and <= 8 layers")
+        dp = 16 * ((d + 15) // 16)
+        self.d, self.dp = d, dp
+        keep = self._keep = []
+
+        def hold(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        P = _RhoParams()
+        P.d, P.n_layers, P.heads, P.ln_eps = d, len(tls), heads, float(ln_eps)
+        P.has_pos = 1 if eigen_encoder is not None else 0
+        if eigen_encoder is not None:
+            ee = eigen_encoder
+            P.pe_w1 = hold(ops.pad_vec(ee.layers[0].weight.detach(), 4))
+            s, h = ops.bn_fold(ee.norms[0].bn, 4)
+            P.pe_bn0_scale, P.pe_bn0_shift = hold(s), hold(h)
+            P.pe_w2 = hold(ops.pad_vec(ee.layers[1].weight.detach()[:, 0], dp))
+            s, h = ops.bn_fold(ee.norms[1].bn, dp)
+            P.pe_bn1_scale, P.pe_bn1_shift = hold(s), hold(h)
+        for l, tl in enumerate(tls):
+            a, f, Lp = tl.slf_attn, tl.pos_ffn, P.layers[l]
+            Lp.wq = hold(ops.pack_weight(a.w_qs.weight.detach()))
+            Lp.wk = hold(ops.pack_weight(a.w_ks.weight.detach()))
+            Lp.wv = hold(ops.pack_weight(a.w_vs.weight.detach()))
+            Lp.wfc = hold(ops.pack_weight(a.fc.weight.detach()))
+            Lp.ln1_g, Lp.ln1_b = hold(ops.pad_vec(a.norm.ln.weight, dp)), hold(ops.pad_vec(a.norm.ln.bias, dp))
+            Lp.w1, Lp.b1 = hold(ops.pack_weight(f.w_1.weight.detach())), hold(ops.pad_vec(f.w_1.bias, dp))
+            Lp.w2, Lp.b2 = hold(ops.pack_weight(f.w_2.weight.detach())), hold(ops.pad_vec(f.w_2.bias, dp))
+            Lp.ln2_g, Lp.ln2_b = hold(ops.pad_vec(f.norm.ln.weight, dp)), hold(ops.pad_vec(f.norm.ln.bias, dp))
+        self.params = P
+
+    def run(self, plan: ops.GraphPlan, bins: ops.Bins, x, eigen_values, K: int):
+        """x [N*K, d] -> sum over valid slots of the encoder output, [N, d]."""
+        out = torch.empty(plan.N, self.d, dtype=torch.float32, device=x.device)
+        with ops._span("sn_rho_fused_f32"):
+            check(lib().sn_rho_fused_f32(C.byref(self.params), ptr(x), ptr(eigen_values), ptr(plan.graph_ptr),
+                                         ptr(plan.node_graph), ptr(plan.nvalid), ptr(bins.node), ptr(bins.slot),
+                                         ptr(bins.meta), bins.max_bins, K, ptr(out), stream()), "sn_rho_fused_f32")
+        return out

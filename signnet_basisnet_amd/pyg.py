@@ -298,6 +298,9 @@ class SignNetGNN(nn.Module):
         sn, g = self.sign_net, self.gnn
         d = self.cfg["n_hid"]
         P["phi_fused"] = fused.PhiPlan(sn.phi) if (self.use_fused and d <= 128 and len(sn.phi.convs) <= 16) else None
+        ee = sn.eigen_encoder if (self.variant == "alchemy" and not sn.ignore_eigval) else None
+        P["rho_fused"] = (fused.RhoPlan(sn.rho, ee, N_HEAD, LN_EPS)
+                          if (self.use_fused and d <= 128 and len(sn.rho.transformer_layers) <= fused.RHO_MAX_LAYERS) else None)
         P["phi"] = []
         for conv, norm in zip(sn.phi.convs, sn.phi.norms):
             P["phi"].append(dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0].bn),
@@ -345,8 +348,13 @@ class SignNetGNN(nn.Module):
         rows_ub = data.eigen_vectors.numel()
         if self.max_k:
             rows_ub = min(rows_ub, data.batch.numel() * int(self.max_k))
-        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0,
-                              bins={0: (ops.PHI_BIN_ROWS, rows_ub)} if use_phi_fused else None)
+        use_rho_fused = P["rho_fused"] is not None
+        bins = {}
+        if use_phi_fused:
+            bins[0] = (ops.PHI_BIN_ROWS, rows_ub)
+        if use_rho_fused:
+            bins[1] = (fused.RHO_BIN_ROWS, rows_ub)
+        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=bins)
         if self.max_k:
             K = int(self.max_k)
             plan.check() if return_stages else None
@@ -379,25 +387,34 @@ class SignNetGNN(nn.Module):
                 stages["phi_fused"] = P["phi_fused"].run(plan, plan.bins[0], data.eigen_vectors, K)
                 stages["phi_bins_meta"] = plan.bins[0].meta
         # ---- rho                    (SetTransformer.forward, sign_net.py:60-72)
-        if want_vals:
-            E_ = P["eig"]
-            p = ops.masked_linear(s0.view(N * K, 1), E_["l0"], nv, K, scale=E_["bn0"][0], shift=E_["bn0"][1], relu=True)
-            p = ops.masked_linear(p, E_["l1"], nv, K, scale=E_["bn1"][0], shift=E_["bn1"][1], relu=True)
-            x = ops.masked_affine(x, nv, K, residual=p)
-        for L in P["rho"]:
-            q = ops.masked_linear(x, L["q"], nv, K)
-            k = ops.masked_linear(x, L["k"], nv, K)
-            v = ops.masked_linear(x, L["v"], nv, K)
-            o = ops.set_attention(q, k, v, N, K, N_HEAD, nv)
-            o = ops.masked_linear(o, L["fc"], nv, K)
-            y = ops.masked_layernorm(o, x, L["ln1"][0], L["ln1"][1], LN_EPS, nv, K)
-            z = ops.masked_linear(y, L["w1"], nv, K, relu=True)
-            z = ops.masked_linear(z, L["w2"], nv, K)
-            x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
-        s = ops.slot_sum(x, N, K)
+        x_phi = x
+        if use_rho_fused and not return_stages:
+            s = P["rho_fused"].run(plan, plan.bins[1], x_phi, data.eigen_values if want_vals else None, K)
+        else:
+            if want_vals:
+                E_ = P["eig"]
+                p = ops.masked_linear(s0.view(N * K, 1), E_["l0"], nv, K, scale=E_["bn0"][0], shift=E_["bn0"][1], relu=True)
+                p = ops.masked_linear(p, E_["l1"], nv, K, scale=E_["bn1"][0], shift=E_["bn1"][1], relu=True)
+                x = ops.masked_affine(x, nv, K, residual=p)
+            for L in P["rho"]:
+                q = ops.masked_linear(x, L["q"], nv, K)
+                k = ops.masked_linear(x, L["k"], nv, K)
+                v = ops.masked_linear(x, L["v"], nv, K)
+                o = ops.set_attention(q, k, v, N, K, N_HEAD, nv)
+                o = ops.masked_linear(o, L["fc"], nv, K)
+                y = ops.masked_layernorm(o, x, L["ln1"][0], L["ln1"][1], LN_EPS, nv, K)
+                z = ops.masked_linear(y, L["w1"], nv, K, relu=True)
+                z = ops.masked_linear(z, L["w2"], nv, K)
+                x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
+            s = ops.slot_sum(x, N, K)
         pe = ops.masked_linear(s, P["rho_out"]["l"], scale=P["rho_out"]["bn"][0], shift=P["rho_out"]["bn"][1])
         if return_stages:
             stages["pos"] = pe
+            stages["rho_sum"] = s
+            if use_rho_fused:
+                stages["rho_sum_fused"] = P["rho_fused"].run(plan, plan.bins[1], x_phi,
+                                                             data.eigen_values if want_vals else None, K)
+                stages["rho_bins_meta"] = plan.bins[1].meta
         # ---- GINE network           (GNN.forward, model.py:36-64)
         xin = data.x.squeeze() if data.x.dim() > 1 and data.x.shape[-1] == 1 else data.x
         if "in_tabs" in P:
