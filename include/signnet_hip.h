@@ -264,6 +264,54 @@ int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* e
                      const int32_t* bin_node, const int32_t* bin_slot, const int32_t* meta,
                      int64_t max_bins, int K, float* out_sum, void* stream);
 
+/* The GINE network on top of the positional encoding, one launch: rho's output Linear+BatchNorm on the slot
+ * sum (sign_net.py:71), then GNN.forward (model.py:36-64 / core/model.py:44-79): input encoder
+ * (DiscreteEncoder elements.py:31-37 or MLP(F,d,1)), Linear(cat[x,pos]), n_layers x [edge encoder, GINEConv
+ * (pyg_gnn_wrapper.py:19-28), BatchNorm, ReLU, +previous], add pooling, 2-layer output encoder.
+ * Bins: kind 2 (whole graphs), R = 64.  Matrices packed, vectors zero-padded to d_pad unless noted. */
+typedef struct {
+  const float* etab[10];  /* discrete edge encoder: embedding tables [V, d] of layer l */
+  const float* ew;        /* float edge encoder: weight [d_pad, F_e] row-major (NOT packed), zero padded rows */
+  const float* e_scale;   /*   its folded BatchNorm */
+  const float* e_shift;
+  const float* w1p;       /* GINE nn.layers.0 packed [d,d] */
+  const float* bn0_scale; /* nn.norms.0 folded */
+  const float* bn0_shift;
+  const float* w2p;       /* nn.layers.1 packed [d,d] */
+  const float* bn_scale;  /* gnn.norms[l] folded */
+  const float* bn_shift;
+  const float* eps;       /* device scalar */
+} sn_gnn_layer;
+
+#define SN_GNN_MAX_LAYERS 16
+#define SN_GNN_BIN_ROWS 64
+typedef struct {
+  int d, n_layers, n_out, reserved;
+  int node_discrete, node_nf; /* discrete: number of int64 feature columns (<=10); float: F (<=16) */
+  int edge_discrete, edge_nf;
+  const float* ntab[10];      /* discrete node encoder tables [V, d] */
+  const float* nw;            /* float node encoder: packed [d, F] */
+  const float* n_scale;
+  const float* n_shift;
+  const float* rho_out_w;     /* sign_net.rho.out.0 packed [d,d] */
+  const float* rho_scale;     /* sign_net.rho.out.1 folded */
+  const float* rho_shift;
+  const float* lin_a;         /* gnn.linear.weight[:, :d] packed */
+  const float* lin_b;         /* gnn.linear.weight[:, d:] packed */
+  const float* lin_bias;
+  const float* head_w1;       /* output_encoder.layers.0 packed [d,d] */
+  const float* head_scale;    /* output_encoder.norms.0 folded */
+  const float* head_shift;
+  const float* head_w2;       /* output_encoder.layers.1 packed [n_out, d] */
+  const float* head_b2;       /* [>= n_out] */
+  sn_gnn_layer layers[SN_GNN_MAX_LAYERS];
+} sn_gnn_params;
+
+int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const void* edge_attr, int lde,
+                     const float* rho_sum, const int32_t* graph_ptr, const int32_t* node_graph,
+                     const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                     const int32_t* bin_node, const int32_t* meta, int64_t max_bins, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

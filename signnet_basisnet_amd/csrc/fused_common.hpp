@@ -36,25 +36,26 @@ __device__ __forceinline__ float4 wfrag(__amdgpu_buffer_rsrc_t rs, int voff, int
 }
 
 
-// Single-row-tile GEMM:  for every output tile ot, acc = W[ot-th 16 outputs] . in  and epi(ot, acc) consumes it.
-// Two accumulators (even / odd k-chunks) keep two independent MFMA chains in flight (16x16x4 f32: 32-cycle
-// issue, 40-cycle dependent latency).  Weight fragments of tile ot+1 are fetched while tile ot computes.
-template <int NT, typename Epi>
-__device__ __forceinline__ void gemm_rows(const float* __restrict__ wp, const f32x4 (&in)[NT], int lane, Epi epi) {
-  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, NT * NT * 1024);
+// Single-row-tile GEMM:  for every output tile ot < NTO, acc = W[ot-th 16 outputs] . in  and epi(ot, acc)
+// consumes it.  W is packed [NTO][NTI][64][4].  Two accumulators (even / odd k-chunks) keep two independent
+// MFMA chains in flight (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency).  Weight fragments of tile
+// ot+1 are fetched while tile ot computes.
+template <int NTI, int NTO, typename Epi>
+__device__ __forceinline__ void gemm_rows2(const float* __restrict__ wp, const f32x4 (&in)[NTI], int lane, Epi epi) {
+  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, NTO * NTI * 1024);
   const int voff = lane * 16;
-  float4 wc[NT], wn[NT];
+  float4 wc[NTI], wn[NTI];
 #pragma unroll
-  for (int kk = 0; kk < NT; ++kk) wc[kk] = wfrag(rs, voff, kk);
+  for (int kk = 0; kk < NTI; ++kk) wc[kk] = wfrag(rs, voff, kk);
 #pragma unroll
-  for (int ot = 0; ot < NT; ++ot) {
-    if (ot + 1 < NT) {
+  for (int ot = 0; ot < NTO; ++ot) {
+    if (ot + 1 < NTO) {
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) wn[kk] = wfrag(rs, voff, (ot + 1) * NT + kk);
+      for (int kk = 0; kk < NTI; ++kk) wn[kk] = wfrag(rs, voff, (ot + 1) * NTI + kk);
     }
     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < NT; ++kk) {
+    for (int kk = 0; kk < NTI; ++kk) {
       const float4 w = wc[kk];
       if (kk & 1) {
         a1 = mfma16(w.x, in[kk][0], a1);
@@ -70,11 +71,15 @@ __device__ __forceinline__ void gemm_rows(const float* __restrict__ wp, const f3
     }
     epi(ot, a0 + a1);
     __builtin_amdgcn_sched_barrier(0);
-    if (ot + 1 < NT) {
+    if (ot + 1 < NTO) {
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) wc[kk] = wn[kk];
+      for (int kk = 0; kk < NTI; ++kk) wc[kk] = wn[kk];
     }
   }
+}
+template <int NT, typename Epi>
+__device__ __forceinline__ void gemm_rows(const float* __restrict__ wp, const f32x4 (&in)[NT], int lane, Epi epi) {
+  gemm_rows2<NT, NT>(wp, in, lane, epi);
 }
 
 // sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one activation row

@@ -149,3 +149,118 @@ class RhoPlan:
                                          ptr(plan.node_graph), ptr(plan.nvalid), ptr(bins.node), ptr(bins.slot),
                                          ptr(bins.meta), bins.max_bins, K, ptr(out), stream()), "sn_rho_fused_f32")
         return out
+
+
+GNN_MAX_LAYERS = 16
+GNN_BIN_ROWS = 64
+
+
+class _GnnLayer(C.Structure):
+    _fields_ = [("etab", C.c_void_p * 10)] + \
+               [(n, C.c_void_p) for n in ("ew", "e_scale", "e_shift", "w1p", "bn0_scale", "bn0_shift", "w2p", "bn_scale",
+                                          "bn_shift", "eps")]
+
+
+class _GnnParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("d", "n_layers", "n_out", "reserved", "node_discrete", "node_nf", "edge_discrete",
+                                       "edge_nf")] + \
+               [("ntab", C.c_void_p * 10)] + \
+               [(n, C.c_void_p) for n in ("nw", "n_scale", "n_shift", "rho_out_w", "rho_scale", "rho_shift", "lin_a", "lin_b",
+                                          "lin_bias", "head_w1", "head_scale", "head_shift", "head_w2", "head_b2")] + \
+               [("layers", _GnnLayer * GNN_MAX_LAYERS)]
+
+
+class GnnPlan:
+    """Packed parameters of rho.out + the GINE `GNN` module for sn_gnn_fused_f32."""
+
+    def __init__(self, rho_out, gnn, node_feat, edge_feat):
+        d = gnn.linear.weight.shape[0]
+        L = len(gnn.convs)
+        n_out = gnn.output_encoder.layers[1].weight.shape[0]
+        if not (0 < d <= 128 and L <= GNN_MAX_LAYERS and 1 <= n_out <= 16 and gnn.pooling == "add"):
+            raise ValueError("fused gnn supports hidden width <= 128, <= 16 layers, n_out <= 16, add pooling")
+        if (node_feat is not None and node_feat > 16) or (edge_feat is not None and edge_feat > 16):
+            raise ValueError("fused gnn supports at most 16 continuous node/edge features")
+        dp = 16 * ((d + 15) // 16)
+        self.d, self.n_out = d, n_out
+        self.node_discrete, self.edge_discrete = node_feat is None, edge_feat is None
+        keep = self._keep = []
+
+        def hold(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        P = _GnnParams()
+        P.d, P.n_layers, P.n_out = d, L, n_out
+        P.node_discrete, P.edge_discrete = int(self.node_discrete), int(self.edge_discrete)
+        P.node_nf = 1 if self.node_discrete else int(node_feat)     # discrete column count is set per call
+        P.edge_nf = 1 if self.edge_discrete else int(edge_feat)
+        if self.node_discrete:
+            for f, e in enumerate(gnn.input_encoder.embeddings):
+                P.ntab[f] = hold(e.weight.detach())
+        else:
+            P.nw = hold(ops.pack_weight(gnn.input_encoder.layers[0].weight.detach()))
+            s, h = ops.bn_fold(gnn.input_encoder.norms[0], dp)
+            P.n_scale, P.n_shift = hold(s), hold(h)
+        P.rho_out_w = hold(ops.pack_weight(rho_out[0].weight.detach()))
+        s, h = ops.bn_fold(rho_out[1], dp)
+        P.rho_scale, P.rho_shift = hold(s), hold(h)
+        W = gnn.linear.weight.detach()
+        P.lin_a, P.lin_b = hold(ops.pack_weight(W[:, :d])), hold(ops.pack_weight(W[:, d:]))
+        P.lin_bias = hold(ops.pad_vec(gnn.linear.bias, dp))
+        oe = gnn.output_encoder
+        P.head_w1 = hold(ops.pack_weight(oe.layers[0].weight.detach()))
+        s, h = ops.bn_fold(oe.norms[0], dp)
+        P.head_scale, P.head_shift = hold(s), hold(h)
+        P.head_w2 = hold(ops.pack_weight(oe.layers[1].weight.detach()))
+        P.head_b2 = hold(ops.pad_vec(oe.layers[1].bias, 16))
+        for l, (enc, conv, norm) in enumerate(zip(gnn.edge_encoders, gnn.convs, gnn.norms)):
+            Lp = P.layers[l]
+            if self.edge_discrete:
+                for f, e in enumerate(enc.embeddings):
+                    Lp.etab[f] = hold(e.weight.detach())
+            else:
+                w = enc.layers[0].weight.detach()                      # [d, F_e]
+                wp = torch.zeros(dp, w.shape[1], dtype=torch.float32, device=w.device)
+                wp[:d].copy_(w)
+                Lp.ew = hold(wp)
+                s, h = ops.bn_fold(enc.norms[0], dp)
+                Lp.e_scale, Lp.e_shift = hold(s), hold(h)
+            Lp.w1p = hold(ops.pack_weight(conv.nn.layers[0].weight.detach()))
+            s, h = ops.bn_fold(conv.nn.norms[0], dp)
+            Lp.bn0_scale, Lp.bn0_shift = hold(s), hold(h)
+            Lp.w2p = hold(ops.pack_weight(conv.nn.layers[1].weight.detach()))
+            s, h = ops.bn_fold(norm, dp)
+            Lp.bn_scale, Lp.bn_shift = hold(s), hold(h)
+            Lp.eps = hold(conv.layer.eps.detach())
+        self.params = P
+
+    def run(self, plan: ops.GraphPlan, bins: ops.Bins, x, edge_attr, rho_sum):
+        """-> model output [B, n_out]."""
+        P = self.params
+        if self.node_discrete:
+            if x.dtype != torch.int64:
+                raise ValueError("discrete node features must be int64")
+            x = x.reshape(plan.N, -1).contiguous()
+            P.node_nf = x.shape[1]
+        else:
+            if x.dtype != torch.float32:
+                raise ValueError("continuous node features must be float32")
+            x = x.reshape(plan.N, -1).contiguous()
+        if self.edge_discrete:
+            if edge_attr.dtype != torch.int64:
+                raise ValueError("discrete edge features must be int64")
+            edge_attr = edge_attr.reshape(plan.E, -1).contiguous()
+            P.edge_nf = edge_attr.shape[1] if plan.E else 1
+        else:
+            edge_attr = edge_attr.reshape(plan.E, -1).contiguous()
+        if P.node_nf > (10 if self.node_discrete else 16) or P.edge_nf > (10 if self.edge_discrete else 16):
+            raise ValueError("too many feature columns for the fused gnn kernel")
+        y = torch.empty(plan.B, self.n_out, dtype=torch.float32, device=rho_sum.device)
+        with ops._span("sn_gnn_fused_f32"):
+            check(lib().sn_gnn_fused_f32(C.byref(P), ptr(x), x.shape[1], ptr(edge_attr),
+                                         edge_attr.shape[1] if edge_attr.dim() > 1 else 1, ptr(rho_sum),
+                                         ptr(plan.graph_ptr), ptr(plan.node_graph), ptr(plan.rowptr), ptr(plan.col),
+                                         ptr(plan.eperm), ptr(bins.node), ptr(bins.meta), bins.max_bins, ptr(y),
+                                         stream()), "sn_gnn_fused_f32")
+        return y

@@ -301,6 +301,10 @@ class SignNetGNN(nn.Module):
         ee = sn.eigen_encoder if (self.variant == "alchemy" and not sn.ignore_eigval) else None
         P["rho_fused"] = (fused.RhoPlan(sn.rho, ee, N_HEAD, LN_EPS)
                           if (self.use_fused and d <= 128 and len(sn.rho.transformer_layers) <= fused.RHO_MAX_LAYERS) else None)
+        P["gnn_fused"] = None
+        if self.use_fused and d <= 128 and len(g.convs) <= fused.GNN_MAX_LAYERS and self.cfg["n_out"] <= 16 \
+                and (self.cfg["node_feat"] or 0) <= 16 and (self.cfg["edge_feat"] or 0) <= 16:
+            P["gnn_fused"] = fused.GnnPlan(sn.rho.out, g, self.cfg["node_feat"], self.cfg["edge_feat"])
         P["phi"] = []
         for conv, norm in zip(sn.phi.convs, sn.phi.norms):
             P["phi"].append(dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0].bn),
@@ -354,6 +358,9 @@ class SignNetGNN(nn.Module):
             bins[0] = (ops.PHI_BIN_ROWS, rows_ub)
         if use_rho_fused:
             bins[1] = (fused.RHO_BIN_ROWS, rows_ub)
+        use_gnn_fused = P["gnn_fused"] is not None
+        if use_gnn_fused:
+            bins[2] = (fused.GNN_BIN_ROWS, data.batch.numel())
         plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=bins)
         if self.max_k:
             K = int(self.max_k)
@@ -407,6 +414,8 @@ class SignNetGNN(nn.Module):
                 z = ops.masked_linear(z, L["w2"], nv, K)
                 x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
             s = ops.slot_sum(x, N, K)
+        if use_gnn_fused and not return_stages:
+            return P["gnn_fused"].run(plan, plan.bins[2], data.x, data.edge_attr, s)
         pe = ops.masked_linear(s, P["rho_out"]["l"], scale=P["rho_out"]["bn"][0], shift=P["rho_out"]["bn"][1])
         if return_stages:
             stages["pos"] = pe
@@ -439,5 +448,8 @@ class SignNetGNN(nn.Module):
         y = ops.masked_linear(y, P["head"]["l1"])
         if return_stages:
             stages["y"] = y
+            if use_gnn_fused:
+                stages["y_gnn_fused"] = P["gnn_fused"].run(plan, plan.bins[2], data.x, data.edge_attr, s)
+                stages["gnn_bins_meta"] = plan.bins[2].meta
             return y, stages
         return y

@@ -43,7 +43,8 @@ def test_golden(name):
     # fused phi kernel: same quantity as the layer path and as the reference
     assert st["phi_bins_meta"].cpu().tolist()[1] == 0
     close(st["phi_fused"], fx.out["eval/phi_plus"] + fx.out["eval/phi_minus"], "fused phi(x)+phi(-x)")
-    assert st["rho_bins_meta"].cpu().tolist()[1] == 0
+    assert st["rho_bins_meta"].cpu().tolist()[1] == 0 and st["gnn_bins_meta"].cpu().tolist()[1] == 0
+    close(st["y_gnn_fused"], fx.out["eval/y"], "fused gnn output (from the layer-path slot sum)")
     close(st["rho_sum_fused"], st["rho_sum"], "fused rho slot-sum vs layer path")
     # and the default forward (fused stages) gives the reference output
     close(model(data), fx.out["eval/y"], "model output (fused path)")
@@ -117,4 +118,5 @@ def test_vs_oracle_real_widths(variant, ctor, feat, max_k):
     close(y, yref, "model output")
     close(st["phi_fused"], out["phi"], "fused phi(x)+phi(-x)")
     close(st["rho_sum_fused"], out["rho_sum"], "fused rho slot-sum")
+    close(st["y_gnn_fused"], yref, "fused gnn output")
     close(model(dd), yref, "model output (fused path)")
