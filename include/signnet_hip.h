@@ -268,7 +268,9 @@ int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* e
  * sum (sign_net.py:71), then GNN.forward (model.py:36-64 / core/model.py:44-79): input encoder
  * (DiscreteEncoder elements.py:31-37 or MLP(F,d,1)), Linear(cat[x,pos]), n_layers x [edge encoder, GINEConv
  * (pyg_gnn_wrapper.py:19-28), BatchNorm, ReLU, +previous], add pooling, 2-layer output encoder.
- * Bins: kind 2 (whole graphs), R = 64.  Matrices packed, vectors zero-padded to d_pad unless noted. */
+ * One workgroup per graph (graphs of more than SN_GNN_MAX_NODES = 64 nodes are skipped and flagged in
+ * status[3]; the caller then uses the layer-at-a-time entry points).  Matrices packed, vectors zero-padded
+ * to d_pad unless noted. */
 typedef struct {
   const float* etab[10];  /* discrete edge encoder: embedding tables [V, d] of layer l */
   const float* ew;        /* float edge encoder: weight [d_pad, F_e] row-major (NOT packed), zero padded rows */
@@ -284,13 +286,13 @@ typedef struct {
 } sn_gnn_layer;
 
 #define SN_GNN_MAX_LAYERS 16
-#define SN_GNN_BIN_ROWS 64
+#define SN_GNN_MAX_NODES 64
 typedef struct {
   int d, n_layers, n_out, reserved;
   int node_discrete, node_nf; /* discrete: number of int64 feature columns (<=10); float: F (<=16) */
   int edge_discrete, edge_nf;
   const float* ntab[10];      /* discrete node encoder tables [V, d] */
-  const float* nw;            /* float node encoder: packed [d, F] */
+  const float* nw;            /* float node encoder: weight [d_pad, F] row-major (NOT packed), zero padded rows */
   const float* n_scale;
   const float* n_shift;
   const float* rho_out_w;     /* sign_net.rho.out.0 packed [d,d] */
@@ -308,9 +310,9 @@ typedef struct {
 } sn_gnn_params;
 
 int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const void* edge_attr, int lde,
-                     const float* rho_sum, const int32_t* graph_ptr, const int32_t* node_graph,
-                     const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
-                     const int32_t* bin_node, const int32_t* meta, int64_t max_bins, float* y, void* stream);
+                     const float* rho_sum, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr,
+                     const int32_t* col, const int32_t* eperm, int32_t* status /* sn_batch_plan's */,
+                     float* y /* [B, n_out] */, void* stream);
 
 #ifdef __cplusplus
 }

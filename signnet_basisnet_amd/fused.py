@@ -152,7 +152,7 @@ class RhoPlan:
 
 
 GNN_MAX_LAYERS = 16
-GNN_BIN_ROWS = 64
+GNN_MAX_NODES = 64
 
 
 class _GnnLayer(C.Structure):
@@ -199,7 +199,10 @@ class GnnPlan:
             for f, e in enumerate(gnn.input_encoder.embeddings):
                 P.ntab[f] = hold(e.weight.detach())
         else:
-            P.nw = hold(ops.pack_weight(gnn.input_encoder.layers[0].weight.detach()))
+            w = gnn.input_encoder.layers[0].weight.detach()            # [d, F]
+            wp = torch.zeros(dp, w.shape[1], dtype=torch.float32, device=w.device)
+            wp[:d].copy_(w)
+            P.nw = hold(wp)
             s, h = ops.bn_fold(gnn.input_encoder.norms[0], dp)
             P.n_scale, P.n_shift = hold(s), hold(h)
         P.rho_out_w = hold(ops.pack_weight(rho_out[0].weight.detach()))
@@ -235,8 +238,8 @@ class GnnPlan:
             Lp.eps = hold(conv.layer.eps.detach())
         self.params = P
 
-    def run(self, plan: ops.GraphPlan, bins: ops.Bins, x, edge_attr, rho_sum):
-        """-> model output [B, n_out]."""
+    def run(self, plan: ops.GraphPlan, x, edge_attr, rho_sum):
+        """-> model output [B, n_out] (graphs with more than 64 nodes set plan.status[3])."""
         P = self.params
         if self.node_discrete:
             if x.dtype != torch.int64:
@@ -260,7 +263,6 @@ class GnnPlan:
         with ops._span("sn_gnn_fused_f32"):
             check(lib().sn_gnn_fused_f32(C.byref(P), ptr(x), x.shape[1], ptr(edge_attr),
                                          edge_attr.shape[1] if edge_attr.dim() > 1 else 1, ptr(rho_sum),
-                                         ptr(plan.graph_ptr), ptr(plan.node_graph), ptr(plan.rowptr), ptr(plan.col),
-                                         ptr(plan.eperm), ptr(bins.node), ptr(bins.meta), bins.max_bins, ptr(y),
-                                         stream()), "sn_gnn_fused_f32")
+                                         ptr(plan.graph_ptr), plan.B, ptr(plan.rowptr), ptr(plan.col),
+                                         ptr(plan.eperm), ptr(plan.status), ptr(y), stream()), "sn_gnn_fused_f32")
         return y

@@ -359,8 +359,6 @@ class SignNetGNN(nn.Module):
         if use_rho_fused:
             bins[1] = (fused.RHO_BIN_ROWS, rows_ub)
         use_gnn_fused = P["gnn_fused"] is not None
-        if use_gnn_fused:
-            bins[2] = (fused.GNN_BIN_ROWS, data.batch.numel())
         plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=bins)
         if self.max_k:
             K = int(self.max_k)
@@ -415,7 +413,7 @@ class SignNetGNN(nn.Module):
                 x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
             s = ops.slot_sum(x, N, K)
         if use_gnn_fused and not return_stages:
-            return P["gnn_fused"].run(plan, plan.bins[2], data.x, data.edge_attr, s)
+            return P["gnn_fused"].run(plan, data.x, data.edge_attr, s)
         pe = ops.masked_linear(s, P["rho_out"]["l"], scale=P["rho_out"]["bn"][0], shift=P["rho_out"]["bn"][1])
         if return_stages:
             stages["pos"] = pe
@@ -449,7 +447,6 @@ class SignNetGNN(nn.Module):
         if return_stages:
             stages["y"] = y
             if use_gnn_fused:
-                stages["y_gnn_fused"] = P["gnn_fused"].run(plan, plan.bins[2], data.x, data.edge_attr, s)
-                stages["gnn_bins_meta"] = plan.bins[2].meta
+                stages["y_gnn_fused"] = P["gnn_fused"].run(plan, data.x, data.edge_attr, s)
             return y, stages
         return y
