@@ -142,6 +142,12 @@ def main():
             info = ops.KERNEL_ROOFLINE.get(name, None)
             if info is not None:
                 roof = info(fl, WORKLOAD, host, mean_ms, per_step)
+        all_roofs = {}
+        for name, (launches, mean_ms) in ktimes.items():
+            f = ops.KERNEL_ROOFLINE.get(name)
+            if f is not None:
+                r = f(fl, WORKLOAD, host, mean_ms, launches / args.steps)
+                all_roofs[name] = {"achieved_tflops": r["achieved"], "frac": r["frac"]}
         out = {
             "metric": "graphs/sec SignNet+GINE forward, ZINC batch=128 k=16",
             "value": total_graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
@@ -151,7 +157,8 @@ def main():
                        "nodes": int(fl["N"]), "valid_rows": int(fl["M"]), "parallelism": f"graph-sharded dp{world}, no collective",
                        "gflop_per_step": fl["total"] / 1e9},
             "roofline": roof,
-            "kernels": {k: {"launches_per_step": v[0] / args.steps, "mean_us": 1e3 * v[1]} for k, v in ktimes.items()},
+            "kernels": {k: {"launches_per_step": v[0] / args.steps, "mean_us": 1e3 * v[1], **all_roofs.get(k, {})}
+                        for k, v in ktimes.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}

@@ -41,42 +41,54 @@ struct PhiStruct {
 };
 
 // out{P,M}[ot] = W (packed) x in{P,M}  — both signs share every weight fragment.
-// The weight fragments of output tile ot+1 are fetched (NT x 1 KiB coalesced wave-loads from L2) while the
-// 8*NT MFMAs of tile ot run; sched_barrier keeps the compiler from hoisting all NT*NT loads to the top
-// (which spills: 64 fragments = 256 VGPRs at NT = 8).
+// True double buffering of the weight fragments: while the 8*NT MFMAs of output tile ot run from buffer A, the
+// NT fragments of tile ot+1 (NT x 1 KiB coalesced wave-loads from L2) land in buffer B, and vice versa.  The
+// sched_barriers pin "issue the next tile's loads FIRST, then this tile's MFMAs" — without them the compiler
+// merges the two buffers and sinks the loads to the end of the MFMA block (measured: MFMA pipe 57 % busy).
+template <int NT>
+__device__ __forceinline__ void mfma_tile_pm(const float4 (&w)[NT], const f32x4 (&inP)[NT], const f32x4 (&inM)[NT],
+                                             f32x4& oP, f32x4& oM) {
+  f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kk = 0; kk < NT; ++kk) {
+    aP = mfma16(w[kk].x, inP[kk][0], aP);
+    aM = mfma16(w[kk].x, inM[kk][0], aM);
+    aP = mfma16(w[kk].y, inP[kk][1], aP);
+    aM = mfma16(w[kk].y, inM[kk][1], aM);
+    aP = mfma16(w[kk].z, inP[kk][2], aP);
+    aM = mfma16(w[kk].z, inM[kk][2], aM);
+    aP = mfma16(w[kk].w, inP[kk][3], aP);
+    aM = mfma16(w[kk].w, inM[kk][3], aM);
+  }
+  oP = aP;
+  oM = aM;
+}
+
 template <int NT>
 __device__ __forceinline__ void gemm_pm(const float* __restrict__ wp, const f32x4 (&inP)[NT], const f32x4 (&inM)[NT],
                                         f32x4 (&oP)[NT], f32x4 (&oM)[NT], int lane) {
   const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, NT * NT * 1024);
   const int voff = lane * 16;
-  float4 wc[NT], wn[NT];
+  float4 wA[NT], wB[NT];
 #pragma unroll
-  for (int kk = 0; kk < NT; ++kk) wc[kk] = wfrag(rs, voff, kk);
+  for (int kk = 0; kk < NT; ++kk) wA[kk] = wfrag(rs, voff, kk);
 #pragma unroll
-  for (int ot = 0; ot < NT; ++ot) {
+  for (int ot = 0; ot < NT; ot += 2) {
     if (ot + 1 < NT) {
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) wn[kk] = wfrag(rs, voff, (ot + 1) * NT + kk);
+      for (int kk = 0; kk < NT; ++kk) wB[kk] = wfrag(rs, voff, (ot + 1) * NT + kk);
     }
-    f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < NT; ++kk) {
-      const float4 w = wc[kk];
-      aP = mfma16(w.x, inP[kk][0], aP);
-      aM = mfma16(w.x, inM[kk][0], aM);
-      aP = mfma16(w.y, inP[kk][1], aP);
-      aM = mfma16(w.y, inM[kk][1], aM);
-      aP = mfma16(w.z, inP[kk][2], aP);
-      aM = mfma16(w.z, inM[kk][2], aM);
-      aP = mfma16(w.w, inP[kk][3], aP);
-      aM = mfma16(w.w, inM[kk][3], aM);
-    }
-    oP[ot] = aP;
-    oM[ot] = aM;
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tile_pm<NT>(wA, inP, inM, oP[ot], oM[ot]);
     __builtin_amdgcn_sched_barrier(0);
     if (ot + 1 < NT) {
+      if (ot + 2 < NT) {
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) wc[kk] = wn[kk];
+        for (int kk = 0; kk < NT; ++kk) wA[kk] = wfrag(rs, voff, (ot + 2) * NT + kk);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tile_pm<NT>(wB, inP, inM, oP[ot + 1], oM[ot + 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }

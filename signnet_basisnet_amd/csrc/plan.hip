@@ -3,6 +3,7 @@
 // the mask construction of SignNet.forward (sign_net.py:100-102) and PyG's per-call COO gather
 // (torch_geometric MessagePassing) — see include/signnet_hip.h.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sn {
 
@@ -288,6 +289,196 @@ __global__ void k_plan_sort(int64_t N, const int32_t* __restrict__ rowptr, int32
   }
 }
 
+// ---------------------------------------------------------------------------- single-workgroup plan (small batches)
+// Everything sn_batch_plan produces, in ONE launch of one 1024-thread workgroup with all intermediate state in
+// LDS — for batches with N <= 4096 nodes, E <= 10240 edges, B <= 512 graphs (the reference's batch sizes:
+// 128-256 molecules).  Five dependent launches cost ~60 us on MI355X; this path costs one.
+constexpr int PS_NMAX = 4096, PS_EMAX = 10240, PS_BMAX = 512, PS_T = 1024;
+
+__device__ __forceinline__ int ps_block_exscan(int v, int* part, int t) {   // exclusive scan of one int per thread
+  part[t] = v;
+  __syncthreads();
+  for (int off = 1; off < PS_T; off <<= 1) {
+    int a = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += a;
+    __syncthreads();
+  }
+  return part[t] - v;
+}
+
+__global__ __launch_bounds__(PS_T) void k_plan_small(const int64_t* __restrict__ batch, int N, int B,
+                                                     const int64_t* __restrict__ ei, int E, int kmax,
+                                                     int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
+                                                     int32_t* __restrict__ nvalid, int64_t* __restrict__ evoff,
+                                                     int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                     int32_t* __restrict__ eperm, int32_t* __restrict__ status, BinsOut bo,
+                                                     int32_t* __restrict__ bins_meta) {
+  extern __shared__ int sm[];
+  int* gp = sm;                      // [B+1]
+  int* deg = gp + (PS_BMAX + 1);     // [N]  in-degree, then fill cursor
+  int* rp = deg + PS_NMAX;           // [N+1]
+  int* lcol = rp + (PS_NMAX + 1);    // [E]
+  int* lperm = lcol + PS_EMAX;       // [E]
+  int* part = lperm + PS_EMAX;       // [PS_T]
+  int* bst = part + PS_T;            // [3][2][B] bin start state per graph
+  __shared__ int s_err, s_nmax, s_dmax, s_nb[3], s_berr[3];
+  const int t = threadIdx.x;
+  if (t == 0) { s_err = 0; s_nmax = 0; s_dmax = 0; }
+  if (t < 3) { s_nb[t] = 0; s_berr[t] = 1; }
+  for (int i = t; i < N; i += PS_T) deg[i] = 0;
+  for (int i = t; i <= B; i += PS_T) gp[i] = N;     // graphs after the last node (and gp[B]) start at N
+  __syncthreads();
+  // ---- nodes: graph ids, boundaries, validation
+  for (int i = t; i < N; i += PS_T) {
+    const long long g = batch[i];
+    const long long gprev = (i == 0) ? -1 : batch[i - 1];
+    if (g < 0 || g >= B) { atomicOr(&s_err, ERR_GRAPH_ID); node_graph[i] = 0; continue; }
+    node_graph[i] = (int)g;
+    if (gprev > g) atomicOr(&s_err, ERR_UNSORTED);
+    if (gprev < g) {
+      const long long lo = gprev < -1 ? 0 : gprev + 1;
+      for (long long k = lo; k <= g; ++k) gp[k] = i;   // ids in (gprev, g) are empty graphs starting here too
+    }
+  }
+  __syncthreads();
+  // ---- three waves walk the graphs for the bin packing while the others count in-degrees
+  const int wave = t >> 6, lane = t & 63;
+  if (wave >= 13) {
+    const int k = wave - 13;
+    if (lane == 0 && bins_meta) {
+      if (bo.node[k]) {
+        const int R = bo.R[k];
+        int bin = 0, fill = 0, err = 0, rows = 0;
+        for (int g = 0; g < B; ++g) {
+          const int n = gp[g + 1] - gp[g];
+          const int kg = (kmax > 0 && n > kmax) ? kmax : n;
+          int us, uc;
+          unit_shape(k, n, kg, us, uc);
+          bst[(2 * k) * PS_BMAX + g] = bin;
+          bst[(2 * k + 1) * PS_BMAX + g] = fill;
+          if (us <= 0 || uc <= 0) continue;
+          if (us > R) { err = 1; continue; }
+          rows += us * uc;
+          int a = idiv_small(R - fill, us);
+          if (a > uc) a = uc;
+          fill += a * us;
+          const int rem = uc - a;
+          if (rem > 0) {
+            const int per = idiv_small(R, us);
+            const int nb = idiv_small(rem + per - 1, per);
+            bin += nb;
+            fill = (rem - (nb - 1) * per) * us;
+          }
+        }
+        const int nbins = fill > 0 ? bin + 1 : bin;
+        const int berr = err | (nbins > bo.max_bins[k] ? 2 : 0);
+        bins_meta[4 * k] = nbins;
+        bins_meta[4 * k + 1] = berr;
+        bins_meta[4 * k + 2] = rows;
+        bins_meta[4 * k + 3] = R;
+        s_nb[k] = nbins;
+        s_berr[k] = berr;
+      } else {
+        bins_meta[4 * k] = 0; bins_meta[4 * k + 1] = 0; bins_meta[4 * k + 2] = 0; bins_meta[4 * k + 3] = 0;
+      }
+    }
+  } else {
+    for (int e = t; e < E; e += 13 * 64) {
+      const long long s = ei[e], d = ei[(long long)E + e];
+      if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(&s_err, ERR_EDGE_RANGE); continue; }
+      if (batch[s] != batch[d]) atomicOr(&s_err, ERR_EDGE_CROSS);
+      atomicAdd(&deg[d], 1);
+    }
+  }
+  __syncthreads();
+  // ---- rowptr = exclusive scan of deg ; evoff = exclusive scan of n^2
+  {
+    const int per = (N + PS_T - 1) / PS_T;
+    const int lo = t * per, hi = (lo + per < N) ? lo + per : N;
+    int s = 0, dmax = 0;
+    for (int i = lo; i < hi; ++i) { s += deg[i]; dmax = dmax > deg[i] ? dmax : deg[i]; }
+    atomicMax(&s_dmax, dmax);
+    int run = ps_block_exscan(s, part, t);
+    for (int i = lo; i < hi; ++i) { const int dg = deg[i]; rp[i] = run; deg[i] = run; run += dg; }
+    if (t == PS_T - 1) rp[N] = part[PS_T - 1];
+    __syncthreads();
+    const int n = (t < B) ? gp[t + 1] - gp[t] : 0;
+    atomicMax(&s_nmax, n);
+    const int ex = ps_block_exscan(n * n, part, t);
+    if (t < B) evoff[t] = ex;
+    if (t == PS_T - 1) evoff[B] = part[PS_T - 1];
+  }
+  __syncthreads();
+  // ---- fill the CSR segments (arbitrary arrival order), then sort each segment by edge id
+  for (int e = t; e < E; e += PS_T) {
+    const long long s = ei[e], d = ei[(long long)E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) continue;
+    const int p = atomicAdd(&deg[d], 1);
+    lcol[p] = (int)s;
+    lperm[p] = e;
+  }
+  __syncthreads();
+  for (int i = t; i < N; i += PS_T) {
+    const int lo = rp[i], hi = rp[i + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+      const int ke = lperm[a], kc = lcol[a];
+      int b = a - 1;
+      while (b >= lo && lperm[b] > ke) { lperm[b + 1] = lperm[b]; lcol[b + 1] = lcol[b]; --b; }
+      lperm[b + 1] = ke;
+      lcol[b + 1] = kc;
+    }
+  }
+  __syncthreads();
+  // ---- write out
+  for (int i = t; i <= N; i += PS_T) rowptr[i] = rp[i];
+  for (int i = t; i < E; i += PS_T) { col[i] = lcol[i]; eperm[i] = lperm[i]; }
+  for (int i = t; i <= B; i += PS_T) graph_ptr[i] = gp[i];
+  for (int i = t; i < N; i += PS_T) {
+    const long long g = batch[i];
+    int nv = 0;
+    if (g >= 0 && g < B) { const int n = gp[g + 1] - gp[g]; nv = (kmax > 0 && n > kmax) ? kmax : n; }
+    nvalid[i] = nv;
+  }
+  if (t == 0) { status[ST_ERR] = s_err; status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
+  // ---- bin rows: padding first (tail of every bin is rewritten below where a unit lands), then one wave per graph
+  for (int k = 0; k < 3; ++k) {
+    if (!bo.node[k] || s_berr[k] != 0) continue;
+    const int R = bo.R[k];
+    const int nb = s_nb[k];
+    for (int i = t; i < nb * R; i += PS_T) { bo.node[k][i] = -1; bo.slot[k][i] = -1; }
+  }
+  __syncthreads();
+  for (int g = wave; g < B; g += PS_T / 64) {
+    const int gs = gp[g], n = gp[g + 1] - gs;
+    const int kg = (kmax > 0 && n > kmax) ? kmax : n;
+    for (int k = 0; k < 3; ++k) {
+      if (!bo.node[k] || s_berr[k] != 0) continue;
+      const int R = bo.R[k];
+      int us, uc;
+      unit_shape(k, n, kg, us, uc);
+      if (us <= 0 || uc <= 0 || us > R) continue;
+      const int b0 = bst[(2 * k) * PS_BMAX + g], f0 = bst[(2 * k + 1) * PS_BMAX + g];
+      int a = idiv_small(R - f0, us);
+      if (a > uc) a = uc;
+      const int per = idiv_small(R, us);
+      for (int i = lane; i < us * uc; i += 64) {
+        const int u = i / us, r = i - u * us;
+        int bin, row0;
+        if (u < a) { bin = b0; row0 = f0 + u * us; }
+        else { const int v = u - a; bin = b0 + 1 + v / per; row0 = (v % per) * us; }
+        int node, slot;
+        if (k == 0) { node = gs + r; slot = u; }
+        else if (k == 1) { node = gs + u; slot = r; }
+        else { node = gs + r; slot = 0; }
+        const long long o = (long long)bin * R + row0 + r;
+        bo.node[k][o] = node;
+        bo.slot[k][o] = slot;
+      }
+    }
+  }
+}
+
 // Eigen-data packing (to_dense_list_EVD, transform.py:52-61).
 __global__ void k_pack_eig(const float* __restrict__ ev, const float* __restrict__ es,
                            const int32_t* __restrict__ graph_ptr, const int32_t* __restrict__ node_graph,
@@ -335,6 +526,21 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
     }
   }
   hipStream_t st = (hipStream_t)stream;
+  static const bool small_path = getenv("SN_PLAN_SMALL") != nullptr;   // experimental: measured slower (124 vs 61 us)
+  if (small_path && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX && N > 0) {
+    const size_t lds = (size_t)((PS_BMAX + 1) + PS_NMAX + (PS_NMAX + 1) + 2 * PS_EMAX + PS_T + 6 * PS_BMAX) * sizeof(int);
+    static bool init = false;
+    if (!init) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess)
+        return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit to %zu", lds);
+      init = true;
+    }
+    hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(PS_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E, kmax, graph_ptr,
+                       node_graph, nvalid, evoff, rowptr, col, eperm, status, bo, bins_meta);
+    SN_CHECK_LAUNCH("sn_batch_plan");
+    return SN_OK;
+  }
   int32_t* deg = scratch;                       // [N]
   int32_t* binstate = scratch + ((N + 3) / 4) * 4;  // [3][2][B]
   const int T = 256;

@@ -390,14 +390,37 @@ def segment_pool(x, plan: GraphPlan, mode="add"):
 
 
 # ----------------------------------------------------------------------------- roofline accounting (bench.py)
-def _roof_linear(fl, wl, host, mean_ms, per_step):
-    """All dense contractions of the layer-at-a-time path go through sn_masked_linear_f32
-    (attention's K x K part excepted): achieved = contraction flops per step / time per step in it."""
-    flops = fl["total"] - wl["nl_rho"] * 4 * sum(n * min(n, wl["k"]) ** 2 for n in host.sizes) * wl["hidden"]
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec
+
+
+def _mfma_roof(label, flops, mean_ms, per_step):
     t = mean_ms * per_step * 1e-3
     ach = flops / t / 1e12
-    return {"kernel": "sn_masked_linear_f32 (k_linear, all launches of a step)", "bound": "mfma", "achieved": ach,
-            "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None}
+    return {"kernel": label, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "flops_per_launch": flops / per_step,
+            "mean_launch_us": mean_ms * 1e3}
 
 
-KERNEL_ROOFLINE = {"sn_masked_linear_f32": _roof_linear}
+def _roof_linear(fl, wl, host, mean_ms, per_step):
+    """Layer path: all dense contractions go through sn_masked_linear_f32 (attention's K x K part excepted)."""
+    flops = fl["total"] - wl["nl_rho"] * 4 * sum(n * min(n, wl["k"]) ** 2 for n in host.sizes) * wl["hidden"]
+    return _mfma_roof("sn_masked_linear_f32 (k_linear, all launches of a step)", flops, mean_ms, per_step)
+
+
+def _roof_phi(fl, wl, host, mean_ms, per_step):
+    """Fused phi: algorithmic flops = 2 signs x (L-1) layers x 2 Linear x 2*d*d per VALID (node, slot) row
+    (SURVEY.md §8(d)); padding rows of the work bins are not counted."""
+    return _mfma_roof("sn_phi_fused_f32 (k_phi_fused)", fl["phi"], mean_ms, per_step)
+
+
+def _roof_rho(fl, wl, host, mean_ms, per_step):
+    return _mfma_roof("sn_rho_fused_f32 (k_rho_fused)", fl["rho"] - 2 * fl["N"] * wl["hidden"] ** 2, mean_ms, per_step)
+
+
+def _roof_gnn(fl, wl, host, mean_ms, per_step):
+    return _mfma_roof("sn_gnn_fused_f32 (k_gnn_coop)", fl["gnn"] + 2 * fl["N"] * wl["hidden"] ** 2, mean_ms, per_step)
+
+
+KERNEL_ROOFLINE = {"sn_masked_linear_f32": _roof_linear, "sn_phi_fused_f32": _roof_phi, "sn_rho_fused_f32": _roof_rho,
+                   "sn_gnn_fused_f32": _roof_gnn}

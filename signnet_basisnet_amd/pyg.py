@@ -368,7 +368,9 @@ class SignNetGNN(nn.Module):
         N, d = plan.N, self.cfg["n_hid"]
         nv = plan.nvalid
         want_vals = "eig" in P
-        x0, s0 = ops.pack_eig(plan, data.eigen_vectors, data.eigen_values if want_vals else None, K, want_vals)
+        x0 = s0 = None
+        if return_stages or not (use_phi_fused and use_rho_fused):     # only the layer path needs the dense [N,K] blocks
+            x0, s0 = ops.pack_eig(plan, data.eigen_vectors, data.eigen_values if want_vals else None, K, want_vals)
         stages = {}
 
         # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)

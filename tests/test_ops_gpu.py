@@ -50,6 +50,27 @@ def test_plan(batch):
         assert col[seg].tolist() == src[ids].tolist()
 
 
+def test_plan_large_batch_multikernel_path(dev):
+    """N > 4096 takes the five-launch path; same contract."""
+    from signnet_basisnet_amd import ops
+    data = synth.make_batch(260, seed=6)
+    d = synth.batch_to(data, dev)
+    n = torch.tensor(data.sizes)
+    assert int(n.sum()) > 4096
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 16, bins={0: (64, int((n * n.clamp(max=16)).sum()))})
+    assert plan.check()[0] == 0
+    gp = torch.cat([torch.zeros(1, dtype=torch.long), n.cumsum(0)])
+    assert plan.graph_ptr.cpu().tolist() == gp.tolist()
+    assert plan.nvalid.cpu().tolist() == n.clamp(max=16)[data.batch].tolist()
+    rowptr, col, eperm = plan.rowptr.cpu(), plan.col.cpu(), plan.eperm.cpu()
+    src, dst = data.edge_index
+    order = torch.argsort(dst * (dst.numel() + 1) + torch.arange(dst.numel()))      # by dst, then edge id
+    assert eperm.tolist() == order.tolist() and col.tolist() == src[order].tolist()
+    nb, err, rows = plan.bins[0].meta.cpu().tolist()[:3]
+    assert err == 0 and rows == int((n * n.clamp(max=16)).sum())
+    assert int((plan.bins[0].node[:nb * 64] >= 0).sum()) == rows
+
+
 def test_plan_kmax_and_errors(dev):
     from signnet_basisnet_amd import ops
     data = synth.make_batch(4, seed=2, sizes=[3, 20, 7, 12])
