@@ -91,18 +91,12 @@ def main():
     if world != args.gpus:
         if args.gpus != 1 and world == 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dist = dist_
+    from signnet_basisnet_amd import dist as D
+    from signnet_basisnet_amd import ops, synth
+    dist = D.init_process_group("nccl") if world > 1 else None      # "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    from signnet_basisnet_amd import ops, synth
     # each rank owns its shard of the global batch: graphs [rank*B, (rank+1)*B)
     host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2 + 1000 * rank)
     data = synth.batch_to(host, dev)
@@ -126,10 +120,7 @@ def main():
                 model(data)
         sync_all()
         dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = D.max_over_ranks(dt, dist, dev)
 
     if rank == 0:
         total_graphs = WORKLOAD["B"] * world * args.steps

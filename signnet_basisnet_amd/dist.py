@@ -1,0 +1,71 @@
+"""Multi-GPU driver pieces: one process per GPU, the batch sharded by graph, no data-path collective.
+
+The forward of SignNet+GINE never mixes graphs (every aggregation is within a graph, pooling is per
+graph, eval-mode BatchNorm uses fixed statistics — SURVEY.md §8(e)), so N ranks simply own disjoint
+contiguous ranges of graphs.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is used
+only for the start/stop barrier and the max-over-ranks step time; a gradient all-reduce would go here
+once the backward exists.
+"""
+from __future__ import annotations
+
+import os
+import types
+
+import torch
+
+
+def shard_range(num_graphs: int, rank: int, world: int):
+    """Contiguous, balanced [lo, hi) range of graph ids owned by `rank`."""
+    base, rem = divmod(num_graphs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(data, rank: int, world: int):
+    """Slice a collated batch (the duck-typed layout of SURVEY.md §8(b)) down to this rank's graphs.
+    Pure indexing on the host; node / edge ids are re-based to the shard."""
+    B = int(data.num_graphs)
+    lo, hi = shard_range(B, rank, world)
+    sizes = list(data.sizes) if hasattr(data, "sizes") else torch.bincount(data.batch, minlength=B).tolist()
+    nstart = sum(sizes[:lo])
+    nend = nstart + sum(sizes[lo:hi])
+    vstart = sum(s * s for s in sizes[:lo])
+    vend = vstart + sum(s * s for s in sizes[lo:hi])
+    src = data.edge_index[0]
+    emask = (src >= nstart) & (src < nend)
+    out = types.SimpleNamespace(
+        x=data.x[nstart:nend], edge_index=data.edge_index[:, emask] - nstart, edge_attr=data.edge_attr[emask],
+        batch=data.batch[nstart:nend] - lo, eigen_values=data.eigen_values[nstart:nend],
+        eigen_vectors=data.eigen_vectors[vstart:vend], num_graphs=hi - lo, num_nodes=nend - nstart)
+    out.sizes = sizes[lo:hi]
+    return out
+
+
+def init_process_group(backend: str):
+    """Env-driven init (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run)."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+    kw = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, **kw)
+    return dist
+
+
+def max_over_ranks(value: float, dist, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_outputs(y: torch.Tensor, dist):
+    """All ranks' [B_r, n_out] outputs concatenated in rank order (graph order)."""
+    if dist is None:
+        return y
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, y.cpu())
+    return torch.cat(parts, 0)

@@ -1,0 +1,69 @@
+"""CPU: host-side logic of the product package (no kernels run here)."""
+import pytest
+import torch
+
+import golden_util as G
+
+
+@pytest.mark.parametrize("name", G.PYG_CASES)
+def test_state_dict_layout_matches_reference(name):
+    """Same keys and shapes as the reference modules' state_dict, so reference weights load."""
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    fx = G.load(name)
+    c = [None if v < 0 else int(v) for v in fx.meta["ctor"]]
+    m = SignNetGNN(*c, variant=str(fx.meta["variant"]))
+    ref = {str(k): tuple(int(s) for s in str(shp).split(",") if s) for k, shp in zip(fx.meta["sd_keys"], fx.meta["sd_shapes"])}
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == ref
+    m.load_state_dict(G.full_state_dict(fx))        # strict
+
+
+def test_reference_constructor_signatures():
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    a = SignNetGNN(6, 4, 108, 12, 8, 16, nl_rho=8)                  # main_alchemy.py:35 (nl_rho is ignored -> 4)
+    assert len(a.sign_net.rho.transformer_layers) == 4 and len(a.sign_net.phi.convs) == 8 and len(a.gnn.convs) == 16
+    g = SignNetGNN(None, None, 128, 1, 4, 6, variant="gine")         # train/zinc.py:33-37
+    assert len(g.sign_net.rho.transformer_layers) == 1
+    with pytest.raises(ValueError):
+        SignNetGNN(6, 4, 108, 12, 8, 16, gnn_type="GATConv")
+    with pytest.raises(ValueError):
+        SignNetGNN(None, None, 30, 1, 2, 2, variant="gine")         # 30 not divisible by the 4 heads
+
+
+def test_no_cpu_fallback():
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    m = SignNetGNN(None, None, 16, 1, 2, 2, variant="gine").eval()
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(synth.make_batch(3, seed=0))
+
+
+def test_synth_batches_are_deterministic_and_well_formed():
+    from signnet_basisnet_amd import synth
+    a, b = synth.make_batch(8, seed=5), synth.make_batch(8, seed=5)
+    assert torch.equal(a.edge_index, b.edge_index) and torch.equal(a.eigen_vectors, b.eigen_vectors)
+    n = torch.tensor(a.sizes)
+    assert a.batch.numel() == int(n.sum()) and a.eigen_vectors.numel() == int((n * n).sum())
+    assert (a.batch[1:] >= a.batch[:-1]).all()
+    src, dst = a.edge_index
+    assert (a.batch[src] == a.batch[dst]).all() and (src != dst).all()
+    key = src * a.batch.numel() + dst
+    assert key.unique().numel() == key.numel()                       # no duplicate edges
+    rev = dst * a.batch.numel() + src
+    assert set(key.tolist()) == set(rev.tolist())                    # symmetric
+    # eigenvectors really are eigenvectors of the sym-normalised Laplacian of graph 0
+    n0 = a.sizes[0]
+    V = a.eigen_vectors[:n0 * n0].view(n0, n0)
+    torch.testing.assert_close(V.T @ V, torch.eye(n0), rtol=0, atol=1e-4)
+    pe = synth.dgl_pos_enc(a, 8)
+    assert pe.shape == (a.batch.numel(), 8)
+
+
+def test_shard_ranges_cover_everything():
+    from signnet_basisnet_amd.dist import shard_range
+    for B in (1, 7, 128, 1024):
+        for W in (1, 2, 3, 8):
+            rs = [shard_range(B, r, W) for r in range(W)]
+            assert rs[0][0] == 0 and rs[-1][1] == B
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(W - 1))
+            assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
