@@ -173,6 +173,15 @@ int sn_embedding_sum_f32(const int64_t* idx, int ldi, int nf, int64_t R, const f
 int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32_t* graph_ptr, int mode,
                         float* out, void* stream);
 
+/* BasisNet: the five equivariant 2->1 contractions of a stack of n x n matrices (eigenspace projectors).
+ * Replaces contractions_2_to_1 (LearningFilters/ign.py:344-374, normalization 'inf'), called from
+ * layer_2_to_1.forward (ign.py:117-128):  ops[b, i, :] = [X_ii, tr(X)/n, rowsum_i/n, colsum_i/n, sum(X)/n^2],
+ * written row-major [b, n, 5] so that the following einsum (ign.py:123) is a 5 -> S masked_linear over the
+ * (b, i) rows.  HBM-bound: X is read exactly once (4*b*n*n bytes).
+ * scratch: sn_ign_contract_scratch_floats(b, n) floats. */
+int64_t sn_ign_contract_scratch_floats(int64_t b, int n);
+int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, float* scratch, void* stream);
+
 /* ==========================================================================================
  * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).
  *

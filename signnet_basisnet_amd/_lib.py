@@ -41,6 +41,7 @@ SIGNATURES = {
     "sn_slot_sum_f32": [_p, _l, _i, _i, _p, _p],
     "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), _i, _p, _p],
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
+    "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],
 }
 _SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
 
@@ -66,6 +67,8 @@ def lib():
         L.sn_packed_weight_floats.restype = C.c_int64
         L.sn_bins_bound.argtypes = [_l, _i]
         L.sn_bins_bound.restype = C.c_int64
+        L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]
+        L.sn_ign_contract_scratch_floats.restype = C.c_int64
         if L.sn_version() != 1:
             raise RuntimeError("libsignnet_hip.so ABI version mismatch")
         _lib = L

@@ -1,0 +1,211 @@
+"""BasisNet / LearningFilters modules (drop-in `nn.Module` surface, HIP forward).
+
+Mirrors LearningFilters/ign.py:9-39 (IGN2to1 with layer_2_to_1 :88-128 and layer_1_to_1 :174-214),
+signbasisnet.py:11-41 (SignPlus, IGNBasisInv) and models.py:58-113 (EqDeepSetsEncoder) — same constructors,
+same forward contracts:
+    IGNBasisInv(mult_lst, in_channels, hidden_channels).forward(proj [b,1,n,n], mult) -> [b, mult, n]
+    EqDeepSetsEncoder(...).forward(x [set, F] or [b, set, F]) -> [..., out]
+    SignPlus(model).forward(v) = model(v) + model(-v)
+All arithmetic runs in libsignnet_hip.so (the 2->1 contractions in sn_ign_contract_2to1_f32, every Linear in
+sn_masked_linear_f32, means / BatchNorm statistics in the segment / column-statistics kernels).  No CPU path.
+
+Difference from the reference worth knowing: the reference's equivariant-layer
+coefficients are `nn.Parameter(...).to(device)`, i.e. NOT registered parameters when the device differs from
+the default; here `coeffs` / `bias` are ordinary registered Parameters with the reference's initialisation.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BN_EPS = 1e-5
+
+
+class layer_2_to_1(nn.Module):
+    def __init__(self, input_depth, output_depth):
+        super().__init__()
+        if input_depth != 1:
+            raise ValueError("HIP IGN2to1: the 2->1 layer takes the single-channel projector stack (in_channels = 1)")
+        self.basis_dimension = 5
+        self.coeffs = nn.Parameter(torch.randn(input_depth, output_depth, 5) * math.sqrt(2.0) / (input_depth + output_depth))
+        self.bias = nn.Parameter(torch.zeros(1, output_depth, 1))
+
+
+class layer_1_to_1(nn.Module):
+    def __init__(self, input_depth, output_depth):
+        super().__init__()
+        self.basis_dimension = 2
+        self.coeffs = nn.Parameter(torch.randn(input_depth, output_depth, 2) * math.sqrt(2.0) / (input_depth + output_depth))
+        self.bias = nn.Parameter(torch.zeros(1, output_depth, 1))
+
+
+def _lin(W, b):
+    W = W.detach().contiguous()
+    return ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], None if b is None else b.detach().reshape(-1).contiguous())
+
+
+class IGN2to1(nn.Module):
+    """batch x 1 x n x n -> batch x out x n   (ign.py:9-39).  `num_layers` is ignored as in the reference."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers=1, device=None, use_bn=True):
+        super().__init__()
+        if not use_bn:
+            raise ValueError("HIP IGN2to1 supports use_bn=True (the reference default)")
+        self.bns = nn.ModuleList([nn.BatchNorm1d(hidden_channels) for _ in range(4)])   # 4 created, 3 used (ign.py:12-25)
+        self.equi_layers = nn.ModuleList([layer_2_to_1(in_channels, hidden_channels),
+                                          layer_1_to_1(hidden_channels, hidden_channels),
+                                          layer_1_to_1(hidden_channels, hidden_channels)])
+        self.fc1 = nn.Linear(hidden_channels, hidden_channels)
+        self.fc2 = nn.Linear(hidden_channels, out_channels)
+        self._prep = None
+
+    def train(self, mode=True):
+        self._prep = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def _prepare(self):
+        e0, e1, e2 = self.equi_layers
+        P = {}
+        # einsum('dsb,ndbi->nsi'): out[s] = sum_k coeffs[0,s,k] * ops[k]  -> weight [S, 5]
+        P["l0"] = _lin(e0.coeffs.detach()[0], e0.bias)
+        for name, e in (("l1", e1), ("l2", e2)):
+            c = e.coeffs.detach()                                              # [D, S, 2]
+            W = torch.cat([c[:, :, 0].t(), c[:, :, 1].t()], dim=1)             # [S, 2D]: [identity | mean] blocks
+            P[name] = _lin(W, e.bias)
+        P["bn"] = [ops.bn_fold(self.bns[i]) for i in range(3)]
+        P["fc1"] = _lin(self.fc1.weight, self.fc1.bias)
+        P["fc2"] = _lin(self.fc2.weight, self.fc2.bias)
+        return P
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+        ops.require_cuda(x)
+        if self._prep is None:
+            self._prep = self._prepare()
+        P = self._prep
+        b, n = x.shape[0], x.shape[-1]
+        o = ops.ign_contract_2to1(x.contiguous())                                          # [b, n, 5]
+        h = ops.masked_linear(o.view(b * n, 5), P["l0"], relu_pre=True, scale=P["bn"][0][0], shift=P["bn"][0][1])
+        seg = torch.arange(0, b * n + 1, n, dtype=torch.int32, device=x.device)             # rows of matrix i: [i*n, (i+1)*n)
+        segplan = _SegPlan(b, seg)
+        for li, name in ((1, "l1"), (2, "l2")):
+            m = ops.segment_pool(h, segplan, "mean")                                       # [b, H]   sum_n h / n (ign.py:405-414)
+            cat = torch.cat([h.view(b, n, -1), m.unsqueeze(1).expand(b, n, m.shape[1])], dim=-1).contiguous()
+            h = ops.masked_linear(cat.view(b * n, -1), P[name], relu_pre=True, scale=P["bn"][li][0], shift=P["bn"][li][1])
+        h = ops.masked_linear(h, P["fc1"], relu=True)
+        y = ops.masked_linear(h, P["fc2"])                                                 # [b*n, out]
+        return y.view(b, n, -1).transpose(2, 1).contiguous()                               # [b, out, n]
+
+
+class _SegPlan:
+    """Just enough of a GraphPlan for ops.segment_pool: equal-length row segments."""
+
+    def __init__(self, B, graph_ptr):
+        self.B, self.graph_ptr = B, graph_ptr
+
+
+class IGNBasisInv(nn.Module):
+    """One IGN2to1 per eigenvalue multiplicity (signbasisnet.py:23-41)."""
+
+    def __init__(self, mult_lst, in_channels, hidden_channels=16, num_layers=2):
+        super().__init__()
+        self.encs = nn.ModuleList()
+        self.mult_to_idx = {}
+        for i, mult in enumerate(mult_lst):
+            self.encs.append(IGN2to1(1, hidden_channels, mult, num_layers=num_layers))
+            self.mult_to_idx[mult] = i
+
+    def forward(self, proj, mult):
+        return self.encs[self.mult_to_idx[mult]](proj)
+
+
+class EqDeepSetsEncoder(nn.Module):
+    """Equivariant DeepSets over the second-to-last axis (models.py:58-113).  BatchNorm here has
+    track_running_stats=False, i.e. it always normalises with the statistics of the current input."""
+
+    def __init__(self, in_channels, hidden_channels=32, out_channels=1, num_layers=3, use_bn=False, use_ln=False, dropout=0.0,
+                 activation="relu"):
+        super().__init__()
+        if use_ln or activation != "relu":
+            raise ValueError("HIP EqDeepSetsEncoder: relu / no LayerNorm only (what the reference instantiates)")
+        self.lins1, self.lins2 = nn.ModuleList(), nn.ModuleList()
+        if use_bn:
+            self.bns = nn.ModuleList()
+        dims = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        for i in range(num_layers):
+            self.lins1.append(nn.Linear(dims[i], dims[i + 1]))
+            self.lins2.append(nn.Linear(dims[i], dims[i + 1]))
+            if use_bn and i < num_layers - 1:
+                self.bns.append(nn.BatchNorm1d(dims[i + 1], track_running_stats=False))
+        self.use_bn = use_bn
+
+    def forward(self, x, *args):
+        ops.require_cuda(x)
+        shp = x.shape
+        three_d = x.dim() == 3
+        if x.dim() not in (2, 3):
+            raise ValueError("invalid x dimension")
+        b, n = (shp[0], shp[1]) if three_d else (1, shp[0])
+        h = x.contiguous().float().view(b * n, shp[-1])
+        seg = _SegPlan(b, torch.arange(0, b * n + 1, n, dtype=torch.int32, device=x.device))
+        L = len(self.lins1)
+        for i in range(L):
+            l1, l2 = self.lins1[i], self.lins2[i]
+            m = ops.segment_pool(h, seg, "mean")                                              # x.mean(dim=-2)
+            cat = torch.cat([h.view(b, n, -1), m.unsqueeze(1).expand(b, n, m.shape[1])], dim=-1).contiguous()
+            W = torch.cat([l1.weight.detach(), l2.weight.detach()], dim=1).contiguous()       # x1 + x2 as one Linear
+            bias = ops.masked_affine(l1.bias.detach().view(1, -1).contiguous(), residual=l2.bias.detach().view(1, -1).contiguous())
+            pl = ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], bias.view(-1))
+            last = i == L - 1
+            h = ops.masked_linear(cat.view(b * n, -1), pl, relu=not last)
+            if self.use_bn and not last:
+                bn = self.bns[i]
+                mean, var, _ = ops.masked_colstats(h)                                         # stats over all b*n rows
+                sc, sh = ops.bn_fold_stats(bn.weight.detach(), bn.bias.detach(), mean, var, bn.eps)
+                h = ops.masked_affine(h, scale=sc, shift=sh)
+        return h.view(*shp[:-1], -1)
+
+
+class SignPlus(nn.Module):
+    """model(v) + model(-v)   (signbasisnet.py:11-20; the `x=` side-feature form is not used by the reference's
+    entry script — it raises NotImplementedError there, training.py:111)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, v, *args, x=None):
+        if x is not None:
+            raise NotImplementedError("SignPlus with side features is not reachable in the reference (training.py:111)")
+        v = v.contiguous().float()
+        neg = ops.masked_affine(v.view(-1, v.shape[-1]), scale=torch.full((v.shape[-1],), -1.0, device=v.device),
+                                shift=torch.zeros(v.shape[-1], device=v.device)).view(v.shape)
+        a, b = self.model(v), self.model(neg)
+        return ops.masked_affine(a.contiguous().view(-1, a.shape[-1]), residual=b.contiguous().view(-1, b.shape[-1])).view(a.shape)
+
+
+def group_eigenspaces(eigvals, eigvecs, decimals=5):
+    """Host-side restatement of the module-level preprocessing of LearningFilters/training.py:47-73 (run once per
+    graph, not part of the forward): projectors V_i V_i^T of the eigenspaces, stacked by multiplicity."""
+    N = eigvecs.shape[0]
+    rounded = torch.round(eigvals * 10 ** decimals) / (10 ** decimals)
+    _, counts = rounded.unique(return_counts=True)
+    sections = torch.cumsum(counts, 0).cpu()
+    spaces = torch.tensor_split(eigvecs, sections, dim=1)[:-1]
+    groups = {}
+    for V, c in zip(spaces, counts.tolist()):
+        groups.setdefault(c, []).append((V @ V.T).reshape(1, 1, N, N))
+    return {m: torch.cat(ps, 0) for m, ps in sorted(groups.items())}

@@ -696,3 +696,104 @@ extern "C" int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32
   SN_CHECK_LAUNCH("sn_segment_pool_f32");
   return SN_OK;
 }
+
+// ============================================================================ IGN 2->1 contractions (BasisNet)
+// Replaces contractions_2_to_1 (LearningFilters/ign.py:344-374, normalization 'inf') for X [b, n, n]:
+//   ops[b, i, :] = [ X_ii, tr(X)/n, rowsum_i/n, colsum_i/n, sum(X)/n^2 ]        (row-major [b, n, 5])
+// HBM-bound: every X element is read exactly once (4*b*n^2 bytes).  Stage A: one workgroup per (matrix,
+// 32-row strip) — row sums finished in the block, column sums as per-strip partials (deterministic, no float
+// atomics).  Stage B: one workgroup per matrix folds the partials.
+namespace sn {
+constexpr int IGN_STRIP = 32;
+
+__global__ __launch_bounds__(256) void k_ign_rowcol(const float* __restrict__ X, int n, int nstrips,
+                                                    float* __restrict__ rowsum /* [b,n] */, float* __restrict__ diag /* [b,n] */,
+                                                    float* __restrict__ colpart /* [b,nstrips,n] */) {
+  __shared__ float red[4];
+  const int b = blockIdx.x / nstrips, st = blockIdx.x - b * nstrips;
+  const int r0 = st * IGN_STRIP, r1 = (r0 + IGN_STRIP < n) ? r0 + IGN_STRIP : n;
+  const float* Xb = X + (int64_t)b * n * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c0 = 0; c0 < n; c0 += 256 * 4) {          // column panels of 1024
+    float ca[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+      float rs = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + k * 256 + tid;
+        if (c < n) {
+          const float v = Xb[(int64_t)r * n + c];
+          ca[k] += v;
+          rs += v;
+          if (c == r) diag[(int64_t)b * n + r] = v;
+        }
+      }
+      rs = wave_sum(rs);
+      if (lane == 0) red[wave] = rs;
+      __syncthreads();
+      if (tid == 0) {
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        if (c0 == 0) rowsum[(int64_t)b * n + r] = t; else rowsum[(int64_t)b * n + r] += t;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + k * 256 + tid;
+      if (c < n) colpart[((int64_t)b * nstrips + st) * n + c] = ca[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ign_finish(const float* __restrict__ rowsum, const float* __restrict__ diag,
+                                                    const float* __restrict__ colpart, int n, int nstrips,
+                                                    float* __restrict__ ops /* [b,n,5] */) {
+  __shared__ float red[2][4];
+  __shared__ float tot[2];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float tsum = 0.f, dsum = 0.f;
+  for (int c = tid; c < n; c += 256) {
+    float cs = 0.f;
+    for (int s = 0; s < nstrips; ++s) cs += colpart[((int64_t)b * nstrips + s) * n + c];
+    ops[((int64_t)b * n + c) * 5 + 3] = cs / (float)n;
+    tsum += cs;
+    dsum += diag[(int64_t)b * n + c];
+  }
+  tsum = wave_sum(tsum);
+  dsum = wave_sum(dsum);
+  if (lane == 0) { red[0][wave] = tsum; red[1][wave] = dsum; }
+  __syncthreads();
+  if (tid == 0) {
+    tot[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    tot[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+  __syncthreads();
+  const float total = tot[0] / ((float)n * (float)n), tr = tot[1] / (float)n;
+  for (int c = tid; c < n; c += 256) {
+    float* o = ops + ((int64_t)b * n + c) * 5;
+    o[0] = diag[(int64_t)b * n + c];
+    o[1] = tr;
+    o[2] = rowsum[(int64_t)b * n + c] / (float)n;
+    o[4] = total;
+  }
+}
+}  // namespace sn
+
+extern "C" int64_t sn_ign_contract_scratch_floats(int64_t b, int n) {
+  return b * (2 * (int64_t)n + sn::cdiv(n, sn::IGN_STRIP) * (int64_t)n);
+}
+
+extern "C" int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, float* scratch, void* stream) {
+  SN_REQUIRE(X && ops_out && scratch && b >= 0 && n > 0, "sn_ign_contract_2to1_f32: bad arguments");
+  if (b == 0) return SN_OK;
+  const int nstrips = (int)sn::cdiv(n, sn::IGN_STRIP);
+  SN_REQUIRE(b * nstrips < (1ll << 31), "sn_ign_contract_2to1_f32: too many workgroups");
+  float* rowsum = scratch;
+  float* diag = scratch + b * n;
+  float* colpart = scratch + 2 * b * n;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sn::k_ign_rowcol, dim3((unsigned)(b * nstrips)), dim3(256), 0, st, X, n, nstrips, rowsum, diag, colpart);
+  hipLaunchKernelGGL(sn::k_ign_finish, dim3((unsigned)b), dim3(256), 0, st, rowsum, diag, colpart, n, nstrips, ops_out);
+  SN_CHECK_LAUNCH("sn_ign_contract_2to1_f32");
+  return SN_OK;
+}

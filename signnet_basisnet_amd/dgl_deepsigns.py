@@ -1,0 +1,223 @@
+"""DGL-tree sign-invariant networks (drop-in `nn.Module` surface, HIP forward).
+
+Mirrors GraphPrediction/layers/deepsigns.py:33-86 (GINDeepSigns, MaskedGINDeepSigns), layers/gnns.py:81-114 (GIN),
+layers/mlp.py:5-56 (MLP) and the factory nets/ZINC_graph_regression/sign_inv_net.py:3-17 — same constructor
+arguments, same `forward(g, x[N,K,1]) -> [N,K,1]`, same state_dict keys (`enc.layers.{l}.apply_func.lins.{i}.*`,
+`enc.layers.{l}.eps`, `enc.bns.{l}.*`, `rho.lins.{i}.*`, `rho.bns.{i}.*`).
+
+`g` is duck-typed: anything with `.edges() -> (src, dst)` int64 tensors and `.batch_num_nodes()` (a DGL batched
+graph, or `signnet_basisnet_amd.dgl_deepsigns.Graph`).  Eval mode (BatchNorm with running statistics) runs
+entirely in the HIP kernels of libsignnet_hip.so; there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Graph:
+    """Minimal batched graph: edge list + per-graph node counts (what the reference reads from a DGLGraph)."""
+
+    def __init__(self, src, dst, batch_num_nodes):
+        self.src, self.dst = src, dst
+        self._bnn = torch.as_tensor(batch_num_nodes)
+
+    def edges(self):
+        return self.src, self.dst
+
+    def batch_num_nodes(self):
+        return self._bnn
+
+    def to(self, device):
+        return Graph(self.src.to(device), self.dst.to(device), self._bnn.to(device))
+
+
+class MLP(nn.Module):
+    """Linear -> activation -> BatchNorm per hidden layer, final Linear (mlp.py:5-56); all Linears have bias."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, use_bn=False, use_ln=False, dropout=0.5,
+                 activation="relu", residual=False):
+        super().__init__()
+        if use_ln or residual or activation != "relu":
+            raise ValueError("HIP path: only relu / no LayerNorm / no residual (what every shipped config uses)")
+        self.lins = nn.ModuleList()
+        if use_bn:
+            self.bns = nn.ModuleList()
+        if num_layers == 1:
+            self.lins.append(nn.Linear(in_channels, out_channels))
+        else:
+            self.lins.append(nn.Linear(in_channels, hidden_channels))
+            if use_bn:
+                self.bns.append(nn.BatchNorm1d(hidden_channels))
+            for _ in range(num_layers - 2):
+                self.lins.append(nn.Linear(hidden_channels, hidden_channels))
+                if use_bn:
+                    self.bns.append(nn.BatchNorm1d(hidden_channels))
+            self.lins.append(nn.Linear(hidden_channels, out_channels))
+        self.use_bn, self.dropout = use_bn, dropout
+
+
+class _GINConv(nn.Module):
+    """dgl.nn.pytorch.GINConv(apply_func, 'sum'): eps is a non-learned buffer initialised to 0."""
+
+    def __init__(self, apply_func):
+        super().__init__()
+        self.apply_func = apply_func
+        self.register_buffer("eps", torch.zeros(1))
+
+
+class GIN(nn.Module):
+    def __init__(self, in_channels, hidden_channels, out_channels, n_layers, use_bn=True, dropout=0.5, activation="relu"):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        if use_bn:
+            self.bns = nn.ModuleList()
+        self.use_bn = use_bn
+        self.layers.append(_GINConv(MLP(in_channels, hidden_channels, hidden_channels, 2, use_bn=use_bn, dropout=dropout,
+                                        activation=activation)))
+        for _ in range(n_layers - 2):
+            self.layers.append(_GINConv(MLP(hidden_channels, hidden_channels, hidden_channels, 2, use_bn=use_bn,
+                                            dropout=dropout, activation=activation)))
+            if use_bn:
+                self.bns.append(nn.BatchNorm1d(hidden_channels))
+        self.layers.append(_GINConv(MLP(hidden_channels, hidden_channels, out_channels, 2, use_bn=use_bn, dropout=dropout,
+                                        activation=activation)))
+        if use_bn:
+            self.bns.append(nn.BatchNorm1d(hidden_channels))
+
+
+def _pack(lin):
+    w = lin.weight.detach()
+    return ops.PackedLinear(ops.pack_weight(w), w.shape[0], w.shape[1], lin.bias.detach().contiguous())
+
+
+def _prep_mlp(mlp: MLP):
+    """[(packed linear, folded BN or None)] per layer."""
+    out = []
+    for i, lin in enumerate(mlp.lins):
+        bn = ops.bn_fold(mlp.bns[i]) if (mlp.use_bn and i < len(mlp.lins) - 1) else None
+        out.append((_pack(lin), bn))
+    return out
+
+
+def _run_mlp(prep, x, nvalid=None, K=0, tail_affine=None):
+    """mlp.py:37-56 (dropout 0): hidden layers = bias -> relu -> BN; the final Linear optionally followed by an
+    affine (the BatchNorm that GIN.forward applies before the NEXT GINConv, gnns.py:105-112, folded in here)."""
+    for i, (pl, bn) in enumerate(prep):
+        last = i == len(prep) - 1
+        if not last:
+            x = ops.masked_linear(x, pl, nvalid, K, relu_pre=True, scale=None if bn is None else bn[0],
+                                  shift=None if bn is None else bn[1])
+        else:
+            x = ops.masked_linear(x, pl, nvalid, K, scale=None if tail_affine is None else tail_affine[0],
+                                  shift=None if tail_affine is None else tail_affine[1])
+    return x
+
+
+class _DeepSignsBase(nn.Module):
+    masked = False
+
+    def _invalidate(self):
+        self._prep = None
+
+    def train(self, mode=True):
+        self._prep = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._prep = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._prep = None
+        return super().load_state_dict(*a, **k)
+
+    def _prepare(self):
+        enc = self.enc
+        P = dict(gin=[], rho=_prep_mlp(self.rho))
+        L = len(enc.layers)
+        for l, conv in enumerate(enc.layers):
+            nxt = ops.bn_fold(enc.bns[l]) if (enc.use_bn and l < L - 1) else None   # BN applied before layer l+1
+            P["gin"].append(dict(eps=conv.eps, mlp=_prep_mlp(conv.apply_func), next_bn=nxt))
+        return P
+
+    def _plan(self, g, N):
+        src, dst = g.edges()
+        bnn = g.batch_num_nodes().to(src.device)
+        B = int(bnn.numel())
+        batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn)      # index plumbing only
+        if batch.numel() != N:
+            raise ValueError("batch_num_nodes does not sum to the number of feature rows")
+        return ops.build_plan(batch.long(), torch.stack([src.long(), dst.long()]), B, self.k)
+
+    def _phi(self, P, plan, x, N, K):
+        """enc(g, x) + enc(g, -x): GIN.forward, gnns.py:102-114, twice."""
+        outs = []
+        for sign in (0, 1):
+            h = x
+            for l, Lp in enumerate(P["gin"]):
+                a = ops.gin_aggregate(h.reshape(N, -1), plan, Lp["eps"], negate=(sign == 1 and l == 0))
+                h = _run_mlp(Lp["mlp"], a.view(N * K, -1), tail_affine=Lp["next_bn"])
+            outs.append(h)
+        return outs
+
+    def forward(self, g, x):
+        if self.training:
+            raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+        ops.require_cuda(x)
+        if x.dim() != 3 or x.shape[1] != self.k or x.shape[2] != 1:
+            raise ValueError(f"expected x of shape [N, {self.k}, 1]")
+        if getattr(self, "_prep", None) is None:
+            self._prep = self._prepare()
+        P = self._prep
+        N, K = x.shape[0], self.k
+        plan = self._plan(g, N)
+        zp, zm = self._phi(P, plan, x.contiguous().float(), N, K)
+        if self.masked:
+            # x[~mask] = 0 ; sum over K ; rho(c -> hidden -> K)             (deepsigns.py:76-84)
+            z = ops.masked_affine(zp, plan.nvalid, K, residual=zm)
+            s = ops.slot_sum(z, N, K)
+            y = _run_mlp(P["rho"], s)
+        else:
+            z = ops.masked_affine(zp, residual=zm)
+            y = _run_mlp(P["rho"], z.view(N, -1))                              # deepsigns.py:47-49
+        return y.view(N, K, 1)
+
+
+class GINDeepSigns(_DeepSignsBase):
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, k, use_bn=False, use_ln=False, dropout=0.5,
+                 activation="relu"):
+        super().__init__()
+        self.enc = GIN(in_channels, hidden_channels, out_channels, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
+        self.rho = MLP(out_channels * k, hidden_channels, k, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
+        self.k = k
+        self._prep = None
+
+
+class MaskedGINDeepSigns(_DeepSignsBase):
+    masked = True
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, k, device=None, use_bn=False, use_ln=False,
+                 dropout=0.5, activation="relu"):
+        super().__init__()
+        self.device = device
+        self.enc = GIN(in_channels, hidden_channels, out_channels, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
+        self.rho = MLP(out_channels, hidden_channels, k, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
+        self.k = k
+        self._prep = None
+
+
+def get_sign_inv_net(net_params):
+    """nets/ZINC_graph_regression/sign_inv_net.py:3-17 (the 'gin' and 'masked_gin' branches — the only ones a shipped
+    config selects)."""
+    assert net_params["sign_inv_net"] is not None, "did not specify sign inv net"
+    kind = net_params["sign_inv_net"]
+    args = (1, net_params["hidden_dim"], net_params["phi_out_dim"], net_params["sign_inv_layers"], net_params["pos_enc_dim"])
+    kw = dict(use_bn=True, dropout=net_params["dropout"], activation=net_params["sign_inv_activation"])
+    if kind == "gin":
+        return GINDeepSigns(*args, **kw)
+    if kind == "masked_gin":
+        return MaskedGINDeepSigns(*args, net_params["device"], **kw)
+    raise ValueError("Invalid sign inv net")

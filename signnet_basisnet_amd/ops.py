@@ -389,6 +389,32 @@ def segment_pool(x, plan: GraphPlan, mode="add"):
     return out
 
 
+def ign_contract_2to1(X):
+    """X [b, 1, n, n] or [b, n, n] -> ops [b, n, 5] (IGN 2->1 contractions, ign.py:344-374)."""
+    require_cuda(X)
+    X = _f32c(X, "X")
+    n = X.shape[-1]
+    if X.shape[-2] != n or (X.dim() == 4 and X.shape[1] != 1) or X.dim() not in (3, 4):
+        raise ValueError("ign_contract_2to1: expected [b, 1, n, n] or [b, n, n]")
+    b = X.shape[0]
+    out = torch.empty(b, n, 5, dtype=torch.float32, device=X.device)
+    scratch = torch.empty(int(lib().sn_ign_contract_scratch_floats(b, n)), dtype=torch.float32, device=X.device)
+    with _span("sn_ign_contract_2to1_f32"):
+        check(lib().sn_ign_contract_2to1_f32(ptr(X), b, n, ptr(out), ptr(scratch), stream()), "sn_ign_contract_2to1_f32")
+    return out
+
+
+def bn_fold_stats(weight, bias, mean, var, eps, c_pad=None):
+    """(scale, shift) of a BatchNorm from explicit statistics (batch statistics of the train-mode / no-running-stats case)."""
+    Cc = mean.numel()
+    cp = Cc if c_pad is None else int(c_pad)
+    scale = torch.empty(cp, dtype=torch.float32, device=mean.device)
+    shift = torch.empty(cp, dtype=torch.float32, device=mean.device)
+    check(lib().sn_bn_fold_f32(ptr(weight), ptr(bias), ptr(mean), ptr(var), float(eps), Cc, cp, ptr(scale), ptr(shift),
+                               stream()), "sn_bn_fold_f32")
+    return scale, shift
+
+
 # ----------------------------------------------------------------------------- roofline accounting (bench.py)
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec

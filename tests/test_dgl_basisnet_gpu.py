@@ -1,0 +1,115 @@
+"""-m gpu: DGL-tree DeepSigns and BasisNet modules (HIP) against the reference fixtures and the oracle."""
+import pytest
+import torch
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, what, rel=4e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    scale = max(1.0, b.abs().max().item())
+    err = (a - b).abs().max().item()
+    assert err <= rel * scale, f"{what}: max|diff| {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("name", ["dgl_gin_k8", "dgl_masked_k10"])
+def test_deepsigns_golden(name):
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    fx = G.load(name)
+    hidden, c, layers, k = (int(v) for v in fx.meta["params"])
+    kind = str(fx.meta["kind"])
+    net = DS.get_sign_inv_net(dict(sign_inv_net=kind, hidden_dim=hidden, phi_out_dim=c, sign_inv_layers=layers,
+                                   pos_enc_dim=k, dropout=0.0, sign_inv_activation="relu", device=DEV))
+    assert sorted(net.state_dict().keys()) == sorted(str(s) for s in fx.meta["sd_keys"])
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).eval()
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    y = net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV))
+    close(y, fx.out["eval/y"], kind)
+
+
+@pytest.mark.parametrize("kind,k,hidden,c", [("gin", 8, 95, 4), ("gin", 16, 64, 4), ("masked_gin", 37, 67, 67)])
+def test_deepsigns_shipped_sizes_vs_oracle(kind, k, hidden, c):
+    """(K, hidden, phi_out) of the shipped configs, 8 layers, vs the CPU oracle."""
+    from oracle import dgl_deepsigns as OD
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import synth
+    torch.manual_seed(0)
+    net = DS.get_sign_inv_net(dict(sign_inv_net=kind, hidden_dim=hidden, phi_out_dim=c, sign_inv_layers=8, pos_enc_dim=k,
+                                   dropout=0.0, sign_inv_activation="relu", device=DEV))
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    data = synth.make_batch(12, seed=41)
+    pe = synth.dgl_pos_enc(data, k)
+    sd = {kk: v.clone() for kk, v in net.state_dict().items()}
+    ei = data.edge_index
+    x = pe.unsqueeze(-1)
+    if kind == "gin":
+        ref = OD.gin_deepsigns(sd, ei[0], ei[1], x, 8, k)
+    else:
+        ref = OD.masked_gin_deepsigns(sd, ei[0], ei[1], torch.tensor(data.sizes), x, 8, k)
+    net = net.to(DEV).eval()
+    y = net(DS.Graph(ei[0].to(DEV), ei[1].to(DEV), torch.tensor(data.sizes)), x.to(DEV))
+    close(y, ref, kind)
+
+
+def test_ign_contractions_vs_fp64():
+    from signnet_basisnet_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for b, n in ((3, 36), (2, 100), (1, 1024), (5, 300)):
+        X = torch.randn(b, 1, n, n, generator=g)
+        o = ops.ign_contract_2to1(X.to(DEV)).cpu().double()
+        Xd = X[:, 0].double()
+        ref = torch.stack([torch.diagonal(Xd, dim1=1, dim2=2), Xd.diagonal(dim1=1, dim2=2).sum(1, keepdim=True).expand(-1, n) / n,
+                           Xd.sum(2) / n, Xd.sum(1) / n, Xd.sum((1, 2)).unsqueeze(1).expand(-1, n) / n ** 2], dim=2)
+        torch.testing.assert_close(o, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_basisnet_golden():
+    from oracle import basisnet as OB
+    from signnet_basisnet_amd import basisnet as BN
+    fx = G.load("basisnet_grid6")
+    D, V = fx.inp["eigvals"], fx.inp["eigvecs"]
+    N = V.shape[0]
+    groups = BN.group_eigenspaces(D, V)
+    mults = [int(m) for m in fx.meta["mults"]]
+    assert sorted(groups) == mults
+    hidden = int(fx.meta["hidden"])
+    net = BN.IGNBasisInv(mults, 1, hidden_channels=hidden)
+    outs = []
+    for m in mults:
+        enc = net.encs[net.mult_to_idx[m]]
+        sd = {k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith(f"enc{m}/")}
+        assert sorted(enc.state_dict().keys()) == sorted(sd.keys())
+        enc.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    for m in mults:
+        o = net(groups[m].to(DEV), m)
+        close(o, fx.out[f"eval/phi_m{m}"], f"IGN2to1 mult {m}", rel=1e-4)
+        outs.append(o.cpu())
+    feats = OB.basis_inv_features(outs, D, N)                 # reshape/concat bookkeeping of training.py:119-123
+    rho = BN.EqDeepSetsEncoder(2 * N, hidden_channels=10, out_channels=8, num_layers=3, use_bn=True)
+    rho.load_state_dict({k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith("rho/")})
+    y = rho.to(DEV)(feats.to(DEV))
+    close(y, fx.out["eval/rho"], "EqDeepSetsEncoder rho", rel=2e-4)
+
+
+def test_signplus_deepsets_golden():
+    from signnet_basisnet_amd import basisnet as BN
+    fx = G.load("basisnet_grid6")
+    sign = BN.SignPlus(BN.EqDeepSetsEncoder(1, num_layers=3, use_bn=True))
+    sign.load_state_dict({k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith("sign/")})
+    v = fx.inp["eigvecs"].transpose(1, 0).unsqueeze(-1).contiguous()
+    y = sign.to(DEV)(v.to(DEV))
+    close(y, fx.out["eval/signplus"], "SignPlus(DeepSets)", rel=2e-4)
+    # invariance to a global sign flip is exact: it swaps the two addends (the batch-statistics BatchNorm over the
+    # stack of eigenvectors makes per-eigenvector flips only approximately invariant — in the reference too)
+    assert torch.equal(y, sign(-v.to(DEV)))
