@@ -67,3 +67,37 @@ def test_shard_ranges_cover_everything():
             assert rs[0][0] == 0 and rs[-1][1] == B
             assert all(rs[i][1] == rs[i + 1][0] for i in range(W - 1))
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+
+
+def test_dropin_import_paths(monkeypatch):
+    """The dotted names the reference's entry scripts import resolve to the HIP modules."""
+    import importlib
+    import os
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "signnet_basisnet_amd", "dropin")
+    for sub, mod, names in (("alchemy", "sign_net.sign_net", ["SignNetGNN"]), ("alchemy", "sign_net.transform", ["EVDTransform"]),
+                            ("gine_pyg", "core.sign_net", ["SignNetGNN"]), ("gine_pyg", "core.transform", ["EVDTransform"]),
+                            ("graphprediction", "layers.deepsigns", ["GINDeepSigns", "MaskedGINDeepSigns"]),
+                            ("graphprediction", "nets.ZINC_graph_regression.sign_inv_net", ["get_sign_inv_net"]),
+                            ("learningfilters", "signbasisnet", ["SignPlus", "IGNBasisInv"]), ("learningfilters", "ign", ["IGN2to1"])):
+        for m in list(sys.modules):
+            if m.split(".")[0] in ("sign_net", "core", "layers", "nets", "signbasisnet", "ign"):
+                del sys.modules[m]
+        monkeypatch.syspath_prepend(os.path.join(root, sub))
+        module = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(module, n)
+
+
+def test_evd_transform_wire_format():
+    import types
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.transform import EVDTransform
+    b = synth.make_batch(1, seed=2, sizes=[11])
+    d = types.SimpleNamespace(edge_index=b.edge_index, num_nodes=11, x=b.x)
+    d = EVDTransform("sym")(d)
+    assert d.eigen_values.shape == (11,) and d.eigen_vectors.shape == (121,)
+    torch.testing.assert_close(d.eigen_values, b.eigen_values, rtol=1e-5, atol=1e-5)
+    V = d.eigen_vectors.view(11, 11)
+    L = V @ torch.diag(d.eigen_values) @ V.T
+    assert abs(float(L.diagonal().mean()) - 1.0) < 1e-4             # sym-normalised Laplacian has unit diagonal
