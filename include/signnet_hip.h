@@ -54,21 +54,28 @@ int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz);
  *     — in-edges of a node are ordered by edge id (deterministic summation order)
  *   status[4]       status[0] != 0 -> malformed batch (unsorted batch, edge across graphs, ...);
  *                   status[1] = max nodes per graph, status[2] = max in-degree
- *   bins[3] / bins_meta[12]  work bins of the fused stages (may be NULL) — see "Fused stages" below
- * scratch: int32[4*ceil(N/4) + 6*B + 8].  Five launches, no host synchronisation.
+ *   bins            work bins of the fused stages (may be NULL) — see "Fused stages" below
+ * scratch: int32[N + 8].  One launch (two workgroups) for batches of <= 4096 nodes / 12288 edges / 1024 graphs,
+ * five launches otherwise; never a host synchronisation.
  */
 typedef struct {
-  int R;            /* rows per bin */
-  int64_t max_bins; /* capacity of node/slot in bins: use sn_bins_bound(rows_upper_bound, R) */
-  int32_t* node;    /* [max_bins*R] node id of each bin row, -1 = padding; NULL = kind not requested */
-  int32_t* slot;    /* [max_bins*R] eigenvector slot of each bin row */
-} sn_bins_out;
+  /* phi (sn_phi_fused_f32): graphs packed into columns of <= 64 rows; bin j of a column = slot j of its graphs */
+  int32_t* phi_bin_col;   /* [phi_max_bins]  column of each bin                                        */
+  int64_t phi_max_bins;   /* capacity of phi_bin_col: sn_phi_bins_bound(B, kmax)                          */
+  int32_t* phi_col_bin0;  /* [B+1]           first bin of each column (columns <= graphs)                 */
+  int32_t* phi_col_mem;   /* [B][8]          member graphs of each column, -1 = none                      */
+  int32_t* phi_col_off;   /* [B][8]          row offset of each member inside a bin                       */
+  /* rho (sn_rho_fused_f32): a node's K_g slot rows padded to 16*ceil(K_g/16); 64/pad nodes per bin, per graph */
+  int32_t* rho_bin0;      /* [B+1]           first bin of each graph                                      */
+  int32_t* meta;          /* [8]  phi: nbins, error, real rows, columns ; rho: nbins, error, real rows, 0 */
+} sn_plan_bins;
 
 int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index, int64_t E,
                   int kmax, int32_t* graph_ptr, int32_t* node_graph, int32_t* nvalid, int64_t* evoff,
                   int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* status,
-                  const sn_bins_out* bins /* [3] or NULL */, int32_t* bins_meta /* [12] */,
+                  const sn_plan_bins* bins /* host struct of device pointers, or NULL */,
                   int32_t* scratch, void* stream);
+int64_t sn_phi_bins_bound(int64_t B, int kmax);
 
 /* Eigen-data packing.  Replaces to_dense_list_EVD (transform.py:52-61): x0[node, j] = V_b[local, j]
  * and s0[node, j] = D_b[j] for j < nvalid[node], else 0.  K = slots per node in the output. */
@@ -185,17 +192,16 @@ int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, f
 /* ==========================================================================================
  * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).
  *
- * Work is cut into *bins* of R activation rows that one workgroup keeps on chip for a whole
- * stage.  A bin holds whole *units* — the sets of rows that exchange data inside the stage:
- *   kind 0 (phi): unit = one (graph, eigenvector slot) slab, n_graph rows   (GIN aggregation)
- *   kind 1 (rho): unit = one node, its nvalid slot rows                     (attention over slots)
- *   kind 2 (gnn): unit = one graph, n_graph rows                            (GINE aggregation + pooling)
- * sn_batch_plan packs the units into bins (next-fit in graph order, on the device, no host sync):
- *   bins[kind].node[b*R + r], .slot[b*R + r] = node id / slot of bin row r (-1 = padding)
- *   bins_meta[4*kind + 0] = number of bins, [+1] != 0 if some unit exceeds R rows (the stage cannot
- *   run fused) or the bins overflow max_bins, [+2] = number of real rows, [+3] = R.
+ * Work is cut into *bins* of 64 activation rows that one workgroup keeps on chip for a whole stage.  A bin
+ * holds whole *units* — the rows that exchange data inside the stage — and sn_batch_plan lays them out on the
+ * device (sn_plan_bins above), with no host synchronisation:
+ *   phi: unit = one (graph, eigenvector slot) slab of n_graph rows (GIN aggregation).  Graphs are packed into
+ *        columns of <= 64 rows by best-fit-decreasing on n_graph; a column of height max K_g yields that many bins.
+ *   rho: unit = one node's K_g slot rows (attention over slots), padded to a multiple of 16 rows.
+ *   The GINE stage needs no bins: one workgroup per graph.
+ * meta[1] / meta[5] != 0: a graph has more than 64 nodes / slots — the stage cannot run fused (the caller uses the
+ * layer-at-a-time entry points).
  */
-int64_t sn_bins_bound(int64_t rows_upper_bound, int R);
 
 /* phi(x) + phi(-x) for every valid (node, slot) row, all L layers in one launch.
  * Replaces the whole of GNN3d.forward called twice (sign_net.py:28-44,113 /
@@ -234,16 +240,16 @@ typedef struct {
 
 #define SN_PHI_BIN_ROWS 64
 int sn_phi_fused_f32(const sn_phi_params* params /* host struct of device pointers */,
-                     const float* eigen_vectors, const int32_t* graph_ptr, const int32_t* node_graph,
-                     const int64_t* evoff, const int32_t* rowptr, const int32_t* col,
-                     const int32_t* bin_node, const int32_t* bin_slot, const int32_t* meta,
-                     int64_t max_bins, int K, float* out, void* stream);
+                     const float* eigen_vectors, const int32_t* graph_ptr, const int64_t* evoff,
+                     const int32_t* rowptr, const int32_t* col, const sn_plan_bins* bins,
+                     int kmax /* as given to sn_batch_plan */, int K /* row stride of out in slots */,
+                     float* out, void* stream);
 
 /* rho: the set-transformer encoder layers over each node's valid slots and the sum over slots, one launch.
  * Replaces SetTransformer.forward up to torch.sum(x, dim=1) (sign_net.py:60-70 / core/sign_net.py:64-75)
  * with its TransformerEncoderLayer stack (transformer_module.py:27-127, 4 heads, post-LN, eps 1e-6) and,
  * when has_pos, the eigenvalue encoder MaskedMLP(1->1->d) added to x (Alchemy sign_net.py:86,108,62).
- * Weight matrices packed (sn_pack_weight_f32), vectors zero-padded to d_pad.  Bins: kind 1, R = 64.
+ * Weight matrices packed (sn_pack_weight_f32), vectors zero-padded to d_pad.  Bins: sn_plan_bins.rho_bin0.
  *   x:       [N*K, d] = phi(x)+phi(-x) (row = node*K + slot; only valid rows are read)
  *   out_sum: [N, d]   sum over the node's valid slots of the last encoder layer's output            */
 typedef struct {
@@ -269,9 +275,8 @@ typedef struct {
 } sn_rho_params;
 
 int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* eigen_values,
-                     const int32_t* graph_ptr, const int32_t* node_graph, const int32_t* nvalid,
-                     const int32_t* bin_node, const int32_t* bin_slot, const int32_t* meta,
-                     int64_t max_bins, int K, float* out_sum, void* stream);
+                     const int32_t* graph_ptr, int64_t B, int64_t N, const sn_plan_bins* bins, int kmax, int K,
+                     float* out_sum, void* stream);
 
 /* The GINE network on top of the positional encoding, one launch: rho's output Linear+BatchNorm on the slot
  * sum (sign_net.py:71), then GNN.forward (model.py:36-64 / core/model.py:44-79): input encoder

@@ -22,7 +22,7 @@ _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "sn_version": [],
     "sn_device_info": [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
-    "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_pack_eig_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
     "sn_pack_weight_f32": [_p, _i, _i, _i, _p, _p],
     "sn_gin_aggregate_f32": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
@@ -31,8 +31,8 @@ SIGNATURES = {
     "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     "sn_bn_fold_f32": [_p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "sn_colstats_blocks": [_l],
-    "sn_phi_fused_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p],
-    "sn_rho_fused_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p],
+    "sn_phi_fused_f32": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p],
+    "sn_rho_fused_f32": [_p, _p, _p, _p, _l, _l, _p, _i, _i, _p, _p],
     "sn_gnn_fused_f32": [_p, _p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p],
     "sn_masked_colstats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "sn_masked_affine_f32": [_p, _i, _l, _i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
@@ -65,8 +65,8 @@ def lib():
         L.sn_last_error.restype = C.c_char_p
         L.sn_packed_weight_floats.argtypes = [_i, _i]
         L.sn_packed_weight_floats.restype = C.c_int64
-        L.sn_bins_bound.argtypes = [_l, _i]
-        L.sn_bins_bound.restype = C.c_int64
+        L.sn_phi_bins_bound.argtypes = [_l, _i]
+        L.sn_phi_bins_bound.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]
         L.sn_ign_contract_scratch_floats.restype = C.c_int64
         if L.sn_version() != 1:

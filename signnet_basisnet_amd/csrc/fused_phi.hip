@@ -6,7 +6,9 @@
 // rows, so the [rows, d] activations never need to touch HBM between layers.
 //
 // Mapping (SN_PHI_BIN_ROWS = 64 rows per workgroup, 4 waves):
-//   * a bin (sn_plan_bins kind 0) holds whole slabs; wave w owns bin rows [16w, 16w+16) for BOTH signs;
+//   * graphs are packed into columns (sn_batch_plan: best-fit-decreasing on the node count, <= 64 rows); bin j of a
+//     column holds the slot-j slab of every member graph; wave w owns bin rows [16w, 16w+16) for BOTH signs and a
+//     wave whose tile has no rows skips the GEMMs;
 //   * a row tile lives in registers in the MFMA operand layout of common.hpp
 //     (lane = (row = l&15, g = l>>4) holds channels 16*kk + 4*g + t), so the accumulators of one GEMM
 //     are directly the operand of the next — no LDS round trip between the two Linears of a MaskedMLP;
@@ -28,17 +30,21 @@ constexpr int PHI_WAVES = PHI_R / 16;
 struct PhiStruct {
   const float* ev;
   const int32_t* graph_ptr;
-  const int32_t* node_graph;
   const int64_t* evoff;
   const int32_t* rowptr;
   const int32_t* col;
-  const int32_t* bin_node;
-  const int32_t* bin_slot;
-  const int32_t* meta;
+  const int32_t* bin_col;    // [nbins]   column of every bin
+  const int32_t* col_bin0;   // [ncol+1]  first bin of every column
+  const int32_t* col_mem;    // [ncol][8] member graphs (-1 = none)
+  const int32_t* col_off;    // [ncol][8] row offset of each member inside a bin
+  const int32_t* meta;       // [0] nbins, [1] error
   int64_t max_bins;
+  int kmax;
   int K;
   float* out;
 };
+
+constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
 
 // out{P,M}[ot] = W (packed) x in{P,M}  — both signs share every weight fragment.
 // True double buffering of the weight fragments: while the 8*NT MFMAs of output tile ot run from buffer A, the
@@ -100,35 +106,48 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
   extern __shared__ __align__(16) float lds[];
   float* X = lds;                         // [2][PHI_R][LD]
   float* xs = lds + 2 * PHI_R * LD;       // [PHI_R] scalar eigenvector entries (layer 0)
+  unsigned char* nbr = reinterpret_cast<unsigned char*>(xs + PHI_R);   // [PHI_R][PHI_NBR] bin rows of the first in-neighbours
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = wave * 16 + (lane & 15), g = lane >> 4;
   const int nbins = S.meta[0];
-  if (S.meta[1] != 0) return;  // a unit does not fit a bin: the host falls back to the layer path
+  if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
-    // ---------------------------------------------------------------- my row
-    const int node = S.bin_node[(int64_t)bin * PHI_R + r];
-    const int slot = S.bin_slot[(int64_t)bin * PHI_R + r];
-    const bool valid = node >= 0;
-    int gs = 0, row0 = 0, e_lo = 0, e_hi = 0;
+    // ---------------------------------------------------------------- my row: bin -> column -> member graph
+    const int colid = S.bin_col[bin];
+    const int slot = bin - S.col_bin0[colid];       // every member contributes its slab of eigenvector `slot`
+    int node = -1, gs = 0, row0 = 0, e_lo = 0, e_hi = 0;
     float xval = 0.f;
-    if (valid) {
-      const int gi = S.node_graph[node];
-      gs = S.graph_ptr[gi];
-      const int n = S.graph_ptr[gi + 1] - gs;
-      const int li = node - gs;
-      row0 = r - li;
-      e_lo = S.rowptr[node];
-      e_hi = S.rowptr[node + 1];
-      xval = S.ev[S.evoff[gi] + (int64_t)li * n + slot];
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+      const int gi = S.col_mem[colid * 8 + k];
+      if (gi < 0) break;
+      const int off = S.col_off[colid * 8 + k];
+      const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
+      const int kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
+      if (r >= off && r < off + n && slot < kg) {
+        const int li = r - off;
+        node = g0 + li;
+        gs = g0;
+        row0 = off;
+        e_lo = S.rowptr[node];
+        e_hi = S.rowptr[node + 1];
+        xval = S.ev[S.evoff[gi] + (int64_t)li * n + slot];
+      }
+    }
+    const bool valid = node >= 0;
+    const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all GEMMs (keeps the barriers)
+    const int deg = e_hi - e_lo;
+    if (g == 0) {
+      xs[r] = xval;
+      for (int e = 0; e < deg && e < PHI_NBR; ++e) nbr[r * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
     }
     float* XP = X + r * LD;                 // my row, sign +
     float* XM = X + (PHI_R + r) * LD;       // my row, sign -
     // ---------------------------------------------------------------- layer 0 (scalar input)
-    if (g == 0) xs[r] = xval;
     __syncthreads();
     float a0 = 0.f;
-    for (int e = e_lo; e < e_hi; ++e) a0 += xs[row0 + S.col[e] - gs];
+    for (int e = 0; e < deg; ++e) a0 += xs[e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs];
     {
 #pragma clang fp contract(off)
       const float sc = 1.f + *P.l0_eps;
@@ -137,7 +156,9 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
     }
     __syncthreads();  // xs may be rewritten by the next bin
     f32x4 inP[NT], inM[NT], oP[NT], oM[NT];
-    if (P.hid0 == 1) {
+    if (!wave_live) {
+      // nothing to compute in this tile
+    } else if (P.hid0 == 1) {
       // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
       const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
       const float tP = fmaxf((a0 * w1) * s0 + h0, 0.f);
@@ -185,52 +206,54 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
         lds_st4(XM + 16 * kk + 4 * g, inM[kk]);
       }
       __syncthreads();
-      // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) { oP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; oM[kk] = oP[kk]; }
-      for (int e = e_lo; e < e_hi; ++e) {
-        const int nb = row0 + S.col[e] - gs;
-        const float* nP = X + nb * LD + 4 * g;
-        const float* nM = nP + PHI_R * LD;
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-          oP[kk] += lds_ld4(nP + 16 * kk);
-          oM[kk] += lds_ld4(nM + 16 * kk);
+      if (wave_live) {
+        // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self
+  #pragma unroll
+        for (int kk = 0; kk < NT; ++kk) { oP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; oM[kk] = oP[kk]; }
+        for (int e = 0; e < deg; ++e) {
+          const int nb = e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs;
+          const float* nP = X + nb * LD + 4 * g;
+          const float* nM = nP + PHI_R * LD;
+  #pragma unroll
+          for (int kk = 0; kk < NT; ++kk) {
+            oP[kk] += lds_ld4(nP + 16 * kk);
+            oM[kk] += lds_ld4(nM + 16 * kk);
+          }
         }
-      }
-      {
-#pragma clang fp contract(off)
-        const float sc = 1.f + *Lp.eps;
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-          const f32x4 sP = inP[kk] * sc, sM = inM[kk] * sc;
-          inP[kk] = oP[kk] + sP;
-          inM[kk] = oM[kk] + sM;
+        {
+  #pragma clang fp contract(off)
+          const float sc = 1.f + *Lp.eps;
+  #pragma unroll
+          for (int kk = 0; kk < NT; ++kk) {
+            const f32x4 sP = inP[kk] * sc, sM = inM[kk] * sc;
+            inP[kk] = oP[kk] + sP;
+            inM[kk] = oM[kk] + sM;
+          }
         }
-      }
-      // MaskedMLP: Linear . BN . ReLU . Linear [+b]
-      gemm_pm<NT>(Lp.w1p, inP, inM, oP, oM, lane);
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        const f32x4 s0 = ld4(Lp.bn0_scale + c), h0 = ld4(Lp.bn0_shift + c);
-        oP[kk] = relu4(oP[kk] * s0 + h0);
-        oM[kk] = relu4(oM[kk] * s0 + h0);
-      }
-      gemm_pm<NT>(Lp.w2p, oP, oM, inP, inM, lane);
-      // GNN3d: mask . BN . ReLU . + previous_x
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        const f32x4 s1 = ld4(Lp.bn_scale + c), h1 = ld4(Lp.bn_shift + c);
-        f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
-        if (Lp.bias2) b2 = ld4(Lp.bias2 + c);
-        inP[kk] = relu4((inP[kk] + b2) * s1 + h1) + lds_ld4(XP + c);
-        inM[kk] = relu4((inM[kk] + b2) * s1 + h1) + lds_ld4(XM + c);
-      }
-      if (!valid) {
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) { inP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; inM[kk] = inP[kk]; }
+        // MaskedMLP: Linear . BN . ReLU . Linear [+b]
+        gemm_pm<NT>(Lp.w1p, inP, inM, oP, oM, lane);
+  #pragma unroll
+        for (int kk = 0; kk < NT; ++kk) {
+          const int c = 16 * kk + 4 * g;
+          const f32x4 s0 = ld4(Lp.bn0_scale + c), h0 = ld4(Lp.bn0_shift + c);
+          oP[kk] = relu4(oP[kk] * s0 + h0);
+          oM[kk] = relu4(oM[kk] * s0 + h0);
+        }
+        gemm_pm<NT>(Lp.w2p, oP, oM, inP, inM, lane);
+        // GNN3d: mask . BN . ReLU . + previous_x
+  #pragma unroll
+        for (int kk = 0; kk < NT; ++kk) {
+          const int c = 16 * kk + 4 * g;
+          const f32x4 s1 = ld4(Lp.bn_scale + c), h1 = ld4(Lp.bn_shift + c);
+          f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
+          if (Lp.bias2) b2 = ld4(Lp.bias2 + c);
+          inP[kk] = relu4((inP[kk] + b2) * s1 + h1) + lds_ld4(XP + c);
+          inM[kk] = relu4((inM[kk] + b2) * s1 + h1) + lds_ld4(XM + c);
+        }
+        if (!valid) {
+  #pragma unroll
+          for (int kk = 0; kk < NT; ++kk) { inP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; inM[kk] = inP[kk]; }
+        }
       }
       __syncthreads();  // everyone is done reading X before it is overwritten
     }
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
 template <int NT>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float);
+  const size_t lds = (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
@@ -278,11 +301,11 @@ static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st
 using namespace sn;
 
 extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_vectors, const int32_t* graph_ptr,
-                                const int32_t* node_graph, const int64_t* evoff, const int32_t* rowptr,
-                                const int32_t* col, const int32_t* bin_node, const int32_t* bin_slot,
-                                const int32_t* meta, int64_t max_bins, int K, float* out, void* stream) {
-  SN_REQUIRE(params && eigen_vectors && graph_ptr && node_graph && evoff && rowptr && bin_node && bin_slot && meta && out,
-             "sn_phi_fused_f32: null pointer");
+                                const int64_t* evoff, const int32_t* rowptr, const int32_t* col,
+                                const sn_plan_bins* bins, int kmax, int K, float* out, void* stream) {
+  SN_REQUIRE(params && eigen_vectors && graph_ptr && evoff && rowptr && bins && out, "sn_phi_fused_f32: null pointer");
+  SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->meta,
+             "sn_phi_fused_f32: incomplete sn_plan_bins");
   const sn_phi_params& P = *params;
   SN_REQUIRE(P.d > 0 && P.d <= 128, "sn_phi_fused_f32: hidden width %d not in (0, 128]", P.d);
   SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS, "sn_phi_fused_f32: %d layers unsupported", P.n_layers);
@@ -294,9 +317,10 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
     SN_REQUIRE(L.w1p && L.bn0_scale && L.bn0_shift && L.w2p && L.bn_scale && L.bn_shift && L.eps,
                "sn_phi_fused_f32: layer %d parameters missing", l);
   }
-  SN_REQUIRE(K > 0 && max_bins >= 0, "sn_phi_fused_f32: bad K / max_bins");
-  if (max_bins == 0) return SN_OK;
-  PhiStruct S{eigen_vectors, graph_ptr, node_graph, evoff, rowptr, col, bin_node, bin_slot, meta, max_bins, K, out};
+  SN_REQUIRE(K > 0 && bins->phi_max_bins >= 0, "sn_phi_fused_f32: bad K / max_bins");
+  if (bins->phi_max_bins == 0) return SN_OK;
+  PhiStruct S{eigen_vectors, graph_ptr, evoff, rowptr, col, bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem,
+              bins->phi_col_off, bins->meta, bins->phi_max_bins, kmax, K, out};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   switch ((P.d + 15) / 16) {

@@ -1,35 +1,317 @@
-// plan.hip — per-batch structure: graph_ptr / nvalid / dst-sorted CSR, and eigen-data packing.
-// Replaces the reference's to_dense_EVD bookkeeping (Alchemy/sign_net/transform.py:26-61),
+// plan.hip — per-batch structure: graph_ptr / nvalid / dst-sorted CSR, the work bins of the fused stages, and
+// eigen-data packing.  Replaces the reference's to_dense_EVD bookkeeping (Alchemy/sign_net/transform.py:26-61),
 // the mask construction of SignNet.forward (sign_net.py:100-102) and PyG's per-call COO gather
-// (torch_geometric MessagePassing) — see include/signnet_hip.h.
+// (torch_geometric MessagePassing) — see include/signnet_hip.h.  Everything runs on the device; the host never
+// learns a graph size.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace sn {
 
-// status words: [0] error bits, [1] max nodes per graph, [2] max in-degree, [3] reserved
+// status words: [0] error bits, [1] max nodes per graph, [2] max in-degree, [3] set by the fused kernels
 enum { ST_ERR = 0, ST_NMAX = 1, ST_DEGMAX = 2 };
 enum { ERR_UNSORTED = 1, ERR_GRAPH_ID = 2, ERR_EDGE_RANGE = 4, ERR_EDGE_CROSS = 8 };
 
-struct BinsOut {           // device-side view of sn_bins_out[3]
-  int R[3];
-  long long max_bins[3];
-  int32_t* node[3];
-  int32_t* slot[3];
+constexpr int PLAN_T = 1024;          // threads of the single-workgroup stages
+constexpr int BINS_BMAX = 8192;       // graphs the bin planner handles (LDS-resident working set)
+
+struct BinsDev {  // device view of sn_plan_bins
+  int32_t* phi_bin_col;
+  long long phi_max_bins;
+  int32_t* phi_col_bin0;
+  int32_t* phi_col_mem;
+  int32_t* phi_col_off;
+  int32_t* rho_bin0;
+  int32_t* meta;
 };
 
-// K1: per node — graph id, graph boundaries; zero the in-degree counters and the status words; mark every
-// bin row as padding (-1).  Nothing here is read by another thread of this launch.
+// exclusive scan of one int per thread over a PLAN_T-thread workgroup; wsum: LDS int[32]; returns the exclusive
+// prefix, *total gets the grand total (valid for every thread).
+__device__ __forceinline__ int block_exscan(int v, int* wsum, int t, int* total) {
+  const int lane = t & 63, w = t >> 6;
+  int x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  if (w == 0) {
+    int s = (lane < PLAN_T / 64) ? wsum[lane] : 0;
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += y;
+    }
+    if (lane < PLAN_T / 64) wsum[lane] = inc - s;
+    if (lane == PLAN_T / 64 - 1) wsum[31] = inc;
+  }
+  __syncthreads();
+  const int r = x - v + wsum[w];
+  *total = wsum[31];
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ int slots_of(int n, int kmax) { return (kmax > 0 && n > kmax) ? kmax : n; }
+
+// ---------------------------------------------------------------------------- work bins (one workgroup)
+// phi: a unit is one (graph, slot) slab of n rows; graphs are packed into COLUMNS by best-fit-decreasing on n
+//      (capacity 64 rows, at most 8 graphs): bin j of a column holds slot j of every member graph, so a column
+//      of height max_g K_g covers all slabs of its graphs and every bin is (nearly) full.
+// rho: a unit is one node's K_g slot rows, padded to p = 16*ceil(K_g/16) so that a unit never straddles a 16-row
+//      tile; 64/p units per bin, bins never mix graphs -> closed form, no sequential pass.
+// gp: graph_ptr in LDS ([B+1]); lds: int scratch [2*B + 3*66 + 32].
+__device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
+  const int t = threadIdx.x;
+  int* bucket = lds;            // [B]   graph ids grouped by size, ascending id inside a group
+  int* nbv = lds + B;           // [B]   rho bins per graph
+  int* hist = lds + 2 * B;      // [66]
+  int* bstart = hist + 66;      // [66]
+  int* bcur = bstart + 66;      // [66]
+  int* wsum = bcur + 66;        // [32]
+  __shared__ int s_err, s_ncol, s_nbins;
+  if (t < 66) { hist[t] = 0; bcur[t] = 0; }
+  if (t == 0) { s_err = 0; s_ncol = 0; s_nbins = 0; }
+  __syncthreads();
+  // ---- rho: bins per graph, prefix
+  {
+    int rows = 0;
+    const int per = (B + PLAN_T - 1) / PLAN_T;
+    const int lo = t * per, hi = (lo + per < B) ? lo + per : B;
+    int mine = 0;
+    for (int g = lo; g < hi; ++g) {
+      const int n = gp[g + 1] - gp[g];
+      const int K = slots_of(n, kmax);
+      int nb = 0;
+      if (n > 0) {
+        if (K > 64) atomicOr(&s_err, 2);
+        else {
+          const int p = ((K + 15) >> 4) << 4;
+          const int upb = 64 / p;                 // 4, 2, 1, 1
+          nb = (n + upb - 1) / upb;
+          rows += n * K;
+        }
+      }
+      nbv[g] = nb;
+      mine += nb;
+    }
+    int total;
+    int run = block_exscan(mine, wsum, t, &total);
+    for (int g = lo; g < hi; ++g) { bd.rho_bin0[g] = run; run += nbv[g]; }
+    int rtot;
+    block_exscan(rows, wsum, t, &rtot);
+    if (t == 0) {
+      bd.rho_bin0[B] = total;
+      bd.meta[4] = total;
+      bd.meta[6] = rtot;
+      bd.meta[7] = 0;
+    }
+  }
+  // ---- phi: group graphs by size
+  for (int g = t; g < B; g += PLAN_T) {
+    const int n = gp[g + 1] - gp[g];
+    if (n > 64) atomicOr(&s_err, 1);
+    else if (n > 0) atomicAdd(&hist[n], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int s = 0; s <= 64; ++s) { bstart[s] = run; run += hist[s]; }
+    bstart[65] = run;
+  }
+  __syncthreads();
+  for (int g = t; g < B; g += PLAN_T) {
+    const int n = gp[g + 1] - gp[g];
+    if (n > 0 && n <= 64) bucket[bstart[n] + atomicAdd(&bcur[n], 1)] = g;
+  }
+  __syncthreads();
+  if (t <= 64) {  // deterministic order inside a size class
+    const int lo = bstart[t], hi = bstart[t + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+      const int k = bucket[a];
+      int b = a - 1;
+      while (b >= lo && bucket[b] > k) { bucket[b + 1] = bucket[b]; --b; }
+      bucket[b + 1] = k;
+    }
+  }
+  __syncthreads();
+  // ---- phi: best-fit-decreasing over the size classes (one lane; ~#graphs cheap steps)
+  if (t == 0) {
+    unsigned long long avail = 0ull;
+    for (int s = 1; s <= 64; ++s)
+      if (hist[s] > 0) avail |= 1ull << (s - 1);
+    for (int s = 0; s <= 64; ++s) bcur[s] = bstart[s];   // next unused item of each class
+    int ncol = 0, bin = 0, rows = 0;
+    while (avail) {
+      const int s = 64 - __clzll(avail);
+      int g = bucket[bcur[s]++];
+      if (bcur[s] == bstart[s + 1]) avail &= ~(1ull << (s - 1));
+      int cap = 64 - s, members = 1;
+      const int H = slots_of(s, kmax);
+      rows += s * H;
+      bd.phi_col_mem[ncol * 8] = g;
+      bd.phi_col_off[ncol * 8] = 0;
+      while (members < 8 && cap > 0) {
+        const unsigned long long m = (cap >= 64) ? avail : (avail & ((1ull << cap) - 1ull));
+        if (!m) break;
+        const int u = 64 - __clzll(m);
+        g = bucket[bcur[u]++];
+        if (bcur[u] == bstart[u + 1]) avail &= ~(1ull << (u - 1));
+        bd.phi_col_mem[ncol * 8 + members] = g;
+        bd.phi_col_off[ncol * 8 + members] = 64 - cap;
+        cap -= u;
+        rows += u * slots_of(u, kmax);
+        ++members;
+      }
+      for (int k = members; k < 8; ++k) { bd.phi_col_mem[ncol * 8 + k] = -1; bd.phi_col_off[ncol * 8 + k] = 0; }
+      bd.phi_col_bin0[ncol] = bin;
+      bin += H;
+      ++ncol;
+    }
+    bd.phi_col_bin0[ncol] = bin;
+    s_ncol = ncol;
+    s_nbins = bin;
+    bd.meta[0] = bin;
+    bd.meta[2] = rows;
+    bd.meta[3] = ncol;
+  }
+  __syncthreads();
+  const int ncol = s_ncol, nbins = s_nbins;
+  const bool over = nbins > bd.phi_max_bins;
+  if (t == 0) {
+    bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
+    bd.meta[5] = (s_err & 2);
+  }
+  if (!over) {
+    for (int c = t; c < ncol; c += PLAN_T) {
+      const int lo = bd.phi_col_bin0[c], hi = bd.phi_col_bin0[c + 1];
+      for (int j = lo; j < hi; ++j) bd.phi_bin_col[j] = c;
+    }
+  }
+}
+
+// graph_ptr from a sorted batch vector, into LDS: gp[k] = first node of graph k (empty graphs included), gp[B] = N.
+__device__ void lds_graph_ptr(const int64_t* __restrict__ batch, int N, int B, int* gp, int* err) {
+  const int t = threadIdx.x;
+  for (int i = t; i <= B; i += PLAN_T) gp[i] = N;
+  __syncthreads();
+  for (int i = t; i < N; i += PLAN_T) {
+    const long long g = batch[i];
+    const long long gprev = (i == 0) ? -1 : batch[i - 1];
+    if (g < 0 || g >= B) { if (err) atomicOr(err, ERR_GRAPH_ID); continue; }
+    if (gprev > g && err) atomicOr(err, ERR_UNSORTED);
+    if (gprev < g) {
+      const long long lo = gprev < -1 ? 0 : gprev + 1;
+      for (long long k = lo; k <= g; ++k) gp[k] = i;
+    }
+  }
+  __syncthreads();
+}
+
+// ============================================================================ small batches: ONE launch, two workgroups
+// Block 0: nodes, CSR (LDS atomics + per-segment sort), scans, write-out.  Block 1: the work bins.
+// Limits: N <= 4096, E <= 12288, B <= 1024 (the reference's batches: 128-256 molecules).
+constexpr int PS_NMAX = 4096, PS_EMAX = 12288, PS_BMAX = 1024;
+
+__global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict__ batch, int N, int B,
+                                                       const int64_t* __restrict__ ei, int E, int kmax,
+                                                       int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
+                                                       int32_t* __restrict__ nvalid, int64_t* __restrict__ evoff,
+                                                       int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                       int32_t* __restrict__ eperm, int32_t* __restrict__ status, BinsDev bd,
+                                                       int do_bins) {
+  extern __shared__ int sm[];
+  const int t = threadIdx.x;
+  if (blockIdx.x == 1) {
+    if (!do_bins) return;
+    int* gp = sm;                      // [B+1]
+    lds_graph_ptr(batch, N, B, gp, nullptr);
+    plan_bins_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
+    return;
+  }
+  int* gp = sm;                        // [B+1]
+  int* deg = gp + (PS_BMAX + 4);       // [N]  in-degree, then fill cursor
+  int* rp = deg + PS_NMAX;             // [N+1]
+  int* lcol = rp + (PS_NMAX + 4);      // [E]
+  int* lperm = lcol + PS_EMAX;         // [E]
+  int* wsum = lperm + PS_EMAX;         // [32]
+  __shared__ int s_err, s_nmax, s_dmax;
+  if (t == 0) { s_err = 0; s_nmax = 0; s_dmax = 0; }
+  for (int i = t; i < N; i += PLAN_T) deg[i] = 0;
+  __syncthreads();
+  lds_graph_ptr(batch, N, B, gp, &s_err);
+  // ---- in-degrees (LDS atomics) + edge validation
+  for (int e = t; e < E; e += PLAN_T) {
+    const long long s = ei[e], d = ei[(long long)E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(&s_err, ERR_EDGE_RANGE); continue; }
+    if (batch[s] != batch[d]) atomicOr(&s_err, ERR_EDGE_CROSS);
+    atomicAdd(&deg[d], 1);
+  }
+  __syncthreads();
+  // ---- rowptr = exclusive scan of deg ; evoff = exclusive scan of n^2
+  {
+    const int per = (N + PLAN_T - 1) / PLAN_T;
+    const int lo = t * per, hi = (lo + per < N) ? lo + per : N;
+    int s = 0, dmax = 0;
+    for (int i = lo; i < hi; ++i) { s += deg[i]; dmax = dmax > deg[i] ? dmax : deg[i]; }
+    atomicMax(&s_dmax, dmax);
+    int total;
+    int run = block_exscan(s, wsum, t, &total);
+    for (int i = lo; i < hi; ++i) { const int dg = deg[i]; rp[i] = run; deg[i] = run; run += dg; }
+    if (t == 0) rp[N] = total;
+    const int perb = (B + PLAN_T - 1) / PLAN_T;
+    const int blo = t * perb, bhi = (blo + perb < B) ? blo + perb : B;
+    int q = 0, nmax = 0;
+    for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; q += n * n; nmax = nmax > n ? nmax : n; }
+    atomicMax(&s_nmax, nmax);
+    int qtot;
+    int qrun = block_exscan(q, wsum, t, &qtot);
+    for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; evoff[g] = qrun; qrun += n * n; }
+    if (t == 0) evoff[B] = qtot;
+  }
+  __syncthreads();
+  // ---- fill the CSR segments (arbitrary arrival order), then sort each segment by edge id
+  for (int e = t; e < E; e += PLAN_T) {
+    const long long s = ei[e], d = ei[(long long)E + e];
+    if (s < 0 || s >= N || d < 0 || d >= N) continue;
+    const int p = atomicAdd(&deg[d], 1);
+    lcol[p] = (int)s;
+    lperm[p] = e;
+  }
+  __syncthreads();
+  for (int i = t; i < N; i += PLAN_T) {
+    const int lo = rp[i], hi = rp[i + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+      const int ke = lperm[a], kc = lcol[a];
+      int b = a - 1;
+      while (b >= lo && lperm[b] > ke) { lperm[b + 1] = lperm[b]; lcol[b + 1] = lcol[b]; --b; }
+      lperm[b + 1] = ke;
+      lcol[b + 1] = kc;
+    }
+  }
+  __syncthreads();
+  // ---- write out
+  for (int i = t; i <= N; i += PLAN_T) rowptr[i] = rp[i];
+  for (int i = t; i < E; i += PLAN_T) { col[i] = lcol[i]; eperm[i] = lperm[i]; }
+  for (int i = t; i <= B; i += PLAN_T) graph_ptr[i] = gp[i];
+  for (int i = t; i < N; i += PLAN_T) {
+    const long long g = batch[i];
+    int nv = 0, gi = 0;
+    if (g >= 0 && g < B) { gi = (int)g; nv = slots_of(gp[g + 1] - gp[g], kmax); }
+    node_graph[i] = gi;
+    nvalid[i] = nv;
+  }
+  if (t == 0) { status[ST_ERR] = s_err; status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
+}
+
+// ============================================================================ general path: five launches
+// K1: per node — graph id, graph boundaries; zero the in-degree counters and the status words.
 __global__ void k_plan_nodes(const int64_t* __restrict__ batch, int64_t N, int64_t B,
                              int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
-                             int32_t* __restrict__ deg, int32_t* __restrict__ status, BinsOut bo) {
+                             int32_t* __restrict__ deg, int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int k = 0; k < 3; ++k) {
-    if (!bo.node[k]) continue;
-    const int64_t tot = bo.max_bins[k] * bo.R[k];
-    for (int64_t j = i; j < tot; j += stride) { bo.node[k][j] = -1; bo.slot[k][j] = -1; }
-  }
   if (i < 4) status[i] = 0;
   if (i == 0) graph_ptr[B] = (int32_t)N;
   if (i >= N) return;
@@ -39,10 +321,8 @@ __global__ void k_plan_nodes(const int64_t* __restrict__ batch, int64_t N, int64
   node_graph[i] = (int32_t)g;
   int64_t gp = (i == 0) ? -1 : batch[i - 1];
   if (gp < -1) gp = -1;
-  if (gp != g && gp < g) {
-    // every graph id in (gp, g] starts here (ids in between are empty graphs)
-    for (int64_t t = gp + 1; t <= g; ++t) graph_ptr[t] = (int32_t)i;
-  }
+  if (gp < g)
+    for (int64_t t = gp + 1; t <= g; ++t) graph_ptr[t] = (int32_t)i;   // ids in between are empty graphs
   if (i == N - 1)
     for (int64_t t = g + 1; t < B; ++t) graph_ptr[t] = (int32_t)N;
 }
@@ -66,97 +346,27 @@ __global__ void k_plan_degree(const int64_t* __restrict__ batch, const int64_t* 
   atomicAdd(&deg[d], 1);
 }
 
-// Units of graph g: kind 0 -> K_g slabs of n_g rows; kind 1 -> n_g nodes of K_g rows; kind 2 -> 1 graph of n_g rows
-// (K_g = min(n_g, kmax)).  Next-fit packing in graph order into bins of R rows.
-__device__ __forceinline__ void unit_shape(int kind, int n, int kg, int& usize, int& ucount) {
-  if (kind == 0) { usize = n; ucount = kg; }
-  else if (kind == 1) { usize = kg; ucount = n; }
-  else { usize = n; ucount = n > 0 ? 1 : 0; }
-}
-
-// Next-fit over the graphs, one wave per stage kind: the per-graph unit shapes are computed by all 64 lanes
-// into LDS, then lane 0 walks the graphs (closed form per graph, small-integer divisions done with exact
-// float reciprocals) recording the (bin, fill) state every graph starts from.
-__device__ __forceinline__ int idiv_small(int a, int b) {   // exact for 0 <= a, 0 < b <= 2^20
-  int q = (int)(((float)a + 0.5f) / (float)b);
-  return q;
-}
-__device__ void bins_scan(int kind, int R, long long max_bins, int kmax, const int32_t* __restrict__ graph_ptr, int64_t B,
-                          int32_t* __restrict__ bin0, int32_t* __restrict__ fill0, int32_t* __restrict__ meta,
-                          int* sh_us, int* sh_uc, int chunk) {
-  const int lane = threadIdx.x & 63;
-  int bin = 0, fill = 0, err = 0, rows = 0;
-  for (int64_t base = 0; base < B; base += chunk) {
-    const int cnt = (int)((B - base) < chunk ? (B - base) : chunk);
-    for (int i = lane; i < cnt; i += 64) {
-      int n = graph_ptr[base + i + 1] - graph_ptr[base + i];
-      int kg = (kmax > 0 && n > kmax) ? kmax : n;
-      int us, uc;
-      unit_shape(kind, n, kg, us, uc);
-      sh_us[i] = us;
-      sh_uc[i] = uc;
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to lane 0
-    if (lane == 0) {
-      for (int i = 0; i < cnt; ++i) {
-        const int us = sh_us[i], uc = sh_uc[i];
-        bin0[base + i] = bin;
-        fill0[base + i] = fill;
-        if (us <= 0 || uc <= 0) continue;
-        if (us > R) { err = 1; continue; }
-        rows += us * uc;
-        int a = idiv_small(R - fill, us);
-        if (a > uc) a = uc;
-        fill += a * us;
-        const int rem = uc - a;
-        if (rem > 0) {
-          const int per = idiv_small(R, us);
-          const int nb = idiv_small(rem + per - 1, per);
-          bin += nb;                         // the open bin is closed, nb new ones are used, the last stays open
-          fill = (rem - (nb - 1) * per) * us;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (lane == 0) {
-    const int nbins = fill > 0 ? bin + 1 : bin;
-    meta[0] = nbins;
-    meta[1] = err | (nbins > max_bins ? 2 : 0);
-    meta[2] = rows;
-    meta[3] = R;
-  }
-}
-
-// K3: one workgroup — exclusive scans: deg -> rowptr (and cursor copy), n_b^2 -> evoff; nvalid; maxima; bin states.
-__global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int kmax,
-                                                    const int32_t* __restrict__ graph_ptr,
-                                                    const int32_t* __restrict__ node_graph,
-                                                    int32_t* __restrict__ deg /* in: degree, out: cursor=rowptr */,
-                                                    int32_t* __restrict__ rowptr,
-                                                    int32_t* __restrict__ nvalid,
-                                                    int64_t* __restrict__ evoff,
-                                                    int32_t* __restrict__ status, BinsOut bo,
-                                                    int32_t* __restrict__ binstate /* [3][2][B] */,
-                                                    int32_t* __restrict__ bins_meta /* [3][4] */) {
-  __shared__ long long part[1024];
-  __shared__ int maxs[2];
+// K3: block 0 — exclusive scans: deg -> rowptr (and cursor copy), n_b^2 -> evoff; nvalid; maxima.
+//     block 1 — the work bins (graph_ptr staged in LDS).
+__global__ __launch_bounds__(PLAN_T) void k_plan_scan(int64_t N, int64_t B, int kmax,
+                                                      const int32_t* __restrict__ graph_ptr,
+                                                      const int32_t* __restrict__ node_graph,
+                                                      int32_t* __restrict__ deg /* in: degree, out: cursor=rowptr */,
+                                                      int32_t* __restrict__ rowptr, int32_t* __restrict__ nvalid,
+                                                      int64_t* __restrict__ evoff, int32_t* __restrict__ status, BinsDev bd) {
+  extern __shared__ int sm[];
   const int T = blockDim.x, t = threadIdx.x;
-  if (t == 0) { maxs[0] = 0; maxs[1] = 0; }
-  __syncthreads();
-  // ---- block 1: the three sequential bin scans (one lane of three waves), concurrent with block 0's scans
   if (blockIdx.x == 1) {
-    __shared__ int sh_shape[3][2][1024];
-    if ((t >> 6) < 3 && bins_meta) {
-      const int k = t >> 6;
-      if (bo.node[k]) bins_scan(k, bo.R[k], bo.max_bins[k], kmax, graph_ptr, B, binstate + (2 * k) * B,
-                                binstate + (2 * k + 1) * B, bins_meta + 4 * k, sh_shape[k][0], sh_shape[k][1], 1024);
-      else if ((t & 63) == 0) { bins_meta[4 * k] = 0; bins_meta[4 * k + 1] = 0; bins_meta[4 * k + 2] = 0; bins_meta[4 * k + 3] = 0; }
-    }
+    int* gp = sm;
+    for (int64_t i = t; i <= B; i += T) gp[i] = graph_ptr[i];
+    __syncthreads();
+    plan_bins_block(gp, (int)B, kmax, bd, sm + B + 4);
     return;
   }
-  // ---- rowptr = exclusive scan of deg (chunked: each thread owns a contiguous run)
+  __shared__ long long part[PLAN_T];
+  __shared__ int maxs[2];
+  if (t == 0) { maxs[0] = 0; maxs[1] = 0; }
+  __syncthreads();
   {
     int64_t per = (N + T - 1) / T;
     int64_t lo = (int64_t)t * per, hi = lo + per < N ? lo + per : N;
@@ -172,17 +382,16 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int km
       part[t] += v;
       __syncthreads();
     }
-    long long run = part[t] - s;  // exclusive prefix of this thread's run
+    long long run = part[t] - s;
     for (int64_t i = lo; i < hi; ++i) {
       int dgi = deg[i];
       rowptr[i] = (int32_t)run;
-      deg[i] = (int32_t)run;  // fill cursor
+      deg[i] = (int32_t)run;
       run += dgi;
     }
     if (t == T - 1) rowptr[N] = (int32_t)part[T - 1];
     __syncthreads();
   }
-  // ---- evoff = exclusive scan of n_b^2 over graphs
   {
     int64_t per = (B + T - 1) / T;
     int64_t lo = (int64_t)t * per, hi = lo + per < B ? lo + per : B;
@@ -211,62 +420,24 @@ __global__ __launch_bounds__(1024) void k_plan_scan(int64_t N, int64_t B, int km
     if (t == T - 1) evoff[B] = part[T - 1];
     __syncthreads();
   }
-  // ---- nvalid per node
   for (int64_t i = t; i < N; i += T) {
     int g = node_graph[i];
-    int n = graph_ptr[g + 1] - graph_ptr[g];
-    nvalid[i] = (kmax > 0 && n > kmax) ? kmax : n;
+    nvalid[i] = slots_of(graph_ptr[g + 1] - graph_ptr[g], kmax);
   }
   if (t == 0) { status[ST_NMAX] = maxs[0]; status[ST_DEGMAX] = maxs[1]; }
 }
 
-// K4: blocks [0, eblocks): per edge — scatter into its destination's segment (arrival order arbitrary, fixed
-// by k_plan_sort);  blocks [eblocks, eblocks + B): one graph each — write its bin rows for the three stage kinds.
-__global__ __launch_bounds__(256) void k_plan_fill(const int64_t* __restrict__ ei, int64_t E, int64_t N, int eblocks,
+// K4: per edge — scatter into its destination's segment (arrival order arbitrary, fixed by k_plan_sort).
+__global__ __launch_bounds__(256) void k_plan_fill(const int64_t* __restrict__ ei, int64_t E, int64_t N,
                                                    int32_t* __restrict__ cursor, int32_t* __restrict__ col,
-                                                   int32_t* __restrict__ eperm, const int32_t* __restrict__ graph_ptr,
-                                                   int64_t B, int kmax, BinsOut bo,
-                                                   const int32_t* __restrict__ binstate,
-                                                   const int32_t* __restrict__ bins_meta) {
-  if ((int)blockIdx.x < eblocks) {
-    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    int64_t s = ei[e], d = ei[E + e];
-    if (s < 0 || s >= N || d < 0 || d >= N) return;
-    int p = atomicAdd(&cursor[d], 1);
-    col[p] = (int32_t)s;
-    eperm[p] = (int32_t)e;
-    return;
-  }
-  const int64_t g = (int64_t)blockIdx.x - eblocks;
-  if (g >= B) return;
-  const int gs = graph_ptr[g];
-  const int n = graph_ptr[g + 1] - gs;
-  const int kg = (kmax > 0 && n > kmax) ? kmax : n;
-  for (int kind = 0; kind < 3; ++kind) {
-    if (!bo.node[kind] || bins_meta[4 * kind + 1] != 0) continue;
-    const int R = bo.R[kind];
-    int us, uc;
-    unit_shape(kind, n, kg, us, uc);
-    if (us <= 0 || uc <= 0 || us > R) continue;
-    const int b0 = binstate[(2 * kind) * B + g], f0 = binstate[(2 * kind + 1) * B + g];
-    int a = (R - f0) / us;
-    if (a > uc) a = uc;
-    const int per = R / us;
-    for (int i = threadIdx.x; i < us * uc; i += blockDim.x) {
-      int u = i / us, r = i - u * us;
-      int bin, row0;
-      if (u < a) { bin = b0; row0 = f0 + u * us; }
-      else { int v = u - a; bin = b0 + 1 + v / per; row0 = (v % per) * us; }
-      int node, slot;
-      if (kind == 0) { node = gs + r; slot = u; }
-      else if (kind == 1) { node = gs + u; slot = r; }
-      else { node = gs + r; slot = 0; }
-      const int64_t o = (int64_t)bin * R + row0 + r;
-      bo.node[kind][o] = node;
-      bo.slot[kind][o] = slot;
-    }
-  }
+                                                   int32_t* __restrict__ eperm) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int64_t s = ei[e], d = ei[E + e];
+  if (s < 0 || s >= N || d < 0 || d >= N) return;
+  int p = atomicAdd(&cursor[d], 1);
+  col[p] = (int32_t)s;
+  eperm[p] = (int32_t)e;
 }
 
 // K5: per node — sort each CSR segment by edge id (insertion sort; molecular degrees are <= 4).
@@ -286,196 +457,6 @@ __global__ void k_plan_sort(int64_t N, const int32_t* __restrict__ rowptr, int32
     }
     eperm[b + 1] = ke;
     col[b + 1] = kc;
-  }
-}
-
-// ---------------------------------------------------------------------------- single-workgroup plan (small batches)
-// Everything sn_batch_plan produces, in ONE launch of one 1024-thread workgroup with all intermediate state in
-// LDS — for batches with N <= 4096 nodes, E <= 10240 edges, B <= 512 graphs (the reference's batch sizes:
-// 128-256 molecules).  Five dependent launches cost ~60 us on MI355X; this path costs one.
-constexpr int PS_NMAX = 4096, PS_EMAX = 10240, PS_BMAX = 512, PS_T = 1024;
-
-__device__ __forceinline__ int ps_block_exscan(int v, int* part, int t) {   // exclusive scan of one int per thread
-  part[t] = v;
-  __syncthreads();
-  for (int off = 1; off < PS_T; off <<= 1) {
-    int a = (t >= off) ? part[t - off] : 0;
-    __syncthreads();
-    part[t] += a;
-    __syncthreads();
-  }
-  return part[t] - v;
-}
-
-__global__ __launch_bounds__(PS_T) void k_plan_small(const int64_t* __restrict__ batch, int N, int B,
-                                                     const int64_t* __restrict__ ei, int E, int kmax,
-                                                     int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
-                                                     int32_t* __restrict__ nvalid, int64_t* __restrict__ evoff,
-                                                     int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
-                                                     int32_t* __restrict__ eperm, int32_t* __restrict__ status, BinsOut bo,
-                                                     int32_t* __restrict__ bins_meta) {
-  extern __shared__ int sm[];
-  int* gp = sm;                      // [B+1]
-  int* deg = gp + (PS_BMAX + 1);     // [N]  in-degree, then fill cursor
-  int* rp = deg + PS_NMAX;           // [N+1]
-  int* lcol = rp + (PS_NMAX + 1);    // [E]
-  int* lperm = lcol + PS_EMAX;       // [E]
-  int* part = lperm + PS_EMAX;       // [PS_T]
-  int* bst = part + PS_T;            // [3][2][B] bin start state per graph
-  __shared__ int s_err, s_nmax, s_dmax, s_nb[3], s_berr[3];
-  const int t = threadIdx.x;
-  if (t == 0) { s_err = 0; s_nmax = 0; s_dmax = 0; }
-  if (t < 3) { s_nb[t] = 0; s_berr[t] = 1; }
-  for (int i = t; i < N; i += PS_T) deg[i] = 0;
-  for (int i = t; i <= B; i += PS_T) gp[i] = N;     // graphs after the last node (and gp[B]) start at N
-  __syncthreads();
-  // ---- nodes: graph ids, boundaries, validation
-  for (int i = t; i < N; i += PS_T) {
-    const long long g = batch[i];
-    const long long gprev = (i == 0) ? -1 : batch[i - 1];
-    if (g < 0 || g >= B) { atomicOr(&s_err, ERR_GRAPH_ID); node_graph[i] = 0; continue; }
-    node_graph[i] = (int)g;
-    if (gprev > g) atomicOr(&s_err, ERR_UNSORTED);
-    if (gprev < g) {
-      const long long lo = gprev < -1 ? 0 : gprev + 1;
-      for (long long k = lo; k <= g; ++k) gp[k] = i;   // ids in (gprev, g) are empty graphs starting here too
-    }
-  }
-  __syncthreads();
-  // ---- three waves walk the graphs for the bin packing while the others count in-degrees
-  const int wave = t >> 6, lane = t & 63;
-  if (wave >= 13) {
-    const int k = wave - 13;
-    if (lane == 0 && bins_meta) {
-      if (bo.node[k]) {
-        const int R = bo.R[k];
-        int bin = 0, fill = 0, err = 0, rows = 0;
-        for (int g = 0; g < B; ++g) {
-          const int n = gp[g + 1] - gp[g];
-          const int kg = (kmax > 0 && n > kmax) ? kmax : n;
-          int us, uc;
-          unit_shape(k, n, kg, us, uc);
-          bst[(2 * k) * PS_BMAX + g] = bin;
-          bst[(2 * k + 1) * PS_BMAX + g] = fill;
-          if (us <= 0 || uc <= 0) continue;
-          if (us > R) { err = 1; continue; }
-          rows += us * uc;
-          int a = idiv_small(R - fill, us);
-          if (a > uc) a = uc;
-          fill += a * us;
-          const int rem = uc - a;
-          if (rem > 0) {
-            const int per = idiv_small(R, us);
-            const int nb = idiv_small(rem + per - 1, per);
-            bin += nb;
-            fill = (rem - (nb - 1) * per) * us;
-          }
-        }
-        const int nbins = fill > 0 ? bin + 1 : bin;
-        const int berr = err | (nbins > bo.max_bins[k] ? 2 : 0);
-        bins_meta[4 * k] = nbins;
-        bins_meta[4 * k + 1] = berr;
-        bins_meta[4 * k + 2] = rows;
-        bins_meta[4 * k + 3] = R;
-        s_nb[k] = nbins;
-        s_berr[k] = berr;
-      } else {
-        bins_meta[4 * k] = 0; bins_meta[4 * k + 1] = 0; bins_meta[4 * k + 2] = 0; bins_meta[4 * k + 3] = 0;
-      }
-    }
-  } else {
-    for (int e = t; e < E; e += 13 * 64) {
-      const long long s = ei[e], d = ei[(long long)E + e];
-      if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(&s_err, ERR_EDGE_RANGE); continue; }
-      if (batch[s] != batch[d]) atomicOr(&s_err, ERR_EDGE_CROSS);
-      atomicAdd(&deg[d], 1);
-    }
-  }
-  __syncthreads();
-  // ---- rowptr = exclusive scan of deg ; evoff = exclusive scan of n^2
-  {
-    const int per = (N + PS_T - 1) / PS_T;
-    const int lo = t * per, hi = (lo + per < N) ? lo + per : N;
-    int s = 0, dmax = 0;
-    for (int i = lo; i < hi; ++i) { s += deg[i]; dmax = dmax > deg[i] ? dmax : deg[i]; }
-    atomicMax(&s_dmax, dmax);
-    int run = ps_block_exscan(s, part, t);
-    for (int i = lo; i < hi; ++i) { const int dg = deg[i]; rp[i] = run; deg[i] = run; run += dg; }
-    if (t == PS_T - 1) rp[N] = part[PS_T - 1];
-    __syncthreads();
-    const int n = (t < B) ? gp[t + 1] - gp[t] : 0;
-    atomicMax(&s_nmax, n);
-    const int ex = ps_block_exscan(n * n, part, t);
-    if (t < B) evoff[t] = ex;
-    if (t == PS_T - 1) evoff[B] = part[PS_T - 1];
-  }
-  __syncthreads();
-  // ---- fill the CSR segments (arbitrary arrival order), then sort each segment by edge id
-  for (int e = t; e < E; e += PS_T) {
-    const long long s = ei[e], d = ei[(long long)E + e];
-    if (s < 0 || s >= N || d < 0 || d >= N) continue;
-    const int p = atomicAdd(&deg[d], 1);
-    lcol[p] = (int)s;
-    lperm[p] = e;
-  }
-  __syncthreads();
-  for (int i = t; i < N; i += PS_T) {
-    const int lo = rp[i], hi = rp[i + 1];
-    for (int a = lo + 1; a < hi; ++a) {
-      const int ke = lperm[a], kc = lcol[a];
-      int b = a - 1;
-      while (b >= lo && lperm[b] > ke) { lperm[b + 1] = lperm[b]; lcol[b + 1] = lcol[b]; --b; }
-      lperm[b + 1] = ke;
-      lcol[b + 1] = kc;
-    }
-  }
-  __syncthreads();
-  // ---- write out
-  for (int i = t; i <= N; i += PS_T) rowptr[i] = rp[i];
-  for (int i = t; i < E; i += PS_T) { col[i] = lcol[i]; eperm[i] = lperm[i]; }
-  for (int i = t; i <= B; i += PS_T) graph_ptr[i] = gp[i];
-  for (int i = t; i < N; i += PS_T) {
-    const long long g = batch[i];
-    int nv = 0;
-    if (g >= 0 && g < B) { const int n = gp[g + 1] - gp[g]; nv = (kmax > 0 && n > kmax) ? kmax : n; }
-    nvalid[i] = nv;
-  }
-  if (t == 0) { status[ST_ERR] = s_err; status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
-  // ---- bin rows: padding first (tail of every bin is rewritten below where a unit lands), then one wave per graph
-  for (int k = 0; k < 3; ++k) {
-    if (!bo.node[k] || s_berr[k] != 0) continue;
-    const int R = bo.R[k];
-    const int nb = s_nb[k];
-    for (int i = t; i < nb * R; i += PS_T) { bo.node[k][i] = -1; bo.slot[k][i] = -1; }
-  }
-  __syncthreads();
-  for (int g = wave; g < B; g += PS_T / 64) {
-    const int gs = gp[g], n = gp[g + 1] - gs;
-    const int kg = (kmax > 0 && n > kmax) ? kmax : n;
-    for (int k = 0; k < 3; ++k) {
-      if (!bo.node[k] || s_berr[k] != 0) continue;
-      const int R = bo.R[k];
-      int us, uc;
-      unit_shape(k, n, kg, us, uc);
-      if (us <= 0 || uc <= 0 || us > R) continue;
-      const int b0 = bst[(2 * k) * PS_BMAX + g], f0 = bst[(2 * k + 1) * PS_BMAX + g];
-      int a = idiv_small(R - f0, us);
-      if (a > uc) a = uc;
-      const int per = idiv_small(R, us);
-      for (int i = lane; i < us * uc; i += 64) {
-        const int u = i / us, r = i - u * us;
-        int bin, row0;
-        if (u < a) { bin = b0; row0 = f0 + u * us; }
-        else { const int v = u - a; bin = b0 + 1 + v / per; row0 = (v % per) * us; }
-        int node, slot;
-        if (k == 0) { node = gs + r; slot = u; }
-        else if (k == 1) { node = gs + u; slot = r; }
-        else { node = gs + r; slot = 0; }
-        const long long o = (long long)bin * R + row0 + r;
-        bo.node[k][o] = node;
-        bo.slot[k][o] = slot;
-      }
-    }
   }
 }
 
@@ -501,7 +482,6 @@ __global__ void k_pack_eig(const float* __restrict__ ev, const float* __restrict
   if (s0) s0[idx] = s;
 }
 
-
 }  // namespace sn
 
 using namespace sn;
@@ -509,26 +489,29 @@ using namespace sn;
 extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index,
                              int64_t E, int kmax, int32_t* graph_ptr, int32_t* node_graph,
                              int32_t* nvalid, int64_t* evoff, int32_t* rowptr, int32_t* col,
-                             int32_t* eperm, int32_t* status, const sn_bins_out* bins, int32_t* bins_meta,
-                             int32_t* scratch, void* stream) {
+                             int32_t* eperm, int32_t* status, const sn_plan_bins* bins, int32_t* scratch,
+                             void* stream) {
   SN_REQUIRE(N >= 0 && B >= 0 && E >= 0, "sn_batch_plan: negative size");
   SN_REQUIRE(N < (1ll << 31) && E < (1ll << 31), "sn_batch_plan: N/E exceed int32");
   SN_REQUIRE(graph_ptr && node_graph && nvalid && evoff && rowptr && status && scratch,
              "sn_batch_plan: null output");
   SN_REQUIRE(N == 0 || batch, "sn_batch_plan: null batch");
   SN_REQUIRE(E == 0 || (edge_index && col && eperm), "sn_batch_plan: null edge arrays");
-  BinsOut bo;
-  for (int k = 0; k < 3; ++k) {
-    bo.R[k] = 0; bo.max_bins[k] = 0; bo.node[k] = nullptr; bo.slot[k] = nullptr;
-    if (bins && bins[k].node) {
-      SN_REQUIRE(bins[k].slot && bins[k].R > 0 && bins[k].max_bins >= 0 && bins_meta, "sn_batch_plan: bad bins[%d]", k);
-      bo.R[k] = bins[k].R; bo.max_bins[k] = bins[k].max_bins; bo.node[k] = bins[k].node; bo.slot[k] = bins[k].slot;
-    }
+  BinsDev bd{};
+  const bool do_bins = bins != nullptr;
+  if (do_bins) {
+    SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->rho_bin0 &&
+                   bins->meta && bins->phi_max_bins >= 0,
+               "sn_batch_plan: incomplete sn_plan_bins");
+    SN_REQUIRE(B <= BINS_BMAX, "sn_batch_plan: work bins support at most %d graphs per batch (got %lld)", BINS_BMAX, (long long)B);
+    bd = BinsDev{bins->phi_bin_col, bins->phi_max_bins, bins->phi_col_bin0, bins->phi_col_mem, bins->phi_col_off,
+                 bins->rho_bin0, bins->meta};
   }
   hipStream_t st = (hipStream_t)stream;
-  static const bool small_path = getenv("SN_PLAN_SMALL") != nullptr;   // experimental: measured slower (124 vs 61 us)
-  if (small_path && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX && N > 0) {
-    const size_t lds = (size_t)((PS_BMAX + 1) + PS_NMAX + (PS_NMAX + 1) + 2 * PS_EMAX + PS_T + 6 * PS_BMAX) * sizeof(int);
+  if (N > 0 && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX) {
+    const size_t lds0 = (size_t)((PS_BMAX + 4) + PS_NMAX + (PS_NMAX + 4) + 2 * PS_EMAX + 32) * sizeof(int);
+    const size_t lds1 = (size_t)((PS_BMAX + 4) + 2 * PS_BMAX + 3 * 66 + 32) * sizeof(int);
+    const size_t lds = lds0 > lds1 ? lds0 : lds1;
     static bool init = false;
     if (!init) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_small), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -536,32 +519,42 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
         return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit to %zu", lds);
       init = true;
     }
-    hipLaunchKernelGGL(k_plan_small, dim3(1), dim3(PS_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E, kmax, graph_ptr,
-                       node_graph, nvalid, evoff, rowptr, col, eperm, status, bo, bins_meta);
+    hipLaunchKernelGGL(k_plan_small, dim3(do_bins ? 2 : 1), dim3(PLAN_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E,
+                       kmax, graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bd, do_bins ? 1 : 0);
     SN_CHECK_LAUNCH("sn_batch_plan");
     return SN_OK;
   }
-  int32_t* deg = scratch;                       // [N]
-  int32_t* binstate = scratch + ((N + 3) / 4) * 4;  // [3][2][B]
+  int32_t* deg = scratch;  // [N]
   const int T = 256;
-  const bool any_bins = bo.node[0] || bo.node[1] || bo.node[2];
-  int64_t nb1 = cdiv(N > 0 ? N : 1, T);
-  if (nb1 < 64) nb1 = 64;                       // enough threads to clear the bin arrays quickly
-  hipLaunchKernelGGL(k_plan_nodes, dim3((unsigned)nb1), dim3(T), 0, st, batch, N, B, graph_ptr, node_graph, deg, status, bo);
+  hipLaunchKernelGGL(k_plan_nodes, dim3((unsigned)cdiv(N > 0 ? N : 1, T)), dim3(T), 0, st, batch, N, B, graph_ptr, node_graph, deg,
+                     status);
   const int64_t ne = N > E ? N : E;
   hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(ne > 0 ? ne : 1, T)), dim3(T), 0, st, batch, edge_index, E, N, B, deg,
                      status);
-  hipLaunchKernelGGL(k_plan_scan, dim3(any_bins ? 2 : 1), dim3(1024), 0, st, N, B, kmax, graph_ptr, node_graph, deg, rowptr, nvalid, evoff,
-                     status, bo, binstate, bins_meta);
-  const int eblocks = (int)cdiv(E, T);
-  const int64_t gblocks = any_bins ? B : 0;
-  if (eblocks + gblocks > 0)
-    hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)(eblocks + gblocks)), dim3(T), 0, st, edge_index, E, N, eblocks, deg, col,
-                       eperm, graph_ptr, B, kmax, bo, binstate, bins_meta);
-  if (E > 0)
+  const size_t lds3 = do_bins ? (size_t)((B + 4) + 2 * B + 3 * 66 + 32) * sizeof(int) : 0;
+  if (lds3 > 48 * 1024) {
+    static bool init3 = false;
+    if (!init3) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)(3 * BINS_BMAX + 4 + 3 * 66 + 32) * sizeof(int))) != hipSuccess)
+        return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit");
+      init3 = true;
+    }
+  }
+  hipLaunchKernelGGL(k_plan_scan, dim3(do_bins ? 2 : 1), dim3(PLAN_T), lds3, st, N, B, kmax, graph_ptr, node_graph, deg, rowptr,
+                     nvalid, evoff, status, bd);
+  if (E > 0) {
+    hipLaunchKernelGGL(k_plan_fill, dim3((unsigned)cdiv(E, T)), dim3(T), 0, st, edge_index, E, N, deg, col, eperm);
     hipLaunchKernelGGL(k_plan_sort, dim3((unsigned)cdiv(N, T)), dim3(T), 0, st, N, rowptr, col, eperm);
+  }
   SN_CHECK_LAUNCH("sn_batch_plan");
   return SN_OK;
+}
+
+extern "C" int64_t sn_phi_bins_bound(int64_t B, int kmax) {
+  // every column has height <= min(kmax, 64); at worst one graph per column
+  const int64_t h = (kmax > 0 && kmax < 64) ? kmax : 64;
+  return B * h + 1;
 }
 
 extern "C" int sn_pack_eig_f32(const float* eigen_vectors, const float* eigen_values,
@@ -577,10 +570,3 @@ extern "C" int sn_pack_eig_f32(const float* eigen_vectors, const float* eigen_va
   SN_CHECK_LAUNCH("sn_pack_eig_f32");
   return SN_OK;
 }
-
-extern "C" int64_t sn_bins_bound(int64_t rows_upper_bound, int R) {
-  // next-fit: two consecutive bins always hold more than R rows together
-  if (R <= 0) return 0;
-  return 2 * cdiv(rows_upper_bound > 0 ? rows_upper_bound : 0, R) + 2;
-}
-

@@ -72,7 +72,7 @@ class PhiPlan:
             Lp.eps = hold(c.layer.eps.detach())
         self.params = P
 
-    def run(self, plan: ops.GraphPlan, bins: ops.Bins, eigen_vectors, K: int, out=None):
+    def run(self, plan: ops.GraphPlan, eigen_vectors, K: int, out=None):
         """phi(x)+phi(-x) -> [N, K, d]; rows of invalid slots are left untouched (zero if `out` is None)."""
         ev = eigen_vectors
         if ev.dtype != torch.float32 or not ev.is_contiguous():
@@ -80,15 +80,13 @@ class PhiPlan:
         if out is None:
             out = torch.zeros(plan.N, K, self.d, dtype=torch.float32, device=ev.device)
         with ops._span("sn_phi_fused_f32"):
-            check(lib().sn_phi_fused_f32(C.byref(self.params), ptr(ev), ptr(plan.graph_ptr), ptr(plan.node_graph),
-                                         ptr(plan.evoff), ptr(plan.rowptr), ptr(plan.col), ptr(bins.node),
-                                         ptr(bins.slot), ptr(bins.meta), bins.max_bins, K, ptr(out), stream()),
-                  "sn_phi_fused_f32")
+            check(lib().sn_phi_fused_f32(C.byref(self.params), ptr(ev), ptr(plan.graph_ptr), ptr(plan.evoff),
+                                         ptr(plan.rowptr), ptr(plan.col), C.byref(plan.bins.cstruct), plan.kmax, K,
+                                         ptr(out), stream()), "sn_phi_fused_f32")
         return out
 
 
 RHO_MAX_LAYERS = 8
-RHO_BIN_ROWS = 64
 
 
 class _RhoLayer(C.Structure):
@@ -141,13 +139,13 @@ class RhoPlan:
             Lp.ln2_g, Lp.ln2_b = hold(ops.pad_vec(f.norm.ln.weight, dp)), hold(ops.pad_vec(f.norm.ln.bias, dp))
         self.params = P
 
-    def run(self, plan: ops.GraphPlan, bins: ops.Bins, x, eigen_values, K: int):
+    def run(self, plan: ops.GraphPlan, x, eigen_values, K: int):
         """x [N*K, d] -> sum over valid slots of the encoder output, [N, d]."""
         out = torch.empty(plan.N, self.d, dtype=torch.float32, device=x.device)
         with ops._span("sn_rho_fused_f32"):
-            check(lib().sn_rho_fused_f32(C.byref(self.params), ptr(x), ptr(eigen_values), ptr(plan.graph_ptr),
-                                         ptr(plan.node_graph), ptr(plan.nvalid), ptr(bins.node), ptr(bins.slot),
-                                         ptr(bins.meta), bins.max_bins, K, ptr(out), stream()), "sn_rho_fused_f32")
+            check(lib().sn_rho_fused_f32(C.byref(self.params), ptr(x), ptr(eigen_values), ptr(plan.graph_ptr), plan.B,
+                                         plan.N, C.byref(plan.bins.cstruct), plan.kmax, K, ptr(out), stream()),
+                  "sn_rho_fused_f32")
         return out
 
 

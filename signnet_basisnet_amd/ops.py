@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, check, lib, ptr,
                    require_cuda, stream)
 
-__all__ = ["KernelTimer", "KERNEL_ROOFLINE", "GraphPlan", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
+__all__ = ["KernelTimer", "KERNEL_ROOFLINE", "GraphPlan", "PlanBins", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
            "masked_linear", "masked_colstats", "masked_affine", "masked_layernorm", "set_attention",
            "slot_sum", "embedding_sum", "segment_pool", "PackedLinear",
            "EPI_BIAS", "EPI_RELU_PRE", "EPI_AFFINE", "EPI_RELU", "EPI_RESIDUAL"]
@@ -92,14 +92,16 @@ def _f32c(t, name):
 
 
 @dataclass
-class Bins:
-    """Work bins of one fused stage (kind 0: (graph,slot) slabs; 1: nodes; 2: graphs)."""
-    kind: int
-    R: int
-    max_bins: int
-    node: torch.Tensor   # int32 [max_bins*R]  node id per bin row, -1 = padding
-    slot: torch.Tensor   # int32 [max_bins*R]
-    meta: torch.Tensor   # int32 [4]: nbins, error flag, real rows, R
+class PlanBins:
+    """Work bins of the fused phi / rho stages (device arrays written by sn_batch_plan; see signnet_hip.h)."""
+    phi_bin_col: torch.Tensor    # int32 [phi_max_bins]
+    phi_max_bins: int
+    phi_col_bin0: torch.Tensor   # int32 [B+1]
+    phi_col_mem: torch.Tensor    # int32 [B*8]
+    phi_col_off: torch.Tensor    # int32 [B*8]
+    rho_bin0: torch.Tensor       # int32 [B+1]
+    meta: torch.Tensor           # int32 [8]
+    cstruct: object              # ctypes mirror (sn_plan_bins) holding the device pointers
 
 
 @dataclass
@@ -116,8 +118,8 @@ class GraphPlan:
     rowptr: torch.Tensor      # int32 [N+1] dst-sorted CSR
     col: torch.Tensor         # int32 [E]   source node of each in-edge
     eperm: torch.Tensor       # int32 [E]   original edge id of each CSR slot
-    status: torch.Tensor      # int32 [4]   [err bits, max nodes/graph, max in-degree, -]
-    bins: dict                # kind -> Bins
+    status: torch.Tensor      # int32 [4]   [err bits, max nodes/graph, max in-degree, fused-stage flags]
+    bins: PlanBins | None
 
     def check(self):
         """Synchronising validity check (raises on malformed batches)."""
@@ -129,12 +131,13 @@ class GraphPlan:
         return st
 
 
-class _BinsOut(C.Structure):
-    _fields_ = [("R", C.c_int), ("max_bins", C.c_int64), ("node", C.c_void_p), ("slot", C.c_void_p)]
+class _PlanBinsC(C.Structure):
+    _fields_ = [("phi_bin_col", C.c_void_p), ("phi_max_bins", C.c_int64), ("phi_col_bin0", C.c_void_p),
+                ("phi_col_mem", C.c_void_p), ("phi_col_off", C.c_void_p), ("rho_bin0", C.c_void_p), ("meta", C.c_void_p)]
 
 
-def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins=None) -> GraphPlan:
-    """bins: optional {kind: (R, rows_upper_bound)} — work bins for the fused stages, built in the same launches."""
+def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins: bool = False) -> GraphPlan:
+    """bins=True also lays out the work bins of the fused stages (same launch, no host sync)."""
     require_cuda(batch, edge_index)
     if batch.dtype != torch.int64 or edge_index.dtype != torch.int64:
         raise ValueError("build_plan: batch and edge_index must be int64 (the reference's index dtype)")
@@ -142,34 +145,29 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     edge_index = edge_index.contiguous()
     N, E, B = batch.numel(), edge_index.shape[1] if edge_index.numel() else 0, int(num_graphs)
     dev = batch.device
-    bins = bins or {}
-    specs = []
-    for kind in range(3):
-        if kind in bins:
-            R, ub = bins[kind]
-            specs.append((kind, int(R), int(lib().sn_bins_bound(int(ub), int(R)))))
     # one int32 arena, carved into the plan arrays (single allocation per batch)
-    sizes = [B + 1, N, N, N + 1, E, E, 4, 12, 4 * ((N + 3) // 4) + 6 * B + 8]
-    for _, R, mb in specs:
-        sizes += [mb * R, mb * R]
+    sizes = [B + 1, N, N, N + 1, E, E, 4, N + 8]
+    mb = 0
+    if bins:
+        mb = int(lib().sn_phi_bins_bound(B, int(kmax)))
+        sizes += [mb, B + 1, 8 * B, 8 * B, B + 1, 8]
     offs = [0]
     for s in sizes:
         offs.append(offs[-1] + ((s + 3) // 4) * 4)
     arena = torch.empty(offs[-1], dtype=torch.int32, device=dev)
     parts = [arena[offs[i]:offs[i] + sizes[i]] for i in range(len(sizes))]
-    graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, bmeta, scratch = parts[:9]
+    graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, scratch = parts[:8]
     evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
-    bo = (_BinsOut * 3)()
-    bdict = {}
-    for j, (kind, R, mb) in enumerate(specs):
-        node, slot = parts[9 + 2 * j], parts[10 + 2 * j]
-        bo[kind].R, bo[kind].max_bins, bo[kind].node, bo[kind].slot = R, mb, node.data_ptr(), slot.data_ptr()
-        bdict[kind] = Bins(kind, R, mb, node, slot, bmeta[4 * kind:4 * kind + 4])
+    pb = None
+    if bins:
+        bc, cb0, mem, off, rb0, meta = parts[8:14]
+        cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr())
+        pb = PlanBins(bc, mb, cb0, mem, off, rb0, meta, cs)
     with _span("sn_batch_plan"):
         check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
                                   ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
-                                  bo if specs else None, ptr(bmeta), ptr(scratch), stream()), "sn_batch_plan")
-    return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bdict)
+                                  C.byref(pb.cstruct) if pb is not None else None, ptr(scratch), stream()), "sn_batch_plan")
+    return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, pb)
 
 
 def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: bool):

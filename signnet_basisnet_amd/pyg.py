@@ -349,17 +349,9 @@ class SignNetGNN(nn.Module):
         P = self._prep
         B = int(data.num_graphs)
         use_phi_fused = P["phi_fused"] is not None
-        rows_ub = data.eigen_vectors.numel()
-        if self.max_k:
-            rows_ub = min(rows_ub, data.batch.numel() * int(self.max_k))
         use_rho_fused = P["rho_fused"] is not None
-        bins = {}
-        if use_phi_fused:
-            bins[0] = (ops.PHI_BIN_ROWS, rows_ub)
-        if use_rho_fused:
-            bins[1] = (fused.RHO_BIN_ROWS, rows_ub)
         use_gnn_fused = P["gnn_fused"] is not None
-        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=bins)
+        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=use_phi_fused or use_rho_fused)
         if self.max_k:
             K = int(self.max_k)
             plan.check() if return_stages else None
@@ -376,7 +368,7 @@ class SignNetGNN(nn.Module):
         # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)
         phis = None
         if use_phi_fused and not return_stages:
-            x = P["phi_fused"].run(plan, plan.bins[0], data.eigen_vectors, K).view(N * K, d)
+            x = P["phi_fused"].run(plan, data.eigen_vectors, K).view(N * K, d)
         else:
             phis = []
             for sign in (0, 1):
@@ -391,12 +383,12 @@ class SignNetGNN(nn.Module):
         if return_stages:
             stages.update(phi_plus=phis[0].view(N, K, d), phi_minus=phis[1].view(N, K, d), phi=x.view(N, K, d))
             if P["phi_fused"] is not None:      # cross-check target for the fused kernel
-                stages["phi_fused"] = P["phi_fused"].run(plan, plan.bins[0], data.eigen_vectors, K)
-                stages["phi_bins_meta"] = plan.bins[0].meta
+                stages["phi_fused"] = P["phi_fused"].run(plan, data.eigen_vectors, K)
+                stages["bins_meta"] = plan.bins.meta
         # ---- rho                    (SetTransformer.forward, sign_net.py:60-72)
         x_phi = x
         if use_rho_fused and not return_stages:
-            s = P["rho_fused"].run(plan, plan.bins[1], x_phi, data.eigen_values if want_vals else None, K)
+            s = P["rho_fused"].run(plan, x_phi, data.eigen_values if want_vals else None, K)
         else:
             if want_vals:
                 E_ = P["eig"]
@@ -421,9 +413,7 @@ class SignNetGNN(nn.Module):
             stages["pos"] = pe
             stages["rho_sum"] = s
             if use_rho_fused:
-                stages["rho_sum_fused"] = P["rho_fused"].run(plan, plan.bins[1], x_phi,
-                                                             data.eigen_values if want_vals else None, K)
-                stages["rho_bins_meta"] = plan.bins[1].meta
+                stages["rho_sum_fused"] = P["rho_fused"].run(plan, x_phi, data.eigen_values if want_vals else None, K)
         # ---- GINE network           (GNN.forward, model.py:36-64)
         xin = data.x.squeeze() if data.x.dim() > 1 and data.x.shape[-1] == 1 else data.x
         if "in_tabs" in P:

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_python_binding_covers_the_header(lib):
     from signnet_basisnet_amd import _lib
-    bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_bins_bound",
+    bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_phi_bins_bound",
                                      "sn_ign_contract_scratch_floats"}
     assert set(declared_symbols()) == bound
 
@@ -48,7 +48,7 @@ def test_version_and_error_string(lib):
     assert rc == -1 and b"sn_pack_weight_f32" in lib.sn_last_error()
     assert lib.sn_packed_weight_floats(128, 128) == 64 * 256
     assert lib.sn_packed_weight_floats(108, 6) == 7 * 1 * 256
-    assert lib.sn_bins_bound(640, 64) == 22
+    assert lib.sn_phi_bins_bound(128, 16) == 128 * 16 + 1 and lib.sn_phi_bins_bound(10, 0) == 641
 
 
 def test_struct_layouts_match_the_header():
@@ -59,7 +59,7 @@ def test_struct_layouts_match_the_header():
 #include <stddef.h>
 #include "signnet_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sn_bins_out), sizeof(sn_phi_layer), sizeof(sn_phi_params),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sn_plan_bins), sizeof(sn_phi_layer), sizeof(sn_phi_params),
          sizeof(sn_rho_layer), sizeof(sn_rho_params), sizeof(sn_gnn_layer), sizeof(sn_gnn_params),
          offsetof(sn_gnn_params, layers));
   printf("%zu %zu %zu\n", offsetof(sn_phi_params, layers), offsetof(sn_rho_params, layers), offsetof(sn_rho_params, pe_w1));
@@ -73,7 +73,7 @@ int main(void) {
         out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
     got = [int(v) for v in out]
     S = ctypes.sizeof
-    want = [S(ops._BinsOut), S(fused._PhiLayer), S(fused._PhiParams), S(fused._RhoLayer), S(fused._RhoParams),
+    want = [S(ops._PlanBinsC), S(fused._PhiLayer), S(fused._PhiParams), S(fused._RhoLayer), S(fused._RhoParams),
             S(fused._GnnLayer), S(fused._GnnParams), fused._GnnParams.layers.offset,
             fused._PhiParams.layers.offset, fused._RhoParams.layers.offset, fused._RhoParams.pe_w1.offset]
     assert got == want

@@ -41,9 +41,8 @@ def test_golden(name):
     close(st["pos"], fx.out["eval/pos"], "sign_net output")
     close(y, fx.out["eval/y"], "model output")
     # fused phi kernel: same quantity as the layer path and as the reference
-    assert st["phi_bins_meta"].cpu().tolist()[1] == 0
+    assert st["bins_meta"].cpu().tolist()[1] == 0 and st["bins_meta"].cpu().tolist()[5] == 0
     close(st["phi_fused"], fx.out["eval/phi_plus"] + fx.out["eval/phi_minus"], "fused phi(x)+phi(-x)")
-    assert st["rho_bins_meta"].cpu().tolist()[1] == 0
     close(st["y_gnn_fused"], fx.out["eval/y"], "fused gnn output (from the layer-path slot sum)")
     close(st["rho_sum_fused"], st["rho_sum"], "fused rho slot-sum vs layer path")
     # and the default forward (fused stages) gives the reference output
@@ -51,39 +50,57 @@ def test_golden(name):
 
 
 def test_plan_bins():
-    """Bin packing invariants: every valid (node, slot) row appears exactly once, slabs are whole."""
+    """Work-bin invariants.  phi: every graph sits in exactly one column, members do not overlap and fit 64 rows,
+    column heights are max K_g, bin_col inverts col_bin0.  rho: bins per graph in closed form."""
     from signnet_basisnet_amd import ops, synth
     data = synth.make_batch(40, seed=9)
     d = synth.batch_to(data, "cuda:0")
+    n = torch.tensor(data.sizes)
     for kmax in (0, 16, 5):
-        n = torch.tensor(data.sizes)
         kg = n.clamp(max=kmax) if kmax else n
-        ubs = {0: int((n * kg).sum()), 1: int((n * kg).sum()), 2: int(n.sum())}
-        plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins={k: (64, ubs[k]) for k in range(3)})
+        plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True)
         assert plan.check()[0] == 0
-        for kind, R in ((0, 64), (1, 64), (2, 64)):
-            rows_ub = ubs[kind]
-            bins = plan.bins[kind]
-            nb, err, rows = bins.meta.cpu().tolist()[:3]
-            assert err == 0 and rows == rows_ub and nb <= bins.max_bins
-            node = bins.node.cpu()[:nb * R].view(nb, R)
-            slot = bins.slot.cpu()[:nb * R].view(nb, R)
-            ok = node >= 0
-            assert int(ok.sum()) == rows_ub
-            K = int(kg.max())
-            key = (node[ok].long() * (K + 1) + slot[ok].long())
-            assert key.unique().numel() == rows_ub                     # no duplicates
-            if kind == 0:      # rows of a slab are consecutive nodes of one graph within one bin
-                for b in range(nb):
-                    r = 0
-                    while r < R and node[b, r] >= 0:
-                        g = int(data.batch[node[b, r]])
-                        ng = data.sizes[g]
-                        assert node[b, r:r + ng].tolist() == list(range(int(node[b, r]), int(node[b, r]) + ng))
-                        assert (slot[b, r:r + ng] == slot[b, r]).all()
-                        r += ng
-            # packing efficiency of next-fit stays reasonable
-            assert rows_ub / (nb * R) > 0.6
+        b = plan.bins
+        meta = b.meta.cpu().tolist()
+        nbins, err, rows, ncol = meta[:4]
+        assert err == 0 and rows == int((n * kg).sum()) and nbins <= b.phi_max_bins
+        mem = b.phi_col_mem.cpu().view(-1, 8)[:ncol]
+        off = b.phi_col_off.cpu().view(-1, 8)[:ncol]
+        cb0 = b.phi_col_bin0.cpu()[:ncol + 1]
+        seen = []
+        for c in range(ncol):
+            gs = [int(g) for g in mem[c] if g >= 0]
+            assert gs, "empty column"
+            seen += gs
+            spans = sorted((int(off[c, k]), int(off[c, k]) + data.sizes[int(mem[c, k])]) for k in range(len(gs)))
+            assert spans[0][0] == 0 and spans[-1][1] <= 64
+            assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+            assert int(cb0[c + 1] - cb0[c]) == max(int(kg[g]) for g in gs)
+        assert sorted(seen) == list(range(len(data.sizes)))
+        assert int(cb0[ncol]) == nbins
+        bc = b.phi_bin_col.cpu()[:nbins]
+        assert bc.tolist() == torch.repeat_interleave(torch.arange(ncol), (cb0[1:] - cb0[:-1]).long()).tolist()
+        assert rows / (nbins * 64) > 0.8, "best-fit-decreasing should pack the phi bins well"
+        # rho
+        rnb, rerr, rrows = meta[4:7]
+        pad = ((kg + 15) // 16) * 16
+        per_graph = (n + (64 // pad) - 1) // (64 // pad)
+        assert rerr == 0 and rrows == rows and rnb == int(per_graph.sum())
+        assert b.rho_bin0.cpu().tolist() == torch.cat([torch.zeros(1, dtype=torch.long), per_graph.cumsum(0)]).tolist()
+
+
+def test_full_eigenvector_mode_uses_the_lds_attention_path():
+    """max_k=None with graphs of more than 16 nodes: rho units span several wave tiles."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(1)
+    ctor = (None, None, 64, 1, 2, 2)
+    model = SignNetGNN(*ctor, variant="gine")
+    data = synth.make_batch(10, seed=5, sizes=[3, 17, 33, 16, 40, 9, 64, 25, 1, 48])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    yref = O.signnet_gnn(sd, O.make_cfg("gine", *ctor), data, training=False)
+    close(model.cuda().eval()(synth.batch_to(data, "cuda:0")), yref, "all-eigenvector forward")
 
 
 @pytest.mark.parametrize("variant,ctor,feat,max_k", [
