@@ -20,6 +20,8 @@ constexpr int GNN_ROWS = SN_GNN_MAX_NODES;   // 64
 constexpr int GNN_WAVES = 8;
 constexpr int GNN_OTS = 4;                   // max output tiles per wave (NT=8 split over >= 2 groups)
 constexpr int GNN_EMAX = 192;                // in-edges of one graph staged in LDS
+constexpr int GNN_EEMAX = 96;                // ... of which this many can have their layer embeddings staged too
+constexpr int GNN_EEPF = (GNN_EEMAX * 32 + GNN_WAVES * 64 - 1) / (GNN_WAVES * 64);   // float4 per thread (d_pad = 128)
 
 struct GnnStruct {
   const void* x;          // int64 [N, ldx] (discrete) or float [N, F]
@@ -33,6 +35,7 @@ struct GnnStruct {
   const int32_t* eperm;
   int32_t* status;        // status[3] |= 1 if a graph has more than 64 nodes (host falls back)
   float* y;               // [B, n_out]
+  int ee_rows;            // edges whose per-layer embeddings fit the LDS staging area
 };
 
 // Weight fragments of two output tiles (ot, ot+1) of one packed matrix, held in registers.
@@ -90,76 +93,103 @@ struct TileRange {
   }
 };
 
-// One Linear over the workgroup's rows.  The wave computes its TileRange, two output tiles at a time (two
-// independent accumulator chains; a lone tile splits its k-chunks over the two chains instead).  `pre` must hold
-// the fragments of the range's first tile pair (prefetched during the previous stage); once the last MFMAs are
-// issued, the fragments of the NEXT Linear's first pair are fetched into `pre`, so that latency overlaps the
-// epilogue, the barrier and the next stage's LDS reads.   img: input image [64][LD]; epi(rt, ot, acc).
-template <int NT, typename Epi>
-__device__ __forceinline__ void coop_gemm(WPair<NT>& pre, const float* __restrict__ wp, int nto, const float* img, int LD,
-                                          TileRange tr, int lane, Epi epi, const float* __restrict__ next_wp, int next_nto,
-                                          TileRange next_tr) {
-  const int g = lane >> 4;
-  bool fresh = true;   // `pre` is valid for the first pair only
-#pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
-    int rt, o_lo, o_hi;
-    tr.group(k, NT, rt, o_lo, o_hi);
-    if (o_lo >= o_hi) continue;
-    f32x4 in[NT];
-    const float* rowp = img + (rt * 16 + (lane & 15)) * LD + 4 * g;
+template <int NT>
+__device__ __forceinline__ void mfma_pair(const WPair<NT>& w, const f32x4 (&in)[NT], bool two, f32x4& a0, f32x4& a1) {
+  a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+  a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (two) {
 #pragma unroll
-    for (int kk = 0; kk < NT; ++kk) in[kk] = lds_ld4(rowp + 16 * kk);
-#pragma unroll 1
-    for (int ot = o_lo; ot < o_hi; ot += 2) {
-      const bool two = ot + 1 < o_hi;
-      if (!fresh) wload<NT>(pre, wp, nto, ot, true, two, lane);
-      fresh = false;
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-      if (two) {
+    for (int kk = 0; kk < NT; ++kk) {
+      a0 = mfma16(w.w0[kk].x, in[kk][0], a0);
+      a1 = mfma16(w.w1[kk].x, in[kk][0], a1);
+      a0 = mfma16(w.w0[kk].y, in[kk][1], a0);
+      a1 = mfma16(w.w1[kk].y, in[kk][1], a1);
+      a0 = mfma16(w.w0[kk].z, in[kk][2], a0);
+      a1 = mfma16(w.w1[kk].z, in[kk][2], a1);
+      a0 = mfma16(w.w0[kk].w, in[kk][3], a0);
+      a1 = mfma16(w.w1[kk].w, in[kk][3], a1);
+    }
+  } else {   // a lone tile: split its k-chunks over the two accumulator chains
 #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-          a0 = mfma16(pre.w0[kk].x, in[kk][0], a0);
-          a1 = mfma16(pre.w1[kk].x, in[kk][0], a1);
-          a0 = mfma16(pre.w0[kk].y, in[kk][1], a0);
-          a1 = mfma16(pre.w1[kk].y, in[kk][1], a1);
-          a0 = mfma16(pre.w0[kk].z, in[kk][2], a0);
-          a1 = mfma16(pre.w1[kk].z, in[kk][2], a1);
-          a0 = mfma16(pre.w0[kk].w, in[kk][3], a0);
-          a1 = mfma16(pre.w1[kk].w, in[kk][3], a1);
-        }
+    for (int kk = 0; kk < NT; ++kk) {
+      if (kk & 1) {
+        a1 = mfma16(w.w0[kk].x, in[kk][0], a1);
+        a1 = mfma16(w.w0[kk].y, in[kk][1], a1);
+        a1 = mfma16(w.w0[kk].z, in[kk][2], a1);
+        a1 = mfma16(w.w0[kk].w, in[kk][3], a1);
       } else {
+        a0 = mfma16(w.w0[kk].x, in[kk][0], a0);
+        a0 = mfma16(w.w0[kk].y, in[kk][1], a0);
+        a0 = mfma16(w.w0[kk].z, in[kk][2], a0);
+        a0 = mfma16(w.w0[kk].w, in[kk][3], a0);
+      }
+    }
+    a0 = a0 + a1;
+  }
+}
+
+// One Linear over the workgroup's rows.  The wave's TileRange (<= 4 tiles) is cut into <= 3 jobs of one or two
+// output tiles of one row tile.  Weight fragments ping-pong between `pre` and `alt`: while job j computes, the
+// fragments of job j+1 — or, for the last job, of the NEXT Linear's first job — are already in flight, so the L2
+// latency overlaps MFMAs, the epilogue, the barrier and the next stage's LDS reads.  On entry `pre` holds job 0's
+// fragments; on exit `pre` holds the next Linear's first job.   img: input image [64][LD]; epi(rt, ot, acc).
+template <int NT, typename Epi>
+__device__ __forceinline__ void coop_gemm(WPair<NT>& pre, WPair<NT>& alt, const float* __restrict__ wp, int nto,
+                                          const float* img, int LD, TileRange tr, int lane, Epi epi,
+                                          const float* __restrict__ next_wp, int next_nto, TileRange next_tr,
+                                          const float* __restrict__ ev0 = nullptr, const float* __restrict__ ev1 = nullptr) {
+  const int g = lane >> 4;
+  int jrt[3], jot[3];
+  bool jtwo[3];
+  int nj = 0;
+  {
+    int t = tr.t_lo;
 #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-          if (kk & 1) {
-            a1 = mfma16(pre.w0[kk].x, in[kk][0], a1);
-            a1 = mfma16(pre.w0[kk].y, in[kk][1], a1);
-            a1 = mfma16(pre.w0[kk].z, in[kk][2], a1);
-            a1 = mfma16(pre.w0[kk].w, in[kk][3], a1);
-          } else {
-            a0 = mfma16(pre.w0[kk].x, in[kk][0], a0);
-            a0 = mfma16(pre.w0[kk].y, in[kk][1], a0);
-            a0 = mfma16(pre.w0[kk].z, in[kk][2], a0);
-            a0 = mfma16(pre.w0[kk].w, in[kk][3], a0);
-          }
-        }
-        a0 = a0 + a1;
+    for (int j = 0; j < 3; ++j) {
+      jrt[j] = 0; jot[j] = 0; jtwo[j] = false;
+      if (t < tr.t_hi) {
+        const int rt = t / NT, ot = t - rt * NT;
+        const bool two = (t + 1 < tr.t_hi) && (ot + 1 < NT);
+        jrt[j] = rt; jot[j] = ot; jtwo[j] = two;
+        t += two ? 2 : 1;
+        nj = j + 1;
       }
-      const bool last = (ot + 2 >= o_hi) && (k == 1 || tr.t_hi <= (tr.t_lo / NT + 1) * NT);
-      if (last && next_wp) {
-        int nxo; bool n1, n2;
-        next_tr.first(NT, nxo, n1, n2);
-        wload<NT>(pre, next_wp, next_nto, nxo, n1, n2, lane);
-      }
-      epi(rt, ot, a0);
-      if (two) epi(rt, ot + 1, a1);
     }
   }
-  if (tr.empty() && next_wp) {   // idle in this Linear: still prefetch for the next one
-    int nxo; bool n1, n2;
-    next_tr.first(NT, nxo, n1, n2);
-    wload<NT>(pre, next_wp, next_nto, nxo, n1, n2, lane);
+  int nxo = 0;
+  bool n1 = false, n2 = false;
+  if (next_wp) next_tr.first(NT, nxo, n1, n2);
+  f32x4 in[NT];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < nj) {
+      WPair<NT>& cur = (j & 1) ? alt : pre;
+      WPair<NT>& oth = (j & 1) ? pre : alt;
+      const bool lastj = (j + 1 == nj);
+      if (!lastj) wload<NT>(oth, wp, nto, jot[j + 1 < 3 ? j + 1 : 2], true, jtwo[j + 1 < 3 ? j + 1 : 2], lane);
+      else if (next_wp) wload<NT>(oth, next_wp, next_nto, nxo, n1, n2, lane);
+      if (j == 0 || jrt[j] != jrt[j > 0 ? j - 1 : 0]) {
+        const float* rowp = img + (jrt[j] * 16 + (lane & 15)) * LD + 4 * g;
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) in[kk] = lds_ld4(rowp + 16 * kk);
+      }
+      // per-channel epilogue vectors (folded BatchNorm / bias) are fetched BEFORE the MFMAs so their L2 latency
+      // is hidden behind them instead of sitting between the last MFMA and the barrier
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      const int c0 = 16 * jot[j] + 4 * g;
+      const f32x4 e00 = ev0 ? ld4(ev0 + c0) : z4, e10 = ev1 ? ld4(ev1 + c0) : z4;
+      const f32x4 e01 = (ev0 && jtwo[j]) ? ld4(ev0 + c0 + 16) : z4, e11 = (ev1 && jtwo[j]) ? ld4(ev1 + c0 + 16) : z4;
+      f32x4 a0, a1;
+      mfma_pair<NT>(cur, in, jtwo[j], a0, a1);
+      epi(jrt[j], jot[j], a0, e00, e10);
+      if (jtwo[j]) epi(jrt[j], jot[j] + 1, a1, e01, e11);
+      if (lastj && next_wp && (j & 1) == 0) {   // the prefetched fragments sit in `alt`: hand them over in `pre`
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) { pre.w0[kk] = alt.w0[kk]; pre.w1[kk] = alt.w1[kk]; }
+      }
+    }
   }
+  if (nj == 0 && next_wp) wload<NT>(pre, next_wp, next_nto, nxo, n1, n2, lane);   // idle here: keep the chain going
 }
 
 template <int NT>
@@ -173,6 +203,7 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   int* erow = reinterpret_cast<int*>(lds + 3 * GNN_ROWS * LD);   // [65]  CSR row pointers local to the graph
   int* esrc = erow + GNN_ROWS + 4;                               // [GNN_EMAX] local source row of every in-edge
   int* efeat = esrc + GNN_EMAX;                                  // [GNN_EMAX][edge_nf] feature words (int idx / float)
+  float* EE = reinterpret_cast<float*>(efeat + GNN_EMAX * (P.n_layers > 0 ? P.edge_nf : 0));   // [ee_rows][LD] this layer's edge embeddings
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const int gi = blockIdx.x;
   const int gs = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - gs;
@@ -198,8 +229,53 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   hr.t_lo = wave < NT ? wave : NT;
   hr.t_hi = wave < NT ? wave + 1 : NT;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bool use_ee = P.n_layers > 0 && ne <= S.ee_rows;
+  // embedding of edge k, channels [c, c+4) for layer Lq: DiscreteEncoder sum (elements.py:31-37) or MLP(F_e, d, 1)
+  auto edge_embed = [&](const sn_gnn_layer& Lq, int k, int c) -> f32x4 {
+    const int EF = P.edge_nf;
+    f32x4 ef = zero4;
+    if (P.edge_discrete) {
+      for (int f = 0; f < EF; ++f) {
+        const float* trow = Lq.etab[f] + (int64_t)efeat[k * EF + f] * d;
+        if ((d & 3) == 0) { if (c < d) ef += ld4(trow + c); }
+        else {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) if (c + qq < d) ef[qq] += trow[c + qq];
+        }
+      }
+    } else {
+      f32x4 acc = zero4;
+      for (int f = 0; f < EF; ++f) {
+        const float a = __int_as_float(efeat[k * EF + f]);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) acc[qq] += a * Lq.ew[(c + qq) * EF + f];
+      }
+      ef = relu4(acc * ld4(Lq.e_scale + c) + ld4(Lq.e_shift + c));
+    }
+    return ef;
+  };
+  // one layer's embeddings of all the graph's edges: fetched into registers early, parked in LDS between barriers
+  f32x4 eepf[GNN_EEPF];
+  auto ee_fetch = [&](int l) {
+    if (!use_ee || l >= P.n_layers) return;
+    const sn_gnn_layer& Lq = P.layers[l];
+#pragma unroll
+    for (int i = 0; i < GNN_EEPF; ++i) {
+      const int idx = threadIdx.x + i * GNN_WAVES * 64;
+      eepf[i] = zero4;
+      if (idx < ne * (D / 4)) eepf[i] = edge_embed(Lq, idx / (D / 4), 4 * (idx % (D / 4)));
+    }
+  };
+  auto ee_store = [&]() {
+    if (!use_ee) return;
+#pragma unroll
+    for (int i = 0; i < GNN_EEPF; ++i) {
+      const int idx = threadIdx.x + i * GNN_WAVES * 64;
+      if (idx < ne * (D / 4)) lds_st4(EE + (idx / (D / 4)) * LD + 4 * (idx % (D / 4)), eepf[i]);
+    }
+  };
 
-  WPair<NT> pre;
+  WPair<NT> pre, alt;
   {
     int fot; bool f1, f2;
     tr.first(NT, fot, f1, f2);
@@ -269,29 +345,29 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
     }
   }
   __syncthreads();
+  ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- pos = BN(W_out . slot_sum): X1 -> X2   (sign_net.py:71)
-  coop_gemm<NT>(pre, P.rho_out_w, NT, X1, LD, tr, lane, [&](int rt, int ot, f32x4 acc) {
-    const int c = 16 * ot + 4 * g;
-    lds_st4(X2 + (rt * 16 + li) * LD + c, acc * ld4(P.rho_scale + c) + ld4(P.rho_shift + c));
-  }, P.lin_a, NT, tr);
+  coop_gemm<NT>(pre, alt, P.rho_out_w, NT, X1, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
+    lds_st4(X2 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc * sc + sh);
+  }, P.lin_a, NT, tr, P.rho_scale, P.rho_shift);
   __syncthreads();
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]): X0, X2 -> X1    (model.py:39-40)
-  coop_gemm<NT>(pre, P.lin_a, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc) {
+  coop_gemm<NT>(pre, alt, P.lin_a, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4) {
     lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);      // readers of X1 (slot sum) passed a barrier
   }, P.lin_b, NT, tr);
-  coop_gemm<NT>(pre, P.lin_b, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc) {
-    const int c = 16 * ot + 4 * g;
-    float* o = X1 + (rt * 16 + li) * LD + c;
-    lds_st4(o, (lds_ld4(o) + acc) + ld4(P.lin_bias + c));
-  }, P.n_layers > 0 ? P.layers[0].w1p : P.head_w1, NT, P.n_layers > 0 ? tr : hr);
+  coop_gemm<NT>(pre, alt, P.lin_b, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4) {
+    float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
+    lds_st4(o, (lds_ld4(o) + acc) + bias);
+  }, P.n_layers > 0 ? P.layers[0].w1p : P.head_w1, NT, P.n_layers > 0 ? tr : hr, P.lin_bias);
+  ee_store();
   __syncthreads();
   // ---------------------------------------------------------------- GINE layers: h lives in X1           (model.py:47-55)
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_gnn_layer& Lp = P.layers[l];
     // u = sum_{j->i} relu(h_j + e_ji) + (1+eps) h_i  for my (row tile, channel tile) pairs: X1 -> X2
+    ee_fetch(l + 1);   // next layer's edge embeddings: in flight during this aggregation
     {
       const float sc = 1.f + *Lp.eps;
-      const int EF = P.edge_nf;
 #pragma unroll 1
       for (int k = 0; k < 2; ++k) {
         int rt, o_lo, o_hi;
@@ -307,25 +383,7 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
           for (int o = 0; o < GNN_OTS; ++o) {
             if (o_lo + o < o_hi) {
               const int c = 16 * (o_lo + o) + 4 * g;
-              f32x4 ef = zero4;
-              if (P.edge_discrete) {
-                for (int f = 0; f < EF; ++f) {
-                  const float* trow = Lp.etab[f] + (int64_t)efeat[e * EF + f] * d;
-                  if ((d & 3) == 0) { if (c < d) ef += ld4(trow + c); }
-                  else {
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) if (c + qq < d) ef[qq] += trow[c + qq];
-                  }
-                }
-              } else {
-                f32x4 acc = zero4;
-                for (int f = 0; f < EF; ++f) {
-                  const float a = __int_as_float(efeat[e * EF + f]);
-#pragma unroll
-                  for (int qq = 0; qq < 4; ++qq) acc[qq] += a * Lp.ew[(c + qq) * EF + f];
-                }
-                ef = relu4(acc * ld4(Lp.e_scale + c) + ld4(Lp.e_shift + c));
-              }
+              const f32x4 ef = use_ee ? lds_ld4(EE + e * LD + c) : edge_embed(Lp, e, c);
               u[o] += relu4(lds_ld4(hsrc + 16 * (o_lo + o)) + ef);
             }
           }
@@ -345,19 +403,18 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       }
     }
     __syncthreads();
+    ee_store();        // every wave is done reading this layer's embeddings
     // nn: Linear . BN . ReLU : X2 -> X0
-    coop_gemm<NT>(pre, Lp.w1p, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc) {
-      const int c = 16 * ot + 4 * g;
-      lds_st4(X0 + (rt * 16 + li) * LD + c, relu4(acc * ld4(Lp.bn0_scale + c) + ld4(Lp.bn0_shift + c)));
-    }, Lp.w2p, NT, tr);
+    coop_gemm<NT>(pre, alt, Lp.w1p, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
+      lds_st4(X0 + (rt * 16 + li) * LD + 16 * ot + 4 * g, relu4(acc * sc + sh));
+    }, Lp.w2p, NT, tr, Lp.bn0_scale, Lp.bn0_shift);
     __syncthreads();
     // Linear ; BN . ReLU ; + previous_x : X0 -> X1 (my tiles only: nobody else reads them at this point)
     const bool lastl = l + 1 == P.n_layers;
-    coop_gemm<NT>(pre, Lp.w2p, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc) {
-      const int c = 16 * ot + 4 * g;
-      float* o = X1 + (rt * 16 + li) * LD + c;
-      lds_st4(o, relu4(acc * ld4(Lp.bn_scale + c) + ld4(Lp.bn_shift + c)) + lds_ld4(o));
-    }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1p, NT, lastl ? hr : tr);
+    coop_gemm<NT>(pre, alt, Lp.w2p, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
+      float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
+      lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
+    }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1p, NT, lastl ? hr : tr, Lp.bn_scale, Lp.bn_shift);
     __syncthreads();
   }
   // ---------------------------------------------------------------- add pooling -> row 0 of X2 (rows 1..15 zero)  (model.py:57-61)
@@ -373,12 +430,11 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   TileRange h2;
   h2.t_lo = 0;
   h2.t_hi = wave == 0 ? 1 : 0;
-  coop_gemm<NT>(pre, P.head_w1, NT, X2, LD, hr, lane, [&](int rt, int ot, f32x4 acc) {
-    const int c = 16 * ot + 4 * g;
-    lds_st4(X0 + li * LD + c, relu4(acc * ld4(P.head_scale + c) + ld4(P.head_shift + c)));
-  }, wave == 0 ? P.head_w2 : nullptr, 1, h2);
+  coop_gemm<NT>(pre, alt, P.head_w1, NT, X2, LD, hr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
+    lds_st4(X0 + li * LD + 16 * ot + 4 * g, relu4(acc * sc + sh));
+  }, wave == 0 ? P.head_w2 : nullptr, 1, h2, P.head_scale, P.head_shift);
   __syncthreads();
-  coop_gemm<NT>(pre, P.head_w2, 1, X0, LD, h2, lane, [&](int rt, int ot, f32x4 acc) {
+  coop_gemm<NT>(pre, alt, P.head_w2, 1, X0, LD, h2, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4) {
     if (li == 0) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
@@ -392,17 +448,23 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
 template <int NT>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)(3 * GNN_ROWS * LD) * sizeof(float) + (size_t)(GNN_ROWS + 4 + GNN_EMAX * (1 + (P.n_layers > 0 ? P.edge_nf : 0))) * sizeof(int);
+  const size_t base = (size_t)(3 * GNN_ROWS * LD) * sizeof(float) + (size_t)(GNN_ROWS + 4 + GNN_EMAX * (1 + (P.n_layers > 0 ? P.edge_nf : 0))) * sizeof(int);
+  const size_t room = base < 160 * 1024 ? 160 * 1024 - base : 0;
+  int ee_rows = (int)(room / ((size_t)LD * sizeof(float)));
+  if (ee_rows > GNN_EEMAX) ee_rows = GNN_EEMAX;
+  GnnStruct S2 = S;
+  S2.ee_rows = P.n_layers > 0 ? ee_rows : 0;
+  const size_t lds = base + (size_t)S2.ee_rows * LD * sizeof(float);
   static bool init = false;
   if (!init) {
-    const size_t lds_max = (size_t)(3 * GNN_ROWS * LD) * sizeof(float) + (size_t)(GNN_ROWS + 4 + GNN_EMAX * 17) * sizeof(int);
+    const size_t lds_max = 160 * 1024;
     if (lds_max > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_gnn_coop<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_max) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_gnn_fused_f32: cannot raise the dynamic LDS limit to %zu", lds_max);
     init = true;
   }
-  hipLaunchKernelGGL((k_gnn_coop<NT>), dim3((unsigned)B), dim3(GNN_WAVES * 64), lds, st, S, P);
+  hipLaunchKernelGGL((k_gnn_coop<NT>), dim3((unsigned)B), dim3(GNN_WAVES * 64), lds, st, S2, P);
   return SN_OK;
 }
 
@@ -435,7 +497,7 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
     else SN_REQUIRE(L.ew && L.e_scale && L.e_shift, "sn_gnn_fused_f32: layer %d edge MLP parameters missing", l);
   }
   if (B == 0) return SN_OK;
-  GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y};
+  GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   switch ((P.d + 15) / 16) {

@@ -12,7 +12,7 @@ enum { ST_ERR = 0, ST_NMAX = 1, ST_DEGMAX = 2 };
 enum { ERR_UNSORTED = 1, ERR_GRAPH_ID = 2, ERR_EDGE_RANGE = 4, ERR_EDGE_CROSS = 8 };
 
 constexpr int PLAN_T = 1024;          // threads of the single-workgroup stages
-constexpr int BINS_BMAX = 8192;       // graphs the bin planner handles (LDS-resident working set)
+constexpr int BINS_BMAX = 6144;       // graphs the bin planner handles (LDS-resident working set)
 
 struct BinsDev {  // device view of sn_plan_bins
   int32_t* phi_bin_col;
@@ -62,7 +62,7 @@ __device__ __forceinline__ int slots_of(int n, int kmax) { return (kmax > 0 && n
 //      of height max_g K_g covers all slabs of its graphs and every bin is (nearly) full.
 // rho: a unit is one node's K_g slot rows, padded to p = 16*ceil(K_g/16) so that a unit never straddles a 16-row
 //      tile; 64/p units per bin, bins never mix graphs -> closed form, no sequential pass.
-// gp: graph_ptr in LDS ([B+1]); lds: int scratch [2*B + 3*66 + 32].
+// gp: graph_ptr in LDS ([B+1]); lds: int scratch [5*B + 3*66 + 32].
 __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
   const int t = threadIdx.x;
   int* bucket = lds;            // [B]   graph ids grouped by size, ascending id inside a group
@@ -71,9 +71,9 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* bstart = hist + 66;      // [66]
   int* bcur = bstart + 66;      // [66]
   int* wsum = bcur + 66;        // [32]
-  __shared__ int s_err, s_ncol, s_nbins;
+  __shared__ int s_err, s_ncol, s_nbins, s_nrec;
   if (t < 66) { hist[t] = 0; bcur[t] = 0; }
-  if (t == 0) { s_err = 0; s_ncol = 0; s_nbins = 0; }
+  if (t == 0) { s_err = 0; s_ncol = 0; s_nbins = 0; s_nrec = 0; }
   __syncthreads();
   // ---- rho: bins per graph, prefix
   {
@@ -116,10 +116,10 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     else if (n > 0) atomicAdd(&hist[n], 1);
   }
   __syncthreads();
-  if (t == 0) {
+  if (t <= 65) {   // bstart = exclusive prefix of hist (66 short independent loops)
     int run = 0;
-    for (int s = 0; s <= 64; ++s) { bstart[s] = run; run += hist[s]; }
-    bstart[65] = run;
+    for (int s2 = 0; s2 < t && s2 <= 64; ++s2) run += hist[s2];
+    bstart[t] = run;
   }
   __syncthreads();
   for (int g = t; g < B; g += PLAN_T) {
@@ -136,46 +136,72 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       bucket[b + 1] = k;
     }
   }
+  // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers:
+  //      lane s-1 owns size class s (remaining count, items taken); the loop-carried chain is scalar/readlane
+  //      arithmetic only.  It emits (class, rank) records; the graph ids are resolved in parallel afterwards.
+  int* rec_cls = nbv;            // [B] reuse (rho is done with nbv): size class of the r-th placed graph
+  int* rec_rank = lds + 2 * B + 3 * 66 + 32;   // [B] rank inside its class          (extra [3*B] ints of scratch)
+  int* rec_col = rec_rank + B;   // [B] column
+  int* rec_off = rec_col + B;    // [B] (member index << 8) | row offset
   __syncthreads();
-  // ---- phi: best-fit-decreasing over the size classes (one lane; ~#graphs cheap steps)
-  if (t == 0) {
-    unsigned long long avail = 0ull;
-    for (int s = 1; s <= 64; ++s)
-      if (hist[s] > 0) avail |= 1ull << (s - 1);
-    for (int s = 0; s <= 64; ++s) bcur[s] = bstart[s];   // next unused item of each class
-    int ncol = 0, bin = 0, rows = 0;
+  if (t < 64) {
+    const int lane = t;
+    int cnt = hist[lane + 1];                       // class s = lane + 1
+    int used = 0;
+    unsigned long long avail = __ballot(cnt > 0);
+    int ncol = 0, bin = 0, rows = 0, nrec = 0;
     while (avail) {
       const int s = 64 - __clzll(avail);
-      int g = bucket[bcur[s]++];
-      if (bcur[s] == bstart[s + 1]) avail &= ~(1ull << (s - 1));
-      int cap = 64 - s, members = 1;
+      int cap = 64 - s, members = 0, off = 0;
       const int H = slots_of(s, kmax);
-      rows += s * H;
-      bd.phi_col_mem[ncol * 8] = g;
-      bd.phi_col_off[ncol * 8] = 0;
-      while (members < 8 && cap > 0) {
+      int cls = s;
+      while (true) {
+        const int rank = __builtin_amdgcn_readlane(used, cls - 1);
+        const int left = __builtin_amdgcn_readlane(cnt, cls - 1) - 1;
+        if (lane == cls - 1) { ++used; --cnt; }
+        if (left == 0) avail &= ~(1ull << (cls - 1));
+        if (lane == 0) {
+          rec_cls[nrec] = cls;
+          rec_rank[nrec] = rank;
+          rec_col[nrec] = ncol;
+          rec_off[nrec] = (members << 8) | off;
+        }
+        ++nrec;
+        rows += cls * slots_of(cls, kmax);
+        off += cls;
+        ++members;
+        if (members == 1) cap = 64 - s; else cap -= cls;
+        if (members >= 8 || cap <= 0) break;
         const unsigned long long m = (cap >= 64) ? avail : (avail & ((1ull << cap) - 1ull));
         if (!m) break;
-        const int u = 64 - __clzll(m);
-        g = bucket[bcur[u]++];
-        if (bcur[u] == bstart[u + 1]) avail &= ~(1ull << (u - 1));
-        bd.phi_col_mem[ncol * 8 + members] = g;
-        bd.phi_col_off[ncol * 8 + members] = 64 - cap;
-        cap -= u;
-        rows += u * slots_of(u, kmax);
-        ++members;
+        cls = 64 - __clzll(m);
       }
-      for (int k = members; k < 8; ++k) { bd.phi_col_mem[ncol * 8 + k] = -1; bd.phi_col_off[ncol * 8 + k] = 0; }
-      bd.phi_col_bin0[ncol] = bin;
+      if (lane == 0) bd.phi_col_bin0[ncol] = bin;
       bin += H;
       ++ncol;
     }
-    bd.phi_col_bin0[ncol] = bin;
-    s_ncol = ncol;
-    s_nbins = bin;
-    bd.meta[0] = bin;
-    bd.meta[2] = rows;
-    bd.meta[3] = ncol;
+    if (lane == 0) {
+      bd.phi_col_bin0[ncol] = bin;
+      s_ncol = ncol;
+      s_nbins = bin;
+      s_nrec = nrec;
+      bd.meta[0] = bin;
+      bd.meta[2] = rows;
+      bd.meta[3] = ncol;
+    }
+  }
+  __syncthreads();
+  {
+    const int ncol_ = s_ncol, nrec = s_nrec;
+    for (int i = t; i < ncol_ * 8; i += PLAN_T) { bd.phi_col_mem[i] = -1; bd.phi_col_off[i] = 0; }
+    __syncthreads();
+    for (int r = t; r < nrec; r += PLAN_T) {
+      const int cls = rec_cls[r];
+      const int g = bucket[bstart[cls] + rec_rank[r]];
+      const int slot = rec_col[r] * 8 + (rec_off[r] >> 8);
+      bd.phi_col_mem[slot] = g;
+      bd.phi_col_off[slot] = rec_off[r] & 255;
+    }
   }
   __syncthreads();
   const int ncol = s_ncol, nbins = s_nbins;
@@ -256,7 +282,8 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     const int lo = t * per, hi = (lo + per < N) ? lo + per : N;
     int s = 0, dmax = 0;
     for (int i = lo; i < hi; ++i) { s += deg[i]; dmax = dmax > deg[i] ? dmax : deg[i]; }
-    atomicMax(&s_dmax, dmax);
+    for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
+    if ((t & 63) == 0) atomicMax(&s_dmax, dmax);
     int total;
     int run = block_exscan(s, wsum, t, &total);
     for (int i = lo; i < hi; ++i) { const int dg = deg[i]; rp[i] = run; deg[i] = run; run += dg; }
@@ -265,7 +292,8 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     const int blo = t * perb, bhi = (blo + perb < B) ? blo + perb : B;
     int q = 0, nmax = 0;
     for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; q += n * n; nmax = nmax > n ? nmax : n; }
-    atomicMax(&s_nmax, nmax);
+    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    if ((t & 63) == 0) atomicMax(&s_nmax, nmax);
     int qtot;
     int qrun = block_exscan(q, wsum, t, &qtot);
     for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; evoff[g] = qrun; qrun += n * n; }
@@ -510,7 +538,7 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   hipStream_t st = (hipStream_t)stream;
   if (N > 0 && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX) {
     const size_t lds0 = (size_t)((PS_BMAX + 4) + PS_NMAX + (PS_NMAX + 4) + 2 * PS_EMAX + 32) * sizeof(int);
-    const size_t lds1 = (size_t)((PS_BMAX + 4) + 2 * PS_BMAX + 3 * 66 + 32) * sizeof(int);
+    const size_t lds1 = (size_t)((PS_BMAX + 4) + 5 * PS_BMAX + 3 * 66 + 32) * sizeof(int);
     const size_t lds = lds0 > lds1 ? lds0 : lds1;
     static bool init = false;
     if (!init) {
@@ -531,12 +559,12 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   const int64_t ne = N > E ? N : E;
   hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(ne > 0 ? ne : 1, T)), dim3(T), 0, st, batch, edge_index, E, N, B, deg,
                      status);
-  const size_t lds3 = do_bins ? (size_t)((B + 4) + 2 * B + 3 * 66 + 32) * sizeof(int) : 0;
+  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32) * sizeof(int) : 0;
   if (lds3 > 48 * 1024) {
     static bool init3 = false;
     if (!init3) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)(3 * BINS_BMAX + 4 + 3 * 66 + 32) * sizeof(int))) != hipSuccess)
+                              (int)((size_t)(6 * BINS_BMAX + 4 + 3 * 66 + 32) * sizeof(int))) != hipSuccess)
         return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit");
       init3 = true;
     }

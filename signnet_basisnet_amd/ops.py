@@ -120,6 +120,7 @@ class GraphPlan:
     eperm: torch.Tensor       # int32 [E]   original edge id of each CSR slot
     status: torch.Tensor      # int32 [4]   [err bits, max nodes/graph, max in-degree, fused-stage flags]
     bins: PlanBins | None
+    flags: torch.Tensor = None   # status (+ bins meta) as one contiguous block
 
     def check(self):
         """Synchronising validity check (raises on malformed batches)."""
@@ -146,28 +147,30 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     N, E, B = batch.numel(), edge_index.shape[1] if edge_index.numel() else 0, int(num_graphs)
     dev = batch.device
     # one int32 arena, carved into the plan arrays (single allocation per batch)
-    sizes = [B + 1, N, N, N + 1, E, E, 4, N + 8]
+    sizes = [B + 1, N, N, N + 1, E, E, N + 8, 4]          # status last: [status | bins meta] is one 12-int block
     mb = 0
     if bins:
         mb = int(lib().sn_phi_bins_bound(B, int(kmax)))
-        sizes += [mb, B + 1, 8 * B, 8 * B, B + 1, 8]
+        sizes += [8, mb, B + 1, 8 * B, 8 * B, B + 1]
     offs = [0]
     for s in sizes:
         offs.append(offs[-1] + ((s + 3) // 4) * 4)
     arena = torch.empty(offs[-1], dtype=torch.int32, device=dev)
     parts = [arena[offs[i]:offs[i] + sizes[i]] for i in range(len(sizes))]
-    graph_ptr, node_graph, nvalid, rowptr, col, eperm, status, scratch = parts[:8]
+    graph_ptr, node_graph, nvalid, rowptr, col, eperm, scratch, status = parts[:8]
     evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
     pb = None
     if bins:
-        bc, cb0, mem, off, rb0, meta = parts[8:14]
+        meta, bc, cb0, mem, off, rb0 = parts[8:14]
         cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr())
         pb = PlanBins(bc, mb, cb0, mem, off, rb0, meta, cs)
     with _span("sn_batch_plan"):
         check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
                                   ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
                                   C.byref(pb.cstruct) if pb is not None else None, ptr(scratch), stream()), "sn_batch_plan")
-    return GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, pb)
+    plan = GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, pb)
+    plan.flags = arena[offs[7]:offs[7] + 12] if bins else status      # [status(4) | meta(8)] contiguous
+    return plan
 
 
 def pack_eig(plan: GraphPlan, eigen_vectors, eigen_values, K: int, want_values: bool):

@@ -266,6 +266,12 @@ class SignNetGNN(nn.Module):
         # nl_rho is fixed by the reference constructors (sign_net.py:123 ignores the argument)
         self.nl_rho = 4 if variant == "alchemy" else 1
         self.use_fused = True       # whole-stage kernels (eval mode); False = layer-at-a-time kernels only
+        # Fused stages require graphs of <= 64 nodes (and <= 192 edges for the GINE stage); a batch that violates
+        # this raises the device-side flags of the plan.  strict=True reads them after every forward (one host
+        # sync) and re-runs such a batch on the layer path; strict=False (default) copies them asynchronously
+        # and raises at the NEXT forward (or at .check_last()) — outputs of the offending batch are invalid.
+        self.strict = False
+        self._pending, self._free_hosts = [], []
         self.sign_net = SignNet(n_hid, nl_signnet, self.nl_rho, variant, ignore_eigval)
         self.gnn = GNN(node_feat, edge_feat, n_hid, n_out, nl_gnn, variant)
         self._prep = None
@@ -339,10 +345,62 @@ class SignNetGNN(nn.Module):
         P["head"] = dict(l0=_pack(oe.layers[0]), bn0=_bn_affine(oe.norms[0]), l1=_pack(oe.layers[1]))
         return P
 
-    # ------------------------------------------------------------------ forward (layer-at-a-time HIP path)
+    # ------------------------------------------------------------------ device-side status of the fused stages
+    @staticmethod
+    def _flags_bad(host):
+        return bool(host[0] or host[3] or host[5] or host[9])       # plan errors, gnn flags, phi / rho bin errors
+        # layout: [status(4) | meta(8)]: status[0] plan errors, status[3] gnn flags, meta[1] phi, meta[5] rho
+
+    def check_last(self, wait=True):
+        """Raise if an earlier forward's batch could not be served by the fused kernels (wait=False: only look at
+        status copies that have already arrived)."""
+        while self._pending:
+            ev, host = self._pending[0]
+            if not wait and len(self._pending) <= 4 and not ev.query():
+                break
+            ev.synchronize()
+            self._pending.pop(0)
+            self._free_hosts.append(host)
+            if self._flags_bad(host.tolist()):
+                self._pending.clear()
+                raise RuntimeError("an earlier batch was malformed or had a graph too large for the fused SignNet kernels "
+                                   "(> 64 nodes or > 192 edges): its outputs are invalid; set model.strict = True "
+                                   "(re-runs such batches layer by layer) or model.use_fused = False")
+
+    def _post_status(self, plan):
+        host = self._free_hosts.pop() if self._free_hosts else torch.zeros(12, dtype=torch.int32, pin_memory=True)
+        n = plan.flags.numel()
+        host[:n].copy_(plan.flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev, host
+
     def forward(self, data, return_stages=False):
         if self.training:
             raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+        self.check_last(wait=False)
+        y = self._forward(data, return_stages)
+        if self.use_fused and not return_stages and self._used_fused:
+            ev, host = self._post_status(self._last_plan)
+            if self.strict:
+                ev.synchronize()
+                flags = host.tolist()
+                self._free_hosts.append(host)
+                if self._flags_bad(flags):
+                    if flags[0]:
+                        self._last_plan.check()
+                    saved, self.use_fused, self._prep = self.use_fused, False, None
+                    try:
+                        y = self._forward(data, False)
+                    finally:
+                        self.use_fused, self._prep = saved, None
+            else:
+                self._pending.append((ev, host))
+        self._last_plan = None
+        return y
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, data, return_stages=False):
         ops.require_cuda(data.edge_index, data.batch, data.eigen_vectors)
         if self._prep is None:
             self._prep = self._prepare()
@@ -352,6 +410,7 @@ class SignNetGNN(nn.Module):
         use_rho_fused = P["rho_fused"] is not None
         use_gnn_fused = P["gnn_fused"] is not None
         plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=use_phi_fused or use_rho_fused)
+        self._last_plan, self._used_fused = plan, (use_phi_fused or use_rho_fused or use_gnn_fused)
         if self.max_k:
             K = int(self.max_k)
             plan.check() if return_stages else None

@@ -137,3 +137,28 @@ def test_vs_oracle_real_widths(variant, ctor, feat, max_k):
     close(st["rho_sum_fused"], out["rho_sum"], "fused rho slot-sum")
     close(st["y_gnn_fused"], yref, "fused gnn output")
     close(model(dd), yref, "model output (fused path)")
+
+
+def test_oversize_graph_is_flagged_and_served_by_the_layer_path():
+    """A graph with more than 64 nodes cannot run in the fused kernels: strict mode re-runs it layer by layer,
+    the default mode raises at the next call."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(2)
+    ctor = (None, None, 32, 1, 2, 2)
+    model = SignNetGNN(*ctor, variant="gine", max_k=8)
+    data = synth.make_batch(3, seed=4, sizes=[10, 70, 12])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    yref = O.signnet_gnn(sd, O.make_cfg("gine", *ctor), data, training=False, max_k=8)
+    model = model.cuda().eval()
+    dd = synth.batch_to(data, "cuda:0")
+    model.strict = True
+    close(model(dd), yref, "strict mode (layer-path fallback)")
+    model.strict = False
+    model(dd)                                   # flags raised on the device, reported late
+    with pytest.raises(RuntimeError, match="too large for the fused"):
+        model.check_last()
+    ok = synth.batch_to(synth.make_batch(3, seed=4, sizes=[10, 20, 12]), "cuda:0")
+    model(ok)
+    model.check_last()                          # a well-formed batch leaves nothing pending
