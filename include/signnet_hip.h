@@ -90,6 +90,18 @@ int sn_pack_eig_f32(const float* eigen_vectors, const float* eigen_values, const
 int64_t sn_packed_weight_floats(int d_out, int d_in);
 int sn_pack_weight_f32(const float* W, int d_out, int d_in, int ldw, float* Wp, void* stream);
 
+/* Split-packed linear for the fused phi / rho stages, which evaluate their fp32 GEMMs on the bf16 matrix pipe:
+ * every fp32 weight is split EXACTLY into three bf16 pieces (8 significand bits each) and every product x*w is
+ * summed from its six partial products of weight >= 2^-16 (fp32 accumulate); the dropped remainder is <= 2^-23
+ * |x||w|, the size of one fp32 rounding (same accuracy class as nn.Linear in fp32, 2.5x the fp32 matrix rate).
+ * Layout: per 16-output tile one chunk of 3*ceil(d_in/32) weight fragments [k block][piece][64 lanes][8 bf16]
+ * followed by SN_SPLIT_EPI per-channel fp32 vectors e0,e1,e2 (bias / folded BatchNorm of the Linear's epilogue,
+ * length d_out, NULL = zeros) in the accumulator layout — the whole Linear streams through LDS as one buffer. */
+#define SN_SPLIT_EPI 3
+int64_t sn_split_packed_bytes(int d_out, int d_in);
+int sn_pack_split_f32(const float* W, int d_out, int d_in, int ldw, const float* e0, const float* e1,
+                      const float* e2, void* Wsp /* 16-byte aligned */, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GIN aggregation.  Replaces PyG GINConv(Identity()).propagate + (1+eps)x
  * (masked_layers.py:70,75; pyg_gnn_wrapper.py:11,16) and dgl.nn.pytorch.GINConv's copy_u/sum
@@ -209,19 +221,14 @@ int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, f
  * (:54-64) -> mask -> MaskedBN -> ReLU -> +previous.  Activations never leave the CU between
  * layers: the slab rows live in registers (MFMA operand layout) and are exchanged through LDS for
  * the neighbour sums.  All per-channel vectors are zero-padded to d_pad = 16*ceil(d/16) floats;
- * weight matrices are in sn_pack_weight_f32 order.
+ * the [d, d] Linears are split-packed (sn_pack_split_f32) with their epilogue vectors.
  *   layer 0 takes the scalar eigenvector entry: Linear(1 -> hid0) [BN, ReLU] Linear(hid0 -> d)
  *   with hid0 == 1 (GINESignNetPyG, core/sign_net.py:20) or hid0 == d (Alchemy, sign_net.py:20).
  * out: [N*K, d] rows (row = node*K + slot); only valid rows are written. */
 typedef struct {
-  const float* w1p;        /* packed [d, d] */
-  const float* bn0_scale;  /* MaskedMLP.norms[0] folded */
-  const float* bn0_shift;
-  const float* w2p;        /* packed [d, d] */
-  const float* bias2;      /* may be NULL */
-  const float* bn_scale;   /* GNN3d.norms[l] folded */
-  const float* bn_shift;
-  const float* eps;        /* device scalar */
+  const void* w1s;   /* MaskedMLP.layers[0], split-packed [d, d] with (e0, e1) = MaskedMLP.norms[0] folded (scale, shift) */
+  const void* w2s;   /* MaskedMLP.layers[1], split-packed [d, d] with (e0, e1, e2) = (bias or 0, GNN3d.norms[l] scale, shift) */
+  const float* eps;  /* device scalar */
 } sn_phi_layer;
 
 #define SN_PHI_MAX_LAYERS 16
@@ -230,10 +237,11 @@ typedef struct {
   const float* l0_w1;        /* [hid0_pad] : Linear(1 -> hid0).weight[:, 0] */
   const float* l0_bn0_scale; /* [hid0_pad] */
   const float* l0_bn0_shift;
-  const float* l0_w2;        /* hid0 == 1: [d_pad] = Linear(1 -> d).weight[:, 0]; else packed [d, d] */
-  const float* l0_bias2;     /* may be NULL */
-  const float* l0_bn_scale;
-  const float* l0_bn_shift;
+  const void* l0_w2;         /* hid0 == 1: float [d_pad] = Linear(1 -> d).weight[:, 0];
+                                else split-packed [d, d] with (e0, e1, e2) = (bias or 0, bn scale, bn shift) */
+  const float* l0_bias2;     /* hid0 == 1 only; may be NULL */
+  const float* l0_bn_scale;  /* hid0 == 1 only */
+  const float* l0_bn_shift;  /* hid0 == 1 only */
   const float* l0_eps;
   sn_phi_layer layers[SN_PHI_MAX_LAYERS - 1]; /* layers 1 .. n_layers-1 */
 } sn_phi_params;
@@ -249,13 +257,13 @@ int sn_phi_fused_f32(const sn_phi_params* params /* host struct of device pointe
  * Replaces SetTransformer.forward up to torch.sum(x, dim=1) (sign_net.py:60-70 / core/sign_net.py:64-75)
  * with its TransformerEncoderLayer stack (transformer_module.py:27-127, 4 heads, post-LN, eps 1e-6) and,
  * when has_pos, the eigenvalue encoder MaskedMLP(1->1->d) added to x (Alchemy sign_net.py:86,108,62).
- * Weight matrices packed (sn_pack_weight_f32), vectors zero-padded to d_pad.  Bins: sn_plan_bins.rho_bin0.
+ * Weight matrices split-packed (sn_pack_split_f32), vectors zero-padded to d_pad.  Bins: sn_plan_bins.rho_bin0.
  *   x:       [N*K, d] = phi(x)+phi(-x) (row = node*K + slot; only valid rows are read)
  *   out_sum: [N, d]   sum over the node's valid slots of the last encoder layer's output            */
 typedef struct {
-  const float *wq, *wk, *wv, *wfc; /* packed [d,d], no bias (transformer_module.py:67-70) */
+  const void *wq, *wk, *wv, *wfc;  /* split-packed [d,d], no bias (transformer_module.py:67-70) */
   const float *ln1_g, *ln1_b;      /* slf_attn.norm.ln */
-  const float *w1, *b1, *w2, *b2;  /* pos_ffn.w_1 / w_2 */
+  const void *w1, *w2;             /* pos_ffn.w_1 / w_2, split-packed with e0 = their bias */
   const float *ln2_g, *ln2_b;      /* pos_ffn.norm.ln */
 } sn_rho_layer;
 

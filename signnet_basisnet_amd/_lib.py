@@ -25,6 +25,7 @@ SIGNATURES = {
     "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_pack_eig_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
     "sn_pack_weight_f32": [_p, _i, _i, _i, _p, _p],
+    "sn_pack_split_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p],
     "sn_gin_aggregate_f32": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
     "sn_gin_aggregate_slab_f32": [_p, _p, _l, _i, _l, _p, _p, _p, _p, _i, _p],
     "sn_gine_aggregate_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p],
@@ -65,6 +66,8 @@ def lib():
         L.sn_last_error.restype = C.c_char_p
         L.sn_packed_weight_floats.argtypes = [_i, _i]
         L.sn_packed_weight_floats.restype = C.c_int64
+        L.sn_split_packed_bytes.argtypes = [_i, _i]
+        L.sn_split_packed_bytes.restype = C.c_int64
         L.sn_phi_bins_bound.argtypes = [_l, _i]
         L.sn_phi_bins_bound.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]

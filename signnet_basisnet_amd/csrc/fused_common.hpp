@@ -89,6 +89,217 @@ __device__ __forceinline__ void gemm_rows(const float* __restrict__ wp, const f3
   gemm_rows2<NT, NT>(wp, in, lane, epi);
 }
 
+
+// =====================================================================================================
+// fp32 GEMMs on the bf16 matrix pipe: three-way significand split (six partial products).
+//
+// An fp32 value is split EXACTLY into three bf16 pieces h + m + l (8 significand bits each, truncation); of the
+// nine partial products of x*w the six with weight >= 2^-16 (hh, hm, mh, hl, lh, mm) are evaluated as
+// v_mfma_f32_16x16x32_bf16 (exact products, fp32 accumulate); the three dropped ones are <= 2^-23 |x||w| — the
+// size of one fp32 rounding.  16x16x32 bf16 issues in ~17 cycles/SIMD for 8192 MACs against 8 x 32 cycles for
+// the same MACs on v_mfma_f32_16x16x4_f32: 2.5x the fp32 matrix peak at fp32 accuracy.
+//
+// Layouts (transposed product as in common.hpp; a K block is 32 channels = two 16-channel operand chunks):
+//   activation operand of K block kb: lane (row = l&15, g = l>>4) holds 8 bf16 k-slots s = 0..7 = channels
+//     32*kb + 16*(s>>2) + 4*g + (s&3)  — exactly in[2kb][0..3], in[2kb+1][0..3] of the fp32 operand layout, so the
+//     accumulators of one GEMM split in place into the operand of the next;
+//   packed weights ("split-packed linear", sn_pack_split_f32): per 16-output tile ot one CHUNK of
+//     NF = 3*NKB weight fragments [kb][plane h,m,l][lane][8 bf16] (1 KiB each) followed by SN_SPLIT_EPI = 3
+//     epilogue fragments [e][lane][4 f32] = vec_e[16*ot + 4*(lane>>4) + t] (bias / folded-BatchNorm vectors).
+//
+// Weight stream: all 4 waves of a workgroup consume the same fragments, so the chunks are staged ONCE per
+// workgroup in an LDS ring (SPLIT_RING chunks) by LDS-DMA (global_load_lds_dwordx4: no staging VGPRs), chunk
+// c+RING issued as soon as every wave has read chunk c; fragments go LDS -> VGPR one K block ahead of their MFMAs.
+// Sync (MI355X guide, "Read a staged buffer one phase AFTER the wait that retires it"): each wave waits its own
+// DMA of chunk c+1 with a counted vmcnt, then the workgroup barrier publishes it; ds_reads of chunk c+1 are issued
+// only after that barrier.  The stream continues across consecutive GEMMs (`wnext`).
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) char lds_char_t;
+
+constexpr int SPLIT_RING = 3;
+static_assert(SPLIT_RING == 3, "slot_of() is x mod 3");
+constexpr int SPLIT_EPI = SN_SPLIT_EPI;
+
+struct Split8 { u32x4 h, m, l; };
+
+__device__ __forceinline__ unsigned pack_hi16(float a, float b) {   // bf16 bits of a | bf16 bits of b << 16
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ Split8 split8(f32x4 a, f32x4 b) {
+  const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  float h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = __uint_as_float(__float_as_uint(x[i]) & 0xffff0000u);
+    const float r = x[i] - h[i];                       // exact
+    m[i] = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    l[i] = r - m[i];                                   // exact, <= 8 significant bits
+  }
+  Split8 s;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s.h[i] = pack_hi16(h[2 * i], h[2 * i + 1]);
+    s.m[i] = pack_hi16(m[2 * i], m[2 * i + 1]);
+    s.l[i] = pack_hi16(l[2 * i], l[2 * i + 1]);
+  }
+  return s;
+}
+template <int NT>
+__device__ __forceinline__ void split_rows(const f32x4 (&in)[NT], Split8 (&xs)[(NT + 1) / 2]) {
+#pragma unroll
+  for (int kb = 0; kb < (NT + 1) / 2; ++kb)
+    xs[kb] = split8(in[2 * kb], (2 * kb + 1 < NT) ? in[2 * kb + 1] : f32x4{0.f, 0.f, 0.f, 0.f});
+}
+__device__ __forceinline__ f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier for LDS traffic only: does not drain in-flight LDS-DMA (a __syncthreads() would)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int NT>
+struct WRing {
+  static constexpr int NKB = (NT + 1) / 2;
+  static constexpr int NF = 3 * NKB;                 // weight fragments per chunk
+  static constexpr int NFE = NF + SPLIT_EPI;         // + epilogue fragments
+  static constexpr int CHUNK = NFE * 1024;           // bytes
+  static constexpr int BYTES = SPLIT_RING * CHUNK;
+  static constexpr int LPC = (NFE + 3) / 4;          // DMA instructions every wave issues per chunk
+  lds_char_t* base;   // LDS
+  int pos;            // ring slot of chunk 0 of the current GEMM (wave-uniform)
+  int wave, lane;
+
+  __device__ __forceinline__ void init(void* lds_base, int wave_, int lane_) {
+    base = (lds_char_t*)lds_base; pos = 0; wave = wave_; lane = lane_;
+  }
+  __device__ __forceinline__ int slot_of(int c) const { const int x = pos + c; return x - SPLIT_RING * ((x * 43) >> 7); }   // x mod 3, x < 128
+  // this wave's share of the DMA of chunk `c` of packed matrix `w` into ring slot `slot`.  Buffer form: the matrix
+  // base lives in an SGPR descriptor, the chunk / fragment offset in an SGPR, lane*16 in one VGPR — no 64-bit
+  // per-lane address per DMA (which the compiler would precompute for every chunk of every matrix and spill).
+  __device__ __forceinline__ void issue(const void* w, int c, int slot) const {
+    const __amdgpu_buffer_rsrc_t rs = weight_rsrc(reinterpret_cast<const float*>(w), 0x7fffffff);
+    lds_char_t* dst = base + slot * CHUNK;
+#pragma unroll
+    for (int f = 0; f < LPC; ++f) {
+      int fr = wave + 4 * f;
+      if (4 * f + 3 >= NFE) fr = fr < NFE - 1 ? fr : NFE - 1;   // branch-free tail: the surplus waves re-stage the last fragment
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + fr * 1024), 16, lane * 16, c * CHUNK + fr * 1024, 0, 0);
+    }
+  }
+  // start of the weight stream (once per kernel when the GEMMs chain, else once per GEMM): chunks 0..RING-1 of `w`
+  // issued, chunk 0 visible to every wave.  All waves call it.
+  __device__ __forceinline__ void prologue(const void* w, int nchunks) {
+    lds_barrier();   // nobody still reads the ring
+    pos = 0;
+#pragma unroll
+    for (int c = 0; c < SPLIT_RING; ++c)
+      if (c < nchunks) issue(w, c, c);
+    if (nchunks >= SPLIT_RING) wait_vmcnt<(SPLIT_RING - 1) * LPC>(); else wait_vmcnt<0>();
+    lds_barrier();
+  }
+  // before the kernel exits: no LDS-DMA of this wave may still be in flight (the LDS would be handed to another workgroup)
+  __device__ __forceinline__ void drain() const { wait_vmcnt<0>(); }
+};
+
+struct WFrag { u32x4 h, m, l; };
+
+// acc(ot) = W[16 outputs of tile ot] . x  for ot < NTO, consumed by epi(ot, acc, e0, e1, e2) (e*: the chunk's
+// epilogue vectors in the accumulator layout).  EVERY wave of the workgroup must call it (barriers, DMA shares);
+// `live` = this wave has rows (a dead wave only keeps the stream going).  `wnext` (never null): the matrix whose
+// first chunks are staged behind this one's — the next wg_gemm_split() of the workgroup must be on `wnext`; the
+// kernel starts the stream with WRing::prologue(first matrix) and ends with WRing::drain().  SWAP: operands exchanged -> acc[r] = Y[row = 4g + r][out = 16*ot + (l&15)].
+template <int NT, int NTO, bool SWAP, typename Epi>
+__device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, const void* wnext, bool live,
+                                              const Split8 (&xs)[(NT + 1) / 2], Epi epi) {
+  using R = WRing<NT>;
+  constexpr int NKB = R::NKB;
+  constexpr bool CHAIN = NTO >= SPLIT_RING;     // the stream runs on into the next matrix; else: one prologue per GEMM
+  if (!CHAIN) ring.prologue(w, NTO);
+  typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+  typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+  const int s0 = ring.slot_of(0), s1 = ring.slot_of(1), s2 = ring.slot_of(2);
+  auto slot = [&](int c) { return (c % 3 == 0) ? s0 : ((c % 3 == 1) ? s1 : s2); };   // c is a compile-time constant
+  auto stage = [&](int ot) {   // after the barrier of step ot: refill the slot of chunk ot with chunk ot + RING
+    if (CHAIN) {
+      const int pc = ot + SPLIT_RING;
+      if (pc < NTO) ring.issue(w, pc, slot(ot)); else ring.issue(wnext, pc - NTO, slot(ot));
+    }
+  };
+  if (live) {
+    const lds_char_t* lbase = ring.base + ring.lane * 16;
+    auto rd = [&](int c, int kb) {
+      const lds_char_t* p = lbase + slot(c) * R::CHUNK + kb * 3072;
+      WFrag f;
+      f.h = *(lds_u32x4*)(p);
+      f.m = *(lds_u32x4*)(p + 1024);
+      f.l = *(lds_u32x4*)(p + 2048);
+      return f;
+    };
+    auto mm = [&](const WFrag& f, const Split8& x, f32x4& a0, f32x4& a1) {
+      if (!SWAP) {
+        a1 = mfma_bf(f.l, x.h, a1);
+        a0 = mfma_bf(f.m, x.h, a0);
+        a1 = mfma_bf(f.h, x.l, a1);
+        a0 = mfma_bf(f.h, x.m, a0);
+        a1 = mfma_bf(f.m, x.m, a1);
+        a0 = mfma_bf(f.h, x.h, a0);
+      } else {
+        a1 = mfma_bf(x.h, f.l, a1);
+        a0 = mfma_bf(x.h, f.m, a0);
+        a1 = mfma_bf(x.l, f.h, a1);
+        a0 = mfma_bf(x.m, f.h, a0);
+        a1 = mfma_bf(x.m, f.m, a1);
+        a0 = mfma_bf(x.h, f.h, a0);
+      }
+    };
+    WFrag fa = rd(0, 0), fb;
+#pragma unroll
+    for (int ot = 0; ot < NTO; ++ot) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb + 1 < NKB; ++kb) {
+        fb = rd(ot, kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa, xs[kb], a0, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        fa = fb;
+      }
+      const lds_char_t* pe = lbase + slot(ot) * R::CHUNK + R::NF * 1024;
+      const f32x4 e0 = *(lds_f32x4*)(pe), e1 = *(lds_f32x4*)(pe + 1024), e2 = *(lds_f32x4*)(pe + 2048);
+      if (CHAIN) {
+        // all my reads of chunk ot are complete and my share of chunk ot+1 has landed -> barrier -> refill the slot
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vmcnt<(SPLIT_RING - 2) * R::LPC>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(ot);
+      }
+      if (ot + 1 < NTO) fb = rd(ot + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa, xs[NKB - 1], a0, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      epi(ot, a0 + a1, e0, e1, e2);
+      fa = fb;
+    }
+  } else if (CHAIN) {
+#pragma unroll
+    for (int ot = 0; ot < NTO; ++ot) {
+      wait_vmcnt<(SPLIT_RING - 2) * R::LPC>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage(ot);
+    }
+  }
+  ring.pos = ring.slot_of(NTO);
+}
+
 // sum over the 4 lane groups (lanes l, l^16, l^32, l^48) that hold one activation row
 __device__ __forceinline__ float row_allsum(float v) {
   v += __shfl_xor(v, 16, 64);

@@ -46,71 +46,25 @@ struct PhiStruct {
 
 constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
 
-// out{P,M}[ot] = W (packed) x in{P,M}  — both signs share every weight fragment.
-// True double buffering of the weight fragments: while the 8*NT MFMAs of output tile ot run from buffer A, the
-// NT fragments of tile ot+1 (NT x 1 KiB coalesced wave-loads from L2) land in buffer B, and vice versa.  The
-// sched_barriers pin "issue the next tile's loads FIRST, then this tile's MFMAs" — without them the compiler
-// merges the two buffers and sinks the loads to the end of the MFMA block (measured: MFMA pipe 57 % busy).
-template <int NT>
-__device__ __forceinline__ void mfma_tile_pm(const float4 (&w)[NT], const f32x4 (&inP)[NT], const f32x4 (&inM)[NT],
-                                             f32x4& oP, f32x4& oM) {
-  f32x4 aP = {0.f, 0.f, 0.f, 0.f}, aM = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kk = 0; kk < NT; ++kk) {
-    aP = mfma16(w[kk].x, inP[kk][0], aP);
-    aM = mfma16(w[kk].x, inM[kk][0], aM);
-    aP = mfma16(w[kk].y, inP[kk][1], aP);
-    aM = mfma16(w[kk].y, inM[kk][1], aM);
-    aP = mfma16(w[kk].z, inP[kk][2], aP);
-    aM = mfma16(w[kk].z, inM[kk][2], aM);
-    aP = mfma16(w[kk].w, inP[kk][3], aP);
-    aM = mfma16(w[kk].w, inM[kk][3], aM);
-  }
-  oP = aP;
-  oM = aM;
-}
-
-template <int NT>
-__device__ __forceinline__ void gemm_pm(const float* __restrict__ wp, const f32x4 (&inP)[NT], const f32x4 (&inM)[NT],
-                                        f32x4 (&oP)[NT], f32x4 (&oM)[NT], int lane) {
-  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, NT * NT * 1024);
-  const int voff = lane * 16;
-  float4 wA[NT], wB[NT];
-#pragma unroll
-  for (int kk = 0; kk < NT; ++kk) wA[kk] = wfrag(rs, voff, kk);
-#pragma unroll
-  for (int ot = 0; ot < NT; ot += 2) {
-    if (ot + 1 < NT) {
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) wB[kk] = wfrag(rs, voff, (ot + 1) * NT + kk);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_tile_pm<NT>(wA, inP, inM, oP[ot], oM[ot]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ot + 1 < NT) {
-      if (ot + 2 < NT) {
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) wA[kk] = wfrag(rs, voff, (ot + 2) * NT + kk);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_tile_pm<NT>(wB, inP, inM, oP[ot + 1], oM[ot + 1]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
 template <int NT>
 __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;  // +4 floats: conflict-free ds_write_b128 of 8 consecutive rows
-  extern __shared__ __align__(16) float lds[];
-  float* X = lds;                         // [2][PHI_R][LD]
-  float* xs = lds + 2 * PHI_R * LD;       // [PHI_R] scalar eigenvector entries (layer 0)
+  constexpr int NKB = (NT + 1) / 2;
+  using Ring = WRing<NT>;
+  extern __shared__ __align__(1024) unsigned char lds_raw[];
+  float* X = reinterpret_cast<float*>(lds_raw + Ring::BYTES);   // [PHI_R][LD]  x_l of the sign being computed
+  float* xs = X + PHI_R * LD;                                   // [PHI_R] scalar eigenvector entries (layer 0)
   unsigned char* nbr = reinterpret_cast<unsigned char*>(xs + PHI_R);   // [PHI_R][PHI_NBR] bin rows of the first in-neighbours
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4;
   const int nbins = S.meta[0];
   if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
+  Ring ring;
+  ring.init(lds_raw, wave, lane);
+  // first [d,d] Linear of a (bin, sign) pass — where the weight stream (re)starts
+  const void* wfirst = (P.hid0 != 1) ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
+  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
     // ---------------------------------------------------------------- my row: bin -> column -> member graph
@@ -136,15 +90,15 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
       }
     }
     const bool valid = node >= 0;
-    const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all GEMMs (keeps the barriers)
+    const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all MFMAs (keeps barriers + DMA)
     const int deg = e_hi - e_lo;
+    __syncthreads();   // previous bin is done with xs / nbr / X
     if (g == 0) {
       xs[r] = xval;
       for (int e = 0; e < deg && e < PHI_NBR; ++e) nbr[r * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
     }
-    float* XP = X + r * LD;                 // my row, sign +
-    float* XM = X + (PHI_R + r) * LD;       // my row, sign -
-    // ---------------------------------------------------------------- layer 0 (scalar input)
+    float* XR = X + r * LD;                 // my row
+    // ---------------------------------------------------------------- layer 0 aggregate (scalar input, sign-free)
     __syncthreads();
     float a0 = 0.f;
     for (int e = 0; e < deg; ++e) a0 += xs[e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs];
@@ -154,132 +108,121 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
       const float self = xval * sc;
       a0 = a0 + self;
     }
-    __syncthreads();  // xs may be rewritten by the next bin
-    f32x4 inP[NT], inM[NT], oP[NT], oM[NT];
-    if (!wave_live) {
-      // nothing to compute in this tile
-    } else if (P.hid0 == 1) {
-      // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
-      const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
-      const float tP = fmaxf((a0 * w1) * s0 + h0, 0.f);
-      const float tM = fmaxf(((-a0) * w1) * s0 + h0, 0.f);
+    f32x4 res[NT];
+#pragma unroll 1
+    for (int sg = 0; sg < 2; ++sg) {
+      const float as = sg ? -a0 : a0;          // phi(-x): the aggregate of -x is exactly -(aggregate of x)
+      f32x4 in[NT], o[NT];
+      Split8 sp[NKB];
+      // -------------------------------------------------------------- layer 0
+      if (P.hid0 == 1) {
+        // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
+        if (wave_live) {
+          const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
+          const float t = fmaxf((as * w1) * s0 + h0, 0.f);
+          const float* w2v = reinterpret_cast<const float*>(P.l0_w2);
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        const f32x4 w2 = ld4(P.l0_w2 + c), s1 = ld4(P.l0_bn_scale + c), h1 = ld4(P.l0_bn_shift + c);
-        f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
-        if (P.l0_bias2) b2 = ld4(P.l0_bias2 + c);
-        inP[kk] = relu4((tP * w2 + b2) * s1 + h1);
-        inM[kk] = relu4((tM * w2 + b2) * s1 + h1);
-      }
-    } else {
-      // Linear(1->d) . BN . ReLU . Linear(d->d) [+b] . BN . ReLU           (Alchemy sign_net.py:20)
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        const f32x4 w1 = ld4(P.l0_w1 + c), s0 = ld4(P.l0_bn0_scale + c), h0 = ld4(P.l0_bn0_shift + c);
-        oP[kk] = relu4((a0 * w1) * s0 + h0);
-        oM[kk] = relu4(((-a0) * w1) * s0 + h0);
-      }
-      gemm_pm<NT>(P.l0_w2, oP, oM, inP, inM, lane);
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        const f32x4 s1 = ld4(P.l0_bn_scale + c), h1 = ld4(P.l0_bn_shift + c);
-        f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
-        if (P.l0_bias2) b2 = ld4(P.l0_bias2 + c);
-        inP[kk] = relu4((inP[kk] + b2) * s1 + h1);
-        inM[kk] = relu4((inM[kk] + b2) * s1 + h1);
-      }
-    }
-    if (!valid) {
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) { inP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; inM[kk] = inP[kk]; }
-    }
-    // ---------------------------------------------------------------- layers 1 .. L-1
-    for (int l = 1; l < P.n_layers; ++l) {
-      const sn_phi_layer& Lp = P.layers[l - 1];
-      // publish x_l (both signs) for the neighbour sums and the residual
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        lds_st4(XP + 16 * kk + 4 * g, inP[kk]);
-        lds_st4(XM + 16 * kk + 4 * g, inM[kk]);
-      }
-      __syncthreads();
-      if (wave_live) {
-        // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self
-  #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) { oP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; oM[kk] = oP[kk]; }
-        for (int e = 0; e < deg; ++e) {
-          const int nb = e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs;
-          const float* nP = X + nb * LD + 4 * g;
-          const float* nM = nP + PHI_R * LD;
-  #pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
-            oP[kk] += lds_ld4(nP + 16 * kk);
-            oM[kk] += lds_ld4(nM + 16 * kk);
+            const int c = 16 * kk + 4 * g;
+            const f32x4 w2 = ld4(w2v + c), s1 = ld4(P.l0_bn_scale + c), h1 = ld4(P.l0_bn_shift + c);
+            f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
+            if (P.l0_bias2) b2 = ld4(P.l0_bias2 + c);
+            in[kk] = relu4((t * w2 + b2) * s1 + h1);
           }
         }
-        {
-  #pragma clang fp contract(off)
-          const float sc = 1.f + *Lp.eps;
-  #pragma unroll
+      } else {
+        // Linear(1->d) . BN . ReLU . Linear(d->d) [+b] . BN . ReLU           (Alchemy sign_net.py:20)
+        if (wave_live) {
+#pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
-            const f32x4 sP = inP[kk] * sc, sM = inM[kk] * sc;
-            inP[kk] = oP[kk] + sP;
-            inM[kk] = oM[kk] + sM;
+            const int c = 16 * kk + 4 * g;
+            const f32x4 w1 = ld4(P.l0_w1 + c), s0 = ld4(P.l0_bn0_scale + c), h0 = ld4(P.l0_bn0_shift + c);
+            o[kk] = relu4((as * w1) * s0 + h0);
           }
+          split_rows<NT>(o, sp);
+        }
+        const void* nxt = P.n_layers > 1 ? P.layers[0].w1s : wfirst;
+        wg_gemm_split<NT, NT, false>(ring, P.l0_w2, nxt, wave_live, sp,
+                                     [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1) { in[ot] = relu4((acc + b2) * s1 + h1); });
+      }
+      if (!valid) {
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      // -------------------------------------------------------------- layers 1 .. L-1
+#pragma unroll 1
+      for (int l = 1; l < P.n_layers; ++l) {
+        const sn_phi_layer& Lp = P.layers[l - 1];
+        // publish x_l for the neighbour sums and the residual
+        if (wave_live) {
+#pragma unroll
+          for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
+        }
+        lds_barrier();
+        if (wave_live) {
+          // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self
+#pragma unroll
+          for (int kk = 0; kk < NT; ++kk) o[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < deg; ++e) {
+            const int nb = e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs;
+            const float* np = X + nb * LD + 4 * g;
+#pragma unroll
+            for (int kk = 0; kk < NT; ++kk) o[kk] += lds_ld4(np + 16 * kk);
+          }
+          {
+#pragma clang fp contract(off)
+            const float sc = 1.f + *Lp.eps;
+#pragma unroll
+            for (int kk = 0; kk < NT; ++kk) {
+              const f32x4 sf = in[kk] * sc;
+              o[kk] = o[kk] + sf;
+            }
+          }
+          split_rows<NT>(o, sp);
         }
         // MaskedMLP: Linear . BN . ReLU . Linear [+b]
-        gemm_pm<NT>(Lp.w1p, inP, inM, oP, oM, lane);
-  #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-          const int c = 16 * kk + 4 * g;
-          const f32x4 s0 = ld4(Lp.bn0_scale + c), h0 = ld4(Lp.bn0_shift + c);
-          oP[kk] = relu4(oP[kk] * s0 + h0);
-          oM[kk] = relu4(oM[kk] * s0 + h0);
-        }
-        gemm_pm<NT>(Lp.w2p, oP, oM, inP, inM, lane);
+        wg_gemm_split<NT, NT, false>(ring, Lp.w1s, Lp.w2s, wave_live, sp,
+                                     [&](int ot, f32x4 acc, f32x4 s0, f32x4 h0, f32x4) { o[ot] = relu4(acc * s0 + h0); });
+        if (wave_live) split_rows<NT>(o, sp);
+        const void* nxt = (l + 1 < P.n_layers) ? P.layers[l].w1s : wfirst;   // next sign / next bin restart the stream here
         // GNN3d: mask . BN . ReLU . + previous_x
-  #pragma unroll
+        wg_gemm_split<NT, NT, false>(ring, Lp.w2s, nxt, wave_live, sp, [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1) {
+          in[ot] = relu4((acc + b2) * s1 + h1) + lds_ld4(XR + 16 * ot + 4 * g);
+        });
+        if (!valid) {
+#pragma unroll
+          for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        lds_barrier();  // everyone is done reading X before it is overwritten
+      }
+      if (sg == 0) {
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) res[kk] = in[kk];
+      } else if (valid) {
+        // ------------------------------------------------------------ phi(x) + phi(-x) -> out[node*K + slot, :]
+        float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
+#pragma unroll
         for (int kk = 0; kk < NT; ++kk) {
           const int c = 16 * kk + 4 * g;
-          const f32x4 s1 = ld4(Lp.bn_scale + c), h1 = ld4(Lp.bn_shift + c);
-          f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
-          if (Lp.bias2) b2 = ld4(Lp.bias2 + c);
-          inP[kk] = relu4((inP[kk] + b2) * s1 + h1) + lds_ld4(XP + c);
-          inM[kk] = relu4((inM[kk] + b2) * s1 + h1) + lds_ld4(XM + c);
-        }
-        if (!valid) {
-  #pragma unroll
-          for (int kk = 0; kk < NT; ++kk) { inP[kk] = f32x4{0.f, 0.f, 0.f, 0.f}; inM[kk] = inP[kk]; }
-        }
-      }
-      __syncthreads();  // everyone is done reading X before it is overwritten
-    }
-    // ---------------------------------------------------------------- phi(x) + phi(-x) -> out[node*K + slot, :]
-    if (valid) {
-      float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
+          const f32x4 v = res[kk] + in[kk];
+          if ((P.d & 3) == 0) {
+            if (c < P.d) *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        const f32x4 v = inP[kk] + inM[kk];
-        if ((P.d & 3) == 0) {
-          if (c < P.d) *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (c + t < P.d) orow[c + t] = v[t];
+            for (int t = 0; t < 4; ++t)
+              if (c + t < P.d) orow[c + t] = v[t];
+          }
         }
       }
     }
   }
+  ring.drain();
 }
 
 template <int NT>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
+  const size_t lds = (size_t)WRing<NT>::BYTES + (size_t)(PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
@@ -310,12 +253,11 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
   SN_REQUIRE(P.d > 0 && P.d <= 128, "sn_phi_fused_f32: hidden width %d not in (0, 128]", P.d);
   SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS, "sn_phi_fused_f32: %d layers unsupported", P.n_layers);
   SN_REQUIRE(P.hid0 == 1 || P.hid0 == P.d, "sn_phi_fused_f32: first hidden width must be 1 or d");
-  SN_REQUIRE(P.l0_w1 && P.l0_bn0_scale && P.l0_bn0_shift && P.l0_w2 && P.l0_bn_scale && P.l0_bn_shift && P.l0_eps,
-             "sn_phi_fused_f32: layer-0 parameters missing");
+  SN_REQUIRE(P.l0_w1 && P.l0_bn0_scale && P.l0_bn0_shift && P.l0_w2 && P.l0_eps, "sn_phi_fused_f32: layer-0 parameters missing");
+  SN_REQUIRE(P.hid0 != 1 || (P.l0_bn_scale && P.l0_bn_shift), "sn_phi_fused_f32: layer-0 BatchNorm vectors missing");
   for (int l = 1; l < P.n_layers; ++l) {
     const sn_phi_layer& L = P.layers[l - 1];
-    SN_REQUIRE(L.w1p && L.bn0_scale && L.bn0_shift && L.w2p && L.bn_scale && L.bn_shift && L.eps,
-               "sn_phi_fused_f32: layer %d parameters missing", l);
+    SN_REQUIRE(L.w1s && L.w2s && L.eps, "sn_phi_fused_f32: layer %d parameters missing", l);
   }
   SN_REQUIRE(K > 0 && bins->phi_max_bins >= 0, "sn_phi_fused_f32: bad K / max_bins");
   if (bins->phi_max_bins == 0) return SN_OK;

@@ -10,12 +10,13 @@
 // pipe, entirely in registers: S^T = K.Q^T and O^T = V^T.P^T are MFMAs whose operand layouts are exactly the
 // accumulator layouts of the q / k projections and of a v projection computed with swapped operands:
 //   * rows live in registers in the MFMA operand layout; the six [rows,d]x[d,d] projections per layer are
-//     chained gemm_rows() calls (fp32 MFMA) — residuals and LayerNorm run on the accumulators;
+//     chained wg_gemm_split() calls (fp32 via the bf16 matrix pipe, fused_common.hpp: weights staged once per
+//     workgroup in an LDS ring by LDS-DMA) — residuals and LayerNorm run on the accumulators;
 //   * attention: q, k, v rows are exchanged through two LDS images; lane (row, head) computes its
 //     query's scores against the node's keys (two passes: max, then exp / sum / P.V), exactly
 //     softmax(q k^T / sqrt(dk)) restricted to the node's valid slots (transformer_module.py:52-57);
 //   * the final sum over slots is done from LDS by each node's first row.
-// Bound: fp32 MFMA; flops per valid row and layer: 6 * 2*d*d (+ 4*K*d attention on the VALU).
+// Bound: matrix pipe (6 bf16 partial products per fp32 product); flops per valid row and layer: 6 * 2*d*d (+ 4*K*d attention).
 #include "fused_common.hpp"
 
 namespace sn {
@@ -62,51 +63,6 @@ __device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* __
   }
 }
 
-// gemm with SWAPPED MFMA operands: acc[r] = Y[row = 4g + r][o = 16*ot + (l&15)] — the "channel in lane, rows in
-// registers" layout that the P.V product needs for V (same packed weight fragments, same k order).
-template <int NT, typename Epi>
-__device__ __forceinline__ void gemm_rows_t(const float* __restrict__ wp, const f32x4 (&in)[NT], int lane, Epi epi) {
-  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, NT * NT * 1024);
-  const int voff = lane * 16;
-  float4 wA[NT], wB[NT];
-#pragma unroll
-  for (int kk = 0; kk < NT; ++kk) wA[kk] = wfrag(rs, voff, kk);
-  auto tile = [&](const float4 (&w)[NT]) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < NT; kk += 2) {
-      a0 = mfma16(in[kk][0], w[kk].x, a0);
-      if (kk + 1 < NT) a1 = mfma16(in[kk + 1][0], w[kk + 1].x, a1);
-      a0 = mfma16(in[kk][1], w[kk].y, a0);
-      if (kk + 1 < NT) a1 = mfma16(in[kk + 1][1], w[kk + 1].y, a1);
-      a0 = mfma16(in[kk][2], w[kk].z, a0);
-      if (kk + 1 < NT) a1 = mfma16(in[kk + 1][2], w[kk + 1].z, a1);
-      a0 = mfma16(in[kk][3], w[kk].w, a0);
-      if (kk + 1 < NT) a1 = mfma16(in[kk + 1][3], w[kk + 1].w, a1);
-    }
-    return a0 + a1;
-  };
-#pragma unroll
-  for (int ot = 0; ot < NT; ot += 2) {
-    if (ot + 1 < NT) {
-#pragma unroll
-      for (int kk = 0; kk < NT; ++kk) wB[kk] = wfrag(rs, voff, (ot + 1) * NT + kk);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    epi(ot, tile(wA));
-    __builtin_amdgcn_sched_barrier(0);
-    if (ot + 1 < NT) {
-      if (ot + 2 < NT) {
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) wA[kk] = wfrag(rs, voff, (ot + 2) * NT + kk);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      epi(ot + 1, tile(wB));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-}
-
 __device__ __forceinline__ float group_allmax(float v) {   // over the 4 lane groups holding one row
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
@@ -118,21 +74,29 @@ __device__ __forceinline__ float tile_rowsum(float v) {    // over the 16 rows (
   return v + __shfl_xor(v, 8, 64);
 }
 
-template <int NT>
+// REGATTN: every node has <= 16 valid slots (0 < kmax <= 16) and the head width is a multiple of 16 -> attention in
+// registers, no LDS images (the host picks the variant; the other one serves any slot count through LDS).
+template <int NT, bool REGATTN>
 __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
   constexpr int DKMAX = (D + 3) / 4;   // heads = 4: dk <= D/4
-  extern __shared__ __align__(16) float lds[];
-  float* A = lds;                 // [RHO_R][LD]   q, then v          (LDS attention path only)
-  float* Bm = lds + RHO_R * LD;   // [RHO_R][LD]   k, then the attention output / slot-sum image
+  constexpr int NKB = (NT + 1) / 2;
+  using Ring = WRing<NT>;
+  extern __shared__ __align__(1024) unsigned char lds_raw[];
+  float* A = reinterpret_cast<float*>(lds_raw + Ring::BYTES);   // [RHO_R][LD]   q, then v          (LDS attention path only)
+  float* Bm = A + RHO_R * LD;                                     // [RHO_R][LD]   k, then the attention output / slot-sum image
   __shared__ int s_graph;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
   const int nbins = S.meta[4];
   if (S.meta[5] != 0) return;
   const int d = P.d, H = P.heads, dk = d / H;
   const float temp = sqrtf((float)dk);
+  Ring ring;
+  ring.init(lds_raw, wave, lane);
+  const void* wfirst = P.n_layers > 0 ? P.layers[0].wq : nullptr;
+  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
     // ---------------------------------------------------------------- bin -> graph (bins never mix graphs)
@@ -152,7 +116,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     const int node = gs + u;
     const int kv = unit_ok ? kg : 0;
     const int u0 = q * pad;                                        // bin row of my node's slot 0
-    const bool mfma_attn = (pad == 16) && ((dk & 15) == 0);        // one node == one wave tile: attention in registers
+    constexpr bool mfma_attn = REGATTN;                             // one node == one wave tile: attention in registers
     const bool wave_live = __ballot(valid) != 0ull;
     float* Ar = A + r * LD;
     float* Br = Bm + r * LD;
@@ -186,72 +150,68 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       }
     }
     // ---------------------------------------------------------------- encoder layers
+#pragma unroll 1
     for (int l = 0; l < P.n_layers; ++l) {
       const sn_rho_layer& Lp = P.layers[l];
+      const void* wafter = (l + 1 < P.n_layers) ? P.layers[l + 1].wq : wfirst;   // the stream restarts at layer 0 for the next bin
       f32x4 o[NT], y[NT];
+      Split8 sp[NKB];
+      if (wave_live) split_rows<NT>(x, sp);
       if (mfma_attn) {
         // ======== attention in registers (K_g <= 16: the node's slots are exactly this wave's 16 rows) ========
+        // q, then k with the scores S^T = K.Q^T accumulated head by head in k's epilogue (k is never stored), softmax,
+        // then v (swapped operands: V[key = 4g+r][c = 16ot + li]) with O^T = V^T.P^T in its epilogue (v is never stored).
+        constexpr int CPH = NT / 4 > 0 ? NT / 4 : 1;   // 16-channel chunks per head
+        f32x4 qf[NT], sc[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { qf[ot] = acc / temp; });   // q / sqrt(dk)  (:52)
+        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, [&](int ot, f32x4 kf, f32x4, f32x4, f32x4) {
+          // lane (query = li, g) accumulates S[query][key = 4g + r] of head ot / CPH
+          const int h = ot / CPH < 4 ? ot / CPH : 3;
+          sc[h] = mfma16(kf[0], qf[ot][0], sc[h]);
+          sc[h] = mfma16(kf[1], qf[ot][1], sc[h]);
+          sc[h] = mfma16(kf[2], qf[ot][2], sc[h]);
+          sc[h] = mfma16(kf[3], qf[ot][3], sc[h]);
+        });
         if (wave_live) {
-          f32x4 qf[NT], kf[NT], vt[NT];
-          gemm_rows<NT>(Lp.wq, x, lane, [&](int ot, f32x4 acc) { qf[ot] = acc / temp; });   // q / sqrt(dk)  (:52)
-          gemm_rows<NT>(Lp.wk, x, lane, [&](int ot, f32x4 acc) { kf[ot] = acc; });
-          gemm_rows_t<NT>(Lp.wv, x, lane, [&](int ot, f32x4 acc) { vt[ot] = acc; });          // V[key = 4g+r][c = 16ot + li]
-          constexpr int CPH = NT / 4 > 0 ? NT / 4 : 1;   // 16-channel chunks per head
 #pragma unroll
           for (int h = 0; h < 4; ++h) {
-            // S^T[key][query]: lane (query = li, g) holds S[query][key = 4g + r]
-            f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int cc = 0; cc < CPH; ++cc) {
-              const int kk = h * CPH + cc;
-              if (kk < NT) {
-                sc = mfma16(kf[kk][0], qf[kk][0], sc);
-                sc = mfma16(kf[kk][1], qf[kk][1], sc);
-                sc = mfma16(kf[kk][2], qf[kk][2], sc);
-                sc = mfma16(kf[kk][3], qf[kk][3], sc);
-              }
-            }
             float m = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { if (4 * g + t >= kv) sc[t] = -INFINITY; m = fmaxf(m, sc[t]); }
+            for (int t = 0; t < 4; ++t) { if (4 * g + t >= kv) sc[h][t] = -INFINITY; m = fmaxf(m, sc[h][t]); }
             m = group_allmax(m);
             float z = 0.f;
-            f32x4 pr;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { pr[t] = (4 * g + t < kv) ? expf(sc[t] - m) : 0.f; z += pr[t]; }
+            for (int t = 0; t < 4; ++t) { sc[h][t] = (4 * g + t < kv) ? expf(sc[h][t] - m) : 0.f; z += sc[h][t]; }
             z = row_allsum(z);
             const float zi = (kv > 0) ? 1.0f / z : 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) pr[t] *= zi;
-            // O^T[c][query] = sum_key V[key][c] P[query][key]  -> lane (query, g) holds O[query][16*ot + 4g + r]
-#pragma unroll
-            for (int cc = 0; cc < CPH; ++cc) {
-              const int ot = h * CPH + cc;
-              if (ot < NT) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mfma16(vt[ot][0], pr[0], acc);
-                acc = mfma16(vt[ot][1], pr[1], acc);
-                acc = mfma16(vt[ot][2], pr[2], acc);
-                acc = mfma16(vt[ot][3], pr[3], acc);
-                o[ot] = acc;
-              }
-            }
+            for (int t = 0; t < 4; ++t) sc[h][t] *= zi;     // P[query][key = 4g + t]
           }
         }
+        wg_gemm_split<NT, NT, true>(ring, Lp.wv, Lp.wfc, wave_live, sp, [&](int ot, f32x4 vt, f32x4, f32x4, f32x4) {
+          // O^T[c][query] = sum_key V[key][c] P[query][key]  -> lane (query, g) holds O[query][16*ot + 4g + r]
+          const int h = ot / CPH < 4 ? ot / CPH : 3;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = mfma16(vt[0], sc[h][0], acc);
+          acc = mfma16(vt[1], sc[h][1], acc);
+          acc = mfma16(vt[2], sc[h][2], acc);
+          acc = mfma16(vt[3], sc[h][3], acc);
+          o[ot] = acc;
+        });
       } else {
         // ======== attention through LDS (nodes of more than 16 slots span several waves' tiles) ========
-        if (wave_live) {
-          gemm_rows<NT>(Lp.wq, x, lane, [&](int ot, f32x4 acc) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
-          gemm_rows<NT>(Lp.wk, x, lane, [&](int ot, f32x4 acc) { lds_st4(Br + 16 * ot + 4 * g, acc); });
-        }
-        __syncthreads();
+        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
+        lds_barrier();
         float qh[DKMAX];
         const int hc = g * dk;
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
         // (q rows are written and read by the same wave only: no barrier before A is reused for v)
-        if (wave_live) gemm_rows<NT>(Lp.wv, x, lane, [&](int ot, f32x4 acc) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
-        __syncthreads();
+        wg_gemm_split<NT, NT, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        lds_barrier();
         float m = -INFINITY;
         float oh[DKMAX];
 #pragma unroll
@@ -303,7 +263,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
           }
         }
         const float zi = (kv > 0) ? 1.0f / z : 0.f;
-        __syncthreads();   // all reads of k (Bm) are done: Bm receives the attention output
+        lds_barrier();   // all reads of k (Bm) are done: Bm receives the attention output
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c)
           if (c < dk) Br[hc + c] = oh[c] * zi;
@@ -314,15 +274,18 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) o[kk] = lds_ld4(Br + 16 * kk + 4 * g);
       }
+      // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
+      if (wave_live) split_rows<NT>(o, sp);
+      wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { y[ot] = acc + x[ot]; });
       if (wave_live) {
-        // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
-        gemm_rows<NT>(Lp.wfc, o, lane, [&](int ot, f32x4 acc) { y[ot] = acc + x[ot]; });
         masked_layernorm<NT>(y, Lp.ln1_g, Lp.ln1_b, P.ln_eps, d, g, valid);
-        // FFN: w2(relu(w1 y + b1)) + b2 + y -> LayerNorm               (transformer_module.py:113-127)
-        gemm_rows<NT>(Lp.w1, y, lane, [&](int ot, f32x4 acc) { o[ot] = relu4(acc + ld4(Lp.b1 + 16 * ot + 4 * g)); });
-        gemm_rows<NT>(Lp.w2, o, lane, [&](int ot, f32x4 acc) { x[ot] = acc + ld4(Lp.b2 + 16 * ot + 4 * g) + y[ot]; });
-        masked_layernorm<NT>(x, Lp.ln2_g, Lp.ln2_b, P.ln_eps, d, g, valid);
+        split_rows<NT>(y, sp);
       }
+      // FFN: w2(relu(w1 y + b1)) + b2 + y -> LayerNorm               (transformer_module.py:113-127)
+      wg_gemm_split<NT, NT, false>(ring, Lp.w1, Lp.w2, wave_live, sp, [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
+      if (wave_live) split_rows<NT>(o, sp);
+      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4) { x[ot] = acc + b2 + y[ot]; });
+      if (wave_live) masked_layernorm<NT>(x, Lp.ln2_g, Lp.ln2_b, P.ln_eps, d, g, valid);
     }
     // ---------------------------------------------------------------- sum over the node's slots -> out_sum[node, :]
     if (mfma_attn) {
@@ -367,16 +330,17 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       }
     }
   }
+  ring.drain();
 }
 
-template <int NT>
+template <int NT, bool REGATTN>
 static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)(2 * RHO_R * LD) * sizeof(float);
+  const size_t lds = (size_t)WRing<NT>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float));
   static int cus = 0;
   if (cus == 0) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_rho_fused_f32: cannot raise the dynamic LDS limit to %zu", lds);
     int dev = 0, n = 256;
@@ -385,8 +349,22 @@ static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_b
   }
   int64_t grid = bins_bound < (int64_t)2 * cus ? bins_bound : (int64_t)2 * cus;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_rho_fused<NT>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
+  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
   return SN_OK;
+}
+
+template <bool REGATTN>
+static int dispatch_rho(int nt, const RhoStruct& S, const sn_rho_params& P, int64_t bound, hipStream_t st) {
+  switch (nt) {
+    case 1: return launch_rho<1, REGATTN>(S, P, bound, st);
+    case 2: return launch_rho<2, REGATTN>(S, P, bound, st);
+    case 3: return launch_rho<3, REGATTN>(S, P, bound, st);
+    case 4: return launch_rho<4, REGATTN>(S, P, bound, st);
+    case 5: return launch_rho<5, REGATTN>(S, P, bound, st);
+    case 6: return launch_rho<6, REGATTN>(S, P, bound, st);
+    case 7: return launch_rho<7, REGATTN>(S, P, bound, st);
+    default: return launch_rho<8, REGATTN>(S, P, bound, st);
+  }
 }
 
 }  // namespace sn
@@ -405,7 +383,7 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
              "sn_rho_fused_f32: eigenvalue encoder parameters missing");
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_rho_layer& L = P.layers[l];
-    SN_REQUIRE(L.wq && L.wk && L.wv && L.wfc && L.ln1_g && L.ln1_b && L.w1 && L.b1 && L.w2 && L.b2 && L.ln2_g && L.ln2_b,
+    SN_REQUIRE(L.wq && L.wk && L.wv && L.wfc && L.ln1_g && L.ln1_b && L.w1 && L.w2 && L.ln2_g && L.ln2_b,
                "sn_rho_fused_f32: layer %d parameters missing", l);
   }
   SN_REQUIRE(K > 0 && B >= 0 && N >= 0 && B < (1ll << 31), "sn_rho_fused_f32: bad sizes");
@@ -413,17 +391,10 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   RhoStruct S{x, eigen_values, graph_ptr, bins->rho_bin0, bins->meta, (int)B, kmax, K, out_sum};
   hipStream_t st = (hipStream_t)stream;
   const int64_t bound = N + B;   // every bin holds at least one node
-  int rc = SN_OK;
-  switch ((P.d + 15) / 16) {
-    case 1: rc = launch_rho<1>(S, P, bound, st); break;
-    case 2: rc = launch_rho<2>(S, P, bound, st); break;
-    case 3: rc = launch_rho<3>(S, P, bound, st); break;
-    case 4: rc = launch_rho<4>(S, P, bound, st); break;
-    case 5: rc = launch_rho<5>(S, P, bound, st); break;
-    case 6: rc = launch_rho<6>(S, P, bound, st); break;
-    case 7: rc = launch_rho<7>(S, P, bound, st); break;
-    default: rc = launch_rho<8>(S, P, bound, st); break;
-  }
+  // attention in registers when every node has <= 16 slots and the head width is a multiple of 16
+  const bool regattn = kmax > 0 && kmax <= 16 && ((P.d / P.heads) & 15) == 0;
+  const int nt = (P.d + 15) / 16;
+  int rc = regattn ? dispatch_rho<true>(nt, S, P, bound, st) : dispatch_rho<false>(nt, S, P, bound, st);
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_rho_fused_f32");
   return SN_OK;

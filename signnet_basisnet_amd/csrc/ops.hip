@@ -20,6 +20,53 @@ __global__ void k_pack_weight(const float* __restrict__ W, int d_out, int d_in, 
   Wp[idx] = (o < d_out && k < d_in) ? W[(int64_t)o * ldw + k] : 0.f;
 }
 
+// ============================================================================ split-packed linear (bf16 x 3 + epilogue vectors)
+// Layout consumed by wg_gemm_split (fused_common.hpp): per 16-output tile ot one chunk of
+//   [kb < NKB][plane h,m,l][lane][8 bf16]   with k-slot s of lane (o = lane&15, g = lane>>4) = channel 32kb + 16(s>>2) + 4g + (s&3)
+//   [e < 3][lane][4 f32] = vec_e[16 ot + 4g + t]
+__global__ void k_pack_split(const float* __restrict__ W, int d_out, int d_in, int ldw, const float* __restrict__ e0,
+                             const float* __restrict__ e1, const float* __restrict__ e2, int nto, int nkb,
+                             unsigned char* __restrict__ dst) {
+  const int nfe = 3 * nkb + SN_SPLIT_EPI;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (chunk, fragment, lane)
+  if (idx >= (int64_t)nto * nfe * 64) return;
+  const int lane = idx & 63;
+  const int fr = (int)((idx >> 6) % nfe), ot = (int)((idx >> 6) / nfe);
+  unsigned char* out = dst + ((int64_t)ot * nfe + fr) * 1024 + lane * 16;
+  const int g = lane >> 4;
+  if (fr < 3 * nkb) {
+    const int kb = fr / 3, plane = fr - 3 * kb;
+    const int o = 16 * ot + (lane & 15);
+    unsigned short v[8];
+    for (int s = 0; s < 8; ++s) {
+      const int ch = 32 * kb + 16 * (s >> 2) + 4 * g + (s & 3);
+      const float w = (o < d_out && ch < d_in) ? W[(int64_t)o * ldw + ch] : 0.f;
+      const float h = __uint_as_float(__float_as_uint(w) & 0xffff0000u);
+      const float r = w - h;
+      const float m = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+      const float l = r - m;
+      const float pick = plane == 0 ? h : (plane == 1 ? m : l);
+      v[s] = (unsigned short)(__float_as_uint(pick) >> 16);
+    }
+    uint4 q;
+    q.x = v[0] | ((unsigned)v[1] << 16);
+    q.y = v[2] | ((unsigned)v[3] << 16);
+    q.z = v[4] | ((unsigned)v[5] << 16);
+    q.w = v[6] | ((unsigned)v[7] << 16);
+    *reinterpret_cast<uint4*>(out) = q;
+  } else {
+    const int e = fr - 3 * nkb;
+    const float* vec = e == 0 ? e0 : (e == 1 ? e1 : e2);
+    float4 q;
+    float* qq = reinterpret_cast<float*>(&q);
+    for (int t = 0; t < 4; ++t) {
+      const int c = 16 * ot + 4 * g + t;
+      qq[t] = (vec && c < d_out) ? vec[c] : 0.f;
+    }
+    *reinterpret_cast<float4*>(out) = q;
+  }
+}
+
 // ============================================================================ BatchNorm(eval) folding
 // scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale; zero padded to Cp.
 __global__ void k_bn_fold(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ rm,
@@ -491,6 +538,23 @@ extern "C" int sn_pack_weight_f32(const float* W, int d_out, int d_in, int ldw, 
   hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, d_out,
                      d_in, ldw, nto, nti, Wp);
   SN_CHECK_LAUNCH("sn_pack_weight_f32");
+  return SN_OK;
+}
+
+extern "C" int64_t sn_split_packed_bytes(int d_out, int d_in) {
+  if (d_out <= 0 || d_in <= 0) return 0;
+  return cdiv(d_out, 16) * (3 * cdiv(d_in, 32) + SN_SPLIT_EPI) * 1024;
+}
+
+extern "C" int sn_pack_split_f32(const float* W, int d_out, int d_in, int ldw, const float* e0, const float* e1,
+                                 const float* e2, void* Wsp, void* stream) {
+  SN_REQUIRE(W && Wsp && d_out > 0 && d_in > 0 && ldw >= d_in, "sn_pack_split_f32: bad arguments");
+  SN_REQUIRE(al16(Wsp), "sn_pack_split_f32: destination must be 16-byte aligned");
+  const int nto = (int)cdiv(d_out, 16), nkb = (int)cdiv(d_in, 32);
+  const int64_t total = (int64_t)nto * (3 * nkb + SN_SPLIT_EPI) * 64;
+  hipLaunchKernelGGL(k_pack_split, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, d_out, d_in,
+                     ldw, e0, e1, e2, nto, nkb, reinterpret_cast<unsigned char*>(Wsp));
+  SN_CHECK_LAUNCH("sn_pack_split_f32");
   return SN_OK;
 }
 

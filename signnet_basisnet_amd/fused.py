@@ -13,7 +13,7 @@ PHI_MAX_LAYERS = 16
 
 
 class _PhiLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w1p", "bn0_scale", "bn0_shift", "w2p", "bias2", "bn_scale", "bn_shift", "eps")]
+    _fields_ = [(n, C.c_void_p) for n in ("w1s", "w2s", "eps")]
 
 
 class _PhiParams(C.Structure):
@@ -53,22 +53,22 @@ class PhiPlan:
         s, h = ops.bn_fold(c0.nn.norms[0].bn, hp)
         P.l0_bn0_scale, P.l0_bn0_shift = hold(s), hold(h)
         w2 = c0.nn.layers[1].weight.detach()          # [d, hid0]
-        P.l0_w2 = hold(ops.pad_vec(w2[:, 0], dp)) if hid0 == 1 else hold(ops.pack_weight(w2))
         b2 = c0.nn.layers[1].bias
-        P.l0_bias2 = hold(ops.pad_vec(b2, dp)) if b2 is not None else None
         s, h = ops.bn_fold(norms[0].bn, dp)
-        P.l0_bn_scale, P.l0_bn_shift = hold(s), hold(h)
+        if hid0 == 1:
+            P.l0_w2 = hold(ops.pad_vec(w2[:, 0], dp))
+            P.l0_bias2 = hold(ops.pad_vec(b2, dp)) if b2 is not None else None
+            P.l0_bn_scale, P.l0_bn_shift = hold(s), hold(h)
+        else:                                          # a [d, d] Linear: split-packed with its epilogue (bias, BN scale, BN shift)
+            P.l0_w2 = hold(ops.pack_split(w2, None if b2 is None else b2.detach(), s, h))
         P.l0_eps = hold(c0.layer.eps.detach())
         for l in range(1, L):
             c, Lp = convs[l], P.layers[l - 1]
-            Lp.w1p = hold(ops.pack_weight(c.nn.layers[0].weight.detach()))
             s, h = ops.bn_fold(c.nn.norms[0].bn, dp)
-            Lp.bn0_scale, Lp.bn0_shift = hold(s), hold(h)
-            Lp.w2p = hold(ops.pack_weight(c.nn.layers[1].weight.detach()))
+            Lp.w1s = hold(ops.pack_split(c.nn.layers[0].weight.detach(), s, h, None))
             b2 = c.nn.layers[1].bias
-            Lp.bias2 = hold(ops.pad_vec(b2, dp)) if b2 is not None else None
             s, h = ops.bn_fold(norms[l].bn, dp)
-            Lp.bn_scale, Lp.bn_shift = hold(s), hold(h)
+            Lp.w2s = hold(ops.pack_split(c.nn.layers[1].weight.detach(), None if b2 is None else b2.detach(), s, h))
             Lp.eps = hold(c.layer.eps.detach())
         self.params = P
 
@@ -90,7 +90,7 @@ RHO_MAX_LAYERS = 8
 
 
 class _RhoLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wq", "wk", "wv", "wfc", "ln1_g", "ln1_b", "w1", "b1", "w2", "b2", "ln2_g", "ln2_b")]
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "wk", "wv", "wfc", "ln1_g", "ln1_b", "w1", "w2", "ln2_g", "ln2_b")]
 
 
 class _RhoParams(C.Structure):
@@ -129,13 +129,13 @@ class RhoPlan:
             P.pe_bn1_scale, P.pe_bn1_shift = hold(s), hold(h)
         for l, tl in enumerate(tls):
             a, f, Lp = tl.slf_attn, tl.pos_ffn, P.layers[l]
-            Lp.wq = hold(ops.pack_weight(a.w_qs.weight.detach()))
-            Lp.wk = hold(ops.pack_weight(a.w_ks.weight.detach()))
-            Lp.wv = hold(ops.pack_weight(a.w_vs.weight.detach()))
-            Lp.wfc = hold(ops.pack_weight(a.fc.weight.detach()))
+            Lp.wq = hold(ops.pack_split(a.w_qs.weight.detach()))
+            Lp.wk = hold(ops.pack_split(a.w_ks.weight.detach()))
+            Lp.wv = hold(ops.pack_split(a.w_vs.weight.detach()))
+            Lp.wfc = hold(ops.pack_split(a.fc.weight.detach()))
             Lp.ln1_g, Lp.ln1_b = hold(ops.pad_vec(a.norm.ln.weight, dp)), hold(ops.pad_vec(a.norm.ln.bias, dp))
-            Lp.w1, Lp.b1 = hold(ops.pack_weight(f.w_1.weight.detach())), hold(ops.pad_vec(f.w_1.bias, dp))
-            Lp.w2, Lp.b2 = hold(ops.pack_weight(f.w_2.weight.detach())), hold(ops.pad_vec(f.w_2.bias, dp))
+            Lp.w1 = hold(ops.pack_split(f.w_1.weight.detach(), f.w_1.bias.detach()))
+            Lp.w2 = hold(ops.pack_split(f.w_2.weight.detach(), f.w_2.bias.detach()))
             Lp.ln2_g, Lp.ln2_b = hold(ops.pad_vec(f.norm.ln.weight, dp)), hold(ops.pad_vec(f.norm.ln.bias, dp))
         self.params = P
 

@@ -228,6 +228,27 @@ def pack_weight(W: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tenso
     return out
 
 
+def pack_split(W: torch.Tensor, e0=None, e1=None, e2=None) -> torch.Tensor:
+    """nn.Linear weight [d_out, d_in] (+ up to three per-output-channel epilogue vectors) -> the split-packed buffer
+    of sn_pack_split_f32: exact 3 x bf16 significand split of every weight, fragment order of the fused phi / rho
+    kernels (csrc/fused_common.hpp).  Returns a uint8 tensor that owns the buffer."""
+    require_cuda(W)
+    if W.dtype != torch.float32 or W.dim() != 2 or W.stride(1) != 1:
+        raise ValueError("pack_split: expected a float32 [d_out, d_in] matrix with unit inner stride")
+    d_out, d_in = W.shape
+    vecs = []
+    for e in (e0, e1, e2):
+        if e is not None:
+            e = e.detach().to(device=W.device, dtype=torch.float32).contiguous()
+            if e.numel() < d_out:
+                raise ValueError("pack_split: epilogue vector shorter than d_out")
+        vecs.append(e)
+    out = torch.empty(int(lib().sn_split_packed_bytes(d_out, d_in)), dtype=torch.uint8, device=W.device)
+    check(lib().sn_pack_split_f32(ptr(W), d_out, d_in, W.stride(0), ptr(vecs[0]), ptr(vecs[1]), ptr(vecs[2]), ptr(out),
+                                  stream()), "sn_pack_split_f32")
+    return out
+
+
 @dataclass
 class PackedLinear:
     wp: torch.Tensor

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_python_binding_covers_the_header(lib):
     from signnet_basisnet_amd import _lib
-    bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_phi_bins_bound",
+    bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_split_packed_bytes", "sn_phi_bins_bound",
                                      "sn_ign_contract_scratch_floats"}
     assert set(declared_symbols()) == bound
 
@@ -48,6 +48,8 @@ def test_version_and_error_string(lib):
     assert rc == -1 and b"sn_pack_weight_f32" in lib.sn_last_error()
     assert lib.sn_packed_weight_floats(128, 128) == 64 * 256
     assert lib.sn_packed_weight_floats(108, 6) == 7 * 1 * 256
+    assert lib.sn_split_packed_bytes(128, 128) == 8 * (3 * 4 + 3) * 1024
+    assert lib.sn_split_packed_bytes(108, 40) == 7 * (3 * 2 + 3) * 1024
     assert lib.sn_phi_bins_bound(128, 16) == 128 * 16 + 1 and lib.sn_phi_bins_bound(10, 0) == 641
 
 
