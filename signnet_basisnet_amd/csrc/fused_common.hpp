@@ -4,6 +4,18 @@
 
 namespace sn {
 
+// Phase timeline for kernel tuning (scratch builds with -DSN_PROFILE only; never in the shipped library).
+#ifdef SN_PROFILE
+static __device__ long long g_prof[64];
+#define SN_STAMP(i) do { if (sn_prof_on && blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] = clock64(); } while (0)
+#define SN_ACCUM(i, t0) do { if (sn_prof_on && blockIdx.x == 0 && threadIdx.x == 0) g_prof[i] += clock64() - (t0); } while (0)
+#define SN_PROF_ON(cond) const bool sn_prof_on = (cond)
+#else
+#define SN_STAMP(i) do { } while (0)
+#define SN_ACCUM(i, t0) do { } while (0)
+#define SN_PROF_ON(cond) do { } while (0)
+#endif
+
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p) {
   float4 t = *reinterpret_cast<const float4*>(p);
   return f32x4{t.x, t.y, t.z, t.w};
@@ -210,14 +222,15 @@ struct WRing {
 
 struct WFrag { u32x4 h, m, l; };
 
-// acc(ot) = W[16 outputs of tile ot] . x  for ot < NTO, consumed by epi(ot, acc, e0, e1, e2) (e*: the chunk's
-// epilogue vectors in the accumulator layout).  EVERY wave of the workgroup must call it (barriers, DMA shares);
+// acc(ot) = W[16 outputs of tile ot] . x  for ot < NTO, consumed by epi(ot, acc, e0, e1, e2, pv) (e*: the chunk's
+// epilogue vectors in the accumulator layout; pv = pre(ot), an f32x4 the caller wants fetched BEFORE the tile's
+// MFMAs, e.g. the residual from LDS).  EVERY wave of the workgroup must call it (barriers, DMA shares);
 // `live` = this wave has rows (a dead wave only keeps the stream going).  `wnext` (never null): the matrix whose
 // first chunks are staged behind this one's — the next wg_gemm_split() of the workgroup must be on `wnext`; the
 // kernel starts the stream with WRing::prologue(first matrix) and ends with WRing::drain().  SWAP: operands exchanged -> acc[r] = Y[row = 4g + r][out = 16*ot + (l&15)].
-template <int NT, int NTO, bool SWAP, typename Epi>
+template <int NT, int NTO, bool SWAP, typename Pre, typename Epi>
 __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, const void* wnext, bool live,
-                                              const Split8 (&xs)[(NT + 1) / 2], Epi epi) {
+                                              const Split8 (&xs)[(NT + 1) / 2], Pre pre, Epi epi) {
   using R = WRing<NT>;
   constexpr int NKB = R::NKB;
   constexpr bool CHAIN = NTO >= SPLIT_RING;     // the stream runs on into the next matrix; else: one prologue per GEMM
@@ -263,6 +276,10 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, co
 #pragma unroll
     for (int ot = 0; ot < NTO; ++ot) {
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      // epilogue operands first: their LDS latency hides behind this tile's MFMAs
+      const lds_char_t* pe = lbase + slot(ot) * R::CHUNK + R::NF * 1024;
+      const f32x4 e0 = *(lds_f32x4*)(pe), e1 = *(lds_f32x4*)(pe + 1024), e2 = *(lds_f32x4*)(pe + 2048);
+      const f32x4 pv = pre(ot);
 #pragma unroll
       for (int kb = 0; kb + 1 < NKB; ++kb) {
         fb = rd(ot, kb + 1);
@@ -271,8 +288,6 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, co
         __builtin_amdgcn_sched_barrier(0);
         fa = fb;
       }
-      const lds_char_t* pe = lbase + slot(ot) * R::CHUNK + R::NF * 1024;
-      const f32x4 e0 = *(lds_f32x4*)(pe), e1 = *(lds_f32x4*)(pe + 1024), e2 = *(lds_f32x4*)(pe + 2048);
       if (CHAIN) {
         // all my reads of chunk ot are complete and my share of chunk ot+1 has landed -> barrier -> refill the slot
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -285,7 +300,7 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, co
       __builtin_amdgcn_sched_barrier(0);
       mm(fa, xs[NKB - 1], a0, a1);
       __builtin_amdgcn_sched_barrier(0);
-      epi(ot, a0 + a1, e0, e1, e2);
+      epi(ot, a0 + a1, e0, e1, e2, pv);
       fa = fb;
     }
   } else if (CHAIN) {
@@ -306,5 +321,8 @@ __device__ __forceinline__ float row_allsum(float v) {
   v += __shfl_xor(v, 32, 64);
   return v;
 }
+
+// wg_gemm_split without a prefetch hook
+struct NoPre { __device__ __forceinline__ f32x4 operator()(int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; } };
 
 }  // namespace sn

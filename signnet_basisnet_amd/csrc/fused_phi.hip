@@ -142,8 +142,8 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
           split_rows<NT>(o, sp);
         }
         const void* nxt = P.n_layers > 1 ? P.layers[0].w1s : wfirst;
-        wg_gemm_split<NT, NT, false>(ring, P.l0_w2, nxt, wave_live, sp,
-                                     [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1) { in[ot] = relu4((acc + b2) * s1 + h1); });
+        wg_gemm_split<NT, NT, false>(ring, P.l0_w2, nxt, wave_live, sp, NoPre(),
+                                     [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4) { in[ot] = relu4((acc + b2) * s1 + h1); });
       }
       if (!valid) {
 #pragma unroll
@@ -181,14 +181,14 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
           split_rows<NT>(o, sp);
         }
         // MaskedMLP: Linear . BN . ReLU . Linear [+b]
-        wg_gemm_split<NT, NT, false>(ring, Lp.w1s, Lp.w2s, wave_live, sp,
-                                     [&](int ot, f32x4 acc, f32x4 s0, f32x4 h0, f32x4) { o[ot] = relu4(acc * s0 + h0); });
+        wg_gemm_split<NT, NT, false>(ring, Lp.w1s, Lp.w2s, wave_live, sp, NoPre(),
+                                     [&](int ot, f32x4 acc, f32x4 s0, f32x4 h0, f32x4, f32x4) { o[ot] = relu4(acc * s0 + h0); });
         if (wave_live) split_rows<NT>(o, sp);
         const void* nxt = (l + 1 < P.n_layers) ? P.layers[l].w1s : wfirst;   // next sign / next bin restart the stream here
         // GNN3d: mask . BN . ReLU . + previous_x
-        wg_gemm_split<NT, NT, false>(ring, Lp.w2s, nxt, wave_live, sp, [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1) {
-          in[ot] = relu4((acc + b2) * s1 + h1) + lds_ld4(XR + 16 * ot + 4 * g);
-        });
+        wg_gemm_split<NT, NT, false>(
+            ring, Lp.w2s, nxt, wave_live, sp, [&](int ot) { return lds_ld4(XR + 16 * ot + 4 * g); },
+            [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4 prev) { in[ot] = relu4((acc + b2) * s1 + h1) + prev; });
         if (!valid) {
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -93,6 +93,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
   if (S.meta[5] != 0) return;
   const int d = P.d, H = P.heads, dk = d / H;
   const float temp = sqrtf((float)dk);
+  { SN_PROF_ON(true); SN_STAMP(13); }
   Ring ring;
   ring.init(lds_raw, wave, lane);
   const void* wfirst = P.n_layers > 0 ? P.layers[0].wq : nullptr;
@@ -100,6 +101,8 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
     // ---------------------------------------------------------------- bin -> graph (bins never mix graphs)
+    SN_PROF_ON(bin == (int)blockIdx.x);
+    SN_STAMP(0);
     __syncthreads();
     for (int gq = threadIdx.x; gq < S.B; gq += RHO_R * 4)
       if (S.rho_bin0[gq] <= bin && bin < S.rho_bin0[gq + 1]) s_graph = gq;
@@ -120,23 +123,32 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     const bool wave_live = __ballot(valid) != 0ull;
     float* Ar = A + r * LD;
     float* Br = Bm + r * LD;
+    SN_STAMP(1);
     // ---------------------------------------------------------------- load x (+ eigenvalue encoding)
+    // branch-free (clamped addresses + selects): per-element branches here would turn x[] into a web of phi copies
     f32x4 x[NT];
+    {
+      const float* xr = S.x + (valid ? ((int64_t)node * S.K + slot) : (int64_t)0) * d;
+      if ((d & 3) == 0) {
 #pragma unroll
-    for (int kk = 0; kk < NT; ++kk) x[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      const float* xr = S.x + ((int64_t)node * S.K + slot) * d;
+        for (int kk = 0; kk < NT; ++kk) {
+          const int c = 16 * kk + 4 * g;
+          const f32x4 v = ld4(xr + (c < d ? c : d - 4));
+          x[kk] = (valid && c < d) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else {
 #pragma unroll
-      for (int kk = 0; kk < NT; ++kk) {
-        const int c = 16 * kk + 4 * g;
-        if ((d & 3) == 0) {
-          if (c < d) x[kk] = ld4(xr + c);
-        } else {
+        for (int kk = 0; kk < NT; ++kk) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (c + t < d) x[kk][t] = xr[c + t];
+          for (int t = 0; t < 4; ++t) {
+            const int c = 16 * kk + 4 * g + t;
+            const float v = xr[c < d ? c : d - 1];
+            x[kk][t] = (valid && c < d) ? v : 0.f;
+          }
         }
       }
+    }
+    if (valid) {
       if (P.has_pos) {
         // eigen_encoder = MaskedMLP(1 -> 1 -> d): Linear . BN . ReLU . Linear . BN . ReLU   (sign_net.py:86,108)
         const float ev = S.eigvals[gs + slot];
@@ -149,6 +161,11 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         }
       }
     }
+    SN_STAMP(12);
+#ifdef SN_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SN_STAMP(2);
     // ---------------------------------------------------------------- encoder layers
 #pragma unroll 1
     for (int l = 0; l < P.n_layers; ++l) {
@@ -165,8 +182,8 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         f32x4 qf[NT], sc[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) sc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { qf[ot] = acc / temp; });   // q / sqrt(dk)  (:52)
-        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, [&](int ot, f32x4 kf, f32x4, f32x4, f32x4) {
+        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc / temp; });   // q / sqrt(dk)  (:52)
+        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 kf, f32x4, f32x4, f32x4, f32x4) {
           // lane (query = li, g) accumulates S[query][key = 4g + r] of head ot / CPH
           const int h = ot / CPH < 4 ? ot / CPH : 3;
           sc[h] = mfma16(kf[0], qf[ot][0], sc[h]);
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
           sc[h] = mfma16(kf[2], qf[ot][2], sc[h]);
           sc[h] = mfma16(kf[3], qf[ot][3], sc[h]);
         });
+        SN_STAMP(3);
         if (wave_live) {
 #pragma unroll
           for (int h = 0; h < 4; ++h) {
@@ -190,7 +208,8 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
             for (int t = 0; t < 4; ++t) sc[h][t] *= zi;     // P[query][key = 4g + t]
           }
         }
-        wg_gemm_split<NT, NT, true>(ring, Lp.wv, Lp.wfc, wave_live, sp, [&](int ot, f32x4 vt, f32x4, f32x4, f32x4) {
+        SN_STAMP(4);
+        wg_gemm_split<NT, NT, true>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 vt, f32x4, f32x4, f32x4, f32x4) {
           // O^T[c][query] = sum_key V[key][c] P[query][key]  -> lane (query, g) holds O[query][16*ot + 4g + r]
           const int h = ot / CPH < 4 ? ot / CPH : 3;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -202,15 +221,15 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         });
       } else {
         // ======== attention through LDS (nodes of more than 16 slots span several waves' tiles) ========
-        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
-        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
         lds_barrier();
         float qh[DKMAX];
         const int hc = g * dk;
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
         // (q rows are written and read by the same wave only: no barrier before A is reused for v)
-        wg_gemm_split<NT, NT, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
         lds_barrier();
         float m = -INFINITY;
         float oh[DKMAX];
@@ -274,18 +293,24 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) o[kk] = lds_ld4(Br + 16 * kk + 4 * g);
       }
+      SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
-      wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, [&](int ot, f32x4 acc, f32x4, f32x4, f32x4) { y[ot] = acc + x[ot]; });
+      wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { y[ot] = acc + x[ot]; });
+      SN_STAMP(6);
       if (wave_live) {
         masked_layernorm<NT>(y, Lp.ln1_g, Lp.ln1_b, P.ln_eps, d, g, valid);
         split_rows<NT>(y, sp);
       }
+      SN_STAMP(7);
       // FFN: w2(relu(w1 y + b1)) + b2 + y -> LayerNorm               (transformer_module.py:113-127)
-      wg_gemm_split<NT, NT, false>(ring, Lp.w1, Lp.w2, wave_live, sp, [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
+      wg_gemm_split<NT, NT, false>(ring, Lp.w1, Lp.w2, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
+      SN_STAMP(8);
       if (wave_live) split_rows<NT>(o, sp);
-      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4) { x[ot] = acc + b2 + y[ot]; });
+      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + y[ot]; });
+      SN_STAMP(9);
       if (wave_live) masked_layernorm<NT>(x, Lp.ln2_g, Lp.ln2_b, P.ln_eps, d, g, valid);
+      SN_STAMP(10);
     }
     // ---------------------------------------------------------------- sum over the node's slots -> out_sum[node, :]
     if (mfma_attn) {
@@ -330,6 +355,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       }
     }
   }
+  { SN_PROF_ON(true); SN_STAMP(11); }
   ring.drain();
 }
 
@@ -370,6 +396,10 @@ static int dispatch_rho(int nt, const RhoStruct& S, const sn_rho_params& P, int6
 }  // namespace sn
 
 using namespace sn;
+
+#ifdef SN_PROFILE
+extern "C" int sn_prof_read_rho(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(long long) * 64); }
+#endif
 
 extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* eigen_values,
                                 const int32_t* graph_ptr, int64_t B, int64_t N, const sn_plan_bins* bins, int kmax,
