@@ -60,6 +60,10 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
   const int r = wave * 16 + (lane & 15), g = lane >> 4;
   const int nbins = S.meta[0];
   if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
+  { SN_PROF_ON(true); SN_STAMP(12); }
+#ifdef SN_PROFILE
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 3; i <= 20; ++i) g_prof[i] = 0;
+#endif
   Ring ring;
   ring.init(lds_raw, wave, lane);
   // first [d,d] Linear of a (bin, sign) pass — where the weight stream (re)starts
@@ -67,27 +71,38 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
   if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
+    SN_PROF_ON(bin == (int)blockIdx.x);
+    SN_STAMP(0);
+#ifdef SN_PROFILE
+    long long pt = 0;
+#endif
     // ---------------------------------------------------------------- my row: bin -> column -> member graph
     const int colid = S.bin_col[bin];
     const int slot = bin - S.col_bin0[colid];       // every member contributes its slab of eigenvector `slot`
-    int node = -1, gs = 0, row0 = 0, e_lo = 0, e_hi = 0;
-    float xval = 0.f;
-#pragma unroll 1
+    // (all eight member slots are decoded at once — wave-uniform scalar loads with no serial dependence between
+    //  members; an empty slot (-1) reads graph 0 and is masked out)
+    int node = -1, gs = 0, row0 = 0, gsel = 0, nsel = 0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int gi = S.col_mem[colid * 8 + k];
-      if (gi < 0) break;
+      const int gi_raw = S.col_mem[colid * 8 + k];
+      const int gi = gi_raw < 0 ? 0 : gi_raw;
       const int off = S.col_off[colid * 8 + k];
       const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
       const int kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
-      if (r >= off && r < off + n && slot < kg) {
-        const int li = r - off;
-        node = g0 + li;
+      if (gi_raw >= 0 && r >= off && r < off + n && slot < kg) {
+        node = g0 + (r - off);
         gs = g0;
         row0 = off;
-        e_lo = S.rowptr[node];
-        e_hi = S.rowptr[node + 1];
-        xval = S.ev[S.evoff[gi] + (int64_t)li * n + slot];
+        gsel = gi;
+        nsel = n;
       }
+    }
+    int e_lo = 0, e_hi = 0;
+    float xval = 0.f;
+    if (node >= 0) {
+      e_lo = S.rowptr[node];
+      e_hi = S.rowptr[node + 1];
+      xval = S.ev[S.evoff[gsel] + (int64_t)(node - gs) * nsel + slot];
     }
     const bool valid = node >= 0;
     const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all MFMAs (keeps barriers + DMA)
@@ -98,22 +113,34 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
       for (int e = 0; e < deg && e < PHI_NBR; ++e) nbr[r * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
     }
     float* XR = X + r * LD;                 // my row
+    SN_STAMP(1);
     // ---------------------------------------------------------------- layer 0 aggregate (scalar input, sign-free)
     __syncthreads();
+    const uint2 nb8 = *reinterpret_cast<const uint2*>(nbr + r * PHI_NBR);   // my first 8 in-neighbours (bin rows), read once
     float a0 = 0.f;
-    for (int e = 0; e < deg; ++e) a0 += xs[e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs];
+    for (int e = 0; e < deg; ++e) a0 += xs[e < PHI_NBR ? (int)(((e < 4 ? nb8.x : nb8.y) >> (8 * (e & 3))) & 255u) : row0 + S.col[e_lo + e] - gs];
     {
 #pragma clang fp contract(off)
       const float sc = 1.f + *P.l0_eps;
       const float self = xval * sc;
       a0 = a0 + self;
     }
-    f32x4 res[NT];
+    SN_STAMP(2);
 #pragma unroll 1
     for (int sg = 0; sg < 2; ++sg) {
+#ifdef SN_PROFILE
+      long long ptop = clock64();
+#endif
+      // (compiler fence: without it the layer-0 vectors — loop invariant — are hoisted out of the bin loop into
+      //  ~128 VGPRs that then live in scratch for the whole kernel)
+      asm volatile("" ::: "memory");
       const float as = sg ? -a0 : a0;          // phi(-x): the aggregate of -x is exactly -(aggregate of x)
       f32x4 in[NT], o[NT];
       Split8 sp[NKB];
+      SN_ACCUM(15, ptop);
+#ifdef SN_PROFILE
+      pt = clock64();
+#endif
       // -------------------------------------------------------------- layer 0
       if (P.hid0 == 1) {
         // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
@@ -149,22 +176,44 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      SN_ACCUM(3, pt);
       // -------------------------------------------------------------- layers 1 .. L-1
 #pragma unroll 1
       for (int l = 1; l < P.n_layers; ++l) {
         const sn_phi_layer& Lp = P.layers[l - 1];
+#ifdef SN_PROFILE
+        pt = clock64();
+#endif
         // publish x_l for the neighbour sums and the residual
         if (wave_live) {
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
         }
         lds_barrier();
+        SN_ACCUM(4, pt);
+#ifdef SN_PROFILE
+        pt = clock64();
+#endif
         if (wave_live) {
-          // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self
+          // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self.  The first four neighbours
+          // (molecular graphs: all of them) are gathered with predicated, fully unrolled reads so that the LDS
+          // latency of one neighbour hides behind the next; a missing neighbour adds +0.
+          const float* n0 = X + (deg > 0 ? (int)(nb8.x & 255u) : r) * LD + 4 * g;
+          const float* n1 = X + (deg > 1 ? (int)((nb8.x >> 8) & 255u) : r) * LD + 4 * g;
+          const float* n2 = X + (deg > 2 ? (int)((nb8.x >> 16) & 255u) : r) * LD + 4 * g;
+          const float* n3 = X + (deg > 3 ? (int)(nb8.x >> 24) : r) * LD + 4 * g;
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int kk = 0; kk < NT; ++kk) o[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
-          for (int e = 0; e < deg; ++e) {
-            const int nb = e < PHI_NBR ? (int)nbr[r * PHI_NBR + e] : row0 + S.col[e_lo + e] - gs;
+          for (int kk = 0; kk < NT; ++kk) {
+            const f32x4 v0 = lds_ld4(n0 + 16 * kk), v1 = lds_ld4(n1 + 16 * kk), v2 = lds_ld4(n2 + 16 * kk), v3 = lds_ld4(n3 + 16 * kk);
+            f32x4 a = deg > 0 ? v0 : zero4;
+            a += deg > 1 ? v1 : zero4;
+            a += deg > 2 ? v2 : zero4;
+            a += deg > 3 ? v3 : zero4;
+            o[kk] = a;
+          }
+          for (int e = 4; e < deg; ++e) {
+            const int nb = e < PHI_NBR ? (int)((nb8.y >> (8 * (e - 4))) & 255u) : row0 + S.col[e_lo + e] - gs;
             const float* np = X + nb * LD + 4 * g;
 #pragma unroll
             for (int kk = 0; kk < NT; ++kk) o[kk] += lds_ld4(np + 16 * kk);
@@ -178,12 +227,30 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
               o[kk] = o[kk] + sf;
             }
           }
+          SN_ACCUM(5, pt);
+#ifdef SN_PROFILE
+          pt = clock64();
+#endif
           split_rows<NT>(o, sp);
+          asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+          SN_ACCUM(6, pt);
         }
+#ifdef SN_PROFILE
+        pt = clock64();
+#endif
         // MaskedMLP: Linear . BN . ReLU . Linear [+b]
         wg_gemm_split<NT, NT, false>(ring, Lp.w1s, Lp.w2s, wave_live, sp, NoPre(),
                                      [&](int ot, f32x4 acc, f32x4 s0, f32x4 h0, f32x4, f32x4) { o[ot] = relu4(acc * s0 + h0); });
+        SN_ACCUM(7, pt);
+#ifdef SN_PROFILE
+        pt = clock64();
+#endif
         if (wave_live) split_rows<NT>(o, sp);
+        asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+        SN_ACCUM(8, pt);
+#ifdef SN_PROFILE
+        pt = clock64();
+#endif
         const void* nxt = (l + 1 < P.n_layers) ? P.layers[l].w1s : wfirst;   // next sign / next bin restart the stream here
         // GNN3d: mask . BN . ReLU . + previous_x
         wg_gemm_split<NT, NT, false>(
@@ -193,29 +260,43 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        SN_ACCUM(9, pt);
+#ifdef SN_PROFILE
+        pt = clock64();
+#endif
         lds_barrier();  // everyone is done reading X before it is overwritten
+        SN_ACCUM(10, pt);
       }
-      if (sg == 0) {
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) res[kk] = in[kk];
-      } else if (valid) {
-        // ------------------------------------------------------------ phi(x) + phi(-x) -> out[node*K + slot, :]
+#ifdef SN_PROFILE
+      pt = clock64();
+#endif
+      // -------------------------------------------------------------- phi(x) [+ phi(-x)] -> out[node*K + slot, :]
+      // The sign + pass parks its result in `out`; the sign - pass reads it back (all loads first, then the adds and
+      // stores) and overwrites it with the sum — same lane, same addresses, so program order is all that is needed.
+      if (valid) {
         float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
+        // (d % 4 == 0 is an entry-point requirement: whole float4 per lane; only the last 16-channel tile can be partial)
+        f32x4 prev[NT];
+        if (sg) {
+#pragma unroll
+          for (int kk = 0; kk < NT; ++kk) {
+            const int c = 16 * kk + 4 * g;
+            prev[kk] = (kk + 1 < NT || c < P.d) ? ld4(orow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int kk = 0; kk < NT; ++kk) in[kk] = prev[kk] + in[kk];
+        }
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) {
           const int c = 16 * kk + 4 * g;
-          const f32x4 v = res[kk] + in[kk];
-          if ((P.d & 3) == 0) {
-            if (c < P.d) *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (c + t < P.d) orow[c + t] = v[t];
-          }
+          if (kk + 1 < NT || c < P.d) *reinterpret_cast<float4*>(orow + c) = make_float4(in[kk][0], in[kk][1], in[kk][2], in[kk][3]);
         }
       }
+      SN_ACCUM(14, pt);
     }
+    SN_STAMP(11);
   }
+  { SN_PROF_ON(true); SN_STAMP(13); }
   ring.drain();
 }
 
@@ -243,6 +324,10 @@ static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st
 
 using namespace sn;
 
+#ifdef SN_PROFILE
+extern "C" int sn_prof_read_phi(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(long long) * 64); }
+#endif
+
 extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_vectors, const int32_t* graph_ptr,
                                 const int64_t* evoff, const int32_t* rowptr, const int32_t* col,
                                 const sn_plan_bins* bins, int kmax, int K, float* out, void* stream) {
@@ -250,7 +335,7 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
   SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->meta,
              "sn_phi_fused_f32: incomplete sn_plan_bins");
   const sn_phi_params& P = *params;
-  SN_REQUIRE(P.d > 0 && P.d <= 128, "sn_phi_fused_f32: hidden width %d not in (0, 128]", P.d);
+  SN_REQUIRE(P.d > 0 && P.d <= 128 && (P.d & 3) == 0, "sn_phi_fused_f32: hidden width %d must be a multiple of 4 in (0, 128]", P.d);
   SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS, "sn_phi_fused_f32: %d layers unsupported", P.n_layers);
   SN_REQUIRE(P.hid0 == 1 || P.hid0 == P.d, "sn_phi_fused_f32: first hidden width must be 1 or d");
   SN_REQUIRE(P.l0_w1 && P.l0_bn0_scale && P.l0_bn0_shift && P.l0_w2 && P.l0_eps, "sn_phi_fused_f32: layer-0 parameters missing");

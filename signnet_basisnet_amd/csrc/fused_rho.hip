@@ -129,23 +129,12 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     f32x4 x[NT];
     {
       const float* xr = S.x + (valid ? ((int64_t)node * S.K + slot) : (int64_t)0) * d;
-      if ((d & 3) == 0) {
 #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-          const int c = 16 * kk + 4 * g;
-          const f32x4 v = ld4(xr + (c < d ? c : d - 4));
-          x[kk] = (valid && c < d) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int c = 16 * kk + 4 * g + t;
-            const float v = xr[c < d ? c : d - 1];
-            x[kk][t] = (valid && c < d) ? v : 0.f;
-          }
-        }
+      for (int kk = 0; kk < NT; ++kk) {      // d % 4 == 0 (entry-point requirement); only the last tile can be partial
+        const int c = 16 * kk + 4 * g;
+        const bool inb = kk + 1 < NT || c < d;
+        const f32x4 v = ld4(xr + (inb ? c : 0));
+        x[kk] = (valid && inb) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
     if (valid) {
@@ -322,15 +311,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 #pragma unroll
           for (int t = 0; t < 4; ++t) s[t] = tile_rowsum(valid ? x[kk][t] : 0.f);
           const int c = 16 * kk + 4 * g;
-          if (li == 0 && unit_ok) {
-            if ((d & 3) == 0) {
-              if (c < d) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
-            } else {
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                if (c + t < d) orow[c + t] = s[t];
-            }
-          }
+          if (li == 0 && unit_ok && (kk + 1 < NT || c < d)) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
         }
       }
     } else {
@@ -344,13 +325,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
           const int c = 16 * kk + 4 * g;
           f32x4 s = {0.f, 0.f, 0.f, 0.f};
           for (int j = 0; j < kv; ++j) s += lds_ld4(Bm + (u0 + j) * LD + c);
-          if ((d & 3) == 0) {
-            if (c < d) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
-          } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (c + t < d) orow[c + t] = s[t];
-          }
+          if (kk + 1 < NT || c < d) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
         }
       }
     }
@@ -406,7 +381,7 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
                                 int K, float* out_sum, void* stream) {
   SN_REQUIRE(params && x && graph_ptr && bins && bins->rho_bin0 && bins->meta && out_sum, "sn_rho_fused_f32: null pointer");
   const sn_rho_params& P = *params;
-  SN_REQUIRE(P.d > 0 && P.d <= 128, "sn_rho_fused_f32: hidden width %d not in (0, 128]", P.d);
+  SN_REQUIRE(P.d > 0 && P.d <= 128 && (P.d & 3) == 0, "sn_rho_fused_f32: hidden width %d must be a multiple of 4 in (0, 128]", P.d);
   SN_REQUIRE(P.heads == 4 && P.d % P.heads == 0, "sn_rho_fused_f32: needs 4 heads dividing d (got %d heads, d=%d)", P.heads, P.d);
   SN_REQUIRE(P.n_layers >= 0 && P.n_layers <= SN_RHO_MAX_LAYERS, "sn_rho_fused_f32: %d layers unsupported", P.n_layers);
   SN_REQUIRE(!P.has_pos || (eigen_values && P.pe_w1 && P.pe_bn0_scale && P.pe_bn0_shift && P.pe_w2 && P.pe_bn1_scale && P.pe_bn1_shift),

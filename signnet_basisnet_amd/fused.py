@@ -30,8 +30,8 @@ class PhiPlan:
         convs, norms = phi_module.convs, phi_module.norms
         L = len(convs)
         d = convs[0].nn.layers[1].weight.shape[0]
-        if not (0 < d <= 128 and 1 <= L <= PHI_MAX_LAYERS):
-            raise ValueError("fused phi supports hidden width <= 128 and <= 16 layers")
+        if not (0 < d <= 128 and d % 4 == 0 and 1 <= L <= PHI_MAX_LAYERS):
+            raise ValueError("fused phi supports hidden width <= 128 (a multiple of 4) and <= 16 layers")
         dp = 16 * ((d + 15) // 16)
         self.d, self.L, self.dp = d, L, dp
         keep = self._keep = []

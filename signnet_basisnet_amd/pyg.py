@@ -303,10 +303,10 @@ class SignNetGNN(nn.Module):
         P = {}
         sn, g = self.sign_net, self.gnn
         d = self.cfg["n_hid"]
-        P["phi_fused"] = fused.PhiPlan(sn.phi) if (self.use_fused and d <= 128 and len(sn.phi.convs) <= 16) else None
+        P["phi_fused"] = fused.PhiPlan(sn.phi) if (self.use_fused and d <= 128 and d % 4 == 0 and len(sn.phi.convs) <= 16) else None
         ee = sn.eigen_encoder if (self.variant == "alchemy" and not sn.ignore_eigval) else None
         P["rho_fused"] = (fused.RhoPlan(sn.rho, ee, N_HEAD, LN_EPS)
-                          if (self.use_fused and d <= 128 and len(sn.rho.transformer_layers) <= fused.RHO_MAX_LAYERS) else None)
+                          if (self.use_fused and d <= 128 and d % 4 == 0 and len(sn.rho.transformer_layers) <= fused.RHO_MAX_LAYERS) else None)
         P["gnn_fused"] = None
         if self.use_fused and d <= 128 and len(g.convs) <= fused.GNN_MAX_LAYERS and self.cfg["n_out"] <= 16 \
                 and (self.cfg["node_feat"] or 0) <= 16 and (self.cfg["edge_feat"] or 0) <= 16:
