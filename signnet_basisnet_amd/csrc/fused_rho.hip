@@ -36,8 +36,8 @@ struct RhoStruct {
 };
 
 template <int NT>
-__device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, float eps, int d, int g, bool valid) {
+__device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* gamma /* LDS */, const float* beta /* LDS */,
+                                                 float eps, int d, int g, bool valid) {
   float s = 0.f;
 #pragma unroll
   for (int kk = 0; kk < NT; ++kk) s += (v[kk][0] + v[kk][1]) + (v[kk][2] + v[kk][3]);   // padded channels hold 0
@@ -55,7 +55,7 @@ __device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* __
 #pragma unroll
   for (int kk = 0; kk < NT; ++kk) {
     const int c = 16 * kk + 4 * g;
-    const f32x4 ga = ld4(gamma + c), be = ld4(beta + c);   // zero padded -> padded channels stay 0
+    const f32x4 ga = lds_ld4(gamma + c), be = lds_ld4(beta + c);   // zero padded -> padded channels stay 0
     f32x4 o;
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = valid ? (v[kk][t] - mean) * rstd * ga[t] + be[t] : 0.f;
@@ -67,11 +67,23 @@ __device__ __forceinline__ float group_allmax(float v) {   // over the 4 lane gr
   v = fmaxf(v, __shfl_xor(v, 16, 64));
   return fmaxf(v, __shfl_xor(v, 32, 64));
 }
-__device__ __forceinline__ float tile_rowsum(float v) {    // over the 16 rows (lanes l&15) of a tile, same lane group
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v + __shfl_xor(v, 8, 64);
+// sum over the 16 rows (lanes l&15) of a tile, same lane group = one DPP row: four VALU+DPP steps, no LDS crossbar
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+  const int x = __float_as_int(v);
+  int y;
+  switch (ctrl_sel) {
+    case 0: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); break;    // quad_perm [1,0,3,2]
+    case 1: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true); break;    // quad_perm [2,3,0,1]
+    case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true); break;   // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true); break;  // row_mirror
+  }
+  return v + __int_as_float(y);
+}
+__device__ __forceinline__ float tile_rowsum(float v) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  return dpp_add(v, 3);
 }
 
 // REGATTN: every node has <= 16 valid slots (0 < kmax <= 16) and the head width is a multiple of 16 -> attention in
@@ -94,6 +106,16 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
   const int d = P.d, H = P.heads, dk = d / H;
   const float temp = sqrtf((float)dk);
   { SN_PROF_ON(true); SN_STAMP(13); }
+  // LayerNorm gamma / beta of every layer, staged once: read between GEMMs they would otherwise wait (vmcnt 0) behind
+  // the weight stream's in-flight LDS-DMA plus their own L2 latency, twice per layer
+  float* lnv = reinterpret_cast<float*>(lds_raw + Ring::BYTES) + (REGATTN ? 0 : 2 * RHO_R * LD);   // [n_layers][4][D]
+  for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
+    const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
+    const sn_rho_layer& Lq = P.layers[l];
+    const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
+    lnv[i] = src[c];
+  }
+  __syncthreads();
   Ring ring;
   ring.init(lds_raw, wave, lane);
   const void* wfirst = P.n_layers > 0 ? P.layers[0].wq : nullptr;
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { y[ot] = acc + x[ot]; });
       SN_STAMP(6);
       if (wave_live) {
-        masked_layernorm<NT>(y, Lp.ln1_g, Lp.ln1_b, P.ln_eps, d, g, valid);
+        masked_layernorm<NT>(y, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
         split_rows<NT>(y, sp);
       }
       SN_STAMP(7);
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       if (wave_live) split_rows<NT>(o, sp);
       wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + y[ot]; });
       SN_STAMP(9);
-      if (wave_live) masked_layernorm<NT>(x, Lp.ln2_g, Lp.ln2_b, P.ln_eps, d, g, valid);
+      if (wave_live) masked_layernorm<NT>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, g, valid);
       SN_STAMP(10);
     }
     // ---------------------------------------------------------------- sum over the node's slots -> out_sum[node, :]
@@ -337,7 +359,8 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 template <int NT, bool REGATTN>
 static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)WRing<NT>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float));
+  const size_t lds = (size_t)WRing<NT>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float)) +
+                     (size_t)SN_RHO_MAX_LAYERS * 4 * 16 * NT * sizeof(float);
   static int cus = 0;
   if (cus == 0) {
     if (lds > 64 * 1024 &&

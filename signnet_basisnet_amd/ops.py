@@ -442,12 +442,25 @@ MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak (
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec
 
 
-def _mfma_roof(label, flops, mean_ms, per_step):
+# fp32 GEMMs evaluated as six bf16 partial products (csrc/fused_common.hpp): the bound is the dense bf16 MFMA peak
+# (MI355X_MICROARCH.md: ~2.5 PFLOP/s) divided by the 6 MFMAs each fp32 multiply-add costs.
+MFMA_BF16_PEAK_TF = 2500.0
+MFMA_SPLIT_F32_PEAK_TF = MFMA_BF16_PEAK_TF / 6.0
+
+
+def _mfma_roof(label, flops, mean_ms, per_step, peak=None, peak_note=None):
+    peak = MFMA_F32_PEAK_TF if peak is None else peak
     t = mean_ms * per_step * 1e-3
     ach = flops / t / 1e12
-    return {"kernel": label, "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-            "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "flops_per_launch": flops / per_step,
-            "mean_launch_us": mean_ms * 1e3}
+    out = {"kernel": label, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+           "frac": ach / peak, "traffic": None, "flops_per_launch": flops / per_step, "mean_launch_us": mean_ms * 1e3}
+    if peak_note:
+        out["peak_note"] = peak_note
+    return out
+
+
+_SPLIT_NOTE = ("fp32-equivalent flops; each fp32 product = 6 v_mfma_f32_16x16x32_bf16 partial products (exact 3 x bf16 "
+               "operand split, fp32 accumulate): peak = 2500 TFLOP/s dense bf16 / 6; the fp32-input MFMA peak is 157.3")
 
 
 def _roof_linear(fl, wl, host, mean_ms, per_step):
@@ -459,11 +472,12 @@ def _roof_linear(fl, wl, host, mean_ms, per_step):
 def _roof_phi(fl, wl, host, mean_ms, per_step):
     """Fused phi: algorithmic flops = 2 signs x (L-1) layers x 2 Linear x 2*d*d per VALID (node, slot) row
     (SURVEY.md §8(d)); padding rows of the work bins are not counted."""
-    return _mfma_roof("sn_phi_fused_f32 (k_phi_fused)", fl["phi"], mean_ms, per_step)
+    return _mfma_roof("sn_phi_fused_f32 (k_phi_fused)", fl["phi"], mean_ms, per_step, MFMA_SPLIT_F32_PEAK_TF, _SPLIT_NOTE)
 
 
 def _roof_rho(fl, wl, host, mean_ms, per_step):
-    return _mfma_roof("sn_rho_fused_f32 (k_rho_fused)", fl["rho"] - 2 * fl["N"] * wl["hidden"] ** 2, mean_ms, per_step)
+    return _mfma_roof("sn_rho_fused_f32 (k_rho_fused)", fl["rho"] - 2 * fl["N"] * wl["hidden"] ** 2, mean_ms, per_step,
+                      MFMA_SPLIT_F32_PEAK_TF, _SPLIT_NOTE)
 
 
 def _roof_gnn(fl, wl, host, mean_ms, per_step):
