@@ -232,3 +232,51 @@ def test_cpu_tensors_are_rejected():
     from signnet_basisnet_amd import ops
     with pytest.raises(RuntimeError):
         ops.pack_weight(torch.randn(4, 4))
+
+
+# ---------------------------------------------------------------------------------------------- split-packed linears
+def _unpack_split(buf, d_out, d_in):
+    """Host-side inverse of sn_pack_split_f32: (W_h, W_m, W_l) as float32 [d_out_pad, d_in_pad32] and the three
+    epilogue vectors, from the documented layout (include/signnet_hip.h, csrc/fused_common.hpp)."""
+    import numpy as np
+    nto, nkb = (d_out + 15) // 16, (d_in + 31) // 32
+    nfe = 3 * nkb + 3
+    raw = buf.cpu().numpy().reshape(nto, nfe, 1024)
+    planes = np.zeros((3, nto * 16, nkb * 32), dtype=np.float32)
+    vecs = np.zeros((3, nto * 16), dtype=np.float32)
+    for ot in range(nto):
+        for kb in range(nkb):
+            for pl in range(3):
+                frag = raw[ot, kb * 3 + pl].view(np.uint16).reshape(64, 8)
+                f32 = (frag.astype(np.uint32) << 16).view(np.float32)
+                for lane in range(64):
+                    o, g = 16 * ot + (lane & 15), lane >> 4
+                    for s in range(8):
+                        planes[pl, o, 32 * kb + 16 * (s >> 2) + 4 * g + (s & 3)] = f32[lane, s]
+        for e in range(3):
+            frag = raw[ot, 3 * nkb + e].view(np.float32).reshape(64, 4)
+            for lane in range(64):
+                vecs[e, 16 * ot + 4 * (lane >> 4):16 * ot + 4 * (lane >> 4) + 4] = frag[lane]
+    return planes, vecs
+
+
+@pytest.mark.parametrize("d_out,d_in", [(128, 128), (108, 108), (44, 16), (16, 40)])
+def test_pack_split_is_an_exact_three_way_split(d_out, d_in):
+    """h + m + l reproduces every fp32 weight bit for bit, each piece is a bf16 value (8 significant bits), the
+    layout is the documented one, padding is zero and the epilogue vectors ride along unchanged."""
+    import numpy as np
+    from signnet_basisnet_amd import ops
+    g = torch.Generator().manual_seed(d_out * 131 + d_in)
+    W = (torch.randn(d_out, d_in, generator=g) * torch.logspace(-6, 3, d_in)).cuda()   # wide dynamic range
+    e0, e2 = torch.randn(d_out, generator=g).cuda(), torch.randn(d_out, generator=g).cuda()
+    buf = ops.pack_split(W, e0, None, e2)
+    torch.cuda.synchronize()
+    assert buf.numel() == ((d_out + 15) // 16) * (3 * ((d_in + 31) // 32) + 3) * 1024
+    planes, vecs = _unpack_split(buf, d_out, d_in)
+    Wn = W.cpu().numpy()
+    rec = (planes[0].astype(np.float64) + planes[1] + planes[2])[:d_out, :d_in]
+    assert np.array_equal(rec.astype(np.float32), Wn) and np.array_equal(rec, Wn.astype(np.float64))
+    assert not planes[:, d_out:, :].any() and not planes[:, :, d_in:].any()
+    assert np.all(np.abs(planes[1]) <= np.abs(planes[0]) * 2.0 ** -7 + 1e-45)        # m < one bf16 ulp of h
+    assert np.array_equal(vecs[0, :d_out], e0.cpu().numpy()) and not vecs[1].any()
+    assert np.array_equal(vecs[2, :d_out], e2.cpu().numpy()) and not vecs[:, d_out:].any()

@@ -162,3 +162,41 @@ def test_oversize_graph_is_flagged_and_served_by_the_layer_path():
     ok = synth.batch_to(synth.make_batch(3, seed=4, sizes=[10, 20, 12]), "cuda:0")
     model(ok)
     model.check_last()                          # a well-formed batch leaves nothing pending
+
+
+def test_split_gemm_path_is_fp32_accurate():
+    """The fused phi / rho stages evaluate fp32 Linears as six bf16 partial products.  Against a float64 run of the
+    oracle their error must be in the same class as the fp32-MFMA layer path's (not bf16-class: that would be ~1e-2)."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(3)
+    m = SignNetGNN(None, None, 128, 1, 4, 3, variant="gine", max_k=16)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+    host = synth.make_batch(24, seed=11)
+    sd64 = {k: (v.detach().double() if v.is_floating_point() else v.detach().clone()) for k, v in m.state_dict().items()}
+    cfg = O.make_cfg("gine", None, None, 128, 1, 4, 3)
+    h64 = synth.batch_to(host, "cpu")
+    h64.eigen_vectors, h64.eigen_values = h64.eigen_vectors.double(), h64.eigen_values.double()
+    out = {}
+    with torch.no_grad():
+        O.signnet_gnn(sd64, cfg, h64, training=False, max_k=16, out=out)
+    ref = out["phi"].double()                                                # phi(x)+phi(-x), [N, K, d]
+    m = m.cuda().eval()
+    data = synth.batch_to(host, "cuda:0")
+    with torch.no_grad():
+        _, st = m(data, return_stages=True)
+    scale = ref.abs().max().item()
+    e_layer = (st["phi"].cpu().double() - ref).abs().max().item() / scale    # fp32-input MFMA, layer by layer
+    e_fused = (st["phi_fused"].cpu().double() - ref).abs().max().item() / scale
+    assert e_layer < 2e-6 and e_fused < 2e-6, (e_layer, e_fused)
+    assert e_fused < 4 * e_layer + 2e-7, (e_layer, e_fused)
+    rs = out["rho_sum"].double()
+    r_layer = (st["rho_sum"].cpu().double() - rs).abs().max().item() / rs.abs().max().item()
+    r_fused = (st["rho_sum_fused"].cpu().double() - rs).abs().max().item() / rs.abs().max().item()
+    assert r_layer < 5e-6 and r_fused < 5e-6 and r_fused < 4 * r_layer + 5e-7, (r_layer, r_fused)
