@@ -16,10 +16,25 @@
 
 namespace sn {
 
+#ifdef SN_PROFILE
+static __device__ int g_prof_block = 0;
+__shared__ unsigned long long s_prof[16];      // per-section cycle sums of thread 0 of the selected block (LDS: cheap to update)
+#undef SN_STAMP
+#undef SN_ACCUM
+#define SN_STAMP(i) do { if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) g_prof[i] = clock64(); } while (0)
+#define SN_ACCUM(i, t0) do { if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) g_prof[i] += clock64() - (t0); } while (0)
+#define SN_T0() const long long sn_t0 = clock64()
+#define SN_LACC(i) do { if (threadIdx.x == 0) atomicAdd(&s_prof[i], (unsigned long long)(clock64() - sn_t0)); } while (0)
+#else
+#define SN_T0() do { } while (0)
+#define SN_LACC(i) do { } while (0)
+#endif
+
+
 constexpr int GNN_ROWS = SN_GNN_MAX_NODES;   // 64
 constexpr int GNN_WAVES = 8;
-constexpr int GNN_OTS = 4;                   // max output tiles per wave (NT=8 split over >= 2 groups)
 constexpr int GNN_EMAX = 192;                // in-edges of one graph staged in LDS
+constexpr int GNN_CLS = 16;                  // edge-feature classes per graph whose embeddings stay in LDS for all layers
 constexpr int GNN_EEMAX = 96;                // ... of which this many can have their layer embeddings staged too
 constexpr int GNN_EEPF = (GNN_EEMAX * 32 + GNN_WAVES * 64 - 1) / (GNN_WAVES * 64);   // float4 per thread (d_pad = 128)
 
@@ -38,158 +53,115 @@ struct GnnStruct {
   int ee_rows;            // edges whose per-layer embeddings fit the LDS staging area
 };
 
-// Weight fragments of two output tiles (ot, ot+1) of one packed matrix, held in registers.
+// Weight fragments of ONE output tile of a packed matrix, held in registers.
 template <int NTI>
-struct WPair { float4 w0[NTI], w1[NTI]; };
+struct WTile { float4 w[NTI]; };
 
 template <int NTI>
-__device__ __forceinline__ void wload(WPair<NTI>& p, const float* __restrict__ wp, int nto, int ot, bool one, bool two,
-                                      int lane) {
+__device__ __forceinline__ void wload(WTile<NTI>& p, const float* __restrict__ wp, int nto, int ot, int lane) {
   const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, (unsigned)nto * NTI * 1024);
   const int voff = lane * 16;
   const int base = __builtin_amdgcn_readfirstlane(ot * NTI * 1024);
-  if (one) {
 #pragma unroll
-    for (int kk = 0; kk < NTI; ++kk) {
-      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + kk * 1024, 0);
-      p.w0[kk] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-    }
-  }
-  if (two) {
-#pragma unroll
-    for (int kk = 0; kk < NTI; ++kk) {
-      u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (NTI + kk) * 1024, 0);
-      p.w1[kk] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-    }
+  for (int kk = 0; kk < NTI; ++kk) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + kk * 1024, 0);
+    p.w[kk] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
   }
 }
 
-// The (row tile, output tile) pairs a wave owns in one Linear: a contiguous range [t_lo, t_hi) of the flattened
-// index t = rt*NT + ot.  It touches at most two row tiles ("groups").
+// The (output tile, row tile) pairs a wave owns in one Linear: a contiguous range [t_lo, t_hi) of the flattened index
+// t = ot*T + rt (T = row tiles of the graph, <= 4) — OUTPUT-TILE MAJOR, so that a wave works on one output tile (two
+// at most) for all the graph's row tiles and every weight fragment is fetched by exactly one wave of the workgroup:
+// the weight traffic of a Linear is the matrix once per CU (it was once per row tile, and the time to issue those
+// loads against the 64 B/clk/CU delivery rate was as long as the MFMAs).
 struct TileRange {
-  int t_lo, t_hi;
+  int t_lo, t_hi, T;
   __device__ __forceinline__ bool empty() const { return t_lo >= t_hi; }
-  // group k in {0,1}: row tile rt and its output tiles [o_lo, o_hi)
-  __device__ __forceinline__ void group(int k, int NT, int& rt, int& o_lo, int& o_hi) const {
-    const int rt0 = t_lo / NT;
-    if (k == 0) {
-      rt = rt0;
-      o_lo = t_lo - rt0 * NT;
-      o_hi = (t_hi < (rt0 + 1) * NT ? t_hi : (rt0 + 1) * NT) - rt0 * NT;
-      if (empty()) o_hi = o_lo;
-    } else {
-      rt = rt0 + 1;
-      o_lo = 0;
-      o_hi = t_hi - (rt0 + 1) * NT;
-      if (o_hi < 0 || empty()) o_hi = 0;
-    }
-  }
-  __device__ __forceinline__ void first(int NT, int& ot, bool& one, bool& two) const {
-    int rt, lo, hi;
-    group(0, NT, rt, lo, hi);
-    ot = lo;
-    one = lo < hi;
-    two = lo + 1 < hi;
-  }
+  __device__ __forceinline__ void decode(int t, int& ot, int& rt) const { ot = t / T; rt = t - ot * T; }
+  __device__ __forceinline__ int first_ot() const { return t_lo / T; }
 };
 
 template <int NT>
-__device__ __forceinline__ void mfma_pair(const WPair<NT>& w, const f32x4 (&in)[NT], bool two, f32x4& a0, f32x4& a1) {
-  a0 = f32x4{0.f, 0.f, 0.f, 0.f};
-  a1 = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (two) {
+__device__ __forceinline__ f32x4 mfma_tile32(const WTile<NT>& w, const f32x4 (&in)[NT]) {
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kk = 0; kk < NT; ++kk) {
-      a0 = mfma16(w.w0[kk].x, in[kk][0], a0);
-      a1 = mfma16(w.w1[kk].x, in[kk][0], a1);
-      a0 = mfma16(w.w0[kk].y, in[kk][1], a0);
-      a1 = mfma16(w.w1[kk].y, in[kk][1], a1);
-      a0 = mfma16(w.w0[kk].z, in[kk][2], a0);
-      a1 = mfma16(w.w1[kk].z, in[kk][2], a1);
-      a0 = mfma16(w.w0[kk].w, in[kk][3], a0);
-      a1 = mfma16(w.w1[kk].w, in[kk][3], a1);
+  for (int kk = 0; kk < NT; ++kk) {
+    if (kk & 1) {
+      a1 = mfma16(w.w[kk].x, in[kk][0], a1);
+      a1 = mfma16(w.w[kk].y, in[kk][1], a1);
+      a1 = mfma16(w.w[kk].z, in[kk][2], a1);
+      a1 = mfma16(w.w[kk].w, in[kk][3], a1);
+    } else {
+      a0 = mfma16(w.w[kk].x, in[kk][0], a0);
+      a0 = mfma16(w.w[kk].y, in[kk][1], a0);
+      a0 = mfma16(w.w[kk].z, in[kk][2], a0);
+      a0 = mfma16(w.w[kk].w, in[kk][3], a0);
     }
-  } else {   // a lone tile: split its k-chunks over the two accumulator chains
-#pragma unroll
-    for (int kk = 0; kk < NT; ++kk) {
-      if (kk & 1) {
-        a1 = mfma16(w.w0[kk].x, in[kk][0], a1);
-        a1 = mfma16(w.w0[kk].y, in[kk][1], a1);
-        a1 = mfma16(w.w0[kk].z, in[kk][2], a1);
-        a1 = mfma16(w.w0[kk].w, in[kk][3], a1);
-      } else {
-        a0 = mfma16(w.w0[kk].x, in[kk][0], a0);
-        a0 = mfma16(w.w0[kk].y, in[kk][1], a0);
-        a0 = mfma16(w.w0[kk].z, in[kk][2], a0);
-        a0 = mfma16(w.w0[kk].w, in[kk][3], a0);
-      }
-    }
-    a0 = a0 + a1;
   }
+  return a0 + a1;
 }
 
-// One Linear over the workgroup's rows.  The wave's TileRange (<= 4 tiles) is cut into <= 3 jobs of one or two
-// output tiles of one row tile.  Weight fragments ping-pong between `pre` and `alt`: while job j computes, the
-// fragments of job j+1 — or, for the last job, of the NEXT Linear's first job — are already in flight, so the L2
-// latency overlaps MFMAs, the epilogue, the barrier and the next stage's LDS reads.  On entry `pre` holds job 0's
-// fragments; on exit `pre` holds the next Linear's first job.   img: input image [64][LD]; epi(rt, ot, acc).
+// One Linear over the workgroup's rows.  The wave's TileRange is <= 4 (ot, rt) pairs touching <= 2 output tiles.
+// Weight fragments ping-pong between `pre` and `alt`: `pre` holds the first output tile's fragments on entry (fetched
+// during the previous stage); a second output tile — or, at the end, the NEXT Linear's first tile — is fetched while
+// the current one computes.  The row-tile operand is double buffered from LDS.  img: input image [64][LD];
+// epi(rt, ot, acc, e0, e1) with e* = ev*[16 ot + 4g ..] (per-channel epilogue vectors, fetched before the MFMAs).
 template <int NT, typename Epi>
-__device__ __forceinline__ void coop_gemm(WPair<NT>& pre, WPair<NT>& alt, const float* __restrict__ wp, int nto,
+__device__ __forceinline__ void coop_gemm(WTile<NT>& pre, WTile<NT>& alt, const float* __restrict__ wp, int nto,
                                           const float* img, int LD, TileRange tr, int lane, Epi epi,
                                           const float* __restrict__ next_wp, int next_nto, TileRange next_tr,
                                           const float* __restrict__ ev0 = nullptr, const float* __restrict__ ev1 = nullptr) {
   const int g = lane >> 4;
-  int jrt[3], jot[3];
-  bool jtwo[3];
-  int nj = 0;
-  {
-    int t = tr.t_lo;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  if (tr.empty()) {
+    if (next_wp && !next_tr.empty()) wload<NT>(pre, next_wp, next_nto, next_tr.first_ot(), lane);   // idle here: keep the chain going
+    return;
+  }
+  int ot0, rt0;
+  tr.decode(tr.t_lo, ot0, rt0);
+  int otl, rtl;
+  tr.decode(tr.t_hi - 1, otl, rtl);
+  const bool two_ots = otl != ot0;
+  const float* rowbase = img + (lane & 15) * LD + 4 * g;
+  f32x4 inA[NT], inB[NT];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      jrt[j] = 0; jot[j] = 0; jtwo[j] = false;
-      if (t < tr.t_hi) {
-        const int rt = t / NT, ot = t - rt * NT;
-        const bool two = (t + 1 < tr.t_hi) && (ot + 1 < NT);
-        jrt[j] = rt; jot[j] = ot; jtwo[j] = two;
-        t += two ? 2 : 1;
-        nj = j + 1;
+  for (int kk = 0; kk < NT; ++kk) inA[kk] = lds_ld4(rowbase + rt0 * 16 * LD + 16 * kk);
+  // prefetch: second output tile of this Linear, else the next Linear's first tile
+  bool next_in_alt = false;
+  if (two_ots) wload<NT>(alt, wp, nto, otl, lane);
+  else if (next_wp && !next_tr.empty()) { wload<NT>(alt, next_wp, next_nto, next_tr.first_ot(), lane); next_in_alt = true; }
+  f32x4 e0 = ev0 ? ld4(ev0 + 16 * ot0 + 4 * g) : z4, e1 = ev1 ? ld4(ev1 + 16 * ot0 + 4 * g) : z4;
+  f32x4 f0 = z4, f1 = z4;
+  if (two_ots) { f0 = ev0 ? ld4(ev0 + 16 * otl + 4 * g) : z4; f1 = ev1 ? ld4(ev1 + 16 * otl + 4 * g) : z4; }
+  bool cur_is_pre = true;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int t = tr.t_lo + i;
+    if (t < tr.t_hi) {
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      const bool second = ot != ot0;
+      if (second && cur_is_pre) {
+        cur_is_pre = false;                                   // switch to the second tile (in alt); pre is free again:
+        if (next_wp && !next_tr.empty()) wload<NT>(pre, next_wp, next_nto, next_tr.first_ot(), lane);   // next Linear's first tile
       }
+      // operand of the NEXT pair (double buffer): its LDS latency hides behind this pair's MFMAs
+      f32x4 (&cur)[NT] = (i & 1) ? inB : inA;
+      f32x4 (&nxt)[NT] = (i & 1) ? inA : inB;
+      if (t + 1 < tr.t_hi) {
+        int ot2, rt2;
+        tr.decode(t + 1, ot2, rt2);
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) nxt[kk] = lds_ld4(rowbase + rt2 * 16 * LD + 16 * kk);
+      }
+      const f32x4 acc = cur_is_pre ? mfma_tile32<NT>(pre, cur) : mfma_tile32<NT>(alt, cur);
+      epi(rt, ot, acc, second ? f0 : e0, second ? f1 : e1);
     }
   }
-  int nxo = 0;
-  bool n1 = false, n2 = false;
-  if (next_wp) next_tr.first(NT, nxo, n1, n2);
-  f32x4 in[NT];
+  if (next_in_alt) {   // single-tile range: the next Linear's first tile sits in alt — hand it over in pre
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (j < nj) {
-      WPair<NT>& cur = (j & 1) ? alt : pre;
-      WPair<NT>& oth = (j & 1) ? pre : alt;
-      const bool lastj = (j + 1 == nj);
-      if (!lastj) wload<NT>(oth, wp, nto, jot[j + 1 < 3 ? j + 1 : 2], true, jtwo[j + 1 < 3 ? j + 1 : 2], lane);
-      else if (next_wp) wload<NT>(oth, next_wp, next_nto, nxo, n1, n2, lane);
-      if (j == 0 || jrt[j] != jrt[j > 0 ? j - 1 : 0]) {
-        const float* rowp = img + (jrt[j] * 16 + (lane & 15)) * LD + 4 * g;
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) in[kk] = lds_ld4(rowp + 16 * kk);
-      }
-      // per-channel epilogue vectors (folded BatchNorm / bias) are fetched BEFORE the MFMAs so their L2 latency
-      // is hidden behind them instead of sitting between the last MFMA and the barrier
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      const int c0 = 16 * jot[j] + 4 * g;
-      const f32x4 e00 = ev0 ? ld4(ev0 + c0) : z4, e10 = ev1 ? ld4(ev1 + c0) : z4;
-      const f32x4 e01 = (ev0 && jtwo[j]) ? ld4(ev0 + c0 + 16) : z4, e11 = (ev1 && jtwo[j]) ? ld4(ev1 + c0 + 16) : z4;
-      f32x4 a0, a1;
-      mfma_pair<NT>(cur, in, jtwo[j], a0, a1);
-      epi(jrt[j], jot[j], a0, e00, e10);
-      if (jtwo[j]) epi(jrt[j], jot[j] + 1, a1, e01, e11);
-      if (lastj && next_wp && (j & 1) == 0) {   // the prefetched fragments sit in `alt`: hand them over in `pre`
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) { pre.w0[kk] = alt.w0[kk]; pre.w1[kk] = alt.w1[kk]; }
-      }
-    }
+    for (int kk = 0; kk < NT; ++kk) pre.w[kk] = alt.w[kk];
   }
-  if (nj == 0 && next_wp) wload<NT>(pre, next_wp, next_nto, nxo, n1, n2, lane);   // idle here: keep the chain going
 }
 
 template <int NT>
@@ -203,9 +175,20 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   int* erow = reinterpret_cast<int*>(lds + 3 * GNN_ROWS * LD);   // [65]  CSR row pointers local to the graph
   int* esrc = erow + GNN_ROWS + 4;                               // [GNN_EMAX] local source row of every in-edge
   int* efeat = esrc + GNN_EMAX;                                  // [GNN_EMAX][edge_nf] feature words (int idx / float)
-  float* EE = reinterpret_cast<float*>(efeat + GNN_EMAX * (P.n_layers > 0 ? P.edge_nf : 0));   // [ee_rows][LD] this layer's edge embeddings
+  int* ecls = efeat + GNN_EMAX * (P.n_layers > 0 ? P.edge_nf : 0);   // [GNN_EMAX] feature class of every in-edge
+  int* elead = ecls + GNN_EMAX;                                     // [GNN_EMAX] first edge with the same features (scratch)
+  int* cedge = elead + GNN_EMAX;                                    // [GNN_CLS]  representative edge of every class
+  float* EE = reinterpret_cast<float*>(cedge + GNN_CLS);           // [ee_rows][LD] edge embeddings (per class x layer, or per edge)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const int gi = blockIdx.x;
+  SN_STAMP(0);
+#ifdef SN_PROFILE
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0;
+#endif
+#ifdef SN_PROFILE
+  if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) for (int i = 8; i < 20; ++i) g_prof[i] = 0;
+  long long pt = 0;
+#endif
   const int gs = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - gs;
   if (n <= 0) return;
   if (n > GNN_ROWS) {
@@ -221,15 +204,24 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   const int d = P.d;
   const int T = (n + 15) >> 4;                               // row tiles (1..4)
   const int ntile = T * NT;
-  const int q = (ntile + GNN_WAVES - 1) / GNN_WAVES;          // tiles per wave (<= NT/2 since T <= 4)
-  TileRange tr;                                               // my share of every node-row Linear
+  const int q = (ntile + GNN_WAVES - 1) / GNN_WAVES;          // pairs per wave (<= T since NT <= 8: at most 2 output tiles)
+  TileRange tr;                                               // my share of every node-row Linear (output-tile major)
+  tr.T = T;
   tr.t_lo = wave * q < ntile ? wave * q : ntile;
   tr.t_hi = tr.t_lo + q < ntile ? tr.t_lo + q : ntile;
   TileRange hr;                                               // my share of the output encoder (one pooled row tile)
+  hr.T = 1;
   hr.t_lo = wave < NT ? wave : NT;
   hr.t_hi = wave < NT ? wave + 1 : NT;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const bool use_ee = P.n_layers > 0 && ne <= S.ee_rows;
+  // Edges of a graph repeat a handful of feature tuples (ZINC: 3 bond types), and an edge's embedding depends on
+  // nothing else.  The staging code below groups the graph's edges into classes of identical features; with at
+  // most GNN_CLS classes the embeddings of every (layer, class) are built ONCE into LDS (use_tab) and the aggregation
+  // reads edge e's embedding as row ecls[e] — no per-edge, per-layer gather.  Otherwise the current layer's
+  // per-edge embeddings are staged (use_ee), or gathered directly.
+  bool use_tab = false;   // decided after the classes are known
+  int ncls = 0;
+  bool use_ee = P.n_layers > 0 && ne <= S.ee_rows;
   // embedding of edge k, channels [c, c+4) for layer Lq: DiscreteEncoder sum (elements.py:31-37) or MLP(F_e, d, 1)
   auto edge_embed = [&](const sn_gnn_layer& Lq, int k, int c) -> f32x4 {
     const int EF = P.edge_nf;
@@ -275,12 +267,8 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
     }
   };
 
-  WPair<NT> pre, alt;
-  {
-    int fot; bool f1, f2;
-    tr.first(NT, fot, f1, f2);
-    wload<NT>(pre, P.rho_out_w, NT, fot, f1, f2, lane);       // in flight while the inputs are staged
-  }
+  WTile<NT> pre, alt;
+  if (!tr.empty()) wload<NT>(pre, P.rho_out_w, NT, tr.first_ot(), lane);       // in flight while the inputs are staged
   // ---------------------------------------------------------------- per-graph CSR + edge data -> LDS (once)
   {
     const int EF = P.edge_nf;
@@ -299,21 +287,57 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       }
     }
   }
-  // ---------------------------------------------------------------- stage the slot sum (rho output) in X1
-  for (int i = threadIdx.x; i < n * d; i += GNN_WAVES * 64) {
-    const int rr = i / d, c = i - rr * d;
-    X1[rr * LD + c] = S.rho_sum[(int64_t)(gs + rr) * d + c];
+  // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
+  if (P.n_layers > 0) {
+    const int EF = P.edge_nf;
+    __syncthreads();                                   // efeat is complete
+    int lead = -1;
+    if ((int)threadIdx.x < ne) {
+      const int k = threadIdx.x;
+      lead = k;                                        // first edge with my feature tuple; with a handful of classes the
+      for (int j = 0; j < k; ++j) {                    // scan stops within the first few edges
+        bool same = true;
+        for (int f = 0; f < EF; ++f) same = same && (efeat[j * EF + f] == efeat[k * EF + f]);
+        if (same) { lead = j; break; }
+      }
+      elead[k] = lead;
+    }
+    ncls = __syncthreads_count((int)threadIdx.x < ne && lead == (int)threadIdx.x);   // leaders = classes (ne <= 192 < blockDim)
+    if ((int)threadIdx.x < ne) {
+      int c = 0;
+      for (int j = 0; j < lead; ++j) c += (elead[j] == j);
+      ecls[threadIdx.x] = c;                           // dense class id = number of leaders before my leader
+      if (lead == (int)threadIdx.x && c < GNN_CLS) cedge[c] = lead;
+    }
+    use_tab = ncls <= GNN_CLS && P.n_layers * ncls <= S.ee_rows;
+    if (use_tab) use_ee = false;
+    __syncthreads();
+    if (use_tab) {   // EE[l * ncls + c][:] = embedding of class c's representative edge in layer l (padded channels: 0)
+      for (int i = threadIdx.x; i < P.n_layers * ncls * (D / 4); i += GNN_WAVES * 64) {
+        const int rowi = i / (D / 4), ch = 4 * (i % (D / 4));
+        const int l = rowi / ncls, c = rowi - l * ncls;
+        lds_st4(EE + rowi * LD + ch, edge_embed(P.layers[l], cedge[c], ch));
+      }
+    }
   }
-  if (d < D) {
-    for (int i = threadIdx.x; i < n * (D - d); i += GNN_WAVES * 64) {
-      const int rr = i / (D - d), c = d + i - rr * (D - d);
-      X1[rr * LD + c] = 0.f;
+  // ---------------------------------------------------------------- stage the slot sum (rho output) in X1 (zero padded to D)
+  if ((d & 3) == 0) {
+    for (int i = threadIdx.x; i < n * (D / 4); i += GNN_WAVES * 64) {
+      const int rr = i / (D / 4), c = 4 * (i % (D / 4));
+      lds_st4(X1 + rr * LD + c, c < d ? ld4(S.rho_sum + (int64_t)(gs + rr) * d + c) : zero4);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n * D; i += GNN_WAVES * 64) {
+      const int rr = i / D, c = i % D;
+      X1[rr * LD + c] = c < d ? S.rho_sum[(int64_t)(gs + rr) * d + c] : 0.f;
     }
   }
   // ---------------------------------------------------------------- input encoder -> X0 (model.py:37)
   if (P.node_discrete) {
     for (int t = tr.t_lo; t < tr.t_hi; ++t) {
-      const int rt = t / NT, ot = t - rt * NT, row = rt * 16 + li, c = 16 * ot + 4 * g;
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      const int row = rt * 16 + li, c = 16 * ot + 4 * g;
       if (row < n) {
         const int64_t* xi = reinterpret_cast<const int64_t*>(S.x) + (int64_t)(gs + row) * S.ldx;
         f32x4 s = zero4;
@@ -331,7 +355,9 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   } else {
     // MLP(nfeat, d, 1): Linear(no bias) . BN . ReLU on <= 16 continuous features — VALU, one output tile at a time
     for (int t = tr.t_lo; t < tr.t_hi; ++t) {
-      const int rt = t / NT, ot = t - rt * NT, row = rt * 16 + li, c = 16 * ot + 4 * g;
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      const int row = rt * 16 + li, c = 16 * ot + 4 * g;
       if (row < n) {
         const float* xr = reinterpret_cast<const float*>(S.x) + (int64_t)(gs + row) * S.ldx;
         f32x4 acc = zero4;
@@ -345,12 +371,14 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
     }
   }
   __syncthreads();
+  SN_STAMP(1);
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- pos = BN(W_out . slot_sum): X1 -> X2   (sign_net.py:71)
   coop_gemm<NT>(pre, alt, P.rho_out_w, NT, X1, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
     lds_st4(X2 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc * sc + sh);
   }, P.lin_a, NT, tr, P.rho_scale, P.rho_shift);
   __syncthreads();
+  SN_STAMP(20);
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]): X0, X2 -> X1    (model.py:39-40)
   coop_gemm<NT>(pre, alt, P.lin_a, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4) {
     lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);      // readers of X1 (slot sum) passed a barrier
@@ -361,54 +389,80 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   }, P.n_layers > 0 ? P.layers[0].w1p : P.head_w1, NT, P.n_layers > 0 ? tr : hr, P.lin_bias);
   ee_store();
   __syncthreads();
+  SN_STAMP(2);
   // ---------------------------------------------------------------- GINE layers: h lives in X1           (model.py:47-55)
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_gnn_layer& Lp = P.layers[l];
     // u = sum_{j->i} relu(h_j + e_ji) + (1+eps) h_i  for my (row tile, channel tile) pairs: X1 -> X2
+#ifdef SN_PROFILE
+    pt = clock64();
+#endif
     ee_fetch(l + 1);   // next layer's edge embeddings: in flight during this aggregation
+    SN_ACCUM(8, pt);
+#ifdef SN_PROFILE
+    pt = clock64();
+#endif
     {
       const float sc = 1.f + *Lp.eps;
 #pragma unroll 1
-      for (int k = 0; k < 2; ++k) {
-        int rt, o_lo, o_hi;
-        tr.group(k, NT, rt, o_lo, o_hi);
-        const int row = rt * 16 + li;
-        if (o_lo >= o_hi || row >= n) continue;
-        f32x4 u[GNN_OTS];
+      for (int t = tr.t_lo; t < tr.t_hi; ++t) {
+        int ot, rt;
+        tr.decode(t, ot, rt);
+        const int row = rt * 16 + li, c = 16 * ot + 4 * g;
+        if (row >= n) continue;
+        f32x4 u = zero4;
+        const int e_lo = erow[row], e_hi = erow[row + 1];
+        int e = e_lo;
+        if (use_tab || use_ee) {
+          // the first four in-edges (molecular graphs: all) with predicated, unrolled reads: index reads, then the
+          // eight row reads, then the adds in edge order (a missing edge adds +0)
+          const int dg = e_hi - e_lo;
+          int sr[4], er[4];
 #pragma unroll
-        for (int o = 0; o < GNN_OTS; ++o) u[o] = zero4;
-        for (int e = erow[row]; e < erow[row + 1]; ++e) {
-          const float* hsrc = X1 + esrc[e] * LD + 4 * g;
-#pragma unroll
-          for (int o = 0; o < GNN_OTS; ++o) {
-            if (o_lo + o < o_hi) {
-              const int c = 16 * (o_lo + o) + 4 * g;
-              const f32x4 ef = use_ee ? lds_ld4(EE + e * LD + c) : edge_embed(Lp, e, c);
-              u[o] += relu4(lds_ld4(hsrc + 16 * (o_lo + o)) + ef);
-            }
+          for (int i = 0; i < 4; ++i) {
+            const int ei = i < dg ? e_lo + i : 0;
+            sr[i] = i < dg ? esrc[ei] : row;
+            er[i] = i < dg ? (use_tab ? l * ncls + ecls[ei] : ei) : 0;
           }
-        }
+          f32x4 hv[4], ev[4];
 #pragma unroll
-        for (int o = 0; o < GNN_OTS; ++o) {
-          if (o_lo + o < o_hi) {
-            const int c = 16 * (o_lo + o) + 4 * g;
-            {
+          for (int i = 0; i < 4; ++i) { hv[i] = lds_ld4(X1 + sr[i] * LD + c); ev[i] = lds_ld4(EE + er[i] * LD + c); }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) u += i < dg ? relu4(hv[i] + ev[i]) : zero4;
+          e = e_lo + (dg < 4 ? dg : 4);
+        }
+        for (; e < e_hi; ++e) {
+          const f32x4 ef = use_tab ? lds_ld4(EE + (l * ncls + ecls[e]) * LD + c)
+                                   : (use_ee ? lds_ld4(EE + e * LD + c) : edge_embed(Lp, e, c));
+          u += relu4(lds_ld4(X1 + esrc[e] * LD + c) + ef);
+        }
+        {
 #pragma clang fp contract(off)
-              const f32x4 self = lds_ld4(X1 + row * LD + c) * sc;
-              u[o] = u[o] + self;
-            }
-            lds_st4(X2 + row * LD + c, u[o]);
-          }
+          const f32x4 self = lds_ld4(X1 + row * LD + c) * sc;
+          u = u + self;
         }
+        lds_st4(X2 + row * LD + c, u);
       }
     }
     __syncthreads();
+    SN_ACCUM(9, pt);
+#ifdef SN_PROFILE
+    pt = clock64();
+#endif
     ee_store();        // every wave is done reading this layer's embeddings
+    SN_ACCUM(10, pt);
+#ifdef SN_PROFILE
+    pt = clock64();
+#endif
     // nn: Linear . BN . ReLU : X2 -> X0
     coop_gemm<NT>(pre, alt, Lp.w1p, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
       lds_st4(X0 + (rt * 16 + li) * LD + 16 * ot + 4 * g, relu4(acc * sc + sh));
     }, Lp.w2p, NT, tr, Lp.bn0_scale, Lp.bn0_shift);
     __syncthreads();
+    SN_ACCUM(11, pt);
+#ifdef SN_PROFILE
+    pt = clock64();
+#endif
     // Linear ; BN . ReLU ; + previous_x : X0 -> X1 (my tiles only: nobody else reads them at this point)
     const bool lastl = l + 1 == P.n_layers;
     coop_gemm<NT>(pre, alt, Lp.w2p, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
@@ -416,7 +470,9 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
     }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1p, NT, lastl ? hr : tr, Lp.bn_scale, Lp.bn_shift);
     __syncthreads();
+    SN_ACCUM(12, pt);
   }
+  SN_STAMP(3);
   // ---------------------------------------------------------------- add pooling -> row 0 of X2 (rows 1..15 zero)  (model.py:57-61)
   for (int c = threadIdx.x; c < 16 * LD; c += GNN_WAVES * 64) {
     const int rr = c / LD, cc = c - rr * LD;
@@ -426,8 +482,10 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
     X2[c] = s;
   }
   __syncthreads();
+  SN_STAMP(4);
   // ---------------------------------------------------------------- output encoder on the pooled row     (model.py:63)
   TileRange h2;
+  h2.T = 1;
   h2.t_lo = 0;
   h2.t_hi = wave == 0 ? 1 : 0;
   coop_gemm<NT>(pre, alt, P.head_w1, NT, X2, LD, hr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
@@ -443,13 +501,21 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       }
     }
   }, nullptr, 0, h2);
+  SN_STAMP(5);
+#ifdef SN_PROFILE
+  if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) for (int i = 0; i < 16; ++i) g_prof[40 + i] = (long long)s_prof[i];
+#endif
+#ifdef SN_PROFILE
+  if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) { g_prof[6] = n; g_prof[7] = ne; }
+#endif
 }
 
 template <int NT>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t base = (size_t)(3 * GNN_ROWS * LD) * sizeof(float) + (size_t)(GNN_ROWS + 4 + GNN_EMAX * (1 + (P.n_layers > 0 ? P.edge_nf : 0))) * sizeof(int);
-  const size_t room = base < 160 * 1024 ? 160 * 1024 - base : 0;
+  const size_t base = (size_t)(3 * GNN_ROWS * LD) * sizeof(float) + (size_t)(GNN_ROWS + 4 + GNN_EMAX * (3 + (P.n_layers > 0 ? P.edge_nf : 0)) + GNN_CLS) * sizeof(int);
+  const size_t lds_cap = 160 * 1024 - 512;     // the kernel also has a few bytes of static LDS (__syncthreads_count)
+  const size_t room = base < lds_cap ? lds_cap - base : 0;
   int ee_rows = (int)(room / ((size_t)LD * sizeof(float)));
   if (ee_rows > GNN_EEMAX) ee_rows = GNN_EEMAX;
   GnnStruct S2 = S;
@@ -457,7 +523,7 @@ static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hip
   const size_t lds = base + (size_t)S2.ee_rows * LD * sizeof(float);
   static bool init = false;
   if (!init) {
-    const size_t lds_max = 160 * 1024;
+    const size_t lds_max = lds_cap;
     if (lds_max > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_gnn_coop<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_max) != hipSuccess)
@@ -471,6 +537,11 @@ static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hip
 }  // namespace sn
 
 using namespace sn;
+
+#ifdef SN_PROFILE
+extern "C" int sn_prof_read_gnn(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(long long) * 64); }
+extern "C" int sn_prof_set_block(int b) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_block), &b, sizeof(int)); }
+#endif
 
 extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const void* edge_attr, int lde,
                                 const float* rho_sum, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr,
