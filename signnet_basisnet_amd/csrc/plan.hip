@@ -63,6 +63,13 @@ __device__ __forceinline__ int slots_of(int n, int kmax) { return (kmax > 0 && n
 // rho: a unit is one node's K_g slot rows, padded to p = 16*ceil(K_g/16) so that a unit never straddles a 16-row
 //      tile; 64/p units per bin, bins never mix graphs -> closed form, no sequential pass.
 // gp: graph_ptr in LDS ([B+1]); lds: int scratch [5*B + 3*66 + 32].
+#ifdef SN_PROFILE
+static __device__ long long g_pprof[32];
+#define PL_STAMP(i) do { if (threadIdx.x == 0) g_pprof[(i) + 16 * blockIdx.x] = clock64(); } while (0)
+#else
+#define PL_STAMP(i) do { } while (0)
+#endif
+
 __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
   const int t = threadIdx.x;
   int* bucket = lds;            // [B]   graph ids grouped by size, ascending id inside a group
@@ -109,6 +116,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       bd.meta[7] = 0;
     }
   }
+  PL_STAMP(3);
   // ---- phi: group graphs by size
   for (int g = t; g < B; g += PLAN_T) {
     const int n = gp[g + 1] - gp[g];
@@ -116,10 +124,16 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     else if (n > 0) atomicAdd(&hist[n], 1);
   }
   __syncthreads();
-  if (t <= 65) {   // bstart = exclusive prefix of hist (66 short independent loops)
-    int run = 0;
-    for (int s2 = 0; s2 < t && s2 <= 64; ++s2) run += hist[s2];
-    bstart[t] = run;
+  if (t < 64) {   // bstart = exclusive prefix of hist[0..65] (wave scan; hist[0] = 0: empty graphs are not binned)
+    const int h = hist[t];
+    int x = h;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if (t >= off) x += y;
+    }
+    bstart[t] = x - h;
+    if (t == 63) { bstart[64] = x; bstart[65] = x + hist[64]; }
   }
   __syncthreads();
   for (int g = t; g < B; g += PLAN_T) {
@@ -144,29 +158,36 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* rec_col = rec_rank + B;   // [B] column
   int* rec_off = rec_col + B;    // [B] (member index << 8) | row offset
   __syncthreads();
+  PL_STAMP(4);
   if (t < 64) {
     const int lane = t;
     int cnt = hist[lane + 1];                       // class s = lane + 1
     int used = 0;
     unsigned long long avail = __ballot(cnt > 0);
     int ncol = 0, bin = 0, rows = 0, nrec = 0;
+    // records and column starts are captured in registers (lane r & 63 keeps record r) and flushed 64 at a time:
+    // no LDS / global store sits on the loop-carried scalar chain
+    int recA = 0, recB = 0, colb = 0;
     while (avail) {
       const int s = 64 - __clzll(avail);
       int cap = 64 - s, members = 0, off = 0;
       const int H = slots_of(s, kmax);
       int cls = s;
+      if (lane == (ncol & 63)) colb = bin;
       while (true) {
         const int rank = __builtin_amdgcn_readlane(used, cls - 1);
         const int left = __builtin_amdgcn_readlane(cnt, cls - 1) - 1;
         if (lane == cls - 1) { ++used; --cnt; }
         if (left == 0) avail &= ~(1ull << (cls - 1));
-        if (lane == 0) {
-          rec_cls[nrec] = cls;
-          rec_rank[nrec] = rank;
-          rec_col[nrec] = ncol;
-          rec_off[nrec] = (members << 8) | off;
-        }
+        if (lane == (nrec & 63)) { recA = cls | (rank << 8); recB = ncol | (members << 13) | (off << 16); }
         ++nrec;
+        if ((nrec & 63) == 0) {                        // flush 64 records
+          const int base = nrec - 64 + lane;
+          rec_cls[base] = recA & 255;
+          rec_rank[base] = recA >> 8;
+          rec_col[base] = recB & 8191;
+          rec_off[base] = (((recB >> 13) & 7) << 8) | (recB >> 16);
+        }
         rows += cls * slots_of(cls, kmax);
         off += cls;
         ++members;
@@ -176,10 +197,18 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
         if (!m) break;
         cls = 64 - __clzll(m);
       }
-      if (lane == 0) bd.phi_col_bin0[ncol] = bin;
       bin += H;
       ++ncol;
+      if ((ncol & 63) == 0) bd.phi_col_bin0[ncol - 64 + lane] = colb;
     }
+    if (lane < (nrec & 63)) {                          // flush the partial groups
+      const int base = (nrec & ~63) + lane;
+      rec_cls[base] = recA & 255;
+      rec_rank[base] = recA >> 8;
+      rec_col[base] = recB & 8191;
+      rec_off[base] = (((recB >> 13) & 7) << 8) | (recB >> 16);
+    }
+    if (lane < (ncol & 63)) bd.phi_col_bin0[(ncol & ~63) + lane] = colb;
     if (lane == 0) {
       bd.phi_col_bin0[ncol] = bin;
       s_ncol = ncol;
@@ -191,6 +220,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     }
   }
   __syncthreads();
+  PL_STAMP(5);
   {
     const int ncol_ = s_ncol, nrec = s_nrec;
     for (int i = t; i < ncol_ * 8; i += PLAN_T) { bd.phi_col_mem[i] = -1; bd.phi_col_off[i] = 0; }
@@ -219,13 +249,14 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
 }
 
 // graph_ptr from a sorted batch vector, into LDS: gp[k] = first node of graph k (empty graphs included), gp[B] = N.
-__device__ void lds_graph_ptr(const int64_t* __restrict__ batch, int N, int B, int* gp, int* err) {
+__device__ void lds_graph_ptr(const int64_t* __restrict__ batch, int N, int B, int* gp, int* err, int* ng = nullptr) {
   const int t = threadIdx.x;
   for (int i = t; i <= B; i += PLAN_T) gp[i] = N;
   __syncthreads();
   for (int i = t; i < N; i += PLAN_T) {
     const long long g = batch[i];
     const long long gprev = (i == 0) ? -1 : batch[i - 1];
+    if (ng) ng[i] = (g < 0 || g >= B) ? -1 : (int)g;
     if (g < 0 || g >= B) { if (err) atomicOr(err, ERR_GRAPH_ID); continue; }
     if (gprev > g && err) atomicOr(err, ERR_UNSORTED);
     if (gprev < g) {
@@ -241,6 +272,8 @@ __device__ void lds_graph_ptr(const int64_t* __restrict__ batch, int N, int B, i
 // Limits: N <= 4096, E <= 12288, B <= 1024 (the reference's batches: 128-256 molecules).
 constexpr int PS_NMAX = 4096, PS_EMAX = 12288, PS_BMAX = 1024;
 
+
+
 __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict__ batch, int N, int B,
                                                        const int64_t* __restrict__ ei, int E, int kmax,
                                                        int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
@@ -250,11 +283,14 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
                                                        int do_bins) {
   extern __shared__ int sm[];
   const int t = threadIdx.x;
+  PL_STAMP(0);
   if (blockIdx.x == 1) {
     if (!do_bins) return;
     int* gp = sm;                      // [B+1]
     lds_graph_ptr(batch, N, B, gp, nullptr);
+    PL_STAMP(1);
     plan_bins_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
+    PL_STAMP(2);
     return;
   }
   int* gp = sm;                        // [B+1]
@@ -263,19 +299,39 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
   int* lcol = rp + (PS_NMAX + 4);      // [E]
   int* lperm = lcol + PS_EMAX;         // [E]
   int* wsum = lperm + PS_EMAX;         // [32]
+  int* ng = wsum + 32;                 // [N]  graph id of every node (edge validation without global gathers)
   __shared__ int s_err, s_nmax, s_dmax;
   if (t == 0) { s_err = 0; s_nmax = 0; s_dmax = 0; }
   for (int i = t; i < N; i += PLAN_T) deg[i] = 0;
   __syncthreads();
-  lds_graph_ptr(batch, N, B, gp, &s_err);
+  lds_graph_ptr(batch, N, B, gp, &s_err, ng);
+  PL_STAMP(1);
   // ---- in-degrees (LDS atomics) + edge validation
-  for (int e = t; e < E; e += PLAN_T) {
-    const long long s = ei[e], d = ei[(long long)E + e];
-    if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(&s_err, ERR_EDGE_RANGE); continue; }
-    if (batch[s] != batch[d]) atomicOr(&s_err, ERR_EDGE_CROSS);
-    atomicAdd(&deg[d], 1);
+  // (four edges per thread and iteration with independent loads; the same-graph check reads the LDS copy of `batch`)
+  for (int e0 = 4 * t; e0 < E; e0 += 4 * PLAN_T) {
+    long long sv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u;
+      sv[u] = e < E ? ei[e] : 0;
+      dv[u] = e < E ? ei[(long long)E + e] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u;
+      if (e < E) {
+        const long long s = sv[u], d = dv[u];
+        const bool bad = s < 0 || s >= N || d < 0 || d >= N;
+        if (bad) atomicOr(&s_err, ERR_EDGE_RANGE);
+        else {
+          if (ng[s] != ng[d]) atomicOr(&s_err, ERR_EDGE_CROSS);
+          atomicAdd(&deg[d], 1);
+        }
+      }
+    }
   }
   __syncthreads();
+  PL_STAMP(2);
   // ---- rowptr = exclusive scan of deg ; evoff = exclusive scan of n^2
   {
     const int per = (N + PLAN_T - 1) / PLAN_T;
@@ -300,17 +356,46 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     if (t == 0) evoff[B] = qtot;
   }
   __syncthreads();
+  PL_STAMP(3);
   // ---- fill the CSR segments (arbitrary arrival order), then sort each segment by edge id
-  for (int e = t; e < E; e += PLAN_T) {
-    const long long s = ei[e], d = ei[(long long)E + e];
-    if (s < 0 || s >= N || d < 0 || d >= N) continue;
-    const int p = atomicAdd(&deg[d], 1);
-    lcol[p] = (int)s;
-    lperm[p] = e;
+  for (int e0 = 4 * t; e0 < E; e0 += 4 * PLAN_T) {
+    long long sv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u;
+      sv[u] = e < E ? ei[e] : 0;
+      dv[u] = e < E ? ei[(long long)E + e] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u;
+      const long long s = sv[u], d = dv[u];
+      if (e < E && !(s < 0 || s >= N || d < 0 || d >= N)) {
+        const int p = atomicAdd(&deg[d], 1);
+        lcol[p] = (int)s;
+        lperm[p] = e;
+      }
+    }
   }
   __syncthreads();
+  PL_STAMP(4);
   for (int i = t; i < N; i += PLAN_T) {
-    const int lo = rp[i], hi = rp[i + 1];
+    const int lo = rp[i], hi = rp[i + 1], dg = hi - lo;
+    if (dg <= 1) continue;
+    if (dg <= 4) {
+      // up to four in-edges (molecular graphs: always): read, 5-comparator network on (edge id, source), write back
+      int ke[4], kc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ke[u] = u < dg ? lperm[lo + u] : 0x7fffffff; kc[u] = u < dg ? lcol[lo + u] : 0; }
+      auto cx = [&](int a, int b) {
+        if (ke[a] > ke[b]) { const int te = ke[a]; ke[a] = ke[b]; ke[b] = te; const int tc = kc[a]; kc[a] = kc[b]; kc[b] = tc; }
+      };
+      cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (u < dg) { lperm[lo + u] = ke[u]; lcol[lo + u] = kc[u]; }
+      continue;
+    }
     for (int a = lo + 1; a < hi; ++a) {
       const int ke = lperm[a], kc = lcol[a];
       int b = a - 1;
@@ -320,6 +405,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     }
   }
   __syncthreads();
+  PL_STAMP(5);
   // ---- write out
   for (int i = t; i <= N; i += PLAN_T) rowptr[i] = rp[i];
   for (int i = t; i < E; i += PLAN_T) { col[i] = lcol[i]; eperm[i] = lperm[i]; }
@@ -332,6 +418,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     nvalid[i] = nv;
   }
   if (t == 0) { status[ST_ERR] = s_err; status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
+  PL_STAMP(6);
 }
 
 // ============================================================================ general path: five launches
@@ -537,7 +624,7 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   }
   hipStream_t st = (hipStream_t)stream;
   if (N > 0 && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX) {
-    const size_t lds0 = (size_t)((PS_BMAX + 4) + PS_NMAX + (PS_NMAX + 4) + 2 * PS_EMAX + 32) * sizeof(int);
+    const size_t lds0 = (size_t)((PS_BMAX + 4) + PS_NMAX + (PS_NMAX + 4) + 2 * PS_EMAX + 32 + PS_NMAX) * sizeof(int);
     const size_t lds1 = (size_t)((PS_BMAX + 4) + 5 * PS_BMAX + 3 * 66 + 32) * sizeof(int);
     const size_t lds = lds0 > lds1 ? lds0 : lds1;
     static bool init = false;
@@ -578,6 +665,10 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   SN_CHECK_LAUNCH("sn_batch_plan");
   return SN_OK;
 }
+
+#ifdef SN_PROFILE
+extern "C" int sn_prof_read_plan(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pprof), sizeof(long long) * 32); }
+#endif
 
 extern "C" int64_t sn_phi_bins_bound(int64_t B, int kmax) {
   // every column has height <= min(kmax, 64); at worst one graph per column

@@ -72,13 +72,15 @@ class PhiPlan:
             Lp.eps = hold(c.layer.eps.detach())
         self.params = P
 
-    def run(self, plan: ops.GraphPlan, eigen_vectors, K: int, out=None):
-        """phi(x)+phi(-x) -> [N, K, d]; rows of invalid slots are left untouched (zero if `out` is None)."""
+    def run(self, plan: ops.GraphPlan, eigen_vectors, K: int, out=None, zero_invalid=True):
+        """phi(x)+phi(-x) -> [N, K, d]; rows of invalid slots are left untouched (zero if `out` is None and
+        zero_invalid; the fused rho stage never reads them, so the forward skips the 24 MB memset)."""
         ev = eigen_vectors
         if ev.dtype != torch.float32 or not ev.is_contiguous():
             raise ValueError("eigen_vectors must be contiguous float32")
         if out is None:
-            out = torch.zeros(plan.N, K, self.d, dtype=torch.float32, device=ev.device)
+            alloc = torch.zeros if zero_invalid else torch.empty
+            out = alloc(plan.N, K, self.d, dtype=torch.float32, device=ev.device)
         with ops._span("sn_phi_fused_f32"):
             check(lib().sn_phi_fused_f32(C.byref(self.params), ptr(ev), ptr(plan.graph_ptr), ptr(plan.evoff),
                                          ptr(plan.rowptr), ptr(plan.col), C.byref(plan.bins.cstruct), plan.kmax, K,

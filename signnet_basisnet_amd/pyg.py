@@ -427,7 +427,7 @@ class SignNetGNN(nn.Module):
         # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)
         phis = None
         if use_phi_fused and not return_stages:
-            x = P["phi_fused"].run(plan, data.eigen_vectors, K).view(N * K, d)
+            x = P["phi_fused"].run(plan, data.eigen_vectors, K, zero_invalid=not use_rho_fused).view(N * K, d)
         else:
             phis = []
             for sign in (0, 1):
