@@ -290,20 +290,16 @@ int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* e
  * sum (sign_net.py:71), then GNN.forward (model.py:36-64 / core/model.py:44-79): input encoder
  * (DiscreteEncoder elements.py:31-37 or MLP(F,d,1)), Linear(cat[x,pos]), n_layers x [edge encoder, GINEConv
  * (pyg_gnn_wrapper.py:19-28), BatchNorm, ReLU, +previous], add pooling, 2-layer output encoder.
- * One workgroup per graph (graphs of more than SN_GNN_MAX_NODES = 64 nodes are skipped and flagged in
- * status[3]; the caller then uses the layer-at-a-time entry points).  Matrices packed, vectors zero-padded
- * to d_pad unless noted. */
+ * One workgroup per graph (graphs of more than SN_GNN_MAX_NODES = 64 nodes or 192 edges are skipped and flagged in
+ * status[3]; the caller then uses the layer-at-a-time entry points).  Every [d,d] Linear is split-packed
+ * (sn_pack_split_f32) together with its epilogue vectors; other vectors are zero-padded to d_pad. */
 typedef struct {
   const float* etab[10];  /* discrete edge encoder: embedding tables [V, d] of layer l */
   const float* ew;        /* float edge encoder: weight [d_pad, F_e] row-major (NOT packed), zero padded rows */
   const float* e_scale;   /*   its folded BatchNorm */
   const float* e_shift;
-  const float* w1p;       /* GINE nn.layers.0 packed [d,d] */
-  const float* bn0_scale; /* nn.norms.0 folded */
-  const float* bn0_shift;
-  const float* w2p;       /* nn.layers.1 packed [d,d] */
-  const float* bn_scale;  /* gnn.norms[l] folded */
-  const float* bn_shift;
+  const void* w1s;        /* GINE nn.layers.0, split-packed with (e0, e1) = nn.norms.0 folded (scale, shift) */
+  const void* w2s;        /* GINE nn.layers.1, split-packed with (e0, e1) = gnn.norms[l] folded (scale, shift) */
   const float* eps;       /* device scalar */
 } sn_gnn_layer;
 
@@ -317,17 +313,11 @@ typedef struct {
   const float* nw;            /* float node encoder: weight [d_pad, F] row-major (NOT packed), zero padded rows */
   const float* n_scale;
   const float* n_shift;
-  const float* rho_out_w;     /* sign_net.rho.out.0 packed [d,d] */
-  const float* rho_scale;     /* sign_net.rho.out.1 folded */
-  const float* rho_shift;
-  const float* lin_a;         /* gnn.linear.weight[:, :d] packed */
-  const float* lin_b;         /* gnn.linear.weight[:, d:] packed */
-  const float* lin_bias;
-  const float* head_w1;       /* output_encoder.layers.0 packed [d,d] */
-  const float* head_scale;    /* output_encoder.norms.0 folded */
-  const float* head_shift;
-  const float* head_w2;       /* output_encoder.layers.1 packed [n_out, d] */
-  const float* head_b2;       /* [>= n_out] */
+  const void* rho_out_w;      /* sign_net.rho.out.0, split-packed with (e0, e1) = sign_net.rho.out.1 folded (scale, shift) */
+  const void* lin_a;          /* gnn.linear.weight[:, :d], split-packed, no epilogue vectors */
+  const void* lin_b;          /* gnn.linear.weight[:, d:], split-packed with e0 = gnn.linear.bias */
+  const void* head_w1;        /* output_encoder.layers.0, split-packed with (e0, e1) = output_encoder.norms.0 folded */
+  const void* head_w2;        /* output_encoder.layers.1 [n_out, d], split-packed with e0 = its bias */
   sn_gnn_layer layers[SN_GNN_MAX_LAYERS];
 } sn_gnn_params;
 

@@ -6,37 +6,41 @@
 //
 // This stage has few rows (one per node, no eigenvector-slot factor) and a long dependent chain
 // (3 + 2*nl_gnn + 2 Linear layers), so it is latency-bound, not throughput-bound.  Mapping: ONE workgroup of
-// 8 waves per graph (n <= 64 nodes).  The graph's node rows live in LDS images [64][d_pad+4]; for every
-// Linear, wave (row tile rt, group grp) reads its 16 rows from the input image into the MFMA operand layout
-// and computes only its share of the output tiles (the output channels are split over the 8/T waves that
-// share a row tile, T = ceil(n/16)), then writes them to the output image — one barrier per Linear.  That
-// spreads one graph's chain over all 4 SIMDs of a CU instead of one wave.  The GINE neighbour sum
-// relu(h_j + e_ji) and the pooling read the same images.
+// 8 waves per graph (n <= 64 nodes) keeps the graph's node rows in LDS for the whole stack:
+//   * X1 [64][d_pad+4] fp32 — the layer input h: read by the GINE neighbour sum relu(h_j + e_ji), by the residual and
+//     by the pooling;
+//   * SA, SB — every Linear's INPUT rows, stored already split into three bf16 planes (the fp32 products are six
+//     bf16 partial products, fused_common.hpp §"fp32 GEMMs on the bf16 matrix pipe"): the producer of a value splits
+//     it once (5.5 VALU ops) and every consumer wave reads ready-made MFMA operands (ds_read_b128 per plane, K block);
+//   * the (output tile, row tile) pairs of a Linear are dealt OUTPUT-TILE MAJOR to the 8 waves, so each weight tile
+//     (split-packed, with its epilogue vectors, sn_pack_split_f32) is fetched by exactly one wave — the weight traffic
+//     of a Linear is the matrix once per CU; one barrier per Linear;
+//   * edges of a graph repeat a handful of feature tuples (ZINC: 3 bond types): their embeddings for every layer are
+//     built once into an LDS table indexed by edge class.
 #include "fused_common.hpp"
 
 namespace sn {
 
 #ifdef SN_PROFILE
 static __device__ int g_prof_block = 0;
-__shared__ unsigned long long s_prof[16];      // per-section cycle sums of thread 0 of the selected block (LDS: cheap to update)
 #undef SN_STAMP
 #undef SN_ACCUM
 #define SN_STAMP(i) do { if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) g_prof[i] = clock64(); } while (0)
 #define SN_ACCUM(i, t0) do { if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) g_prof[i] += clock64() - (t0); } while (0)
-#define SN_T0() const long long sn_t0 = clock64()
-#define SN_LACC(i) do { if (threadIdx.x == 0) atomicAdd(&s_prof[i], (unsigned long long)(clock64() - sn_t0)); } while (0)
-#else
-#define SN_T0() do { } while (0)
-#define SN_LACC(i) do { } while (0)
 #endif
-
 
 constexpr int GNN_ROWS = SN_GNN_MAX_NODES;   // 64
 constexpr int GNN_WAVES = 8;
 constexpr int GNN_EMAX = 192;                // in-edges of one graph staged in LDS
 constexpr int GNN_CLS = 16;                  // edge-feature classes per graph whose embeddings stay in LDS for all layers
-constexpr int GNN_EEMAX = 96;                // ... of which this many can have their layer embeddings staged too
+constexpr int GNN_EEMAX = 96;                // rows of the edge-embedding area (class x layer table, or per-edge staging)
 constexpr int GNN_EEPF = (GNN_EEMAX * 32 + GNN_WAVES * 64 - 1) / (GNN_WAVES * 64);   // float4 per thread (d_pad = 128)
+
+// split image: three bf16 planes [64 rows][SP_STRIDE bytes]; inside a row the k-slots of K block kb and lane group g
+// are contiguous (kb*64 + g*16 bytes: 8 bf16 = channels 32kb + 16(s>>2) + 4g + (s&3)) -> one ds_read_b128 per plane.
+constexpr int SP_STRIDE = 272;                       // 256 + 16: staggers rows over the LDS banks
+constexpr int SP_PLANE = GNN_ROWS * SP_STRIDE;
+constexpr int SP_IMAGE = 3 * SP_PLANE;               // 52224 bytes
 
 struct GnnStruct {
   const void* x;          // int64 [N, ldx] (discrete) or float [N, F]
@@ -50,30 +54,47 @@ struct GnnStruct {
   const int32_t* eperm;
   int32_t* status;        // status[3] |= 1 if a graph has more than 64 nodes (host falls back)
   float* y;               // [B, n_out]
-  int ee_rows;            // edges whose per-layer embeddings fit the LDS staging area
+  int ee_rows;            // rows of the edge-embedding area
 };
 
-// Weight fragments of ONE output tile of a packed matrix, held in registers.
-template <int NTI>
-struct WTile { float4 w[NTI]; };
-
-template <int NTI>
-__device__ __forceinline__ void wload(WTile<NTI>& p, const float* __restrict__ wp, int nto, int ot, int lane) {
-  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(wp, (unsigned)nto * NTI * 1024);
-  const int voff = lane * 16;
-  const int base = __builtin_amdgcn_readfirstlane(ot * NTI * 1024);
+// the four channels 16*ot + 4g + t of `row` -> the three planes of a split image (exact 3-way split, fused_common.hpp)
+__device__ __forceinline__ void sp_store4(unsigned char* img, int row, int ot, int g, f32x4 v) {
+  float h[4], m[4], l[4];
 #pragma unroll
-  for (int kk = 0; kk < NTI; ++kk) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + kk * 1024, 0);
-    p.w[kk] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  for (int i = 0; i < 4; ++i) {
+    h[i] = __uint_as_float(__float_as_uint(v[i]) & 0xffff0000u);
+    const float r = v[i] - h[i];
+    m[i] = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    l[i] = r - m[i];
+  }
+  unsigned char* p = img + row * SP_STRIDE + (ot >> 1) * 64 + g * 16 + (ot & 1) * 8;
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
+  *reinterpret_cast<uint2*>(p + SP_PLANE) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
+  *reinterpret_cast<uint2*>(p + 2 * SP_PLANE) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+}
+
+// One output tile of a split-packed Linear in registers: NKB x 3 weight fragments + the 3 epilogue vectors.
+template <int NKB>
+struct WSplit { u32x4 f[NKB * 3]; f32x4 e[SPLIT_EPI]; };
+
+template <int NKB>
+__device__ __forceinline__ void wload(WSplit<NKB>& p, const void* wsp, int ot, int lane) {
+  constexpr int NFE = 3 * NKB + SPLIT_EPI;
+  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(reinterpret_cast<const float*>(wsp), 0x7fffffff);
+  const int voff = lane * 16;
+  const int base = __builtin_amdgcn_readfirstlane(ot * NFE * 1024);
+#pragma unroll
+  for (int i = 0; i < 3 * NKB; ++i) p.f[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + i * 1024, 0);
+#pragma unroll
+  for (int j = 0; j < SPLIT_EPI; ++j) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (3 * NKB + j) * 1024, 0);
+    p.e[j] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   }
 }
 
 // The (output tile, row tile) pairs a wave owns in one Linear: a contiguous range [t_lo, t_hi) of the flattened index
 // t = ot*T + rt (T = row tiles of the graph, <= 4) — OUTPUT-TILE MAJOR, so that a wave works on one output tile (two
-// at most) for all the graph's row tiles and every weight fragment is fetched by exactly one wave of the workgroup:
-// the weight traffic of a Linear is the matrix once per CU (it was once per row tile, and the time to issue those
-// loads against the 64 B/clk/CU delivery rate was as long as the MFMAs).
+// at most) for all the graph's row tiles and every weight fragment is fetched by exactly one wave of the workgroup.
 struct TileRange {
   int t_lo, t_hi, T;
   __device__ __forceinline__ bool empty() const { return t_lo >= t_hi; }
@@ -81,40 +102,31 @@ struct TileRange {
   __device__ __forceinline__ int first_ot() const { return t_lo / T; }
 };
 
-template <int NT>
-__device__ __forceinline__ f32x4 mfma_tile32(const WTile<NT>& w, const f32x4 (&in)[NT]) {
+template <int NKB>
+__device__ __forceinline__ f32x4 mfma_split_tile(const WSplit<NKB>& w, const Split8 (&x)[NKB]) {
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kk = 0; kk < NT; ++kk) {
-    if (kk & 1) {
-      a1 = mfma16(w.w[kk].x, in[kk][0], a1);
-      a1 = mfma16(w.w[kk].y, in[kk][1], a1);
-      a1 = mfma16(w.w[kk].z, in[kk][2], a1);
-      a1 = mfma16(w.w[kk].w, in[kk][3], a1);
-    } else {
-      a0 = mfma16(w.w[kk].x, in[kk][0], a0);
-      a0 = mfma16(w.w[kk].y, in[kk][1], a0);
-      a0 = mfma16(w.w[kk].z, in[kk][2], a0);
-      a0 = mfma16(w.w[kk].w, in[kk][3], a0);
-    }
+  for (int kb = 0; kb < NKB; ++kb) {
+    const u32x4 wh = w.f[3 * kb], wm = w.f[3 * kb + 1], wl = w.f[3 * kb + 2];
+    a1 = mfma_bf(wl, x[kb].h, a1);
+    a0 = mfma_bf(wm, x[kb].h, a0);
+    a1 = mfma_bf(wh, x[kb].l, a1);
+    a0 = mfma_bf(wh, x[kb].m, a0);
+    a1 = mfma_bf(wm, x[kb].m, a1);
+    a0 = mfma_bf(wh, x[kb].h, a0);
   }
   return a0 + a1;
 }
 
 // One Linear over the workgroup's rows.  The wave's TileRange is <= 4 (ot, rt) pairs touching <= 2 output tiles.
-// Weight fragments ping-pong between `pre` and `alt`: `pre` holds the first output tile's fragments on entry (fetched
-// during the previous stage); a second output tile — or, at the end, the NEXT Linear's first tile — is fetched while
-// the current one computes.  The row-tile operand is double buffered from LDS.  img: input image [64][LD];
-// epi(rt, ot, acc, e0, e1) with e* = ev*[16 ot + 4g ..] (per-channel epilogue vectors, fetched before the MFMAs).
-template <int NT, typename Epi>
-__device__ __forceinline__ void coop_gemm(WTile<NT>& pre, WTile<NT>& alt, const float* __restrict__ wp, int nto,
-                                          const float* img, int LD, TileRange tr, int lane, Epi epi,
-                                          const float* __restrict__ next_wp, int next_nto, TileRange next_tr,
-                                          const float* __restrict__ ev0 = nullptr, const float* __restrict__ ev1 = nullptr) {
-  const int g = lane >> 4;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+// Weight tiles ping-pong between `pre` and `alt`: `pre` holds the first output tile on entry (fetched during the
+// previous stage); a second output tile — or, at the end, the NEXT Linear's first tile — is fetched while the current
+// one computes.  img: split input image; epi(rt, ot, acc, e0, e1, e2) with e* the tile's epilogue vectors.
+template <int NKB, typename Epi>
+__device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, const void* wsp, const unsigned char* img,
+                                          TileRange tr, int lane, Epi epi, const void* next_wsp, TileRange next_tr) {
   if (tr.empty()) {
-    if (next_wp && !next_tr.empty()) wload<NT>(pre, next_wp, next_nto, next_tr.first_ot(), lane);   // idle here: keep the chain going
+    if (next_wsp && !next_tr.empty()) wload<NKB>(pre, next_wsp, next_tr.first_ot(), lane);   // idle here: keep the chain going
     return;
   }
   int ot0, rt0;
@@ -122,17 +134,22 @@ __device__ __forceinline__ void coop_gemm(WTile<NT>& pre, WTile<NT>& alt, const 
   int otl, rtl;
   tr.decode(tr.t_hi - 1, otl, rtl);
   const bool two_ots = otl != ot0;
-  const float* rowbase = img + (lane & 15) * LD + 4 * g;
-  f32x4 inA[NT], inB[NT];
+  const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE + (lane >> 4) * 16;
+  auto load_rows = [&](int rt, Split8 (&x)[NKB]) {
+    const unsigned char* p = rowbase + rt * 16 * SP_STRIDE;
 #pragma unroll
-  for (int kk = 0; kk < NT; ++kk) inA[kk] = lds_ld4(rowbase + rt0 * 16 * LD + 16 * kk);
+    for (int kb = 0; kb < NKB; ++kb) {
+      x[kb].h = *reinterpret_cast<const u32x4*>(p + kb * 64);
+      x[kb].m = *reinterpret_cast<const u32x4*>(p + kb * 64 + SP_PLANE);
+      x[kb].l = *reinterpret_cast<const u32x4*>(p + kb * 64 + 2 * SP_PLANE);
+    }
+  };
+  Split8 in[NKB];
+  load_rows(rt0, in);
   // prefetch: second output tile of this Linear, else the next Linear's first tile
   bool next_in_alt = false;
-  if (two_ots) wload<NT>(alt, wp, nto, otl, lane);
-  else if (next_wp && !next_tr.empty()) { wload<NT>(alt, next_wp, next_nto, next_tr.first_ot(), lane); next_in_alt = true; }
-  f32x4 e0 = ev0 ? ld4(ev0 + 16 * ot0 + 4 * g) : z4, e1 = ev1 ? ld4(ev1 + 16 * ot0 + 4 * g) : z4;
-  f32x4 f0 = z4, f1 = z4;
-  if (two_ots) { f0 = ev0 ? ld4(ev0 + 16 * otl + 4 * g) : z4; f1 = ev1 ? ld4(ev1 + 16 * otl + 4 * g) : z4; }
+  if (two_ots) wload<NKB>(alt, wsp, otl, lane);
+  else if (next_wsp && !next_tr.empty()) { wload<NKB>(alt, next_wsp, next_tr.first_ot(), lane); next_in_alt = true; }
   bool cur_is_pre = true;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -140,27 +157,20 @@ __device__ __forceinline__ void coop_gemm(WTile<NT>& pre, WTile<NT>& alt, const 
     if (t < tr.t_hi) {
       int ot, rt;
       tr.decode(t, ot, rt);
-      const bool second = ot != ot0;
-      if (second && cur_is_pre) {
+      if (ot != ot0 && cur_is_pre) {
         cur_is_pre = false;                                   // switch to the second tile (in alt); pre is free again:
-        if (next_wp && !next_tr.empty()) wload<NT>(pre, next_wp, next_nto, next_tr.first_ot(), lane);   // next Linear's first tile
+        if (next_wsp && !next_tr.empty()) wload<NKB>(pre, next_wsp, next_tr.first_ot(), lane);   // next Linear's first tile
       }
-      // operand of the NEXT pair (double buffer): its LDS latency hides behind this pair's MFMAs
-      f32x4 (&cur)[NT] = (i & 1) ? inB : inA;
-      f32x4 (&nxt)[NT] = (i & 1) ? inA : inB;
-      if (t + 1 < tr.t_hi) {
-        int ot2, rt2;
-        tr.decode(t + 1, ot2, rt2);
-#pragma unroll
-        for (int kk = 0; kk < NT; ++kk) nxt[kk] = lds_ld4(rowbase + rt2 * 16 * LD + 16 * kk);
-      }
-      const f32x4 acc = cur_is_pre ? mfma_tile32<NT>(pre, cur) : mfma_tile32<NT>(alt, cur);
-      epi(rt, ot, acc, second ? f0 : e0, second ? f1 : e1);
+      if (i > 0) load_rows(rt, in);
+      if (cur_is_pre) epi(rt, ot, mfma_split_tile<NKB>(pre, in), pre.e[0], pre.e[1], pre.e[2]);
+      else epi(rt, ot, mfma_split_tile<NKB>(alt, in), alt.e[0], alt.e[1], alt.e[2]);
     }
   }
   if (next_in_alt) {   // single-tile range: the next Linear's first tile sits in alt — hand it over in pre
 #pragma unroll
-    for (int kk = 0; kk < NT; ++kk) pre.w[kk] = alt.w[kk];
+    for (int i = 0; i < 3 * NKB; ++i) pre.f[i] = alt.f[i];
+#pragma unroll
+    for (int j = 0; j < SPLIT_EPI; ++j) pre.e[j] = alt.e[j];
   }
 }
 
@@ -168,11 +178,12 @@ template <int NT>
 __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_gnn_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
-  extern __shared__ __align__(16) float lds[];
-  float* X0 = lds;                    // [64][LD]
-  float* X1 = lds + GNN_ROWS * LD;
-  float* X2 = lds + 2 * GNN_ROWS * LD;
-  int* erow = reinterpret_cast<int*>(lds + 3 * GNN_ROWS * LD);   // [65]  CSR row pointers local to the graph
+  constexpr int NKB = (NT + 1) / 2;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  unsigned char* SA = lds_raw;                                   // split image: slot sum, then u, then the pooled row
+  unsigned char* SB = lds_raw + SP_IMAGE;                        // split image: encoder output, pos, hidden rows
+  float* X1 = reinterpret_cast<float*>(lds_raw + 2 * SP_IMAGE);  // [64][LD] fp32: h
+  int* erow = reinterpret_cast<int*>(X1 + GNN_ROWS * LD);        // [65]  CSR row pointers local to the graph
   int* esrc = erow + GNN_ROWS + 4;                               // [GNN_EMAX] local source row of every in-edge
   int* efeat = esrc + GNN_EMAX;                                  // [GNN_EMAX][edge_nf] feature words (int idx / float)
   int* ecls = efeat + GNN_EMAX * (P.n_layers > 0 ? P.edge_nf : 0);   // [GNN_EMAX] feature class of every in-edge
@@ -182,9 +193,6 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const int gi = blockIdx.x;
   SN_STAMP(0);
-#ifdef SN_PROFILE
-  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0;
-#endif
 #ifdef SN_PROFILE
   if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) for (int i = 8; i < 20; ++i) g_prof[i] = 0;
   long long pt = 0;
@@ -267,8 +275,11 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
     }
   };
 
-  WTile<NT> pre, alt;
-  if (!tr.empty()) wload<NT>(pre, P.rho_out_w, NT, tr.first_ot(), lane);       // in flight while the inputs are staged
+  WSplit<NKB> pre, alt;
+  if (!tr.empty()) wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);       // in flight while the inputs are staged
+  // ---------------------------------------------------------------- clear the split images (K padding must read as 0)
+  for (int i = threadIdx.x; i < 2 * SP_IMAGE / 16; i += GNN_WAVES * 64)
+    reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
   // ---------------------------------------------------------------- per-graph CSR + edge data -> LDS (once)
   {
     const int EF = P.edge_nf;
@@ -287,10 +298,10 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       }
     }
   }
+  __syncthreads();                                   // images cleared, efeat complete
   // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
   if (P.n_layers > 0) {
     const int EF = P.edge_nf;
-    __syncthreads();                                   // efeat is complete
     int lead = -1;
     if ((int)threadIdx.x < ne) {
       const int k = threadIdx.x;
@@ -320,19 +331,23 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       }
     }
   }
-  // ---------------------------------------------------------------- stage the slot sum (rho output) in X1 (zero padded to D)
+  // ---------------------------------------------------------------- stage the slot sum (rho output), split, in SA
   if ((d & 3) == 0) {
     for (int i = threadIdx.x; i < n * (D / 4); i += GNN_WAVES * 64) {
-      const int rr = i / (D / 4), c = 4 * (i % (D / 4));
-      lds_st4(X1 + rr * LD + c, c < d ? ld4(S.rho_sum + (int64_t)(gs + rr) * d + c) : zero4);
+      const int rr = i / (D / 4), c4 = i % (D / 4);
+      const f32x4 v = 4 * c4 < d ? ld4(S.rho_sum + (int64_t)(gs + rr) * d + 4 * c4) : zero4;
+      sp_store4(SA, rr, c4 >> 2, c4 & 3, v);
     }
   } else {
-    for (int i = threadIdx.x; i < n * D; i += GNN_WAVES * 64) {
-      const int rr = i / D, c = i % D;
-      X1[rr * LD + c] = c < d ? S.rho_sum[(int64_t)(gs + rr) * d + c] : 0.f;
+    for (int i = threadIdx.x; i < n * (D / 4); i += GNN_WAVES * 64) {
+      const int rr = i / (D / 4), c4 = i % (D / 4);
+      f32x4 v = zero4;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) if (4 * c4 + qq < d) v[qq] = S.rho_sum[(int64_t)(gs + rr) * d + 4 * c4 + qq];
+      sp_store4(SA, rr, c4 >> 2, c4 & 3, v);
     }
   }
-  // ---------------------------------------------------------------- input encoder -> X0 (model.py:37)
+  // ---------------------------------------------------------------- input encoder -> SB (model.py:37)
   if (P.node_discrete) {
     for (int t = tr.t_lo; t < tr.t_hi; ++t) {
       int ot, rt;
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
             for (int qq = 0; qq < 4; ++qq) if (c + qq < d) s[qq] += trow[c + qq];
           }
         }
-        lds_st4(X0 + row * LD + c, s);
+        sp_store4(SB, row, ot, g, s);
       }
     }
   } else {
@@ -366,42 +381,39 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) acc[qq] += a * P.nw[(c + qq) * P.node_nf + f];   // nw: [d_pad, F] row-major
         }
-        lds_st4(X0 + row * LD + c, relu4(acc * ld4(P.n_scale + c) + ld4(P.n_shift + c)));
+        sp_store4(SB, row, ot, g, relu4(acc * ld4(P.n_scale + c) + ld4(P.n_shift + c)));
       }
     }
   }
   __syncthreads();
   SN_STAMP(1);
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
-  // ---------------------------------------------------------------- pos = BN(W_out . slot_sum): X1 -> X2   (sign_net.py:71)
-  coop_gemm<NT>(pre, alt, P.rho_out_w, NT, X1, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
-    lds_st4(X2 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc * sc + sh);
-  }, P.lin_a, NT, tr, P.rho_scale, P.rho_shift);
+  // ---------------------------------------------------------------- h = Linear(cat[x, pos]) (model.py:39-40), pos = BN(W_out . slot_sum)
+  //   (sign_net.py:71).  Order: x part (SB -> X1), pos (SA -> SB, SB being free after a barrier), pos part (SB -> X1 +=).
+  coop_gemm<NKB>(pre, alt, P.lin_a, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) {
+    lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);
+  }, P.rho_out_w, tr);
   __syncthreads();
   SN_STAMP(20);
-  // ---------------------------------------------------------------- h = Linear(cat[x, pos]): X0, X2 -> X1    (model.py:39-40)
-  coop_gemm<NT>(pre, alt, P.lin_a, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4) {
-    lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);      // readers of X1 (slot sum) passed a barrier
-  }, P.lin_b, NT, tr);
-  coop_gemm<NT>(pre, alt, P.lin_b, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4) {
+  coop_gemm<NKB>(pre, alt, P.rho_out_w, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
+    sp_store4(SB, rt * 16 + li, ot, g, acc * sc + sh);
+  }, P.lin_b, tr);
+  __syncthreads();
+  coop_gemm<NKB>(pre, alt, P.lin_b, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
     float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
     lds_st4(o, (lds_ld4(o) + acc) + bias);
-  }, P.n_layers > 0 ? P.layers[0].w1p : P.head_w1, NT, P.n_layers > 0 ? tr : hr, P.lin_bias);
+  }, P.n_layers > 0 ? P.layers[0].w1s : P.head_w1, P.n_layers > 0 ? tr : hr);
   ee_store();
   __syncthreads();
   SN_STAMP(2);
   // ---------------------------------------------------------------- GINE layers: h lives in X1           (model.py:47-55)
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_gnn_layer& Lp = P.layers[l];
-    // u = sum_{j->i} relu(h_j + e_ji) + (1+eps) h_i  for my (row tile, channel tile) pairs: X1 -> X2
+    // u = sum_{j->i} relu(h_j + e_ji) + (1+eps) h_i  for my (channel tile, row tile) pairs: X1 -> SA (split)
 #ifdef SN_PROFILE
     pt = clock64();
 #endif
     ee_fetch(l + 1);   // next layer's edge embeddings: in flight during this aggregation
-    SN_ACCUM(8, pt);
-#ifdef SN_PROFILE
-    pt = clock64();
-#endif
     {
       const float sc = 1.f + *Lp.eps;
 #pragma unroll 1
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
           const f32x4 self = lds_ld4(X1 + row * LD + c) * sc;
           u = u + self;
         }
-        lds_st4(X2 + row * LD + c, u);
+        sp_store4(SA, row, ot, g, u);
       }
     }
     __syncthreads();
@@ -450,36 +462,32 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
     pt = clock64();
 #endif
     ee_store();        // every wave is done reading this layer's embeddings
-    SN_ACCUM(10, pt);
-#ifdef SN_PROFILE
-    pt = clock64();
-#endif
-    // nn: Linear . BN . ReLU : X2 -> X0
-    coop_gemm<NT>(pre, alt, Lp.w1p, NT, X2, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
-      lds_st4(X0 + (rt * 16 + li) * LD + 16 * ot + 4 * g, relu4(acc * sc + sh));
-    }, Lp.w2p, NT, tr, Lp.bn0_scale, Lp.bn0_shift);
+    // nn: Linear . BN . ReLU : SA -> SB
+    coop_gemm<NKB>(pre, alt, Lp.w1s, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
+      sp_store4(SB, rt * 16 + li, ot, g, relu4(acc * sc + sh));
+    }, Lp.w2s, tr);
     __syncthreads();
     SN_ACCUM(11, pt);
 #ifdef SN_PROFILE
     pt = clock64();
 #endif
-    // Linear ; BN . ReLU ; + previous_x : X0 -> X1 (my tiles only: nobody else reads them at this point)
+    // Linear ; BN . ReLU ; + previous_x : SB -> X1 (my tiles only: nobody else reads them at this point)
     const bool lastl = l + 1 == P.n_layers;
-    coop_gemm<NT>(pre, alt, Lp.w2p, NT, X0, LD, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
+    coop_gemm<NKB>(pre, alt, Lp.w2s, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
       float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
       lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
-    }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1p, NT, lastl ? hr : tr, Lp.bn_scale, Lp.bn_shift);
+    }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
     __syncthreads();
     SN_ACCUM(12, pt);
   }
   SN_STAMP(3);
-  // ---------------------------------------------------------------- add pooling -> row 0 of X2 (rows 1..15 zero)  (model.py:57-61)
-  for (int c = threadIdx.x; c < 16 * LD; c += GNN_WAVES * 64) {
-    const int rr = c / LD, cc = c - rr * LD;
-    float s = 0.f;
-    if (rr == 0 && cc < D)
-      for (int j = 0; j < n; ++j) s += X1[j * LD + cc];
-    X2[c] = s;
+  // ---------------------------------------------------------------- add pooling -> row 0 of SA (rows 1..15: zero)   (model.py:57-61)
+  for (int i = threadIdx.x; i < 16 * (D / 4); i += GNN_WAVES * 64) {
+    const int rr = i / (D / 4), c4 = i % (D / 4);
+    f32x4 s = zero4;
+    if (rr == 0)
+      for (int j = 0; j < n; ++j) s += lds_ld4(X1 + j * LD + 4 * c4);
+    sp_store4(SA, rr, c4 >> 2, c4 & 3, s);
   }
   __syncthreads();
   SN_STAMP(4);
@@ -488,23 +496,20 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   h2.T = 1;
   h2.t_lo = 0;
   h2.t_hi = wave == 0 ? 1 : 0;
-  coop_gemm<NT>(pre, alt, P.head_w1, NT, X2, LD, hr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh) {
-    lds_st4(X0 + li * LD + 16 * ot + 4 * g, relu4(acc * sc + sh));
-  }, wave == 0 ? P.head_w2 : nullptr, 1, h2, P.head_scale, P.head_shift);
+  coop_gemm<NKB>(pre, alt, P.head_w1, SA, hr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
+    sp_store4(SB, li, ot, g, relu4(acc * sc + sh));
+  }, wave == 0 ? P.head_w2 : nullptr, h2);
   __syncthreads();
-  coop_gemm<NT>(pre, alt, P.head_w2, 1, X0, LD, h2, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4) {
+  coop_gemm<NKB>(pre, alt, P.head_w2, SB, h2, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
     if (li == 0) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int c = 4 * g + qq;
-        if (c < P.n_out) S.y[(int64_t)gi * P.n_out + c] = acc[qq] + P.head_b2[c];
+        if (c < P.n_out) S.y[(int64_t)gi * P.n_out + c] = acc[qq] + bias[qq];
       }
     }
-  }, nullptr, 0, h2);
+  }, nullptr, h2);
   SN_STAMP(5);
-#ifdef SN_PROFILE
-  if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) for (int i = 0; i < 16; ++i) g_prof[40 + i] = (long long)s_prof[i];
-#endif
 #ifdef SN_PROFILE
   if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) { g_prof[6] = n; g_prof[7] = ne; }
 #endif
@@ -513,7 +518,8 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
 template <int NT>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t base = (size_t)(3 * GNN_ROWS * LD) * sizeof(float) + (size_t)(GNN_ROWS + 4 + GNN_EMAX * (3 + (P.n_layers > 0 ? P.edge_nf : 0)) + GNN_CLS) * sizeof(int);
+  const size_t base = (size_t)2 * SP_IMAGE + (size_t)(GNN_ROWS * LD) * sizeof(float) +
+                      (size_t)(GNN_ROWS + 4 + GNN_EMAX * (3 + (P.n_layers > 0 ? P.edge_nf : 0)) + GNN_CLS) * sizeof(int);
   const size_t lds_cap = 160 * 1024 - 512;     // the kernel also has a few bytes of static LDS (__syncthreads_count)
   const size_t room = base < lds_cap ? lds_cap - base : 0;
   int ee_rows = (int)(room / ((size_t)LD * sizeof(float)));
@@ -555,15 +561,12 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
              "sn_gnn_fused_f32: node feature count %d unsupported", P.node_nf);
   SN_REQUIRE(P.n_layers == 0 || (edge_attr && P.edge_nf >= 1 && P.edge_nf <= (P.edge_discrete ? 10 : 16) && lde >= P.edge_nf),
              "sn_gnn_fused_f32: edge feature count %d unsupported", P.edge_nf);
-  SN_REQUIRE(P.rho_out_w && P.rho_scale && P.rho_shift && P.lin_a && P.lin_b && P.lin_bias && P.head_w1 && P.head_scale &&
-                 P.head_shift && P.head_w2 && P.head_b2,
-             "sn_gnn_fused_f32: parameters missing");
+  SN_REQUIRE(P.rho_out_w && P.lin_a && P.lin_b && P.head_w1 && P.head_w2, "sn_gnn_fused_f32: parameters missing");
   if (P.node_discrete) { for (int f = 0; f < P.node_nf; ++f) SN_REQUIRE(P.ntab[f], "sn_gnn_fused_f32: node table %d missing", f); }
   else SN_REQUIRE(P.nw && P.n_scale && P.n_shift, "sn_gnn_fused_f32: node MLP parameters missing");
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_gnn_layer& L = P.layers[l];
-    SN_REQUIRE(L.w1p && L.bn0_scale && L.bn0_shift && L.w2p && L.bn_scale && L.bn_shift && L.eps,
-               "sn_gnn_fused_f32: layer %d parameters missing", l);
+    SN_REQUIRE(L.w1s && L.w2s && L.eps, "sn_gnn_fused_f32: layer %d parameters missing", l);
     if (P.edge_discrete) { for (int f = 0; f < P.edge_nf; ++f) SN_REQUIRE(L.etab[f], "sn_gnn_fused_f32: layer %d edge table %d missing", l, f); }
     else SN_REQUIRE(L.ew && L.e_scale && L.e_shift, "sn_gnn_fused_f32: layer %d edge MLP parameters missing", l);
   }

@@ -157,16 +157,14 @@ GNN_MAX_NODES = 64
 
 class _GnnLayer(C.Structure):
     _fields_ = [("etab", C.c_void_p * 10)] + \
-               [(n, C.c_void_p) for n in ("ew", "e_scale", "e_shift", "w1p", "bn0_scale", "bn0_shift", "w2p", "bn_scale",
-                                          "bn_shift", "eps")]
+               [(n, C.c_void_p) for n in ("ew", "e_scale", "e_shift", "w1s", "w2s", "eps")]
 
 
 class _GnnParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("d", "n_layers", "n_out", "reserved", "node_discrete", "node_nf", "edge_discrete",
                                        "edge_nf")] + \
                [("ntab", C.c_void_p * 10)] + \
-               [(n, C.c_void_p) for n in ("nw", "n_scale", "n_shift", "rho_out_w", "rho_scale", "rho_shift", "lin_a", "lin_b",
-                                          "lin_bias", "head_w1", "head_scale", "head_shift", "head_w2", "head_b2")] + \
+               [(n, C.c_void_p) for n in ("nw", "n_scale", "n_shift", "rho_out_w", "lin_a", "lin_b", "head_w1", "head_w2")] + \
                [("layers", _GnnLayer * GNN_MAX_LAYERS)]
 
 
@@ -205,18 +203,15 @@ class GnnPlan:
             P.nw = hold(wp)
             s, h = ops.bn_fold(gnn.input_encoder.norms[0], dp)
             P.n_scale, P.n_shift = hold(s), hold(h)
-        P.rho_out_w = hold(ops.pack_weight(rho_out[0].weight.detach()))
         s, h = ops.bn_fold(rho_out[1], dp)
-        P.rho_scale, P.rho_shift = hold(s), hold(h)
-        W = gnn.linear.weight.detach()
-        P.lin_a, P.lin_b = hold(ops.pack_weight(W[:, :d])), hold(ops.pack_weight(W[:, d:]))
-        P.lin_bias = hold(ops.pad_vec(gnn.linear.bias, dp))
+        P.rho_out_w = hold(ops.pack_split(rho_out[0].weight.detach(), s, h))
+        W = gnn.linear.weight.detach()                                  # [d, 2d]: x part | pos part
+        P.lin_a = hold(ops.pack_split(W[:, :d]))
+        P.lin_b = hold(ops.pack_split(W[:, d:], gnn.linear.bias.detach()))
         oe = gnn.output_encoder
-        P.head_w1 = hold(ops.pack_weight(oe.layers[0].weight.detach()))
         s, h = ops.bn_fold(oe.norms[0], dp)
-        P.head_scale, P.head_shift = hold(s), hold(h)
-        P.head_w2 = hold(ops.pack_weight(oe.layers[1].weight.detach()))
-        P.head_b2 = hold(ops.pad_vec(oe.layers[1].bias, 16))
+        P.head_w1 = hold(ops.pack_split(oe.layers[0].weight.detach(), s, h))
+        P.head_w2 = hold(ops.pack_split(oe.layers[1].weight.detach(), oe.layers[1].bias.detach()))
         for l, (enc, conv, norm) in enumerate(zip(gnn.edge_encoders, gnn.convs, gnn.norms)):
             Lp = P.layers[l]
             if self.edge_discrete:
@@ -229,12 +224,10 @@ class GnnPlan:
                 Lp.ew = hold(wp)
                 s, h = ops.bn_fold(enc.norms[0], dp)
                 Lp.e_scale, Lp.e_shift = hold(s), hold(h)
-            Lp.w1p = hold(ops.pack_weight(conv.nn.layers[0].weight.detach()))
             s, h = ops.bn_fold(conv.nn.norms[0], dp)
-            Lp.bn0_scale, Lp.bn0_shift = hold(s), hold(h)
-            Lp.w2p = hold(ops.pack_weight(conv.nn.layers[1].weight.detach()))
+            Lp.w1s = hold(ops.pack_split(conv.nn.layers[0].weight.detach(), s, h))
             s, h = ops.bn_fold(norm, dp)
-            Lp.bn_scale, Lp.bn_shift = hold(s), hold(h)
+            Lp.w2s = hold(ops.pack_split(conv.nn.layers[1].weight.detach(), s, h))
             Lp.eps = hold(conv.layer.eps.detach())
         self.params = P
 
