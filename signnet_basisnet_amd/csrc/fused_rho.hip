@@ -182,7 +182,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     for (int l = 0; l < P.n_layers; ++l) {
       const sn_rho_layer& Lp = P.layers[l];
       const void* wafter = (l + 1 < P.n_layers) ? P.layers[l + 1].wq : wfirst;   // the stream restarts at layer 0 for the next bin
-      f32x4 o[NT], y[NT];
+      f32x4 o[NT];
       Split8 sp[NKB];
       if (wave_live) split_rows<NT>(x, sp);
       if (mfma_attn) {
@@ -307,18 +307,22 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
-      wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { y[ot] = acc + x[ot]; });
+      wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
       if (wave_live) {
-        masked_layernorm<NT>(y, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
-        split_rows<NT>(y, sp);
+        masked_layernorm<NT>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
+        split_rows<NT>(x, sp);
       }
       SN_STAMP(7);
       // FFN: w2(relu(w1 y + b1)) + b2 + y -> LayerNorm               (transformer_module.py:113-127)
       wg_gemm_split<NT, NT, false>(ring, Lp.w1, Lp.w2, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
       SN_STAMP(8);
       if (wave_live) split_rows<NT>(o, sp);
-      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + y[ot]; });
+#ifdef SN_PROFILE
+      asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+#endif
+      SN_STAMP(14);
+      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + x[ot]; });
       SN_STAMP(9);
       if (wave_live) masked_layernorm<NT>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, g, valid);
       SN_STAMP(10);
@@ -372,6 +376,9 @@ static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_b
     cus = n > 0 ? n : 256;
   }
   int64_t grid = bins_bound < (int64_t)2 * cus ? bins_bound : (int64_t)2 * cus;
+#ifdef SN_RHO_GRID1
+  grid = cus;
+#endif
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL((k_rho_fused<NT, REGATTN>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
   return SN_OK;
