@@ -105,6 +105,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
   if (S.meta[5] != 0) return;
   const int d = P.d, H = P.heads, dk = d / H;
   const float temp = sqrtf((float)dk);
+  const float rtemp = 1.0f / temp;
   { SN_PROF_ON(true); SN_STAMP(13); }
   // LayerNorm gamma / beta of every layer, staged once: read between GEMMs they would otherwise wait (vmcnt 0) behind
   // the weight stream's in-flight LDS-DMA plus their own L2 latency, twice per layer
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         f32x4 qf[NT], sc[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) sc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc / temp; });   // q / sqrt(dk)  (:52)
+        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc * rtemp; });   // q / sqrt(dk)  (:52), as a multiply by the rounded reciprocal (<= 1 ulp)
         wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 kf, f32x4, f32x4, f32x4, f32x4) {
           // lane (query = li, g) accumulates S[query][key = 4g + r] of head ot / CPH
           const int h = ot / CPH < 4 ? ot / CPH : 3;
