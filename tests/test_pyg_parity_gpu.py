@@ -200,3 +200,59 @@ def test_split_gemm_path_is_fp32_accurate():
     r_layer = (st["rho_sum"].cpu().double() - rs).abs().max().item() / rs.abs().max().item()
     r_fused = (st["rho_sum_fused"].cpu().double() - rs).abs().max().item() / rs.abs().max().item()
     assert r_layer < 5e-6 and r_fused < 5e-6 and r_fused < 4 * r_layer + 5e-7, (r_layer, r_fused)
+
+
+def _bn_randomize(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+
+
+def test_large_batch_fused_equals_layer_path():
+    """BASELINE configs[3] per-rank shape and beyond: 640 graphs (N ~ 14.7k nodes: the five-launch plan path, more
+    bins than resident workgroups for every stage).  Size-independent checks: the fused stages agree with the
+    layer-at-a-time path on every stage, and the output of graph i does not depend on what else is in the batch."""
+    from signnet_basisnet_amd import dist as D
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(5)
+    m = SignNetGNN(None, None, 128, 1, 4, 6, variant="gine", max_k=16)
+    _bn_randomize(m, 6)
+    m = m.cuda().eval()
+    host = synth.make_batch(640, seed=21)
+    data = synth.batch_to(host, "cuda:0")
+    with torch.no_grad():
+        y_fused = m(data)
+        m.check_last()
+        y_layer, st = m(data, return_stages=True)
+        close(st["phi_fused"], st["phi"], "fused phi vs layer path (640 graphs)")
+        close(st["rho_sum_fused"], st["rho_sum"], "fused rho vs layer path (640 graphs)")
+        close(y_fused, y_layer, "fused forward vs layer path (640 graphs)")
+        # batch independence: a shard run alone gives the same rows
+        shard = synth.batch_to(D.shard_batch(host, 1, 5), "cuda:0")          # graphs [128, 256)
+        y_shard = m(shard)
+        m.check_last()
+    close(y_shard, y_fused[128:256], "shard alone vs inside the big batch")
+
+
+def test_fused_width_not_multiple_of_32():
+    """d = 108 (Alchemy's hidden width): 7 output tiles, a half-filled last K block of the split GEMMs."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(8)
+    m = SignNetGNN(6, 4, 108, 12, 3, 3, variant="alchemy", max_k=12)
+    _bn_randomize(m, 9)
+    host = synth.make_batch(20, seed=31, features="alchemy")
+    cfg = O.make_cfg("alchemy", 6, 4, 108, 12, 3, 3)
+    with torch.no_grad():
+        ref = O.signnet_gnn({k: v.detach().clone() for k, v in m.state_dict().items()}, cfg, synth.batch_to(host, "cpu"),
+                            training=False, max_k=12)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(synth.batch_to(host, "cuda:0"))
+        m.check_last()
+    close(y, ref, "alchemy d=108 fused forward vs oracle")
