@@ -56,19 +56,6 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 acc) {
 // i.e. the MFMA "A" operand is the weight fragment (i = output channel), the "B" operand is the
 // activation fragment (j = row), and the k index of lane group g at step (kk, t) is 16*kk+4*g+t —
 // a permutation of k that both operands share, so the sum is over every k exactly once.
-__device__ __forceinline__ f32x4 tile_dot(const float4* __restrict__ wp_ot, const f32x4* in, int nti,
-                                          int lane) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int kk = 0; kk < nti; ++kk) {
-    float4 w = wp_ot[kk * 64 + lane];
-    acc = mfma16(w.x, in[kk][0], acc);
-    acc = mfma16(w.y, in[kk][1], acc);
-    acc = mfma16(w.z, in[kk][2], acc);
-    acc = mfma16(w.w, in[kk][3], acc);
-  }
-  return acc;
-}
-
 // XCD-aware remap of a 1-D block id: consecutive *logical* blocks land on the same XCD (and its
 // private L2) in chunks of `chunk` blocks.  Hardware places physical block b on XCD b % 8
 // (observed, used for speed only).  Returns a logical id in [0, ceil(nblk/(8*chunk))*8*chunk);
