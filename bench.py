@@ -170,8 +170,9 @@ def main():
             "value": total_graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 in / fp32 out / fp32 accumulate; phi and rho Linears: operands split exactly into 3 bf16 pieces, "
-                          "6 partial products on the bf16 matrix pipe (error <= 2^-23 |x||w| per product); GINE Linears: fp32-input MFMA",
+            "arithmetic": "fp32 in / fp32 out / fp32 accumulate; every [d,d] Linear of phi, rho and GINE: operands split exactly into "
+                          "3 bf16 pieces, 6 partial products on the bf16 matrix pipe (error <= 2^-23 |x||w| per product); "
+                          "attention scores and P.V: fp32-input MFMA",
             "config": {"workload": WORKLOAD["name"], "graphs_per_gpu": WORKLOAD["B"], "global_batch": WORKLOAD["B"] * world,
                        "nodes": int(fl["N"]), "valid_rows": int(fl["M"]), "parallelism": f"graph-sharded dp{world}, no collective",
                        "gflop_per_step": fl["total"] / 1e9},

@@ -481,7 +481,8 @@ def _roof_rho(fl, wl, host, mean_ms, per_step):
 
 
 def _roof_gnn(fl, wl, host, mean_ms, per_step):
-    return _mfma_roof("sn_gnn_fused_f32 (k_gnn_coop)", fl["gnn"] + 2 * fl["N"] * wl["hidden"] ** 2, mean_ms, per_step)
+    return _mfma_roof("sn_gnn_fused_f32 (k_gnn_coop)", fl["gnn"] + 2 * fl["N"] * wl["hidden"] ** 2, mean_ms, per_step,
+                      MFMA_SPLIT_F32_PEAK_TF, _SPLIT_NOTE)
 
 
 KERNEL_ROOFLINE = {"sn_masked_linear_f32": _roof_linear, "sn_phi_fused_f32": _roof_phi, "sn_rho_fused_f32": _roof_rho,
