@@ -73,7 +73,8 @@ def make_batch(num_graphs: int, seed: int = 1234, n_lo: int = 9, n_hi: int = 37,
         evecs.append(V.reshape(-1))
         batch.append(np.full(n, b, dtype=np.int64))
         off += n
-    edge_index = torch.from_numpy(np.concatenate(eis, axis=1)) if eis else torch.zeros(2, 0, dtype=torch.long)
+    # C-contiguous [2, E], as PyG's collate produces it (a strided edge_index costs every forward a device copy)
+    edge_index = torch.from_numpy(np.ascontiguousarray(np.concatenate(eis, axis=1))) if eis else torch.zeros(2, 0, dtype=torch.long)
     N, E = off, edge_index.shape[1]
     g = torch.Generator().manual_seed(seed)
     if features == "zinc":
