@@ -139,12 +139,21 @@ struct WRing {
   // per-lane address per DMA (which the compiler would precompute for every chunk of every matrix and spill).
   __device__ __forceinline__ void issue(const void* w, int c, int slot) const {
     const __amdgpu_buffer_rsrc_t rs = weight_rsrc(reinterpret_cast<const float*>(w), 0x7fffffff);
-    lds_char_t* dst = base + slot * CHUNK;
+    // (the wave's fragment offset is laundered through an empty asm: otherwise the compiler precomputes the LDS
+    //  address and the buffer offset of every (slot, fragment) pair of every GEMM as loop invariants and the ~40
+    //  scalar registers they occupy spill — and a kernel with a private segment pays ~6 us at launch)
+    int wo = wave * 1024;
+    asm volatile("" : "+s"(wo));
+    lds_char_t* dst = base + slot * CHUNK + wo;
+    const int src = c * CHUNK + wo;
 #pragma unroll
     for (int f = 0; f < LPC; ++f) {
-      int fr = wave + 4 * f;
-      if (4 * f + 3 >= NFE) fr = fr < NFE - 1 ? fr : NFE - 1;   // branch-free tail: the surplus waves re-stage the last fragment
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + fr * 1024), 16, lane * 16, c * CHUNK + fr * 1024, 0, 0);
+      int fo = 4096 * f;
+      if (4 * f + 3 >= NFE) {            // branch-free tail: the surplus waves re-stage the last fragment
+        const int last = (NFE - 1) * 1024 - wo;
+        fo = fo < last ? fo : last;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + fo), 16, lane * 16, src + fo, 0, 0);
     }
   }
   // start of the weight stream (once per kernel when the GEMMs chain, else once per GEMM): chunks 0..RING-1 of `w`
@@ -170,7 +179,7 @@ struct WFrag { u32x4 h, m, l; };
 // `live` = this wave has rows (a dead wave only keeps the stream going).  `wnext` (never null): the matrix whose
 // first chunks are staged behind this one's — the next wg_gemm_split() of the workgroup must be on `wnext`; the
 // kernel starts the stream with WRing::prologue(first matrix) and ends with WRing::drain().  SWAP: operands exchanged -> acc[r] = Y[row = 4g + r][out = 16*ot + (l&15)].
-template <int NT, int NTO, bool SWAP, typename Pre, typename Epi>
+template <int NT, int NTO, bool SWAP, bool EPIV = true, typename Pre, typename Epi>
 __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, const void* wnext, bool live,
                                               const Split8 (&xs)[(NT + 1) / 2], Pre pre, Epi epi) {
   using R = WRing<NT>;
@@ -188,7 +197,9 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, co
     }
   };
   if (live) {
-    const lds_char_t* lbase = ring.base + ring.lane * 16;
+    int ln16 = ring.lane * 16;
+    asm volatile("" : "+v"(ln16));   // per call: keeps the per-lane fragment addresses of every GEMM from being hoisted and held
+    const lds_char_t* lbase = ring.base + ln16;
     auto rd = [&](int c, int kb) {
       const lds_char_t* p = lbase + slot(c) * R::CHUNK + kb * 3072;
       WFrag f;
@@ -219,8 +230,11 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, co
     for (int ot = 0; ot < NTO; ++ot) {
       f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
       // epilogue operands first: their LDS latency hides behind this tile's MFMAs
-      const lds_char_t* pe = lbase + slot(ot) * R::CHUNK + R::NF * 1024;
-      const f32x4 e0 = *(lds_f32x4*)(pe), e1 = *(lds_f32x4*)(pe + 1024), e2 = *(lds_f32x4*)(pe + 2048);
+      f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0;
+      if (EPIV) {     // EPIV = false: the Linear has no epilogue vectors (their fragments are still staged, never read)
+        const lds_char_t* pe = lbase + slot(ot) * R::CHUNK + R::NF * 1024;
+        e0 = *(lds_f32x4*)(pe); e1 = *(lds_f32x4*)(pe + 1024); e2 = *(lds_f32x4*)(pe + 2048);
+      }
       const f32x4 pv = pre(ot);
 #pragma unroll
       for (int kb = 0; kb + 1 < NKB; ++kb) {

@@ -46,7 +46,9 @@ struct PhiStruct {
 
 constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
 
-template <int NT>
+// HID1: layer 0 is Linear(1->1).BN.ReLU.Linear(1->d) (GINESignNetPyG) — no [d,d] GEMM in layer 0; else Linear(1->d)...Linear(d->d)
+// (Alchemy).  A template parameter so that the variant without the layer-0 GEMM does not carry its registers.
+template <int NT, bool HID1>
 __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;  // +4 floats: conflict-free ds_write_b128 of 8 consecutive rows
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
   Ring ring;
   ring.init(lds_raw, wave, lane);
   // first [d,d] Linear of a (bin, sign) pass — where the weight stream (re)starts
-  const void* wfirst = (P.hid0 != 1) ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
+  const void* wfirst = !HID1 ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
   if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
       pt = clock64();
 #endif
       // -------------------------------------------------------------- layer 0
-      if (P.hid0 == 1) {
+      if (HID1) {
         // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
         if (wave_live) {
           const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
@@ -300,14 +302,14 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
   ring.drain();
 }
 
-template <int NT>
+template <int NT, bool HID1>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   const size_t lds = (size_t)WRing<NT>::BYTES + (size_t)(PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_phi_fused<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_phi_fused<NT, HID1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_phi_fused_f32: cannot raise the dynamic LDS limit to %zu", lds);
     int dev = 0, n = 256;
@@ -316,7 +318,7 @@ static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st
   }
   int64_t grid = S.max_bins < (int64_t)2 * cus ? S.max_bins : (int64_t)2 * cus;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_phi_fused<NT>), dim3((unsigned)grid), dim3(PHI_R * 4), lds, st, S, P);
+  hipLaunchKernelGGL((k_phi_fused<NT, HID1>), dim3((unsigned)grid), dim3(PHI_R * 4), lds, st, S, P);
   return SN_OK;
 }
 
@@ -350,15 +352,29 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
               bins->phi_col_off, bins->meta, bins->phi_max_bins, kmax, K, out};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
-  switch ((P.d + 15) / 16) {
-    case 1: rc = launch_phi<1>(S, P, st); break;
-    case 2: rc = launch_phi<2>(S, P, st); break;
-    case 3: rc = launch_phi<3>(S, P, st); break;
-    case 4: rc = launch_phi<4>(S, P, st); break;
-    case 5: rc = launch_phi<5>(S, P, st); break;
-    case 6: rc = launch_phi<6>(S, P, st); break;
-    case 7: rc = launch_phi<7>(S, P, st); break;
-    default: rc = launch_phi<8>(S, P, st); break;
+  const int nt = (P.d + 15) / 16;
+  if (P.hid0 == 1) {
+    switch (nt) {
+      case 1: rc = launch_phi<1, true>(S, P, st); break;
+      case 2: rc = launch_phi<2, true>(S, P, st); break;
+      case 3: rc = launch_phi<3, true>(S, P, st); break;
+      case 4: rc = launch_phi<4, true>(S, P, st); break;
+      case 5: rc = launch_phi<5, true>(S, P, st); break;
+      case 6: rc = launch_phi<6, true>(S, P, st); break;
+      case 7: rc = launch_phi<7, true>(S, P, st); break;
+      default: rc = launch_phi<8, true>(S, P, st); break;
+    }
+  } else {
+    switch (nt) {
+      case 1: rc = launch_phi<1, false>(S, P, st); break;
+      case 2: rc = launch_phi<2, false>(S, P, st); break;
+      case 3: rc = launch_phi<3, false>(S, P, st); break;
+      case 4: rc = launch_phi<4, false>(S, P, st); break;
+      case 5: rc = launch_phi<5, false>(S, P, st); break;
+      case 6: rc = launch_phi<6, false>(S, P, st); break;
+      case 7: rc = launch_phi<7, false>(S, P, st); break;
+      default: rc = launch_phi<8, false>(S, P, st); break;
+    }
   }
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_phi_fused_f32");

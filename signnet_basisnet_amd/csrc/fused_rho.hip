@@ -192,10 +192,10 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         // then v (swapped operands: V[key = 4g+r][c = 16ot + li]) with O^T = V^T.P^T in its epilogue (v is never stored).
         constexpr int CPH = NT / 4 > 0 ? NT / 4 : 1;   // 16-channel chunks per head
         f32x4 qf[NT], sc[4];
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc * rtemp; });   // q / sqrt(dk)  (:52), as a multiply by the rounded reciprocal (<= 1 ulp)
 #pragma unroll
         for (int h = 0; h < 4; ++h) sc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc * rtemp; });   // q / sqrt(dk)  (:52), as a multiply by the rounded reciprocal (<= 1 ulp)
-        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 kf, f32x4, f32x4, f32x4, f32x4) {
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 kf, f32x4, f32x4, f32x4, f32x4) {
           // lane (query = li, g) accumulates S[query][key = 4g + r] of head ot / CPH
           const int h = ot / CPH < 4 ? ot / CPH : 3;
           sc[h] = mfma16(kf[0], qf[ot][0], sc[h]);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
           }
         }
         SN_STAMP(4);
-        wg_gemm_split<NT, NT, true>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 vt, f32x4, f32x4, f32x4, f32x4) {
+        wg_gemm_split<NT, NT, true, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 vt, f32x4, f32x4, f32x4, f32x4) {
           // O^T[c][query] = sum_key V[key][c] P[query][key]  -> lane (query, g) holds O[query][16*ot + 4g + r]
           const int h = ot / CPH < 4 ? ot / CPH : 3;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -233,15 +233,15 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         });
       } else {
         // ======== attention through LDS (nodes of more than 16 slots span several waves' tiles) ========
-        wg_gemm_split<NT, NT, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
-        wg_gemm_split<NT, NT, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
         lds_barrier();
         float qh[DKMAX];
         const int hc = g * dk;
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
         // (q rows are written and read by the same wave only: no barrier before A is reused for v)
-        wg_gemm_split<NT, NT, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
         lds_barrier();
         float m = -INFINITY;
         float oh[DKMAX];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
-      wg_gemm_split<NT, NT, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
+      wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
       if (wave_live) {
         masked_layernorm<NT>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
