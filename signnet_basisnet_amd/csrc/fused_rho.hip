@@ -42,12 +42,15 @@ __device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* ga
 #pragma unroll
   for (int kk = 0; kk < NT; ++kk) s += (v[kk][0] + v[kk][1]) + (v[kk][2] + v[kk][3]);   // padded channels hold 0
   const float mean = row_allsum(s) / (float)d;
+  // d % 4 == 0: whole float4 groups are either real channels or padding, and only the last 16-channel tile can hold
+  // padding — ONE lane mask instead of one per element (32 of them were precomputed into 64 scalar registers)
+  const bool last_ok = 16 * (NT - 1) + 4 * g < d;
   float q = 0.f;
 #pragma unroll
   for (int kk = 0; kk < NT; ++kk) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float dlt = (16 * kk + 4 * g + t < d) ? v[kk][t] - mean : 0.f;
+      const float dlt = (kk + 1 < NT || last_ok) ? v[kk][t] - mean : 0.f;
       q += dlt * dlt;
     }
   }
