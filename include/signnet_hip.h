@@ -52,8 +52,9 @@ int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz);
  *   evoff[B+1]      prefix of n_b^2   (offset of graph b's eigenvector block, int64)
  *   rowptr[N+1], col[E] (source node of each in-edge), eperm[E] (edge id, for edge_attr)
  *     — in-edges of a node are ordered by edge id (deterministic summation order)
- *   status[4]       status[0] != 0 -> malformed batch (unsorted batch, edge across graphs, ...);
- *                   status[1] = max nodes per graph, status[2] = max in-degree
+ *   status[8]       status[0] != 0 -> malformed batch (unsorted batch, edge across graphs, ...);
+ *                   status[1] = max nodes per graph, status[2] = max in-degree, status[3] = flags of the fused GINE
+ *                   stage (set by sn_gnn_fused_f32), status[4] = its completion counter (zeroed here), [5..7] reserved
  *   bins            work bins of the fused stages (may be NULL) — see "Fused stages" below
  * scratch: int32[N + 8].  One launch (two workgroups) for batches of <= 4096 nodes / 12288 edges / 1024 graphs,
  * five launches otherwise; never a host synchronisation.
@@ -324,7 +325,13 @@ typedef struct {
 int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const void* edge_attr, int lde,
                      const float* rho_sum, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr,
                      const int32_t* col, const int32_t* eperm, int32_t* status /* sn_batch_plan's */,
-                     float* y /* [B, n_out] */, void* stream);
+                     float* y /* [B, n_out] */,
+                     const int32_t* flags_src, int n_flags, int32_t* flags_host /* optional report, see below */,
+                     void* stream);
+/* Flag report without a separate copy: when flags_host (device-accessible pinned host memory) is not NULL, the last
+ * workgroup to finish copies flags_src[0 .. n_flags) (device; typically sn_batch_plan's status words followed by
+ * sn_plan_bins.meta) to it, after every workgroup's own flag updates.  The caller reads it once an event recorded
+ * behind the launch has completed. */
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,9 @@ struct GnnStruct {
   int32_t* status;        // status[3] |= 1 if a graph has more than 64 nodes (host falls back)
   float* y;               // [B, n_out]
   int ee_rows;            // rows of the edge-embedding area
+  const int32_t* flags_src;   // optional flag report (see sn_gnn_fused_f32)
+  int n_flags;
+  int32_t* flags_host;
 };
 
 // the four channels 16*ot + 4g + t of `row` -> the three planes of a split image (exact 3-way split, fused_common.hpp)
@@ -175,7 +178,7 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
 }
 
 template <int NT>
-__global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_gnn_params P) {
+__device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_params& P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
   constexpr int NKB = (NT + 1) / 2;
@@ -515,6 +518,24 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
 #endif
 }
 
+// One workgroup per graph; the last workgroup to finish reports the batch's flags to the host (no separate copy).
+template <int NT>
+__global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_gnn_params P) {
+  gnn_graph<NT>(S, P);
+  if (S.flags_host != nullptr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();                                              // my flag updates are visible device-wide
+      if (atomicAdd(&S.status[4], 1) == (int)gridDim.x - 1) {       // every other workgroup has passed its fence
+        __threadfence();
+        for (int i = 0; i < S.n_flags; ++i)
+          S.flags_host[i] = __hip_atomic_load(&S.flags_src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+      }
+    }
+  }
+}
+
 template <int NT>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
@@ -551,7 +572,8 @@ extern "C" int sn_prof_set_block(int b) { return (int)hipMemcpyToSymbol(HIP_SYMB
 
 extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const void* edge_attr, int lde,
                                 const float* rho_sum, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr,
-                                const int32_t* col, const int32_t* eperm, int32_t* status, float* y, void* stream) {
+                                const int32_t* col, const int32_t* eperm, int32_t* status, float* y,
+                                const int32_t* flags_src, int n_flags, int32_t* flags_host, void* stream) {
   SN_REQUIRE(params && x && rho_sum && graph_ptr && rowptr && status && y && B >= 0, "sn_gnn_fused_f32: null pointer");
   const sn_gnn_params& P = *params;
   SN_REQUIRE(P.d > 0 && P.d <= 128, "sn_gnn_fused_f32: hidden width %d not in (0, 128]", P.d);
@@ -571,7 +593,8 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
     else SN_REQUIRE(L.ew && L.e_scale && L.e_shift, "sn_gnn_fused_f32: layer %d edge MLP parameters missing", l);
   }
   if (B == 0) return SN_OK;
-  GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y, 0};
+  SN_REQUIRE(!flags_host || (flags_src && n_flags > 0 && n_flags <= 64), "sn_gnn_fused_f32: flag report needs flags_src and 0 < n_flags <= 64");
+  GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y, 0, flags_src, n_flags, flags_host};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   switch ((P.d + 15) / 16) {

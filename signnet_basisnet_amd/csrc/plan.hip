@@ -418,6 +418,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     nvalid[i] = nv;
   }
   if (t == 0) { status[ST_ERR] = s_err; status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
+  if (t >= 4 && t < 8) status[t] = 0;
   PL_STAMP(6);
 }
 
@@ -427,7 +428,7 @@ __global__ void k_plan_nodes(const int64_t* __restrict__ batch, int64_t N, int64
                              int32_t* __restrict__ graph_ptr, int32_t* __restrict__ node_graph,
                              int32_t* __restrict__ deg, int32_t* __restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 4) status[i] = 0;
+  if (i < 8) status[i] = 0;
   if (i == 0) graph_ptr[B] = (int32_t)N;
   if (i >= N) return;
   int64_t g = batch[i];

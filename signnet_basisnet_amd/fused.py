@@ -231,8 +231,9 @@ class GnnPlan:
             Lp.eps = hold(conv.layer.eps.detach())
         self.params = P
 
-    def run(self, plan: ops.GraphPlan, x, edge_attr, rho_sum):
-        """-> model output [B, n_out] (graphs with more than 64 nodes set plan.status[3])."""
+    def run(self, plan: ops.GraphPlan, x, edge_attr, rho_sum, flags_host=None):
+        """-> model output [B, n_out] (graphs with more than 64 nodes set plan.status[3]).  flags_host: optional pinned
+        int32 host tensor (>= plan.flags.numel()) that the kernel's last workgroup fills with plan.flags."""
         P = self.params
         if self.node_discrete:
             if x.dtype != torch.int64:
@@ -257,5 +258,8 @@ class GnnPlan:
             check(lib().sn_gnn_fused_f32(C.byref(P), ptr(x), x.shape[1], ptr(edge_attr),
                                          edge_attr.shape[1] if edge_attr.dim() > 1 else 1, ptr(rho_sum),
                                          ptr(plan.graph_ptr), plan.B, ptr(plan.rowptr), ptr(plan.col),
-                                         ptr(plan.eperm), ptr(plan.status), ptr(y), stream()), "sn_gnn_fused_f32")
+                                         ptr(plan.eperm), ptr(plan.status), ptr(y),
+                                         ptr(plan.flags) if flags_host is not None else None,
+                                         plan.flags.numel() if flags_host is not None else 0, ptr(flags_host), stream()),
+                  "sn_gnn_fused_f32")
         return y

@@ -118,7 +118,7 @@ class GraphPlan:
     rowptr: torch.Tensor      # int32 [N+1] dst-sorted CSR
     col: torch.Tensor         # int32 [E]   source node of each in-edge
     eperm: torch.Tensor       # int32 [E]   original edge id of each CSR slot
-    status: torch.Tensor      # int32 [4]   [err bits, max nodes/graph, max in-degree, fused-stage flags]
+    status: torch.Tensor      # int32 [8]   [err bits, max nodes/graph, max in-degree, fused-stage flags, gnn completion counter, -, -, -]
     bins: PlanBins | None
     flags: torch.Tensor = None   # status (+ bins meta) as one contiguous block
 
@@ -147,7 +147,7 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     N, E, B = batch.numel(), edge_index.shape[1] if edge_index.numel() else 0, int(num_graphs)
     dev = batch.device
     # one int32 arena, carved into the plan arrays (single allocation per batch)
-    sizes = [B + 1, N, N, N + 1, E, E, N + 8, 4]          # status last: [status | bins meta] is one 12-int block
+    sizes = [B + 1, N, N, N + 1, E, E, N + 8, 8]          # status last: [status(8) | bins meta(8)] is one 16-int block
     mb = 0
     if bins:
         mb = int(lib().sn_phi_bins_bound(B, int(kmax)))
@@ -169,7 +169,7 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
                                   ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
                                   C.byref(pb.cstruct) if pb is not None else None, ptr(scratch), stream()), "sn_batch_plan")
     plan = GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, pb)
-    plan.flags = arena[offs[7]:offs[7] + 12] if bins else status      # [status(4) | meta(8)] contiguous
+    plan.flags = arena[offs[7]:offs[7] + 16] if bins else status      # [status(8) | meta(8)] contiguous
     return plan
 
 

@@ -17,6 +17,8 @@ import torch.nn as nn
 
 from . import fused, ops
 
+import os as _os
+_NO_KERNEL_FLAGS = bool(_os.environ.get("SN_NO_KERNEL_FLAGS"))   # debugging: report flags with a stream copy instead
 N_HEAD = 4          # TransformerEncoderLayer(nhid, n_head=4): sign_net.py:50 / core/sign_net.py:57
 LN_EPS = 1e-6       # masked_layers.py:25
 
@@ -271,7 +273,7 @@ class SignNetGNN(nn.Module):
         # sync) and re-runs such a batch on the layer path; strict=False (default) copies them asynchronously
         # and raises at the NEXT forward (or at .check_last()) — outputs of the offending batch are invalid.
         self.strict = False
-        self._pending, self._free_hosts = [], []
+        self._pending, self._free_hosts, self._flags_host = [], [], None
         self.sign_net = SignNet(n_hid, nl_signnet, self.nl_rho, variant, ignore_eigval)
         self.gnn = GNN(node_feat, edge_feat, n_hid, n_out, nl_gnn, variant)
         self._prep = None
@@ -348,8 +350,8 @@ class SignNetGNN(nn.Module):
     # ------------------------------------------------------------------ device-side status of the fused stages
     @staticmethod
     def _flags_bad(host):
-        return bool(host[0] or host[3] or host[5] or host[9])       # plan errors, gnn flags, phi / rho bin errors
-        # layout: [status(4) | meta(8)]: status[0] plan errors, status[3] gnn flags, meta[1] phi, meta[5] rho
+        # layout: [status(8) | meta(8)]: status[0] plan errors, status[3] gnn flags, meta[1] phi, meta[5] rho bin errors
+        return bool(host[0] or host[3] or host[9] or host[13])
 
     def check_last(self, wait=True):
         """Raise if an earlier forward's batch could not be served by the fused kernels (wait=False: only look at
@@ -367,10 +369,19 @@ class SignNetGNN(nn.Module):
                                    "(> 64 nodes or > 192 edges): its outputs are invalid; set model.strict = True "
                                    "(re-runs such batches layer by layer) or model.use_fused = False")
 
+    def _host_flags(self):
+        """A pooled pinned buffer for one forward's device flags."""
+        return self._free_hosts.pop() if self._free_hosts else torch.zeros(16, dtype=torch.int32, pin_memory=True)
+
     def _post_status(self, plan):
-        host = self._free_hosts.pop() if self._free_hosts else torch.zeros(12, dtype=torch.int32, pin_memory=True)
-        n = plan.flags.numel()
-        host[:n].copy_(plan.flags, non_blocking=True)
+        """Event after which this forward's flags are in their pinned buffer.  With the fused GINE stage its last
+        workgroup wrote them there itself (no copy on the stream); otherwise an asynchronous copy is queued."""
+        host = self._flags_host
+        self._flags_host = None
+        if host is None:
+            host = self._host_flags()
+            n = plan.flags.numel()
+            host[:n].copy_(plan.flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return ev, host
@@ -466,7 +477,10 @@ class SignNetGNN(nn.Module):
                 x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
             s = ops.slot_sum(x, N, K)
         if use_gnn_fused and not return_stages:
-            return P["gnn_fused"].run(plan, data.x, data.edge_attr, s)
+            self._flags_host = self._host_flags() if (plan.bins is not None and not _NO_KERNEL_FLAGS) else None
+            if self._flags_host is not None:
+                self._flags_host.zero_()          # host-side; the kernel's last workgroup overwrites it
+            return P["gnn_fused"].run(plan, data.x, data.edge_attr, s, self._flags_host)
         pe = ops.masked_linear(s, P["rho_out"]["l"], scale=P["rho_out"]["bn"][0], shift=P["rho_out"]["bn"][1])
         if return_stages:
             stages["pos"] = pe
