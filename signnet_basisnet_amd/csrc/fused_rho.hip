@@ -91,7 +91,10 @@ __device__ __forceinline__ float tile_rowsum(float v) {
 
 // REGATTN: every node has <= 16 valid slots (0 < kmax <= 16) and the head width is a multiple of 16 -> attention in
 // registers, no LDS images (the host picks the variant; the other one serves any slot count through LDS).
-template <int NT, bool REGATTN>
+// ONE: exactly one encoder layer without eigenvalue encoding (GINESignNetPyG: nl_rho is ignored, 1 layer).  The layer's
+// input rows are then still in the input buffer when the residual needs them, so they are not kept in registers across
+// the q / k / v projections and the attention but re-read right before the output projection.
+template <int NT, bool REGATTN, bool ONE>
 __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     // ---------------------------------------------------------------- load x (+ eigenvalue encoding)
     // branch-free (clamped addresses + selects): per-element branches here would turn x[] into a web of phi copies
     f32x4 x[NT];
-    {
+    auto load_x = [&]() {
       const float* xr = S.x + (valid ? ((int64_t)node * S.K + slot) : (int64_t)0) * d;
 #pragma unroll
       for (int kk = 0; kk < NT; ++kk) {      // d % 4 == 0 (entry-point requirement); only the last tile can be partial
@@ -162,7 +165,8 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
         const f32x4 v = ld4(xr + (inb ? c : 0));
         x[kk] = (valid && inb) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    }
+    };
+    load_x();
     if (valid) {
       if (P.has_pos) {
         // eigen_encoder = MaskedMLP(1 -> 1 -> d): Linear . BN . ReLU . Linear . BN . ReLU   (sign_net.py:86,108)
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     SN_STAMP(2);
     // ---------------------------------------------------------------- encoder layers
 #pragma unroll 1
-    for (int l = 0; l < P.n_layers; ++l) {
+    for (int l = 0; l < (ONE ? 1 : P.n_layers); ++l) {
       const sn_rho_layer& Lp = P.layers[l];
       const void* wafter = (l + 1 < P.n_layers) ? P.layers[l + 1].wq : wfirst;   // the stream restarts at layer 0 for the next bin
       f32x4 o[NT];
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
+      if (ONE) load_x();   // the residual operand, straight from the input buffer (see ONE above)
       wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
       if (wave_live) {
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
   ring.drain();
 }
 
-template <int NT, bool REGATTN>
+template <int NT, bool REGATTN, bool ONE>
 static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   const size_t lds = (size_t)WRing<NT>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float)) +
@@ -372,7 +377,7 @@ static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_b
   static int cus = 0;
   if (cus == 0) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_rho_fused_f32: cannot raise the dynamic LDS limit to %zu", lds);
     int dev = 0, n = 256;
@@ -384,21 +389,21 @@ static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_b
   grid = cus;
 #endif
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
+  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN, ONE>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
   return SN_OK;
 }
 
-template <bool REGATTN>
+template <bool REGATTN, bool ONE>
 static int dispatch_rho(int nt, const RhoStruct& S, const sn_rho_params& P, int64_t bound, hipStream_t st) {
   switch (nt) {
-    case 1: return launch_rho<1, REGATTN>(S, P, bound, st);
-    case 2: return launch_rho<2, REGATTN>(S, P, bound, st);
-    case 3: return launch_rho<3, REGATTN>(S, P, bound, st);
-    case 4: return launch_rho<4, REGATTN>(S, P, bound, st);
-    case 5: return launch_rho<5, REGATTN>(S, P, bound, st);
-    case 6: return launch_rho<6, REGATTN>(S, P, bound, st);
-    case 7: return launch_rho<7, REGATTN>(S, P, bound, st);
-    default: return launch_rho<8, REGATTN>(S, P, bound, st);
+    case 1: return launch_rho<1, REGATTN, ONE>(S, P, bound, st);
+    case 2: return launch_rho<2, REGATTN, ONE>(S, P, bound, st);
+    case 3: return launch_rho<3, REGATTN, ONE>(S, P, bound, st);
+    case 4: return launch_rho<4, REGATTN, ONE>(S, P, bound, st);
+    case 5: return launch_rho<5, REGATTN, ONE>(S, P, bound, st);
+    case 6: return launch_rho<6, REGATTN, ONE>(S, P, bound, st);
+    case 7: return launch_rho<7, REGATTN, ONE>(S, P, bound, st);
+    default: return launch_rho<8, REGATTN, ONE>(S, P, bound, st);
   }
 }
 
@@ -433,7 +438,9 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   // attention in registers when every node has <= 16 slots and the head width is a multiple of 16
   const bool regattn = kmax > 0 && kmax <= 16 && ((P.d / P.heads) & 15) == 0;
   const int nt = (P.d + 15) / 16;
-  int rc = regattn ? dispatch_rho<true>(nt, S, P, bound, st) : dispatch_rho<false>(nt, S, P, bound, st);
+  const bool one = P.n_layers == 1 && !P.has_pos;
+  int rc = regattn ? (one ? dispatch_rho<true, true>(nt, S, P, bound, st) : dispatch_rho<true, false>(nt, S, P, bound, st))
+                   : (one ? dispatch_rho<false, true>(nt, S, P, bound, st) : dispatch_rho<false, false>(nt, S, P, bound, st));
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_rho_fused_f32");
   return SN_OK;
