@@ -155,6 +155,12 @@ int sn_bn_fold_f32(const float* weight, const float* bias, const float* running_
                    const float* running_var, float eps, int C, int C_pad, float* scale, float* shift,
                    void* stream);
 
+/* The running-statistics side effect of a train-mode nn.BatchNorm1d forward (torch: momentum 0.1, running_var from
+ * the UNBIASED batch variance): running = (1-m)*running + m*batch, with mean / var (biased) / count as produced by
+ * sn_masked_colstats_f32. */
+int sn_bn_running_update_f32(const float* mean, const float* var, const float* count /* device scalar */, float momentum,
+                             int C, float* running_mean, float* running_var, void* stream);
+
 /* Per-channel masked statistics for train-mode BatchNorm (MaskedBN on the compacted valid rows,
  * masked_layers.py:19; nn.BatchNorm1d model.py:50): mean[c], biased var[c] over valid rows,
  * count written to *count.  scratch: float[2*C*nblocks] (nblocks = sn_colstats_blocks(R)). */

@@ -67,6 +67,18 @@ __global__ void k_pack_split(const float* __restrict__ W, int d_out, int d_in, i
   }
 }
 
+// running_mean / running_var update of a train-mode BatchNorm1d forward (momentum m, unbiased variance),
+// from the batch statistics of sn_masked_colstats_f32 (biased variance, row count on the device).
+__global__ void k_bn_running_update(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ count,
+                                    float momentum, int C, float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float n = count[0];
+  const float unb = n > 1.f ? var[c] * (n / (n - 1.f)) : var[c];
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+}
+
 // ============================================================================ BatchNorm(eval) folding
 // scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale; zero padded to Cp.
 __global__ void k_bn_fold(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ rm,
@@ -565,6 +577,15 @@ extern "C" int sn_bn_fold_f32(const float* weight, const float* bias, const floa
   hipLaunchKernelGGL(k_bn_fold, dim3((unsigned)cdiv(C_pad, 128)), dim3(128), 0, (hipStream_t)stream, weight, bias,
                      running_mean, running_var, eps, C, C_pad, scale, shift);
   SN_CHECK_LAUNCH("sn_bn_fold_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_bn_running_update_f32(const float* mean, const float* var, const float* count, float momentum, int C,
+                                        float* running_mean, float* running_var, void* stream) {
+  SN_REQUIRE(mean && var && count && running_mean && running_var && C > 0, "sn_bn_running_update_f32: bad arguments");
+  hipLaunchKernelGGL(k_bn_running_update, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, mean, var, count,
+                     momentum, C, running_mean, running_var);
+  SN_CHECK_LAUNCH("sn_bn_running_update_f32");
   return SN_OK;
 }
 

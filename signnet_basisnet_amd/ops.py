@@ -437,6 +437,17 @@ def bn_fold_stats(weight, bias, mean, var, eps, c_pad=None):
     return scale, shift
 
 
+def bn_running_update(bn, mean, var, count):
+    """Side effect of a train-mode BatchNorm1d forward on its buffers (momentum None = cumulative average is not supported)."""
+    if not bn.track_running_stats or bn.running_mean is None:
+        return
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not supported")
+    check(lib().sn_bn_running_update_f32(ptr(mean), ptr(var), ptr(count), float(bn.momentum), bn.num_features,
+                                         ptr(bn.running_mean), ptr(bn.running_var), stream()), "sn_bn_running_update_f32")
+    bn.num_batches_tracked += 1
+
+
 # ----------------------------------------------------------------------------- roofline accounting (bench.py)
 MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA dense peak (= fp32 vector peak)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E spec

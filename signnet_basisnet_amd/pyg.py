@@ -237,9 +237,32 @@ class GNN(nn.Module):
 
 
 # ----------------------------------------------------------------------------- prepared (packed) parameters
-def _bn_affine(bn: nn.BatchNorm1d):
-    """Eval-mode BatchNorm as y = x*scale + shift (running statistics), folded on the device."""
-    return ops.bn_fold(bn)
+class _BN:
+    """A BatchNorm1d site of the layer path: the module (train mode: batch statistics) and, in eval mode, its running
+    statistics folded to y = x*scale + shift on the device."""
+    __slots__ = ("mod", "scale", "shift")
+
+    def __init__(self, bn: nn.BatchNorm1d, fold: bool):
+        self.mod = bn
+        self.scale, self.shift = ops.bn_fold(bn) if fold else (None, None)
+
+    def __getitem__(self, i):
+        return (self.scale, self.shift)[i]
+
+
+def _lin_bn(x, pl, bn: _BN, train: bool, nvalid=None, K=0, relu=True, residual=None):
+    """Linear -> [mask] -> BatchNorm -> [ReLU] [-> + residual].  eval: one launch (BN folded into the GEMM epilogue).
+    train: GEMM, masked column statistics over the valid rows, fold, affine (+ running-statistics update) — the
+    reference's `x[mask] = bn(x[mask])` in training mode (masked_layers.py:13-20) / plain BatchNorm1d (model.py:50)."""
+    if not train:
+        return ops.masked_linear(x, pl, nvalid, K, scale=bn.scale, shift=bn.shift, relu=relu, residual=residual)
+    y = ops.masked_linear(x, pl, nvalid, K)
+    m = bn.mod
+    mean, var, count = ops.masked_colstats(y, nvalid, K)
+    sc, sh = ops.bn_fold_stats(None if m.weight is None else m.weight.detach(), None if m.bias is None else m.bias.detach(),
+                               mean, var, m.eps)
+    ops.bn_running_update(m, mean, var, count)
+    return ops.masked_affine(y, nvalid, K, scale=sc, shift=sh, relu=relu, residual=residual)
 
 
 def _pack(lin: nn.Linear) -> ops.PackedLinear:
@@ -301,26 +324,34 @@ class SignNetGNN(nn.Module):
         self._prep = None
 
     # ------------------------------------------------------------------ prepare
-    def _prepare(self):
+    def _prepare(self, train=False):
         P = {}
+        fold = not train
+        use_fused = self.use_fused and not train
         sn, g = self.sign_net, self.gnn
         d = self.cfg["n_hid"]
-        P["phi_fused"] = fused.PhiPlan(sn.phi) if (self.use_fused and d <= 128 and d % 4 == 0 and len(sn.phi.convs) <= 16) else None
+        P["phi_fused"] = fused.PhiPlan(sn.phi) if (use_fused and d <= 128 and d % 4 == 0 and len(sn.phi.convs) <= 16) else None
         ee = sn.eigen_encoder if (self.variant == "alchemy" and not sn.ignore_eigval) else None
         P["rho_fused"] = (fused.RhoPlan(sn.rho, ee, N_HEAD, LN_EPS)
-                          if (self.use_fused and d <= 128 and d % 4 == 0 and len(sn.rho.transformer_layers) <= fused.RHO_MAX_LAYERS) else None)
+                          if (use_fused and d <= 128 and d % 4 == 0 and len(sn.rho.transformer_layers) <= fused.RHO_MAX_LAYERS) else None)
         P["gnn_fused"] = None
-        if self.use_fused and d <= 128 and len(g.convs) <= fused.GNN_MAX_LAYERS and self.cfg["n_out"] <= 16 \
+        if use_fused and d <= 128 and len(g.convs) <= fused.GNN_MAX_LAYERS and self.cfg["n_out"] <= 16 \
                 and (self.cfg["node_feat"] or 0) <= 16 and (self.cfg["edge_feat"] or 0) <= 16:
             P["gnn_fused"] = fused.GnnPlan(sn.rho.out, g, self.cfg["node_feat"], self.cfg["edge_feat"])
         P["phi"] = []
         for conv, norm in zip(sn.phi.convs, sn.phi.norms):
-            P["phi"].append(dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0].bn),
-                                 l1=_pack(conv.nn.layers[1]), bn=_bn_affine(norm.bn)))
+            P["phi"].append(dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_BN(conv.nn.norms[0].bn, fold),
+                                 l1=_pack(conv.nn.layers[1]), bn=_BN(norm.bn, fold)))
         if self.variant == "alchemy" and not sn.ignore_eigval:
             ee = sn.eigen_encoder
-            P["eig"] = dict(l0=_pack(ee.layers[0]), bn0=_bn_affine(ee.norms[0].bn), l1=_pack(ee.layers[1]),
-                            bn1=_bn_affine(ee.norms[1].bn))
+            P["eig"] = dict(l0=_pack(ee.layers[0]), bn0=_BN(ee.norms[0].bn, fold), l1=_pack(ee.layers[1]),
+                            bn1=_BN(ee.norms[1].bn, fold))
+        if train and self.variant != "alchemy":
+            # GINESignNetPyG evaluates eigen_encoder2 and throws the result away (core/sign_net.py:111-112); in training
+            # mode that call still moves the running statistics of its two BatchNorms — reproduced, value discarded
+            ee2 = sn.eigen_encoder2
+            P["eig2"] = dict(l0=_pack(ee2.layers[0]), bn0=_BN(ee2.norms[0].bn, False), l1=_pack(ee2.layers[1]),
+                             bn1=_BN(ee2.norms[1].bn, False))
         P["rho"] = []
         for tl in sn.rho.transformer_layers:
             a, f = tl.slf_attn, tl.pos_ffn
@@ -328,23 +359,23 @@ class SignNetGNN(nn.Module):
                                  ln1=(a.norm.ln.weight.detach(), a.norm.ln.bias.detach()),
                                  w1=_pack(f.w_1), w2=_pack(f.w_2),
                                  ln2=(f.norm.ln.weight.detach(), f.norm.ln.bias.detach())))
-        P["rho_out"] = dict(l=_pack(sn.rho.out[0]), bn=_bn_affine(sn.rho.out[1]))
+        P["rho_out"] = dict(l=_pack(sn.rho.out[0]), bn=_BN(sn.rho.out[1], fold))
         if isinstance(g.input_encoder, DiscreteEncoder):
             P["in_tabs"] = [e.weight.detach() for e in g.input_encoder.embeddings]
         else:
-            P["in_mlp"] = dict(l=_pack(g.input_encoder.layers[0]), bn=_bn_affine(g.input_encoder.norms[0]))
+            P["in_mlp"] = dict(l=_pack(g.input_encoder.layers[0]), bn=_BN(g.input_encoder.norms[0], fold))
         P["lin"] = _pack(g.linear)
         P["gine"] = []
         for enc, conv, norm in zip(g.edge_encoders, g.convs, g.norms):
-            d = dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_bn_affine(conv.nn.norms[0]),
-                     l1=_pack(conv.nn.layers[1]), bn=_bn_affine(norm))
+            d = dict(eps=conv.layer.eps.detach(), l0=_pack(conv.nn.layers[0]), bn0=_BN(conv.nn.norms[0], fold),
+                     l1=_pack(conv.nn.layers[1]), bn=_BN(norm, fold))
             if isinstance(enc, DiscreteEncoder):
                 d["tabs"] = [e.weight.detach() for e in enc.embeddings]
             else:
-                d["emlp"] = dict(l=_pack(enc.layers[0]), bn=_bn_affine(enc.norms[0]))
+                d["emlp"] = dict(l=_pack(enc.layers[0]), bn=_BN(enc.norms[0], fold))
             P["gine"].append(d)
         oe = g.output_encoder
-        P["head"] = dict(l0=_pack(oe.layers[0]), bn0=_bn_affine(oe.norms[0]), l1=_pack(oe.layers[1]))
+        P["head"] = dict(l0=_pack(oe.layers[0]), bn0=_BN(oe.norms[0], fold), l1=_pack(oe.layers[1]))
         return P
 
     # ------------------------------------------------------------------ device-side status of the fused stages
@@ -388,7 +419,14 @@ class SignNetGNN(nn.Module):
 
     def forward(self, data, return_stages=False):
         if self.training:
-            raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+            # train-mode forward VALUE (no autograd): BatchNorm with batch statistics over the valid rows and the
+            # running-statistics update, layer by layer.  The attention dropout p = 0.1 that the reference leaves
+            # active in training (transformer_module.py:46,55) is random and NOT applied (fixtures: p = 0).
+            self._prep = None                      # parameters may have changed since the last call
+            try:
+                return self._forward(data, return_stages, train=True)
+            finally:
+                self._prep = None
         self.check_last(wait=False)
         y = self._forward(data, return_stages)
         if self.use_fused and not return_stages and self._used_fused:
@@ -411,10 +449,10 @@ class SignNetGNN(nn.Module):
         return y
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, data, return_stages=False):
+    def _forward(self, data, return_stages=False, train=False):
         ops.require_cuda(data.edge_index, data.batch, data.eigen_vectors)
         if self._prep is None:
-            self._prep = self._prepare()
+            self._prep = self._prepare(train)
         P = self._prep
         B = int(data.num_graphs)
         use_phi_fused = P["phi_fused"] is not None
@@ -429,12 +467,16 @@ class SignNetGNN(nn.Module):
             K = plan.check()[1]          # N_max: one host sync, as the reference's to_dense_EVD does
         N, d = plan.N, self.cfg["n_hid"]
         nv = plan.nvalid
-        want_vals = "eig" in P
+        want_vals = "eig" in P or "eig2" in P
         x0 = s0 = None
         if return_stages or not (use_phi_fused and use_rho_fused):     # only the layer path needs the dense [N,K] blocks
             x0, s0 = ops.pack_eig(plan, data.eigen_vectors, data.eigen_values if want_vals else None, K, want_vals)
         stages = {}
 
+        if "eig2" in P:      # train mode, GINESignNetPyG: side effects only (see _prepare)
+            E2 = P["eig2"]
+            p2 = _lin_bn(s0.view(N * K, 1), E2["l0"], E2["bn0"], True, nv, K, relu=True)
+            _lin_bn(p2, E2["l1"], E2["bn1"], True, nv, K, relu=True)
         # ---- phi(x) + phi(-x)      (GNN3d.forward, sign_net.py:28-44)
         phis = None
         if use_phi_fused and not return_stages:
@@ -445,8 +487,8 @@ class SignNetGNN(nn.Module):
                 x, prev = x0, None
                 for l, L in enumerate(P["phi"]):
                     a = ops.gin_aggregate(x.view(N, -1), plan, L["eps"], negate=(sign == 1 and l == 0))
-                    h = ops.masked_linear(a.view(N * K, -1), L["l0"], nv, K, scale=L["bn0"][0], shift=L["bn0"][1], relu=True)
-                    x = ops.masked_linear(h, L["l1"], nv, K, scale=L["bn"][0], shift=L["bn"][1], relu=True, residual=prev)
+                    h = _lin_bn(a.view(N * K, -1), L["l0"], L["bn0"], train, nv, K, relu=True)
+                    x = _lin_bn(h, L["l1"], L["bn"], train, nv, K, relu=True, residual=prev)
                     prev = x
                 phis.append(x)
             x = ops.masked_affine(phis[0], nv, K, residual=phis[1])          # phi(x) + phi(-x)
@@ -460,10 +502,10 @@ class SignNetGNN(nn.Module):
         if use_rho_fused and not return_stages:
             s = P["rho_fused"].run(plan, x_phi, data.eigen_values if want_vals else None, K)
         else:
-            if want_vals:
+            if "eig" in P:
                 E_ = P["eig"]
-                p = ops.masked_linear(s0.view(N * K, 1), E_["l0"], nv, K, scale=E_["bn0"][0], shift=E_["bn0"][1], relu=True)
-                p = ops.masked_linear(p, E_["l1"], nv, K, scale=E_["bn1"][0], shift=E_["bn1"][1], relu=True)
+                p = _lin_bn(s0.view(N * K, 1), E_["l0"], E_["bn0"], train, nv, K, relu=True)
+                p = _lin_bn(p, E_["l1"], E_["bn1"], train, nv, K, relu=True)
                 x = ops.masked_affine(x, nv, K, residual=p)
             for L in P["rho"]:
                 q = ops.masked_linear(x, L["q"], nv, K)
@@ -481,7 +523,7 @@ class SignNetGNN(nn.Module):
             if self._flags_host is not None:
                 self._flags_host.zero_()          # host-side; the kernel's last workgroup overwrites it
             return P["gnn_fused"].run(plan, data.x, data.edge_attr, s, self._flags_host)
-        pe = ops.masked_linear(s, P["rho_out"]["l"], scale=P["rho_out"]["bn"][0], shift=P["rho_out"]["bn"][1])
+        pe = _lin_bn(s, P["rho_out"]["l"], P["rho_out"]["bn"], train, relu=False)
         if return_stages:
             stages["pos"] = pe
             stages["rho_sum"] = s
@@ -492,22 +534,20 @@ class SignNetGNN(nn.Module):
         if "in_tabs" in P:
             h = ops.embedding_sum(xin, P["in_tabs"])
         else:
-            h = ops.masked_linear(xin.contiguous(), P["in_mlp"]["l"], scale=P["in_mlp"]["bn"][0],
-                                  shift=P["in_mlp"]["bn"][1], relu=True)
+            h = _lin_bn(xin.contiguous(), P["in_mlp"]["l"], P["in_mlp"]["bn"], train, relu=True)
         h = ops.masked_linear(torch.cat([h, pe], dim=-1), P["lin"])
         for l, L in enumerate(P["gine"]):
             if "tabs" in L:
                 e = ops.embedding_sum(data.edge_attr, L["tabs"])
             else:
-                e = ops.masked_linear(data.edge_attr.contiguous(), L["emlp"]["l"], scale=L["emlp"]["bn"][0],
-                                      shift=L["emlp"]["bn"][1], relu=True)
+                e = _lin_bn(data.edge_attr.contiguous(), L["emlp"]["l"], L["emlp"]["bn"], train, relu=True)
             u = ops.gine_aggregate(h, e, plan, L["eps"])
-            u = ops.masked_linear(u, L["l0"], scale=L["bn0"][0], shift=L["bn0"][1], relu=True)
-            h = ops.masked_linear(u, L["l1"], scale=L["bn"][0], shift=L["bn"][1], relu=True, residual=h)
+            u = _lin_bn(u, L["l0"], L["bn0"], train, relu=True)
+            h = _lin_bn(u, L["l1"], L["bn"], train, relu=True, residual=h)
             if return_stages:
                 stages[f"gine{l}"] = h
         pooled = ops.segment_pool(h, plan, self.gnn.pooling)
-        y = ops.masked_linear(pooled, P["head"]["l0"], scale=P["head"]["bn0"][0], shift=P["head"]["bn0"][1], relu=True)
+        y = _lin_bn(pooled, P["head"]["l0"], P["head"]["bn0"], train, relu=True)
         y = ops.masked_linear(y, P["head"]["l1"])
         if return_stages:
             stages["y"] = y

@@ -256,3 +256,51 @@ def test_fused_width_not_multiple_of_32():
         y = m(synth.batch_to(host, "cuda:0"))
         m.check_last()
     close(y, ref, "alchemy d=108 fused forward vs oracle")
+
+
+@pytest.mark.parametrize("name", G.PYG_CASES)
+def test_train_mode_forward_value_and_running_stats(name):
+    """model.train() forward: BatchNorm with batch statistics over the valid rows (reference fixture generated with the
+    attention dropout switched off), and the running-statistics side effect of every BatchNorm (momentum 0.1, unbiased
+    variance) against what torch's own BatchNorm1d does on the oracle's activations."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    fx = G.load(name)
+    model = build(fx)
+    model.train()
+    data = synth.batch_to(G.as_data(fx.inp), "cuda:0")
+    before = {k: v.detach().clone() for k, v in model.state_dict().items() if k.endswith("running_mean") or k.endswith("running_var")}
+    with torch.no_grad():
+        y, st = model(data, return_stages=True)
+    scale = max(1.0, fx.out["train/y"].abs().max().item())
+    err = (y.cpu() - fx.out["train/y"]).abs().max().item()
+    assert err <= 5e-4 * scale + 5e-5, f"train-mode y: {err:.3e} (scale {scale:.3e})"      # TOL_BS of test_oracle_golden.py
+    perr = (st["pos"].cpu() - fx.out["train/pos"]).abs().max().item()
+    assert perr <= 5e-4 * max(1.0, fx.out["train/pos"].abs().max().item()) + 5e-5, f"train-mode pos: {perr:.3e}"
+    after = model.state_dict()
+    # every BatchNorm that the forward visits moved its running statistics; the rho.out BatchNorm is checked exactly
+    unchanged = [k for k, v in before.items() if torch.equal(after[k].cpu(), v.cpu())]
+    # only BatchNorms the reference never calls may keep their statistics (rho.pos_encoder, the commented-out eigen_encoder1;
+    # eigen_encoder2 IS called by GINESignNetPyG and discarded — its statistics move)
+    # ... and the BatchNorm that MaskedMLP / MLP register for their LAST layer but skip when with_final_activation=False
+    # (masked_layers.py:60-63, elements.py:63-66): `.nn.norms.1`, `output_encoder.norms.1`
+    import re
+    never_called = re.compile(r"pos_encoder|eigen_encoder1|\.nn\.norms\.1\.|output_encoder\.norms\.1\.")
+    assert all(never_called.search(k) for k in unchanged), [k for k in unchanged if not never_called.search(k)]
+    assert len(unchanged) < len(before) // 2
+    out = {}
+    O.signnet_gnn(fx.sd, G.pyg_cfg(fx), G.as_data(fx.inp), training=True, out=out)
+    z = torch.nn.functional.linear(out["rho_sum"], fx.sd["sign_net.rho.out.0.weight"])
+    bn = torch.nn.BatchNorm1d(z.shape[1])
+    bn.running_mean.copy_(fx.sd["sign_net.rho.out.1.running_mean"])
+    bn.running_var.copy_(fx.sd["sign_net.rho.out.1.running_var"])
+    bn.train()
+    bn(z)
+    torch.testing.assert_close(after["sign_net.rho.out.1.running_mean"].cpu(), bn.running_mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(after["sign_net.rho.out.1.running_var"].cpu(), bn.running_var, rtol=1e-4, atol=1e-5)
+    assert int(after["sign_net.rho.out.1.num_batches_tracked"]) == int(fx.sd["sign_net.rho.out.1.num_batches_tracked"]) + 1
+    # and eval() afterwards still runs the fused stages
+    model.eval()
+    with torch.no_grad():
+        model(data)
+        model.check_last()
