@@ -8,6 +8,7 @@ same forward contracts:
     SignPlus(model).forward(v) = model(v) + model(-v)
 All arithmetic runs in libsignnet_hip.so (the 2->1 contractions in sn_ign_contract_2to1_f32, every Linear in
 sn_masked_linear_f32, means / BatchNorm statistics in the segment / column-statistics kernels).  No CPU path.
+IGN2to1 in train mode gives the forward VALUE with batch-statistic BatchNorm (running statistics updated; no autograd).
 
 Difference from the reference worth knowing: the reference's equivariant-layer
 coefficients are `nn.Parameter(...).to(device)`, i.e. NOT registered parameters when the device differs from
@@ -75,7 +76,8 @@ class IGN2to1(nn.Module):
         self._prep = None
         return super().load_state_dict(*a, **k)
 
-    def _prepare(self):
+    def _prepare(self, train=False):
+        from .dgl_deepsigns import _BNSite
         e0, e1, e2 = self.equi_layers
         P = {}
         # einsum('dsb,ndbi->nsi'): out[s] = sum_k coeffs[0,s,k] * ops[k]  -> weight [S, 5]
@@ -84,27 +86,38 @@ class IGN2to1(nn.Module):
             c = e.coeffs.detach()                                              # [D, S, 2]
             W = torch.cat([c[:, :, 0].t(), c[:, :, 1].t()], dim=1)             # [S, 2D]: [identity | mean] blocks
             P[name] = _lin(W, e.bias)
-        P["bn"] = [ops.bn_fold(self.bns[i]) for i in range(3)]
+        P["bn"] = [_BNSite(self.bns[i], train) for i in range(3)]
         P["fc1"] = _lin(self.fc1.weight, self.fc1.bias)
         P["fc2"] = _lin(self.fc2.weight, self.fc2.bias)
         return P
 
+    def _relu_bn(self, x, pl, site, train):
+        """equivariant layer (a Linear over the contraction basis) -> ReLU -> BatchNorm1d(hidden) on [b, hidden, n]
+        (ign.py:31-33: activation BEFORE the norm).  train: batch statistics over the b*n rows + running-stat update."""
+        if not train:
+            return ops.masked_linear(x, pl, relu_pre=True, scale=site.scale, shift=site.shift)
+        y = ops.masked_linear(x, pl, relu=True)
+        sc, sh = site.affine(y, True)
+        return ops.masked_affine(y, scale=sc, shift=sh)
+
     def forward(self, x):
-        if self.training:
-            raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+        train = self.training     # forward VALUE with batch statistics (no autograd)
         ops.require_cuda(x)
-        if self._prep is None:
-            self._prep = self._prepare()
-        P = self._prep
+        if train:
+            P = self._prepare(True)
+        else:
+            if self._prep is None:
+                self._prep = self._prepare()
+            P = self._prep
         b, n = x.shape[0], x.shape[-1]
         o = ops.ign_contract_2to1(x.contiguous())                                          # [b, n, 5]
-        h = ops.masked_linear(o.view(b * n, 5), P["l0"], relu_pre=True, scale=P["bn"][0][0], shift=P["bn"][0][1])
+        h = self._relu_bn(o.view(b * n, 5), P["l0"], P["bn"][0], train)
         seg = torch.arange(0, b * n + 1, n, dtype=torch.int32, device=x.device)             # rows of matrix i: [i*n, (i+1)*n)
         segplan = _SegPlan(b, seg)
         for li, name in ((1, "l1"), (2, "l2")):
             m = ops.segment_pool(h, segplan, "mean")                                       # [b, H]   sum_n h / n (ign.py:405-414)
             cat = torch.cat([h.view(b, n, -1), m.unsqueeze(1).expand(b, n, m.shape[1])], dim=-1).contiguous()
-            h = ops.masked_linear(cat.view(b * n, -1), P[name], relu_pre=True, scale=P["bn"][li][0], shift=P["bn"][li][1])
+            h = self._relu_bn(cat.view(b * n, -1), P[name], P["bn"][li], train)
         h = ops.masked_linear(h, P["fc1"], relu=True)
         y = ops.masked_linear(h, P["fc2"])                                                 # [b*n, out]
         return y.view(b, n, -1).transpose(2, 1).contiguous()                               # [b, out, n]

@@ -7,7 +7,8 @@ arguments, same `forward(g, x[N,K,1]) -> [N,K,1]`, same state_dict keys (`enc.la
 
 `g` is duck-typed: anything with `.edges() -> (src, dst)` int64 tensors and `.batch_num_nodes()` (a DGL batched
 graph, or `signnet_basisnet_amd.dgl_deepsigns.Graph`).  Eval mode (BatchNorm with running statistics) runs
-entirely in the HIP kernels of libsignnet_hip.so; there is no CPU path.
+entirely in the HIP kernels of libsignnet_hip.so; there is no CPU path.  Train mode gives the forward VALUE with
+batch-statistic BatchNorm (and updates the running statistics); there is no autograd.
 """
 from __future__ import annotations
 
@@ -93,26 +94,50 @@ def _pack(lin):
     return ops.PackedLinear(ops.pack_weight(w), w.shape[0], w.shape[1], lin.bias.detach().contiguous())
 
 
-def _prep_mlp(mlp: MLP):
-    """[(packed linear, folded BN or None)] per layer."""
+class _BNSite:
+    """A BatchNorm1d of the layer path: eval -> running statistics folded to (scale, shift) once; train -> the module,
+    whose batch statistics are taken per forward (and whose running statistics are updated)."""
+    __slots__ = ("mod", "scale", "shift")
+
+    def __init__(self, bn, train):
+        self.mod = bn
+        self.scale, self.shift = (None, None) if train else ops.bn_fold(bn)
+
+    def affine(self, y, train):
+        """(scale, shift) to apply to the rows `y` [R, C] (train: from y's own column statistics)."""
+        if not train:
+            return self.scale, self.shift
+        m = self.mod
+        mean, var, count = ops.masked_colstats(y)
+        ops.bn_running_update(m, mean, var, count)
+        return ops.bn_fold_stats(None if m.weight is None else m.weight.detach(), None if m.bias is None else m.bias.detach(),
+                                 mean, var, m.eps)
+
+
+def _prep_mlp(mlp: MLP, train=False):
+    """[(packed linear, BN site or None)] per layer."""
     out = []
     for i, lin in enumerate(mlp.lins):
-        bn = ops.bn_fold(mlp.bns[i]) if (mlp.use_bn and i < len(mlp.lins) - 1) else None
+        bn = _BNSite(mlp.bns[i], train) if (mlp.use_bn and i < len(mlp.lins) - 1) else None
         out.append((_pack(lin), bn))
     return out
 
 
-def _run_mlp(prep, x, nvalid=None, K=0, tail_affine=None):
-    """mlp.py:37-56 (dropout 0): hidden layers = bias -> relu -> BN; the final Linear optionally followed by an
-    affine (the BatchNorm that GIN.forward applies before the NEXT GINConv, gnns.py:105-112, folded in here)."""
+def _run_mlp(prep, x, nvalid=None, K=0, tail_bn=None, train=False):
+    """mlp.py:37-56 (dropout 0): hidden layers = bias -> relu -> BN; the final Linear optionally followed by the
+    BatchNorm that GIN.forward applies before the NEXT GINConv (gnns.py:105-112; in eval folded into the GEMM epilogue).
+    train: BatchNorm over ALL rows of the layer (the reference normalises [N, C, K] tensors, padded slots included)."""
     for i, (pl, bn) in enumerate(prep):
         last = i == len(prep) - 1
-        if not last:
-            x = ops.masked_linear(x, pl, nvalid, K, relu_pre=True, scale=None if bn is None else bn[0],
-                                  shift=None if bn is None else bn[1])
+        site = tail_bn if last else bn
+        if not train:
+            sc, sh = (None, None) if site is None else (site.scale, site.shift)
+            x = ops.masked_linear(x, pl, nvalid, K, relu_pre=not last, scale=sc, shift=sh)
         else:
-            x = ops.masked_linear(x, pl, nvalid, K, scale=None if tail_affine is None else tail_affine[0],
-                                  shift=None if tail_affine is None else tail_affine[1])
+            x = ops.masked_linear(x, pl, nvalid, K, relu=not last)
+            if site is not None:
+                sc, sh = site.affine(x, True)
+                x = ops.masked_affine(x, scale=sc, shift=sh)
     return x
 
 
@@ -134,13 +159,13 @@ class _DeepSignsBase(nn.Module):
         self._prep = None
         return super().load_state_dict(*a, **k)
 
-    def _prepare(self):
+    def _prepare(self, train=False):
         enc = self.enc
-        P = dict(gin=[], rho=_prep_mlp(self.rho))
+        P = dict(gin=[], rho=_prep_mlp(self.rho, train))
         L = len(enc.layers)
         for l, conv in enumerate(enc.layers):
-            nxt = ops.bn_fold(enc.bns[l]) if (enc.use_bn and l < L - 1) else None   # BN applied before layer l+1
-            P["gin"].append(dict(eps=conv.eps, mlp=_prep_mlp(conv.apply_func), next_bn=nxt))
+            nxt = _BNSite(enc.bns[l], train) if (enc.use_bn and l < L - 1) else None   # BN applied before layer l+1
+            P["gin"].append(dict(eps=conv.eps, mlp=_prep_mlp(conv.apply_func, train), next_bn=nxt))
         return P
 
     def _plan(self, g, N):
@@ -152,37 +177,39 @@ class _DeepSignsBase(nn.Module):
             raise ValueError("batch_num_nodes does not sum to the number of feature rows")
         return ops.build_plan(batch.long(), torch.stack([src.long(), dst.long()]), B, self.k)
 
-    def _phi(self, P, plan, x, N, K):
+    def _phi(self, P, plan, x, N, K, train=False):
         """enc(g, x) + enc(g, -x): GIN.forward, gnns.py:102-114, twice."""
         outs = []
         for sign in (0, 1):
             h = x
             for l, Lp in enumerate(P["gin"]):
                 a = ops.gin_aggregate(h.reshape(N, -1), plan, Lp["eps"], negate=(sign == 1 and l == 0))
-                h = _run_mlp(Lp["mlp"], a.view(N * K, -1), tail_affine=Lp["next_bn"])
+                h = _run_mlp(Lp["mlp"], a.view(N * K, -1), tail_bn=Lp["next_bn"], train=train)
             outs.append(h)
         return outs
 
     def forward(self, g, x):
-        if self.training:
-            raise NotImplementedError("train-mode (batch-statistics) forward is not wired yet; call .eval()")
+        train = self.training     # forward VALUE with batch statistics + running-statistics update (no autograd, dropout 0)
         ops.require_cuda(x)
         if x.dim() != 3 or x.shape[1] != self.k or x.shape[2] != 1:
             raise ValueError(f"expected x of shape [N, {self.k}, 1]")
-        if getattr(self, "_prep", None) is None:
-            self._prep = self._prepare()
-        P = self._prep
+        if train:
+            P = self._prepare(True)          # parameters may change between training-mode calls: nothing is cached
+        else:
+            if getattr(self, "_prep", None) is None:
+                self._prep = self._prepare()
+            P = self._prep
         N, K = x.shape[0], self.k
         plan = self._plan(g, N)
-        zp, zm = self._phi(P, plan, x.contiguous().float(), N, K)
+        zp, zm = self._phi(P, plan, x.contiguous().float(), N, K, train)
         if self.masked:
             # x[~mask] = 0 ; sum over K ; rho(c -> hidden -> K)             (deepsigns.py:76-84)
             z = ops.masked_affine(zp, plan.nvalid, K, residual=zm)
             s = ops.slot_sum(z, N, K)
-            y = _run_mlp(P["rho"], s)
+            y = _run_mlp(P["rho"], s, train=train)
         else:
             z = ops.masked_affine(zp, residual=zm)
-            y = _run_mlp(P["rho"], z.view(N, -1))                              # deepsigns.py:47-49
+            y = _run_mlp(P["rho"], z.view(N, -1), train=train)                 # deepsigns.py:47-49
         return y.view(N, K, 1)
 
 

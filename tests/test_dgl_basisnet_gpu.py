@@ -113,3 +113,45 @@ def test_signplus_deepsets_golden():
     # invariance to a global sign flip is exact: it swaps the two addends (the batch-statistics BatchNorm over the
     # stack of eigenvectors makes per-eigenvector flips only approximately invariant — in the reference too)
     assert torch.equal(y, sign(-v.to(DEV)))
+
+
+@pytest.mark.parametrize("name", ["dgl_gin_k8", "dgl_masked_k10"])
+def test_deepsigns_train_mode_forward(name):
+    """net.train(): BatchNorm with batch statistics over all N*K rows (gnns.py:105-112, mlp.py:44-50) against the
+    reference's train-mode fixture (tolerance of tests/test_oracle_golden.py::TOL_BS), plus the running-stat side effect."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    fx = G.load(name)
+    hidden, c, layers, k = (int(v) for v in fx.meta["params"])
+    kind = str(fx.meta["kind"])
+    net = DS.get_sign_inv_net(dict(sign_inv_net=kind, hidden_dim=hidden, phi_out_dim=c, sign_inv_layers=layers,
+                                   pos_enc_dim=k, dropout=0.0, sign_inv_activation="relu", device=DEV))
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train()
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    with torch.no_grad():
+        y = net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV))
+    torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=5e-4, atol=5e-5)
+    moved = [kk for kk, v in net.state_dict().items() if kk.endswith("running_mean") and not torch.equal(v.cpu(), fx.sd[kk])]
+    assert len(moved) == sum(1 for kk in fx.sd if kk.endswith("running_mean")), moved
+    y_eval = net.eval()(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV))      # new running statistics are picked up
+    assert not torch.allclose(y_eval.cpu(), fx.out["eval/y"], rtol=1e-3, atol=1e-4)
+
+
+def test_ign_train_mode_forward():
+    """IGN2to1.train(): BatchNorm1d(hidden) with batch statistics over the b*n rows of [b, hidden, n] (ign.py:31-33)."""
+    from signnet_basisnet_amd import basisnet as BN
+    fx = G.load("basisnet_grid6")
+    groups = BN.group_eigenspaces(fx.inp["eigvals"], fx.inp["eigvecs"])
+    mults = [int(m) for m in fx.meta["mults"]]
+    net = BN.IGNBasisInv(mults, 1, hidden_channels=int(fx.meta["hidden"]))
+    for m in mults:
+        enc = net.encs[net.mult_to_idx[m]]
+        enc.load_state_dict({k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith(f"enc{m}/")})
+    net = net.to(DEV).train()
+    for m in mults:
+        with torch.no_grad():
+            o = net(groups[m].to(DEV), m)
+        torch.testing.assert_close(o.cpu(), fx.out[f"train/phi_m{m}"], rtol=2e-3, atol=2e-4)
+        enc = net.encs[net.mult_to_idx[m]]
+        assert int(enc.bns[0].num_batches_tracked) == int(fx.sd[f"enc{m}/bns.0.num_batches_tracked"]) + 1
