@@ -78,6 +78,21 @@ def cpu_baseline(data, model_cpu_sd, budget_s=20.0):
                        f"(torch CPU fp32, {cores} threads)")
 
 
+def recorded_traffic(kernel):
+    """HBM bytes per launch from the committed PMC pass of this same command (profiles/hbm_traffic.json; FETCH_SIZE and
+    WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected in the timed run).  None for another workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec["workload"] != WORKLOAD["name"]:
+            return {"traffic": None}
+        return {"traffic": rec["kernels"][kernel]["bytes"], "traffic_unit": "bytes/launch",
+                "traffic_source": rec["source"] + " (separate rocprofv3 --pmc passes; 2 x FETCH_SIZE + WRITE_SIZE)"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +172,7 @@ def main():
         if DOMINANT in dom_times:
             launches, mean_ms = dom_times[DOMINANT]
             roof = ops.KERNEL_ROOFLINE[DOMINANT](fl, WORKLOAD, host, mean_ms, launches / args.steps)
+            roof.update(recorded_traffic(DOMINANT))
         ktimes = rec_all.summary()
         nall = min(args.steps, 20)
         all_roofs = {}
