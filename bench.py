@@ -78,6 +78,49 @@ def cpu_baseline(data, model_cpu_sd, budget_s=20.0):
                        f"(torch CPU fp32, {cores} threads)")
 
 
+def evd_bench(args, dev):
+    """Secondary workload (not the headline metric): `--workload evd` times the batched Laplacian
+    eigendecomposition (sn_laplacian_evd_f32) that produces the forward's eigen-data, on the same 128-graph batch
+    and on a large batch for the throughput limit.  Prints its own JSON line."""
+    import numpy as np
+    from oracle import evd as OE
+    from signnet_basisnet_amd import ops, synth
+    out = {"metric": "graphs/sec batched Laplacian eigendecomposition ('sym'), ZINC-like graphs", "unit": "graphs/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "roofline": None,
+           "roofline_note": "one-sided Jacobi in registers: bound by the dependent ds_bpermute / FMA chain of one wave per "
+                            "graph group (latency), neither HBM nor MFMA"}
+    for tag, B in (("batch128", WORKLOAD["B"]), ("batch8192", 8192)):
+        base = synth.make_batch(min(B, 1024), seed=1236)
+        reps = max(1, B // 1024)
+        ei = torch.cat([base.edge_index + r * base.num_nodes for r in range(reps)], 1)
+        sizes = list(base.sizes) * reps
+        gp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+        eid, N, total = ei.to(dev), sum(sizes), sum(v * v for v in sizes)
+        for _ in range(args.warmup):
+            ops.laplacian_evd(eid, gp, N, total, "sym")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st = ops.laplacian_evd(eid, gp, N, total, "sym")[-1]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        out[tag] = {"graphs": len(sizes), "nodes": N, "ms_per_step": 1e3 * dt, "value": len(sizes) / dt,
+                    "status": st.tolist()}
+        if tag == "batch128":
+            out["value"], out["ms_per_step"] = len(sizes) / dt, 1e3 * dt
+            out["config"] = {"workload": f"EVDTransform('sym') of one collated batch of {len(sizes)} ZINC-like graphs (n 9..37)"}
+            t0 = time.perf_counter()
+            n_rep = 0
+            while time.perf_counter() - t0 < 10.0:
+                OE.evd_batch(ei.numpy(), sizes, "sym")
+                n_rep += 1
+            out["cpu_baseline"] = {"value": n_rep * len(sizes) / (time.perf_counter() - t0), "unit": "graphs/s", "cores": 1,
+                                   "kind": "port", "sample": f"{n_rep} passes over the same batch, oracle/evd.py "
+                                   "(numpy LAPACK ssyevd per graph, one thread, as a DataLoader worker runs the reference's transform)"}
+    print(json.dumps(out))
+
+
 def recorded_traffic(kernel):
     """HBM bytes per launch from the committed PMC pass of this same command (profiles/hbm_traffic.json; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected in the timed run).  None for another workload."""
@@ -99,6 +142,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="forward", choices=["forward", "evd"],
+                    help="forward = the headline metric (default); evd = the eigendecomposition pre-transform (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
     args = ap.parse_args()
@@ -114,6 +159,13 @@ def main():
     dist = D.init_process_group("nccl") if world > 1 else None      # "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+
+    if args.workload == "evd":
+        if rank == 0:
+            evd_bench(args, dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # each rank owns its shard of the global batch: graphs [rank*B, (rank+1)*B)
     host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2 + 1000 * rank)

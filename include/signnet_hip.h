@@ -208,6 +208,28 @@ int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32_t* graph_p
 int64_t sn_ign_contract_scratch_floats(int64_t b, int n);
 int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, float* scratch, void* stream);
 
+/* Batched Laplacian eigendecomposition (the step before the path).  Replaces, for a whole collated
+ * batch on the device, the reference's per-sample host transforms
+ *   EVDTransform.__call__ / EVD_Laplacian  (Alchemy/sign_net/transform.py:7-23, GINESignNetPyG/core/transform.py:7-26:
+ *     to_undirected -> get_laplacian(normalization) -> dense -> torch.linalg.eigh), and
+ *   lap_positional_encoding                (GraphPrediction/data/molecules.py:148-181: I - D^-1/2 A D^-1/2, eig,
+ *     ascending sort, eigenvector columns 1..k, zero padding when n <= k).
+ * Inputs : edge_index[2,E] int64 (any order; made undirected, self loops dropped, duplicates coalesced);
+ *          graph_ptr[B+1] int32 (first node of each graph);  norm 0 = None (D - A), 1 = 'sym'.
+ * Outputs: evoff[B+1] int64 = prefix of n_b^2;  eigen_values[N] ascending per graph;
+ *          eigen_vectors[total] = the n_b x n_b blocks, row-major V[node, eig] (the reference's flattened wire format,
+ *          transform.py:14), total >= sum n_b^2 (the buffer doubles as the dense-adjacency scratch);
+ *          pos_enc[N,k] (optional, may be NULL) = V[:, skip : skip+k], zero padded (DGL layout: skip = 1).
+ * Eigenvector signs / the basis inside a repeated eigenvalue are arbitrary, as with LAPACK.  Graphs of up to 64 nodes
+ * (one-sided Jacobi in registers, 16/32/64 lanes per graph).
+ * work: int32[sn_evd_work_ints(B)].  status[4] (zeroed here): status[0] bit 0 = an edge leaves its graph / bad node id,
+ * bit 1 = a graph has > 64 nodes (its outputs are left zero), bit 2 = no convergence, bit 3 = `total` too small;
+ * status[1] = the largest number of Jacobi sweeps any wave ran (diagnostic). */
+int64_t sn_evd_work_ints(int64_t B);
+int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* graph_ptr, int64_t B, int64_t N,
+                         int norm, int64_t* evoff, float* eigen_values, float* eigen_vectors, int64_t total,
+                         float* pos_enc, int k, int skip, int32_t* work, int32_t* status, void* stream);
+
 /* ==========================================================================================
  * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).
  *

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), _i, _p, _p],
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],
+    "sn_laplacian_evd_f32": [_p, _l, _p, _l, _l, _i, _p, _p, _p, _l, _p, _i, _i, _p, _p, _p],
 }
 _SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
 
@@ -71,6 +72,8 @@ def lib():
         L.sn_split_packed_bytes.restype = C.c_int64
         L.sn_phi_bins_bound.argtypes = [_l, _i]
         L.sn_phi_bins_bound.restype = C.c_int64
+        L.sn_evd_work_ints.argtypes = [_l]
+        L.sn_evd_work_ints.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]
         L.sn_ign_contract_scratch_floats.restype = C.c_int64
         if L.sn_version() != 1:

@@ -426,6 +426,38 @@ def ign_contract_2to1(X):
     return out
 
 
+EVD_STATUS = {1: "an edge leaves its graph (or a node id is out of range)", 2: "a graph has more than 64 nodes",
+              4: "the Jacobi iteration did not converge", 8: "eigen_vectors buffer too small"}
+
+
+def laplacian_evd(edge_index, graph_ptr, N, total, norm=None, pos_enc_dim=0, skip=1):
+    """Batched Laplacian eigendecomposition on the device (transform.py:7-23 for every graph of a collated batch).
+
+    edge_index [2,E] int64, graph_ptr [B+1] int32 (device), N nodes, total = sum n_b^2 (host int).
+    Returns (eigen_values [N], eigen_vectors [total], evoff [B+1] int64, pos_enc [N,k] or None, status int32[4])."""
+    require_cuda(edge_index, graph_ptr)
+    if norm not in (None, "sym"):
+        raise ValueError(f"unsupported normalization {norm!r} (None or 'sym')")
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError("edge_index: expected int64 [2, E]")
+    if graph_ptr.dtype != torch.int32:
+        raise ValueError("graph_ptr: expected int32 [B+1]")
+    edge_index = edge_index.contiguous()
+    dev = edge_index.device
+    B, E = graph_ptr.numel() - 1, edge_index.shape[1]
+    val = torch.empty(N, dtype=torch.float32, device=dev)
+    vec = torch.empty(total, dtype=torch.float32, device=dev)
+    evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    pe = torch.empty(N, pos_enc_dim, dtype=torch.float32, device=dev) if pos_enc_dim > 0 else None
+    work = torch.empty(int(lib().sn_evd_work_ints(B)), dtype=torch.int32, device=dev)
+    status = torch.empty(4, dtype=torch.int32, device=dev)
+    with _span("sn_laplacian_evd_f32"):
+        check(lib().sn_laplacian_evd_f32(ptr(edge_index), E, ptr(graph_ptr), B, N, 0 if norm is None else 1, ptr(evoff),
+                                         ptr(val), ptr(vec), total, ptr(pe), int(pos_enc_dim), int(skip), ptr(work),
+                                         ptr(status), stream()), "sn_laplacian_evd_f32")
+    return val, vec, evoff, pe, status
+
+
 def bn_fold_stats(weight, bias, mean, var, eps, c_pad=None):
     """(scale, shift) of a BatchNorm from explicit statistics (batch statistics of the train-mode / no-running-stats case)."""
     Cc = mean.numel()

@@ -198,6 +198,39 @@ def basisnet_case(name, side, hidden, seed):
     save(name, **arrays)
 
 
+# ------------------------------------------------------------------ eigendecomposition transform
+def evd_case(name, sizes, seed):
+    """The reference's own EVDTransform (Alchemy/sign_net/transform.py:7-23) per sample, both normalisations.
+    (GINESignNetPyG/core/transform.py holds the same code.)  Includes a self loop, a duplicated and a one-directional
+    edge so that to_undirected / get_laplacian's clean-up is exercised."""
+    (mod,) = _fresh_import("Alchemy", ["sign_net.transform"])
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes, features="zinc")
+    ei = data.edge_index
+    extra = []
+    off = 0
+    for n in sizes:
+        if n >= 3:
+            extra += [(off, off), (off, off + 2), (off + 1, off + 2), (off + 1, off + 2)]   # loop, one-way, duplicate
+        off += n
+    if extra:
+        ei = torch.cat([ei, torch.tensor(extra, dtype=torch.int64).t()], 1)
+    arrays = {"in/edge_index": ei.numpy(), "in/sizes": np.array(sizes, dtype=np.int64)}
+    for norm in (None, "sym"):
+        vals, vecs = [], []
+        off = 0
+        for n in sizes:
+            sel = (ei[0] >= off) & (ei[0] < off + n)
+            sample = types.SimpleNamespace(edge_index=ei[:, sel] - off, num_nodes=n)
+            out = mod.EVDTransform(norm)(sample)
+            vals.append(out.eigen_values.numpy())
+            vecs.append(out.eigen_vectors.numpy())
+            off += n
+        tag = "none" if norm is None else norm
+        arrays[f"out/{tag}/eigen_values"] = np.concatenate(vals)
+        arrays[f"out/{tag}/eigen_vectors"] = np.concatenate(vecs)
+    save(name, **arrays)
+
+
 def main():
     # GINESignNetPyG: SignNetGNN(None, None, n_hid, n_out, nl_signnet, nl_gnn)
     pyg_case("gine_d16", "gine", (None, None, 16, 1, 3, 2), [5, 7, 6, 9], "zinc", 11)
@@ -211,6 +244,8 @@ def main():
     dgl_case("dgl_masked_k10", "masked_gin", 20, 20, 3, 10, [5, 13, 8, 11], 32)
     # BasisNet on a small grid
     basisnet_case("basisnet_grid6", 6, 8, 41)
+    # eigendecomposition transform: sizes across the kernel's 16 / 32 / 64-lane classes, odd and even, 1- and 2-node graphs
+    evd_case("evd_transform", [1, 2, 3, 8, 15, 16, 17, 23, 31, 32, 33, 37, 48, 63, 64], 51)
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_python_binding_covers_the_header(lib):
     from signnet_basisnet_amd import _lib
     bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_split_packed_bytes", "sn_phi_bins_bound",
-                                     "sn_ign_contract_scratch_floats"}
+                                     "sn_ign_contract_scratch_floats", "sn_evd_work_ints"}
     assert set(declared_symbols()) == bound
 
 
@@ -47,6 +47,9 @@ def test_version_and_error_string(lib):
     rc = lib.sn_pack_weight_f32(None, 4, 4, 4, None, None)
     assert rc == -1 and b"sn_pack_weight_f32" in lib.sn_last_error()
     assert lib.sn_packed_weight_floats(128, 128) == 64 * 256
+    assert lib.sn_evd_work_ints(128) == 3 * 128 + 8
+    rc = lib.sn_laplacian_evd_f32(None, 0, None, 0, 0, 0, None, None, None, 0, None, 0, 0, None, None, None)
+    assert rc == -1 and b"sn_laplacian_evd_f32" in lib.sn_last_error()
     assert lib.sn_packed_weight_floats(108, 6) == 7 * 1 * 256
     assert lib.sn_split_packed_bytes(128, 128) == 8 * (3 * 4 + 3) * 1024
     assert lib.sn_split_packed_bytes(108, 40) == 7 * (3 * 2 + 3) * 1024

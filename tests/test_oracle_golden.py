@@ -70,3 +70,51 @@ def test_signplus_deepsets():
     sd = {k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith("sign/")}
     v = fx.inp["eigvecs"].transpose(1, 0).unsqueeze(-1)
     torch.testing.assert_close(OB.sign_plus_deepsets(sd, v, 3, True), fx.out["eval/signplus"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("norm,tag", [(None, "none"), ("sym", "sym")])
+def test_evd_transform_restatement(norm, tag):
+    """oracle/evd.py against the reference's own EVDTransform outputs (transform.py:7-23): eigenvalues, residual,
+    orthogonality and — since eigenvector signs / degenerate bases are solver-specific — cluster projectors."""
+    import numpy as np
+    from oracle import evd as OE
+    fx = G.load("evd_transform")
+    ei = fx.inp["edge_index"].numpy()
+    sizes = [int(s) for s in fx.inp["sizes"]]
+    D, V = OE.evd_batch(ei, sizes, norm)
+    Dr, Vr = fx.out[f"{tag}/eigen_values"].numpy(), fx.out[f"{tag}/eigen_vectors"].numpy()
+    assert D.shape == Dr.shape and V.shape == Vr.shape
+    off = o2 = 0
+    for n in sizes:
+        sel = (ei[0] >= off) & (ei[0] < off + n)
+        L = OE.dense_laplacian(ei[:, sel] - off, n, norm)
+        r = OE.compare_decompositions(D[off:off + n], V[o2:o2 + n * n].reshape(n, n), Dr[off:off + n],
+                                      Vr[o2:o2 + n * n].reshape(n, n), L, 2e-6)
+        assert r["ok"], (n, r)
+        off += n
+        o2 += n * n
+
+
+def test_lap_positional_encoding_restatement_properties():
+    """molecules.py:148-181 restated (parity unpinned, see oracle/evd.py): shape, zero padding, and that the columns are
+    eigenvectors 1..k of the symmetric-normalised Laplacian."""
+    import numpy as np
+    from oracle import evd as OE
+    fx = G.load("evd_transform")
+    ei = fx.inp["edge_index"].numpy()
+    sizes = [int(s) for s in fx.inp["sizes"]]
+    off = 0
+    for n in sizes:
+        sel = (ei[0] >= off) & (ei[0] < off + n) & (ei[0] != ei[1])
+        loc = ei[:, sel] - off
+        loc = np.concatenate([loc, loc[::-1]], 1)                  # molecules are stored with both directions
+        pe = OE.lap_positional_encoding(loc, n, 8)
+        assert pe.shape == (n, 8) and pe.dtype == np.float32
+        if n <= 8:
+            assert not pe[:, max(n - 1, 0):].any()
+        L = OE.dense_laplacian(loc, n, "sym", np.float64)
+        w = np.linalg.eigvalsh(L)
+        kk = min(8, n - 1)
+        if kk:
+            assert np.abs(L @ pe[:, :kk].astype(np.float64) - pe[:, :kk] * w[1:1 + kk]).max() < 1e-5
+        off += n
