@@ -358,8 +358,9 @@ int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const 
                      void* stream);
 /* Flag report without a separate copy: when flags_host (device-accessible pinned host memory) is not NULL, the last
  * workgroup to finish copies flags_src[0 .. n_flags) (device; typically sn_batch_plan's status words followed by
- * sn_plan_bins.meta) to it, after every workgroup's own flag updates.  The caller reads it once an event recorded
- * behind the launch has completed. */
+ * sn_plan_bins.meta) to it, after every workgroup's own flag updates, and then — behind a system-scope fence — stores 1 to
+ * flags_host[n_flags] (so flags_host holds n_flags + 1 ints).  A caller that zeroed that word before the launch can poll
+ * it from the host: once it reads 1 the flags are there; no event / marker packet on the stream is needed. */
 
 #ifdef __cplusplus
 }

@@ -531,6 +531,8 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
         for (int i = 0; i < S.n_flags; ++i)
           S.flags_host[i] = __hip_atomic_load(&S.flags_src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();
+        __hip_atomic_store(&S.flags_host[S.n_flags], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // "ready": a host polling
+        __threadfence_system();                                                                        // this word sees the flags
       }
     }
   }

@@ -12,6 +12,8 @@ hold parameters; all arithmetic runs in the HIP kernels of libsignnet_hip.so thr
 """
 from __future__ import annotations
 
+import time
+
 import torch
 import torch.nn as nn
 
@@ -386,33 +388,58 @@ class SignNetGNN(nn.Module):
 
     def check_last(self, wait=True):
         """Raise if an earlier forward's batch could not be served by the fused kernels (wait=False: only look at
-        status copies that have already arrived)."""
+        status reports that have already arrived)."""
         while self._pending:
             ev, host = self._pending[0]
-            if not wait and len(self._pending) <= 4 and not ev.query():
+            if not wait and len(self._pending) <= 4 and not self._arrived(ev, host):
                 break
-            ev.synchronize()
+            self._wait_status(ev, host)
             self._pending.pop(0)
             self._free_hosts.append(host)
-            if self._flags_bad(host.tolist()):
+            if self._flags_bad(host[1]):
                 self._pending.clear()
                 raise RuntimeError("an earlier batch was malformed or had a graph too large for the fused SignNet kernels "
                                    "(> 64 nodes or > 192 edges): its outputs are invalid; set model.strict = True "
                                    "(re-runs such batches layer by layer) or model.use_fused = False")
 
+    _READY = 16          # word of the pinned buffer the GINE kernel sets to 1 after the 16 flags (sn_gnn_fused_f32)
+
+    @classmethod
+    def _arrived(cls, ev, host):
+        return bool(host[1][cls._READY]) if ev is None else ev.query()
+
+    @classmethod
+    def _wait_status(cls, ev, host):
+        if ev is not None:
+            ev.synchronize()
+            return
+        view = host[1]
+        t_end = time.perf_counter() + 2e-3
+        while not view[cls._READY]:                       # normally already there; spin briefly, then block on the device
+            if time.perf_counter() > t_end:
+                torch.cuda.synchronize()
+                if not view[cls._READY]:
+                    raise RuntimeError("the fused GINE kernel did not report its status flags")
+                break
+
     def _host_flags(self):
-        """A pooled pinned buffer for one forward's device flags."""
-        return self._free_hosts.pop() if self._free_hosts else torch.zeros(16, dtype=torch.int32, pin_memory=True)
+        """A pooled pinned buffer (tensor, numpy view) for one forward's device flags + the kernel's ready word."""
+        if self._free_hosts:
+            return self._free_hosts.pop()
+        t = torch.zeros(32, dtype=torch.int32, pin_memory=True)
+        return t, t.numpy()
 
     def _post_status(self, plan):
-        """Event after which this forward's flags are in their pinned buffer.  With the fused GINE stage its last
-        workgroup wrote them there itself (no copy on the stream); otherwise an asynchronous copy is queued."""
+        """(event | None, buffer) of this forward's flags.  With the fused GINE stage its last workgroup writes them to the
+        pinned buffer itself and then sets the ready word — no copy and no event (a marker packet costs ~6 us of idle
+        stream per forward); otherwise an asynchronous copy + event is queued."""
         host = self._flags_host
         self._flags_host = None
-        if host is None:
-            host = self._host_flags()
-            n = plan.flags.numel()
-            host[:n].copy_(plan.flags, non_blocking=True)
+        if host is not None:
+            return None, host
+        host = self._host_flags()
+        n = plan.flags.numel()
+        host[0][:n].copy_(plan.flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         return ev, host
@@ -432,8 +459,8 @@ class SignNetGNN(nn.Module):
         if self.use_fused and not return_stages and self._used_fused:
             ev, host = self._post_status(self._last_plan)
             if self.strict:
-                ev.synchronize()
-                flags = host.tolist()
+                self._wait_status(ev, host)
+                flags = host[1].tolist()
                 self._free_hosts.append(host)
                 if self._flags_bad(flags):
                     if flags[0]:
@@ -521,8 +548,8 @@ class SignNetGNN(nn.Module):
         if use_gnn_fused and not return_stages:
             self._flags_host = self._host_flags() if (plan.bins is not None and not _NO_KERNEL_FLAGS) else None
             if self._flags_host is not None:
-                self._flags_host.zero_()          # host-side; the kernel's last workgroup overwrites it
-            return P["gnn_fused"].run(plan, data.x, data.edge_attr, s, self._flags_host)
+                self._flags_host[1][:] = 0        # host-side; the kernel's last workgroup overwrites it, ready word last
+            return P["gnn_fused"].run(plan, data.x, data.edge_attr, s, None if self._flags_host is None else self._flags_host[0])
         pe = _lin_bn(s, P["rho_out"]["l"], P["rho_out"]["bn"], train, relu=False)
         if return_stages:
             stages["pos"] = pe
