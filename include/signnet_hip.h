@@ -230,6 +230,54 @@ int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* gr
                          int norm, int64_t* evoff, float* eigen_values, float* eigen_vectors, int64_t total,
                          float* pos_enc, int k, int skip, int32_t* work, int32_t* status, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Backward of the layer-at-a-time train path.  The reference obtains these from torch.autograd over
+ * ATen / PyG / torch_scatter kernels (loss.backward(): Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62-63);
+ * here each forward entry point above has a hand-written adjoint.  Rows r = node*K + slot with slot >= nvalid[node]
+ * carry zero gradient.  dX of a Linear is sn_masked_linear_f32 with the transposed weight packed.
+ *
+ * sn_linear_wgrad_f32: dW[o,i] = sum_r dy[r,o] x[r,i], db[o] = sum_r dy[r,o] over the valid rows (nn.Linear weight / bias
+ *   gradients; fp32-input MFMA, per-row-chunk partials + a deterministic reduction).  db may be NULL.
+ *   scratch: float[sn_linear_wgrad_scratch_floats(R, d_in, d_out)].
+ * sn_bn_act_bwd_f32: train-mode BatchNorm1d (+ ReLU after it) backward.  Forward was a = scale*z + shift with
+ *   scale = gamma*rstd, shift = beta - mean*scale (sn_bn_fold_f32 on the batch statistics), y = relu?(a).  Writes
+ *   sums[0..C) = d beta = sum g, sums[C..2C) = d gamma = sum g*xhat (g = dy*[a>0], xhat = (z-mean)*rstd) and
+ *   dz = scale*(g - d beta/M - xhat*d gamma/M), M = *count.  scratch: float[2*C*sn_colstats_blocks(R)].
+ * sn_relu_bwd_f32: dx = dy*[y>0].
+ * sn_masked_layernorm_bwd_f32: adjoint of sn_masked_layernorm_f32 (MaskedLN, masked_layers.py:22-32): du (gradient of
+ *   both x and residual), d gamma, d beta.  scratch: float[sn_layernorm_bwd_scratch_floats(R, C)].
+ * sn_set_attention_bwd_f32: adjoint of sn_set_attention_f32 (softmax recomputed): dq, dk, dv.
+ * sn_gine_aggregate_bwd_f32: adjoint of sn_gine_aggregate_f32 w.r.t. the node features (dh) and the per-edge features
+ *   (dee, [E,C] in edge-id order) over the REVERSE CSR (rows = source nodes, rev_col = destination, rev_eperm = edge id:
+ *   sn_batch_plan on the flipped edge_index).  (GIN's adjoint is sn_gin_aggregate_f32 itself on the reverse CSR.)
+ * sn_slot_broadcast_f32 / sn_segment_broadcast_f32: adjoints of sn_slot_sum_f32 (valid slots only) / sn_segment_pool_f32.
+ * sn_embedding_sum_bwd_f32: dtables[f][idx[r,f],:] += g[r,:] (fp32 atomics; dtables zeroed by the caller).
+ * sn_dot_f32: out[0] = sum a[i] b[i] (the GIN / GINE eps gradients).  scratch: float[256].
+ * sn_adam_step_f32: one torch.optim.Adam step (no amsgrad; weight_decay added to the gradient) on a flat tensor. */
+int64_t sn_linear_wgrad_scratch_floats(int64_t R, int d_in, int d_out);
+int sn_linear_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, int64_t R, int d_in, int d_out,
+                        const int32_t* nvalid, int K, float* dW, float* db, float* scratch, void* stream);
+int sn_bn_act_bwd_f32(const float* z, int ldz, const float* dy, int ldd, int64_t R, int C, const int32_t* nvalid, int K,
+                      const float* mean, const float* rstd, const float* scale, const float* shift, int relu,
+                      const float* count, float* sums, float* dz, int ldo, float* scratch, void* stream);
+int sn_relu_bwd_f32(const float* y, const float* dy, int64_t R, int C, const int32_t* nvalid, int K, float* dx, void* stream);
+int64_t sn_layernorm_bwd_scratch_floats(int64_t R, int C);
+int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const float* dy, int64_t R, int C, const float* gamma,
+                                float eps, const int32_t* nvalid, int K, float* du, float* dgamma, float* dbeta,
+                                float* scratch, void* stream);
+int sn_set_attention_bwd_f32(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K, int heads,
+                             int dk, const int32_t* nvalid, float* dq, float* dk_out, float* dv, void* stream);
+int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, int64_t N, int C, const int32_t* rev_rowptr,
+                              const int32_t* rev_col, const int32_t* rev_eperm, const float* eps, float* dh, float* dee,
+                              void* stream);
+int sn_slot_broadcast_f32(const float* g, int64_t N, int K, int C, const int32_t* nvalid, float* dx, void* stream);
+int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const int32_t* graph_ptr, int mode, float* dx, void* stream);
+int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, int C, const float* g,
+                             void* stream);
+int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch, void* stream);
+int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void* stream);
+
 /* ==========================================================================================
  * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).
  *

@@ -45,6 +45,17 @@ SIGNATURES = {
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],
     "sn_laplacian_evd_f32": [_p, _l, _p, _l, _l, _i, _p, _p, _p, _l, _p, _i, _i, _p, _p, _p],
+    "sn_linear_wgrad_f32": [_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p],
+    "sn_bn_act_bwd_f32": [_p, _i, _p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],
+    "sn_relu_bwd_f32": [_p, _p, _l, _i, _p, _i, _p, _p],
+    "sn_masked_layernorm_bwd_f32": [_p, _p, _p, _l, _i, _p, _f, _p, _i, _p, _p, _p, _p, _p],
+    "sn_set_attention_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p],
+    "sn_gine_aggregate_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
+    "sn_slot_broadcast_f32": [_p, _l, _i, _i, _p, _p, _p],
+    "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],
+    "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, _i, _p, _p],
+    "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
+    "sn_adam_step_f32": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
 }
 _SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
 
@@ -72,6 +83,10 @@ def lib():
         L.sn_split_packed_bytes.restype = C.c_int64
         L.sn_phi_bins_bound.argtypes = [_l, _i]
         L.sn_phi_bins_bound.restype = C.c_int64
+        L.sn_linear_wgrad_scratch_floats.argtypes = [_l, _i, _i]
+        L.sn_linear_wgrad_scratch_floats.restype = C.c_int64
+        L.sn_layernorm_bwd_scratch_floats.argtypes = [_l, _i]
+        L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
         L.sn_evd_work_ints.argtypes = [_l]
         L.sn_evd_work_ints.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]

@@ -1,0 +1,315 @@
+"""torch.autograd.Function wrappers: forward = the layer-at-a-time HIP entry points, backward = their hand-written
+adjoints (csrc/backward.hip).  SURVEY.md §8 f1 — what the reference gets from torch.autograd over ATen / PyG /
+torch_scatter kernels (loss.backward(), Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62-63).
+
+torch only records the graph and owns the buffers; no arithmetic of the path runs in ATen.  Conventions as in ops.py:
+row matrices [R, C] with R = N*K slot rows (valid iff slot < nvalid[node]) or R = N / E / B plain rows (nvalid None).
+Gradients flowing into an op are zero on invalid rows because every producer masks them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import check, lib, ptr, stream
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- raw adjoint launches
+def linear_wgrad(x, dy, nvalid, K, want_bias=True):
+    d_in, d_out = x.shape[-1], dy.shape[-1]
+    R = x.numel() // d_in
+    dW = torch.empty(d_out, d_in, dtype=torch.float32, device=x.device)
+    db = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
+    scratch = torch.empty(int(lib().sn_linear_wgrad_scratch_floats(R, d_in, d_out)), dtype=torch.float32, device=x.device)
+    with ops._span("sn_linear_wgrad_f32"):
+        check(lib().sn_linear_wgrad_f32(ptr(x), d_in, ptr(dy), d_out, R, d_in, d_out, ptr(nvalid), int(K), ptr(dW), ptr(db),
+                                        ptr(scratch), stream()), "sn_linear_wgrad_f32")
+    return dW, db
+
+
+def relu_bwd(y, dy, nvalid, K):
+    Cc = y.shape[-1]
+    dx = torch.empty_like(y)
+    check(lib().sn_relu_bwd_f32(ptr(y), ptr(dy), y.numel() // Cc, Cc, ptr(nvalid), int(K), ptr(dx), stream()), "sn_relu_bwd_f32")
+    return dx
+
+
+def dot(a, b):
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    scratch = torch.empty(256, dtype=torch.float32, device=a.device)
+    check(lib().sn_dot_f32(ptr(a), ptr(b), a.numel(), ptr(out), ptr(scratch), stream()), "sn_dot_f32")
+    return out
+
+
+# ----------------------------------------------------------------------------- Linear (+ mask, optional ReLU)
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, W, b, nvalid, K, relu):
+        x = _c(x)
+        pl = ops.PackedLinear(ops.pack_weight(W.detach()), W.shape[0], W.shape[1], None if b is None else _c(b.detach()))
+        y = ops.masked_linear(x, pl, nvalid, K, relu=relu)
+        ctx.save_for_backward(x, W, y if relu else None)
+        ctx.meta = (nvalid, K, relu, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        nvalid, K, relu, has_b = ctx.meta
+        dy = _c(dy)
+        if relu:
+            dy = relu_bwd(y, dy, nvalid, K)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty(W.shape[1], W.shape[0], dtype=torch.float32, device=W.device).copy_(W.detach().t())
+            plt = ops.PackedLinear(ops.pack_weight(wt), wt.shape[0], wt.shape[1], None)
+            dx = ops.masked_linear(dy, plt, nvalid, K, use_bias=False).view(x.shape)
+        dW, db = linear_wgrad(x, dy, nvalid, K, has_b)
+        return dx, dW, db, None, None, None
+
+
+def linear(x, W, b=None, nvalid=None, K=0, relu=False):
+    """y = [relu](x @ W^T + b) on valid rows, 0 elsewhere (nn.Linear + the reference's mask)."""
+    return _Linear.apply(x, W, b, nvalid, K, relu)
+
+
+# ----------------------------------------------------------------------------- train-mode BatchNorm (+ReLU) (+residual)
+class _BnAct(Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, residual, bn, nvalid, K, relu):
+        z = _c(z)
+        mean, var, count = ops.masked_colstats(z, nvalid, K)
+        g = None if gamma is None else gamma.detach()
+        b = None if beta is None else beta.detach()
+        scale, shift = ops.bn_fold_stats(g, b, mean, var, bn.eps)
+        rstd, _ = ops.bn_fold_stats(None, None, mean, var, bn.eps)
+        ops.bn_running_update(bn, mean, var, count)
+        res = None if residual is None else _c(residual)
+        y = ops.masked_affine(z, nvalid, K, scale=scale, shift=shift, relu=relu, residual=res)
+        ctx.save_for_backward(z, mean, rstd, scale, shift, count)
+        ctx.meta = (nvalid, K, relu, gamma is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, scale, shift, count = ctx.saved_tensors
+        nvalid, K, relu, affine, has_res = ctx.meta
+        dy = _c(dy)
+        Cc = z.shape[-1]
+        R = z.numel() // Cc
+        sums = torch.empty(2 * Cc, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        scratch = torch.empty(2 * Cc * int(lib().sn_colstats_blocks(R)), dtype=torch.float32, device=z.device)
+        with ops._span("sn_bn_act_bwd_f32"):
+            check(lib().sn_bn_act_bwd_f32(ptr(z), Cc, ptr(dy), Cc, R, Cc, ptr(nvalid), int(K), ptr(mean), ptr(rstd), ptr(scale),
+                                          ptr(shift), int(relu), ptr(count), ptr(sums), ptr(dz), Cc, ptr(scratch), stream()),
+                  "sn_bn_act_bwd_f32")
+        dres = None
+        if has_res:
+            dres = dy if nvalid is None else ops.masked_affine(dy, nvalid, K)      # the output is 0 on invalid rows
+        return dz, sums[Cc:] if affine else None, sums[:Cc] if affine else None, dres, None, None, None, None
+
+
+def bn_act(z, bn, nvalid=None, K=0, relu=True, residual=None):
+    """[relu](BatchNorm1d(z) with batch statistics over the valid rows) [+ residual]; updates bn's running statistics."""
+    return _BnAct.apply(z, bn.weight, bn.bias, residual, bn, nvalid, K, relu)
+
+
+# ----------------------------------------------------------------------------- masked add (phi(x) + phi(-x), residuals)
+class _MaskedAdd(Function):
+    @staticmethod
+    def forward(ctx, a, b, nvalid, K):
+        ctx.meta = (nvalid, K)
+        return ops.masked_affine(_c(a), nvalid, K, residual=_c(b))
+
+    @staticmethod
+    def backward(ctx, dy):
+        nvalid, K = ctx.meta
+        g = _c(dy) if nvalid is None else ops.masked_affine(_c(dy), nvalid, K)
+        return g, g, None, None
+
+
+def masked_add(a, b, nvalid=None, K=0):
+    return _MaskedAdd.apply(a, b, nvalid, K)
+
+
+# ----------------------------------------------------------------------------- GIN / GINE aggregation
+class _GinAgg(Function):
+    @staticmethod
+    def forward(ctx, x, eps, plan, rplan, negate):
+        x = _c(x)
+        ctx.save_for_backward(x, eps)
+        ctx.meta = (rplan, negate)
+        return ops.gin_aggregate(x, plan, eps.detach(), negate=negate)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, eps = ctx.saved_tensors
+        rplan, negate = ctx.meta
+        g = _c(g)
+        dx = ops.gin_aggregate(g, rplan, eps.detach(), negate=negate) if ctx.needs_input_grad[0] else None
+        deps = None
+        if ctx.needs_input_grad[1]:
+            deps = dot(g, x)
+            if negate:
+                deps = -deps
+        return dx, deps, None, None, None
+
+
+def gin_aggregate(x, eps, plan, rplan, negate=False):
+    """(1+eps) x_i + sum_{j->i} x_j over the node axis of x [N, F] (F = K*C flattened), optionally of -x."""
+    return _GinAgg.apply(x, eps, plan, rplan, negate)
+
+
+class _GineAgg(Function):
+    @staticmethod
+    def forward(ctx, h, ee, eps, plan, rplan):
+        h, ee = _c(h), _c(ee)
+        ctx.save_for_backward(h, ee, eps)
+        ctx.rplan = rplan
+        return ops.gine_aggregate(h, ee, plan, eps.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        h, ee, eps = ctx.saved_tensors
+        rp = ctx.rplan
+        g = _c(g)
+        dh, dee = torch.empty_like(h), torch.empty_like(ee)
+        with ops._span("sn_gine_aggregate_bwd_f32"):
+            check(lib().sn_gine_aggregate_bwd_f32(ptr(h), ptr(ee), ptr(g), h.shape[0], h.shape[1], ptr(rp.rowptr), ptr(rp.col),
+                                                  ptr(rp.eperm), ptr(eps.detach()), ptr(dh), ptr(dee), stream()),
+                  "sn_gine_aggregate_bwd_f32")
+        return dh, dee, (dot(g, h) if ctx.needs_input_grad[2] else None), None, None
+
+
+def gine_aggregate(h, ee, eps, plan, rplan):
+    return _GineAgg.apply(h, ee, eps, plan, rplan)
+
+
+# ----------------------------------------------------------------------------- set attention / LayerNorm / slot sum
+class _Attention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, N, K, heads, nvalid):
+        q, k, v = _c(q), _c(k), _c(v)
+        ctx.save_for_backward(q, k, v)
+        ctx.meta = (N, K, heads, nvalid)
+        return ops.set_attention(q, k, v, N, K, heads, nvalid)
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v = ctx.saved_tensors
+        N, K, heads, nvalid = ctx.meta
+        g = _c(g)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        with ops._span("sn_set_attention_bwd_f32"):
+            check(lib().sn_set_attention_bwd_f32(ptr(q), ptr(k), ptr(v), ptr(g), N, K, heads, q.shape[-1] // heads, ptr(nvalid),
+                                                 ptr(dq), ptr(dk), ptr(dv), stream()), "sn_set_attention_bwd_f32")
+        return dq, dk, dv, None, None, None, None
+
+
+def set_attention(q, k, v, N, K, heads, nvalid=None):
+    return _Attention.apply(q, k, v, N, K, heads, nvalid)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps, nvalid, K):
+        x = _c(x)
+        res = None if residual is None else _c(residual)
+        ctx.save_for_backward(x, res, gamma)
+        ctx.meta = (eps, nvalid, K)
+        return ops.masked_layernorm(x, res, gamma.detach(), beta.detach(), eps, nvalid, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, res, gamma = ctx.saved_tensors
+        eps, nvalid, K = ctx.meta
+        g = _c(g)
+        Cc = x.shape[-1]
+        R = x.numel() // Cc
+        du = torch.empty_like(x)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        scratch = torch.empty(int(lib().sn_layernorm_bwd_scratch_floats(R, Cc)), dtype=torch.float32, device=x.device)
+        with ops._span("sn_masked_layernorm_bwd_f32"):
+            check(lib().sn_masked_layernorm_bwd_f32(ptr(x), ptr(res), ptr(g), R, Cc, ptr(gamma.detach()), float(eps), ptr(nvalid),
+                                                    int(K), ptr(du), ptr(dgamma), ptr(dbeta), ptr(scratch), stream()),
+                  "sn_masked_layernorm_bwd_f32")
+        return du, (du if res is not None else None), dgamma, dbeta, None, None, None
+
+
+def masked_layernorm(x, residual, gamma, beta, eps, nvalid=None, K=0):
+    return _LayerNorm.apply(x, residual, gamma, beta, eps, nvalid, K)
+
+
+class _SlotSum(Function):
+    @staticmethod
+    def forward(ctx, x, N, K, nvalid):
+        ctx.meta = (N, K, nvalid, x.shape)
+        return ops.slot_sum(_c(x), N, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, K, nvalid, shape = ctx.meta
+        g = _c(g)
+        dx = torch.empty(N * K, g.shape[-1], dtype=torch.float32, device=g.device)
+        check(lib().sn_slot_broadcast_f32(ptr(g), N, K, g.shape[-1], ptr(nvalid), ptr(dx), stream()), "sn_slot_broadcast_f32")
+        return dx.view(shape), None, None, None
+
+
+def slot_sum(x, N, K, nvalid=None):
+    return _SlotSum.apply(x, N, K, nvalid)
+
+
+# ----------------------------------------------------------------------------- embeddings / pooling
+class _EmbeddingSum(Function):
+    @staticmethod
+    def forward(ctx, idx, *tables):
+        if idx.dim() == 1:
+            idx = idx.unsqueeze(1)
+        idx = idx.contiguous()
+        ctx.idx = idx
+        ctx.shapes = [t.shape for t in tables]
+        return ops.embedding_sum(idx, [t.detach() for t in tables])
+
+    @staticmethod
+    def backward(ctx, g):
+        idx = ctx.idx
+        g = _c(g)
+        R, nf = idx.shape
+        grads = [torch.zeros(s, dtype=torch.float32, device=g.device) if f < nf else None for f, s in enumerate(ctx.shapes)]
+        arr = (C.c_void_p * nf)(*[grads[f].data_ptr() for f in range(nf)])
+        check(lib().sn_embedding_sum_bwd_f32(ptr(idx), nf, nf, R, arr, g.shape[-1], ptr(g), stream()), "sn_embedding_sum_bwd_f32")
+        return (None, *grads)
+
+
+def embedding_sum(idx, tables):
+    """sum_f tables[f][idx[:, f]] (DiscreteEncoder); tables beyond idx's feature columns get no gradient."""
+    return _EmbeddingSum.apply(idx, *tables)
+
+
+class _SegmentPool(Function):
+    @staticmethod
+    def forward(ctx, h, plan, mode):
+        ctx.meta = (plan, mode, h.shape)
+        return ops.segment_pool(_c(h), plan, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, mode, shape = ctx.meta
+        g = _c(g)
+        dx = torch.empty(shape, dtype=torch.float32, device=g.device)
+        check(lib().sn_segment_broadcast_f32(ptr(g), plan.B, g.shape[-1], ptr(plan.graph_ptr), 1 if mode == "mean" else 0, ptr(dx),
+                                             stream()), "sn_segment_broadcast_f32")
+        return dx, None, None
+
+
+def segment_pool(h, plan, mode="add"):
+    return _SegmentPool.apply(h, plan, mode)

@@ -1,0 +1,499 @@
+// backward.hip — gradients of the layer-at-a-time train path (backward + optimiser step).
+//
+// The reference gets these from torch.autograd over ATen / PyG / torch_scatter kernels (loss.backward() at
+// Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62-63).  Here every forward entry point of
+// signnet_hip.h has its hand-written adjoint; the Python side (signnet_basisnet_amd/autograd.py) only wires them
+// into torch.autograd.Function objects.  Same conventions as the forward: fp32 row matrices, a row r = node*K +
+// slot is valid iff slot < nvalid[node], invalid rows carry zero gradient.
+#include "common.hpp"
+
+namespace sn {
+namespace {
+
+__device__ __forceinline__ bool row_ok(const int32_t* __restrict__ nvalid, int K, int64_t r) {
+  if (!nvalid) return true;
+  const int64_t node = r / K;
+  return (int)(r - node * K) < nvalid[node];
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ============================================================================ dW = dy^T x, db = sum dy   (fp32 MFMA)
+// grid (row chunks, groups of 64 outputs, groups of 128 inputs); 4 waves, wave w owns output tile 4*og + w and all
+// 8 input tiles of the group: acc[t][r] = dW[16(4og+w) + 4(l>>4) + r][128 ig + 16 t + (l&15)].
+constexpr int WG_OC = 64, WG_IC = 128, WG_LDO = WG_OC + 16, WG_LDI = WG_IC + 16;
+__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int ldy,
+                                               int64_t R, int d_in, int d_out, const int32_t* __restrict__ nvalid, int K,
+                                               int64_t rows_per_block, float* __restrict__ part, float* __restrict__ part_b) {
+  __shared__ float xs[16 * WG_LDI];
+  __shared__ float ds[16 * WG_LDO];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int oc0 = blockIdx.y * WG_OC, ic0 = blockIdx.z * WG_IC;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  f32x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  for (int64_t rb = r0; rb < r1; rb += 16) {
+    __syncthreads();
+    for (int i = t; i < 16 * WG_IC; i += 256) {
+      const int rr = i / WG_IC, c = i - rr * WG_IC;
+      const int64_t r = rb + rr;
+      float v = 0.f;
+      if (r < r1 && ic0 + c < d_in && row_ok(nvalid, K, r)) v = x[r * ldx + ic0 + c];
+      xs[rr * WG_LDI + c] = v;
+    }
+    for (int i = t; i < 16 * WG_OC; i += 256) {
+      const int rr = i / WG_OC, c = i - rr * WG_OC;
+      const int64_t r = rb + rr;
+      float v = 0.f;
+      if (r < r1 && oc0 + c < d_out && row_ok(nvalid, K, r)) v = dy[r * ldy + oc0 + c];
+      ds[rr * WG_LDO + c] = v;
+    }
+    __syncthreads();
+    if (t < WG_OC) {
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) bsum += ds[rr * WG_LDO + t];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int row = 4 * kk + (lane >> 4);
+      const float a = ds[row * WG_LDO + 16 * w + (lane & 15)];
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) acc[tt] = mfma16(a, xs[row * WG_LDI + 16 * tt + (lane & 15)], acc[tt]);
+    }
+  }
+  float* p = part + (int64_t)blockIdx.x * d_out * d_in;
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt) {
+    const int ic = ic0 + 16 * tt + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int oc = oc0 + 16 * w + 4 * (lane >> 4) + r;
+      if (oc < d_out && ic < d_in) p[(int64_t)oc * d_in + ic] = acc[tt][r];
+    }
+  }
+  if (part_b && blockIdx.z == 0 && t < WG_OC && oc0 + t < d_out) part_b[(int64_t)blockIdx.x * d_out + oc0 + t] = bsum;
+}
+// out[i] = sum_b part[b][i]
+__global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int nblk, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * n + i];
+  out[i] = s;
+}
+
+// ============================================================================ train-mode BatchNorm (+ReLU) backward
+// forward: a = scale[c]*z + shift[c] (scale = gamma*rstd, shift = beta - mean*scale), y = relu?(a) (+ residual).
+// g = dy * [a > 0];  s1 = sum g, s2 = sum g*xhat (xhat = (z-mean)*rstd);  dz = scale*(g - s1/M - xhat*s2/M).
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict__ z, int ldz, const float* __restrict__ dy,
+                                                        int ldd, int64_t R, int C, const int32_t* __restrict__ nvalid, int K,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int relu, int64_t rows_per_block, float* __restrict__ part) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float m = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      if (!row_ok(nvalid, K, r)) continue;
+      const float zv = z[r * ldz + c];
+      float g = dy[r * ldd + c];
+      if (relu && !(zv * sc + sh > 0.f)) g = 0.f;
+      s1 += g;
+      s2 += g * ((zv - m) * rs);
+    }
+    part[(int64_t)blockIdx.x * 2 * C + c] = s1;
+    part[(int64_t)blockIdx.x * 2 * C + C + c] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ z, int ldz, const float* __restrict__ dy, int ldd,
+                                                      int64_t R, int C, const int32_t* __restrict__ nvalid, int K,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      int relu, const float* __restrict__ sums, const float* __restrict__ count,
+                                                      float* __restrict__ dz, int ldo) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * C) return;
+  const int64_t r = idx / C;
+  const int c = (int)(idx - r * C);
+  float v = 0.f;
+  if (row_ok(nvalid, K, r)) {
+    const float zv = z[r * ldz + c], sc = scale[c];
+    float g = dy[r * ldd + c];
+    if (relu && !(zv * sc + shift[c] > 0.f)) g = 0.f;
+    const float M = *count, inv = M > 0.f ? 1.0f / M : 0.f;
+    const float xh = (zv - mean[c]) * rstd[c];
+    v = sc * (g - sums[c] * inv - xh * sums[C + c] * inv);
+  }
+  dz[r * ldo + c] = v;
+}
+// dx = dy * [y > 0] on valid rows (plain ReLU epilogue without a norm)
+__global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ y, const float* __restrict__ dy, int64_t R, int C,
+                                                  const int32_t* __restrict__ nvalid, int K, float* __restrict__ dx) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * C) return;
+  const int64_t r = idx / C;
+  dx[idx] = (row_ok(nvalid, K, r) && y[idx] > 0.f) ? dy[idx] : 0.f;
+}
+
+// ============================================================================ masked LayerNorm backward
+// forward (k_layernorm): u = x + res, y = (u - mean_r)*rstd_r*gamma + beta.  One wave per row, LN_ROWS rows per wave.
+constexpr int LN_ROWS = 16;
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, const float* __restrict__ res,
+                                                       const float* __restrict__ dy, int64_t R, int C,
+                                                       const float* __restrict__ gamma, float eps,
+                                                       const int32_t* __restrict__ nvalid, int K, float* __restrict__ du,
+                                                       float* __restrict__ part /* [nblk][2C] */) {
+  extern __shared__ float sm[];          // [4][2C]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* mine = sm + (size_t)w * 2 * C;
+  for (int c = lane; c < 2 * C; c += 64) mine[c] = 0.f;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + w) * LN_ROWS;
+  for (int i = 0; i < LN_ROWS; ++i) {
+    const int64_t row = row0 + i;
+    if (row >= R) break;
+    float* dr = du + row * C;
+    if (!row_ok(nvalid, K, row)) {
+      for (int c = lane; c < C; c += 64) dr[c] = 0.f;
+      continue;
+    }
+    const float* xr = x + row * C;
+    const float* rr = res ? res + row * C : nullptr;
+    const float* gr = dy + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c] + (rr ? rr[c] : 0.f);
+    const float mean = wsum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] + (rr ? rr[c] : 0.f) - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + eps);
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] + (rr ? rr[c] : 0.f) - mean) * rstd, h = gr[c] * gamma[c];
+      m1 += h;
+      m2 += h * xh;
+      mine[c] += gr[c] * xh;            // d gamma
+      mine[C + c] += gr[c];             // d beta
+    }
+    m1 = wsum(m1) / (float)C;
+    m2 = wsum(m2) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] + (rr ? rr[c] : 0.f) - mean) * rstd;
+      dr[c] = rstd * (gr[c] * gamma[c] - m1 - xh * m2);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    part[(int64_t)blockIdx.x * 2 * C + c] = sm[c] + sm[2 * C + c] + sm[4 * C + c] + sm[6 * C + c];
+}
+
+// ============================================================================ per-node set attention backward
+// One wave per (node, head), mirroring k_set_attention: P = softmax(q k^T / sqrt(dk)) over the valid slots, o = P v.
+__global__ __launch_bounds__(64) void k_set_attention_bwd(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ dout, int K,
+                                                          int H, int dk, const int32_t* __restrict__ nvalid,
+                                                          float* __restrict__ dq, float* __restrict__ dkk, float* __restrict__ dv) {
+  extern __shared__ float sm[];
+  const int node = blockIdx.x / H, h = blockIdx.x - node * H;
+  const int lane = threadIdx.x;
+  const int kv = nvalid ? nvalid[node] : K;
+  const int D = H * dk;
+  float* sq = sm;                // [K][dk]  q / sqrt(dk)
+  float* sk = sq + K * dk;
+  float* sv = sk + K * dk;
+  float* sg = sv + K * dk;       // [K][dk]  d out
+  float* sp = sg + K * dk;       // [K][K+1] P
+  float* sd = sp + K * (K + 1);  // [K][K+1] dS
+  const float temp = sqrtf((float)dk);
+  const int64_t base = (int64_t)node * K * D + (int64_t)h * dk;
+  for (int i = lane; i < kv * dk; i += 64) {
+    const int r = i / dk, c = i - r * dk;
+    const int64_t o = base + (int64_t)r * D + c;
+    sq[i] = q[o] / temp;
+    sk[i] = k[o];
+    sv[i] = v[o];
+    sg[i] = dout[o];
+  }
+  __syncthreads();
+  for (int i = lane; i < kv * kv; i += 64) {
+    const int a = i / kv, b = i - a * kv;
+    float s = 0.f, d = 0.f;
+    for (int c = 0; c < dk; ++c) { s += sq[a * dk + c] * sk[b * dk + c]; d += sg[a * dk + c] * sv[b * dk + c]; }
+    sp[a * (K + 1) + b] = s;
+    sd[a * (K + 1) + b] = d;       // dP
+  }
+  __syncthreads();
+  for (int a = lane; a < kv; a += 64) {
+    float m = -INFINITY;
+    for (int b = 0; b < kv; ++b) m = fmaxf(m, sp[a * (K + 1) + b]);
+    float zs = 0.f;
+    for (int b = 0; b < kv; ++b) { const float e = expf(sp[a * (K + 1) + b] - m); sp[a * (K + 1) + b] = e; zs += e; }
+    float dot = 0.f;
+    for (int b = 0; b < kv; ++b) { const float p = sp[a * (K + 1) + b] / zs; sp[a * (K + 1) + b] = p; dot += p * sd[a * (K + 1) + b]; }
+    for (int b = 0; b < kv; ++b) sd[a * (K + 1) + b] = sp[a * (K + 1) + b] * (sd[a * (K + 1) + b] - dot);     // dS
+  }
+  __syncthreads();
+  for (int i = lane; i < K * dk; i += 64) {
+    const int a = i / dk, c = i - a * dk;
+    float gq = 0.f, gk = 0.f, gv = 0.f;
+    if (a < kv)
+      for (int b = 0; b < kv; ++b) {
+        gq += sd[a * (K + 1) + b] * sk[b * dk + c];
+        gk += sd[b * (K + 1) + a] * sq[b * dk + c];
+        gv += sp[b * (K + 1) + a] * sg[b * dk + c];
+      }
+    const int64_t o = base + (int64_t)a * D + c;
+    dq[o] = gq / temp;
+    dkk[o] = gk;
+    dv[o] = gv;
+  }
+}
+
+// ============================================================================ GINE aggregation backward
+// forward: out_i = (1+eps) h_i + sum_{e: j->i} relu(h_j + ee_e).  Per SOURCE node j over its out-edges (reverse CSR:
+// rcol = destination, rperm = edge id):  dh_j = (1+eps) g_j + sum_e [h_j + ee_e > 0] g_i ;  dee_e = [..] g_i.
+__global__ __launch_bounds__(256) void k_gine_bwd(const float* __restrict__ h, const float* __restrict__ ee,
+                                                  const float* __restrict__ g, int64_t N, int C,
+                                                  const int32_t* __restrict__ rrow, const int32_t* __restrict__ rcol,
+                                                  const int32_t* __restrict__ rperm, const float* __restrict__ eps,
+                                                  float* __restrict__ dh, float* __restrict__ dee) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * C) return;
+  const int64_t j = idx / C;
+  const int c = (int)(idx - j * C);
+  const float hv = h[idx];
+  float acc = (1.0f + (eps ? *eps : 0.f)) * g[idx];
+  for (int s = rrow[j]; s < rrow[j + 1]; ++s) {
+    const int64_t e = rperm[s];
+    const float gi = (hv + ee[e * C + c] > 0.f) ? g[(int64_t)rcol[s] * C + c] : 0.f;
+    acc += gi;
+    dee[e * C + c] = gi;
+  }
+  dh[idx] = acc;
+}
+
+// ============================================================================ broadcasts / scatters / reductions
+// dx[n,k,:] = g[n,:] for k < nvalid[n], else 0      (adjoint of k_slot_sum over the valid slots)
+__global__ __launch_bounds__(256) void k_slot_bcast(const float* __restrict__ g, int64_t N, int K, int C,
+                                                    const int32_t* __restrict__ nvalid, float* __restrict__ dx) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K * C) return;
+  const int64_t r = idx / C;
+  const int c = (int)(idx - r * C);
+  const int64_t n = r / K;
+  dx[idx] = row_ok(nvalid, K, r) ? g[n * C + c] : 0.f;
+}
+// dx[i,:] = g[graph(i),:] (* 1/n_g for mean pooling)
+__global__ __launch_bounds__(256) void k_segment_bcast(const float* __restrict__ g, int C, const int32_t* __restrict__ graph_ptr,
+                                                       int mode, float* __restrict__ dx) {
+  const int b = blockIdx.x;
+  const int lo = graph_ptr[b], hi = graph_ptr[b + 1];
+  const float w = (mode == 1 && hi > lo) ? 1.0f / (float)(hi - lo) : 1.0f;
+  for (int64_t i = threadIdx.x; i < (int64_t)(hi - lo) * C; i += 256) {
+    const int c = (int)(i % C);
+    dx[(int64_t)lo * C + i] = g[(int64_t)b * C + c] * w;
+  }
+}
+struct GradTables { float* t[10]; };
+// dT_f[idx[r,f], :] += g[r, :]
+__global__ __launch_bounds__(256) void k_embedding_bwd(const int64_t* __restrict__ idx, int ldi, int nf, int64_t R, GradTables tp,
+                                                       int C, const float* __restrict__ g) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  const float v = g[i];
+  for (int f = 0; f < nf; ++f) atomicAdd(&tp.t[f][idx[r * ldi + f] * C + c], v);
+}
+// out[0] = sum_i a[i]*b[i]   (two stages, deterministic)
+__global__ __launch_bounds__(256) void k_dot_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                     float* __restrict__ part) {
+  __shared__ float ws[4];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += a[i] * b[i];
+  s = wsum(s);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// ============================================================================ Adam (torch.optim.Adam, no amsgrad)
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                              float wd, float bc1, float bc2_sqrt) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  if (wd != 0.f) gi += wd * p[i];
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+}  // namespace sn
+
+using namespace sn;
+
+static inline int64_t wgrad_rows_per_block(int64_t R) {
+  int64_t rpb = 512;
+  while (cdiv(R, rpb) > 256) rpb *= 2;
+  return rpb;
+}
+extern "C" int64_t sn_linear_wgrad_scratch_floats(int64_t R, int d_in, int d_out) {
+  const int64_t nblk = cdiv(R > 0 ? R : 1, wgrad_rows_per_block(R));
+  return nblk * ((int64_t)d_in * d_out + d_out);
+}
+extern "C" int sn_linear_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, int64_t R, int d_in, int d_out,
+                                   const int32_t* nvalid, int K, float* dW, float* db, float* scratch, void* stream) {
+  SN_REQUIRE(x && dy && dW && scratch && R >= 0 && d_in > 0 && d_out > 0, "sn_linear_wgrad_f32: bad arguments");
+  SN_REQUIRE(ldx >= d_in && ldy >= d_out, "sn_linear_wgrad_f32: leading dimension too small");
+  SN_REQUIRE(!nvalid || K > 0, "sn_linear_wgrad_f32: nvalid needs K > 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rpb = wgrad_rows_per_block(R);
+  const int nblk = (int)cdiv(R > 0 ? R : 1, rpb);
+  float* part = scratch;
+  float* part_b = scratch + (int64_t)nblk * d_in * d_out;
+  dim3 grid((unsigned)nblk, (unsigned)cdiv(d_out, WG_OC), (unsigned)cdiv(d_in, WG_IC));
+  hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, st, x, ldx, dy, ldy, R, d_in, d_out, nvalid, K, rpb, part, db ? part_b : nullptr);
+  SN_CHECK_LAUNCH("k_wgrad");
+  const int64_t n = (int64_t)d_in * d_out;
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, part, nblk, n, dW);
+  if (db) hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(d_out, 256)), dim3(256), 0, st, part_b, nblk, (int64_t)d_out, db);
+  SN_CHECK_LAUNCH("k_sum_parts");
+  return SN_OK;
+}
+
+extern "C" int sn_bn_act_bwd_f32(const float* z, int ldz, const float* dy, int ldd, int64_t R, int C, const int32_t* nvalid, int K,
+                                 const float* mean, const float* rstd, const float* scale, const float* shift, int relu,
+                                 const float* count, float* sums /* [2C]: d beta, d (gamma) */, float* dz, int ldo,
+                                 float* scratch /* [2C * sn_colstats_blocks(R)] */, void* stream) {
+  SN_REQUIRE(z && dy && mean && rstd && scale && shift && count && sums && dz && scratch && R >= 0 && C > 0,
+             "sn_bn_act_bwd_f32: bad arguments");
+  SN_REQUIRE(ldz >= C && ldd >= C && ldo >= C, "sn_bn_act_bwd_f32: leading dimension too small");
+  SN_REQUIRE(!nvalid || K > 0, "sn_bn_act_bwd_f32: nvalid needs K > 0");
+  if (R == 0) return SN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = sn_colstats_blocks(R);
+  const int64_t rpb = cdiv(R, nblk);
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)nblk), dim3(256), 0, st, z, ldz, dy, ldd, R, C, nvalid, K, mean, rstd, scale,
+                     shift, relu, rpb, scratch);
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(2 * C, 256)), dim3(256), 0, st, scratch, nblk, (int64_t)2 * C, sums);
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, st, z, ldz, dy, ldd, R, C, nvalid, K, mean,
+                     rstd, scale, shift, relu, sums, count, dz, ldo);
+  SN_CHECK_LAUNCH("sn_bn_act_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_relu_bwd_f32(const float* y, const float* dy, int64_t R, int C, const int32_t* nvalid, int K, float* dx,
+                               void* stream) {
+  SN_REQUIRE(y && dy && dx && R >= 0 && C > 0 && (!nvalid || K > 0), "sn_relu_bwd_f32: bad arguments");
+  if (R == 0) return SN_OK;
+  hipLaunchKernelGGL(k_relu_bwd, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, R, C, nvalid, K, dx);
+  SN_CHECK_LAUNCH("sn_relu_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int64_t sn_layernorm_bwd_scratch_floats(int64_t R, int C) { return cdiv(R > 0 ? R : 1, 4 * LN_ROWS) * 2 * C; }
+extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const float* dy, int64_t R, int C,
+                                           const float* gamma, float eps, const int32_t* nvalid, int K, float* du,
+                                           float* dgamma, float* dbeta /* contiguous pair is NOT required */, float* scratch,
+                                           void* stream) {
+  SN_REQUIRE(x && dy && gamma && du && dgamma && dbeta && scratch && R >= 0 && C > 0 && (!nvalid || K > 0),
+             "sn_masked_layernorm_bwd_f32: bad arguments");
+  SN_REQUIRE((size_t)8 * C * sizeof(float) <= 64 * 1024, "sn_masked_layernorm_bwd_f32: C too large");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv(R > 0 ? R : 1, 4 * LN_ROWS);
+  hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)8 * C * sizeof(float), st, x, residual, dy, R, C,
+                     gamma, eps, nvalid, K, du, scratch);
+  // scratch rows are [d gamma (C) | d beta (C)]: reduce with a stride of 2C
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(2 * C, 256)), dim3(256), 0, st, scratch, nblk, (int64_t)2 * C, scratch);
+  SN_CHECK_LAUNCH("sn_masked_layernorm_bwd_f32");
+  hipError_t e = hipMemcpyAsync(dgamma, scratch, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dbeta, scratch + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return fail(SN_ERR_LAUNCH, "sn_masked_layernorm_bwd_f32: copy: %s", hipGetErrorString(e));
+  return SN_OK;
+}
+
+extern "C" int sn_set_attention_bwd_f32(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K,
+                                        int heads, int dk, const int32_t* nvalid, float* dq, float* dk_out, float* dv,
+                                        void* stream) {
+  SN_REQUIRE(q && k && v && dout && dq && dk_out && dv && N >= 0 && K > 0 && heads > 0 && dk > 0,
+             "sn_set_attention_bwd_f32: bad arguments");
+  if (N == 0) return SN_OK;
+  const size_t lds = ((size_t)4 * K * dk + (size_t)2 * K * (K + 1)) * sizeof(float);
+  SN_REQUIRE(lds <= 64 * 1024, "sn_set_attention_bwd_f32: K*dk too large for LDS (%zu bytes)", lds);
+  hipLaunchKernelGGL(k_set_attention_bwd, dim3((unsigned)(N * heads)), dim3(64), lds, (hipStream_t)stream, q, k, v, dout, K,
+                     heads, dk, nvalid, dq, dk_out, dv);
+  SN_CHECK_LAUNCH("sn_set_attention_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, int64_t N, int C,
+                                         const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm,
+                                         const float* eps, float* dh, float* dee, void* stream) {
+  SN_REQUIRE(h && ee && g && rev_rowptr && dh && dee && N >= 0 && C > 0, "sn_gine_aggregate_bwd_f32: bad arguments");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_gine_bwd, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, h, ee, g, N, C, rev_rowptr,
+                     rev_col, rev_eperm, eps, dh, dee);
+  SN_CHECK_LAUNCH("sn_gine_aggregate_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_slot_broadcast_f32(const float* g, int64_t N, int K, int C, const int32_t* nvalid, float* dx, void* stream) {
+  SN_REQUIRE(g && dx && N >= 0 && K > 0 && C > 0, "sn_slot_broadcast_f32: bad arguments");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_slot_bcast, dim3((unsigned)cdiv(N * K * C, 256)), dim3(256), 0, (hipStream_t)stream, g, N, K, C, nvalid, dx);
+  SN_CHECK_LAUNCH("sn_slot_broadcast_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const int32_t* graph_ptr, int mode, float* dx,
+                                        void* stream) {
+  SN_REQUIRE(g && dx && graph_ptr && B >= 0 && C > 0 && (mode == 0 || mode == 1), "sn_segment_broadcast_f32: bad arguments");
+  if (B == 0) return SN_OK;
+  hipLaunchKernelGGL(k_segment_bcast, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, g, C, graph_ptr, mode, dx);
+  SN_CHECK_LAUNCH("sn_segment_broadcast_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, int C,
+                                        const float* g, void* stream) {
+  SN_REQUIRE(idx && dtables && g && nf > 0 && nf <= 10 && ldi >= nf && R >= 0 && C > 0, "sn_embedding_sum_bwd_f32: bad arguments");
+  if (R == 0) return SN_OK;
+  GradTables tp;
+  for (int f = 0; f < 10; ++f) tp.t[f] = f < nf ? dtables[f] : nullptr;
+  hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, ldi, nf, R, tp, C, g);
+  SN_CHECK_LAUNCH("sn_embedding_sum_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch /* [256] */, void* stream) {
+  SN_REQUIRE(a && b && out && scratch && n >= 0, "sn_dot_f32: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)(n > 0 ? (cdiv(n, 256) < 256 ? cdiv(n, 256) : 256) : 1);
+  hipLaunchKernelGGL(k_dot_partial, dim3((unsigned)nblk), dim3(256), 0, st, a, b, n, scratch);
+  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, scratch, nblk, (int64_t)1, out);
+  SN_CHECK_LAUNCH("sn_dot_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int step, void* stream) {
+  SN_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "sn_adam_step_f32: bad arguments");
+  if (n == 0) return SN_OK;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, sqrtf(bc2));
+  SN_CHECK_LAUNCH("sn_adam_step_f32");
+  return SN_OK;
+}
