@@ -449,6 +449,8 @@ class SignNetGNN(nn.Module):
             # train-mode forward VALUE (no autograd): BatchNorm with batch statistics over the valid rows and the
             # running-statistics update, layer by layer.  The attention dropout p = 0.1 that the reference leaves
             # active in training (transformer_module.py:46,55) is random and NOT applied (fixtures: p = 0).
+            if torch.is_grad_enabled() and not return_stages and any(p.requires_grad for p in self.parameters()):
+                return self._forward_grad(data)    # differentiable: autograd.Function per layer op (csrc/backward.hip)
             self._prep = None                      # parameters may have changed since the last call
             try:
                 return self._forward(data, return_stages, train=True)
@@ -474,6 +476,87 @@ class SignNetGNN(nn.Module):
                 self._pending.append((ev, host))
         self._last_plan = None
         return y
+
+    # ------------------------------------------------------------------ differentiable train-mode forward
+    def _forward_grad(self, data):
+        """Train-mode forward recorded for torch.autograd: the same layer-at-a-time HIP launches as `_forward(train=True)`,
+        each wrapped in a torch.autograd.Function whose backward is its hand-written adjoint (autograd.py).  `.backward()`
+        on a loss of the result fills `.grad` of every parameter the reference's forward uses (loss.backward() at
+        Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62).  As in the value path the attention dropout
+        (p = 0.1, transformer_module.py:46,55) is not applied."""
+        from . import autograd as AG
+        ops.require_cuda(data.edge_index, data.batch, data.eigen_vectors)
+        sn, g = self.sign_net, self.gnn
+        B = int(data.num_graphs)
+        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0)
+        rplan = ops.build_plan(data.batch, data.edge_index.flip(0).contiguous(), B, self.max_k or 0)   # out-edge CSR
+        K = int(self.max_k) if self.max_k else plan.check()[1]
+        N, nv = plan.N, plan.nvalid
+        alchemy_eig = self.variant == "alchemy" and not sn.ignore_eigval
+        want_vals = alchemy_eig or self.variant != "alchemy"
+        x0, s0 = ops.pack_eig(plan, data.eigen_vectors, data.eigen_values if want_vals else None, K, want_vals)
+
+        def lin_bn(x, lin, norm, nvalid=None, K_=0, relu=True, residual=None):
+            if isinstance(norm, _Identity):
+                y = AG.linear(x, lin.weight, lin.bias, nvalid, K_, relu=relu)
+                return y if residual is None else AG.masked_add(y, residual, nvalid, K_)
+            bn = norm.bn if isinstance(norm, MaskedBN) else norm
+            return AG.bn_act(AG.linear(x, lin.weight, lin.bias, nvalid, K_), bn, nvalid, K_, relu=relu, residual=residual)
+
+        if self.variant != "alchemy":      # computed and discarded by the reference (core/sign_net.py:111-112): side effects only
+            with torch.no_grad():
+                ee2 = sn.eigen_encoder2
+                p2 = lin_bn(s0.view(N * K, 1), ee2.layers[0], ee2.norms[0], nv, K)
+                lin_bn(p2, ee2.layers[1], ee2.norms[1], nv, K)
+        # ---- phi(x) + phi(-x)
+        phis = []
+        for sign in (0, 1):
+            x, prev = x0, None
+            for l, (conv, norm) in enumerate(zip(sn.phi.convs, sn.phi.norms)):
+                a = AG.gin_aggregate(x.view(N, -1), conv.layer.eps, plan, rplan, negate=(sign == 1 and l == 0))
+                h = lin_bn(a.view(N * K, -1), conv.nn.layers[0], conv.nn.norms[0], nv, K)
+                x = lin_bn(h, conv.nn.layers[1], norm, nv, K, residual=prev)
+                prev = x
+            phis.append(x)
+        x = AG.masked_add(phis[0], phis[1], nv, K)
+        # ---- rho
+        if alchemy_eig:
+            ee = sn.eigen_encoder
+            p = lin_bn(s0.view(N * K, 1), ee.layers[0], ee.norms[0], nv, K)
+            p = lin_bn(p, ee.layers[1], ee.norms[1], nv, K)
+            x = AG.masked_add(x, p, nv, K)
+        for tl in sn.rho.transformer_layers:
+            a, f = tl.slf_attn, tl.pos_ffn
+            q = AG.linear(x, a.w_qs.weight, None, nv, K)
+            k = AG.linear(x, a.w_ks.weight, None, nv, K)
+            v = AG.linear(x, a.w_vs.weight, None, nv, K)
+            o = AG.set_attention(q, k, v, N, K, N_HEAD, nv)
+            o = AG.linear(o, a.fc.weight, None, nv, K)
+            y = AG.masked_layernorm(o, x, a.norm.ln.weight, a.norm.ln.bias, LN_EPS, nv, K)
+            z = AG.linear(y, f.w_1.weight, f.w_1.bias, nv, K, relu=True)
+            z = AG.linear(z, f.w_2.weight, f.w_2.bias, nv, K)
+            x = AG.masked_layernorm(z, y, f.norm.ln.weight, f.norm.ln.bias, LN_EPS, nv, K)
+        s = AG.slot_sum(x, N, K, nv)
+        pe = lin_bn(s, sn.rho.out[0], sn.rho.out[1], relu=False)
+        # ---- GINE network
+        xin = data.x.squeeze() if data.x.dim() > 1 and data.x.shape[-1] == 1 else data.x
+        if isinstance(g.input_encoder, DiscreteEncoder):
+            h = AG.embedding_sum(xin, [e.weight for e in g.input_encoder.embeddings])
+        else:
+            h = lin_bn(xin.contiguous(), g.input_encoder.layers[0], g.input_encoder.norms[0])
+        h = AG.linear(torch.cat([h, pe], dim=-1), g.linear.weight, g.linear.bias)
+        for enc, conv, norm in zip(g.edge_encoders, g.convs, g.norms):
+            if isinstance(enc, DiscreteEncoder):
+                e = AG.embedding_sum(data.edge_attr, [t.weight for t in enc.embeddings])
+            else:
+                e = lin_bn(data.edge_attr.contiguous(), enc.layers[0], enc.norms[0])
+            u = AG.gine_aggregate(h, e, conv.layer.eps, plan, rplan)
+            u = lin_bn(u, conv.nn.layers[0], conv.nn.norms[0])
+            h = lin_bn(u, conv.nn.layers[1], norm, residual=h)
+        pooled = AG.segment_pool(h, plan, g.pooling)
+        oe = g.output_encoder
+        y = lin_bn(pooled, oe.layers[0], oe.norms[0])
+        return AG.linear(y, oe.layers[1].weight, oe.layers[1].bias)
 
     # ------------------------------------------------------------------ forward
     def _forward(self, data, return_stages=False, train=False):

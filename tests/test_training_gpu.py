@@ -1,0 +1,104 @@
+"""-m gpu: the differentiable train-mode forward of SignNetGNN: parameter gradients and a few Adam steps
+against torch.autograd / torch.optim.Adam running the float64 CPU oracle on the reference's fixtures (same state_dict,
+same batch).  Tolerance: 2e-3 of each tensor's largest gradient entry (+1e-6): train-mode BatchNorm over few rows
+amplifies fp32 rounding, cf. TOL_BS of test_oracle_golden.py."""
+import pytest
+import torch
+
+import golden_util as G
+from test_pyg_parity_gpu import build
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def oracle_setup(fx):
+    sd = {k: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone().double()
+              if v.is_floating_point() else v.clone()) for k, v in fx.sd.items()}
+    data = G.as_data(fx.inp)
+    for a in ("eigen_values", "eigen_vectors"):
+        setattr(data, a, getattr(data, a).double())
+    if data.x.is_floating_point():
+        data.x, data.edge_attr = data.x.double(), data.edge_attr.double()
+    return sd, data
+
+
+def ref_grad(sd, name):
+    """Gradient the oracle assigns to a model parameter; PyG registers GINEConv's MLP twice (`.nn.` and `.layer.nn.`)."""
+    g = None
+    for k in (name, name.replace(".nn.", ".layer.nn.", 1)):
+        if k in sd and sd[k].requires_grad and sd[k].grad is not None:
+            g = sd[k].grad if g is None else g + sd[k].grad
+        if k == name.replace(".nn.", ".layer.nn.", 1) and k == name:
+            break
+    return g
+
+
+@pytest.mark.parametrize("name", ["gine_d16", "gine_d44_ragged", "alchemy_d12", "alchemy_d36"])
+def test_parameter_gradients_match_oracle_autograd(name):
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    fx = G.load(name)
+    model = build(fx).train()
+    data = synth.batch_to(G.as_data(fx.inp), DEV)
+    y = model(data)
+    assert y.requires_grad
+    cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+    (y * cot.float().to(DEV)).sum().backward()
+    sd, odata = oracle_setup(fx)
+    yo = O.signnet_gnn(sd, G.pyg_cfg(fx), odata, training=True)
+    err = (y.detach().cpu().double() - yo.detach()).abs().max().item()
+    assert err <= 5e-4 * max(1.0, yo.abs().max().item()), f"forward: {err:.3e}"
+    (yo * cot).sum().backward()
+    checked, worst = 0, (0.0, "")
+    # a bias in front of a batch-statistics BatchNorm has zero true gradient: the oracle's float64 gives 1e-14, fp32 sums of
+    # +-1 terms give 1e-5 — hence an absolute term tied to the largest gradient of the whole model
+    gmax = max(v.grad.abs().max().item() for v in sd.values() if torch.is_tensor(v) and v.requires_grad and v.grad is not None)
+    for pname, p in model.named_parameters():
+        gr = ref_grad(sd, pname)
+        if gr is None or gr.abs().max() == 0:
+            assert p.grad is None or p.grad.abs().max().item() <= 1e-5 * gmax + 1e-6, f"{pname}: gradient where the reference has none"
+            continue
+        assert p.grad is not None, f"{pname}: no gradient"
+        scale = gr.abs().max().item()
+        e = (p.grad.detach().cpu().double() - gr).abs().max().item()
+        worst = max(worst, (e / (scale + 1e-3 * gmax), pname))
+        assert e <= 2e-3 * scale + 1e-5 * gmax + 1e-6, f"{pname}: max|diff| {e:.3e} vs max|grad| {scale:.3e} (model max {gmax:.3e})"
+        checked += 1
+    assert checked >= 40, checked
+    print(f"{name}: {checked} parameter tensors, worst relative error {worst[0]:.2e} ({worst[1]})")
+
+
+def test_adam_training_steps_follow_the_oracle():
+    """Three optimiser steps (forward, L1 loss as main_alchemy.py:106 / train.py:60, backward, Adam) on the device against
+    the same three steps of torch.optim.Adam on the float64 oracle: losses and the final eval output agree."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import optim, synth
+    fx = G.load("gine_d16")
+    model = build(fx).train()
+    data = synth.batch_to(G.as_data(fx.inp), DEV)
+    sd, odata = oracle_setup(fx)
+    cfg = G.pyg_cfg(fx)
+    target = torch.randn(len(odata.sizes), int(fx.meta["ctor"][3]), generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    opt = optim.Adam(model.parameters(), lr=1e-3)
+    names = {k for k, _ in model.named_parameters()}
+    # the oracle holds GINEConv's MLP under two names; optimise the one it reads
+    oparams = [v for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
+    oopt = torch.optim.Adam(oparams, lr=1e-3)
+    for step in range(3):
+        opt.zero_grad()
+        loss = (model(data) - target.float().to(DEV)).abs().mean()
+        loss.backward()
+        opt.step()
+        oopt.zero_grad()
+        # running statistics are buffers of the module; the functional oracle does not carry them between calls
+        oloss = (O.signnet_gnn(sd, cfg, odata, training=True) - target).abs().mean()
+        oloss.backward()
+        oopt.step()
+        assert abs(loss.item() - oloss.item()) <= 2e-3 * max(1.0, abs(oloss.item())), (step, loss.item(), oloss.item())
+    with torch.no_grad():
+        y = model(data)          # still train mode: batch statistics, no running-stat dependence
+        yo = O.signnet_gnn(sd, cfg, odata, training=True)
+    err = (y.cpu().double() - yo).abs().max().item()
+    assert err <= 5e-3 * max(1.0, yo.abs().max().item()), err
+    assert names
