@@ -121,6 +121,70 @@ def evd_bench(args, dev):
     print(json.dumps(out))
 
 
+def train_bench(args, dev):
+    """Secondary workload (not the headline metric): `--workload train` times full training steps
+    (differentiable train-mode forward on the layer kernels, L1 loss, backward through the hand-written adjoints, one
+    FlatAdam launch) of the headline model on the headline batch.  Prints its own JSON line."""
+    from signnet_basisnet_amd import ops, optim, synth
+    host = synth.make_batch(WORKLOAD["B"], seed=1236)
+    data = synth.batch_to(host, dev)
+    model = build_model(dev).train()
+    opt = optim.FlatAdam(model.parameters(), lr=1e-3)
+    target = torch.randn(WORKLOAD["B"], WORKLOAD["n_out"], generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def step():
+        opt.zero_grad()
+        loss = (model(data) - target).abs().mean()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    rec = ops.KernelTimer()
+    with rec:
+        for _ in range(3):
+            step()
+    kt = rec.summary()
+    per = {k: {"launches_per_step": v[0] / 3, "mean_us": 1e3 * v[1], "us_per_step": 1e3 * v[1] * v[0] / 3} for k, v in kt.items()}
+    fl = algorithmic_flops(host, WORKLOAD["k"], WORKLOAD["hidden"], WORKLOAD["nl_signnet"], WORKLOAD["nl_rho"], WORKLOAD["nl_gnn"])
+    out = {"metric": "graphs/sec SignNet+GINE training step (forward + backward + Adam), ZINC batch=128 k=16", "unit": "graphs/s",
+           "value": WORKLOAD["B"] / dt, "ms_per_step": 1e3 * dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None, "final_loss": float(loss.detach()),
+           "config": {"workload": WORKLOAD["name"] + ", train step", "gflop_per_step": 3 * fl["total"] / 1e9},
+           "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF,
+                        "achieved": 3 * fl["total"] / dt / 1e12, "frac": 3 * fl["total"] / dt / 1e12 / MFMA_F32_PEAK_TF,
+                        "note": "whole step, ~3x the forward's dense flops (forward + dX + dW), layer-at-a-time fp32-MFMA kernels; "
+                                "this path is launch/HBM bound (one kernel per op), not matrix-pipe bound"},
+           "kernels": dict(sorted(per.items(), key=lambda kv: -kv[1]["us_per_step"]))}
+    if not args.no_cpu_baseline:
+        # the float32 CPU oracle under torch.autograd + torch.optim.Adam: what the reference's training loop does on the host
+        from oracle import pyg_signnet as O
+        cfg = O.make_cfg("gine", None, None, WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"])
+        sd = {k: (torch.nn.Parameter(v.detach().cpu().clone()) if v.is_floating_point() and "running" not in k else v.detach().cpu().clone())
+              for k, v in model.state_dict().items()}
+        oopt = torch.optim.Adam([v for v in sd.values() if isinstance(v, torch.nn.Parameter)], lr=1e-3)
+        tcpu = target.cpu()
+        ts = []
+        t_end = time.perf_counter() + 20.0
+        while len(ts) < 2 or (time.perf_counter() < t_end and len(ts) < 6):
+            t0 = time.perf_counter()
+            oopt.zero_grad()
+            (O.signnet_gnn(sd, cfg, host, training=True, max_k=WORKLOAD["k"]) - tcpu).abs().mean().backward()
+            oopt.step()
+            ts.append(time.perf_counter() - t0)
+        med = sorted(ts[1:])[len(ts[1:]) // 2]
+        out["cpu_baseline"] = {"value": WORKLOAD["B"] / med, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{len(ts) - 1} training step(s) of the same batch after one warm-up, median; oracle/pyg_signnet.py "
+                                         "under torch.autograd + torch.optim.Adam (CPU fp32)"}
+    print(json.dumps(out))
+
+
 def recorded_traffic(kernel):
     """HBM bytes per launch from the committed PMC pass of this same command (profiles/hbm_traffic.json; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected in the timed run).  None for another workload."""
@@ -142,8 +206,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="forward", choices=["forward", "evd"],
-                    help="forward = the headline metric (default); evd = the eigendecomposition pre-transform (secondary)")
+    ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train"],
+                    help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
     ap.add_argument("--event-stride", type=int, default=1,
@@ -162,9 +226,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if args.workload == "evd":
+    if args.workload in ("evd", "train"):
         if rank == 0:
-            evd_bench(args, dev)
+            (evd_bench if args.workload == "evd" else train_bench)(args, dev)
         if dist is not None:
             dist.destroy_process_group()
         return

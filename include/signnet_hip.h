@@ -242,7 +242,7 @@ int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* gr
  * sn_bn_act_bwd_f32: train-mode BatchNorm1d (+ ReLU after it) backward.  Forward was a = scale*z + shift with
  *   scale = gamma*rstd, shift = beta - mean*scale (sn_bn_fold_f32 on the batch statistics), y = relu?(a).  Writes
  *   sums[0..C) = d beta = sum g, sums[C..2C) = d gamma = sum g*xhat (g = dy*[a>0], xhat = (z-mean)*rstd) and
- *   dz = scale*(g - d beta/M - xhat*d gamma/M), M = *count.  scratch: float[2*C*sn_colstats_blocks(R)].
+ *   dz = scale*(g - d beta/M - xhat*d gamma/M), M = *count.  scratch: float[sn_bn_act_bwd_scratch_floats(R, C)].
  * sn_relu_bwd_f32: dx = dy*[y>0].
  * sn_masked_layernorm_bwd_f32: adjoint of sn_masked_layernorm_f32 (MaskedLN, masked_layers.py:22-32): du (gradient of
  *   both x and residual), d gamma, d beta.  scratch: float[sn_layernorm_bwd_scratch_floats(R, C)].
@@ -253,10 +253,12 @@ int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* gr
  * sn_slot_broadcast_f32 / sn_segment_broadcast_f32: adjoints of sn_slot_sum_f32 (valid slots only) / sn_segment_pool_f32.
  * sn_embedding_sum_bwd_f32: dtables[f][idx[r,f],:] += g[r,:] (fp32 atomics; dtables zeroed by the caller).
  * sn_dot_f32: out[0] = sum a[i] b[i] (the GIN / GINE eps gradients).  scratch: float[256].
- * sn_adam_step_f32: one torch.optim.Adam step (no amsgrad; weight_decay added to the gradient) on a flat tensor. */
+ * sn_adam_step_f32: one torch.optim.Adam step (no amsgrad; weight_decay added to the gradient) on a flat tensor; the gradient is
+ *   read as g*grad_scale (1/world_size after a SUM all-reduce of data-parallel ranks). */
 int64_t sn_linear_wgrad_scratch_floats(int64_t R, int d_in, int d_out);
 int sn_linear_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, int64_t R, int d_in, int d_out,
                         const int32_t* nvalid, int K, float* dW, float* db, float* scratch, void* stream);
+int64_t sn_bn_act_bwd_scratch_floats(int64_t R, int C);
 int sn_bn_act_bwd_f32(const float* z, int ldz, const float* dy, int ldd, int64_t R, int C, const int32_t* nvalid, int K,
                       const float* mean, const float* rstd, const float* scale, const float* shift, int relu,
                       const float* count, float* sums, float* dz, int ldo, float* scratch, void* stream);
@@ -276,7 +278,7 @@ int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, flo
                              void* stream);
 int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch, void* stream);
 int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                     float weight_decay, int step, void* stream);
+                     float weight_decay, int step, float grad_scale, void* stream);
 
 /* ==========================================================================================
  * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).

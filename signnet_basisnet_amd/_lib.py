@@ -55,7 +55,7 @@ SIGNATURES = {
     "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, _i, _p, _p],
     "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
-    "sn_adam_step_f32": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p],
+    "sn_adam_step_f32": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
 }
 _SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
 
@@ -85,6 +85,8 @@ def lib():
         L.sn_phi_bins_bound.restype = C.c_int64
         L.sn_linear_wgrad_scratch_floats.argtypes = [_l, _i, _i]
         L.sn_linear_wgrad_scratch_floats.restype = C.c_int64
+        L.sn_bn_act_bwd_scratch_floats.argtypes = [_l, _i]
+        L.sn_bn_act_bwd_scratch_floats.restype = C.c_int64
         L.sn_layernorm_bwd_scratch_floats.argtypes = [_l, _i]
         L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
         L.sn_evd_work_ints.argtypes = [_l]

@@ -106,7 +106,7 @@ class _BnAct(Function):
         R = z.numel() // Cc
         sums = torch.empty(2 * Cc, dtype=torch.float32, device=z.device)
         dz = torch.empty_like(z)
-        scratch = torch.empty(2 * Cc * int(lib().sn_colstats_blocks(R)), dtype=torch.float32, device=z.device)
+        scratch = torch.empty(int(lib().sn_bn_act_bwd_scratch_floats(R, Cc)), dtype=torch.float32, device=z.device)
         with ops._span("sn_bn_act_bwd_f32"):
             check(lib().sn_bn_act_bwd_f32(ptr(z), Cc, ptr(dy), Cc, R, Cc, ptr(nvalid), int(K), ptr(mean), ptr(rstd), ptr(scale),
                                           ptr(shift), int(relu), ptr(count), ptr(sums), ptr(dz), Cc, ptr(scratch), stream()),

@@ -10,10 +10,11 @@
 namespace sn {
 namespace {
 
+// rows are < 2^31 everywhere (checked on the host): 32-bit division
 __device__ __forceinline__ bool row_ok(const int32_t* __restrict__ nvalid, int K, int64_t r) {
   if (!nvalid) return true;
-  const int64_t node = r / K;
-  return (int)(r - node * K) < nvalid[node];
+  const unsigned node = (unsigned)r / (unsigned)K;
+  return (int)((unsigned)r - node * (unsigned)K) < nvalid[node];
 }
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -27,9 +28,11 @@ __device__ __forceinline__ float wsum(float v) {
 constexpr int WG_OC = 64, WG_IC = 128, WG_LDO = WG_OC + 16, WG_LDI = WG_IC + 16;
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int ldy,
                                                int64_t R, int d_in, int d_out, const int32_t* __restrict__ nvalid, int K,
-                                               int64_t rows_per_block, float* __restrict__ part, float* __restrict__ part_b) {
-  __shared__ float xs[16 * WG_LDI];
-  __shared__ float ds[16 * WG_LDO];
+                                               int64_t rows_per_block, float* __restrict__ part, float* __restrict__ part_b,
+                                               int vec) {
+  __shared__ __attribute__((aligned(16))) float xs[16 * WG_LDI];
+  __shared__ __attribute__((aligned(16))) float ds[16 * WG_LDO];
+  __shared__ int okrow[16];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int oc0 = blockIdx.y * WG_OC, ic0 = blockIdx.z * WG_IC;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -40,19 +43,31 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int 
   float bsum = 0.f;
   for (int64_t rb = r0; rb < r1; rb += 16) {
     __syncthreads();
-    for (int i = t; i < 16 * WG_IC; i += 256) {
-      const int rr = i / WG_IC, c = i - rr * WG_IC;
-      const int64_t r = rb + rr;
-      float v = 0.f;
-      if (r < r1 && ic0 + c < d_in && row_ok(nvalid, K, r)) v = x[r * ldx + ic0 + c];
-      xs[rr * WG_LDI + c] = v;
-    }
-    for (int i = t; i < 16 * WG_OC; i += 256) {
-      const int rr = i / WG_OC, c = i - rr * WG_OC;
-      const int64_t r = rb + rr;
-      float v = 0.f;
-      if (r < r1 && oc0 + c < d_out && row_ok(nvalid, K, r)) v = dy[r * ldy + oc0 + c];
-      ds[rr * WG_LDO + c] = v;
+    if (t < 16) okrow[t] = (rb + t < r1 && row_ok(nvalid, K, rb + t)) ? 1 : 0;
+    __syncthreads();
+    if (vec) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {                       // 16 rows x 32 float4
+        const int rr = (t >> 5) + 8 * j, c = (t & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (okrow[rr] && ic0 + c < d_in) v = *reinterpret_cast<const float4*>(x + (rb + rr) * ldx + ic0 + c);
+        *reinterpret_cast<float4*>(&xs[rr * WG_LDI + c]) = v;
+      }
+      {
+        const int rr = t >> 4, c = (t & 15) * 4;          // 16 rows x 16 float4
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (okrow[rr] && oc0 + c < d_out) v = *reinterpret_cast<const float4*>(dy + (rb + rr) * ldy + oc0 + c);
+        *reinterpret_cast<float4*>(&ds[rr * WG_LDO + c]) = v;
+      }
+    } else {
+      for (int i = t; i < 16 * WG_IC; i += 256) {
+        const int rr = i / WG_IC, c = i - rr * WG_IC;
+        xs[rr * WG_LDI + c] = (okrow[rr] && ic0 + c < d_in) ? x[(rb + rr) * ldx + ic0 + c] : 0.f;
+      }
+      for (int i = t; i < 16 * WG_OC; i += 256) {
+        const int rr = i / WG_OC, c = i - rr * WG_OC;
+        ds[rr * WG_LDO + c] = (okrow[rr] && oc0 + c < d_out) ? dy[(rb + rr) * ldy + oc0 + c] : 0.f;
+      }
     }
     __syncthreads();
     if (t < WG_OC) {
@@ -79,13 +94,33 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int 
   }
   if (part_b && blockIdx.z == 0 && t < WG_OC && oc0 + t < d_out) part_b[(int64_t)blockIdx.x * d_out + oc0 + t] = bsum;
 }
-// out[i] = sum_b part[b][i]
+// out[i] = sum_b part[b][i]   (blockIdx.y splits the partials; four independent accumulators keep loads in flight)
 __global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int nblk, int64_t n, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * n + i];
-  out[i] = s;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += part[(int64_t)b * n + i];
+    s1 += part[(int64_t)(b + 1) * n + i];
+    s2 += part[(int64_t)(b + 2) * n + i];
+    s3 += part[(int64_t)(b + 3) * n + i];
+  }
+  for (; b < b1; ++b) s0 += part[(int64_t)b * n + i];
+  out[(int64_t)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
+}
+// deterministic two-stage reduction of nblk partial vectors of n floats; tmp: float[16 * n] when nblk > 32
+static inline void sum_parts(const float* part, int nblk, int64_t n, float* out, float* tmp, hipStream_t st) {
+  const dim3 blk(256);
+  const unsigned gx = (unsigned)((n + 255) / 256);
+  if (nblk > 32 && tmp != nullptr) {
+    hipLaunchKernelGGL(k_sum_parts, dim3(gx, 16), blk, 0, st, part, nblk, n, tmp);
+    hipLaunchKernelGGL(k_sum_parts, dim3(gx, 1), blk, 0, st, (const float*)tmp, 16, n, out);
+  } else {
+    hipLaunchKernelGGL(k_sum_parts, dim3(gx, 1), blk, 0, st, part, nblk, n, out);
+  }
 }
 
 // ============================================================================ train-mode BatchNorm (+ReLU) backward
@@ -96,21 +131,32 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         int relu, int64_t rows_per_block, float* __restrict__ part) {
+  __shared__ float red[2][4][64];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float m = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-      if (!row_ok(nvalid, K, r)) continue;
-      const float zv = z[r * ldz + c];
-      float g = dy[r * ldd + c];
-      if (relu && !(zv * sc + sh > 0.f)) g = 0.f;
-      s1 += g;
-      s2 += g * ((zv - m) * rs);
+    if (c < C) {
+      const float m = mean[c], rs = rstd[c], sc = scale[c], sh = shift[c];
+      for (int64_t r = r0 + rl; r < r1; r += 4) {
+        if (!row_ok(nvalid, K, r)) continue;
+        const float zv = z[r * ldz + c];
+        float g = dy[r * ldd + c];
+        if (relu && !(zv * sc + sh > 0.f)) g = 0.f;
+        s1 += g;
+        s2 += g * ((zv - m) * rs);
+      }
     }
-    part[(int64_t)blockIdx.x * 2 * C + c] = s1;
-    part[(int64_t)blockIdx.x * 2 * C + C + c] = s2;
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      part[(int64_t)blockIdx.x * 2 * C + c] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+      part[(int64_t)blockIdx.x * 2 * C + C + c] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ z, int ldz, const float* __restrict__ dy, int ldd,
@@ -121,7 +167,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float* __restrict__ 
                                                       float* __restrict__ dz, int ldo) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= R * C) return;
-  const int64_t r = idx / C;
+  const int64_t r = (unsigned)idx / (unsigned)C;            // R*C < 2^32 (checked on the host)
   const int c = (int)(idx - r * C);
   float v = 0.f;
   if (row_ok(nvalid, K, r)) {
@@ -326,10 +372,10 @@ __global__ __launch_bounds__(256) void k_dot_partial(const float* __restrict__ a
 // ============================================================================ Adam (torch.optim.Adam, no amsgrad)
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                              float wd, float bc1, float bc2_sqrt) {
+                                              float wd, float bc1, float bc2_sqrt, float gscale) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float gi = g[i];
+  float gi = g[i] * gscale;
   if (wd != 0.f) gi += wd * p[i];
   const float mi = b1 * m[i] + (1.0f - b1) * gi;
   const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
@@ -345,13 +391,13 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 using namespace sn;
 
 static inline int64_t wgrad_rows_per_block(int64_t R) {
-  int64_t rpb = 512;
-  while (cdiv(R, rpb) > 256) rpb *= 2;
+  int64_t rpb = 128;                       // >= 2 workgroups per CU at the bench's 47 k rows; partials stay a few MB
+  while (cdiv(R, rpb) > 512) rpb *= 2;
   return rpb;
 }
 extern "C" int64_t sn_linear_wgrad_scratch_floats(int64_t R, int d_in, int d_out) {
   const int64_t nblk = cdiv(R > 0 ? R : 1, wgrad_rows_per_block(R));
-  return nblk * ((int64_t)d_in * d_out + d_out);
+  return (nblk + 16) * ((int64_t)d_in * d_out + d_out);
 }
 extern "C" int sn_linear_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, int64_t R, int d_in, int d_out,
                                    const int32_t* nvalid, int K, float* dW, float* db, float* scratch, void* stream) {
@@ -364,30 +410,41 @@ extern "C" int sn_linear_wgrad_f32(const float* x, int ldx, const float* dy, int
   float* part = scratch;
   float* part_b = scratch + (int64_t)nblk * d_in * d_out;
   dim3 grid((unsigned)nblk, (unsigned)cdiv(d_out, WG_OC), (unsigned)cdiv(d_in, WG_IC));
-  hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, st, x, ldx, dy, ldy, R, d_in, d_out, nvalid, K, rpb, part, db ? part_b : nullptr);
+  const int vec = (d_in % 4 == 0 && d_out % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) ? 1 : 0;
+  SN_REQUIRE(R < (1ll << 31), "sn_linear_wgrad_f32: too many rows");
+  hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, st, x, ldx, dy, ldy, R, d_in, d_out, nvalid, K, rpb, part, db ? part_b : nullptr,
+                     vec);
   SN_CHECK_LAUNCH("k_wgrad");
   const int64_t n = (int64_t)d_in * d_out;
-  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, part, nblk, n, dW);
-  if (db) hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(d_out, 256)), dim3(256), 0, st, part_b, nblk, (int64_t)d_out, db);
+  float* tmp = part_b + (int64_t)nblk * d_out;
+  sum_parts(part, nblk, n, dW, tmp, st);
+  if (db) sum_parts(part_b, nblk, (int64_t)d_out, db, tmp + 16 * n, st);
   SN_CHECK_LAUNCH("k_sum_parts");
   return SN_OK;
 }
 
+static inline int bn_bwd_blocks(int64_t R) {
+  const int64_t b = cdiv(R > 0 ? R : 1, 64);
+  return (int)(b > 2048 ? 2048 : b);
+}
+extern "C" int64_t sn_bn_act_bwd_scratch_floats(int64_t R, int C) { return (int64_t)(bn_bwd_blocks(R) + 16) * 2 * C; }
 extern "C" int sn_bn_act_bwd_f32(const float* z, int ldz, const float* dy, int ldd, int64_t R, int C, const int32_t* nvalid, int K,
                                  const float* mean, const float* rstd, const float* scale, const float* shift, int relu,
                                  const float* count, float* sums /* [2C]: d beta, d (gamma) */, float* dz, int ldo,
-                                 float* scratch /* [2C * sn_colstats_blocks(R)] */, void* stream) {
+                                 float* scratch /* [sn_bn_act_bwd_scratch_floats(R, C)] */, void* stream) {
   SN_REQUIRE(z && dy && mean && rstd && scale && shift && count && sums && dz && scratch && R >= 0 && C > 0,
              "sn_bn_act_bwd_f32: bad arguments");
   SN_REQUIRE(ldz >= C && ldd >= C && ldo >= C, "sn_bn_act_bwd_f32: leading dimension too small");
   SN_REQUIRE(!nvalid || K > 0, "sn_bn_act_bwd_f32: nvalid needs K > 0");
   if (R == 0) return SN_OK;
+  SN_REQUIRE(R * C < (1ll << 32) && R < (1ll << 31), "sn_bn_act_bwd_f32: R*C too large");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = sn_colstats_blocks(R);
+  const int nblk = bn_bwd_blocks(R);
   const int64_t rpb = cdiv(R, nblk);
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3((unsigned)nblk), dim3(256), 0, st, z, ldz, dy, ldd, R, C, nvalid, K, mean, rstd, scale,
                      shift, relu, rpb, scratch);
-  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(2 * C, 256)), dim3(256), 0, st, scratch, nblk, (int64_t)2 * C, sums);
+  sum_parts(scratch, nblk, (int64_t)2 * C, sums, scratch + (int64_t)nblk * 2 * C, st);
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, st, z, ldz, dy, ldd, R, C, nvalid, K, mean,
                      rstd, scale, shift, relu, sums, count, dz, ldo);
   SN_CHECK_LAUNCH("sn_bn_act_bwd_f32");
@@ -403,7 +460,7 @@ extern "C" int sn_relu_bwd_f32(const float* y, const float* dy, int64_t R, int C
   return SN_OK;
 }
 
-extern "C" int64_t sn_layernorm_bwd_scratch_floats(int64_t R, int C) { return cdiv(R > 0 ? R : 1, 4 * LN_ROWS) * 2 * C; }
+extern "C" int64_t sn_layernorm_bwd_scratch_floats(int64_t R, int C) { return (cdiv(R > 0 ? R : 1, 4 * LN_ROWS) + 17) * 2 * C; }
 extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const float* dy, int64_t R, int C,
                                            const float* gamma, float eps, const int32_t* nvalid, int K, float* du,
                                            float* dgamma, float* dbeta /* contiguous pair is NOT required */, float* scratch,
@@ -415,11 +472,12 @@ extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual
   const int nblk = (int)cdiv(R > 0 ? R : 1, 4 * LN_ROWS);
   hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)8 * C * sizeof(float), st, x, residual, dy, R, C,
                      gamma, eps, nvalid, K, du, scratch);
-  // scratch rows are [d gamma (C) | d beta (C)]: reduce with a stride of 2C
-  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)cdiv(2 * C, 256)), dim3(256), 0, st, scratch, nblk, (int64_t)2 * C, scratch);
+  // scratch rows are [d gamma (C) | d beta (C)]; reduced into the row behind the partials and the two-stage temporaries
+  float* tot = scratch + (int64_t)(nblk + 16) * 2 * C;
+  sum_parts(scratch, nblk, (int64_t)2 * C, tot, scratch + (int64_t)nblk * 2 * C, st);
   SN_CHECK_LAUNCH("sn_masked_layernorm_bwd_f32");
-  hipError_t e = hipMemcpyAsync(dgamma, scratch, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(dbeta, scratch + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  hipError_t e = hipMemcpyAsync(dgamma, tot, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dbeta, tot + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return fail(SN_ERR_LAUNCH, "sn_masked_layernorm_bwd_f32: copy: %s", hipGetErrorString(e));
   return SN_OK;
 }
@@ -482,18 +540,18 @@ extern "C" int sn_dot_f32(const float* a, const float* b, int64_t n, float* out,
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (int)(n > 0 ? (cdiv(n, 256) < 256 ? cdiv(n, 256) : 256) : 1);
   hipLaunchKernelGGL(k_dot_partial, dim3((unsigned)nblk), dim3(256), 0, st, a, b, n, scratch);
-  hipLaunchKernelGGL(k_sum_parts, dim3(1), dim3(256), 0, st, scratch, nblk, (int64_t)1, out);
+  hipLaunchKernelGGL(k_sum_parts, dim3(1, 1), dim3(256), 0, st, (const float*)scratch, nblk, (int64_t)1, out);
   SN_CHECK_LAUNCH("sn_dot_f32");
   return SN_OK;
 }
 
 extern "C" int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                                float eps, float weight_decay, int step, void* stream) {
+                                float eps, float weight_decay, int step, float grad_scale, void* stream) {
   SN_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "sn_adam_step_f32: bad arguments");
   if (n == 0) return SN_OK;
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrtf(bc2));
+                     weight_decay, bc1, sqrtf(bc2), grad_scale);
   SN_CHECK_LAUNCH("sn_adam_step_f32");
   return SN_OK;
 }

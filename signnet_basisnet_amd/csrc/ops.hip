@@ -332,27 +332,59 @@ __global__ __launch_bounds__(256) void k_gine_gather(const VT* __restrict__ x, c
 
 // ============================================================================ masked column statistics
 // pass 0: per-block partial sums of x over valid rows; pass 1: partial sums of (x-mean)^2.
+// A block = 4 row lanes x 64 column lanes over <= rows_per_block rows (coalesced 256-byte row segments, four rows in flight).
 __global__ __launch_bounds__(256) void k_colstats_partial(const float* __restrict__ x, int ldx, int64_t R, int C,
                                                           const int32_t* __restrict__ nvalid, int K,
                                                           const float* __restrict__ mean, int pass,
                                                           int64_t rows_per_block, float* __restrict__ part,
                                                           float* __restrict__ cnt_part) {
+  __shared__ float red[4][64];
+  __shared__ int cred[4];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f, m = pass ? mean[c] : 0.f;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
+    const float m = (pass && c < C) ? mean[c] : 0.f;
+    float s = 0.f;
     int cnt = 0;
-    for (int64_t r = r0; r < r1; ++r) {
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
       bool ok = true;
-      if (nvalid) { int64_t node = r / K; ok = (int)(r - node * K) < nvalid[node]; }
+      if (nvalid) { unsigned node = (unsigned)r / (unsigned)K; ok = (int)((unsigned)r - node * (unsigned)K) < nvalid[node]; }   // rows < 2^31
       if (ok) {
-        float v = x[r * ldx + c] - m;
-        s += pass ? v * v : v;
         ++cnt;
+        if (c < C) { const float v = x[r * ldx + c] - m; s += pass ? v * v : v; }
       }
     }
-    part[(int64_t)blockIdx.x * C + c] = s;
-    if (c == 0 && cnt_part) cnt_part[blockIdx.x] = (float)cnt;
+    red[rl][cl] = s;
+    if (cl == 0) cred[rl] = cnt;
+    __syncthreads();
+    if (rl == 0 && c < C) part[(int64_t)blockIdx.x * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (threadIdx.x == 0 && c0 == 0 && cnt_part) cnt_part[blockIdx.x] = (float)(cred[0] + cred[1] + cred[2] + cred[3]);
+    __syncthreads();
+  }
+}
+// sums a slice of the partial rows: out[y][c] = sum_{b in slice y} part[b][c]  (c == C: the per-block counts)
+__global__ __launch_bounds__(256) void k_colstats_reduce(const float* __restrict__ part, const float* __restrict__ cnt_part,
+                                                         int nblk, int C, float* __restrict__ out, float* __restrict__ out_cnt) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c > C || (c == C && !cnt_part)) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = (b0 + per < nblk) ? b0 + per : nblk;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  if (c < C) {
+    for (; b + 3 < b1; b += 4) {
+      s0 += part[(int64_t)b * C + c];
+      s1 += part[(int64_t)(b + 1) * C + c];
+      s2 += part[(int64_t)(b + 2) * C + c];
+      s3 += part[(int64_t)(b + 3) * C + c];
+    }
+    for (; b < b1; ++b) s0 += part[(int64_t)b * C + c];
+    out[(int64_t)blockIdx.y * C + c] = (s0 + s1) + (s2 + s3);
+  } else {
+    for (; b < b1; ++b) s0 += cnt_part[b];
+    out_cnt[blockIdx.y] = s0;
   }
 }
 __global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict__ part, const float* __restrict__ cnt_part,
@@ -384,7 +416,7 @@ __global__ __launch_bounds__(256) void k_affine(const float* __restrict__ x, int
   int64_t r = idx / C;
   int c = (int)(idx - r * C);
   bool ok = true;
-  if (nvalid) { int64_t node = r / K; ok = (int)(r - node * K) < nvalid[node]; }
+  if (nvalid) { unsigned node = (unsigned)r / (unsigned)K; ok = (int)((unsigned)r - node * (unsigned)K) < nvalid[node]; }   // rows < 2^31
   float v = 0.f;
   if (ok) {
     v = x[r * ldx + c];
@@ -412,7 +444,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
   bool ok = true;
-  if (nvalid) { int64_t node = row / K; ok = (int)(row - node * K) < nvalid[node]; }
+  if (nvalid) { unsigned node = (unsigned)row / (unsigned)K; ok = (int)((unsigned)row - node * (unsigned)K) < nvalid[node]; }
   const float* xr = x + row * C;
   const float* rr = res ? res + row * C : nullptr;
   float* yr = y + row * C;
@@ -685,26 +717,37 @@ extern "C" int sn_gine_aggregate_f32(const float* x, const float* ea, float* out
   return SN_OK;
 }
 
+constexpr int CS_SPLIT = 16;      // second-level partial rows of the column-statistics reduction
 extern "C" int sn_colstats_blocks(int64_t R) {
-  int64_t b = cdiv(R, 256);
-  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+  int64_t b = cdiv(R, 64);
+  b = b < 1 ? 1 : (b > 2048 ? 2048 : b);
+  return (int)(b + CS_SPLIT);      // + room for the second-level partials (callers size scratch as nblocks*(C+1))
 }
 
 extern "C" int sn_masked_colstats_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K,
                                       float* mean, float* var, float* count, float* scratch, void* stream) {
   SN_REQUIRE(x && mean && var && count && scratch && C > 0 && R >= 0 && ldx >= C, "sn_masked_colstats_f32: bad arguments");
   SN_REQUIRE(!nvalid || K > 0, "sn_masked_colstats_f32: nvalid needs K > 0");
+  SN_REQUIRE(R < (1ll << 31), "sn_masked_colstats_f32: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  int nblk = sn_colstats_blocks(R);
+  const int ntot = sn_colstats_blocks(R), nblk = ntot - CS_SPLIT;
   int64_t rpb = cdiv(R > 0 ? R : 1, nblk);
-  float* part = scratch;
-  float* cnt = scratch + (int64_t)nblk * C;
+  float* part = scratch;                              // [nblk][C] then [CS_SPLIT][C]
+  float* part2 = scratch + (int64_t)nblk * C;
+  float* cnt = scratch + (int64_t)ntot * C;           // [nblk] then [CS_SPLIT]
+  float* cnt2 = cnt + nblk;
+  const bool two = nblk > 2 * CS_SPLIT;
+  const dim3 rgrid((unsigned)cdiv(C + 1, 256), CS_SPLIT);
   hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)nullptr, 0,
                      rpb, part, cnt);
-  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, part, cnt, nblk, C, mean, count, 0);
+  if (two) hipLaunchKernelGGL(k_colstats_reduce, rgrid, dim3(256), 0, st, (const float*)part, (const float*)cnt, nblk, C, part2, cnt2);
+  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, two ? part2 : part, two ? cnt2 : cnt, two ? CS_SPLIT : nblk, C,
+                     mean, count, 0);
   hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)mean, 1,
                      rpb, part, (float*)nullptr);
-  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, part, cnt, nblk, C, var, count, 1);
+  if (two) hipLaunchKernelGGL(k_colstats_reduce, rgrid, dim3(256), 0, st, (const float*)part, (const float*)nullptr, nblk, C, part2,
+                              (float*)nullptr);
+  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, two ? part2 : part, cnt, two ? CS_SPLIT : nblk, C, var, count, 1);
   SN_CHECK_LAUNCH("sn_masked_colstats_f32");
   return SN_OK;
 }

@@ -72,3 +72,54 @@ def test_shard_batch_is_a_partition():
     for p in parts:
         if p.batch.numel():
             assert int(p.batch.min()) == 0 and int(p.edge_index.max()) < p.batch.numel()
+
+
+def _grad_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import golden_util as G
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import dist as D
+    from signnet_basisnet_amd import optim, synth
+    dist = D.init_process_group("gloo")
+    fx = G.load("gine_d16")
+    cfg = G.pyg_cfg(fx)
+    data = synth.make_batch(6, seed=22, sizes=[5, 9, 4, 12, 6, 7])
+
+    def grads_of(batch):
+        sd = {k: (torch.nn.Parameter(v.clone()) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in fx.sd.items()}
+        names = [k for k, v in sd.items() if isinstance(v, torch.nn.Parameter)]
+        opt = optim.FlatAdam([sd[k] for k in names], dist=dist)          # CPU tensors: only the gradient plumbing is used here
+        O.signnet_gnn(sd, cfg, batch, training=False).sum().backward()   # eval-mode BN: graphs do not interact
+        return opt
+
+    opt = grads_of(D.shard_batch(data, rank, world))
+    scale = opt.all_reduce_gradients()                                   # ONE all-reduce of the flat gradient
+    summed = opt.flat_g.clone()
+    dist.barrier()
+    if rank == 0:
+        full = grads_of(data)                                            # single-rank gradient of the whole batch
+        err = float((summed - full.flat_g).abs().max())
+        q.put((err, float(full.flat_g.abs().max()), scale, summed.numel()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_full_batch_gradient():
+    """Data-parallel training exchange (SURVEY.md §8 f1 / BASELINE config 4): per-rank gradients of the rank's graphs,
+    summed by one all-reduce of FlatAdam's flat gradient buffer, equal the gradient of the unsharded batch."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    err, gmax, scale, n = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert scale == 0.5 and n > 1000
+    assert err <= 1e-4 * gmax, (err, gmax)
