@@ -188,11 +188,52 @@ class _DeepSignsBase(nn.Module):
             outs.append(h)
         return outs
 
+    def _forward_grad(self, g, x):
+        """Differentiable train-mode forward: the same launches as the value path, recorded as
+        torch.autograd.Function nodes whose backward are the hand-written adjoints of csrc/backward.hip, so that the
+        gradient a DGL base network sends back into `p = sign_inv_net(g, pos_enc)` (train_ZINC_graph_regression.py:20-25)
+        reaches these parameters.  Dropout is not applied (the shipped configs use 0.0)."""
+        from . import autograd as AG
+        N, K = x.shape[0], self.k
+        plan = self._plan(g, N)
+        src, dst = g.edges()
+        rplan = self._plan(Graph(dst, src, g.batch_num_nodes()), N)              # out-edge CSR for the aggregation adjoint
+        enc = self.enc
+
+        def run_mlp(mlp, h, tail_bn=None):
+            n = len(mlp.lins)
+            for i, lin in enumerate(mlp.lins):
+                last = i == n - 1
+                h = AG.linear(h, lin.weight, lin.bias, relu=not last)             # mlp.py:40-46: bias -> relu -> BN
+                bn = tail_bn if last else (mlp.bns[i] if mlp.use_bn else None)
+                if bn is not None:
+                    h = AG.bn_act(h, bn, relu=False)                               # statistics over ALL rows, as the reference
+            return h
+
+        outs = []
+        L = len(enc.layers)
+        x = x.contiguous().float()
+        for sign in (0, 1):
+            h = x
+            for l, conv in enumerate(enc.layers):
+                a = AG.gin_aggregate(h.reshape(N, -1), conv.eps, plan, rplan, negate=(sign == 1 and l == 0))
+                h = run_mlp(conv.apply_func, a.view(N * K, -1), enc.bns[l] if (enc.use_bn and l < L - 1) else None)
+            outs.append(h)
+        if self.masked:
+            z = AG.masked_add(outs[0], outs[1], plan.nvalid, K)
+            y = run_mlp(self.rho, AG.slot_sum(z, N, K, plan.nvalid))
+        else:
+            z = AG.masked_add(outs[0], outs[1])
+            y = run_mlp(self.rho, z.view(N, -1))
+        return y.view(N, K, 1)
+
     def forward(self, g, x):
-        train = self.training     # forward VALUE with batch statistics + running-statistics update (no autograd, dropout 0)
+        train = self.training     # train: batch statistics + running-statistics update (dropout 0)
         ops.require_cuda(x)
         if x.dim() != 3 or x.shape[1] != self.k or x.shape[2] != 1:
             raise ValueError(f"expected x of shape [N, {self.k}, 1]")
+        if train and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_grad(g, x)
         if train:
             P = self._prepare(True)          # parameters may change between training-mode calls: nothing is cached
         else:
