@@ -121,15 +121,17 @@ def evd_bench(args, dev):
     print(json.dumps(out))
 
 
-def train_bench(args, dev):
+def train_bench(args, dev, dist=None, rank=0, world=1):
     """Secondary workload (not the headline metric): `--workload train` times full training steps
     (differentiable train-mode forward on the layer kernels, L1 loss, backward through the hand-written adjoints, one
-    FlatAdam launch) of the headline model on the headline batch.  Prints its own JSON line."""
+    gradient all-reduce over RCCL when --gpus N > 1, one FlatAdam launch) of the headline model; every rank trains on its
+    own 128-graph shard (weak scaling, BASELINE config 4's data-parallel pattern).  Rank 0 prints its own JSON line."""
+    from signnet_basisnet_amd import dist as D
     from signnet_basisnet_amd import ops, optim, synth
-    host = synth.make_batch(WORKLOAD["B"], seed=1236)
+    host = synth.make_batch(WORKLOAD["B"], seed=1236 + 1000 * rank)
     data = synth.batch_to(host, dev)
     model = build_model(dev).train()
-    opt = optim.FlatAdam(model.parameters(), lr=1e-3)
+    opt = optim.FlatAdam(model.parameters(), lr=1e-3, dist=dist)
     target = torch.randn(WORKLOAD["B"], WORKLOAD["n_out"], generator=torch.Generator().manual_seed(0)).to(dev)
 
     def step():
@@ -138,31 +140,38 @@ def train_bench(args, dev):
         loss.backward()
         opt.step()
         return loss
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    sync_all()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dist, dev) / args.steps
     rec = ops.KernelTimer()
-    with rec:
+    with rec:                       # untimed per-kernel pass; every rank takes part (the step contains the all-reduce)
         for _ in range(3):
             step()
     kt = rec.summary()
+    if rank != 0:
+        return
     per = {k: {"launches_per_step": v[0] / 3, "mean_us": 1e3 * v[1], "us_per_step": 1e3 * v[1] * v[0] / 3} for k, v in kt.items()}
     fl = algorithmic_flops(host, WORKLOAD["k"], WORKLOAD["hidden"], WORKLOAD["nl_signnet"], WORKLOAD["nl_rho"], WORKLOAD["nl_gnn"])
     out = {"metric": "graphs/sec SignNet+GINE training step (forward + backward + Adam), ZINC batch=128 k=16", "unit": "graphs/s",
-           "value": WORKLOAD["B"] / dt, "ms_per_step": 1e3 * dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None, "final_loss": float(loss.detach()),
+           "value": WORKLOAD["B"] * world / dt, "ms_per_step": 1e3 * dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic", "vs_baseline": None, "final_loss": float(loss.detach()),
            "config": {"workload": WORKLOAD["name"] + ", train step", "gflop_per_step": 3 * fl["total"] / 1e9},
            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF,
                         "achieved": 3 * fl["total"] / dt / 1e12, "frac": 3 * fl["total"] / dt / 1e12 / MFMA_F32_PEAK_TF,
                         "note": "whole step, ~3x the forward's dense flops (forward + dX + dW), layer-at-a-time fp32-MFMA kernels; "
                                 "this path is launch/HBM bound (one kernel per op), not matrix-pipe bound"},
            "kernels": dict(sorted(per.items(), key=lambda kv: -kv[1]["us_per_step"]))}
-    if not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         # the float32 CPU oracle under torch.autograd + torch.optim.Adam: what the reference's training loop does on the host
         from oracle import pyg_signnet as O
         cfg = O.make_cfg("gine", None, None, WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"])
@@ -226,9 +235,14 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    if args.workload in ("evd", "train"):
+    if args.workload == "train":
+        train_bench(args, dev, dist, rank, world)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if args.workload == "evd":
         if rank == 0:
-            (evd_bench if args.workload == "evd" else train_bench)(args, dev)
+            evd_bench(args, dev)
         if dist is not None:
             dist.destroy_process_group()
         return
