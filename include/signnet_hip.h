@@ -182,9 +182,11 @@ int sn_masked_layernorm_f32(const float* x, const float* residual /* may be NULL
 
 /* Per-node multi-head attention over the slot axis (ScaledDotProductAttention,
  * transformer_module.py:50-58, heads split as :85-98): q,k,v,out are [N*K, heads*dk];
- * softmax over the valid slots of the node; invalid query rows -> 0. */
+ * softmax over the valid slots of the node; invalid query rows -> 0.  prob_mask (may be NULL): the train-mode
+ * attention dropout of transformer_module.py:49,55 as an explicit mask [N, heads, K, K] of 0 / 1/(1-p) factors applied to
+ * the softmax output (drawn by the caller, so that forward and backward see the same one). */
 int sn_set_attention_f32(const float* q, const float* k, const float* v, int64_t N, int K, int heads,
-                         int dk, const int32_t* nvalid, float* out, void* stream);
+                         int dk, const int32_t* nvalid, const float* prob_mask, float* out, void* stream);
 
 /* out[n, :] = sum_k x[n, k, :]  (torch.sum(x, dim=1), sign_net.py:70). */
 int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* out, void* stream);
@@ -268,7 +270,8 @@ int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const flo
                                 float eps, const int32_t* nvalid, int K, float* du, float* dgamma, float* dbeta,
                                 float* scratch, void* stream);
 int sn_set_attention_bwd_f32(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K, int heads,
-                             int dk, const int32_t* nvalid, float* dq, float* dk_out, float* dv, void* stream);
+                             int dk, const int32_t* nvalid, const float* prob_mask, float* dq, float* dk_out, float* dv,
+                             void* stream);
 int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, int64_t N, int C, const int32_t* rev_rowptr,
                               const int32_t* rev_col, const int32_t* rev_eperm, const float* eps, float* dh, float* dee,
                               void* stream);

@@ -39,7 +39,7 @@ SIGNATURES = {
     "sn_masked_colstats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "sn_masked_affine_f32": [_p, _i, _l, _i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     "sn_masked_layernorm_f32": [_p, _p, _l, _i, _p, _p, _f, _p, _i, _p, _p],
-    "sn_set_attention_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
+    "sn_set_attention_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
     "sn_slot_sum_f32": [_p, _l, _i, _i, _p, _p],
     "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), _i, _p, _p],
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
@@ -49,7 +49,7 @@ SIGNATURES = {
     "sn_bn_act_bwd_f32": [_p, _i, _p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],
     "sn_relu_bwd_f32": [_p, _p, _l, _i, _p, _i, _p, _p],
     "sn_masked_layernorm_bwd_f32": [_p, _p, _p, _l, _i, _p, _f, _p, _i, _p, _p, _p, _p, _p],
-    "sn_set_attention_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p],
+    "sn_set_attention_bwd_f32": [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p],
     "sn_gine_aggregate_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "sn_slot_broadcast_f32": [_p, _l, _i, _i, _p, _p, _p],
     "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],

@@ -196,26 +196,27 @@ def gine_aggregate(h, ee, eps, plan, rplan):
 # ----------------------------------------------------------------------------- set attention / LayerNorm / slot sum
 class _Attention(Function):
     @staticmethod
-    def forward(ctx, q, k, v, N, K, heads, nvalid):
+    def forward(ctx, q, k, v, N, K, heads, nvalid, prob_mask):
         q, k, v = _c(q), _c(k), _c(v)
         ctx.save_for_backward(q, k, v)
-        ctx.meta = (N, K, heads, nvalid)
-        return ops.set_attention(q, k, v, N, K, heads, nvalid)
+        ctx.meta = (N, K, heads, nvalid, prob_mask)
+        return ops.set_attention(q, k, v, N, K, heads, nvalid, prob_mask)
 
     @staticmethod
     def backward(ctx, g):
         q, k, v = ctx.saved_tensors
-        N, K, heads, nvalid = ctx.meta
+        N, K, heads, nvalid, prob_mask = ctx.meta
         g = _c(g)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         with ops._span("sn_set_attention_bwd_f32"):
             check(lib().sn_set_attention_bwd_f32(ptr(q), ptr(k), ptr(v), ptr(g), N, K, heads, q.shape[-1] // heads, ptr(nvalid),
-                                                 ptr(dq), ptr(dk), ptr(dv), stream()), "sn_set_attention_bwd_f32")
-        return dq, dk, dv, None, None, None, None
+                                                 ptr(prob_mask), ptr(dq), ptr(dk), ptr(dv), stream()), "sn_set_attention_bwd_f32")
+        return dq, dk, dv, None, None, None, None, None
 
 
-def set_attention(q, k, v, N, K, heads, nvalid=None):
-    return _Attention.apply(q, k, v, N, K, heads, nvalid)
+def set_attention(q, k, v, N, K, heads, nvalid=None, prob_mask=None):
+    """prob_mask: ops.attention_dropout_mask(...) for the train-mode attention dropout, or None."""
+    return _Attention.apply(q, k, v, N, K, heads, nvalid, prob_mask)
 
 
 class _LayerNorm(Function):

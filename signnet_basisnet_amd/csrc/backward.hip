@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
 __global__ __launch_bounds__(64) void k_set_attention_bwd(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, const float* __restrict__ dout, int K,
                                                           int H, int dk, const int32_t* __restrict__ nvalid,
-                                                          float* __restrict__ dq, float* __restrict__ dkk, float* __restrict__ dv) {
+                                                          const float* __restrict__ pmask, float* __restrict__ dq,
+                                                          float* __restrict__ dkk, float* __restrict__ dv) {
   extern __shared__ float sm[];
   const int node = blockIdx.x / H, h = blockIdx.x - node * H;
   const int lane = threadIdx.x;
@@ -280,9 +281,20 @@ __global__ __launch_bounds__(64) void k_set_attention_bwd(const float* __restric
     for (int b = 0; b < kv; ++b) m = fmaxf(m, sp[a * (K + 1) + b]);
     float zs = 0.f;
     for (int b = 0; b < kv; ++b) { const float e = expf(sp[a * (K + 1) + b] - m); sp[a * (K + 1) + b] = e; zs += e; }
+    // with attention dropout the forward used P' = P*m (m = 0 or 1/(1-p)): dP = dP'*m, and dV below needs P'
+    const float* pm = pmask ? pmask + ((int64_t)blockIdx.x * K + a) * K : nullptr;
     float dot = 0.f;
-    for (int b = 0; b < kv; ++b) { const float p = sp[a * (K + 1) + b] / zs; sp[a * (K + 1) + b] = p; dot += p * sd[a * (K + 1) + b]; }
-    for (int b = 0; b < kv; ++b) sd[a * (K + 1) + b] = sp[a * (K + 1) + b] * (sd[a * (K + 1) + b] - dot);     // dS
+    for (int b = 0; b < kv; ++b) {
+      const float p = sp[a * (K + 1) + b] / zs, m = pm ? pm[b] : 1.0f, dp = sd[a * (K + 1) + b] * m;
+      sp[a * (K + 1) + b] = p;
+      sd[a * (K + 1) + b] = dp;
+      dot += p * dp;
+    }
+    for (int b = 0; b < kv; ++b) {
+      const float p = sp[a * (K + 1) + b];
+      sd[a * (K + 1) + b] = p * (sd[a * (K + 1) + b] - dot);     // dS
+      sp[a * (K + 1) + b] = p * (pm ? pm[b] : 1.0f);             // P' for dV
+    }
   }
   __syncthreads();
   for (int i = lane; i < K * dk; i += 64) {
@@ -483,15 +495,15 @@ extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual
 }
 
 extern "C" int sn_set_attention_bwd_f32(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K,
-                                        int heads, int dk, const int32_t* nvalid, float* dq, float* dk_out, float* dv,
-                                        void* stream) {
+                                        int heads, int dk, const int32_t* nvalid, const float* prob_mask, float* dq,
+                                        float* dk_out, float* dv, void* stream) {
   SN_REQUIRE(q && k && v && dout && dq && dk_out && dv && N >= 0 && K > 0 && heads > 0 && dk > 0,
              "sn_set_attention_bwd_f32: bad arguments");
   if (N == 0) return SN_OK;
   const size_t lds = ((size_t)4 * K * dk + (size_t)2 * K * (K + 1)) * sizeof(float);
   SN_REQUIRE(lds <= 64 * 1024, "sn_set_attention_bwd_f32: K*dk too large for LDS (%zu bytes)", lds);
   hipLaunchKernelGGL(k_set_attention_bwd, dim3((unsigned)(N * heads)), dim3(64), lds, (hipStream_t)stream, q, k, v, dout, K,
-                     heads, dk, nvalid, dq, dk_out, dv);
+                     heads, dk, nvalid, prob_mask, dq, dk_out, dv);
   SN_CHECK_LAUNCH("sn_set_attention_bwd_f32");
   return SN_OK;
 }

@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, 
 // One wave per (node, head).  q,k,v rows are [N*K, H*dk]; head h owns columns [h*dk, (h+1)*dk).
 __global__ __launch_bounds__(64) void k_set_attention(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, int K, int H, int dk,
-                                                      const int32_t* __restrict__ nvalid, float* __restrict__ out) {
+                                                      const int32_t* __restrict__ nvalid, const float* __restrict__ pmask,
+                                                      float* __restrict__ out) {
   extern __shared__ float sm[];
   const int node = blockIdx.x / H, h = blockIdx.x - node * H;
   const int lane = threadIdx.x;
@@ -500,7 +501,9 @@ __global__ __launch_bounds__(64) void k_set_attention(const float* __restrict__ 
     for (int b = 0; b < kv; ++b) m = fmaxf(m, sp[a * (K + 1) + b]);
     float z = 0.f;
     for (int b = 0; b < kv; ++b) { float e = expf(sp[a * (K + 1) + b] - m); sp[a * (K + 1) + b] = e; z += e; }
-    for (int b = 0; b < kv; ++b) sp[a * (K + 1) + b] /= z;
+    // attention dropout (transformer_module.py:55): the caller's mask holds 0 or 1/(1-p) per (node, head, query, key)
+    const float* pm = pmask ? pmask + ((int64_t)blockIdx.x * K + a) * K : nullptr;
+    for (int b = 0; b < kv; ++b) sp[a * (K + 1) + b] = sp[a * (K + 1) + b] / z * (pm ? pm[b] : 1.0f);
   }
   __syncthreads();
   for (int i = lane; i < K * dk; i += 64) {
@@ -779,7 +782,7 @@ extern "C" int sn_masked_layernorm_f32(const float* x, const float* residual, in
 }
 
 extern "C" int sn_set_attention_f32(const float* q, const float* k, const float* v, int64_t N, int K, int heads,
-                                    int dk, const int32_t* nvalid, float* out, void* stream) {
+                                    int dk, const int32_t* nvalid, const float* prob_mask, float* out, void* stream) {
   SN_REQUIRE(q && k && v && out && N >= 0 && K > 0 && heads > 0 && dk > 0, "sn_set_attention_f32: bad arguments");
   size_t lds = ((size_t)3 * K * dk + (size_t)K * (K + 1)) * sizeof(float);
   SN_REQUIRE(lds <= 160 * 1024, "sn_set_attention_f32: K=%d dk=%d needs %zu B of LDS (> 160 KiB)", K, dk, lds);
@@ -790,7 +793,7 @@ extern "C" int sn_set_attention_f32(const float* q, const float* k, const float*
       return fail(SN_ERR_LAUNCH, "sn_set_attention_f32: cannot raise dynamic LDS limit");
   }
   hipLaunchKernelGGL(k_set_attention, dim3((unsigned)(N * heads)), dim3(64), lds, (hipStream_t)stream, q, k, v, K, heads,
-                     dk, nvalid, out);
+                     dk, nvalid, prob_mask, out);
   SN_CHECK_LAUNCH("sn_set_attention_f32");
   return SN_OK;
 }

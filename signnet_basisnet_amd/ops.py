@@ -368,13 +368,23 @@ def masked_layernorm(x, residual, gamma, beta, eps, nvalid=None, K=0):
     return out
 
 
-def set_attention(q, k, v, N, K, heads, nvalid=None):
+def attention_dropout_mask(N, K, heads, p, device):
+    """Bernoulli keep-mask of the attention dropout (transformer_module.py:49,55), scaled: 0 or 1/(1-p), [N, heads, K, K].
+    Drawn with torch's device generator (reproducible under torch.manual_seed); None when p == 0."""
+    if not p:
+        return None
+    return (torch.rand(N, heads, K, K, device=device) >= p).to(torch.float32).mul_(1.0 / (1.0 - p))
+
+
+def set_attention(q, k, v, N, K, heads, nvalid=None, prob_mask=None):
     require_cuda(q, k, v)
     q, k, v = _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
     D = q.shape[-1]
+    if prob_mask is not None and (prob_mask.shape != (N, heads, K, K) or not prob_mask.is_contiguous()):
+        raise ValueError("set_attention: prob_mask must be a contiguous [N, heads, K, K] tensor")
     out = torch.empty_like(q)
     with _span("sn_set_attention_f32"):
-        check(lib().sn_set_attention_f32(ptr(q), ptr(k), ptr(v), N, K, heads, D // heads, ptr(nvalid), ptr(out),
+        check(lib().sn_set_attention_f32(ptr(q), ptr(k), ptr(v), N, K, heads, D // heads, ptr(nvalid), ptr(prob_mask), ptr(out),
                                          stream()), "sn_set_attention_f32")
     return out
 

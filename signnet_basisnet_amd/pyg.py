@@ -298,6 +298,9 @@ class SignNetGNN(nn.Module):
         # sync) and re-runs such a batch on the layer path; strict=False (default) copies them asynchronously
         # and raises at the NEXT forward (or at .check_last()) — outputs of the offending batch are invalid.
         self.strict = False
+        # train-mode dropout of the attention probabilities (ScaledDotProductAttention's default attn_dropout=0.1,
+        # transformer_module.py:46-55 — the only dropout the reference leaves active); 0.0 switches it off
+        self.attn_dropout = 0.1
         self._pending, self._free_hosts, self._flags_host = [], [], None
         self.sign_net = SignNet(n_hid, nl_signnet, self.nl_rho, variant, ignore_eigval)
         self.gnn = GNN(node_feat, edge_feat, n_hid, n_out, nl_gnn, variant)
@@ -446,9 +449,8 @@ class SignNetGNN(nn.Module):
 
     def forward(self, data, return_stages=False):
         if self.training:
-            # train-mode forward VALUE (no autograd): BatchNorm with batch statistics over the valid rows and the
-            # running-statistics update, layer by layer.  The attention dropout p = 0.1 that the reference leaves
-            # active in training (transformer_module.py:46,55) is random and NOT applied (fixtures: p = 0).
+            # train mode: BatchNorm with batch statistics over the valid rows and the running-statistics update, layer by
+            # layer, and the attention dropout the reference leaves active (self.attn_dropout; the fixtures use 0).
             if torch.is_grad_enabled() and not return_stages and any(p.requires_grad for p in self.parameters()):
                 return self._forward_grad(data)    # differentiable: autograd.Function per layer op (csrc/backward.hip)
             self._prep = None                      # parameters may have changed since the last call
@@ -482,8 +484,8 @@ class SignNetGNN(nn.Module):
         """Train-mode forward recorded for torch.autograd: the same layer-at-a-time HIP launches as `_forward(train=True)`,
         each wrapped in a torch.autograd.Function whose backward is its hand-written adjoint (autograd.py).  `.backward()`
         on a loss of the result fills `.grad` of every parameter the reference's forward uses (loss.backward() at
-        Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62).  As in the value path the attention dropout
-        (p = 0.1, transformer_module.py:46,55) is not applied."""
+        Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62).  The attention dropout (self.attn_dropout,
+        transformer_module.py:46,55) is an explicit mask drawn once per layer and shared by forward and backward."""
         from . import autograd as AG
         ops.require_cuda(data.edge_index, data.batch, data.eigen_vectors)
         sn, g = self.sign_net, self.gnn
@@ -530,7 +532,7 @@ class SignNetGNN(nn.Module):
             q = AG.linear(x, a.w_qs.weight, None, nv, K)
             k = AG.linear(x, a.w_ks.weight, None, nv, K)
             v = AG.linear(x, a.w_vs.weight, None, nv, K)
-            o = AG.set_attention(q, k, v, N, K, N_HEAD, nv)
+            o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device))
             o = AG.linear(o, a.fc.weight, None, nv, K)
             y = AG.masked_layernorm(o, x, a.norm.ln.weight, a.norm.ln.bias, LN_EPS, nv, K)
             z = AG.linear(y, f.w_1.weight, f.w_1.bias, nv, K, relu=True)
@@ -621,7 +623,8 @@ class SignNetGNN(nn.Module):
                 q = ops.masked_linear(x, L["q"], nv, K)
                 k = ops.masked_linear(x, L["k"], nv, K)
                 v = ops.masked_linear(x, L["v"], nv, K)
-                o = ops.set_attention(q, k, v, N, K, N_HEAD, nv)
+                pm = ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device) if train else None
+                o = ops.set_attention(q, k, v, N, K, N_HEAD, nv, pm)
                 o = ops.masked_linear(o, L["fc"], nv, K)
                 y = ops.masked_layernorm(o, x, L["ln1"][0], L["ln1"][1], LN_EPS, nv, K)
                 z = ops.masked_linear(y, L["w1"], nv, K, relu=True)

@@ -151,6 +151,22 @@ def test_attention_layernorm_slotsum_backward():
         o = torch.softmax(s, -1) @ vh
         return o.permute(0, 2, 1, 3).reshape(N * K, D) * mask
     run_pair(lambda q, k, v: AG.set_attention(q, k, v, N, K, H, nvd), att_ref, [q, k, v], "set_attention", 5e-5)
+    # attention dropout as an explicit mask (transformer_module.py:55: dropout(softmax(.)))
+    from signnet_basisnet_amd import ops
+    torch.manual_seed(7)
+    pm = ops.attention_dropout_mask(N, K, H, 0.25, DEV)
+    kept = (pm > 0).float().mean().item()
+    assert 0.6 < kept < 0.9 and abs(pm.max().item() - 1 / 0.75) < 1e-6
+    pmc = pm.cpu().double()
+
+    def att_drop_ref(q, k, v):
+        qh, kh, vh = (t.view(N, K, H, dk).permute(0, 2, 1, 3) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) / dk ** 0.5
+        valid = torch.arange(K)[None, :] < nv[:, None]
+        s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+        o = (torch.softmax(s, -1) * pmc) @ vh
+        return o.permute(0, 2, 1, 3).reshape(N * K, D) * mask
+    run_pair(lambda q, k, v: AG.set_attention(q, k, v, N, K, H, nvd, pm), att_drop_ref, [q, k, v], "set_attention+dropout", 5e-5)
 
     x, r = torch.randn(N * K, D, generator=g), torch.randn(N * K, D, generator=g)
     gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)

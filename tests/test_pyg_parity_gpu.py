@@ -26,6 +26,7 @@ def build(fx, max_k=None):
     for k, v in m.state_dict().items():
         assert tuple(v.shape) == tuple(sd[k].shape), k
     m.load_state_dict(sd)
+    m.attn_dropout = 0.0        # the train-mode fixtures were generated with the (random) attention dropout switched off
     return m.cuda().eval()
 
 
