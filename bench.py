@@ -28,15 +28,27 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (f32 in / f32 acc) dense peak
 
 DOMINANT = "sn_phi_fused_f32"     # the kernel the roofline block is quoted on (largest share of the step)
-WORKLOAD = dict(name="ZINC SignNet k=16 hidden=128 batch=128 (GINESignNetPyG SignNetGNN(None,None,128,1,4,6))",
-                B=128, k=16, hidden=128, nl_signnet=4, nl_rho=1, nl_gnn=6, n_out=1)
+# BASELINE.json `configs`: [1] is the configuration the metric is quoted on (the default and the driver's bench line);
+# [0] and [2] can be selected with --config for extra measurements (they are parity-test cases, not the headline).
+WORKLOADS = {
+    1: dict(name="ZINC SignNet k=16 hidden=128 batch=128 (GINESignNetPyG SignNetGNN(None,None,128,1,4,6))",
+            variant="gine", node_feat=None, edge_feat=None, features="zinc", n_lo=9, n_hi=37,
+            B=128, k=16, hidden=128, nl_signnet=4, nl_rho=1, nl_gnn=6, n_out=1),
+    0: dict(name="ZINC-subset SignNet k=8 hidden=64 batch=32 (GINESignNetPyG SignNetGNN(None,None,64,1,4,6))",
+            variant="gine", node_feat=None, edge_feat=None, features="zinc", n_lo=9, n_hi=37,
+            B=32, k=8, hidden=64, nl_signnet=4, nl_rho=1, nl_gnn=6, n_out=1),
+    2: dict(name="Alchemy SignNet batch=256 (main_alchemy.py:35 SignNetGNN(6,4,108,12,8,16), all eigenvectors)",
+            variant="alchemy", node_feat=6, edge_feat=4, features="alchemy", n_lo=6, n_hi=14,
+            B=256, k=None, hidden=108, nl_signnet=8, nl_rho=4, nl_gnn=16, n_out=12),
+}
+WORKLOAD = WORKLOADS[1]
 
 
 def build_model(dev):
     from signnet_basisnet_amd.pyg import SignNetGNN
     torch.manual_seed(0)
-    m = SignNetGNN(None, None, WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"],
-                   variant="gine", max_k=WORKLOAD["k"])
+    m = SignNetGNN(WORKLOAD["node_feat"], WORKLOAD["edge_feat"], WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"],
+                   WORKLOAD["nl_gnn"], variant=WORKLOAD["variant"], max_k=WORKLOAD["k"])
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():          # eval-BN must not be the identity
         for mod in m.modules():
@@ -49,10 +61,14 @@ def build_model(dev):
 def algorithmic_flops(data, k, d, L_phi, L_rho, L_g):
     """Dense-contraction flops of one forward on this batch (SURVEY.md §8(d) formulas, valid rows only)."""
     n = torch.tensor(data.sizes, dtype=torch.float64)
-    M = float((n * torch.clamp(n, max=k)).sum())          # valid (node, slot) rows
+    kk = torch.clamp(n, max=k) if k else n                # slots per node: min(n_graph, k), or all eigenvectors
+    M = float((n * kk).sum())                             # valid (node, slot) rows
     N = float(n.sum())
     phi = 2 * (L_phi - 1) * 2 * 2 * M * d * d + 2 * 2 * M * d           # hidden layers, both signs (+ tiny first layer)
-    rho = L_rho * (6 * 2 * M * d * d + 4 * float((n * torch.clamp(n, max=k) ** 2).sum()) * d) + 2 * N * d * d
+    rho = L_rho * (6 * 2 * M * d * d + 4 * float((n * kk ** 2).sum()) * d) + 2 * N * d * d
+    if WORKLOAD["variant"] == "alchemy":                  # first phi layer is 1 -> d -> d; eigenvalue encoder 1 -> d -> d
+        phi += 2 * 2 * M * d * d
+        rho += 2 * M * d * d
     gnn = 2 * N * 2 * d * d + L_g * 2 * 2 * N * d * d + 2 * len(data.sizes) * d * d
     return dict(phi=phi, rho=rho, gnn=gnn, total=phi + rho + gnn, M=M, N=N)
 
@@ -60,7 +76,8 @@ def algorithmic_flops(data, k, d, L_phi, L_rho, L_g):
 def cpu_baseline(data, model_cpu_sd, budget_s=20.0):
     """The oracle (CPU restatement of the reference) timed on this host's cores on the same batch."""
     from oracle import pyg_signnet as O
-    cfg = O.make_cfg("gine", None, None, WORKLOAD["hidden"], WORKLOAD["n_out"], WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"])
+    cfg = O.make_cfg(WORKLOAD["variant"], WORKLOAD["node_feat"], WORKLOAD["edge_feat"], WORKLOAD["hidden"], WORKLOAD["n_out"],
+                     WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"])
     cores = torch.get_num_threads()
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -215,6 +232,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2],
+                    help="BASELINE.json configs index: 1 = the headline (default); 0 / 2 = extra measurements of the other configs")
     ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train"],
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
@@ -223,6 +242,8 @@ def main():
                     help="inside the timed region, bracket every n-th launch of the dominant kernel with HIP events (1 = all)")
     args = ap.parse_args()
 
+    global WORKLOAD
+    WORKLOAD = WORKLOADS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,7 +269,8 @@ def main():
         return
 
     # each rank owns its shard of the global batch: graphs [rank*B, (rank+1)*B)
-    host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2 + 1000 * rank)
+    host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2 + 1000 * rank, n_lo=WORKLOAD["n_lo"], n_hi=WORKLOAD["n_hi"],
+                            features=WORKLOAD["features"])
     data = synth.batch_to(host, dev)
     model = build_model(dev)
     fl = algorithmic_flops(host, WORKLOAD["k"], WORKLOAD["hidden"], WORKLOAD["nl_signnet"], WORKLOAD["nl_rho"], WORKLOAD["nl_gnn"])
@@ -316,7 +338,8 @@ def main():
                 r = f(fl, WORKLOAD, host, mean_ms, launches / nall)
                 all_roofs[name] = {"achieved_tflops": r["achieved"], "frac": r["frac"]}
         out = {
-            "metric": "graphs/sec SignNet+GINE forward, ZINC batch=128 k=16",
+            "metric": "graphs/sec SignNet+GINE forward, ZINC batch=128 k=16" if args.config == 1 else
+                      f"graphs/sec SignNet+GINE forward, BASELINE configs[{args.config}] (extra measurement, not the headline)",
             "value": total_graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -354,7 +354,10 @@ typedef struct {
 typedef struct {
   int d, n_layers, heads, has_pos;
   float ln_eps;
-  int reserved;
+  int head_pad;              /* 0: natural channel layout.  16 / 32: every weight and vector is zero-padded to heads*head_pad
+                                channels, and the OUTPUT rows of wq/wk/wv and the INPUT columns of wfc are permuted so that head h
+                                owns channels [h*head_pad, h*head_pad + d/heads): the attention then runs in registers for any
+                                head width (used when d/heads is not a multiple of 16 and kmax <= 16) */
   const float* pe_w1;        /* [>=1]  eigen_encoder.layers.0.weight */
   const float* pe_bn0_scale; /* [>=1] */
   const float* pe_bn0_shift;

@@ -35,7 +35,9 @@ struct RhoStruct {
   float* out_sum;        // [N, d]
 };
 
-template <int NT>
+// HP (head-padded layout, see sn_rho_params.head_pad): the tile count exceeds ceil(d/16), so every tile from the one holding
+// channel d on is (partly) padding and gets its own mask; otherwise only the last tile can be partial.
+template <int NT, bool HP = false>
 __device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* gamma /* LDS */, const float* beta /* LDS */,
                                                  float eps, int d, int g, bool valid) {
   float s = 0.f;
@@ -50,7 +52,8 @@ __device__ __forceinline__ void masked_layernorm(f32x4 (&v)[NT], const float* ga
   for (int kk = 0; kk < NT; ++kk) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const float dlt = (kk + 1 < NT || last_ok) ? v[kk][t] - mean : 0.f;
+      const bool real = HP ? (16 * kk + 4 * g < d) : (kk + 1 < NT || last_ok);
+      const float dlt = real ? v[kk][t] - mean : 0.f;
       q += dlt * dlt;
     }
   }
@@ -94,7 +97,7 @@ __device__ __forceinline__ float tile_rowsum(float v) {
 // ONE: exactly one encoder layer without eigenvalue encoding (GINESignNetPyG: nl_rho is ignored, 1 layer).  The layer's
 // input rows are then still in the input buffer when the residual needs them, so they are not kept in registers across
 // the q / k / v projections and the attention but re-read right before the output projection.
-template <int NT, bool REGATTN, bool ONE>
+template <int NT, bool REGATTN, bool ONE, bool HP = false>
 __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 #pragma unroll
       for (int kk = 0; kk < NT; ++kk) {      // d % 4 == 0 (entry-point requirement); only the last tile can be partial
         const int c = 16 * kk + 4 * g;
-        const bool inb = kk + 1 < NT || c < d;
+        const bool inb = HP ? c < d : (kk + 1 < NT || c < d);
         const f32x4 v = ld4(xr + (inb ? c : 0));
         x[kk] = (valid && inb) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
       if (wave_live) {
-        masked_layernorm<NT>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
+        masked_layernorm<NT, HP>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
         split_rows<NT>(x, sp);
       }
       SN_STAMP(7);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
       SN_STAMP(14);
       wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + x[ot]; });
       SN_STAMP(9);
-      if (wave_live) masked_layernorm<NT>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, g, valid);
+      if (wave_live) masked_layernorm<NT, HP>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, g, valid);
       SN_STAMP(10);
     }
     // ---------------------------------------------------------------- sum over the node's slots -> out_sum[node, :]
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 #pragma unroll
           for (int t = 0; t < 4; ++t) s[t] = tile_rowsum(valid ? x[kk][t] : 0.f);
           const int c = 16 * kk + 4 * g;
-          if (li == 0 && unit_ok && (kk + 1 < NT || c < d)) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
+          if (li == 0 && unit_ok && (HP ? c < d : (kk + 1 < NT || c < d))) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
         }
       }
     } else {
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
   ring.drain();
 }
 
-template <int NT, bool REGATTN, bool ONE>
+template <int NT, bool REGATTN, bool ONE, bool HP = false>
 static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   const size_t lds = (size_t)WRing<NT>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float)) +
@@ -377,7 +380,7 @@ static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_b
   static int cus = 0;
   if (cus == 0) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN, ONE, HP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_rho_fused_f32: cannot raise the dynamic LDS limit to %zu", lds);
     int dev = 0, n = 256;
@@ -389,7 +392,7 @@ static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_b
   grid = cus;
 #endif
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN, ONE>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
+  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN, ONE, HP>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
   return SN_OK;
 }
 
@@ -436,11 +439,25 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   hipStream_t st = (hipStream_t)stream;
   const int64_t bound = N + B;   // every bin holds at least one node
   // attention in registers when every node has <= 16 slots and the head width is a multiple of 16
-  const bool regattn = kmax > 0 && kmax <= 16 && ((P.d / P.heads) & 15) == 0;
-  const int nt = (P.d + 15) / 16;
   const bool one = P.n_layers == 1 && !P.has_pos;
-  int rc = regattn ? (one ? dispatch_rho<true, true>(nt, S, P, bound, st) : dispatch_rho<true, false>(nt, S, P, bound, st))
-                   : (one ? dispatch_rho<false, true>(nt, S, P, bound, st) : dispatch_rho<false, false>(nt, S, P, bound, st));
+  // most valid slots any node can have: kmax when set, else the dense slot count K (= the largest graph; all eigenvectors)
+  const int kcap = (kmax > 0 && kmax < K) ? kmax : K;
+  int rc;
+  if (P.head_pad > 0 && kcap <= 16) {
+    // head-padded packing: every head occupies head_pad (16 or 32) channels of the q/k/v/attention tensors, so the register
+    // attention applies to any d; all weights / vectors are zero-padded to heads*head_pad channels by the caller
+    SN_REQUIRE((P.head_pad == 16 || P.head_pad == 32) && P.head_pad >= P.d / P.heads,
+               "sn_rho_fused_f32: head_pad must be 16 or 32 and >= d/heads (got %d for d=%d)", P.head_pad, P.d);
+    if (P.head_pad == 16) rc = one ? launch_rho<4, true, true, true>(S, P, bound, st) : launch_rho<4, true, false, true>(S, P, bound, st);
+    else rc = one ? launch_rho<8, true, true, true>(S, P, bound, st) : launch_rho<8, true, false, true>(S, P, bound, st);
+  } else {
+    SN_REQUIRE(P.head_pad == 0, "sn_rho_fused_f32: head-padded parameters need <= 16 slots per node (got %d); pass the "
+               "natural-layout parameters for this batch", kcap);
+    const bool regattn = kcap <= 16 && ((P.d / P.heads) & 15) == 0;
+    const int nt = (P.d + 15) / 16;
+    rc = regattn ? (one ? dispatch_rho<true, true>(nt, S, P, bound, st) : dispatch_rho<true, false>(nt, S, P, bound, st))
+                 : (one ? dispatch_rho<false, true>(nt, S, P, bound, st) : dispatch_rho<false, false>(nt, S, P, bound, st));
+  }
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_rho_fused_f32");
   return SN_OK;

@@ -97,7 +97,7 @@ class _RhoLayer(C.Structure):
 
 class _RhoParams(C.Structure):
     _fields_ = [("d", C.c_int), ("n_layers", C.c_int), ("heads", C.c_int), ("has_pos", C.c_int),
-                ("ln_eps", C.c_float), ("reserved", C.c_int)] + \
+                ("ln_eps", C.c_float), ("head_pad", C.c_int)] + \
                [(n, C.c_void_p) for n in ("pe_w1", "pe_bn0_scale", "pe_bn0_shift", "pe_w2", "pe_bn1_scale", "pe_bn1_shift")] + \
                [("layers", _RhoLayer * RHO_MAX_LAYERS)]
 
@@ -110,16 +110,48 @@ class RhoPlan:
         d = rho_module.out[0].weight.shape[1]
         if not (0 < d <= 128 and len(tls) <= RHO_MAX_LAYERS and heads == 4 and d % heads == 0):
             raise ValueError("fused rho supports hidden width <= 128 (divisible by 4 heads) and <= 8 layers")
-        dp = 16 * ((d + 15) // 16)
-        self.d, self.dp = d, dp
-        keep = self._keep = []
+        dk = d // heads
+        self._keep = []
+        hp_want = 0 if dk % 16 == 0 else 16 * ((dk + 15) // 16)
+        self.d, self.head_pad = d, hp_want
+        self.params = self._build(rho_module, eigen_encoder, heads, ln_eps, 0)
+        # a second, head-padded packing for batches whose nodes have <= 16 slots (chosen per call in run())
+        self.params_hp = self._build(rho_module, eigen_encoder, heads, ln_eps, hp_want) if hp_want else None
+
+    def _build(self, rho_module, eigen_encoder, heads, ln_eps, hp):
+        tls = rho_module.transformer_layers
+        d = self.d
+        dk = d // heads
+        # hp > 0: head width not a multiple of 16 (e.g. the Alchemy config's 108/4 = 27): pack every head into hp = 16 or 32 channels
+        # (zero padded), permuting the q/k/v output rows and fc's input columns, so that the kernel's register attention
+        # (one 16-channel MFMA chunk never straddles two heads) applies; all other tensors are zero padded to heads*hp
+        dp = heads * hp if hp else 16 * ((d + 15) // 16)
+        keep = self._keep
 
         def hold(t):
             keep.append(t)
             return t.data_ptr()
 
+        dev = rho_module.out[0].weight.device
+        if hp:
+            hidx = torch.tensor([h * hp + j for h in range(heads) for j in range(dk)], device=dev)     # padded slot of channel h*dk+j
+
+        def wpad(W, head_rows=False, head_cols=False):
+            """Weight as the kernel streams it: [dp, dp] zero padded, optionally with head-permuted rows / columns."""
+            W = W.detach()
+            if not hp:
+                return W
+            out = torch.zeros(dp, dp, dtype=torch.float32, device=dev)
+            rows = hidx if head_rows else torch.arange(W.shape[0], device=dev)
+            cols = hidx if head_cols else torch.arange(W.shape[1], device=dev)
+            out[rows[:, None], cols[None, :]] = W
+            return out
+
+        def vpad(v):
+            return ops.pad_vec(v.detach(), dp)
+
         P = _RhoParams()
-        P.d, P.n_layers, P.heads, P.ln_eps = d, len(tls), heads, float(ln_eps)
+        P.d, P.n_layers, P.heads, P.ln_eps, P.head_pad = d, len(tls), heads, float(ln_eps), hp
         P.has_pos = 1 if eigen_encoder is not None else 0
         if eigen_encoder is not None:
             ee = eigen_encoder
@@ -131,21 +163,23 @@ class RhoPlan:
             P.pe_bn1_scale, P.pe_bn1_shift = hold(s), hold(h)
         for l, tl in enumerate(tls):
             a, f, Lp = tl.slf_attn, tl.pos_ffn, P.layers[l]
-            Lp.wq = hold(ops.pack_split(a.w_qs.weight.detach()))
-            Lp.wk = hold(ops.pack_split(a.w_ks.weight.detach()))
-            Lp.wv = hold(ops.pack_split(a.w_vs.weight.detach()))
-            Lp.wfc = hold(ops.pack_split(a.fc.weight.detach()))
-            Lp.ln1_g, Lp.ln1_b = hold(ops.pad_vec(a.norm.ln.weight, dp)), hold(ops.pad_vec(a.norm.ln.bias, dp))
-            Lp.w1 = hold(ops.pack_split(f.w_1.weight.detach(), f.w_1.bias.detach()))
-            Lp.w2 = hold(ops.pack_split(f.w_2.weight.detach(), f.w_2.bias.detach()))
-            Lp.ln2_g, Lp.ln2_b = hold(ops.pad_vec(f.norm.ln.weight, dp)), hold(ops.pad_vec(f.norm.ln.bias, dp))
-        self.params = P
+            Lp.wq = hold(ops.pack_split(wpad(a.w_qs.weight, head_rows=True)))
+            Lp.wk = hold(ops.pack_split(wpad(a.w_ks.weight, head_rows=True)))
+            Lp.wv = hold(ops.pack_split(wpad(a.w_vs.weight, head_rows=True)))
+            Lp.wfc = hold(ops.pack_split(wpad(a.fc.weight, head_cols=True)))
+            Lp.ln1_g, Lp.ln1_b = hold(vpad(a.norm.ln.weight)), hold(vpad(a.norm.ln.bias))
+            Lp.w1 = hold(ops.pack_split(wpad(f.w_1.weight), vpad(f.w_1.bias) if hp else f.w_1.bias.detach()))
+            Lp.w2 = hold(ops.pack_split(wpad(f.w_2.weight), vpad(f.w_2.bias) if hp else f.w_2.bias.detach()))
+            Lp.ln2_g, Lp.ln2_b = hold(vpad(f.norm.ln.weight)), hold(vpad(f.norm.ln.bias))
+        return P
 
     def run(self, plan: ops.GraphPlan, x, eigen_values, K: int):
         """x [N*K, d] -> sum over valid slots of the encoder output, [N, d]."""
         out = torch.empty(plan.N, self.d, dtype=torch.float32, device=x.device)
+        kcap = min(plan.kmax, K) if plan.kmax > 0 else K
+        params = self.params_hp if (self.params_hp is not None and kcap <= 16) else self.params
         with ops._span("sn_rho_fused_f32"):
-            check(lib().sn_rho_fused_f32(C.byref(self.params), ptr(x), ptr(eigen_values), ptr(plan.graph_ptr), plan.B,
+            check(lib().sn_rho_fused_f32(C.byref(params), ptr(x), ptr(eigen_values), ptr(plan.graph_ptr), plan.B,
                                          plan.N, C.byref(plan.bins.cstruct), plan.kmax, K, ptr(out), stream()),
                   "sn_rho_fused_f32")
         return out

@@ -109,6 +109,7 @@ def test_full_eigenvector_mode_uses_the_lds_attention_path():
     ("gine", (None, None, 64, 1, 4, 6), "zinc", 8),
     ("gine", (None, None, 128, 1, 4, 6), "zinc", None),
     ("alchemy", (6, 4, 108, 12, 3, 4), "alchemy", None),
+    ("alchemy", (6, 4, 108, 12, 8, 16), "alchemy", None),       # main_alchemy.py:35 exactly (BASELINE configs[2])
 ])
 def test_vs_oracle_real_widths(variant, ctor, feat, max_k):
     """Reference-sized widths on a seeded synthetic batch: HIP vs the CPU oracle (same weights)."""
