@@ -78,7 +78,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* bstart = hist + 66;      // [66]
   int* bcur = bstart + 66;      // [66]
   int* wsum = bcur + 66;        // [32]
-  __shared__ int s_err, s_ncol, s_nbins, s_nrec;
+  __shared__ int s_err, s_ncol, s_nbins, s_nrec, s_maxcls;
   if (t < 66) { hist[t] = 0; bcur[t] = 0; }
   if (t == 0) { s_err = 0; s_ncol = 0; s_nbins = 0; s_nrec = 0; }
   __syncthreads();
@@ -134,20 +134,42 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     }
     bstart[t] = x - h;
     if (t == 63) { bstart[64] = x; bstart[65] = x + hist[64]; }
+    int hm = h;                                        // largest size class (hist[64] joins below)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hm = max(hm, __shfl_xor(hm, off, 64));
+    if (t == 0) s_maxcls = max(hm, hist[64]);
   }
   __syncthreads();
-  for (int g = t; g < B; g += PLAN_T) {
-    const int n = gp[g + 1] - gp[g];
-    if (n > 0 && n <= 64) bucket[bstart[n] + atomicAdd(&bcur[n], 1)] = g;
-  }
-  __syncthreads();
-  if (t <= 64) {  // deterministic order inside a size class
-    const int lo = bstart[t], hi = bstart[t + 1];
-    for (int a = lo + 1; a < hi; ++a) {
-      const int k = bucket[a];
-      int b = a - 1;
-      while (b >= lo && bucket[b] > k) { bucket[b + 1] = bucket[b]; --b; }
-      bucket[b + 1] = k;
+  if (B <= 2048 && s_maxcls > 12) {
+    // crowded size classes (Alchemy: 256 graphs in 9 classes): rank inside the class = number of earlier graphs of the same
+    // size (LDS broadcast scan) — deterministic order without the per-class serial insertion sort (116 k cycles there);
+    // sparse classes (ZINC: ~4 graphs per class) keep the atomic placement + tiny sorts, which is cheaper
+    for (int g = t; g < B; g += PLAN_T) {
+      const int n = gp[g + 1] - gp[g];
+      if (n > 0 && n <= 64) {
+        int rank = 0, prev = gp[0];
+        for (int q = 0; q < g; ++q) {
+          const int nx = gp[q + 1];
+          rank += (nx - prev == n) ? 1 : 0;
+          prev = nx;
+        }
+        bucket[bstart[n] + rank] = g;
+      }
+    }
+  } else {
+    for (int g = t; g < B; g += PLAN_T) {
+      const int n = gp[g + 1] - gp[g];
+      if (n > 0 && n <= 64) bucket[bstart[n] + atomicAdd(&bcur[n], 1)] = g;
+    }
+    __syncthreads();
+    if (t <= 64) {  // deterministic order inside a size class
+      const int lo = bstart[t], hi = bstart[t + 1];
+      for (int a = lo + 1; a < hi; ++a) {
+        const int k = bucket[a];
+        int b = a - 1;
+        while (b >= lo && bucket[b] > k) { bucket[b + 1] = bucket[b]; --b; }
+        bucket[b + 1] = k;
+      }
     }
   }
   // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers:
