@@ -57,6 +57,14 @@ def ign2to1(sd, eq, X, training=False, pfx=""):
     return h.transpose(2, 1)
 
 
+def ign_shared(sd, eq, X, mult_idx, training=False):
+    """IGNShared.forward — signbasisnet.py:57-64: shared IGN2to1(1,hidden,1) then Linear(1, mult) on the transposed output."""
+    x = ign2to1(sd, eq, X, training, pfx="enc.")                  # [b, 1, n]
+    x = x.transpose(2, 1)
+    x = F.linear(x, sd[f"fcs.{mult_idx}.weight"], sd[f"fcs.{mult_idx}.bias"])
+    return x.transpose(2, 1)
+
+
 def eq_deepsets(sd, x, num_layers, use_bn, pfx=""):
     """EqDeepSetsEncoder.forward — models.py:91-113.  BN has track_running_stats=False, so it
     always normalises with batch statistics (models.py:74,80)."""

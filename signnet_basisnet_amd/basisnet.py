@@ -145,6 +145,26 @@ class IGNBasisInv(nn.Module):
         return self.encs[self.mult_to_idx[mult]](proj)
 
 
+class IGNShared(nn.Module):
+    """IGN BasisNet with one shared IGN2to1(1, hidden, 1) and a Linear(1, mult) per multiplicity (signbasisnet.py:43-64)."""
+
+    def __init__(self, mult_lst, in_channels, hidden_channels=16, num_layers=2):
+        super().__init__()
+        self.enc = IGN2to1(1, hidden_channels, 1, num_layers=num_layers)
+        self.fcs = nn.ModuleList()
+        self.mult_to_idx = {}
+        for i, mult in enumerate(mult_lst):
+            self.fcs.append(nn.Linear(1, mult))
+            self.mult_to_idx[mult] = i
+
+    def forward(self, proj, mult):
+        fc = self.fcs[self.mult_to_idx[mult]]
+        x = self.enc(proj)                                                   # [b, 1, n]
+        b, n = x.shape[0], x.shape[2]
+        y = ops.masked_linear(x.reshape(b * n, 1), _lin(fc.weight, fc.bias))   # transpose(2,1) . Linear(1, mult)   (:60-62)
+        return y.view(b, n, -1).transpose(2, 1).contiguous()                # [b, mult, n]
+
+
 class EqDeepSetsEncoder(nn.Module):
     """Equivariant DeepSets over the second-to-last axis (models.py:58-113).  BatchNorm here has
     track_running_stats=False, i.e. it always normalises with the statistics of the current input."""

@@ -155,3 +155,28 @@ def test_ign_train_mode_forward():
         torch.testing.assert_close(o.cpu(), fx.out[f"train/phi_m{m}"], rtol=2e-3, atol=2e-4)
         enc = net.encs[net.mult_to_idx[m]]
         assert int(enc.bns[0].num_batches_tracked) == int(fx.sd[f"enc{m}/bns.0.num_batches_tracked"]) + 1
+
+
+def test_ign_shared_vs_oracle():
+    """IGNShared (signbasisnet.py:43-64): the shared IGN2to1(1, hidden, 1) followed by a per-multiplicity Linear(1, mult)."""
+    from oracle import basisnet as OB
+    from signnet_basisnet_amd import basisnet as BN
+    fx = G.load("basisnet_grid6")
+    groups = BN.group_eigenspaces(fx.inp["eigvals"], fx.inp["eigvecs"])
+    mults = sorted(groups)
+    torch.manual_seed(3)
+    net = BN.IGNShared(mults, 1, hidden_channels=8)
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    eq = [(net.enc.equi_layers[i].coeffs.detach().clone(), net.enc.equi_layers[i].bias.detach().clone()) for i in range(3)]
+    net = net.to(DEV).eval()
+    for m in mults:
+        ref = OB.ign_shared(sd, eq, groups[m], net.mult_to_idx[m])
+        y = net(groups[m].to(DEV), m)
+        assert y.shape == ref.shape == (groups[m].shape[0], m, groups[m].shape[-1])
+        close(y, ref, f"IGNShared mult {m}", rel=1e-4)
