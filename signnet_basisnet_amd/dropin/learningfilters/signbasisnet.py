@@ -1,2 +1,2 @@
 """`from signbasisnet import SignPlus, IGNBasisInv, IGNShared` (LearningFilters/training.py)."""
-from signnet_basisnet_amd.basisnet import IGN2to1, IGNBasisInv, SignPlus  # noqa: F401
+from signnet_basisnet_amd.basisnet import IGN2to1, IGNBasisInv, IGNShared, SignPlus  # noqa: F401
