@@ -211,6 +211,93 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
     print(json.dumps(out))
 
 
+def basisnet_bench(args, dev):
+    """BASELINE configs[4] (extra measurement, `--config 4`): BasisNet on one 32x32 2-D grid graph (LearningFilters/training.py:
+    47-73,119-126,205-222): the eigenspaces of the normalised Laplacian grouped by multiplicity, IGNBasisInv(hidden 32) over the
+    stacked projectors, EqDeepSetsEncoder(2N -> 10 -> 10 -> 32).  A step = one forward of phi for every multiplicity + rho.
+    The contraction kernel streams every projector element exactly once: its roofline is HBM."""
+    import numpy as np
+    from oracle import basisnet as OB
+    from signnet_basisnet_amd import basisnet as BN
+    from signnet_basisnet_amd import ops
+    side = 32
+    N = side * side
+    idx = np.arange(N).reshape(side, side)
+    A = np.zeros((N, N))
+    for a, b in ((idx[:-1, :], idx[1:, :]), (idx[:, :-1], idx[:, 1:])):
+        A[a.ravel(), b.ravel()] = 1
+        A[b.ravel(), a.ravel()] = 1
+    dis = 1.0 / np.sqrt(A.sum(1))
+    L = np.eye(N) - dis[:, None] * A * dis[None, :]                       # utils.py:72-78 (fp64 eigh, then .float())
+    w, V = np.linalg.eigh(L)
+    eigvals, eigvecs = torch.from_numpy(w).float(), torch.from_numpy(V).float()
+    groups_dev = {}
+    ev_dev = eigvecs.to(dev)
+    rounded = torch.round(eigvals * 1e5) / 1e5
+    _, counts = rounded.unique(return_counts=True)
+    start = 0
+    for c in counts.tolist():                                              # projectors built on the device, once (not timed)
+        Vs = ev_dev[:, start:start + c]
+        groups_dev.setdefault(c, []).append((Vs @ Vs.T).reshape(1, 1, N, N))
+        start += c
+    groups_dev = {m: torch.cat(ps, 0) for m, ps in sorted(groups_dev.items())}
+    mults = sorted(groups_dev)
+    torch.manual_seed(0)
+    phi = BN.IGNBasisInv(mults, 1, hidden_channels=32).to(dev).eval()
+    rho = BN.EqDeepSetsEncoder(2 * N, hidden_channels=10, num_layers=3, out_channels=32, use_bn=True).to(dev).eval()
+    evm = eigvals.to(dev).unsqueeze(0).repeat(N, 1)
+
+    def step():
+        outs = [phi(groups_dev[m], m) for m in mults]
+        feats = torch.cat([o.reshape(N, -1) for o in outs] + [evm], dim=-1)       # training.py:119-123 (the caller's concat)
+        return rho(feats)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        rec = ops.KernelTimer()
+        with rec:
+            for _ in range(min(args.steps, 5)):
+                step()
+        kt = rec.summary()
+    nrep = min(args.steps, 5)
+    proj_bytes = 4.0 * sum(int(g.shape[0]) for g in groups_dev.values()) * N * N
+    launches, mean_ms = kt["sn_ign_contract_2to1_f32"]
+    per_step_ms = mean_ms * launches / nrep
+    out = {"metric": "forwards/sec BasisNet (IGNBasisInv + DeepSets rho) on one 32x32 grid graph, BASELINE configs[4] (extra measurement)",
+           "value": 1.0 / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+           "config": {"workload": "LearningFilters BasisNet, 2-D grid 32x32 (N = 1024), eigenspace multiplicities "
+                                  + str({m: int(g.shape[0]) for m, g in groups_dev.items()}),
+                      "projector_bytes": proj_bytes},
+           "roofline": {"kernel": "sn_ign_contract_2to1_f32 (k_ign_rowcol + k_ign_finish, all multiplicities of a step)",
+                        "bound": "hbm", "achieved": proj_bytes / (per_step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": proj_bytes / (per_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "bytes_per_step": proj_bytes, "ms_per_step": per_step_ms,
+                        "note": "algorithmic bytes = every projector element read once (4*b*n*n)"},
+           "kernels": {k: {"launches_per_step": v[0] / nrep, "mean_us": 1e3 * v[1]} for k, v in kt.items()}}
+    if not args.no_cpu_baseline:
+        sdphi = [{k: v.detach().cpu() for k, v in phi.encs[phi.mult_to_idx[m]].state_dict().items()} for m in mults]
+        eqs = [[(e.coeffs.detach().cpu(), e.bias.detach().cpu()) for e in phi.encs[phi.mult_to_idx[m]].equi_layers] for m in mults]
+        small = {m: groups_dev[m][:min(4, groups_dev[m].shape[0])].cpu() for m in mults}        # bounded sample: <= 4 projectors per class
+        nproj = sum(int(g.shape[0]) for g in small.values())
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for m, sd_, eq in zip(mults, sdphi, eqs):
+                OB.ign2to1(sd_, eq, small[m], training=False)
+        tcpu = time.perf_counter() - t0
+        total = sum(int(g.shape[0]) for g in groups_dev.values())
+        out["cpu_baseline"] = {"value": 1.0 / (tcpu * total / nproj), "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"oracle/basisnet.py IGN2to1 on {nproj} of the {total} projectors (<= 4 per multiplicity), "
+                                         "time scaled to all of them; rho not included"}
+    print(json.dumps(out))
+
+
 def recorded_traffic(kernel):
     """HBM bytes per launch from the committed PMC pass of this same command (profiles/hbm_traffic.json; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected in the timed run).  None for another workload."""
@@ -232,8 +319,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2],
-                    help="BASELINE.json configs index: 1 = the headline (default); 0 / 2 = extra measurements of the other configs")
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 4],
+                    help="BASELINE.json configs index: 1 = the headline (default); 0 / 2 / 4 = extra measurements of the other "
+                         "single-GPU configs (4 = BasisNet on the 2-D grid)")
     ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train"],
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
@@ -243,6 +331,11 @@ def main():
     args = ap.parse_args()
 
     global WORKLOAD
+    if args.config == 4:
+        if int(os.environ.get("RANK", "0")) == 0:
+            torch.cuda.set_device(0)
+            basisnet_bench(args, torch.device("cuda", 0))
+        return
     WORKLOAD = WORKLOADS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
