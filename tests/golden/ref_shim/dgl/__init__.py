@@ -17,3 +17,29 @@ class Graph:
 
     def number_of_nodes(self):
         return int(self._bnn.sum())
+
+    @property
+    def ndata(self):
+        if not hasattr(self, "_ndata"):
+            self._ndata = {}
+        return self._ndata
+
+    @property
+    def edata(self):
+        if not hasattr(self, "_edata"):
+            self._edata = {}
+        return self._edata
+
+
+def _segments(g):
+    return torch.repeat_interleave(torch.arange(len(g.batch_num_nodes())), g.batch_num_nodes())
+
+
+def sum_nodes(g, key):
+    x = g.ndata[key]
+    return torch.zeros(len(g.batch_num_nodes()), *x.shape[1:], dtype=x.dtype).index_add_(0, _segments(g), x)
+
+
+def mean_nodes(g, key):
+    n = g.batch_num_nodes().to(g.ndata[key].dtype).clamp(min=1)
+    return sum_nodes(g, key) / n.view(-1, *([1] * (g.ndata[key].dim() - 1)))

@@ -180,3 +180,36 @@ def test_ign_shared_vs_oracle():
         y = net(groups[m].to(DEV), m)
         assert y.shape == ref.shape == (groups[m].shape[0], m, groups[m].shape[-1])
         close(y, ref, f"IGNShared mult {m}", rel=1e-4)
+
+
+def _ginnet(fx):
+    from signnet_basisnet_amd import dgl_nets
+    hidden, L, k = (int(v) for v in fx.meta["params"])
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  readout="mean", batch_norm=True, residual=True, edge_feat=True, device=DEV, pe_init="lap_pe",
+                  lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k,
+                  sign_inv_net="gin", sign_inv_layers=3, sign_inv_activation="relu", pe_aggregate="add", phi_out_dim=4)
+    net = dgl_nets.GINNet(params)
+    assert sorted(net.state_dict().keys()) == sorted(fx.sd.keys())
+    net.load_state_dict(fx.sd)
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gin_base_net_golden(mode):
+    """GraphPrediction tree end to end: sign_inv_net -> GINNet (gin_net.py), driven like train_ZINC_graph_regression.py:20-25,
+    against the reference's own outputs (state_dict keys identical)."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    fx = G.load("dgl_ginnet_k6")
+    net = _ginnet(fx).train(mode == "train")
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    with torch.no_grad():
+        p = net.sign_inv_net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV)).squeeze(-1)
+        y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p, fx.inp["edge_attr"].to(DEV), None)
+    if mode == "eval":
+        close(p, fx.out["eval/p"], "sign_inv_net output")
+        close(y, fx.out["eval/y"], "GINNet scores")
+    else:
+        torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=5e-4, atol=5e-5)
+        torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=5e-4, atol=5e-5)

@@ -118,3 +118,17 @@ def test_lap_positional_encoding_restatement_properties():
         if kk:
             assert np.abs(L @ pe[:, :kk].astype(np.float64) - pe[:, :kk] * w[1:1 + kk]).max() < 1e-5
         off += n
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gin_base_net(mode):
+    """oracle/dgl_nets.py against the reference's GINNet + sign_inv_net (GraphPrediction tree) fixture."""
+    from oracle import dgl_nets as ON
+    fx = G.load("dgl_ginnet_k6")
+    hidden, L, k = (int(v) for v in fx.meta["params"])
+    ei = fx.inp["edge_index"]
+    y, p = ON.gin_net_with_sign_inv(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.inp["pos_enc"], L, 3, k,
+                                    training=(mode == "train"))
+    tol = dict(rtol=5e-4, atol=5e-5) if mode == "train" else dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **tol)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **tol)

@@ -171,3 +171,36 @@ def test_deepsigns_gradients_match_oracle_autograd(name):
         assert e <= 2e-3 * gr.abs().max().item() + 1e-5 * gmax + 1e-6, f"{pname}: {e:.3e} vs {gr.abs().max().item():.3e}"
         checked += 1
     assert checked >= 10
+
+
+def test_dgl_gin_base_net_training_step_gradients():
+    """loss.backward() through GINNet AND the sign_inv_net that produced its p (one autograd graph, as in
+    train_ZINC_graph_regression.py:70-85): every parameter gradient against torch.autograd on the float64 oracle."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from test_dgl_basisnet_gpu import _ginnet
+    fx = G.load("dgl_ginnet_k6")
+    hidden, L, k = (int(v) for v in fx.meta["params"])
+    net = _ginnet(fx).train()
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    target = torch.randn(len(fx.inp["sizes"]), 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    p = net.sign_inv_net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV)).squeeze(-1)
+    y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p, fx.inp["edge_attr"].to(DEV), None)
+    net.loss(y, target.float().to(DEV)).backward()
+    sd = {kk: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in kk and not kk.endswith("eps") else
+               (v.clone().double() if v.is_floating_point() else v.clone())) for kk, v in fx.sd.items()}
+    yo, _ = ON.gin_net_with_sign_inv(sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.inp["pos_enc"].double(), L, 3, k,
+                                     training=True)
+    (yo - target).abs().mean().backward()
+    gmax = max(v.grad.abs().max().item() for v in sd.values() if v.requires_grad and v.grad is not None)
+    checked = 0
+    for pname, prm in net.named_parameters():
+        gr = sd[pname].grad
+        if gr is None or gr.abs().max() == 0:
+            assert prm.grad is None or prm.grad.abs().max().item() <= 1e-5 * gmax + 1e-7, pname
+            continue
+        e = (prm.grad.detach().cpu().double() - gr).abs().max().item()
+        assert e <= 2e-3 * gr.abs().max().item() + 1e-5 * gmax + 1e-7, f"{pname}: {e:.3e} vs {gr.abs().max().item():.3e}"
+        checked += 1
+    assert checked >= 25, checked
