@@ -283,6 +283,22 @@ int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scr
 int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, void* stream);
 
+/* GatedGCN edge-gated aggregation.  Replaces the DGL message passing of GatedGCNLayer.forward
+ * (GraphPrediction/layers/gatedgcn_layer.py:51-56: apply_edges(u_add_v) + sigmoid + two update_all sums):
+ *   e_out[e,:] = Dh[src(e),:] + Eh[dst(e),:] + Ce[e,:];   sigma = sigmoid(e_out)
+ *   h_out[i,:] = Ah[i,:] + (sum_{e -> i} sigma_e * Bh[src(e),:]) / (sum_{e -> i} sigma_e + 1e-6)
+ * over sn_batch_plan's destination-sorted CSR (rowptr / col = source / eperm = edge id); den_out (may be NULL) keeps the
+ * per-node sum of gates for the backward.  sn_gated_aggregate_bwd_f32: gradients w.r.t. Bh, Dh, Eh (dB, dD, dE, [N,C]) and
+ * de_new [E,C] = the gradient of e_out's three addends (= d Ce; d Ah = dh), from dh [N,C] and de [E,C] (NULL = 0); two passes,
+ * by destination and by source (reverse CSR = sn_batch_plan of the flipped edge_index), no atomics.  scratch: float[N*C]. */
+int sn_gated_aggregate_f32(const float* Ah, const float* Bh, const float* Dh, const float* Eh, const float* Ce, int64_t N, int C,
+                           const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* h_out, float* e_out,
+                           float* den_out, void* stream);
+int sn_gated_aggregate_bwd_f32(const float* Ah, const float* Bh, const float* e_new, const float* h_new, const float* den,
+                               const float* dh, const float* de, int64_t N, int C, const int32_t* rowptr, const int32_t* col,
+                               const int32_t* eperm, const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm,
+                               float* dB, float* dD, float* dE, float* de_new, float* scratch, void* stream);
+
 /* ==========================================================================================
  * Fused stages (eval mode: BatchNorm folded to per-channel scale/shift).
  *

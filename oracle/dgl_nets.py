@@ -39,3 +39,56 @@ def gin_net_with_sign_inv(sd, src, dst, batch_num_nodes, h_idx, pos_enc, n_layer
     ssd = {kk[len("sign_inv_net."):]: v for kk, v in sd.items() if kk.startswith("sign_inv_net.")}
     p = OD.gin_deepsigns(ssd, src, dst, pos_enc.unsqueeze(-1), sign_inv_layers, k, training=training).squeeze(-1)
     return gin_net(sd, src, dst, batch_num_nodes, h_idx, p, n_layers, readout, training), p
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GatedGCN: /root/reference/GraphPrediction/layers/gatedgcn_layer.py:12-81 (GatedGCNLayer),
+# nets/ZINC_graph_regression/gatedgcn_net.py:18-148 (GatedGCNNet, lap_pe / lap_lspe = False).  dgl.function's
+# u_add_v / u_mul_e / copy_e / sum restated: edge field from source / destination node fields, sum over in-edges.
+# Pinned against tests/golden/dgl_gatedgcn_{concat_k6,add_k8}.npz (the reference's own modules through the DGL stand-in).
+def _bn_rows(sd, pfx, x, training):
+    if training:
+        return F.batch_norm(x, None, None, sd[pfx + ".weight"], sd[pfx + ".bias"], True, 0.0, OD.BN_EPS)
+    return F.batch_norm(x, sd[pfx + ".running_mean"], sd[pfx + ".running_var"], sd[pfx + ".weight"], sd[pfx + ".bias"], False, 0.0,
+                        OD.BN_EPS)
+
+
+def gatedgcn_layer(sd, pfx, src, dst, h, e, batch_norm=True, residual=True, training=False):
+    """GatedGCNLayer.forward (gatedgcn_layer.py:36-77, graph_norm False, dropout 0): returns (h, e)."""
+    lin = lambda n, x: F.linear(x, sd[f"{pfx}.{n}.weight"], sd[f"{pfx}.{n}.bias"])      # noqa: E731
+    Ah, Bh, Dh, Eh, Ce = lin("A", h), lin("B", h), lin("D", h), lin("E", h), lin("C", e)
+    e_new = Dh[src] + Eh[dst] + Ce                                                      # u_add_v('Dh','Eh') + Ce   (:51-52)
+    sigma = torch.sigmoid(e_new)
+    num = torch.zeros_like(Ah).index_add_(0, dst, Bh[src] * sigma)                      # u_mul_e('Bh','sigma') summed (:54)
+    den = torch.zeros_like(Ah).index_add_(0, dst, sigma)                                # copy_e('sigma') summed       (:55)
+    h_new = Ah + num / (den + 1e-6)                                                     # (:56)
+    if batch_norm:
+        h_new, e_new = _bn_rows(sd, pfx + ".bn_node_h", h_new, training), _bn_rows(sd, pfx + ".bn_node_e", e_new, training)
+    h_new, e_new = torch.relu(h_new), torch.relu(e_new)
+    if residual and h_new.shape[1] == h.shape[1]:
+        h_new, e_new = h + h_new, e + e_new
+    return h_new, e_new
+
+
+def gatedgcn_net(sd, src, dst, batch_num_nodes, h_idx, p, e_idx, n_layers, pe_aggregate="concat", readout="mean", training=False,
+                 out=None):
+    """GatedGCNNet.forward (gatedgcn_net.py:84-148) for pe_init='lap_pe', lap_lspe=False, edge_feat=True."""
+    h = sd["embedding_h.weight"][h_idx]
+    pp = F.linear(p, sd["embedding_p.weight"], sd["embedding_p.bias"])
+    if pe_aggregate == "concat":
+        h = F.linear(torch.cat([h, pp], dim=1), sd["pe_proj.weight"], sd["pe_proj.bias"])
+    else:
+        h = h + pp
+    e = sd["embedding_e.weight"][e_idx]
+    for l in range(n_layers):
+        h, e = gatedgcn_layer(sd, f"layers.{l}", src, dst, h, e, True, True, training)
+    if out is not None:
+        out["h_last"] = h
+    bnn = torch.as_tensor(batch_num_nodes)
+    seg = torch.repeat_interleave(torch.arange(len(bnn)), bnn)
+    hg = torch.zeros(len(bnn), h.shape[1], dtype=h.dtype).index_add_(0, seg, h)
+    if readout != "sum":
+        hg = hg / bnn.to(h.dtype).clamp(min=1).unsqueeze(1)
+    y = torch.relu(F.linear(hg, sd["MLP_layer.FC_layers.0.weight"], sd["MLP_layer.FC_layers.0.bias"]))
+    y = torch.relu(F.linear(y, sd["MLP_layer.FC_layers.1.weight"], sd["MLP_layer.FC_layers.1.bias"]))
+    return F.linear(y, sd["MLP_layer.FC_layers.2.weight"], sd["MLP_layer.FC_layers.2.bias"])

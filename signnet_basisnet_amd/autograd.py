@@ -314,3 +314,33 @@ class _SegmentPool(Function):
 
 def segment_pool(h, plan, mode="add"):
     return _SegmentPool.apply(h, plan, mode)
+
+
+# ----------------------------------------------------------------------------- GatedGCN edge-gated aggregation
+class _Gated(Function):
+    @staticmethod
+    def forward(ctx, Ah, Bh, Dh, Eh, Ce, plan, rplan):
+        h, e, den = ops.gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan, want_den=True)
+        ctx.save_for_backward(_c(Ah), _c(Bh), e, h, den)
+        ctx.meta = (plan, rplan)
+        return h, e
+
+    @staticmethod
+    def backward(ctx, dh, de):
+        Ah, Bh, e, h, den = ctx.saved_tensors
+        plan, rp = ctx.meta
+        dh = _c(dh) if dh is not None else torch.zeros_like(h)
+        de = _c(de) if de is not None else None
+        N, Cc = Ah.shape
+        dB, dD, dE = torch.empty_like(Ah), torch.empty_like(Ah), torch.empty_like(Ah)
+        de_new, scratch = torch.empty_like(e), torch.empty_like(Ah)
+        with ops._span("sn_gated_aggregate_bwd_f32"):
+            check(lib().sn_gated_aggregate_bwd_f32(ptr(Ah), ptr(Bh), ptr(e), ptr(h), ptr(den), ptr(dh), ptr(de), N, Cc, ptr(plan.rowptr),
+                                                   ptr(plan.col), ptr(plan.eperm), ptr(rp.rowptr), ptr(rp.col), ptr(rp.eperm), ptr(dB),
+                                                   ptr(dD), ptr(dE), ptr(de_new), ptr(scratch), stream()), "sn_gated_aggregate_bwd_f32")
+        return dh, dB, dD, dE, de_new, None, None
+
+
+def gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan, rplan):
+    """(h, e) of GatedGCN's message passing (gatedgcn_layer.py:51-56); differentiable in all five inputs."""
+    return _Gated.apply(Ah, Bh, Dh, Eh, Ce, plan, rplan)

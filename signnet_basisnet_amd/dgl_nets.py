@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .dgl_deepsigns import MLP, _GINConv, _prep_mlp, _run_mlp, get_sign_inv_net
+from .dgl_deepsigns import MLP, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
 
 
 class MLPReadout(nn.Module):
@@ -119,4 +119,124 @@ class GINNet(nn.Module):
 
     def loss(self, scores, targets):
         """gin_net.py:141-143 (use_lapeig_loss = False): the L1 task loss (a torch reduction over B scalars)."""
+        return (scores - targets).abs().mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class GatedGCNLayer(nn.Module):
+    """layers/gatedgcn_layer.py:12-81 (parameters only; the arithmetic is in GatedGCNNet.forward)."""
+
+    def __init__(self, input_dim, output_dim, dropout, batch_norm, residual=False, graph_norm=True):
+        super().__init__()
+        if dropout or graph_norm:
+            raise NotImplementedError("HIP GatedGCNLayer: dropout 0.0 and graph_norm=False (what gatedgcn_net.py builds for lap_pe)")
+        self.in_channels, self.out_channels = input_dim, output_dim
+        self.batch_norm, self.residual = batch_norm, residual and input_dim == output_dim
+        for n in "ABCDE":
+            setattr(self, n, nn.Linear(input_dim, output_dim, bias=True))
+        self.bn_node_h = nn.BatchNorm1d(output_dim)
+        self.bn_node_e = nn.BatchNorm1d(output_dim)
+
+
+class GatedGCNNet(nn.Module):
+    """nets/ZINC_graph_regression/gatedgcn_net.py:18-148 for pe_init = 'lap_pe', lap_lspe = False (the sign-invariant PE configs
+    GatedGCN_ZINC_LapPE_signinv_GIN[_mask].json): embedding_h / embedding_p with `add` or `concat` + pe_proj (:93-103), edge
+    embedding, L GatedGCN layers on sn_gated_aggregate_f32, mean / sum readout, MLPReadout.  Same constructor, forward contract
+    `model(g, h, p, e, snorm_n) -> (scores, g)`, state_dict keys and attached `sign_inv_net` as the reference."""
+
+    def __init__(self, net_params):
+        super().__init__()
+        p = net_params
+        hidden, out_dim = p["hidden_dim"], p["out_dim"]
+        self.n_layers, self.readout, self.batch_norm = p["L"], p["readout"], p["batch_norm"]
+        self.residual, self.edge_feat, self.device = p["residual"], p["edge_feat"], p["device"]
+        self.pe_init, self.lap_method, self.lap_lspe = p["pe_init"], p["lap_method"], p["lap_lspe"]
+        self.use_lapeig_loss, self.lambda_loss, self.alpha_loss = p["use_lapeig_loss"], p["lambda_loss"], p["alpha_loss"]
+        self.pos_enc_dim, self.pe_aggregate = p["pos_enc_dim"], p["pe_aggregate"]
+        if self.pe_init != "lap_pe" or self.lap_lspe or self.use_lapeig_loss:
+            raise NotImplementedError("HIP GatedGCNNet covers pe_init='lap_pe' / lap_lspe=False (the sign-invariant PE configs)")
+        if self.readout == "max" or not self.edge_feat or not self.batch_norm:
+            raise NotImplementedError("HIP GatedGCNNet: readout sum/mean, edge_feat=True, batch_norm=True")
+        if p.get("in_feat_dropout", 0.0) or p.get("dropout", 0.0):
+            raise NotImplementedError("HIP GatedGCNNet: dropout 0.0 (as in the shipped configs)")
+        self.embedding_p = nn.Linear(self.pos_enc_dim, hidden)
+        self.embedding_h = nn.Embedding(p["num_atom_type"], hidden)
+        self.embedding_e = nn.Embedding(p["num_bond_type"], hidden)
+        self.layers = nn.ModuleList([GatedGCNLayer(hidden, hidden, 0.0, True, residual=self.residual, graph_norm=False)
+                                     for _ in range(self.n_layers - 1)] +
+                                    [GatedGCNLayer(hidden, out_dim, 0.0, True, residual=self.residual, graph_norm=False)])
+        self.MLP_layer = MLPReadout(out_dim, 1)
+        self.g = None
+        if self.lap_method == "sign_inv":
+            self.sign_inv_net = get_sign_inv_net(net_params)
+        if self.pe_aggregate == "concat":
+            self.pe_proj = nn.Linear(2 * hidden, hidden)
+
+    _plan = GINNet._plan
+
+    def forward(self, g, h, p, e, snorm_n=None):
+        ops.require_cuda(h)
+        if p is None:
+            raise NotImplementedError("HIP GatedGCNNet needs the positional encoding p")
+        N = h.shape[0]
+        batch, ei, B = self._plan(g, N)
+        plan = ops.build_plan(batch, ei, B, 0)
+        hidx, eidx = h.long().reshape(N), e.long().reshape(-1)
+        p = p.contiguous().float()
+        train = self.training
+        if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            y = self._forward_grad(plan, batch, ei, B, hidx, p, eidx)
+        else:
+            with torch.no_grad():
+                y = self._forward_value(plan, hidx, p, eidx, train)
+        self.g = g
+        return y, g
+
+    def _forward_value(self, plan, hidx, p, eidx, train):
+        x = ops.embedding_sum(hidx, [self.embedding_h.weight])
+        if self.pe_aggregate == "concat":
+            pp = ops.masked_linear(p, _pack(self.embedding_p))
+            x = ops.masked_linear(torch.cat([x, pp], dim=1), _pack(self.pe_proj))                  # (:96-98)
+        else:
+            x = ops.masked_linear(p, _pack(self.embedding_p), residual=x)                         # (:100-101)
+        e = ops.embedding_sum(eidx, [self.embedding_e.weight])
+        for L in self.layers:
+            Ah, Bh, Dh, Eh = (ops.masked_linear(x, _pack(getattr(L, n))) for n in "ABDE")
+            Ce = ops.masked_linear(e, _pack(L.C))
+            h2, e2 = ops.gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan)
+            sh, se = _BNSite(L.bn_node_h, train), _BNSite(L.bn_node_e, train)
+            sc, sf = sh.affine(h2, train)
+            x = ops.masked_affine(h2, scale=sc, shift=sf, relu=True, residual=x if L.residual else None)
+            sc, sf = se.affine(e2, train)
+            e = ops.masked_affine(e2, scale=sc, shift=sf, relu=True, residual=e if L.residual else None)
+        hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+        fcs = self.MLP_layer.FC_layers
+        for i, fc in enumerate(fcs):
+            hg = ops.masked_linear(hg, _pack(fc), relu=i < len(fcs) - 1)
+        return hg
+
+    def _forward_grad(self, plan, batch, ei, B, hidx, p, eidx):
+        from . import autograd as AG
+        rplan = ops.build_plan(batch, ei.flip(0).contiguous(), B, 0)
+        x = AG.embedding_sum(hidx, [self.embedding_h.weight])
+        pp = AG.linear(p, self.embedding_p.weight, self.embedding_p.bias)
+        if self.pe_aggregate == "concat":
+            x = AG.linear(torch.cat([x, pp], dim=1), self.pe_proj.weight, self.pe_proj.bias)
+        else:
+            x = AG.masked_add(pp, x)
+        e = AG.embedding_sum(eidx, [self.embedding_e.weight])
+        for L in self.layers:
+            Ah, Bh, Dh, Eh = (AG.linear(x, getattr(L, n).weight, getattr(L, n).bias) for n in "ABDE")
+            Ce = AG.linear(e, L.C.weight, L.C.bias)
+            h2, e2 = AG.gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan, rplan)
+            x = AG.bn_act(h2, L.bn_node_h, relu=True, residual=x if L.residual else None)
+            e = AG.bn_act(e2, L.bn_node_e, relu=True, residual=e if L.residual else None)
+        hg = AG.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+        fcs = self.MLP_layer.FC_layers
+        for i, fc in enumerate(fcs):
+            hg = AG.linear(hg, fc.weight, fc.bias, relu=i < len(fcs) - 1)
+        return hg
+
+    def loss(self, scores, targets):
+        """gatedgcn_net.py:150-152 (use_lapeig_loss = False): the L1 task loss."""
         return (scores - targets).abs().mean()

@@ -296,6 +296,21 @@ def gine_aggregate(x, ea, plan: GraphPlan, eps=None):
     return out
 
 
+def gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan: GraphPlan, want_den=False):
+    """GatedGCN message passing (gatedgcn_layer.py:51-56): -> (h [N,C], e [E,C][, den [N,C]])."""
+    require_cuda(Ah, Bh, Dh, Eh, Ce)
+    Ah, Bh, Dh, Eh, Ce = (_f32c(t, n) for t, n in ((Ah, "Ah"), (Bh, "Bh"), (Dh, "Dh"), (Eh, "Eh"), (Ce, "Ce")))
+    N, Cc = Ah.shape
+    if Ce.shape != (plan.E, Cc):
+        raise ValueError("gated_aggregate: Ce must be [E, C]")
+    h, e = torch.empty_like(Ah), torch.empty_like(Ce)
+    den = torch.empty_like(Ah) if want_den else None
+    with _span("sn_gated_aggregate_f32"):
+        check(lib().sn_gated_aggregate_f32(ptr(Ah), ptr(Bh), ptr(Dh), ptr(Eh), ptr(Ce), N, Cc, ptr(plan.rowptr), ptr(plan.col),
+                                           ptr(plan.eperm), ptr(h), ptr(e), ptr(den), stream()), "sn_gated_aggregate_f32")
+    return (h, e, den) if want_den else (h, e)
+
+
 def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False,
                   residual=None, use_bias=True, out=None):
     """y = epilogue(x @ W^T); x is a row matrix [..., d_in] (leading dims flattened to rows)."""

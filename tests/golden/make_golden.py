@@ -181,6 +181,36 @@ def dgl_ginnet_case(name, hidden, L, k, sizes, seed):
     save(name, **arrays)
 
 
+def dgl_gatedgcn_case(name, hidden, L, k, sizes, seed, pe_aggregate):
+    """The DGL tree's GatedGCN base network with a sign-invariant PE (nets/ZINC_graph_regression/gatedgcn_net.py +
+    layers/gatedgcn_layer.py, config GatedGCN_ZINC_LapPE_signinv_GIN.json scaled down)."""
+    mods = _fresh_import("GraphPrediction", ["nets.ZINC_graph_regression.gatedgcn_net"])
+    import dgl  # the shim
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  readout="mean", batch_norm=True, residual=True, edge_feat=True, device="cpu", pe_init="lap_pe",
+                  lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k,
+                  sign_inv_net="masked_gin", sign_inv_layers=3, sign_inv_activation="relu", pe_aggregate=pe_aggregate, phi_out_dim=4)
+    torch.manual_seed(seed)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = mods[0].GatedGCNNet(params)
+    randomise(net, seed + 1)
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes)
+    pe = synth.dgl_pos_enc(data, k)
+    g = dgl.Graph(data.edge_index[0], data.edge_index[1], torch.tensor(data.sizes))
+    arrays = {**sd_arrays(net), **data_arrays(data), "in/pos_enc": pe.numpy(),
+              "meta/params": np.array([hidden, L, k], dtype=np.int64), "meta/pe_aggregate": np.array(pe_aggregate)}
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        with torch.no_grad():
+            p = net.sign_inv_net(g, pe.unsqueeze(-1).clone()).squeeze(-1)
+            y, _ = net(g, data.x.squeeze(-1), p, data.edge_attr, None)
+        arrays[f"out/{mode}/p"] = p.numpy()
+        arrays[f"out/{mode}/y"] = y.numpy()
+        arrays[f"out/{mode}/h_last"] = g.ndata["h"].numpy()
+    save(name, **arrays)
+
+
 # ------------------------------------------------------------------ LearningFilters
 def basisnet_case(name, side, hidden, seed):
     ign, sbn, models = _fresh_import("LearningFilters", ["ign", "signbasisnet", "models"])
@@ -272,6 +302,8 @@ def main():
     dgl_case("dgl_gin_k8", "gin", 24, 4, 3, 8, [5, 9, 12, 7], 31)
     dgl_case("dgl_masked_k10", "masked_gin", 20, 20, 3, 10, [5, 13, 8, 11], 32)
     dgl_ginnet_case("dgl_ginnet_k6", 24, 3, 6, [5, 9, 12, 7, 3], 33)
+    dgl_gatedgcn_case("dgl_gatedgcn_concat_k6", 20, 3, 6, [5, 9, 12, 7, 3], 34, "concat")
+    dgl_gatedgcn_case("dgl_gatedgcn_add_k8", 28, 2, 8, [6, 4, 11, 2], 35, "add")
     # BasisNet on a small grid
     basisnet_case("basisnet_grid6", 6, 8, 41)
     # eigendecomposition transform: sizes across the kernel's 16 / 32 / 64-lane classes, odd and even, 1- and 2-node graphs

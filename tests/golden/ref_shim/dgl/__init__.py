@@ -1,6 +1,7 @@
 """Stand-in for dgl (absent, unpinned by the reference): GINConv + a minimal batched graph."""
 import torch
 from . import nn
+from . import function  # noqa: F401
 
 
 class Graph:
@@ -29,6 +30,23 @@ class Graph:
         if not hasattr(self, "_edata"):
             self._edata = {}
         return self._edata
+
+
+def _apply_edges(self, func):
+    kind, f, out = func
+    self.edata[out] = f(self)
+
+
+def _update_all(self, message_func, reduce_func):
+    _, f, mout = message_func
+    _, msg, out = reduce_func
+    assert msg == mout
+    m = f(self)
+    self.ndata[out] = torch.zeros(self.number_of_nodes(), *m.shape[1:], dtype=m.dtype).index_add_(0, self.dst, m)
+
+
+Graph.apply_edges = _apply_edges
+Graph.update_all = _update_all
 
 
 def _segments(g):

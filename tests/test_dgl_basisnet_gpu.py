@@ -213,3 +213,38 @@ def test_dgl_gin_base_net_golden(mode):
     else:
         torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=5e-4, atol=5e-5)
         torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=5e-4, atol=5e-5)
+
+
+def _gatedgcn(fx):
+    from signnet_basisnet_amd import dgl_nets
+    hidden, L, k = (int(v) for v in fx.meta["params"])
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  readout="mean", batch_norm=True, residual=True, edge_feat=True, device=DEV, pe_init="lap_pe",
+                  lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k,
+                  sign_inv_net="masked_gin", sign_inv_layers=3, sign_inv_activation="relu",
+                  pe_aggregate=str(fx.meta["pe_aggregate"]), phi_out_dim=4)
+    net = dgl_nets.GatedGCNNet(params)
+    assert sorted(net.state_dict().keys()) == sorted(fx.sd.keys())
+    net.load_state_dict(fx.sd)
+    return net.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["dgl_gatedgcn_concat_k6", "dgl_gatedgcn_add_k8"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gatedgcn_base_net_golden(name, mode):
+    """GraphPrediction tree, GatedGCN_ZINC_LapPE_signinv_GIN_mask.json's model scaled down: MaskedGINDeepSigns -> GatedGCNNet
+    (gatedgcn_net.py + gatedgcn_layer.py) against the reference's own outputs."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    fx = G.load(name)
+    net = _gatedgcn(fx).train(mode == "train")
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    with torch.no_grad():
+        p = net.sign_inv_net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV)).squeeze(-1)
+        y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p, fx.inp["edge_attr"].to(DEV), None)
+    if mode == "eval":
+        close(p, fx.out["eval/p"], "sign_inv_net output")
+        close(y, fx.out["eval/y"], "GatedGCNNet scores")
+    else:
+        torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=1e-3, atol=1e-4)

@@ -132,3 +132,25 @@ def test_dgl_gin_base_net(mode):
     tol = dict(rtol=5e-4, atol=5e-5) if mode == "train" else dict(rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(p, fx.out[f"{mode}/p"], **tol)
     torch.testing.assert_close(y, fx.out[f"{mode}/y"], **tol)
+
+
+@pytest.mark.parametrize("name", ["dgl_gatedgcn_concat_k6", "dgl_gatedgcn_add_k8"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gatedgcn_base_net(name, mode):
+    """oracle/dgl_nets.py (GatedGCN layer + net) against the reference's GatedGCNNet + MaskedGINDeepSigns fixture."""
+    from oracle import dgl_deepsigns as OD
+    from oracle import dgl_nets as ON
+    fx = G.load(name)
+    hidden, L, k = (int(v) for v in fx.meta["params"])
+    ei, sizes = fx.inp["edge_index"], fx.inp["sizes"]
+    training = mode == "train"
+    ssd = {kk[len("sign_inv_net."):]: v for kk, v in fx.sd.items() if kk.startswith("sign_inv_net.")}
+    p = OD.masked_gin_deepsigns(ssd, ei[0], ei[1], torch.as_tensor(sizes), fx.inp["pos_enc"].unsqueeze(-1), 3, k,
+                                training=training).squeeze(-1)
+    out = {}
+    y = ON.gatedgcn_net(fx.sd, ei[0], ei[1], sizes, fx.inp["x"].squeeze(-1), p, fx.inp["edge_attr"], L,
+                        pe_aggregate=str(fx.meta["pe_aggregate"]), training=training, out=out)
+    tol = dict(rtol=1e-3, atol=1e-4) if training else dict(rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **tol)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **tol)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **tol)

@@ -204,3 +204,42 @@ def test_dgl_gin_base_net_training_step_gradients():
         assert e <= 2e-3 * gr.abs().max().item() + 1e-5 * gmax + 1e-7, f"{pname}: {e:.3e} vs {gr.abs().max().item():.3e}"
         checked += 1
     assert checked >= 25, checked
+
+
+@pytest.mark.parametrize("name", ["dgl_gatedgcn_concat_k6", "dgl_gatedgcn_add_k8"])
+def test_dgl_gatedgcn_training_step_gradients(name):
+    """loss.backward() through GatedGCNNet (edge-gated aggregation adjoint) and its MaskedGINDeepSigns: parameter gradients
+    against torch.autograd on the float64 oracle."""
+    from oracle import dgl_deepsigns as OD
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from test_dgl_basisnet_gpu import _gatedgcn
+    fx = G.load(name)
+    hidden, L, k = (int(v) for v in fx.meta["params"])
+    net = _gatedgcn(fx).train()
+    ei, sizes = fx.inp["edge_index"], fx.inp["sizes"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), sizes)
+    target = torch.randn(len(sizes), 1, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+    p = net.sign_inv_net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV)).squeeze(-1)
+    y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p, fx.inp["edge_attr"].to(DEV), None)
+    net.loss(y, target.float().to(DEV)).backward()
+    sd = {kk: (v.clone().double().requires_grad_(True) if v.is_floating_point() and "running" not in kk and not kk.endswith("eps") else
+               (v.clone().double() if v.is_floating_point() else v.clone())) for kk, v in fx.sd.items()}
+    ssd = {kk[len("sign_inv_net."):]: v for kk, v in sd.items() if kk.startswith("sign_inv_net.")}
+    po = OD.masked_gin_deepsigns(ssd, ei[0], ei[1], torch.as_tensor(sizes), fx.inp["pos_enc"].double().unsqueeze(-1), 3, k,
+                                 training=True).squeeze(-1)
+    yo = ON.gatedgcn_net(sd, ei[0], ei[1], sizes, fx.inp["x"].squeeze(-1), po, fx.inp["edge_attr"], L,
+                         pe_aggregate=str(fx.meta["pe_aggregate"]), training=True)
+    assert (y.detach().cpu().double() - yo.detach()).abs().max().item() <= 1e-3 * max(1.0, yo.abs().max().item())
+    (yo - target).abs().mean().backward()
+    gmax = max(v.grad.abs().max().item() for v in sd.values() if v.requires_grad and v.grad is not None)
+    checked = 0
+    for pname, prm in net.named_parameters():
+        gr = sd[pname].grad
+        if gr is None or gr.abs().max() == 0:
+            assert prm.grad is None or prm.grad.abs().max().item() <= 2e-5 * gmax + 1e-7, pname
+            continue
+        e = (prm.grad.detach().cpu().double() - gr).abs().max().item()
+        assert e <= 3e-3 * gr.abs().max().item() + 2e-5 * gmax + 1e-7, f"{pname}: {e:.3e} vs {gr.abs().max().item():.3e} (max {gmax:.3e})"
+        checked += 1
+    assert checked >= 30, checked
