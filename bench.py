@@ -298,6 +298,99 @@ def basisnet_bench(args, dev):
     print(json.dumps(out))
 
 
+def dgl_bench(args, dev):
+    """`--workload dgl` (extra measurement): the GraphPrediction tree's shipped GatedGCN_ZINC_LapPE_signinv_GIN.json model
+    (GINDeepSigns sign_inv_net with 8 layers, k = 8, phi_out 4; GatedGCNNet L = 16, hidden 68, concat PE) in eval mode on a
+    128-graph ZINC-like batch, driven as train_ZINC_graph_regression.py:20-25,77-80 does; plus the edge-gated aggregation
+    kernel alone on an 8192-graph batch, where it is HBM-bound (gathers of Bh / Dh rows per edge)."""
+    import numpy as np
+    from oracle import dgl_deepsigns as OD
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets, ops, synth
+    k, hidden, L = 8, 68, 16
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  readout="mean", batch_norm=True, residual=True, edge_feat=True, device=str(dev), pe_init="lap_pe",
+                  lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k,
+                  sign_inv_net="gin", sign_inv_layers=8, sign_inv_activation="relu", pe_aggregate="concat", phi_out_dim=4)
+    torch.manual_seed(0)
+    net = dgl_nets.GatedGCNNet(params)
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    sd_cpu = {kk: v.detach().clone() for kk, v in net.state_dict().items()}
+    net = net.to(dev).eval()
+    host = synth.make_batch(128, seed=1236)
+    pe = synth.dgl_pos_enc(host, k)
+    ei = host.edge_index
+    g = DS.Graph(ei[0].to(dev), ei[1].to(dev), torch.tensor(host.sizes))
+    hx, ex, ped = host.x.squeeze(-1).to(dev), host.edge_attr.to(dev), pe.unsqueeze(-1).to(dev)
+
+    def step():
+        p = net.sign_inv_net(g, ped).squeeze(-1)
+        return net(g, hx, p, ex, None)[0]
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        rec = ops.KernelTimer()
+        with rec:
+            for _ in range(3):
+                step()
+        kt = rec.summary()
+        # the gather kernel alone, large batch
+        reps = 8
+        base = synth.make_batch(1024, seed=7)
+        big_ei = torch.cat([base.edge_index + r * base.num_nodes for r in range(reps)], 1).to(dev)
+        sizes = list(base.sizes) * reps
+        batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
+        plan = ops.build_plan(batch, big_ei, len(sizes), 0)
+        Nn, E = plan.N, plan.E
+        A_, B_, D_, E_ = (torch.randn(Nn, hidden, device=dev) for _ in range(4))
+        Ce = torch.randn(E, hidden, device=dev)
+        for _ in range(3):
+            ops.gated_aggregate(A_, B_, D_, E_, Ce, plan)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.gated_aggregate(A_, B_, D_, E_, Ce, plan)
+        e1.record()
+        torch.cuda.synchronize()
+        gms = e0.elapsed_time(e1) / 10
+    gbytes = 4.0 * hidden * (3 * E + 4 * Nn)
+    out = {"metric": "graphs/sec GINDeepSigns + GatedGCN eval forward (GatedGCN_ZINC_LapPE_signinv_GIN.json), ZINC batch=128 (extra measurement)",
+           "value": 128 / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+           "config": {"workload": "DGL tree: sign_inv_net gin (8 layers, k=8) + GatedGCNNet (L=16, hidden 68, concat), batch 128"},
+           "roofline": {"kernel": "sn_gated_aggregate_f32 (k_gated_fwd) on an 8192-graph batch", "bound": "hbm",
+                        "achieved": gbytes / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": gbytes,
+                        "mean_launch_us": 1e3 * gms, "nodes": Nn, "edges": E,
+                        "note": "algorithmic bytes 4*d*(3E + 4N): Ce in, e out, Bh and Dh gathered per edge; Ah, Eh in, h out (+den)"},
+           "kernels": {kk: {"launches_per_step": v[0] / 3, "mean_us": 1e3 * v[1]} for kk, v in kt.items()}}
+    if not args.no_cpu_baseline:
+        ssd = {kk[len("sign_inv_net."):]: v for kk, v in sd_cpu.items() if kk.startswith("sign_inv_net.")}
+        ts = []
+        with torch.no_grad():
+            for _ in range(4):
+                t0 = time.perf_counter()
+                po = OD.gin_deepsigns(ssd, ei[0], ei[1], pe.unsqueeze(-1), 8, k).squeeze(-1)
+                ON.gatedgcn_net(sd_cpu, ei[0], ei[1], host.sizes, host.x.squeeze(-1), po, host.edge_attr, L, "concat")
+                ts.append(time.perf_counter() - t0)
+        med = sorted(ts[1:])[1]
+        out["cpu_baseline"] = {"value": 128 / med, "unit": "graphs/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "3 forwards of the same batch after a warm-up, median; oracle/dgl_deepsigns.py + oracle/dgl_nets.py (torch CPU fp32)"}
+    print(json.dumps(out))
+
+
 def recorded_traffic(kernel):
     """HBM bytes per launch from the committed PMC pass of this same command (profiles/hbm_traffic.json; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected in the timed run).  None for another workload."""
@@ -322,7 +415,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 4],
                     help="BASELINE.json configs index: 1 = the headline (default); 0 / 2 / 4 = extra measurements of the other "
                          "single-GPU configs (4 = BasisNet on the 2-D grid)")
-    ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train"],
+    ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train", "dgl"],
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
@@ -354,9 +447,9 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    if args.workload == "evd":
+    if args.workload in ("evd", "dgl"):
         if rank == 0:
-            evd_bench(args, dev)
+            (evd_bench if args.workload == "evd" else dgl_bench)(args, dev)
         if dist is not None:
             dist.destroy_process_group()
         return
