@@ -29,7 +29,51 @@ class MLPReadout(nn.Module):
         self.L = L
 
 
-class GINNet(nn.Module):
+class _PackCache:
+    """Eval-mode cache of packed Linears / folded BatchNorms (rebuilt after train(), .to(), load_state_dict(); call
+    `invalidate()` after changing parameters in place while in eval mode).  Train mode packs per call: parameters move."""
+
+    def invalidate(self):
+        self._cache = {}
+
+    def train(self, mode=True):
+        self._cache = {}
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._cache = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._cache = {}
+        return super().load_state_dict(*a, **k)
+
+    def _pk(self, lin):
+        if self.training:
+            return _pack(lin)
+        c = self.__dict__.setdefault("_cache", {})
+        if id(lin) not in c:
+            c[id(lin)] = _pack(lin)
+        return c[id(lin)]
+
+    def _bn(self, bn, train):
+        if train:
+            return _BNSite(bn, True)
+        c = self.__dict__.setdefault("_cache", {})
+        if id(bn) not in c:
+            c[id(bn)] = _BNSite(bn, False)
+        return c[id(bn)]
+
+    def _mlp(self, mlp, train):
+        if train:
+            return _prep_mlp(mlp, True)
+        c = self.__dict__.setdefault("_cache", {})
+        if id(mlp) not in c:
+            c[id(mlp)] = _prep_mlp(mlp, False)
+        return c[id(mlp)]
+
+
+class GINNet(_PackCache, nn.Module):
     def __init__(self, net_params):
         super().__init__()
         p = net_params
@@ -82,17 +126,14 @@ class GINNet(nn.Module):
         else:
             with torch.no_grad():
                 x = ops.embedding_sum(hidx, [self.embedding_h.weight])
-                pl = ops.PackedLinear(ops.pack_weight(self.embedding_p.weight.detach()), *self.embedding_p.weight.shape,
-                                      self.embedding_p.bias.detach().contiguous())
-                x = ops.masked_linear(p, pl, residual=x)                                              # h + embedding_p(p)   (:87-92)
+                x = ops.masked_linear(p, self._pk(self.embedding_p), residual=x)                                              # h + embedding_p(p)   (:87-92)
                 for conv in self.layers:
                     a = ops.gin_aggregate(x, plan, conv.eps)
-                    x = _run_mlp(_prep_mlp(conv.apply_func, train), a, train=train)
+                    x = _run_mlp(self._mlp(conv.apply_func, train), a, train=train)
                 hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
                 fcs = self.MLP_layer.FC_layers
                 for i, fc in enumerate(fcs):
-                    plf = ops.PackedLinear(ops.pack_weight(fc.weight.detach()), *fc.weight.shape, fc.bias.detach().contiguous())
-                    hg = ops.masked_linear(hg, plf, relu=i < len(fcs) - 1)
+                    hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
                 y = hg
         self.g = g
         return y, g
@@ -138,7 +179,7 @@ class GatedGCNLayer(nn.Module):
         self.bn_node_e = nn.BatchNorm1d(output_dim)
 
 
-class GatedGCNNet(nn.Module):
+class GatedGCNNet(_PackCache, nn.Module):
     """nets/ZINC_graph_regression/gatedgcn_net.py:18-148 for pe_init = 'lap_pe', lap_lspe = False (the sign-invariant PE configs
     GatedGCN_ZINC_LapPE_signinv_GIN[_mask].json): embedding_h / embedding_p with `add` or `concat` + pe_proj (:93-103), edge
     embedding, L GatedGCN layers on sn_gated_aggregate_f32, mean / sum readout, MLPReadout.  Same constructor, forward contract
@@ -195,16 +236,16 @@ class GatedGCNNet(nn.Module):
     def _forward_value(self, plan, hidx, p, eidx, train):
         x = ops.embedding_sum(hidx, [self.embedding_h.weight])
         if self.pe_aggregate == "concat":
-            pp = ops.masked_linear(p, _pack(self.embedding_p))
-            x = ops.masked_linear(torch.cat([x, pp], dim=1), _pack(self.pe_proj))                  # (:96-98)
+            pp = ops.masked_linear(p, self._pk(self.embedding_p))
+            x = ops.masked_linear(torch.cat([x, pp], dim=1), self._pk(self.pe_proj))                  # (:96-98)
         else:
-            x = ops.masked_linear(p, _pack(self.embedding_p), residual=x)                         # (:100-101)
+            x = ops.masked_linear(p, self._pk(self.embedding_p), residual=x)                         # (:100-101)
         e = ops.embedding_sum(eidx, [self.embedding_e.weight])
         for L in self.layers:
-            Ah, Bh, Dh, Eh = (ops.masked_linear(x, _pack(getattr(L, n))) for n in "ABDE")
-            Ce = ops.masked_linear(e, _pack(L.C))
+            Ah, Bh, Dh, Eh = (ops.masked_linear(x, self._pk(getattr(L, n))) for n in "ABDE")
+            Ce = ops.masked_linear(e, self._pk(L.C))
             h2, e2 = ops.gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan)
-            sh, se = _BNSite(L.bn_node_h, train), _BNSite(L.bn_node_e, train)
+            sh, se = self._bn(L.bn_node_h, train), self._bn(L.bn_node_e, train)
             sc, sf = sh.affine(h2, train)
             x = ops.masked_affine(h2, scale=sc, shift=sf, relu=True, residual=x if L.residual else None)
             sc, sf = se.affine(e2, train)
@@ -212,7 +253,7 @@ class GatedGCNNet(nn.Module):
         hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
         fcs = self.MLP_layer.FC_layers
         for i, fc in enumerate(fcs):
-            hg = ops.masked_linear(hg, _pack(fc), relu=i < len(fcs) - 1)
+            hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
         return hg
 
     def _forward_grad(self, plan, batch, ei, B, hidx, p, eidx):
