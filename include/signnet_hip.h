@@ -288,12 +288,16 @@ int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   e_out[e,:] = Dh[src(e),:] + Eh[dst(e),:] + Ce[e,:];   sigma = sigmoid(e_out)
  *   h_out[i,:] = Ah[i,:] + (sum_{e -> i} sigma_e * Bh[src(e),:]) / (sum_{e -> i} sigma_e + 1e-6)
  * over sn_batch_plan's destination-sorted CSR (rowptr / col = source / eperm = edge id); den_out (may be NULL) keeps the
- * per-node sum of gates for the backward.  sn_gated_aggregate_bwd_f32: gradients w.r.t. Bh, Dh, Eh (dB, dD, dE, [N,C]) and
+ * per-node sum of gates for the backward.  ldn = row stride of Ah/Bh/Dh/Eh (column blocks of one [N,4C] GEMM output when the
+ * four Linears are evaluated as one).  Optional fused eval-mode epilogue (all of h_scale/h_shift/e_scale/e_shift, or none):
+ * h_out = [h_res +] relu(h_scale*h + h_shift), e_out = [e_res +] relu(e_scale*e + e_shift) — bn_node_h / bn_node_e folded, ReLU,
+ * residual (gatedgcn_layer.py:64-72).  sn_gated_aggregate_bwd_f32: gradients w.r.t. Bh, Dh, Eh (dB, dD, dE, [N,C]) and
  * de_new [E,C] = the gradient of e_out's three addends (= d Ce; d Ah = dh), from dh [N,C] and de [E,C] (NULL = 0); two passes,
  * by destination and by source (reverse CSR = sn_batch_plan of the flipped edge_index), no atomics.  scratch: float[N*C]. */
-int sn_gated_aggregate_f32(const float* Ah, const float* Bh, const float* Dh, const float* Eh, const float* Ce, int64_t N, int C,
-                           const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* h_out, float* e_out,
-                           float* den_out, void* stream);
+int sn_gated_aggregate_f32(const float* Ah, const float* Bh, const float* Dh, const float* Eh, int ldn, const float* Ce, int64_t N,
+                           int C, const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* h_out, float* e_out,
+                           float* den_out, const float* h_scale, const float* h_shift, const float* e_scale, const float* e_shift,
+                           const float* h_res, const float* e_res, void* stream);
 int sn_gated_aggregate_bwd_f32(const float* Ah, const float* Bh, const float* e_new, const float* h_new, const float* den,
                                const float* dh, const float* de, int64_t N, int C, const int32_t* rowptr, const int32_t* col,
                                const int32_t* eperm, const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm,

@@ -14,27 +14,43 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ldn: row stride of the four node arrays (they may be column blocks of ONE [N, 4C] GEMM output).  Optional fused eval-mode
+// epilogue (hs/ht, es/et = folded BatchNorm scale/shift of bn_node_h / bn_node_e; hres / eres = residual inputs):
+//   h_out = [hres +] relu(hs*h + ht),  e_out = [eres +] relu(es*e + et)        (gatedgcn_layer.py:64-72)
+struct GatedEpi { const float *hs, *ht, *es, *et, *hres, *eres; };
 __global__ __launch_bounds__(256) void k_gated_fwd(const float* __restrict__ Ah, const float* __restrict__ Bh,
-                                                   const float* __restrict__ Dh, const float* __restrict__ Eh,
+                                                   const float* __restrict__ Dh, const float* __restrict__ Eh, int ldn,
                                                    const float* __restrict__ Ce, int64_t N, int C,
                                                    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                    const int32_t* __restrict__ eperm, float* __restrict__ h_out,
-                                                   float* __restrict__ e_out, float* __restrict__ den_out) {
+                                                   float* __restrict__ e_out, float* __restrict__ den_out, GatedEpi ep) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= N * C) return;
   const int64_t i = idx / C;
   const int c = (int)(idx - i * C);
-  const float eh = Eh[idx];
+  const float eh = Eh[i * ldn + c];
+  const bool fuse = ep.hs != nullptr;
+  const float es = fuse ? ep.es[c] : 1.f, et = fuse ? ep.et[c] : 0.f;
   float num = 0.f, den = 0.f;
   for (int s = rowptr[i]; s < rowptr[i + 1]; ++s) {
     const int64_t j = col[s], e = eperm[s];
-    const float en = Dh[j * C + c] + eh + Ce[e * C + c];
+    const float en = Dh[j * ldn + c] + eh + Ce[e * C + c];
     const float sg = sigmoidf_(en);
-    e_out[e * C + c] = en;
-    num += Bh[j * C + c] * sg;
+    float eo = en;
+    if (fuse) {
+      eo = fmaxf(en * es + et, 0.f);
+      if (ep.eres) eo += ep.eres[e * C + c];
+    }
+    e_out[e * C + c] = eo;
+    num += Bh[j * ldn + c] * sg;
     den += sg;
   }
-  h_out[idx] = Ah[idx] + num / (den + 1e-6f);
+  float h = Ah[i * ldn + c] + num / (den + 1e-6f);
+  if (fuse) {
+    h = fmaxf(h * ep.hs[c] + ep.ht[c], 0.f);
+    if (ep.hres) h += ep.hres[idx];
+  }
+  h_out[idx] = h;
   if (den_out) den_out[idx] = den;
 }
 
@@ -92,14 +108,21 @@ __global__ __launch_bounds__(256) void k_gated_bwd_src(const float* __restrict__
 
 using namespace sn;
 
-extern "C" int sn_gated_aggregate_f32(const float* Ah, const float* Bh, const float* Dh, const float* Eh, const float* Ce,
+extern "C" int sn_gated_aggregate_f32(const float* Ah, const float* Bh, const float* Dh, const float* Eh, int ldn, const float* Ce,
                                       int64_t N, int C, const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
-                                      float* h_out, float* e_out, float* den_out, void* stream) {
-  SN_REQUIRE(Ah && Bh && Dh && Eh && Ce && rowptr && col && eperm && h_out && e_out && N >= 0 && C > 0, "sn_gated_aggregate_f32: bad arguments");
-  SN_REQUIRE(N * (int64_t)C < (1ll << 40), "sn_gated_aggregate_f32: too large");
+                                      float* h_out, float* e_out, float* den_out, const float* h_scale, const float* h_shift,
+                                      const float* e_scale, const float* e_shift, const float* h_res, const float* e_res,
+                                      void* stream) {
+  SN_REQUIRE(Ah && Bh && Dh && Eh && Ce && rowptr && col && eperm && h_out && e_out && N >= 0 && C > 0 && ldn >= C,
+             "sn_gated_aggregate_f32: bad arguments");
+  SN_REQUIRE((h_scale != nullptr) == (h_shift != nullptr) && (h_scale != nullptr) == (e_scale != nullptr) &&
+             (e_scale != nullptr) == (e_shift != nullptr), "sn_gated_aggregate_f32: the fused epilogue needs all four scale/shift vectors");
+  SN_REQUIRE(h_scale || (!h_res && !e_res), "sn_gated_aggregate_f32: residuals only with the fused epilogue");
+  SN_REQUIRE(!h_scale || !den_out, "sn_gated_aggregate_f32: the fused (eval) epilogue and den_out (training) exclude each other");
   if (N == 0) return SN_OK;
-  hipLaunchKernelGGL(k_gated_fwd, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, Ah, Bh, Dh, Eh, Ce, N, C,
-                     rowptr, col, eperm, h_out, e_out, den_out);
+  GatedEpi ep{h_scale, h_shift, e_scale, e_shift, h_res, e_res};
+  hipLaunchKernelGGL(k_gated_fwd, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, Ah, Bh, Dh, Eh, ldn, Ce, N, C,
+                     rowptr, col, eperm, h_out, e_out, den_out, ep);
   SN_CHECK_LAUNCH("sn_gated_aggregate_f32");
   return SN_OK;
 }

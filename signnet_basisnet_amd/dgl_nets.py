@@ -64,6 +64,16 @@ class _PackCache:
             c[id(bn)] = _BNSite(bn, False)
         return c[id(bn)]
 
+    def _abde(self, L):
+        """The four node Linears of a GatedGCN layer packed as one [4d, d] Linear (eval cache)."""
+        c = self.__dict__.setdefault("_cache", {})
+        key = ("abde", id(L))
+        if key not in c:
+            W = torch.cat([getattr(L, n).weight.detach() for n in "ABDE"], 0).contiguous()
+            b = torch.cat([getattr(L, n).bias.detach() for n in "ABDE"], 0).contiguous()
+            c[key] = ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], b)
+        return c[key]
+
     def _mlp(self, mlp, train):
         if train:
             return _prep_mlp(mlp, True)
@@ -242,6 +252,17 @@ class GatedGCNNet(_PackCache, nn.Module):
             x = ops.masked_linear(p, self._pk(self.embedding_p), residual=x)                         # (:100-101)
         e = ops.embedding_sum(eidx, [self.embedding_e.weight])
         for L in self.layers:
+            if not train:
+                # eval: A, B, D, E as ONE GEMM ([4d, d] weight, column blocks of the result go to the gather kernel by stride),
+                # BatchNorm (folded) + ReLU + residual of both h and e fused into the gather pass: 3 launches per layer
+                d = L.out_channels
+                Y = ops.masked_linear(x, self._abde(L))
+                Ce = ops.masked_linear(e, self._pk(L.C))
+                sh, se = self._bn(L.bn_node_h, False), self._bn(L.bn_node_e, False)
+                x, e = ops.gated_aggregate(Y[:, 0:d], Y[:, d:2 * d], Y[:, 2 * d:3 * d], Y[:, 3 * d:4 * d], Ce, plan,
+                                           epilogue=(sh.scale, sh.shift, se.scale, se.shift, x if L.residual else None,
+                                                     e if L.residual else None))
+                continue
             Ah, Bh, Dh, Eh = (ops.masked_linear(x, self._pk(getattr(L, n))) for n in "ABDE")
             Ce = ops.masked_linear(e, self._pk(L.C))
             h2, e2 = ops.gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan)

@@ -296,18 +296,27 @@ def gine_aggregate(x, ea, plan: GraphPlan, eps=None):
     return out
 
 
-def gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan: GraphPlan, want_den=False):
-    """GatedGCN message passing (gatedgcn_layer.py:51-56): -> (h [N,C], e [E,C][, den [N,C]])."""
+def gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan: GraphPlan, want_den=False, epilogue=None):
+    """GatedGCN message passing (gatedgcn_layer.py:51-56): -> (h [N,C], e [E,C][, den [N,C]]).
+    Ah/Bh/Dh/Eh may be column blocks (views) of one [N, 4C] tensor.  epilogue = (h_scale, h_shift, e_scale, e_shift, h_res, e_res):
+    eval-mode BatchNorm + ReLU + residual fused into the same pass (residuals may be None)."""
     require_cuda(Ah, Bh, Dh, Eh, Ce)
-    Ah, Bh, Dh, Eh, Ce = (_f32c(t, n) for t, n in ((Ah, "Ah"), (Bh, "Bh"), (Dh, "Dh"), (Eh, "Eh"), (Ce, "Ce")))
     N, Cc = Ah.shape
+    ldn = Ah.stride(0)
+    for t, n in ((Ah, "Ah"), (Bh, "Bh"), (Dh, "Dh"), (Eh, "Eh")):
+        if t.dtype != torch.float32 or t.shape != (N, Cc) or t.stride(1) != 1 or t.stride(0) != ldn:
+            raise ValueError(f"gated_aggregate: {n} must be a float32 [N, C] row block with the common row stride")
+    Ce = _f32c(Ce, "Ce")
     if Ce.shape != (plan.E, Cc):
         raise ValueError("gated_aggregate: Ce must be [E, C]")
-    h, e = torch.empty_like(Ah), torch.empty_like(Ce)
-    den = torch.empty_like(Ah) if want_den else None
+    h = torch.empty(N, Cc, dtype=torch.float32, device=Ah.device)
+    e = torch.empty_like(Ce)
+    den = torch.empty_like(h) if want_den else None
+    ep = epilogue if epilogue is not None else (None,) * 6
     with _span("sn_gated_aggregate_f32"):
-        check(lib().sn_gated_aggregate_f32(ptr(Ah), ptr(Bh), ptr(Dh), ptr(Eh), ptr(Ce), N, Cc, ptr(plan.rowptr), ptr(plan.col),
-                                           ptr(plan.eperm), ptr(h), ptr(e), ptr(den), stream()), "sn_gated_aggregate_f32")
+        check(lib().sn_gated_aggregate_f32(ptr(Ah), ptr(Bh), ptr(Dh), ptr(Eh), ldn, ptr(Ce), N, Cc, ptr(plan.rowptr), ptr(plan.col),
+                                           ptr(plan.eperm), ptr(h), ptr(e), ptr(den), *(ptr(t) for t in ep), stream()),
+              "sn_gated_aggregate_f32")
     return (h, e, den) if want_den else (h, e)
 
 
