@@ -69,6 +69,8 @@ typedef struct {
   /* rho (sn_rho_fused_f32): a node's K_g slot rows padded to 16*ceil(K_g/16); 64/pad nodes per bin, per graph */
   int32_t* rho_bin0;      /* [B+1]           first bin of each graph                                      */
   int32_t* meta;          /* [8]  phi: nbins, error, real rows, columns ; rho: nbins, error, real rows, 0 */
+  const int32_t* node_graph; /* [N] sn_batch_plan's node_graph output (set by the caller): with <= 16 slots per node rho uses
+                                node-major bins — four consecutive nodes of the batch per bin, ceil(N/4) bins — instead of rho_bin0 */
 } sn_plan_bins;
 
 int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index, int64_t E,

@@ -33,6 +33,8 @@ struct RhoStruct {
   int kmax;
   int K;
   float* out_sum;        // [N, d]
+  const int32_t* node_graph;  // [N] graph of every node (register-attention variants: node-major bins)
+  int N;
 };
 
 // HP (head-padded layout, see sn_rho_params.head_pad): the tile count exceeds ceil(d/16), so every tile from the one holding
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
   __shared__ int s_graph;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
-  const int nbins = S.meta[4];
+  const int nbins = REGATTN ? (S.N + 3) >> 2 : S.meta[4];
   if (S.meta[5] != 0) return;
   const int d = P.d, H = P.heads, dk = d / H;
   const float temp = sqrtf((float)dk);
@@ -135,22 +137,41 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
     // ---------------------------------------------------------------- bin -> graph (bins never mix graphs)
     SN_PROF_ON(bin == (int)blockIdx.x);
     SN_STAMP(0);
-    __syncthreads();
-    for (int gq = threadIdx.x; gq < S.B; gq += RHO_R * 4)
-      if (S.rho_bin0[gq] <= bin && bin < S.rho_bin0[gq + 1]) s_graph = gq;
-    __syncthreads();
-    const int gi = s_graph;
-    const int gs = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - gs;
-    const int kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;    // valid slots of every node of this graph
-    const int pad = ((kg + 15) >> 4) << 4;                        // rows reserved per node (tile aligned)
-    const int upb = RHO_R / pad;                                   // nodes per bin
-    const int q = r / pad, slot = r - q * pad;
-    const int u = (bin - S.rho_bin0[gi]) * upb + q;                // node index inside the graph
-    const bool unit_ok = q < upb && u < n;                          // rows past upb*pad are padding
+    int gs, n, kg, q, slot, node, kv, u0;
+    bool unit_ok;
+    if constexpr (REGATTN) {
+      // node-major bins: every node owns one 16-row tile (all K_g <= 16), four consecutive nodes of the BATCH per bin, graphs
+      // mixed freely — ceil(N/4) bins instead of sum_g ceil(n_g/4) (6 % fewer on ZINC sizes), no bin -> graph search
+      q = wave;
+      slot = lane & 15;
+      node = __builtin_amdgcn_readfirstlane(bin * 4 + wave);
+      unit_ok = node < S.N;
+      const int gi = unit_ok ? S.node_graph[node] : 0;
+      gs = S.graph_ptr[gi];
+      n = S.graph_ptr[gi + 1] - gs;
+      kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
+      kv = unit_ok ? kg : 0;
+      u0 = q * 16;
+    } else {
+      __syncthreads();
+      for (int gq = threadIdx.x; gq < S.B; gq += RHO_R * 4)
+        if (S.rho_bin0[gq] <= bin && bin < S.rho_bin0[gq + 1]) s_graph = gq;
+      __syncthreads();
+      const int gi = s_graph;
+      gs = S.graph_ptr[gi];
+      n = S.graph_ptr[gi + 1] - gs;
+      kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;                // valid slots of every node of this graph
+      const int pad = ((kg + 15) >> 4) << 4;                        // rows reserved per node (tile aligned)
+      const int upb = RHO_R / pad;                                   // nodes per bin
+      q = r / pad;
+      slot = r - q * pad;
+      const int u = (bin - S.rho_bin0[gi]) * upb + q;                // node index inside the graph
+      unit_ok = q < upb && u < n;                                    // rows past upb*pad are padding
+      node = gs + u;
+      kv = unit_ok ? kg : 0;
+      u0 = q * pad;                                                  // bin row of my node's slot 0
+    }
     const bool valid = unit_ok && slot < kg;
-    const int node = gs + u;
-    const int kv = unit_ok ? kg : 0;
-    const int u0 = q * pad;                                        // bin row of my node's slot 0
     constexpr bool mfma_attn = REGATTN;                             // one node == one wave tile: attention in registers
     const bool wave_live = __ballot(valid) != 0ull;
     float* Ar = A + r * LD;
@@ -435,7 +456,8 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   }
   SN_REQUIRE(K > 0 && B >= 0 && N >= 0 && B < (1ll << 31), "sn_rho_fused_f32: bad sizes");
   if (B == 0 || N == 0) return SN_OK;
-  RhoStruct S{x, eigen_values, graph_ptr, bins->rho_bin0, bins->meta, (int)B, kmax, K, out_sum};
+  SN_REQUIRE(N < (1ll << 31), "sn_rho_fused_f32: too many nodes");
+  RhoStruct S{x, eigen_values, graph_ptr, bins->rho_bin0, bins->meta, (int)B, kmax, K, out_sum, bins->node_graph, (int)N};
   hipStream_t st = (hipStream_t)stream;
   const int64_t bound = N + B;   // every bin holds at least one node
   // attention in registers when every node has <= 16 slots and the head width is a multiple of 16
@@ -443,6 +465,7 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   // most valid slots any node can have: kmax when set, else the dense slot count K (= the largest graph; all eigenvectors)
   const int kcap = (kmax > 0 && kmax < K) ? kmax : K;
   int rc;
+  SN_REQUIRE(kcap > 16 || bins->node_graph, "sn_rho_fused_f32: sn_plan_bins.node_graph is needed when every node has <= 16 slots");
   if (P.head_pad > 0 && kcap <= 16) {
     // head-padded packing: every head occupies head_pad (16 or 32) channels of the q/k/v/attention tensors, so the register
     // attention applies to any d; all weights / vectors are zero-padded to heads*head_pad channels by the caller

@@ -142,7 +142,8 @@ class GraphPlan:
 
 class _PlanBinsC(C.Structure):
     _fields_ = [("phi_bin_col", C.c_void_p), ("phi_max_bins", C.c_int64), ("phi_col_bin0", C.c_void_p),
-                ("phi_col_mem", C.c_void_p), ("phi_col_off", C.c_void_p), ("rho_bin0", C.c_void_p), ("meta", C.c_void_p)]
+                ("phi_col_mem", C.c_void_p), ("phi_col_off", C.c_void_p), ("rho_bin0", C.c_void_p), ("meta", C.c_void_p),
+                ("node_graph", C.c_void_p)]
 
 
 def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins: bool = False) -> GraphPlan:
@@ -170,7 +171,8 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     pb = None
     if bins:
         meta, bc, cb0, mem, off, rb0 = parts[8:14]
-        cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr())
+        cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr(),
+                        node_graph.data_ptr())
         pb = PlanBins(bc, mb, cb0, mem, off, rb0, meta, cs)
     with _span("sn_batch_plan"):
         check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
