@@ -20,6 +20,7 @@ import torch.nn as nn
 from . import fused, ops
 
 import os as _os
+MAX_FUSED_GRAPHS = 6144      # sn_batch_plan's work-bin limit per call
 _NO_KERNEL_FLAGS = bool(_os.environ.get("SN_NO_KERNEL_FLAGS"))   # debugging: report flags with a stream copy instead
 N_HEAD = 4          # TransformerEncoderLayer(nhid, n_head=4): sign_net.py:50 / core/sign_net.py:57
 LN_EPS = 1e-6       # masked_layers.py:25
@@ -458,6 +459,12 @@ class SignNetGNN(nn.Module):
                 return self._forward(data, return_stages, train=True)
             finally:
                 self._prep = None
+        if self.use_fused and not return_stages and int(data.num_graphs) > MAX_FUSED_GRAPHS:
+            # the work bins of the fused stages are laid out by one workgroup (<= 6144 graphs per plan): larger batches run
+            # as consecutive graph ranges — the eval forward never mixes graphs, so the concatenation is the same result
+            from . import dist as D
+            n = -(-int(data.num_graphs) // MAX_FUSED_GRAPHS)
+            return torch.cat([self.forward(D.shard_batch(data, i, n)) for i in range(n)], 0)
         self.check_last(wait=False)
         y = self._forward(data, return_stages)
         if self.use_fused and not return_stages and self._used_fused:

@@ -306,3 +306,27 @@ def test_train_mode_forward_value_and_running_stats(name):
     with torch.no_grad():
         model(data)
         model.check_last()
+
+
+def test_batches_beyond_the_plan_limit_are_served_in_graph_ranges():
+    """More graphs than one sn_batch_plan lays out work bins for (6144): the module runs consecutive graph ranges and
+    concatenates — checked against the same graphs evaluated in one small batch (the forward never mixes graphs)."""
+    import types
+    from signnet_basisnet_amd import pyg, synth
+    torch.manual_seed(0)
+    model = pyg.SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
+    base = synth.make_batch(205, seed=9)
+    reps = 31
+    assert 205 * reps > pyg.MAX_FUSED_GRAPHS
+    big = types.SimpleNamespace(
+        x=base.x.repeat(reps, 1), edge_index=torch.cat([base.edge_index + r * base.num_nodes for r in range(reps)], 1),
+        edge_attr=base.edge_attr.repeat(reps), batch=torch.cat([base.batch + r * 205 for r in range(reps)]),
+        eigen_values=base.eigen_values.repeat(reps), eigen_vectors=base.eigen_vectors.repeat(reps),
+        num_graphs=205 * reps, num_nodes=base.num_nodes * reps)
+    big.sizes = list(base.sizes) * reps
+    with torch.no_grad():
+        y0 = model(synth.batch_to(base, "cuda:0"))
+        y = model(synth.batch_to(big, "cuda:0"))
+    model.check_last()
+    assert y.shape == (205 * reps, 1)
+    close(y, y0.repeat(reps, 1), "chunked large batch")
