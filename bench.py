@@ -409,8 +409,8 @@ def recorded_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 4],
                     help="BASELINE.json configs index: 1 = the headline (default); 0 / 2 / 4 = extra measurements of the other "
