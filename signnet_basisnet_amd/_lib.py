@@ -112,8 +112,27 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_stream_handle = None      # set by stream_scope: one torch.cuda.current_stream() lookup (~8 us) per forward instead of per launch
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    return _stream_handle if _stream_handle is not None else torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope:
+    """Pin the launch stream for a sequence of launches issued from one Python call (the caller does not switch
+    torch streams in between)."""
+
+    def __enter__(self):
+        global _stream_handle
+        self.prev = _stream_handle
+        _stream_handle = torch.cuda.current_stream().cuda_stream
+        return self
+
+    def __exit__(self, *a):
+        global _stream_handle
+        _stream_handle = self.prev
+        return False
 
 
 def require_cuda(*tensors):

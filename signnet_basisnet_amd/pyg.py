@@ -17,6 +17,7 @@ import time
 import torch
 import torch.nn as nn
 
+from . import _lib as _lib_mod
 from . import fused, ops
 
 import os as _os
@@ -466,7 +467,8 @@ class SignNetGNN(nn.Module):
             n = -(-int(data.num_graphs) // MAX_FUSED_GRAPHS)
             return torch.cat([self.forward(D.shard_batch(data, i, n)) for i in range(n)], 0)
         self.check_last(wait=False)
-        y = self._forward(data, return_stages)
+        with _lib_mod.stream_scope():
+            y = self._forward(data, return_stages)
         if self.use_fused and not return_stages and self._used_fused:
             ev, host = self._post_status(self._last_plan)
             if self.strict:
