@@ -70,10 +70,53 @@ static __device__ long long g_pprof[32];
 #define PL_STAMP(i) do { } while (0)
 #endif
 
+// rho bins (closed form per graph + a prefix): independent of the phi columns — its own workgroup in the single-launch plan
+__device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
+  const int t = threadIdx.x;
+  int* nbv = lds;               // [B]   rho bins per graph
+  int* wsum = lds + B;          // [32]
+  __shared__ int s_rerr;
+  if (t == 0) s_rerr = 0;
+  __syncthreads();
+  int rows = 0;
+  const int per = (B + PLAN_T - 1) / PLAN_T;
+  const int lo = t * per, hi = (lo + per < B) ? lo + per : B;
+  int mine = 0;
+  for (int g = lo; g < hi; ++g) {
+    const int n = gp[g + 1] - gp[g];
+    const int K = slots_of(n, kmax);
+    int nb = 0;
+    if (n > 0) {
+      if (K > 64) atomicOr(&s_rerr, 2);
+      else {
+        const int p = ((K + 15) >> 4) << 4;
+        const int upb = 64 / p;                 // 4, 2, 1, 1
+        nb = (n + upb - 1) / upb;
+        rows += n * K;
+      }
+    }
+    nbv[g] = nb;
+    mine += nb;
+  }
+  int total;
+  int run = block_exscan(mine, wsum, t, &total);
+  for (int g = lo; g < hi; ++g) { bd.rho_bin0[g] = run; run += nbv[g]; }
+  int rtot;
+  block_exscan(rows, wsum, t, &rtot);
+  __syncthreads();
+  if (t == 0) {
+    bd.rho_bin0[B] = total;
+    bd.meta[4] = total;
+    bd.meta[5] = (s_rerr & 2);
+    bd.meta[6] = rtot;
+    bd.meta[7] = 0;
+  }
+}
+
 __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
   const int t = threadIdx.x;
   int* bucket = lds;            // [B]   graph ids grouped by size, ascending id inside a group
-  int* nbv = lds + B;           // [B]   rho bins per graph
+  int* nbv = lds + B;           // [B]   (record scratch of the column packing)
   int* hist = lds + 2 * B;      // [66]
   int* bstart = hist + 66;      // [66]
   int* bcur = bstart + 66;      // [66]
@@ -82,40 +125,6 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   if (t < 66) { hist[t] = 0; bcur[t] = 0; }
   if (t == 0) { s_err = 0; s_ncol = 0; s_nbins = 0; s_nrec = 0; }
   __syncthreads();
-  // ---- rho: bins per graph, prefix
-  {
-    int rows = 0;
-    const int per = (B + PLAN_T - 1) / PLAN_T;
-    const int lo = t * per, hi = (lo + per < B) ? lo + per : B;
-    int mine = 0;
-    for (int g = lo; g < hi; ++g) {
-      const int n = gp[g + 1] - gp[g];
-      const int K = slots_of(n, kmax);
-      int nb = 0;
-      if (n > 0) {
-        if (K > 64) atomicOr(&s_err, 2);
-        else {
-          const int p = ((K + 15) >> 4) << 4;
-          const int upb = 64 / p;                 // 4, 2, 1, 1
-          nb = (n + upb - 1) / upb;
-          rows += n * K;
-        }
-      }
-      nbv[g] = nb;
-      mine += nb;
-    }
-    int total;
-    int run = block_exscan(mine, wsum, t, &total);
-    for (int g = lo; g < hi; ++g) { bd.rho_bin0[g] = run; run += nbv[g]; }
-    int rtot;
-    block_exscan(rows, wsum, t, &rtot);
-    if (t == 0) {
-      bd.rho_bin0[B] = total;
-      bd.meta[4] = total;
-      bd.meta[6] = rtot;
-      bd.meta[7] = 0;
-    }
-  }
   PL_STAMP(3);
   // ---- phi: group graphs by size
   for (int g = t; g < B; g += PLAN_T) {
@@ -260,7 +269,6 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   const bool over = nbins > bd.phi_max_bins;
   if (t == 0) {
     bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
-    bd.meta[5] = (s_err & 2);
   }
   if (!over) {
     for (int c = t; c < ncol; c += PLAN_T) {
@@ -313,6 +321,12 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     PL_STAMP(1);
     plan_bins_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
     PL_STAMP(2);
+    return;
+  }
+  if (blockIdx.x == 2) {               // rho bins: third workgroup (off the critical path of the column packing)
+    int* gp = sm;
+    lds_graph_ptr(batch, N, B, gp, nullptr);
+    plan_rho_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
     return;
   }
   int* gp = sm;                        // [B+1]
@@ -498,6 +512,8 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_scan(int64_t N, int64_t B, int 
     int* gp = sm;
     for (int64_t i = t; i <= B; i += T) gp[i] = graph_ptr[i];
     __syncthreads();
+    plan_rho_block(gp, (int)B, kmax, bd, sm + B + 4);
+    __syncthreads();
     plan_bins_block(gp, (int)B, kmax, bd, sm + B + 4);
     return;
   }
@@ -657,7 +673,7 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
         return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit to %zu", lds);
       init = true;
     }
-    hipLaunchKernelGGL(k_plan_small, dim3(do_bins ? 2 : 1), dim3(PLAN_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E,
+    hipLaunchKernelGGL(k_plan_small, dim3(do_bins ? 3 : 1), dim3(PLAN_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E,
                        kmax, graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bd, do_bins ? 1 : 0);
     SN_CHECK_LAUNCH("sn_batch_plan");
     return SN_OK;
