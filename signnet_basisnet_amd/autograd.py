@@ -2,7 +2,8 @@
 adjoints (csrc/backward.hip).  SURVEY.md §8 f1 — what the reference gets from torch.autograd over ATen / PyG /
 torch_scatter kernels (loss.backward(), Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62-63).
 
-torch only records the graph and owns the buffers; no arithmetic of the path runs in ATen.  Conventions as in ops.py:
+torch only records the graph and owns the buffers; no arithmetic of the path runs in ATen except autograd's own gradient
+accumulation (the adds where a tensor feeds several ops, and the += into .grad).  Conventions as in ops.py:
 row matrices [R, C] with R = N*K slot rows (valid iff slot < nvalid[node]) or R = N / E / B plain rows (nvalid None).
 Gradients flowing into an op are zero on invalid rows because every producer masks them.
 """
