@@ -170,6 +170,14 @@ int sn_colstats_blocks(int64_t R);
 int sn_masked_colstats_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K,
                            float* mean, float* var, float* count, float* scratch, void* stream);
 
+/* Train-mode BatchNorm1d statistics in one call (the sequence sn_masked_colstats_f32 -> sn_bn_fold_f32 (x2) ->
+ * sn_bn_running_update_f32 with the last four launches fused): mean / biased var / count over the valid rows, rstd, the folded
+ * scale = gamma*rstd and shift = beta - mean*scale (gamma / beta may be NULL), and — when running_mean / running_var are given —
+ * their momentum update with the unbiased variance.  scratch as for sn_masked_colstats_f32. */
+int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                          float* var, float* rstd, float* scale, float* shift, float* count, float* scratch, void* stream);
+
 /* Elementwise y = [relu]( [relu_pre](x) * scale + shift ) [+ residual] on valid rows, 0 elsewhere
  * (the un-fused BatchNorm apply used by the train-mode forward). */
 int sn_masked_affine_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K,

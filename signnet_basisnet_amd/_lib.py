@@ -45,6 +45,7 @@ SIGNATURES = {
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],
     "sn_laplacian_evd_f32": [_p, _l, _p, _l, _l, _i, _p, _p, _p, _l, _p, _i, _i, _p, _p, _p],
+    "sn_bn_train_stats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_linear_wgrad_f32": [_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p],
     "sn_bn_act_bwd_f32": [_p, _i, _p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],
     "sn_relu_bwd_f32": [_p, _p, _l, _i, _p, _i, _p, _p],

@@ -26,13 +26,14 @@ def _c(t):
 def linear_wgrad(x, dy, nvalid, K, want_bias=True):
     d_in, d_out = x.shape[-1], dy.shape[-1]
     R = x.numel() // d_in
-    dW = torch.empty(d_out, d_in, dtype=torch.float32, device=x.device)
-    db = torch.empty(d_out, dtype=torch.float32, device=x.device) if want_bias else None
+    buf = torch.empty(d_out * d_in + d_out, dtype=torch.float32, device=x.device)     # dW | db: one reduction produces both
+    dW = buf[:d_out * d_in].view(d_out, d_in)
+    db = buf[d_out * d_in:]
     scratch = torch.empty(int(lib().sn_linear_wgrad_scratch_floats(R, d_in, d_out)), dtype=torch.float32, device=x.device)
     with ops._span("sn_linear_wgrad_f32"):
         check(lib().sn_linear_wgrad_f32(ptr(x), d_in, ptr(dy), d_out, R, d_in, d_out, ptr(nvalid), int(K), ptr(dW), ptr(db),
                                         ptr(scratch), stream()), "sn_linear_wgrad_f32")
-    return dW, db
+    return dW, (db if want_bias else None)
 
 
 def relu_bwd(y, dy, nvalid, K):
@@ -86,12 +87,7 @@ class _BnAct(Function):
     @staticmethod
     def forward(ctx, z, gamma, beta, residual, bn, nvalid, K, relu):
         z = _c(z)
-        mean, var, count = ops.masked_colstats(z, nvalid, K)
-        g = None if gamma is None else gamma.detach()
-        b = None if beta is None else beta.detach()
-        scale, shift = ops.bn_fold_stats(g, b, mean, var, bn.eps)
-        rstd, _ = ops.bn_fold_stats(None, None, mean, var, bn.eps)
-        ops.bn_running_update(bn, mean, var, count)
+        mean, _, rstd, scale, shift, count = ops.bn_train_stats(z, bn, nvalid, K)      # gamma / beta are bn.weight / bn.bias
         res = None if residual is None else _c(residual)
         y = ops.masked_affine(z, nvalid, K, scale=scale, shift=shift, relu=relu, residual=res)
         ctx.save_for_backward(z, mean, rstd, scale, shift, count)

@@ -28,8 +28,8 @@ __device__ __forceinline__ float wsum(float v) {
 constexpr int WG_OC = 64, WG_IC = 128, WG_LDO = WG_OC + 16, WG_LDI = WG_IC + 16;
 __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int ldy,
                                                int64_t R, int d_in, int d_out, const int32_t* __restrict__ nvalid, int K,
-                                               int64_t rows_per_block, float* __restrict__ part, float* __restrict__ part_b,
-                                               int vec) {
+                                               int64_t rows_per_block, float* __restrict__ part /* [chunk][pstride] */,
+                                               int64_t pstride, int want_b /* bias partial at part[chunk][d_out*d_in ..] */, int vec) {
   __shared__ __attribute__((aligned(16))) float xs[16 * WG_LDI];
   __shared__ __attribute__((aligned(16))) float ds[16 * WG_LDO];
   __shared__ int okrow[16];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int 
       for (int tt = 0; tt < 8; ++tt) acc[tt] = mfma16(a, xs[row * WG_LDI + 16 * tt + (lane & 15)], acc[tt]);
     }
   }
-  float* p = part + (int64_t)blockIdx.x * d_out * d_in;
+  float* p = part + (int64_t)blockIdx.x * pstride;
 #pragma unroll
   for (int tt = 0; tt < 8; ++tt) {
     const int ic = ic0 + 16 * tt + (lane & 15);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ x, int 
       if (oc < d_out && ic < d_in) p[(int64_t)oc * d_in + ic] = acc[tt][r];
     }
   }
-  if (part_b && blockIdx.z == 0 && t < WG_OC && oc0 + t < d_out) part_b[(int64_t)blockIdx.x * d_out + oc0 + t] = bsum;
+  if (want_b && blockIdx.z == 0 && t < WG_OC && oc0 + t < d_out) p[(int64_t)d_out * d_in + oc0 + t] = bsum;
 }
 // out[i] = sum_b part[b][i]   (blockIdx.y splits the partials; four independent accumulators keep loads in flight)
 __global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ part, int nblk, int64_t n, float* __restrict__ out) {
@@ -110,6 +110,15 @@ __global__ __launch_bounds__(256) void k_sum_parts(const float* __restrict__ par
   }
   for (; b < b1; ++b) s0 += part[(int64_t)b * n + i];
   out[(int64_t)blockIdx.y * n + i] = (s0 + s1) + (s2 + s3);
+}
+// out[i] = sum_b part[b*stride + i]  (single stage; the fallback when dW / db are not one buffer)
+__global__ __launch_bounds__(256) void k_sum_strided(const float* __restrict__ part, int nblk, int64_t stride, int64_t n,
+                                                     float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * stride + i];
+  out[i] = s;
 }
 // deterministic two-stage reduction of nblk partial vectors of n floats; tmp: float[16 * n] when nblk > 32
 static inline void sum_parts(const float* part, int nblk, int64_t n, float* out, float* tmp, hipStream_t st) {
@@ -419,19 +428,25 @@ extern "C" int sn_linear_wgrad_f32(const float* x, int ldx, const float* dy, int
   hipStream_t st = (hipStream_t)stream;
   const int64_t rpb = wgrad_rows_per_block(R);
   const int nblk = (int)cdiv(R > 0 ? R : 1, rpb);
+  // one partial row per chunk: [d_out*d_in weight sums | d_out bias sums]; when db directly follows dW in memory (the Python
+  // wrapper allocates them as one buffer) a single two-stage reduction produces both
+  const int64_t n = (int64_t)d_in * d_out, pstride = n + d_out;
   float* part = scratch;
-  float* part_b = scratch + (int64_t)nblk * d_in * d_out;
+  float* tmp = scratch + (int64_t)nblk * pstride;
   dim3 grid((unsigned)nblk, (unsigned)cdiv(d_out, WG_OC), (unsigned)cdiv(d_in, WG_IC));
   const int vec = (d_in % 4 == 0 && d_out % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 &&
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) ? 1 : 0;
   SN_REQUIRE(R < (1ll << 31), "sn_linear_wgrad_f32: too many rows");
-  hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, st, x, ldx, dy, ldy, R, d_in, d_out, nvalid, K, rpb, part, db ? part_b : nullptr,
-                     vec);
+  hipLaunchKernelGGL(k_wgrad, grid, dim3(256), 0, st, x, ldx, dy, ldy, R, d_in, d_out, nvalid, K, rpb, part, pstride, db ? 1 : 0, vec);
   SN_CHECK_LAUNCH("k_wgrad");
-  const int64_t n = (int64_t)d_in * d_out;
-  float* tmp = part_b + (int64_t)nblk * d_out;
-  sum_parts(part, nblk, n, dW, tmp, st);
-  if (db) sum_parts(part_b, nblk, (int64_t)d_out, db, tmp + 16 * n, st);
+  if (db == dW + n) {
+    sum_parts(part, nblk, pstride, dW, tmp, st);
+  } else {
+    // strided partials -> two reductions (k_sum_parts takes a dense [nblk][n] block: reduce the weight part through tmp rows)
+    hipLaunchKernelGGL(k_sum_strided, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, (const float*)part, nblk, pstride, n, dW);
+    if (db) hipLaunchKernelGGL(k_sum_strided, dim3((unsigned)cdiv(d_out, 256)), dim3(256), 0, st, (const float*)(part + n), nblk, pstride,
+                               (int64_t)d_out, db);
+  }
   SN_CHECK_LAUNCH("k_sum_parts");
   return SN_OK;
 }

@@ -405,6 +405,33 @@ __global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict_
   }
 }
 
+// Second-pass finish of a train-mode BatchNorm in ONE launch: variance from the partial sums of (x-mean)^2, then
+// rstd, the folded (scale, shift) and the running-statistics update (what k_colstats_final + two k_bn_fold + k_bn_running_update did).
+__global__ __launch_bounds__(256) void k_bn_train_finish(const float* __restrict__ part, int nblk, int C, const float* __restrict__ count,
+                                                         const float* __restrict__ mean, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, float momentum,
+                                                         float* __restrict__ var, float* __restrict__ rstd,
+                                                         float* __restrict__ scale, float* __restrict__ shift,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float n = count[0];
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(int64_t)b * C + c];
+  const float v = n > 0.f ? s / n : 0.f;
+  const float rs = 1.0f / sqrtf(v + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * rs;
+  var[c] = v;
+  rstd[c] = rs;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - mean[c] * sc;
+  if (rmean) {
+    const float unb = n > 1.f ? v * (n / (n - 1.f)) : v;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
 // ============================================================================ masked affine (un-fused BN apply)
 __global__ __launch_bounds__(256) void k_affine(const float* __restrict__ x, int ldx, int64_t R, int C,
                                                 const int32_t* __restrict__ nvalid, int K, int flags,
@@ -775,6 +802,40 @@ extern "C" int sn_masked_colstats_f32(const float* x, int ldx, int64_t R, int C,
                               (float*)nullptr);
   hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, two ? part2 : part, cnt, two ? CS_SPLIT : nblk, C, var, count, 1);
   SN_CHECK_LAUNCH("sn_masked_colstats_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                     float* mean, float* var, float* rstd, float* scale, float* shift, float* count,
+                                     float* scratch, void* stream) {
+  SN_REQUIRE(x && mean && var && rstd && scale && shift && count && scratch && C > 0 && R >= 0 && ldx >= C,
+             "sn_bn_train_stats_f32: bad arguments");
+  SN_REQUIRE(!nvalid || K > 0, "sn_bn_train_stats_f32: nvalid needs K > 0");
+  SN_REQUIRE((running_mean != nullptr) == (running_var != nullptr), "sn_bn_train_stats_f32: running_mean / running_var go together");
+  SN_REQUIRE(R < (1ll << 31), "sn_bn_train_stats_f32: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  const int ntot = sn_colstats_blocks(R), nblk = ntot - CS_SPLIT;
+  int64_t rpb = cdiv(R > 0 ? R : 1, nblk);
+  float* part = scratch;
+  float* part2 = scratch + (int64_t)nblk * C;
+  float* cnt = scratch + (int64_t)ntot * C;
+  float* cnt2 = cnt + nblk;
+  const bool two = nblk > 2 * CS_SPLIT;
+  const dim3 rgrid((unsigned)cdiv(C + 1, 256), CS_SPLIT);
+  hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)nullptr, 0,
+                     rpb, part, cnt);
+  if (two) hipLaunchKernelGGL(k_colstats_reduce, rgrid, dim3(256), 0, st, (const float*)part, (const float*)cnt, nblk, C, part2, cnt2);
+  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, two ? part2 : part, two ? cnt2 : cnt, two ? CS_SPLIT : nblk, C,
+                     mean, count, 0);
+  hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)mean, 1,
+                     rpb, part, (float*)nullptr);
+  if (two) hipLaunchKernelGGL(k_colstats_reduce, rgrid, dim3(256), 0, st, (const float*)part, (const float*)nullptr, nblk, C, part2,
+                              (float*)nullptr);
+  hipLaunchKernelGGL(k_bn_train_finish, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const float*)(two ? part2 : part),
+                     two ? CS_SPLIT : nblk, C, (const float*)count, (const float*)mean, gamma, beta, eps, momentum, var, rstd, scale,
+                     shift, running_mean, running_var);
+  SN_CHECK_LAUNCH("sn_bn_train_stats_f32");
   return SN_OK;
 }
 

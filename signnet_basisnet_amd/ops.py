@@ -368,6 +368,32 @@ def masked_colstats(x, nvalid=None, K=0):
     return mean, var, count
 
 
+def bn_train_stats(x, bn, nvalid=None, K=0):
+    """Batch statistics of a train-mode BatchNorm1d over the valid rows of x, the folded (scale, shift), rstd, and the
+    running-statistics side effect on `bn` — one C call (sn_bn_train_stats_f32).  -> (mean, var, rstd, scale, shift, count)."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    nb = int(lib().sn_colstats_blocks(R))
+    out = torch.empty(5 * Cc + 1, dtype=torch.float32, device=x.device)
+    mean, var, rstd, scale, shift = (out[i * Cc:(i + 1) * Cc] for i in range(5))
+    count = out[5 * Cc:]
+    scratch = torch.empty(nb * Cc + nb, dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not supported")
+    g = None if bn.weight is None else bn.weight.detach()
+    b = None if bn.bias is None else bn.bias.detach()
+    check(lib().sn_bn_train_stats_f32(ptr(x), Cc, R, Cc, ptr(nvalid), int(K), ptr(g), ptr(b), float(bn.eps),
+                                      float(bn.momentum or 0.0), ptr(bn.running_mean) if track else None,
+                                      ptr(bn.running_var) if track else None, ptr(mean), ptr(var), ptr(rstd), ptr(scale), ptr(shift),
+                                      ptr(count), ptr(scratch), stream()), "sn_bn_train_stats_f32")
+    if track:
+        bn.num_batches_tracked += 1
+    return mean, var, rstd, scale, shift, count
+
+
 def masked_affine(x, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False, residual=None):
     require_cuda(x)
     x = _f32c(x, "x")
