@@ -127,7 +127,8 @@ class stream_scope:
     def __enter__(self):
         global _stream_handle
         self.prev = _stream_handle
-        _stream_handle = torch.cuda.current_stream().cuda_stream
+        # (no GPU: leave it unset — the first op's require_cuda raises the proper 'GPU only' error)
+        _stream_handle = torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else None
         return self
 
     def __exit__(self, *a):
