@@ -330,3 +330,18 @@ def test_batches_beyond_the_plan_limit_are_served_in_graph_ranges():
     model.check_last()
     assert y.shape == (205 * reps, 1)
     close(y, y0.repeat(reps, 1), "chunked large batch")
+
+
+def test_stream_pipeline_returns_the_same_outputs_in_order():
+    """serving.StreamPipeline: independent batches round-robin on three streams give the outputs of sequential forwards."""
+    from signnet_basisnet_amd import pyg, serving, synth
+    torch.manual_seed(0)
+    model = pyg.SignNetGNN(None, None, 64, 1, 3, 3, variant="gine", max_k=16).cuda().eval()
+    batches = [synth.batch_to(synth.make_batch(40 + 7 * i, seed=60 + i), "cuda:0") for i in range(7)]
+    with torch.no_grad():
+        ref = [model(b).clone() for b in batches]
+    model.check_last()
+    outs = serving.StreamPipeline(model, streams=3).map(batches)
+    assert len(outs) == len(ref)
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
