@@ -391,6 +391,44 @@ def dgl_bench(args, dev):
     print(json.dumps(out))
 
 
+def scatter_bench(args, dev):
+    """`--workload scatter` (extra measurement): the standalone GIN / GINE aggregation entry points of the layer-at-a-time path —
+    the reference's "eigvec scatter" (PyG GINConv over the [N, K*d] slot tensor, masked_layers.py:75; GINEConv, pyg_gnn_wrapper.py:28)
+    — against the HBM roofline.  (In eval the fused phi / GINE stages do this aggregation inside LDS and never touch HBM for it.)"""
+    from signnet_basisnet_amd import ops, synth
+    res = {}
+    for B in (128, 2048):
+        base = synth.make_batch(min(B, 1024), seed=5)
+        reps = max(1, B // 1024)
+        ei = torch.cat([base.edge_index + r * base.num_nodes for r in range(reps)], 1).to(dev)
+        batch = torch.cat([base.batch + r * base.num_graphs for r in range(reps)]).to(dev)
+        plan = ops.build_plan(batch, ei, base.num_graphs * reps, 16)
+        N, E = plan.N, plan.E
+        eps = torch.zeros(1, device=dev)
+        x1, x2, ea = torch.randn(N, 16 * 128, device=dev), torch.randn(N, 128, device=dev), torch.randn(E, 128, device=dev)
+        for name, f, byt in (("sn_gin_aggregate_f32 [N, K*d = 2048]", lambda: ops.gin_aggregate(x1, plan, eps), 8 * 2048 * N + 4 * (E + N + 1)),
+                             ("sn_gine_aggregate_f32 [N, d = 128]", lambda: ops.gine_aggregate(x2, ea, plan, eps), 4 * 128 * (2 * N + E))):
+            for _ in range(args.warmup):
+                f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.steps
+            res[f"{name}, {B} graphs"] = {"nodes": N, "edges": E, "mean_launch_us": 1e3 * ms, "algorithmic_bytes": byt,
+                                          "achieved": byt / ms / 1e6, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+    best = res["sn_gin_aggregate_f32 [N, K*d = 2048], 2048 graphs"]
+    print(json.dumps({"metric": "HBM roofline fraction of the standalone GIN / GINE aggregation (extra measurement)", "value": best["frac"],
+                      "unit": "fraction of 8 TB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                      "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                      "roofline": {"kernel": "sn_gin_aggregate_f32 (k_gin_gather), 2048 graphs", "bound": "hbm", "achieved": best["achieved"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"], "traffic": None,
+                                   "note": "algorithmic bytes 8*F*N + 4*(E+N+1): every feature row read once and written once, int32 CSR"},
+                      "kernels": res}))
+
+
 def recorded_traffic(kernel):
     """HBM bytes per launch from the committed PMC pass of this same command (profiles/hbm_traffic.json; FETCH_SIZE and
     WRITE_SIZE need their own rocprofv3 passes, so they cannot be collected in the timed run).  None for another workload."""
@@ -415,7 +453,7 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 4],
                     help="BASELINE.json configs index: 1 = the headline (default); 0 / 2 / 4 = extra measurements of the other "
                          "single-GPU configs (4 = BasisNet on the 2-D grid)")
-    ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train", "dgl"],
+    ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train", "dgl", "scatter"],
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
@@ -447,9 +485,9 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
-    if args.workload in ("evd", "dgl"):
+    if args.workload in ("evd", "dgl", "scatter"):
         if rank == 0:
-            (evd_bench if args.workload == "evd" else dgl_bench)(args, dev)
+            {"evd": evd_bench, "dgl": dgl_bench, "scatter": scatter_bench}[args.workload](args, dev)
         if dist is not None:
             dist.destroy_process_group()
         return
