@@ -147,8 +147,16 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
       x[kb].l = *reinterpret_cast<const u32x4*>(p + kb * 64 + 2 * SP_PLANE);
     }
   };
+#ifdef SN_PROFILE
+  long long ct = clock64();
+#endif
   Split8 in[NKB];
   load_rows(rt0, in);
+#ifdef SN_PROFILE
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  SN_ACCUM(42, ct);
+  ct = clock64();
+#endif
   // prefetch: second output tile of this Linear, else the next Linear's first tile
   bool next_in_alt = false;
   if (two_ots) wload<NKB>(alt, wsp, otl, lane);
@@ -164,9 +172,28 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
         cur_is_pre = false;                                   // switch to the second tile (in alt); pre is free again:
         if (next_wsp && !next_tr.empty()) wload<NKB>(pre, next_wsp, next_tr.first_ot(), lane);   // next Linear's first tile
       }
+#ifdef SN_PROFILE
+      ct = clock64();
+#endif
       if (i > 0) load_rows(rt, in);
+#ifdef SN_PROFILE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      SN_ACCUM(42, ct);
+      ct = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // weights of this tile
+      SN_ACCUM(41, ct);
+      ct = clock64();
+      f32x4 accp = cur_is_pre ? mfma_split_tile<NKB>(pre, in) : mfma_split_tile<NKB>(alt, in);
+      asm volatile("" :: "v"(accp));
+      SN_ACCUM(43, ct);
+      ct = clock64();
+      if (cur_is_pre) epi(rt, ot, accp, pre.e[0], pre.e[1], pre.e[2]);
+      else epi(rt, ot, accp, alt.e[0], alt.e[1], alt.e[2]);
+      SN_ACCUM(44, ct);
+#else
       if (cur_is_pre) epi(rt, ot, mfma_split_tile<NKB>(pre, in), pre.e[0], pre.e[1], pre.e[2]);
       else epi(rt, ot, mfma_split_tile<NKB>(alt, in), alt.e[0], alt.e[1], alt.e[2]);
+#endif
     }
   }
   if (next_in_alt) {   // single-tile range: the next Linear's first tile sits in alt — hand it over in pre
