@@ -227,6 +227,19 @@ class _DeepSignsBase(nn.Module):
             y = run_mlp(self.rho, z.view(N, -1))
         return y.view(N, K, 1)
 
+    def _phi_eval_merged(self, P, plan, x, N, K):
+        """Eval: enc(g, x) and enc(g, -x) in ONE pass — the two signs ride in the feature axis ([N, 2, K, C]), so a layer is one
+        aggregation launch and two Linears instead of two and four (folded BatchNorm is row-wise, the signs never mix until the
+        final sum).  Returns phi(x) + phi(-x) as [N*K, c]."""
+        if "neg1" not in P:
+            P["neg1"] = (torch.full((1,), -1.0, device=x.device), torch.zeros(1, device=x.device))
+        xm = ops.masked_affine(x.view(N * K, 1), scale=P["neg1"][0], shift=P["neg1"][1]).view(N, K, 1)      # -x
+        h = torch.stack([x, xm], dim=1).contiguous()                                                        # [N, 2, K, 1]
+        for Lp in P["gin"]:
+            a = ops.gin_aggregate(h.reshape(N, -1), plan, Lp["eps"])
+            h = _run_mlp(Lp["mlp"], a.view(N * 2 * K, -1), tail_bn=Lp["next_bn"])
+        return ops.slot_sum(h.view(N * 2, -1), N, 2).view(N * K, -1)                                         # sum over the sign axis
+
     def forward(self, g, x):
         train = self.training     # train: batch statistics + running-statistics update (dropout 0)
         ops.require_cuda(x)
@@ -242,14 +255,17 @@ class _DeepSignsBase(nn.Module):
             P = self._prep
         N, K = x.shape[0], self.k
         plan = self._plan(g, N)
-        zp, zm = self._phi(P, plan, x.contiguous().float(), N, K, train)
-        if self.masked:
-            # x[~mask] = 0 ; sum over K ; rho(c -> hidden -> K)             (deepsigns.py:76-84)
-            z = ops.masked_affine(zp, plan.nvalid, K, residual=zm)
-            s = ops.slot_sum(z, N, K)
-            y = _run_mlp(P["rho"], s, train=train)
+        if not train:
+            z = self._phi_eval_merged(P, plan, x.contiguous().float(), N, K)
+            if self.masked:
+                z = ops.masked_affine(z, plan.nvalid, K)                     # x[~mask] = 0       (deepsigns.py:76-80)
         else:
-            z = ops.masked_affine(zp, residual=zm)
+            zp, zm = self._phi(P, plan, x.contiguous().float(), N, K, train)
+            z = ops.masked_affine(zp, plan.nvalid, K, residual=zm) if self.masked else ops.masked_affine(zp, residual=zm)
+        if self.masked:
+            # sum over K ; rho(c -> hidden -> K)                              (deepsigns.py:81-84)
+            y = _run_mlp(P["rho"], ops.slot_sum(z, N, K), train=train)
+        else:
             y = _run_mlp(P["rho"], z.view(N, -1), train=train)                 # deepsigns.py:47-49
         return y.view(N, K, 1)
 
