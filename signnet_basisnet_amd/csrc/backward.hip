@@ -516,7 +516,11 @@ extern "C" int sn_set_attention_bwd_f32(const float* q, const float* k, const fl
              "sn_set_attention_bwd_f32: bad arguments");
   if (N == 0) return SN_OK;
   const size_t lds = ((size_t)4 * K * dk + (size_t)2 * K * (K + 1)) * sizeof(float);
-  SN_REQUIRE(lds <= 64 * 1024, "sn_set_attention_bwd_f32: K*dk too large for LDS (%zu bytes)", lds);
+  SN_REQUIRE(lds <= 160 * 1024, "sn_set_attention_bwd_f32: K=%d dk=%d needs %zu B of LDS (> 160 KiB)", K, dk, lds);
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_set_attention_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+          hipSuccess)
+    return fail(SN_ERR_LAUNCH, "sn_set_attention_bwd_f32: cannot raise the dynamic LDS limit");
   hipLaunchKernelGGL(k_set_attention_bwd, dim3((unsigned)(N * heads)), dim3(64), lds, (hipStream_t)stream, q, k, v, dout, K,
                      heads, dk, nvalid, prob_mask, dq, dk_out, dv);
   SN_CHECK_LAUNCH("sn_set_attention_bwd_f32");

@@ -206,6 +206,20 @@ def test_attention_layernorm_slotsum_backward():
     xm = x * mask.float()
     run_pair(lambda x: AG.slot_sum(x, N, K, nvd), lambda x: (x * mask).view(N, K, D).sum(1), [xm], "slot_sum")
     run_pair(lambda a, b: AG.masked_add(a, b, nvd, K), lambda a, b: (a + b) * mask, [xm, r * mask.float()], "masked_add")
+    # the largest slot count of the fused-path envelope (64 slots, head width 32): > 64 KiB of LDS in the backward
+    N2, K2 = 3, 64
+    g2 = torch.Generator().manual_seed(11)
+    nv2 = torch.tensor([64, 40, 1], dtype=torch.int32)
+    mask2 = (torch.arange(K2)[None, :] < nv2[:, None]).reshape(N2 * K2, 1).double()
+    q2, k2, v2 = (torch.randn(N2 * K2, 128, generator=g2) * mask2.float() for _ in range(3))
+
+    def att_ref2(q, k, v):
+        qh, kh, vh = (t.view(N2, K2, 4, 32).permute(0, 2, 1, 3) for t in (q, k, v))
+        s = qh @ kh.transpose(-1, -2) / 32 ** 0.5
+        valid = torch.arange(K2)[None, :] < nv2[:, None]
+        s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+        return (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(N2 * K2, 128) * mask2
+    run_pair(lambda q, k, v: AG.set_attention(q, k, v, N2, K2, 4, nv2.to(DEV)), att_ref2, [q2, k2, v2], "set_attention K=64", 5e-5)
 
 
 def test_embedding_and_pool_backward():
