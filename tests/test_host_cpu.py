@@ -101,3 +101,33 @@ def test_evd_transform_wire_format():
     V = d.eigen_vectors.view(11, 11)
     L = V @ torch.diag(d.eigen_values) @ V.T
     assert abs(float(L.diagonal().mean()) - 1.0) < 1e-4             # sym-normalised Laplacian has unit diagonal
+
+
+def test_widening_modules_import_without_a_gpu_and_keep_the_reference_surface():
+    """The f-row modules (training, eigendecomposition, DGL base nets, serving) import on a CPU-only box; constructors mirror the
+    reference's (net_params dictionaries / positional arguments) and the state_dict key sets match the fixtures'."""
+    import torch
+    import golden_util as G
+    from signnet_basisnet_amd import autograd, dgl_nets, optim, serving, transform  # noqa: F401
+    for name, cls, kind, agg in (("dgl_ginnet_k6", dgl_nets.GINNet, "gin", "add"),
+                                 ("dgl_gatedgcn_concat_k6", dgl_nets.GatedGCNNet, "masked_gin", "concat")):
+        fx = G.load(name)
+        hidden, L, k = (int(v) for v in fx.meta["params"])
+        net = cls(dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                       readout="mean", batch_norm=True, residual=True, edge_feat=True, device="cpu", pe_init="lap_pe",
+                       lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k,
+                       sign_inv_net=kind, sign_inv_layers=3, sign_inv_activation="relu", pe_aggregate=agg, phi_out_dim=4))
+        assert sorted(net.state_dict().keys()) == sorted(fx.sd.keys())
+        net.load_state_dict(fx.sd)
+    with pytest.raises(NotImplementedError):
+        dgl_nets.GINNet(dict(num_atom_type=28, num_bond_type=4, hidden_dim=8, out_dim=8, in_feat_dropout=0.0, dropout=0.0, L=2,
+                             readout="mean", batch_norm=True, residual=True, edge_feat=True, device="cpu", pe_init="rand_walk",
+                             lap_method="sign_inv", lap_lspe=True, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=4,
+                             sign_inv_net="gin", sign_inv_layers=2, sign_inv_activation="relu", pe_aggregate="add", phi_out_dim=4))
+    t = transform.EVDTransform("sym")          # the per-sample host transform keeps the reference's call contract
+    import types
+    d = t(types.SimpleNamespace(edge_index=torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]]), num_nodes=3, x=torch.zeros(3, 1)))
+    assert d.eigen_values.shape == (3,) and d.eigen_vectors.shape == (9,)
+    with pytest.raises(RuntimeError, match="GPU only|No HIP|cuda"):
+        transform.BatchEVDTransform("sym")(types.SimpleNamespace(edge_index=torch.tensor([[0, 1], [1, 0]]), batch=torch.zeros(2, dtype=torch.long),
+                                                                 num_graphs=1, sizes=[2]))
