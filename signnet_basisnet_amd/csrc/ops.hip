@@ -1000,9 +1000,17 @@ __global__ __launch_bounds__(256) void k_ign_rowcol_v4(const float* __restrict__
         if (r < r1) {
           const int dc = r - c0;                       // the diagonal element of this row, if it lies in the panel
           if (dc >= 0 && dc < 1024 && ((dc & 255) >> 2) == lane) {
-            const float4 q = v[u][dc >> 8];
-            const int e = dc & 3;
-            diag[(int64_t)b * n + r] = e == 0 ? q.x : (e == 1 ? q.y : (e == 2 ? q.z : q.w));
+            // (static indices only: `v[u][dc >> 8]` made the compiler keep all of v[][] in scratch memory — every loaded
+            //  element was written to and read back from private memory, WRITE_SIZE = FETCH_SIZE in the counters)
+            float dv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if ((dc >> 8) == j) {
+                const int e = dc & 3;
+                dv = e == 0 ? v[u][j].x : (e == 1 ? v[u][j].y : (e == 2 ? v[u][j].z : v[u][j].w));
+              }
+            }
+            diag[(int64_t)b * n + r] = dv;
           }
           if (lane == 0) {
             if (c0 == 0) rowsum[(int64_t)b * n + r] = rs; else rowsum[(int64_t)b * n + r] += rs;
