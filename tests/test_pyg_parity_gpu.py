@@ -3,17 +3,10 @@ import pytest
 import torch
 
 import golden_util as G
+import parity_util as PU
+from parity_util import close      # max|hip - ref| <= 1e-5 * max|ref| (north_star), float64 attribution when `ref64` is given
 
 pytestmark = pytest.mark.gpu
-
-REL = 1e-5     # north_star: outputs within 1e-5 relative fp32 of the CPU path
-
-
-def close(a, b, what):
-    a, b = a.detach().cpu().double(), b.detach().cpu().double()
-    scale = max(1.0, b.abs().max().item())
-    err = (a - b).abs().max().item()
-    assert err <= REL * scale * 4, f"{what}: max|diff| {err:.3e} vs scale {scale:.3e}"
 
 
 def build(fx, max_k=None):
@@ -33,21 +26,26 @@ def build(fx, max_k=None):
 @pytest.mark.parametrize("name", G.PYG_CASES)
 def test_golden(name):
     from signnet_basisnet_amd import synth
+    from oracle import pyg_signnet as O
     fx = G.load(name)
     model = build(fx)
     data = synth.batch_to(G.as_data(fx.inp), "cuda:0")
     y, st = model(data, return_stages=True)
-    close(st["phi_plus"], fx.out["eval/phi_plus"], "phi(+x)")
-    close(st["phi_minus"], fx.out["eval/phi_minus"], "phi(-x)")
-    close(st["pos"], fx.out["eval/pos"], "sign_net output")
-    close(y, fx.out["eval/y"], "model output")
+    # the exact (float64) value of every stage, for attribution where two fp32 evaluations differ by ~1e-5 (parity_util.close)
+    o64 = {}
+    with torch.no_grad():
+        y64 = O.signnet_gnn(PU.to_f64(fx.sd), G.pyg_cfg(fx), PU.data_f64(G.as_data(fx.inp)), training=False, out=o64)
+    close(st["phi_plus"], fx.out["eval/phi_plus"], "phi(+x)", ref64=o64["phi_plus_layers"][-1])
+    close(st["phi_minus"], fx.out["eval/phi_minus"], "phi(-x)", ref64=o64["phi_minus_layers"][-1])
+    close(st["pos"], fx.out["eval/pos"], "sign_net output", ref64=o64["pos"])
+    close(y, fx.out["eval/y"], "model output", ref64=y64)
     # fused phi kernel: same quantity as the layer path and as the reference
     assert st["bins_meta"].cpu().tolist()[1] == 0 and st["bins_meta"].cpu().tolist()[5] == 0
-    close(st["phi_fused"], fx.out["eval/phi_plus"] + fx.out["eval/phi_minus"], "fused phi(x)+phi(-x)")
-    close(st["y_gnn_fused"], fx.out["eval/y"], "fused gnn output (from the layer-path slot sum)")
-    close(st["rho_sum_fused"], st["rho_sum"], "fused rho slot-sum vs layer path")
+    close(st["phi_fused"], fx.out["eval/phi_plus"] + fx.out["eval/phi_minus"], "fused phi(x)+phi(-x)", ref64=o64["phi"])
+    close(st["y_gnn_fused"], fx.out["eval/y"], "fused gnn output (from the layer-path slot sum)", ref64=y64)
+    close(st["rho_sum_fused"], st["rho_sum"], "fused rho slot-sum vs layer path", ref64=o64["rho_sum"])
     # and the default forward (fused stages) gives the reference output
-    close(model(data), fx.out["eval/y"], "model output (fused path)")
+    close(model(data), fx.out["eval/y"], "model output (fused path)", ref64=y64)
 
 
 def test_plan_bins():
