@@ -100,6 +100,23 @@ __device__ __forceinline__ Split8 split8(f32x4 a, f32x4 b) {
   }
   return s;
 }
+// half of split8: the four values `a` become k-slots 4*half .. 4*half+3 of the operand block `s` (same arithmetic as split8)
+__device__ __forceinline__ void split4(f32x4 a, Split8& s, int half) {
+  float h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = __uint_as_float(__float_as_uint(a[i]) & 0xffff0000u);
+    const float r = a[i] - h[i];                       // exact
+    m[i] = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    l[i] = r - m[i];                                   // exact
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    s.h[2 * half + i] = pack_hi16(h[2 * i], h[2 * i + 1]);
+    s.m[2 * half + i] = pack_hi16(m[2 * i], m[2 * i + 1]);
+    s.l[2 * half + i] = pack_hi16(l[2 * i], l[2 * i + 1]);
+  }
+}
 template <int NT>
 __device__ __forceinline__ void split_rows(const f32x4 (&in)[NT], Split8 (&xs)[(NT + 1) / 2]) {
 #pragma unroll
@@ -118,14 +135,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int NT>
+template <int NT, int NW = 4>     // NW: waves of the workgroup (all of them share the DMA of every chunk)
 struct WRing {
   static constexpr int NKB = (NT + 1) / 2;
   static constexpr int NF = 3 * NKB;                 // weight fragments per chunk
   static constexpr int NFE = NF + SPLIT_EPI;         // + epilogue fragments
   static constexpr int CHUNK = NFE * 1024;           // bytes
   static constexpr int BYTES = SPLIT_RING * CHUNK;
-  static constexpr int LPC = (NFE + 3) / 4;          // DMA instructions every wave issues per chunk
+  static constexpr int LPC = (NFE + NW - 1) / NW;    // DMA instructions every wave issues per chunk
   lds_char_t* base;   // LDS
   int pos;            // ring slot of chunk 0 of the current GEMM (wave-uniform)
   int wave, lane;
@@ -148,8 +165,8 @@ struct WRing {
     const int src = c * CHUNK + wo;
 #pragma unroll
     for (int f = 0; f < LPC; ++f) {
-      int fo = 4096 * f;
-      if (4 * f + 3 >= NFE) {            // branch-free tail: the surplus waves re-stage the last fragment
+      int fo = NW * 1024 * f;
+      if (NW * f + NW - 1 >= NFE) {      // branch-free tail: the surplus waves re-stage the last fragment
         const int last = (NFE - 1) * 1024 - wo;
         fo = fo < last ? fo : last;
       }
@@ -179,10 +196,10 @@ struct WFrag { u32x4 h, m, l; };
 // `live` = this wave has rows (a dead wave only keeps the stream going).  `wnext` (never null): the matrix whose
 // first chunks are staged behind this one's — the next wg_gemm_split() of the workgroup must be on `wnext`; the
 // kernel starts the stream with WRing::prologue(first matrix) and ends with WRing::drain().  SWAP: operands exchanged -> acc[r] = Y[row = 4g + r][out = 16*ot + (l&15)].
-template <int NT, int NTO, bool SWAP, bool EPIV = true, typename Pre, typename Epi>
-__device__ __forceinline__ void wg_gemm_split(WRing<NT>& ring, const void* w, const void* wnext, bool live,
+template <int NT, int NTO, bool SWAP, bool EPIV = true, int NW = 4, typename Pre, typename Epi>
+__device__ __forceinline__ void wg_gemm_split(WRing<NT, NW>& ring, const void* w, const void* wnext, bool live,
                                               const Split8 (&xs)[(NT + 1) / 2], Pre pre, Epi epi) {
-  using R = WRing<NT>;
+  using R = WRing<NT, NW>;
   constexpr int NKB = R::NKB;
   constexpr bool CHAIN = NTO >= SPLIT_RING;     // the stream runs on into the next matrix; else: one prologue per GEMM
   if (!CHAIN) ring.prologue(w, NTO);

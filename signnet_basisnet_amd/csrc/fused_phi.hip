@@ -5,27 +5,32 @@
 // an affine, every op of every phi layer is local to one (graph, slot, sign) slab of n_graph <= 64
 // rows, so the [rows, d] activations never need to touch HBM between layers.
 //
-// Mapping (SN_PHI_BIN_ROWS = 64 rows per workgroup, 4 waves):
+// Mapping (SN_PHI_BIN_ROWS = 64 rows per workgroup, 8 waves = two per SIMD, ONE workgroup per CU):
 //   * graphs are packed into columns (sn_batch_plan: best-fit-decreasing on the node count, <= 64 rows); bin j of a
-//     column holds the slot-j slab of every member graph; wave w owns bin rows [16w, 16w+16) for BOTH signs and a
-//     wave whose tile has no rows skips the GEMMs;
+//     column holds the slot-j slab of every member graph; wave w < 4 owns bin rows [16w, 16w+16) of phi(+x), wave w+4 the
+//     same rows of phi(-x) — the two co-resident waves of a SIMD; a wave whose tile has no rows skips the GEMMs.  Both
+//     signs of a bin are resident together: the weights stream through the LDS ring ONCE per bin for all eight waves, and
+//     phi(x)+phi(-x) is formed at the end of the bin through the LDS image, so `out` is written exactly once
+//     (HBM traffic = the eigenvector scalars in + the [valid rows, d] sum out);
 //   * a row tile lives in registers in the MFMA operand layout of common.hpp
 //     (lane = (row = l&15, g = l>>4) holds channels 16*kk + 4*g + t), so the accumulators of one GEMM
 //     are directly the operand of the next — no LDS round trip between the two Linears of a MaskedMLP;
-//   * the GIN neighbour sum goes through LDS: every wave writes its rows (both signs) to X[sign][row][ch],
+//   * the GIN neighbour sum goes through LDS: every wave writes its rows to X[sign][row][ch],
 //     one barrier, then each lane gathers its CSR neighbours' rows (ds_read_b128) — the reference's
 //     [K,E,d] gather + scatter_add (masked_layers.py:75) becomes LDS traffic; the residual `+ previous_x`
 //     (sign_net.py:42) is re-read from the same LDS image;
-//   * weights are streamed from L2 in pre-packed fragment order (1 KiB coalesced per wave-load), each
-//     fragment feeding 8 MFMAs (4 k-steps x 2 signs).
-// Bound: fp32 MFMA (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s chip peak); algorithmic flops per valid row:
-// 2 signs * (L-1) layers * 2 GEMMs * 2*d*d.
+//   * weights: split-bf16 chunks staged once per workgroup in an LDS ring by LDS-DMA (fused_common.hpp).
+// Why two single-tile waves per SIMD rather than one wave carrying both signs as two MFMA tiles (tried: 166 us against
+// 136 us): a lone wave per SIMD is issue-bound — per 48 MFMAs it also issues ~300 other instructions (operand split,
+// epilogue, fragment reads, AGPR moves at 400 registers) and nothing else can fill the matrix pipe meanwhile.
+// Bound: bf16 MFMA / 6 (exact three-way split of both operands, six partial products, fp32 accumulate); algorithmic
+// flops per valid row: 2 signs * (L-1) layers * 2 GEMMs * 2*d*d.
 #include "fused_common.hpp"
 
 namespace sn {
 
 constexpr int PHI_R = SN_PHI_BIN_ROWS;  // rows per bin / workgroup
-constexpr int PHI_WAVES = PHI_R / 16;
+constexpr int PHI_WAVES = 2 * (PHI_R / 16);   // one wave per (16-row tile, sign)
 
 struct PhiStruct {
   const float* ev;
@@ -49,17 +54,19 @@ constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read f
 // HID1: layer 0 is Linear(1->1).BN.ReLU.Linear(1->d) (GINESignNetPyG) — no [d,d] GEMM in layer 0; else Linear(1->d)...Linear(d->d)
 // (Alchemy).  A template parameter so that the variant without the layer-0 GEMM does not carry its registers.
 template <int NT, bool HID1>
-__global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_params P) {
+__global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn_phi_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;  // +4 floats: conflict-free ds_write_b128 of 8 consecutive rows
   constexpr int NKB = (NT + 1) / 2;
-  using Ring = WRing<NT>;
+  using Ring = WRing<NT, PHI_WAVES>;
   extern __shared__ __align__(1024) unsigned char lds_raw[];
-  float* X = reinterpret_cast<float*>(lds_raw + Ring::BYTES);   // [PHI_R][LD]  x_l of the sign being computed
-  float* xs = X + PHI_R * LD;                                   // [PHI_R] scalar eigenvector entries (layer 0)
+  float* X2 = reinterpret_cast<float*>(lds_raw + Ring::BYTES);  // [2 signs][PHI_R][LD]  x_l
+  float* xs = X2 + 2 * PHI_R * LD;                              // [PHI_R] scalar eigenvector entries (layer 0)
   unsigned char* nbr = reinterpret_cast<unsigned char*>(xs + PHI_R);   // [PHI_R][PHI_NBR] bin rows of the first in-neighbours
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r = wave * 16 + (lane & 15), g = lane >> 4;
+  const int sg = wave >> 2;                                     // 0: phi(+x), 1: phi(-x)   (wave-uniform)
+  float* X = X2 + sg * PHI_R * LD;                              // the image of my sign
+  const int r = (wave & 3) * 16 + (lane & 15), g = lane >> 4;
   const int nbins = S.meta[0];
   if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
   { SN_PROF_ON(true); SN_STAMP(12); }
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
     const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all MFMAs (keeps barriers + DMA)
     const int deg = e_hi - e_lo;
     __syncthreads();   // previous bin is done with xs / nbr / X
-    if (g == 0) {
+    if (g == 0 && sg == 0) {
       xs[r] = xval;
       for (int e = 0; e < deg && e < PHI_NBR; ++e) nbr[r * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
     }
@@ -128,15 +135,14 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
       a0 = a0 + self;
     }
     SN_STAMP(2);
-#pragma unroll 1
-    for (int sg = 0; sg < 2; ++sg) {
+    {
 #ifdef SN_PROFILE
       long long ptop = clock64();
 #endif
       // (compiler fence: without it the layer-0 vectors — loop invariant — are hoisted out of the bin loop into
       //  ~128 VGPRs that then live in scratch for the whole kernel)
       asm volatile("" ::: "memory");
-      const float as = sg ? -a0 : a0;          // phi(-x): the aggregate of -x is exactly -(aggregate of x)
+      const float as = sg ? -a0 : a0;          // phi(-x): the aggregate of -x is exactly -(aggregate of x)   (sg: my wave's sign)
       f32x4 in[NT], o[NT];
       Split8 sp[NKB];
       SN_ACCUM(15, ptop);
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
 #ifdef SN_PROFILE
         pt = clock64();
 #endif
-        const void* nxt = (l + 1 < P.n_layers) ? P.layers[l].w1s : wfirst;   // next sign / next bin restart the stream here
+        const void* nxt = (l + 1 < P.n_layers) ? P.layers[l].w1s : wfirst;   // the next bin restarts the stream here
         // GNN3d: mask . BN . ReLU . + previous_x
         wg_gemm_split<NT, NT, false>(
             ring, Lp.w2s, nxt, wave_live, sp, [&](int ot) { return lds_ld4(XR + 16 * ot + 4 * g); },
@@ -272,26 +278,29 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
 #ifdef SN_PROFILE
       pt = clock64();
 #endif
-      // -------------------------------------------------------------- phi(x) [+ phi(-x)] -> out[node*K + slot, :]
-      // The sign + pass parks its result in `out`; the sign - pass reads it back (all loads first, then the adds and
-      // stores) and overwrites it with the sum — same lane, same addresses, so program order is all that is needed.
+      // -------------------------------------------------------------- phi(x) + phi(-x) -> out[node*K + slot, :], written once
+      // The two waves of a row tile exchange their results through the LDS image (free now: every wave is past the last
+      // layer's gathers — it went through that layer's GEMM barriers); the + wave stores the lower half of the channel tiles
+      // of the sum, the - wave the upper half.
+      if (wave_live) {
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
+      }
+      lds_barrier();
       if (valid) {
         float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
+        const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;     // the same row in the other sign's image
+        constexpr int H = (NT + 1) / 2;
         // (d % 4 == 0 is an entry-point requirement: whole float4 per lane; only the last 16-channel tile can be partial)
-        f32x4 prev[NT];
-        if (sg) {
-#pragma unroll
-          for (int kk = 0; kk < NT; ++kk) {
-            const int c = 16 * kk + 4 * g;
-            prev[kk] = (kk + 1 < NT || c < P.d) ? ld4(orow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-#pragma unroll
-          for (int kk = 0; kk < NT; ++kk) in[kk] = prev[kk] + in[kk];
-        }
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) {
+          const bool mine = sg ? (kk >= H) : (kk < H);
           const int c = 16 * kk + 4 * g;
-          if (kk + 1 < NT || c < P.d) *reinterpret_cast<float4*>(orow + c) = make_float4(in[kk][0], in[kk][1], in[kk][2], in[kk][3]);
+          if (mine && (kk + 1 < NT || c < P.d)) {
+            const f32x4 o4 = lds_ld4(XO + c);
+            const f32x4 v = sg ? o4 + in[kk] : in[kk] + o4;        // phi(x) + phi(-x), in that order on both waves
+            *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
       }
       SN_ACCUM(14, pt);
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(PHI_R * 4, 2) void k_phi_fused(PhiStruct S, sn_phi_
 template <int NT, bool HID1>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)WRing<NT>::BYTES + (size_t)(PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
+  const size_t lds = (size_t)WRing<NT, PHI_WAVES>::BYTES + (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
@@ -316,9 +325,9 @@ static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     cus = n > 0 ? n : 256;
   }
-  int64_t grid = S.max_bins < (int64_t)2 * cus ? S.max_bins : (int64_t)2 * cus;
+  int64_t grid = S.max_bins < (int64_t)cus ? S.max_bins : (int64_t)cus;   // one 8-wave workgroup per CU (113 KB of LDS)
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_phi_fused<NT, HID1>), dim3((unsigned)grid), dim3(PHI_R * 4), lds, st, S, P);
+  hipLaunchKernelGGL((k_phi_fused<NT, HID1>), dim3((unsigned)grid), dim3(PHI_WAVES * 64), lds, st, S, P);
   return SN_OK;
 }
 
