@@ -428,9 +428,11 @@ typedef struct {
   const float* nw;            /* float node encoder: weight [d_pad, F] row-major (NOT packed), zero padded rows */
   const float* n_scale;
   const float* n_shift;
-  const void* rho_out_w;      /* sign_net.rho.out.0, split-packed with (e0, e1) = sign_net.rho.out.1 folded (scale, shift) */
+  const void* rho_out_w;      /* must be NULL: rho.out (Linear + eval BatchNorm, sign_net.py:71) is folded by the caller into lin_b —
+                                 one dependent GEMM stage and one barrier fewer in the per-graph chain (field kept for layout) */
   const void* lin_a;          /* gnn.linear.weight[:, :d], split-packed, no epilogue vectors */
-  const void* lin_b;          /* gnn.linear.weight[:, d:], split-packed with e0 = gnn.linear.bias */
+  const void* lin_b;          /* W_pos . diag(scale) . W_out with e0 = W_pos . shift + gnn.linear.bias, split-packed
+                                 (W_pos = gnn.linear.weight[:, d:], W_out = sign_net.rho.out.0.weight, (scale, shift) = rho.out.1 folded) */
   const void* head_w1;        /* output_encoder.layers.0, split-packed with (e0, e1) = output_encoder.norms.0 folded */
   const void* head_w2;        /* output_encoder.layers.1 [n_out, d], split-packed with e0 = its bias */
   sn_gnn_layer layers[SN_GNN_MAX_LAYERS];

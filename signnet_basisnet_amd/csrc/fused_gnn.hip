@@ -420,19 +420,21 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]) (model.py:39-40), pos = BN(W_out . slot_sum)
   //   (sign_net.py:71).  Order: x part (SB -> X1), pos (SA -> SB, SB being free after a barrier), pos part (SB -> X1 +=).
-  coop_gemm<NKB>(pre, alt, P.lin_a, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) {
-    lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);
-  }, P.rho_out_w, tr);
-  __syncthreads();
-  SN_STAMP(20);
-  coop_gemm<NKB>(pre, alt, P.rho_out_w, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
-    sp_store4(SB, rt * 16 + li, ot, g, acc * sc + sh);
-  }, P.lin_b, tr);
-  __syncthreads();
-  coop_gemm<NKB>(pre, alt, P.lin_b, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
-    float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
-    lds_st4(o, (lds_ld4(o) + acc) + bias);
-  }, P.n_layers > 0 ? P.layers[0].w1s : P.head_w1, P.n_layers > 0 ? tr : hr);
+  const void* first_w = P.n_layers > 0 ? P.layers[0].w1s : P.head_w1;
+  const TileRange first_tr = P.n_layers > 0 ? tr : hr;
+  {
+    // rho.out folded into the pos half of `linear` by the caller (lin_b = W_pos . diag(bn scale) . W_out, bias' = W_pos . bn shift + b):
+    // h = lin_a . x + lin_b . slot_sum + bias' — two GEMMs over two images that are both complete; each lane parks its own
+    // tiles of the first product in X1 and reads them back itself: no barrier between the two
+    coop_gemm<NKB>(pre, alt, P.lin_a, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) {
+      lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);
+    }, P.lin_b, tr);
+    SN_STAMP(20);
+    coop_gemm<NKB>(pre, alt, P.lin_b, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
+      float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
+      lds_st4(o, (lds_ld4(o) + acc) + bias);
+    }, first_w, first_tr);
+  }
   ee_store();
   __syncthreads();
   SN_STAMP(2);
@@ -612,7 +614,8 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
              "sn_gnn_fused_f32: node feature count %d unsupported", P.node_nf);
   SN_REQUIRE(P.n_layers == 0 || (edge_attr && P.edge_nf >= 1 && P.edge_nf <= (P.edge_discrete ? 10 : 16) && lde >= P.edge_nf),
              "sn_gnn_fused_f32: edge feature count %d unsupported", P.edge_nf);
-  SN_REQUIRE(P.rho_out_w && P.lin_a && P.lin_b && P.head_w1 && P.head_w2, "sn_gnn_fused_f32: parameters missing");
+  SN_REQUIRE(P.lin_a && P.lin_b && P.head_w1 && P.head_w2, "sn_gnn_fused_f32: parameters missing");
+  SN_REQUIRE(P.rho_out_w == nullptr, "sn_gnn_fused_f32: rho_out_w must be NULL — fold rho.out into lin_b (see signnet_hip.h)");
   if (P.node_discrete) { for (int f = 0; f < P.node_nf; ++f) SN_REQUIRE(P.ntab[f], "sn_gnn_fused_f32: node table %d missing", f); }
   else SN_REQUIRE(P.nw && P.n_scale && P.n_shift, "sn_gnn_fused_f32: node MLP parameters missing");
   for (int l = 0; l < P.n_layers; ++l) {

@@ -237,11 +237,20 @@ class GnnPlan:
             P.nw = hold(wp)
             s, h = ops.bn_fold(gnn.input_encoder.norms[0], dp)
             P.n_scale, P.n_shift = hold(s), hold(h)
-        s, h = ops.bn_fold(rho_out[1], dp)
-        P.rho_out_w = hold(ops.pack_split(rho_out[0].weight.detach(), s, h))
+        # rho.out (Linear(no bias) + eval BatchNorm, sign_net.py:71) and the pos half of `linear` (model.py:39-40) are two affine maps
+        # with nothing in between: folded once into  W' = W_pos . diag(scale) . W_out,  b' = W_pos . shift + b  on the device
+        # (fp32 MFMA GEMM kernels; rounding differs from the two-step evaluation by ~1e-7 relative), which removes one whole
+        # dependent GEMM stage and a barrier from the per-graph latency chain of the kernel
         W = gnn.linear.weight.detach()                                  # [d, 2d]: x part | pos part
+        Wp = W[:, d:].contiguous()
+        s, h = ops.bn_fold(rho_out[1], d)
+        A = ops.masked_affine(Wp, scale=s, shift=torch.zeros_like(s))   # W_pos . diag(scale)
+        Wt = rho_out[0].weight.detach().t().contiguous()                # y = x . Wt^T = x . W_out
+        Wf = ops.masked_linear(A, ops.PackedLinear(ops.pack_weight(Wt), d, d, None))
+        bf = ops.masked_linear(h.view(1, d).contiguous(), ops.PackedLinear(ops.pack_weight(Wp), d, d, gnn.linear.bias.detach().contiguous()))
+        P.rho_out_w = None
         P.lin_a = hold(ops.pack_split(W[:, :d]))
-        P.lin_b = hold(ops.pack_split(W[:, d:], gnn.linear.bias.detach()))
+        P.lin_b = hold(ops.pack_split(Wf, bf.view(-1)))
         oe = gnn.output_encoder
         s, h = ops.bn_fold(oe.norms[0], dp)
         P.head_w1 = hold(ops.pack_split(oe.layers[0].weight.detach(), s, h))
