@@ -415,7 +415,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   }
-  __syncthreads();
+  lds_barrier();   // LDS hazards only: a __syncthreads() would also drain the weight prefetch in flight (vmcnt(0))
   SN_STAMP(1);
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]) (model.py:39-40), pos = BN(W_out . slot_sum)
@@ -436,7 +436,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     }, first_w, first_tr);
   }
   ee_store();
-  __syncthreads();
+  lds_barrier();
   SN_STAMP(2);
   // ---------------------------------------------------------------- GINE layers: h lives in X1           (model.py:47-55)
   for (int l = 0; l < P.n_layers; ++l) {
@@ -456,6 +456,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         if (row >= n) continue;
         f32x4 u = zero4;
         const int e_lo = erow[row], e_hi = erow[row + 1];
+
         int e = e_lo;
         if (use_tab || use_ee) {
           // the first four in-edges (molecular graphs: all) with predicated, unrolled reads: index reads, then the
@@ -471,6 +472,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
           f32x4 hv[4], ev[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) { hv[i] = lds_ld4(X1 + sr[i] * LD + c); ev[i] = lds_ld4(EE + er[i] * LD + c); }
+
 #pragma unroll
           for (int i = 0; i < 4; ++i) u += i < dg ? relu4(hv[i] + ev[i]) : zero4;
           e = e_lo + (dg < 4 ? dg : 4);
@@ -488,7 +490,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         sp_store4(SA, row, ot, g, u);
       }
     }
-    __syncthreads();
+    lds_barrier();
     SN_ACCUM(9, pt);
 #ifdef SN_PROFILE
     pt = clock64();
@@ -498,7 +500,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     coop_gemm<NKB>(pre, alt, Lp.w1s, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
       sp_store4(SB, rt * 16 + li, ot, g, relu4(acc * sc + sh));
     }, Lp.w2s, tr);
-    __syncthreads();
+    lds_barrier();
     SN_ACCUM(11, pt);
 #ifdef SN_PROFILE
     pt = clock64();
@@ -509,8 +511,9 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
       lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
     }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
-    __syncthreads();
+    lds_barrier();
     SN_ACCUM(12, pt);
+    SN_STAMP(24 + l);
   }
   SN_STAMP(3);
   // ---------------------------------------------------------------- add pooling -> row 0 of SA (rows 1..15: zero)   (model.py:57-61)
@@ -521,7 +524,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       for (int j = 0; j < n; ++j) s += lds_ld4(X1 + j * LD + 4 * c4);
     sp_store4(SA, rr, c4 >> 2, c4 & 3, s);
   }
-  __syncthreads();
+  lds_barrier();
   SN_STAMP(4);
   // ---------------------------------------------------------------- output encoder on the pooled row     (model.py:63)
   TileRange h2;
@@ -531,7 +534,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   coop_gemm<NKB>(pre, alt, P.head_w1, SA, hr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
     sp_store4(SB, li, ot, g, relu4(acc * sc + sh));
   }, wave == 0 ? P.head_w2 : nullptr, h2);
-  __syncthreads();
+  lds_barrier();
   coop_gemm<NKB>(pre, alt, P.head_w2, SB, h2, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
     if (li == 0) {
 #pragma unroll
