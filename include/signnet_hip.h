@@ -202,9 +202,11 @@ int sn_set_attention_f32(const float* q, const float* k, const float* v, int64_t
 int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* out, void* stream);
 
 /* DiscreteEncoder (elements.py:31-37): out[r,:] = sum_f tables[f][idx[r*ldi + f], :], nf <= 10.
- * `tables` is a HOST array of nf device pointers (each table [V, C] fp32). */
+ * `tables` is a HOST array of nf device pointers (each table [table_rows[f], C] fp32), `table_rows` a HOST array of nf row counts.
+ * An index outside [0, table_rows[f]) — nn.Embedding raises IndexError there — is never dereferenced: it contributes 0 and sets
+ * bit 0 of *status (device int32, may be NULL). */
 int sn_embedding_sum_f32(const int64_t* idx, int ldi, int nf, int64_t R, const float* const* tables,
-                         int C, float* out, void* stream);
+                         const int64_t* table_rows, int C, float* out, int32_t* status, void* stream);
 
 /* Graph pooling (torch_scatter.scatter add/mean, model.py:57-61): out[b,:] over nodes of graph b.
  * mode 0 = add, 1 = mean. */
@@ -263,7 +265,8 @@ int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* gr
  *   (dee, [E,C] in edge-id order) over the REVERSE CSR (rows = source nodes, rev_col = destination, rev_eperm = edge id:
  *   sn_batch_plan on the flipped edge_index).  (GIN's adjoint is sn_gin_aggregate_f32 itself on the reverse CSR.)
  * sn_slot_broadcast_f32 / sn_segment_broadcast_f32: adjoints of sn_slot_sum_f32 (valid slots only) / sn_segment_pool_f32.
- * sn_embedding_sum_bwd_f32: dtables[f][idx[r,f],:] += g[r,:] (fp32 atomics; dtables zeroed by the caller).
+ * sn_embedding_sum_bwd_f32: dtables[f][v,:] += sum_{r: idx[r,f] = v} g[r,:] in row order (no atomics: bitwise reproducible; C <= 512);
+ *   out-of-range indices contribute nothing and set bit 0 of *status (device int32, may be NULL); table_rows as in the forward.
  * sn_dot_f32: out[0] = sum a[i] b[i] (the GIN / GINE eps gradients).  scratch: float[256].
  * sn_adam_step_f32: one torch.optim.Adam step (no amsgrad; weight_decay added to the gradient) on a flat tensor; the gradient is
  *   read as g*grad_scale (1/world_size after a SUM all-reduce of data-parallel ranks). */
@@ -287,8 +290,8 @@ int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, i
                               void* stream);
 int sn_slot_broadcast_f32(const float* g, int64_t N, int K, int C, const int32_t* nvalid, float* dx, void* stream);
 int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const int32_t* graph_ptr, int mode, float* dx, void* stream);
-int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, int C, const float* g,
-                             void* stream);
+int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, const int64_t* table_rows,
+                             int C, const float* g, int32_t* status, void* stream);
 int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch, void* stream);
 int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, void* stream);
@@ -406,10 +409,12 @@ int sn_rho_fused_f32(const sn_rho_params* params, const float* x, const float* e
  * (DiscreteEncoder elements.py:31-37 or MLP(F,d,1)), Linear(cat[x,pos]), n_layers x [edge encoder, GINEConv
  * (pyg_gnn_wrapper.py:19-28), BatchNorm, ReLU, +previous], add pooling, 2-layer output encoder.
  * One workgroup per graph (graphs of more than SN_GNN_MAX_NODES = 64 nodes or 192 edges are skipped and flagged in
- * status[3]; the caller then uses the layer-at-a-time entry points).  Every [d,d] Linear is split-packed
+ * status[3] (bits 0 / 1); the caller then uses the layer-at-a-time entry points).  A graph that cannot be evaluated — too large,
+ * a feature id out of range (bit 2), or an earlier stage of the same batch flagged in `flags_src` (malformed batch, phi / rho work
+ * bins not laid out) — gets a NaN output row: nothing uninitialised is ever handed back.  Every [d,d] Linear is split-packed
  * (sn_pack_split_f32) together with its epilogue vectors; other vectors are zero-padded to d_pad. */
 typedef struct {
-  const float* etab[10];  /* discrete edge encoder: embedding tables [V, d] of layer l */
+  const float* etab[10];  /* discrete edge encoder: embedding tables [edge_vocab, d] of layer l */
   const float* ew;        /* float edge encoder: weight [d_pad, F_e] row-major (NOT packed), zero padded rows */
   const float* e_scale;   /*   its folded BatchNorm */
   const float* e_shift;
@@ -424,7 +429,10 @@ typedef struct {
   int d, n_layers, n_out, reserved;
   int node_discrete, node_nf; /* discrete: number of int64 feature columns (<=10); float: F (<=16) */
   int edge_discrete, edge_nf;
-  const float* ntab[10];      /* discrete node encoder tables [V, d] */
+  int node_vocab, edge_vocab; /* rows of every discrete node / edge table (DiscreteEncoder's max_num_values, elements.py:22): a feature
+                                 value outside [0, vocab) — nn.Embedding raises IndexError there — is never dereferenced; the graph's
+                                 output row is NaN and status[3] bit 2 is set */
+  const float* ntab[10];      /* discrete node encoder tables [node_vocab, d] */
   const float* nw;            /* float node encoder: weight [d_pad, F] row-major (NOT packed), zero padded rows */
   const float* n_scale;
   const float* n_shift;

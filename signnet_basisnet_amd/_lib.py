@@ -41,7 +41,7 @@ SIGNATURES = {
     "sn_masked_layernorm_f32": [_p, _p, _l, _i, _p, _p, _f, _p, _i, _p, _p],
     "sn_set_attention_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
     "sn_slot_sum_f32": [_p, _l, _i, _i, _p, _p],
-    "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), _i, _p, _p],
+    "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), C.POINTER(C.c_int64), _i, _p, _p, _p],
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],
     "sn_laplacian_evd_f32": [_p, _l, _p, _l, _l, _i, _p, _p, _p, _l, _p, _i, _i, _p, _p, _p],
@@ -54,7 +54,7 @@ SIGNATURES = {
     "sn_gine_aggregate_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "sn_slot_broadcast_f32": [_p, _l, _i, _i, _p, _p, _p],
     "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],
-    "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, _i, _p, _p],
+    "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, C.POINTER(C.c_int64), _i, _p, _p, _p],
     "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
     "sn_gated_aggregate_f32": [_p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_gated_aggregate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

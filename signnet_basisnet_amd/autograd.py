@@ -269,13 +269,13 @@ def slot_sum(x, N, K, nvalid=None):
 # ----------------------------------------------------------------------------- embeddings / pooling
 class _EmbeddingSum(Function):
     @staticmethod
-    def forward(ctx, idx, *tables):
+    def forward(ctx, idx, status, *tables):
         if idx.dim() == 1:
             idx = idx.unsqueeze(1)
         idx = idx.contiguous()
         ctx.idx = idx
         ctx.shapes = [t.shape for t in tables]
-        return ops.embedding_sum(idx, [t.detach() for t in tables])
+        return ops.embedding_sum(idx, [t.detach() for t in tables], status)
 
     @staticmethod
     def backward(ctx, g):
@@ -284,13 +284,16 @@ class _EmbeddingSum(Function):
         R, nf = idx.shape
         grads = [torch.zeros(s, dtype=torch.float32, device=g.device) if f < nf else None for f, s in enumerate(ctx.shapes)]
         arr = (C.c_void_p * nf)(*[grads[f].data_ptr() for f in range(nf)])
-        check(lib().sn_embedding_sum_bwd_f32(ptr(idx), nf, nf, R, arr, g.shape[-1], ptr(g), stream()), "sn_embedding_sum_bwd_f32")
-        return (None, *grads)
+        rows = (C.c_int64 * nf)(*[ctx.shapes[f][0] for f in range(nf)])
+        # (out-of-range indices were reported by the forward; the backward skips them — deterministic, no atomics)
+        check(lib().sn_embedding_sum_bwd_f32(ptr(idx), nf, nf, R, arr, rows, g.shape[-1], ptr(g), None, stream()), "sn_embedding_sum_bwd_f32")
+        return (None, None, *grads)
 
 
-def embedding_sum(idx, tables):
-    """sum_f tables[f][idx[:, f]] (DiscreteEncoder); tables beyond idx's feature columns get no gradient."""
-    return _EmbeddingSum.apply(idx, *tables)
+def embedding_sum(idx, tables, status=None):
+    """sum_f tables[f][idx[:, f]] (DiscreteEncoder); tables beyond idx's feature columns get no gradient.  `status`: see
+    ops.embedding_sum (None = the op checks the index range itself, one host sync)."""
+    return _EmbeddingSum.apply(idx, status, *tables)
 
 
 class _SegmentPool(Function):

@@ -63,6 +63,8 @@ class IGN2to1(nn.Module):
         self.fc1 = nn.Linear(hidden_channels, hidden_channels)
         self.fc2 = nn.Linear(hidden_channels, out_channels)
         self._prep = None
+        # fires also when a PARENT module's (IGNBasisInv, a wrapper) load_state_dict recurses into this one
+        self.register_load_state_dict_post_hook(lambda m, keys=None: setattr(m, "_prep", None))
 
     def train(self, mode=True):
         self._prep = None

@@ -367,16 +367,28 @@ __global__ __launch_bounds__(256) void k_segment_bcast(const float* __restrict__
     dx[(int64_t)lo * C + i] = g[(int64_t)b * C + c] * w;
   }
 }
-struct GradTables { float* t[10]; };
-// dT_f[idx[r,f], :] += g[r, :]
-__global__ __launch_bounds__(256) void k_embedding_bwd(const int64_t* __restrict__ idx, int ldi, int nf, int64_t R, GradTables tp,
-                                                       int C, const float* __restrict__ g) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= R * C) return;
-  const int64_t r = i / C;
-  const int c = (int)(i - r * C);
-  const float v = g[i];
-  for (int f = 0; f < nf; ++f) atomicAdd(&tp.t[f][idx[r * ldi + f] * C + c], v);
+// dT_f[v, :] = sum over the rows r with idx[r,f] == v of g[r, :], in row order — one workgroup per table row v: no atomics, so
+// the embedding gradients are bitwise reproducible (nn.Embedding's own backward is not).  The index column is re-read by every
+// workgroup (wave-uniform scalar loads, V*R*8 bytes of L2 traffic): V <= 500 in the reference (elements.py:22).  An index outside
+// [0, V) contributes nothing and raises bit 0 of *status (workgroup 0 checks the whole column).
+__global__ __launch_bounds__(256) void k_embedding_bwd(const int64_t* __restrict__ idx, int ldi, int f, int64_t R, int64_t V,
+                                                       float* __restrict__ dT, int C, const float* __restrict__ g,
+                                                       int32_t* __restrict__ status) {
+  const int64_t v = blockIdx.x;
+  const int c0 = threadIdx.x, c1 = threadIdx.x + 256;
+  float a0 = 0.f, a1 = 0.f;
+  bool bad = false;
+  for (int64_t r = 0; r < R; ++r) {
+    const int64_t id = idx[r * ldi + f];                     // uniform across the workgroup
+    if (id == v) {
+      if (c0 < C) a0 += g[r * C + c0];
+      if (c1 < C) a1 += g[r * C + c1];
+    }
+    bad = bad || (uint64_t)id >= (uint64_t)V;
+  }
+  if (c0 < C) dT[v * C + c0] += a0;
+  if (c1 < C) dT[v * C + c1] += a1;
+  if (bad && v == 0 && threadIdx.x == 0 && status != nullptr) atomicOr(status, 1);
 }
 // out[0] = sum_i a[i]*b[i]   (two stages, deterministic)
 __global__ __launch_bounds__(256) void k_dot_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
@@ -555,13 +567,16 @@ extern "C" int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const 
   return SN_OK;
 }
 
-extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, int C,
-                                        const float* g, void* stream) {
-  SN_REQUIRE(idx && dtables && g && nf > 0 && nf <= 10 && ldi >= nf && R >= 0 && C > 0, "sn_embedding_sum_bwd_f32: bad arguments");
+extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables,
+                                        const int64_t* table_rows, int C, const float* g, int32_t* status, void* stream) {
+  SN_REQUIRE(idx && dtables && table_rows && g && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && C <= 512 && R >= 0,
+             "sn_embedding_sum_bwd_f32: bad arguments (C <= 512)");
   if (R == 0) return SN_OK;
-  GradTables tp;
-  for (int f = 0; f < 10; ++f) tp.t[f] = f < nf ? dtables[f] : nullptr;
-  hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, ldi, nf, R, tp, C, g);
+  for (int f = 0; f < nf; ++f) {
+    SN_REQUIRE(dtables[f] && table_rows[f] > 0, "sn_embedding_sum_bwd_f32: table %d missing or empty", f);
+    hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)table_rows[f]), dim3(256), 0, (hipStream_t)stream, idx, ldi, f, R,
+                       table_rows[f], dtables[f], C, g, status);
+  }
   SN_CHECK_LAUNCH("sn_embedding_sum_bwd_f32");
   return SN_OK;
 }

@@ -55,7 +55,7 @@ struct GnnStruct {
   int32_t* status;        // status[3] |= 1 if a graph has more than 64 nodes (host falls back)
   float* y;               // [B, n_out]
   int ee_rows;            // rows of the edge-embedding area
-  const int32_t* flags_src;   // optional flag report (see sn_gnn_fused_f32)
+  const int32_t* flags_src;   // the batch's flag block [status(8) | bins meta(8)]: read for upstream failures, optionally reported
   int n_flags;
   int32_t* flags_host;
 };
@@ -228,17 +228,18 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   long long pt = 0;
 #endif
   const int gs = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - gs;
-  if (n <= 0) return;
-  if (n > GNN_ROWS) {
-    if (threadIdx.x == 0) atomicOr(&S.status[3], 1);
-    return;
-  }
+  // a graph that cannot be evaluated gets a NaN output row (never uninitialised memory): see sn_gnn_fused_f32
+  auto give_up = [&](int bit) {
+    if (threadIdx.x == 0 && bit) atomicOr(&S.status[3], bit);
+    if ((int)threadIdx.x < P.n_out) S.y[(int64_t)gi * P.n_out + threadIdx.x] = __uint_as_float(0x7fc00000u);
+  };
+  // earlier stages of this batch failed (malformed batch: status[0]; phi / rho bins not laid out: meta[1], meta[5])
+  if (S.flags_src != nullptr && (S.flags_src[0] != 0 || (S.n_flags >= 16 && (S.flags_src[9] != 0 || S.flags_src[13] != 0)))) { give_up(0); return; }
+  if (n <= 0) { give_up(0); return; }
+  if (n > GNN_ROWS) { give_up(1); return; }
   const int e_base = S.rowptr[gs];
   const int ne = S.rowptr[gs + n] - e_base;
-  if (ne > GNN_EMAX) {
-    if (threadIdx.x == 0) atomicOr(&S.status[3], 2);
-    return;
-  }
+  if (ne > GNN_EMAX) { give_up(2); return; }
   const int d = P.d;
   const int T = (n + 15) >> 4;                               // row tiles (1..4)
   const int ntile = T * NT;
@@ -311,6 +312,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   for (int i = threadIdx.x; i < 2 * SP_IMAGE / 16; i += GNN_WAVES * 64)
     reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
   // ---------------------------------------------------------------- per-graph CSR + edge data -> LDS (once)
+  bool id_bad = false;        // a discrete feature value of this graph lies outside its embedding table
   {
     const int EF = P.edge_nf;
     for (int k = threadIdx.x; k <= n; k += GNN_WAVES * 64) erow[k] = S.rowptr[gs + k] - e_base;
@@ -320,7 +322,12 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       if (P.n_layers > 0) {
         if (P.edge_discrete) {
           const int64_t* ei = reinterpret_cast<const int64_t*>(S.edge_attr) + (int64_t)eid * S.lde;
-          for (int f = 0; f < EF; ++f) efeat[k * EF + f] = (int)ei[f];
+          for (int f = 0; f < EF; ++f) {
+            const int64_t v = ei[f];
+            const bool ok = (uint64_t)v < (uint64_t)P.edge_vocab;      // nn.Embedding would raise IndexError: never dereferenced
+            efeat[k * EF + f] = ok ? (int)v : 0;
+            if (!ok) { atomicOr(&S.status[3], 4); id_bad = true; }
+          }
         } else {
           const float* ea = reinterpret_cast<const float*>(S.edge_attr) + (int64_t)eid * S.lde;
           for (int f = 0; f < EF; ++f) efeat[k * EF + f] = __float_as_int(ea[f]);
@@ -328,7 +335,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   }
-  __syncthreads();                                   // images cleared, efeat complete
+  int graph_bad = __syncthreads_or(id_bad);          // images cleared, efeat complete (+ did anyone see a bad edge feature id)
+  id_bad = false;
   // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
   if (P.n_layers > 0) {
     const int EF = P.edge_nf;
@@ -387,7 +395,9 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         const int64_t* xi = reinterpret_cast<const int64_t*>(S.x) + (int64_t)(gs + row) * S.ldx;
         f32x4 s = zero4;
         for (int f = 0; f < P.node_nf; ++f) {
-          const float* trow = P.ntab[f] + xi[f] * d;
+          int64_t xv = xi[f];
+          if ((uint64_t)xv >= (uint64_t)P.node_vocab) { xv = 0; atomicOr(&S.status[3], 4); id_bad = true; }    // see the edge features above
+          const float* trow = P.ntab[f] + xv * d;
           if ((d & 3) == 0) { if (c < d) s += ld4(trow + c); }
           else {
 #pragma unroll
@@ -415,8 +425,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   }
-  lds_barrier();   // LDS hazards only: a __syncthreads() would also drain the weight prefetch in flight (vmcnt(0))
-  SN_STAMP(1);
+  graph_bad |= __syncthreads_or(id_bad);   // inputs staged (+ did anyone see a bad node feature id); later barriers are LDS-only:
+  SN_STAMP(1);                             // a __syncthreads() would also drain the weight prefetch in flight (vmcnt(0))
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]) (model.py:39-40), pos = BN(W_out . slot_sum)
   //   (sign_net.py:71).  Order: x part (SB -> X1), pos (SA -> SB, SB being free after a barrier), pos part (SB -> X1 +=).
@@ -540,7 +550,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int c = 4 * g + qq;
-        if (c < P.n_out) S.y[(int64_t)gi * P.n_out + c] = acc[qq] + bias[qq];
+        if (c < P.n_out) S.y[(int64_t)gi * P.n_out + c] = graph_bad ? __uint_as_float(0x7fc00000u) : acc[qq] + bias[qq];
       }
     }
   }, nullptr, h2);
@@ -629,6 +639,9 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
   }
   if (B == 0) return SN_OK;
   SN_REQUIRE(!flags_host || (flags_src && n_flags > 0 && n_flags <= 64), "sn_gnn_fused_f32: flag report needs flags_src and 0 < n_flags <= 64");
+  SN_REQUIRE(!flags_src || n_flags >= 1, "sn_gnn_fused_f32: flags_src needs n_flags >= 1");
+  SN_REQUIRE((!P.node_discrete || P.node_vocab > 0) && (P.n_layers == 0 || !P.edge_discrete || P.edge_vocab > 0),
+             "sn_gnn_fused_f32: node_vocab / edge_vocab (rows of the embedding tables) missing");
   GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y, 0, flags_src, n_flags, flags_host};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;

@@ -555,17 +555,24 @@ __global__ __launch_bounds__(256) void k_slot_sum(const float* __restrict__ x, i
   out[idx] = s;
 }
 
-struct TablePtrs { const float* t[10]; };
+struct TablePtrs { const float* t[10]; int64_t rows[10]; };
 
+// An index outside [0, rows) (nn.Embedding raises IndexError there) is never dereferenced: it contributes 0 and raises bit 0 of *status.
 __global__ __launch_bounds__(256) void k_embedding_sum(const int64_t* __restrict__ idx, int ldi, int nf, int64_t R,
-                                                       TablePtrs tp, int C, float* __restrict__ out) {
+                                                       TablePtrs tp, int C, float* __restrict__ out, int32_t* __restrict__ status) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R * C) return;
   int64_t r = i / C;
   int c = (int)(i - r * C);
   float s = 0.f;
-  for (int f = 0; f < nf; ++f) s += tp.t[f][idx[r * ldi + f] * C + c];
+  bool bad = false;
+  for (int f = 0; f < nf; ++f) {
+    const int64_t id = idx[r * ldi + f];
+    if ((uint64_t)id < (uint64_t)tp.rows[f]) s += tp.t[f][id * C + c];
+    else bad = true;
+  }
   out[i] = s;
+  if (bad && c == 0 && status != nullptr) atomicOr(status, 1);
 }
 
 // One workgroup per segment; 256 threads = RL row lanes x CW column lanes (CW = the power of two >= min(C, 256)), folded in LDS.
@@ -891,14 +898,15 @@ extern "C" int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* o
 }
 
 extern "C" int sn_embedding_sum_f32(const int64_t* idx, int ldi, int nf, int64_t R, const float* const* tables,
-                                    int C, float* out, void* stream) {
-  SN_REQUIRE(idx && tables && out && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && R >= 0,
+                                    const int64_t* table_rows, int C, float* out, int32_t* status, void* stream) {
+  SN_REQUIRE(idx && tables && table_rows && out && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && R >= 0,
              "sn_embedding_sum_f32: bad arguments");
   if (R == 0) return SN_OK;
   TablePtrs tp;
-  for (int f = 0; f < 10; ++f) tp.t[f] = f < nf ? tables[f] : nullptr;
+  for (int f = 0; f < 10; ++f) { tp.t[f] = f < nf ? tables[f] : nullptr; tp.rows[f] = f < nf ? table_rows[f] : 0; }
+  for (int f = 0; f < nf; ++f) SN_REQUIRE(tp.t[f] && tp.rows[f] > 0, "sn_embedding_sum_f32: table %d missing or empty", f);
   hipLaunchKernelGGL(k_embedding_sum, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, ldi, nf,
-                     R, tp, C, out);
+                     R, tp, C, out, status);
   SN_CHECK_LAUNCH("sn_embedding_sum_f32");
   return SN_OK;
 }

@@ -141,8 +141,21 @@ def _run_mlp(prep, x, nvalid=None, K=0, tail_bn=None, train=False):
     return x
 
 
+def _no_dropout(dropout, who):
+    """The reference applies F.dropout(p=dropout) in MLP.forward / GIN.forward while training (mlp.py:52, gnns.py:104); the shipped
+    sign_inv configs all set dropout 0.0.  A non-zero value is refused instead of being silently ignored."""
+    if float(dropout) != 0.0:
+        raise NotImplementedError(f"{who}: dropout={dropout} is not implemented by the HIP modules (the shipped configs use 0.0); "
+                                  "pass dropout=0.0")
+
+
 class _DeepSignsBase(nn.Module):
     masked = False
+
+    def __init__(self):
+        super().__init__()
+        # fires also when a PARENT module's load_state_dict recurses into this one (its own override below does not)
+        self.register_load_state_dict_post_hook(lambda m, keys=None: m._invalidate())
 
     def _invalidate(self):
         self._prep = None
@@ -274,6 +287,7 @@ class GINDeepSigns(_DeepSignsBase):
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, k, use_bn=False, use_ln=False, dropout=0.5,
                  activation="relu"):
         super().__init__()
+        _no_dropout(dropout, "GINDeepSigns")
         self.enc = GIN(in_channels, hidden_channels, out_channels, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
         self.rho = MLP(out_channels * k, hidden_channels, k, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
         self.k = k
@@ -286,6 +300,7 @@ class MaskedGINDeepSigns(_DeepSignsBase):
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, k, device=None, use_bn=False, use_ln=False,
                  dropout=0.5, activation="relu"):
         super().__init__()
+        _no_dropout(dropout, "MaskedGINDeepSigns")
         self.device = device
         self.enc = GIN(in_channels, hidden_channels, out_channels, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)
         self.rho = MLP(out_channels, hidden_channels, k, num_layers, use_bn=use_bn, dropout=dropout, activation=activation)

@@ -48,6 +48,11 @@ class _PackCache:
         self._cache = {}
         return super().load_state_dict(*a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        # reached also when a PARENT module's load_state_dict recurses into this one (the override above is not)
+        self._cache = {}
+        return super()._load_from_state_dict(*a, **k)
+
     def _pk(self, lin):
         if self.training:
             return _pack(lin)

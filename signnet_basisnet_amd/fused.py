@@ -196,7 +196,7 @@ class _GnnLayer(C.Structure):
 
 class _GnnParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("d", "n_layers", "n_out", "reserved", "node_discrete", "node_nf", "edge_discrete",
-                                       "edge_nf")] + \
+                                       "edge_nf", "node_vocab", "edge_vocab")] + \
                [("ntab", C.c_void_p * 10)] + \
                [(n, C.c_void_p) for n in ("nw", "n_scale", "n_shift", "rho_out_w", "lin_a", "lin_b", "head_w1", "head_w2")] + \
                [("layers", _GnnLayer * GNN_MAX_LAYERS)]
@@ -227,7 +227,9 @@ class GnnPlan:
         P.node_discrete, P.edge_discrete = int(self.node_discrete), int(self.edge_discrete)
         P.node_nf = 1 if self.node_discrete else int(node_feat)     # discrete column count is set per call
         P.edge_nf = 1 if self.edge_discrete else int(edge_feat)
+        P.node_vocab = P.edge_vocab = 0
         if self.node_discrete:
+            P.node_vocab = gnn.input_encoder.embeddings[0].weight.shape[0]
             for f, e in enumerate(gnn.input_encoder.embeddings):
                 P.ntab[f] = hold(e.weight.detach())
         else:
@@ -258,6 +260,7 @@ class GnnPlan:
         for l, (enc, conv, norm) in enumerate(zip(gnn.edge_encoders, gnn.convs, gnn.norms)):
             Lp = P.layers[l]
             if self.edge_discrete:
+                P.edge_vocab = enc.embeddings[0].weight.shape[0]
                 for f, e in enumerate(enc.embeddings):
                     Lp.etab[f] = hold(e.weight.detach())
             else:
@@ -302,7 +305,6 @@ class GnnPlan:
                                          edge_attr.shape[1] if edge_attr.dim() > 1 else 1, ptr(rho_sum),
                                          ptr(plan.graph_ptr), plan.B, ptr(plan.rowptr), ptr(plan.col),
                                          ptr(plan.eperm), ptr(plan.status), ptr(y),
-                                         ptr(plan.flags) if flags_host is not None else None,
-                                         plan.flags.numel() if flags_host is not None else 0, ptr(flags_host), stream()),
+                                         ptr(plan.flags), plan.flags.numel(), ptr(flags_host), stream()),
                   "sn_gnn_fused_f32")
         return y

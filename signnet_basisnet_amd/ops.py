@@ -126,7 +126,8 @@ class GraphPlan:
     rowptr: torch.Tensor      # int32 [N+1] dst-sorted CSR
     col: torch.Tensor         # int32 [E]   source node of each in-edge
     eperm: torch.Tensor       # int32 [E]   original edge id of each CSR slot
-    status: torch.Tensor      # int32 [8]   [err bits, max nodes/graph, max in-degree, fused-stage flags, gnn completion counter, -, -, -]
+    status: torch.Tensor      # int32 [8]   [err bits, max nodes/graph, max in-degree, fused-stage flags, gnn completion counter,
+                              #              embedding index out of range (layer path), -, -]
     bins: PlanBins | None
     flags: torch.Tensor = None   # status (+ bins meta) as one contiguous block
 
@@ -137,6 +138,8 @@ class GraphPlan:
             bits = [n for b, n in ((1, "batch not sorted"), (2, "graph id out of range"),
                                    (4, "edge endpoint out of range"), (8, "edge crosses graphs")) if st[0] & b]
             raise ValueError("malformed graph batch: " + ", ".join(bits))
+        if st[5] or (st[3] & 4):
+            raise IndexError(EMBEDDING_INDEX_ERROR)
         return st
 
 
@@ -451,8 +454,15 @@ def slot_sum(x, N, K):
     return out
 
 
-def embedding_sum(idx, tables):
-    """sum_f tables[f][idx[:, f]] — DiscreteEncoder; idx int64 [R] or [R, F]."""
+EMBEDDING_INDEX_ERROR = ("index out of range in embedding: a discrete node / edge feature value lies outside its table "
+                         "(DiscreteEncoder's max_num_values) — nn.Embedding raises IndexError here too")
+
+
+def embedding_sum(idx, tables, status=None):
+    """sum_f tables[f][idx[:, f]] — DiscreteEncoder; idx int64 [R] or [R, F].  An index outside its table is never
+    dereferenced (it contributes 0) and sets bit 0 of `status` (device int32, e.g. a slot of the batch plan's status block
+    that the caller checks later); with status=None the op checks it itself — one host sync — and raises IndexError like
+    nn.Embedding does."""
     require_cuda(idx)
     if idx.dtype != torch.int64:
         raise ValueError("embedding_sum: integer features must be int64")
@@ -465,9 +475,15 @@ def embedding_sum(idx, tables):
     tabs = [_f32c(t, "embedding table") for t in tables[:nf]]
     Cc = tabs[0].shape[1]
     arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs])
+    rows = (C.c_int64 * nf)(*[t.shape[0] for t in tabs])
     out = torch.empty(R, Cc, dtype=torch.float32, device=idx.device)
+    own = status is None
+    if own:
+        status = torch.zeros(1, dtype=torch.int32, device=idx.device)
     with _span("sn_embedding_sum_f32"):
-        check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, Cc, ptr(out), stream()), "sn_embedding_sum_f32")
+        check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, rows, Cc, ptr(out), ptr(status), stream()), "sn_embedding_sum_f32")
+    if own and int(status.item()):
+        raise IndexError(EMBEDDING_INDEX_ERROR)
     return out
 
 

@@ -275,6 +275,11 @@ def _pack(lin: nn.Linear) -> ops.PackedLinear:
                             None if lin.bias is None else lin.bias.detach().contiguous())
 
 
+def _drop_prepared(module, incompatible_keys=None):
+    """load_state_dict post hook: the packed (eval-mode) weights are stale."""
+    module._prep = None
+
+
 class SignNetGNN(nn.Module):
     """HIP SignNet + GINE.  `variant` selects which reference tree's semantics are reproduced.
 
@@ -295,10 +300,13 @@ class SignNetGNN(nn.Module):
         # nl_rho is fixed by the reference constructors (sign_net.py:123 ignores the argument)
         self.nl_rho = 4 if variant == "alchemy" else 1
         self.use_fused = True       # whole-stage kernels (eval mode); False = layer-at-a-time kernels only
-        # Fused stages require graphs of <= 64 nodes (and <= 192 edges for the GINE stage); a batch that violates
-        # this raises the device-side flags of the plan.  strict=True reads them after every forward (one host
-        # sync) and re-runs such a batch on the layer path; strict=False (default) copies them asynchronously
-        # and raises at the NEXT forward (or at .check_last()) — outputs of the offending batch are invalid.
+        # Fused stages require graphs of <= 64 nodes (and <= 192 edges for the GINE stage); a batch that violates this, a
+        # malformed batch, or a discrete feature value outside its embedding table raises device-side flags.
+        #   strict=True : the flags are read after every forward (one host sync); an oversize batch is re-run on the layer
+        #                 path, anything else raises immediately — the reference's behaviour, at the price of the sync.
+        #   strict=False: (default) no sync.  The outputs of every graph that could not be evaluated are NaN (never
+        #                 uninitialised memory: the GINE kernel fills them), and the error itself is raised at the next
+        #                 forward, at check_last(), at train()/eval() or when the module is deleted, whichever comes first.
         self.strict = False
         # train-mode dropout of the attention probabilities (ScaledDotProductAttention's default attn_dropout=0.1,
         # transformer_module.py:46-55 — the only dropout the reference leaves active); 0.0 switches it off
@@ -307,6 +315,9 @@ class SignNetGNN(nn.Module):
         self.sign_net = SignNet(n_hid, nl_signnet, self.nl_rho, variant, ignore_eigval)
         self.gnn = GNN(node_feat, edge_feat, n_hid, n_out, nl_gnn, variant)
         self._prep = None
+        # nn.Module.load_state_dict on a PARENT (a wrapper, DDP, a bigger model) recurses through _load_from_state_dict and never
+        # calls this module's load_state_dict override — the post hook below does fire for every submodule of that recursion
+        self.register_load_state_dict_post_hook(_drop_prepared)
 
     def reset_parameters(self):
         self.sign_net.reset_parameters()
@@ -316,6 +327,7 @@ class SignNetGNN(nn.Module):
     # cache invalidation: packed weights depend on parameters, buffers, device and mode
     def train(self, mode=True):
         self._prep = None
+        self._drain_status()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
@@ -327,8 +339,23 @@ class SignNetGNN(nn.Module):
         return super().load_state_dict(*a, **k)
 
     def invalidate(self):
-        """Call after modifying parameters in place while in eval mode."""
+        """Call after modifying parameters in place while in eval mode (an optimiser step, `p.data.copy_()`, ...): the packed
+        copies are rebuilt on the next forward.  train()/eval(), .to()/.cuda(), load_state_dict (also through a parent module)
+        and reset_parameters() do this themselves."""
         self._prep = None
+
+    def __del__(self):
+        try:
+            if self._pending:
+                self._drain_status()
+        except RuntimeError:
+            raise
+        except Exception:               # interpreter shutdown etc.
+            pass
+
+    def _drain_status(self):
+        if getattr(self, "_pending", None):
+            self.check_last()
 
     # ------------------------------------------------------------------ prepare
     def _prepare(self, train=False):
@@ -388,8 +415,21 @@ class SignNetGNN(nn.Module):
     # ------------------------------------------------------------------ device-side status of the fused stages
     @staticmethod
     def _flags_bad(host):
-        # layout: [status(8) | meta(8)]: status[0] plan errors, status[3] gnn flags, meta[1] phi, meta[5] rho bin errors
-        return bool(host[0] or host[3] or host[9] or host[13])
+        # layout: [status(8) | meta(8)]: status[0] plan errors, status[3] gnn flags, status[5] embedding index (layer path),
+        # meta[1] phi, meta[5] rho bin errors
+        return bool(host[0] or host[3] or host[5] or host[9] or host[13])
+
+    @staticmethod
+    def _flags_error(host):
+        """The exception an offending batch deserves (same types as the reference raises: IndexError from nn.Embedding)."""
+        if (host[3] & 4) or host[5]:
+            return IndexError(ops.EMBEDDING_INDEX_ERROR + " — the outputs of the affected graphs are NaN")
+        if host[0]:
+            return ValueError("an earlier batch was malformed (unsorted batch vector, graph id / edge endpoint out of range or an edge "
+                              "across graphs): its outputs are NaN")
+        return RuntimeError("an earlier batch had a graph too large for the fused SignNet kernels (> 64 nodes or > 192 edges): "
+                            "the outputs of that batch are NaN; set model.strict = True (re-runs such batches layer by layer) or "
+                            "model.use_fused = False")
 
     def check_last(self, wait=True):
         """Raise if an earlier forward's batch could not be served by the fused kernels (wait=False: only look at
@@ -403,9 +443,7 @@ class SignNetGNN(nn.Module):
             self._free_hosts.append(host)
             if self._flags_bad(host[1]):
                 self._pending.clear()
-                raise RuntimeError("an earlier batch was malformed or had a graph too large for the fused SignNet kernels "
-                                   "(> 64 nodes or > 192 edges): its outputs are invalid; set model.strict = True "
-                                   "(re-runs such batches layer by layer) or model.use_fused = False")
+                raise self._flags_error(host[1])
 
     _READY = 16          # word of the pinned buffer the GINE kernel sets to 1 after the 16 flags (sn_gnn_fused_f32)
 
@@ -476,8 +514,8 @@ class SignNetGNN(nn.Module):
                 flags = host[1].tolist()
                 self._free_hosts.append(host)
                 if self._flags_bad(flags):
-                    if flags[0]:
-                        self._last_plan.check()
+                    if flags[0] or flags[5] or (flags[3] & 4):
+                        raise self._flags_error(flags)
                     saved, self.use_fused, self._prep = self.use_fused, False, None
                     try:
                         y = self._forward(data, False)
@@ -552,13 +590,13 @@ class SignNetGNN(nn.Module):
         # ---- GINE network
         xin = data.x.squeeze() if data.x.dim() > 1 and data.x.shape[-1] == 1 else data.x
         if isinstance(g.input_encoder, DiscreteEncoder):
-            h = AG.embedding_sum(xin, [e.weight for e in g.input_encoder.embeddings])
+            h = AG.embedding_sum(xin, [e.weight for e in g.input_encoder.embeddings], plan.status[5:6])
         else:
             h = lin_bn(xin.contiguous(), g.input_encoder.layers[0], g.input_encoder.norms[0])
         h = AG.linear(torch.cat([h, pe], dim=-1), g.linear.weight, g.linear.bias)
         for enc, conv, norm in zip(g.edge_encoders, g.convs, g.norms):
             if isinstance(enc, DiscreteEncoder):
-                e = AG.embedding_sum(data.edge_attr, [t.weight for t in enc.embeddings])
+                e = AG.embedding_sum(data.edge_attr, [t.weight for t in enc.embeddings], plan.status[5:6])
             else:
                 e = lin_bn(data.edge_attr.contiguous(), enc.layers[0], enc.norms[0])
             u = AG.gine_aggregate(h, e, conv.layer.eps, plan, rplan)
@@ -567,7 +605,10 @@ class SignNetGNN(nn.Module):
         pooled = AG.segment_pool(h, plan, g.pooling)
         oe = g.output_encoder
         y = lin_bn(pooled, oe.layers[0], oe.norms[0])
-        return AG.linear(y, oe.layers[1].weight, oe.layers[1].bias)
+        y = AG.linear(y, oe.layers[1].weight, oe.layers[1].bias)
+        if isinstance(g.input_encoder, DiscreteEncoder) and int(plan.status[5]):     # one sync per training step
+            raise IndexError(ops.EMBEDDING_INDEX_ERROR)
+        return y
 
     # ------------------------------------------------------------------ forward
     def _forward(self, data, return_stages=False, train=False):
@@ -654,13 +695,13 @@ class SignNetGNN(nn.Module):
         # ---- GINE network           (GNN.forward, model.py:36-64)
         xin = data.x.squeeze() if data.x.dim() > 1 and data.x.shape[-1] == 1 else data.x
         if "in_tabs" in P:
-            h = ops.embedding_sum(xin, P["in_tabs"])
+            h = ops.embedding_sum(xin, P["in_tabs"], plan.status[5:6])
         else:
             h = _lin_bn(xin.contiguous(), P["in_mlp"]["l"], P["in_mlp"]["bn"], train, relu=True)
         h = ops.masked_linear(torch.cat([h, pe], dim=-1), P["lin"])
         for l, L in enumerate(P["gine"]):
             if "tabs" in L:
-                e = ops.embedding_sum(data.edge_attr, L["tabs"])
+                e = ops.embedding_sum(data.edge_attr, L["tabs"], plan.status[5:6])
             else:
                 e = _lin_bn(data.edge_attr.contiguous(), L["emlp"]["l"], L["emlp"]["bn"], train, relu=True)
             u = ops.gine_aggregate(h, e, plan, L["eps"])
@@ -671,6 +712,8 @@ class SignNetGNN(nn.Module):
         pooled = ops.segment_pool(h, plan, self.gnn.pooling)
         y = _lin_bn(pooled, P["head"]["l0"], P["head"]["bn0"], train, relu=True)
         y = ops.masked_linear(y, P["head"]["l1"])
+        if "in_tabs" in P and int(plan.status[5]):      # layer path only (train mode / return_stages / fallback): one host sync
+            raise IndexError(ops.EMBEDDING_INDEX_ERROR)
         if return_stages:
             stages["y"] = y
             if use_gnn_fused:

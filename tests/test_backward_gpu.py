@@ -235,6 +235,18 @@ def test_embedding_and_pool_backward():
     a, b, c = leaf(t0, DEV), leaf(t1, DEV), leaf(t2, DEV)
     AG.embedding_sum(idx_d, [a, b, c]).sum().backward()
     assert c.grad is None and a.grad is not None
+    # no atomics: the table gradients are bitwise reproducible (500-row tables as in GINESignNetPyG, many repeated ids)
+    big = torch.randint(0, 28, (5000, 1), generator=g).to(DEV)
+    tab = torch.randn(500, 128, generator=g)
+    up = torch.randn(5000, 128, generator=g).to(DEV)
+    grads = []
+    for _ in range(3):
+        t = leaf(tab, DEV)
+        (AG.embedding_sum(big, [t]) * up).sum().backward()
+        grads.append(t.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    ref = torch.zeros(500, 128, dtype=torch.float64).index_add_(0, big[:, 0].cpu(), up.cpu().double())
+    close(grads[0], ref, "embedding table gradient", 1e-5)
     sizes = [5, 1, 17, 30, 9]
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     plan = ops.build_plan(batch.to(DEV), torch.zeros(2, 0, dtype=torch.int64, device=DEV), len(sizes), 0)

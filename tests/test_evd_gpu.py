@@ -155,7 +155,7 @@ def test_signnet_on_device_evd_matches_host_evd():
     data.edge_attr = torch.randint(1, 4, (E,), generator=gen)
     Dh, Vh = OE.evd_batch(data.edge_index.numpy(), list(data.sizes), "sym")
     torch.manual_seed(0)
-    model = pyg.SignNetGNN(None, None, 32, 1, 3, 2).to(DEV).eval()
+    model = pyg.SignNetGNN(None, None, 32, 1, 3, 2, variant="gine").to(DEV).eval()      # 500-row tables (the alchemy variant has 6: ids 0..27 would be out of range)
     dd = synth.batch_to(data, torch.device(DEV))
     dd.eigen_values, dd.eigen_vectors = torch.from_numpy(Dh).to(DEV), torch.from_numpy(Vh).to(DEV)
     with torch.no_grad():

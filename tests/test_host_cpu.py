@@ -131,3 +131,45 @@ def test_widening_modules_import_without_a_gpu_and_keep_the_reference_surface():
     with pytest.raises(RuntimeError, match="GPU only|No HIP|cuda"):
         transform.BatchEVDTransform("sym")(types.SimpleNamespace(edge_index=torch.tensor([[0, 1], [1, 0]]), batch=torch.zeros(2, dtype=torch.long),
                                                                  num_graphs=1, sizes=[2]))
+
+
+def test_packed_weight_caches_are_dropped_when_a_parent_loads_a_state_dict():
+    """nn.Module.load_state_dict on a PARENT recurses through _load_from_state_dict and never calls a child's
+    load_state_dict override: every module that caches packed eval-mode weights must notice it anyway."""
+    import torch.nn as nn
+    from signnet_basisnet_amd import basisnet, dgl_deepsigns, dgl_nets
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    stale = object()
+    m = SignNetGNN(None, None, 16, 1, 2, 2, variant="gine")
+    wrap = nn.ModuleDict({"model": m})
+    m._prep = stale
+    wrap.load_state_dict(wrap.state_dict())
+    assert m._prep is None
+    inv = basisnet.IGNBasisInv([1, 2], 1, hidden_channels=8)
+    for e in inv.encs:
+        e._prep = stale
+    inv.load_state_dict(inv.state_dict())
+    assert all(e._prep is None for e in inv.encs)
+    ds = dgl_deepsigns.GINDeepSigns(1, 8, 4, 3, 6, use_bn=True, dropout=0.0)
+    holder = nn.Sequential(ds)
+    ds._prep = stale
+    holder.load_state_dict(holder.state_dict())
+    assert ds._prep is None
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=16, out_dim=16, in_feat_dropout=0.0, dropout=0.0, L=2, readout="mean",
+                  batch_norm=True, residual=True, edge_feat=True, device="cpu", pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False,
+                  use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=6, sign_inv_net="gin", sign_inv_layers=3,
+                  sign_inv_activation="relu", pe_aggregate="add", phi_out_dim=4)
+    net = dgl_nets.GINNet(params)
+    net.sign_inv_net._prep = stale
+    net._cache = {"x": stale}
+    outer = nn.ModuleDict({"net": net})
+    outer.load_state_dict(outer.state_dict())
+    assert net.sign_inv_net._prep is None and net._cache == {}
+
+
+def test_unimplemented_dropout_is_refused_not_ignored():
+    from signnet_basisnet_amd import dgl_deepsigns
+    with pytest.raises(NotImplementedError, match="dropout"):
+        dgl_deepsigns.GINDeepSigns(1, 8, 4, 3, 6, use_bn=True)                 # the reference's default dropout=0.5
+    with pytest.raises(NotImplementedError, match="dropout"):
+        dgl_deepsigns.MaskedGINDeepSigns(1, 8, 4, 3, 6, use_bn=True, dropout=0.1)

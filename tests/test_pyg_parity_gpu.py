@@ -156,12 +156,81 @@ def test_oversize_graph_is_flagged_and_served_by_the_layer_path():
     model.strict = True
     close(model(dd), yref, "strict mode (layer-path fallback)")
     model.strict = False
-    model(dd)                                   # flags raised on the device, reported late
+    y = model(dd)                               # flags raised on the device, reported late ...
+    torch.cuda.synchronize()
+    assert torch.isnan(y).all(), "a batch the fused kernels cannot serve must come back as NaN, never as uninitialised memory"
     with pytest.raises(RuntimeError, match="too large for the fused"):
         model.check_last()
     ok = synth.batch_to(synth.make_batch(3, seed=4, sizes=[10, 20, 12]), "cuda:0")
-    model(ok)
+    y_ok = model(ok)
     model.check_last()                          # a well-formed batch leaves nothing pending
+    assert torch.isfinite(y_ok).all()
+    # ... at the latest when the module changes mode (an evaluation loop's LAST batch is not lost)
+    model(dd)
+    with pytest.raises(RuntimeError, match="too large for the fused"):
+        model.train()
+    model.eval()
+
+
+def test_feature_id_outside_the_embedding_table_raises_like_nn_embedding():
+    """DiscreteEncoder tables have max_num_values rows (500 / 6, elements.py:22); nn.Embedding raises IndexError for an id
+    outside.  The HIP kernels never dereference such an id: the affected graph's output is NaN, the others are exact, and
+    IndexError is raised (immediately in strict mode and on the layer path, at the next check otherwise)."""
+    from signnet_basisnet_amd import ops, synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    model = SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
+    host = synth.make_batch(5, seed=12)
+    good = synth.batch_to(host, "cuda:0")
+    with torch.no_grad():
+        y_good = model(good).clone()
+    model.check_last()
+    for what in ("node", "edge"):
+        bad_host = synth.make_batch(5, seed=12)
+        if what == "node":
+            row = int(sum(host.sizes[:2]))                     # first node of graph 2
+            bad_host.x[row, 0] = 500                           # table rows: 500 -> valid ids 0..499
+        else:
+            e = int((bad_host.batch[bad_host.edge_index[0]] == 3).nonzero()[0])
+            bad_host.edge_attr[e] = -1
+        gi = 2 if what == "node" else 3
+        bad = synth.batch_to(bad_host, "cuda:0")
+        with torch.no_grad():
+            y = model(bad)
+        torch.cuda.synchronize()
+        assert torch.isnan(y[gi]).all()
+        keep = [i for i in range(5) if i != gi]
+        assert torch.equal(y[keep], y_good[keep]), "graphs without a bad id are unaffected"
+        with pytest.raises(IndexError, match="index out of range in embedding"):
+            model.check_last()
+        model.strict = True
+        with pytest.raises(IndexError, match="index out of range in embedding"):
+            model(bad)
+        model.strict = False
+        with pytest.raises(IndexError, match="index out of range in embedding"):       # layer path (one sync at the end)
+            model(bad, return_stages=True)
+    # the standalone op: checks itself unless the caller passes a status word
+    tab = torch.randn(6, 8, device="cuda:0")
+    with pytest.raises(IndexError):
+        ops.embedding_sum(torch.tensor([0, 6, 1], device="cuda:0"), [tab])
+    st = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+    out = ops.embedding_sum(torch.tensor([0, 6, 1], device="cuda:0"), [tab], st)
+    assert int(st) == 1 and torch.equal(out[1], torch.zeros(8, device="cuda:0")) and torch.equal(out[0], tab[0])
+
+
+def test_malformed_batch_comes_back_as_nan_and_raises():
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    model = SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
+    host = synth.make_batch(4, seed=3)
+    host.batch = host.batch.flip(0).contiguous()               # not sorted
+    with torch.no_grad():
+        y = model(synth.batch_to(host, "cuda:0"))
+    torch.cuda.synchronize()
+    assert torch.isnan(y).all()
+    with pytest.raises(ValueError, match="malformed"):
+        model.check_last()
 
 
 def test_split_gemm_path_is_fp32_accurate():
