@@ -73,26 +73,56 @@ def algorithmic_flops(data, k, d, L_phi, L_rho, L_g):
     return dict(phi=phi, rho=rho, gnn=gnn, total=phi + rho + gnn, M=M, N=N)
 
 
-def cpu_baseline(data, model_cpu_sd, budget_s=20.0):
-    """The oracle (CPU restatement of the reference) timed on this host's cores on the same batch."""
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(data, model_cpu_sd, budget_s=14.0):
+    """The oracle (CPU restatement of the reference) timed on this host's cores: the whole batch with P = all threads torch gives
+    this process (the baseline `value`), and a bounded sample (the first graphs of the same batch) with P = 1 — SURVEY.md §8(d)
+    asks for both, with the CPU model and the thread counts stated."""
     from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import dist as D
     cfg = O.make_cfg(WORKLOAD["variant"], WORKLOAD["node_feat"], WORKLOAD["edge_feat"], WORKLOAD["hidden"], WORKLOAD["n_out"],
                      WORKLOAD["nl_signnet"], WORKLOAD["nl_gnn"])
     cores = torch.get_num_threads()
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        O.signnet_gnn(model_cpu_sd, cfg, data, training=False, max_k=WORKLOAD["k"])     # warm-up
-        first = time.perf_counter() - t0
-        iters = max(1, min(10, int(budget_s / max(first, 1e-3)) - 1))
-        ts = []
-        for _ in range(iters):
+
+    def run(batch, budget):
+        with torch.no_grad():
             t0 = time.perf_counter()
-            O.signnet_gnn(model_cpu_sd, cfg, data, training=False, max_k=WORKLOAD["k"])
-            ts.append(time.perf_counter() - t0)
-    med = sorted(ts)[len(ts) // 2]
-    return dict(value=len(data.sizes) / med, unit="graphs/s", cores=cores, kind="port",
-                sample=f"{iters} forward(s) of the same {len(data.sizes)}-graph batch, median; oracle/pyg_signnet.py "
-                       f"(torch CPU fp32, {cores} threads)")
+            O.signnet_gnn(model_cpu_sd, cfg, batch, training=False, max_k=WORKLOAD["k"])     # warm-up
+            first = time.perf_counter() - t0
+            iters = max(1, min(10, int(budget / max(first, 1e-3)) - 1))
+            ts = []
+            for _ in range(iters):
+                t0 = time.perf_counter()
+                O.signnet_gnn(model_cpu_sd, cfg, batch, training=False, max_k=WORKLOAD["k"])
+                ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2], iters
+
+    med, iters = run(data, budget_s)
+    out = dict(value=len(data.sizes) / med, unit="graphs/s", cores=cores, kind="port", cpu_model=cpu_model_string(),
+               logical_cpus=os.cpu_count(),
+               sample=f"{iters} forward(s) of the same {len(data.sizes)}-graph batch, median; oracle/pyg_signnet.py "
+                      f"(torch CPU fp32, {cores} threads)")
+    # P = 1 on a bounded sample: the first 1/8 of the batch (forward cost is per graph; no cross-graph op in eval mode)
+    sub = D.shard_batch(data, 0, 8) if len(data.sizes) >= 16 else data
+    torch.set_num_threads(1)
+    try:
+        med1, it1 = run(sub, budget_s / 2)
+    finally:
+        torch.set_num_threads(cores)
+    out["single_thread"] = dict(value=len(sub.sizes) / med1, unit="graphs/s", cores=1,
+                                sample=f"{it1} forward(s) of the first {len(sub.sizes)} graphs of the batch, median (torch.set_num_threads(1))")
+    return out
 
 
 def evd_bench(args, dev):
@@ -175,6 +205,7 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
         for _ in range(3):
             step()
     kt = rec.summary()
+    rccl = rccl_allreduce_probe(dist, dev, opt.flat_g.numel()) if dist is not None else None     # collective: every rank
     if rank != 0:
         return
     per = {k: {"launches_per_step": v[0] / 3, "mean_us": 1e3 * v[1], "us_per_step": 1e3 * v[1] * v[0] / 3} for k, v in kt.items()}
@@ -187,6 +218,9 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
                         "achieved": 3 * fl["total"] / dt / 1e12, "frac": 3 * fl["total"] / dt / 1e12 / MFMA_F32_PEAK_TF,
                         "note": "whole step, ~3x the forward's dense flops (forward + dX + dW), layer-at-a-time fp32-MFMA kernels; "
                                 "this path is launch/HBM bound (one kernel per op), not matrix-pipe bound"},
+           "distributed": {"world_size": world, "backend": "nccl (RCCL)" if dist is not None else None,
+                           "gradient_allreduce": rccl,
+                           "note": "one SUM all-reduce of the flat gradient per step (optim.FlatAdam), 1/world folded into the Adam kernel"},
            "kernels": dict(sorted(per.items(), key=lambda kv: -kv[1]["us_per_step"]))}
     if world == 1 and not args.no_cpu_baseline:
         # the float32 CPU oracle under torch.autograd + torch.optim.Adam: what the reference's training loop does on the host
@@ -391,34 +425,67 @@ def dgl_bench(args, dev):
     print(json.dumps(out))
 
 
-def scatter_bench(args, dev):
-    """`--workload scatter` (extra measurement): the standalone GIN / GINE aggregation entry points of the layer-at-a-time path —
-    the reference's "eigvec scatter" (PyG GINConv over the [N, K*d] slot tensor, masked_layers.py:75; GINEConv, pyg_gnn_wrapper.py:28)
-    — against the HBM roofline.  (In eval the fused phi / GINE stages do this aggregation inside LDS and never touch HBM for it.)"""
+def scatter_measure(dev, graphs, feat, kind, steps=20, warmup=5, base=None):
+    """One standalone aggregation launch (layer-at-a-time entry point) on `graphs` synthetic ZINC-like graphs, timed with HIP
+    events on the launch stream.  kind 'gin': sn_gin_aggregate_f32 over the [N, feat] slot tensor (the reference's eigvec scatter:
+    PyG GINConv over [K, N, d], masked_layers.py:75) — algorithmic bytes 8*feat*N + 4*(E+N+1): every feature row read once and
+    written once, int32 CSR.  kind 'gine': sn_gine_aggregate_f32 over [N, feat] nodes and [E, feat] edge embeddings
+    (pyg_gnn_wrapper.py:28) — 4*feat*(2N+E)."""
     from signnet_basisnet_amd import ops, synth
+    if base is None:
+        base = synth.make_batch(min(graphs, 1024), seed=5)
+    reps = max(1, graphs // base.num_graphs)
+    ei = torch.cat([base.edge_index + r * base.num_nodes for r in range(reps)], 1).to(dev)
+    batch = torch.cat([base.batch + r * base.num_graphs for r in range(reps)]).to(dev)
+    plan = ops.build_plan(batch, ei, base.num_graphs * reps, 16)
+    N, E = plan.N, plan.E
+    eps = torch.zeros(1, device=dev)
+    if kind == "gin":
+        x = torch.randn(N, feat, device=dev)
+        f = lambda: ops.gin_aggregate(x, plan, eps)
+        byt = 8 * feat * N + 4 * (E + N + 1)
+        name = f"sn_gin_aggregate_f32 [N, K*d = {feat}]"
+    else:
+        x, ea = torch.randn(N, feat, device=dev), torch.randn(E, feat, device=dev)
+        f = lambda: ops.gine_aggregate(x, ea, plan, eps)
+        byt = 4 * feat * (2 * N + E)
+        name = f"sn_gine_aggregate_f32 [N, d = {feat}]"
+    for _ in range(warmup):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"kernel": name, "graphs": base.num_graphs * reps, "nodes": N, "edges": E, "mean_launch_us": 1e3 * ms,
+            "algorithmic_bytes": byt, "working_set_mib": byt / 2 ** 20, "bound": "hbm", "achieved": byt / ms / 1e6, "unit": "GB/s",
+            "peak": HBM_PEAK_GBS, "frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+
+
+def scatter_roofline(dev):
+    """The north_star's second figure — HBM bandwidth of the eigenvector scatter against the chip peak (target >= 40 %) — measured
+    in the same run as the headline, on working sets beyond the 256 MiB Infinity Cache: GIN over [N, K*d = 2048] on 1024 graphs
+    (~390 MB) and GINE over [N, 128] + [E, 128] on 6144 graphs (~300 MB).  In the eval forward this aggregation happens inside LDS
+    (fused phi / GINE stages) and has no HBM figure; these are the standalone entry points of the layer-at-a-time / training path."""
+    from signnet_basisnet_amd import synth
+    base = synth.make_batch(1024, seed=5)
+    gin = scatter_measure(dev, 1024, 2048, "gin", base=base)
+    gine = scatter_measure(dev, 6144, 128, "gine", base=base)
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": gin["achieved"], "frac": gin["frac"],
+            "kernel": gin["kernel"], "target_frac": 0.40, "gin": gin, "gine": gine,
+            "note": "achieved = algorithmic bytes / mean launch time (HIP events on the launch stream); working sets > 256 MiB so that "
+                    "the Infinity Cache cannot serve them"}
+
+
+def scatter_bench(args, dev):
+    """`--workload scatter` (extra measurement): the standalone GIN / GINE aggregation entry points at several sizes."""
     res = {}
-    for B in (128, 2048):
-        base = synth.make_batch(min(B, 1024), seed=5)
-        reps = max(1, B // 1024)
-        ei = torch.cat([base.edge_index + r * base.num_nodes for r in range(reps)], 1).to(dev)
-        batch = torch.cat([base.batch + r * base.num_graphs for r in range(reps)]).to(dev)
-        plan = ops.build_plan(batch, ei, base.num_graphs * reps, 16)
-        N, E = plan.N, plan.E
-        eps = torch.zeros(1, device=dev)
-        x1, x2, ea = torch.randn(N, 16 * 128, device=dev), torch.randn(N, 128, device=dev), torch.randn(E, 128, device=dev)
-        for name, f, byt in (("sn_gin_aggregate_f32 [N, K*d = 2048]", lambda: ops.gin_aggregate(x1, plan, eps), 8 * 2048 * N + 4 * (E + N + 1)),
-                             ("sn_gine_aggregate_f32 [N, d = 128]", lambda: ops.gine_aggregate(x2, ea, plan, eps), 4 * 128 * (2 * N + E))):
-            for _ in range(args.warmup):
-                f()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.steps):
-                f()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / args.steps
-            res[f"{name}, {B} graphs"] = {"nodes": N, "edges": E, "mean_launch_us": 1e3 * ms, "algorithmic_bytes": byt,
-                                          "achieved": byt / ms / 1e6, "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": byt / ms / 1e6 / HBM_PEAK_GBS}
+    for B in (128, 1024, 2048, 6144):
+        for kind, feat in (("gin", 2048), ("gine", 128)):
+            r = scatter_measure(dev, B, feat, kind, args.steps, args.warmup)
+            res[f"{r['kernel']}, {r['graphs']} graphs"] = r
     best = res["sn_gin_aggregate_f32 [N, K*d = 2048], 2048 graphs"]
     print(json.dumps({"metric": "HBM roofline fraction of the standalone GIN / GINE aggregation (extra measurement)", "value": best["frac"],
                       "unit": "fraction of 8 TB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
@@ -427,6 +494,27 @@ def scatter_bench(args, dev):
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"], "traffic": None,
                                    "note": "algorithmic bytes 8*F*N + 4*(E+N+1): every feature row read once and written once, int32 CSR"},
                       "kernels": res}))
+
+
+def rccl_allreduce_probe(dist, dev, numel, iters=20):
+    """What the training variant's gradient exchange costs on this node: ONE fp32 SUM all-reduce of the model's flat gradient
+    (optim.FlatAdam) over RCCL, device buffers, timed with HIP events after a warm-up (not part of the timed forward region)."""
+    buf = torch.ones(numel, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / iters
+    w = dist.get_world_size()
+    return {"world_size": w, "backend": dist.get_backend(), "allreduce_bytes": 4 * numel, "allreduce_us": us,
+            "busbw_gbs": 4 * numel * 2 * (w - 1) / w / us / 1e3,
+            "note": "one SUM all-reduce of the flat fp32 gradient buffer (all parameters of the model), ring bus bandwidth"}
 
 
 def recorded_traffic(kernel):
@@ -457,6 +545,7 @@ def main():
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
+    ap.add_argument("--no-scatter", action="store_true", help="skip the scatter_roofline block (standalone GIN / GINE aggregation on > 256 MiB)")
     ap.add_argument("--event-stride", type=int, default=1,
                     help="inside the timed region, bracket every n-th launch of the dominant kernel with HIP events (1 = all)")
     args = ap.parse_args()
@@ -552,6 +641,7 @@ def main():
             launches, mean_ms = dom_times[DOMINANT]
             roof = ops.KERNEL_ROOFLINE[DOMINANT](fl, WORKLOAD, host, mean_ms, 1.0)      # one launch per step
             roof.update({"timed_launches": launches, "event_stride": args.event_stride})
+            roof["frac_vs_f32_mfma"] = roof["achieved"] / MFMA_F32_PEAK_TF      # the same rate against the fp32-input MFMA peak (157.3)
             roof.update(recorded_traffic(DOMINANT))
         ktimes = rec_all.summary()
         nall = min(args.steps, 20)
@@ -584,6 +674,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
             out["cpu_baseline"] = cpu_baseline(host, sd)
+            out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    # (outside the timed region) every rank takes part in the RCCL probe; rank 0 measures the scatter roofline
+    rccl = None
+    if dist is not None:
+        rccl = rccl_allreduce_probe(dist, dev, sum(p.numel() for p in model.parameters()))
+    if rank == 0:
+        out["distributed"] = {"world_size": world, "backend": "nccl (RCCL)" if dist is not None else None,
+                              "data_path_collectives": 0, "gradient_allreduce": rccl}
+        if args.config == 1 and not args.no_scatter:
+            out["scatter_roofline"] = scatter_roofline(dev)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
