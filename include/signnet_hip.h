@@ -296,6 +296,26 @@ int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scr
 int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, void* stream);
 
+/* BasisNet preprocessing on the device — replaces the module-level code of LearningFilters/training.py:47-73.
+ * sn_eigenspace_group: `around(eigvals, decimals)` (round-half-even of x*10^decimals, fp32 as torch evaluates it), `unique(...,
+ *   return_counts)` as run-length grouping (eigvals ascending, what eigh returns; else meta[2] bit 0), and the order in which the
+ *   reference stacks the projectors: by multiplicity ascending, eigenvalue order inside a multiplicity.  All outputs device int32:
+ *   space_of[N] (eigenspace of every eigenvector), space_start[N+1] (first eigenvector of every eigenspace, [n_spaces] = N),
+ *   space_mult[N], space_slot[N] (position of the eigenspace in the multiplicity-major stack), mult_list[N] / mult_count[N] (sorted
+ *   distinct multiplicities and how many eigenspaces have each), meta[4] = {n_spaces, n_mults, error bits, largest multiplicity}.
+ *   One workgroup; N <= 8192.  A one-off per graph: the caller reads meta / mult_list / mult_count back once to size its tensors.
+ * sn_eigenspace_projectors_f32: out[space_slot[s], :, :] = V_s V_s^T (`projectors = [V @ V.T ...]`, `torch.cat` by multiplicity):
+ *   out is the [n_spaces, N, N] stack; eigvecs row-major [N, ldv] with V[node, eigenvector] (training.py:42-43).
+ * sn_ign_contract_eigvecs_f32: the five 2->1 contractions of every P_s = V_s V_s^T (contractions_2_to_1, ign.py:344-374, what
+ *   sn_ign_contract_2to1_f32 computes from the projector) evaluated from V_s alone — out [n_spaces, N, 5] in slot order; reads
+ *   4*N*mult bytes per eigenspace instead of 4*N^2.  Same maths, different fp32 summation order. */
+int sn_eigenspace_group(const float* eigvals, int N, int decimals, int32_t* space_of, int32_t* space_start, int32_t* space_mult,
+                        int32_t* space_slot, int32_t* mult_list, int32_t* mult_count, int32_t* meta, void* stream);
+int sn_eigenspace_projectors_f32(const float* eigvecs, int N, int ldv, const int32_t* space_start, const int32_t* space_slot,
+                                 int n_spaces, float* out, void* stream);
+int sn_ign_contract_eigvecs_f32(const float* eigvecs, int N, int ldv, const int32_t* space_start, const int32_t* space_slot,
+                                int n_spaces, int max_mult, float* out, void* stream);
+
 /* GatedGCN edge-gated aggregation.  Replaces the DGL message passing of GatedGCNLayer.forward
  * (GraphPrediction/layers/gatedgcn_layer.py:51-56: apply_edges(u_add_v) + sigmoid + two update_all sums):
  *   e_out[e,:] = Dh[src(e),:] + Eh[dst(e),:] + Ce[e,:];   sigma = sigmoid(e_out)

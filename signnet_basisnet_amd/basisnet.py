@@ -103,18 +103,22 @@ class IGN2to1(nn.Module):
         return ops.masked_affine(y, scale=sc, shift=sh)
 
     def forward(self, x):
-        train = self.training     # forward VALUE with batch statistics (no autograd)
         ops.require_cuda(x)
+        return self.forward_contractions(ops.ign_contract_2to1(x.contiguous()))           # [b, n, 5]
+
+    def forward_contractions(self, o):
+        """Everything after the 2->1 contractions: o [b, n, 5] = contractions_2_to_1 of the input stack (ign.py:344-374), from
+        sn_ign_contract_2to1_f32 (the projectors) or sn_ign_contract_eigvecs_f32 (the eigenvectors alone)."""
+        train = self.training     # forward VALUE with batch statistics (no autograd)
         if train:
             P = self._prepare(True)
         else:
             if self._prep is None:
                 self._prep = self._prepare()
             P = self._prep
-        b, n = x.shape[0], x.shape[-1]
-        o = ops.ign_contract_2to1(x.contiguous())                                          # [b, n, 5]
-        h = self._relu_bn(o.view(b * n, 5), P["l0"], P["bn"][0], train)
-        seg = torch.arange(0, b * n + 1, n, dtype=torch.int32, device=x.device)             # rows of matrix i: [i*n, (i+1)*n)
+        b, n = o.shape[0], o.shape[1]
+        h = self._relu_bn(o.reshape(b * n, 5), P["l0"], P["bn"][0], train)
+        seg = torch.arange(0, b * n + 1, n, dtype=torch.int32, device=o.device)             # rows of matrix i: [i*n, (i+1)*n)
         segplan = _SegPlan(b, seg)
         for li, name in ((1, "l1"), (2, "l2")):
             m = ops.segment_pool(h, segplan, "mean")                                       # [b, H]   sum_n h / n (ign.py:405-414)
@@ -145,6 +149,14 @@ class IGNBasisInv(nn.Module):
 
     def forward(self, proj, mult):
         return self.encs[self.mult_to_idx[mult]](proj)
+
+    def forward_eigvecs(self, eigvecs, plan, contractions=None):
+        """Extension (not in the reference): every multiplicity group evaluated from the eigenvectors alone — the 2->1
+        contractions of P = V V^T are computed from V (4*N*mult bytes per eigenspace instead of the 4*N^2 of the projector;
+        SURVEY.md §8 a20).  Returns {mult: [b, mult, N]}, the values `forward(same_size_projs[mult], mult)` gives (same maths,
+        different fp32 summation order in the contractions)."""
+        o = ops.ign_contract_eigvecs(eigvecs, plan) if contractions is None else contractions
+        return {m: self.encs[self.mult_to_idx[m]].forward_contractions(plan.group(o, m)).contiguous() for m in plan.mults}
 
 
 class IGNShared(nn.Module):
@@ -232,15 +244,13 @@ class SignPlus(nn.Module):
         return ops.masked_affine(a.contiguous().view(-1, a.shape[-1]), residual=b.contiguous().view(-1, b.shape[-1])).view(a.shape)
 
 
-def group_eigenspaces(eigvals, eigvecs, decimals=5):
-    """Host-side restatement of the module-level preprocessing of LearningFilters/training.py:47-73 (run once per
-    graph, not part of the forward): projectors V_i V_i^T of the eigenspaces, stacked by multiplicity."""
-    N = eigvecs.shape[0]
-    rounded = torch.round(eigvals * 10 ** decimals) / (10 ** decimals)
-    _, counts = rounded.unique(return_counts=True)
-    sections = torch.cumsum(counts, 0).cpu()
-    spaces = torch.tensor_split(eigvecs, sections, dim=1)[:-1]
-    groups = {}
-    for V, c in zip(spaces, counts.tolist()):
-        groups.setdefault(c, []).append((V @ V.T).reshape(1, 1, N, N))
-    return {m: torch.cat(ps, 0) for m, ps in sorted(groups.items())}
+def group_eigenspaces(eigvals, eigvecs, decimals=5, return_plan=False):
+    """The module-level preprocessing of LearningFilters/training.py:47-73 on the device (run once per graph): eigenvalues
+    rounded to `decimals`, eigenvectors grouped by rounded value, P = V_s V_s^T per eigenspace, stacked by multiplicity.
+    Returns {mult: [b, 1, N, N]} (views of one [n_spaces, N, N] device buffer, ascending multiplicity — the reference's
+    `same_size_projs`); with return_plan also the ops.EigenspacePlan (for IGNBasisInv.forward_eigvecs)."""
+    plan = ops.eigenspace_group(eigvals, decimals)
+    stack = ops.eigenspace_projectors(eigvecs, plan)
+    N = plan.N
+    groups = {m: plan.group(stack, m).view(-1, 1, N, N) for m in plan.mults}
+    return (groups, plan) if return_plan else groups

@@ -512,6 +512,70 @@ def ign_contract_2to1(X):
     return out
 
 
+class EigenspacePlan:
+    """Device-side result of sn_eigenspace_group (LearningFilters/training.py:47-61 without the projectors) + the few numbers the
+    host needs to size tensors (read back once: this is a per-graph one-off, as in the reference).
+    mults: sorted distinct multiplicities; counts[i]: eigenspaces with multiplicity mults[i]; slot_base[i]: first slot of that
+    multiplicity in the multiplicity-major stack (the order of the reference's {mult: torch.cat(projectors)} dict)."""
+
+    def __init__(self, N, space_of, space_start, space_mult, space_slot, mults, counts, n_spaces, max_mult):
+        self.N, self.space_of, self.space_start, self.space_mult, self.space_slot = N, space_of, space_start, space_mult, space_slot
+        self.mults, self.counts, self.n_spaces, self.max_mult = mults, counts, n_spaces, max_mult
+        self.slot_base = {}
+        off = 0
+        for m, c in zip(mults, counts):
+            self.slot_base[m] = off
+            off += c
+
+    def group(self, stack, mult):
+        """The rows of a [n_spaces, ...] slot-ordered stack that belong to multiplicity `mult`."""
+        i = self.mults.index(mult)
+        off = self.slot_base[mult]
+        return stack[off:off + self.counts[i]]
+
+
+def eigenspace_group(eigvals, decimals=5) -> EigenspacePlan:
+    """`around(eigvals, 5)` + `unique(return_counts)` + the multiplicity grouping of training.py:47-73, on the device."""
+    require_cuda(eigvals)
+    ev = _f32c(eigvals, "eigvals")
+    N = ev.numel()
+    ints = torch.empty(6 * N + 8, dtype=torch.int32, device=ev.device)
+    space_of, space_start, space_mult, space_slot = ints[:N], ints[N:2 * N + 1], ints[2 * N + 1:3 * N + 1], ints[3 * N + 1:4 * N + 1]
+    mult_list, mult_count, meta = ints[4 * N + 1:5 * N + 1], ints[5 * N + 1:6 * N + 1], ints[6 * N + 1:6 * N + 5]
+    check(lib().sn_eigenspace_group(ptr(ev), N, int(decimals), ptr(space_of), ptr(space_start), ptr(space_mult), ptr(space_slot),
+                                    ptr(mult_list), ptr(mult_count), ptr(meta), stream()), "sn_eigenspace_group")
+    ns, nm, err, mmax = meta.tolist()                   # one host sync (per graph, once)
+    if err:
+        raise ValueError("eigenspace_group: the eigenvalues must be in ascending order (as eigh returns them)")
+    return EigenspacePlan(N, space_of, space_start, space_mult, space_slot, mult_list[:nm].tolist(), mult_count[:nm].tolist(), ns, mmax)
+
+
+def eigenspace_projectors(eigvecs, plan: EigenspacePlan):
+    """[n_spaces, N, N] stack of P_s = V_s V_s^T in multiplicity-major order (training.py:61-73)."""
+    require_cuda(eigvecs)
+    V = _f32c(eigvecs, "eigvecs")
+    N = plan.N
+    if V.shape != (N, N):
+        raise ValueError("eigenspace_projectors: eigvecs must be [N, N] (V[node, eigenvector])")
+    out = torch.empty(plan.n_spaces, N, N, dtype=torch.float32, device=V.device)
+    with _span("sn_eigenspace_projectors_f32"):
+        check(lib().sn_eigenspace_projectors_f32(ptr(V), N, N, ptr(plan.space_start), ptr(plan.space_slot), plan.n_spaces, ptr(out),
+                                                 stream()), "sn_eigenspace_projectors_f32")
+    return out
+
+
+def ign_contract_eigvecs(eigvecs, plan: EigenspacePlan):
+    """The 2->1 contractions [n_spaces, N, 5] of every projector V_s V_s^T, computed from V alone (no N x N matrix)."""
+    require_cuda(eigvecs)
+    V = _f32c(eigvecs, "eigvecs")
+    N = plan.N
+    out = torch.empty(plan.n_spaces, N, 5, dtype=torch.float32, device=V.device)
+    with _span("sn_ign_contract_eigvecs_f32"):
+        check(lib().sn_ign_contract_eigvecs_f32(ptr(V), N, N, ptr(plan.space_start), ptr(plan.space_slot), plan.n_spaces,
+                                                plan.max_mult, ptr(out), stream()), "sn_ign_contract_eigvecs_f32")
+    return out
+
+
 EVD_STATUS = {1: "an edge leaves its graph (or a node id is out of range)", 2: "a graph has more than 64 nodes",
               4: "the Jacobi iteration did not converge", 8: "eigen_vectors buffer too small"}
 

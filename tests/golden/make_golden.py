@@ -212,12 +212,66 @@ def dgl_gatedgcn_case(name, hidden, L, k, sizes, seed, pe_aggregate):
 
 
 # ------------------------------------------------------------------ LearningFilters
+def reference_grouping(eigvals, eigvecs):
+    """Eigenspace grouping by EXECUTING the reference's own statements: LearningFilters/training.py is a script (argparse and
+    dataset loading at module level), so lines 47-73 — `around()` and the whole `if args.lap_method == 'basis_inv':` block — are read
+    from the reference file at generation time and exec'd in a namespace that supplies the names the script has defined by
+    then (`eigvals`, `eigvecs`, `N`, `args`, `torch`).  Nothing of that source is stored in the repo; the fixture holds the
+    resulting arrays only.  Returns (counts, uniq_mults, {mult: [b,1,N,N]})."""
+    import contextlib
+    import io
+    lines = open(os.path.join(REF, "LearningFilters", "training.py")).read().splitlines()
+    block = "\n".join(lines[46:73])                    # 1-based lines 47..73
+    assert block.lstrip().startswith("def around(") and "same_size_projs[mult] = torch.cat(projs, dim=0)" in block, \
+        "the reference file moved: re-check the line range of the grouping block"
+    ns = {"torch": torch, "eigvals": eigvals, "eigvecs": eigvecs, "N": eigvecs.shape[0],
+          "args": types.SimpleNamespace(lap_method="basis_inv")}
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(block, "reference:LearningFilters/training.py:47-73", "exec"), ns)
+    return ns["counts"], ns["uniq_mults"], ns["same_size_projs"]
+
+
+def grid_eig(side, normalised_f64=False):
+    """Eigen-data of the side x side grid as the reference computes it (utils.py:67-78: dense sym-normalised Laplacian in float64,
+    scipy/numpy eigh, then `.float()` in training.py:42-43)."""
+    ei, N = synth.grid_graph(side)
+    A = np.zeros((N, N))
+    A[ei[0], ei[1]] = 1.0
+    dis = 1.0 / np.sqrt(A.sum(1))
+    L = np.eye(N) - np.diag(dis) @ A @ np.diag(dis)
+    w, V = np.linalg.eigh(L)
+    return ei, N, torch.from_numpy(w).float(), torch.from_numpy(V).float()
+
+
+def grouping_case(name, sides):
+    """Fixture of the grouping itself, pinned to the reference's statements: eigenvalue multiplicities, the
+    multiplicity groups and every projector.  Small grids store the projector stacks in full; larger ones store, per projector,
+    the two vectors the IGN 2->1 layer reads from it (diagonal and row sums, ign.py:344-374) plus its trace and total."""
+    arrays = {"meta/sides": np.array(sides, dtype=np.int64)}
+    for side in sides:
+        ei, N, D, V = grid_eig(side)
+        counts, uniq_mults, projs = reference_grouping(D, V)
+        t = f"s{side}"
+        arrays[f"in/{t}/eigvals"], arrays[f"in/{t}/eigvecs"] = D.numpy(), V.numpy()
+        arrays[f"out/{t}/counts"] = counts.numpy().astype(np.int64)
+        arrays[f"out/{t}/mults"] = uniq_mults.numpy().astype(np.int64)
+        for m, P in projs.items():
+            assert P.shape[1:] == (1, N, N)
+            if N <= 64:
+                arrays[f"out/{t}/proj_m{m}"] = P.numpy()
+            Pd = P[:, 0].double()
+            arrays[f"out/{t}/sig_m{m}"] = torch.stack([torch.diagonal(Pd, dim1=1, dim2=2), Pd.sum(2)], dim=2).float().numpy()   # [b,N,2]
+            arrays[f"out/{t}/tr_m{m}"] = torch.diagonal(Pd, dim1=1, dim2=2).sum(1).numpy()
+            arrays[f"out/{t}/tot_m{m}"] = Pd.sum((1, 2)).numpy()
+    save(name, **arrays)
+
+
 def basisnet_case(name, side, hidden, seed):
     ign, sbn, models = _fresh_import("LearningFilters", ["ign", "signbasisnet", "models"])
     from oracle import basisnet as ob
     ei, N = synth.grid_graph(side)
     D, V = synth.sym_laplacian_eigh(ei, N)
-    groups, counts = ob.group_eigenspaces(D, V)        # restates training.py:47-73 (module-level code)
+    counts, _, groups = reference_grouping(D, V)        # training.py:47-73 executed (module-level code of a script)
     mults = sorted(groups)
     torch.manual_seed(seed)
     # IGNBasisInv builds IGN2to1 with device='cuda' (signbasisnet.py:33) -> build the pieces on CPU
@@ -306,6 +360,7 @@ def main():
     dgl_gatedgcn_case("dgl_gatedgcn_add_k8", 28, 2, 8, [6, 4, 11, 2], 35, "add")
     # BasisNet on a small grid
     basisnet_case("basisnet_grid6", 6, 8, 41)
+    grouping_case("basisnet_grouping", [6, 12, 32])
     # eigendecomposition transform: sizes across the kernel's 16 / 32 / 64-lane classes, odd and even, 1- and 2-node graphs
     evd_case("evd_transform", [1, 2, 3, 8, 15, 16, 17, 23, 31, 32, 33, 37, 48, 63, 64], 51)
 

@@ -84,7 +84,7 @@ def test_basisnet_golden():
     fx = G.load("basisnet_grid6")
     D, V = fx.inp["eigvals"], fx.inp["eigvecs"]
     N = V.shape[0]
-    groups = BN.group_eigenspaces(D, V)
+    groups = BN.group_eigenspaces(D.to(DEV), V.to(DEV))          # device op (sn_eigenspace_group + sn_eigenspace_projectors_f32)
     mults = [int(m) for m in fx.meta["mults"]]
     assert sorted(groups) == mults
     hidden = int(fx.meta["hidden"])
@@ -97,11 +97,11 @@ def test_basisnet_golden():
         enc.load_state_dict(sd)
     net = net.to(DEV).eval()
     for m in mults:
-        o = net(groups[m].to(DEV), m)
+        o = net(groups[m], m)
         sdm = {k.split("/", 1)[1]: v for k, v in fx.sd.items() if k.startswith(f"enc{m}/")}
         eq64 = [(fx.eq[f"enc{m}/{i}/coeffs"].double(), fx.eq[f"enc{m}/{i}/bias"].double()) for i in range(3)]
         with torch.no_grad():
-            r64 = OB.ign2to1(PU.to_f64(sdm), eq64, groups[m].double(), training=False)
+            r64 = OB.ign2to1(PU.to_f64(sdm), eq64, groups[m].cpu().double(), training=False)
         close(o, fx.out[f"eval/phi_m{m}"], f"IGN2to1 mult {m}", ref64=r64)
         outs.append(o.cpu())
     # rho on the reference's own phi outputs (identical inputs on both sides; the phi stage is checked above).  Its BatchNorm has
@@ -164,7 +164,7 @@ def test_ign_train_mode_forward():
     """IGN2to1.train(): BatchNorm1d(hidden) with batch statistics over the b*n rows of [b, hidden, n] (ign.py:31-33)."""
     from signnet_basisnet_amd import basisnet as BN
     fx = G.load("basisnet_grid6")
-    groups = BN.group_eigenspaces(fx.inp["eigvals"], fx.inp["eigvecs"])
+    groups = BN.group_eigenspaces(fx.inp["eigvals"].to(DEV), fx.inp["eigvecs"].to(DEV))
     mults = [int(m) for m in fx.meta["mults"]]
     net = BN.IGNBasisInv(mults, 1, hidden_channels=int(fx.meta["hidden"]))
     for m in mults:
@@ -173,7 +173,7 @@ def test_ign_train_mode_forward():
     net = net.to(DEV).train()
     for m in mults:
         with torch.no_grad():
-            o = net(groups[m].to(DEV), m)
+            o = net(groups[m], m)
         torch.testing.assert_close(o.cpu(), fx.out[f"train/phi_m{m}"], rtol=2e-3, atol=2e-4)
         enc = net.encs[net.mult_to_idx[m]]
         assert int(enc.bns[0].num_batches_tracked) == int(fx.sd[f"enc{m}/bns.0.num_batches_tracked"]) + 1
@@ -184,7 +184,7 @@ def test_ign_shared_vs_oracle():
     from oracle import basisnet as OB
     from signnet_basisnet_amd import basisnet as BN
     fx = G.load("basisnet_grid6")
-    groups = BN.group_eigenspaces(fx.inp["eigvals"], fx.inp["eigvecs"])
+    groups = BN.group_eigenspaces(fx.inp["eigvals"].to(DEV), fx.inp["eigvecs"].to(DEV))
     mults = sorted(groups)
     torch.manual_seed(3)
     net = BN.IGNShared(mults, 1, hidden_channels=8)
@@ -199,9 +199,9 @@ def test_ign_shared_vs_oracle():
     net = net.to(DEV).eval()
     for m in mults:
         with torch.no_grad():
-            ref = OB.ign_shared(sd, eq, groups[m], net.mult_to_idx[m])
-            r64 = OB.ign_shared(PU.to_f64(sd), [(a.double(), b.double()) for a, b in eq], groups[m].double(), net.mult_to_idx[m])
-        y = net(groups[m].to(DEV), m)
+            ref = OB.ign_shared(sd, eq, groups[m].cpu(), net.mult_to_idx[m])
+            r64 = OB.ign_shared(PU.to_f64(sd), [(a.double(), b.double()) for a, b in eq], groups[m].cpu().double(), net.mult_to_idx[m])
+        y = net(groups[m], m)
         assert y.shape == ref.shape == (groups[m].shape[0], m, groups[m].shape[-1])
         close(y, ref, f"IGNShared mult {m}", ref64=r64)
 
@@ -272,3 +272,62 @@ def test_dgl_gatedgcn_base_net_golden(name, mode):
     else:
         torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=1e-3, atol=1e-4)
         torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("side", [6, 12, 32])
+def test_eigenspace_grouping_device_op_vs_reference_statements(side):
+    """SURVEY.md §8 a18 on the device: sn_eigenspace_group / sn_eigenspace_projectors_f32 against the fixture produced by EXECUTING
+    LearningFilters/training.py:47-73 (tests/golden/make_golden.py::reference_grouping).  Integer results (multiplicities, grouping,
+    stacking order) bit-exact; projector entries are fp32 dot products of <= 32 terms whose order differs from the CPU BLAS:
+    1e-6 of the largest entry.  The projector-free contractions (sn_ign_contract_eigvecs_f32) against the same fixture."""
+    from signnet_basisnet_amd import basisnet as BN
+    from signnet_basisnet_amd import ops
+    fx = G.load("basisnet_grouping")
+    t = f"s{side}"
+    D, V = fx.inp[f"{t}/eigvals"].to(DEV), fx.inp[f"{t}/eigvecs"].to(DEV)
+    N = V.shape[0]
+    groups, plan = BN.group_eigenspaces(D, V, return_plan=True)
+    counts = fx.out[f"{t}/counts"]
+    assert plan.mults == fx.out[f"{t}/mults"].tolist() and plan.n_spaces == counts.numel()
+    assert plan.space_mult[:plan.n_spaces].cpu().tolist() == counts.tolist()
+    assert plan.space_start[:plan.n_spaces + 1].cpu().tolist() == [0] + counts.cumsum(0).tolist()
+    assert plan.space_of.cpu().tolist() == torch.repeat_interleave(torch.arange(counts.numel()), counts).tolist()
+    contr = ops.ign_contract_eigvecs(V, plan)
+    for m in plan.mults:
+        P = groups[m]
+        b = int((counts == m).sum())
+        assert P.shape == (b, 1, N, N)
+        sig = fx.out[f"{t}/sig_m{m}"].double()                                    # [b, N, 2]: diagonal, row sums (float64 of the reference projector)
+        Pd = P[:, 0].double().cpu()
+        if f"{t}/proj_m{m}" in fx.out:
+            ref = fx.out[f"{t}/proj_m{m}"]
+            scale = ref.abs().max().item()
+            assert (P.cpu() - ref).abs().max().item() <= 1e-6 * scale
+        dscale = sig[..., 0].abs().max().item()
+        assert (torch.diagonal(Pd, dim1=1, dim2=2) - sig[..., 0]).abs().max().item() <= 2e-6 * dscale
+        assert (Pd.sum(2) - sig[..., 1]).abs().max().item() <= 2e-5 * dscale * 1.0 + 1e-6      # a row sum adds N entries of size <= dscale
+        # projector-free contractions: [diag, tr/n, rowsum/n, colsum/n, total/n^2]
+        c = plan.group(contr, m).double().cpu()
+        assert (c[..., 0] - sig[..., 0]).abs().max().item() <= 2e-6 * dscale
+        assert (c[..., 2] - sig[..., 1] / N).abs().max().item() <= 2e-6 * dscale and torch.equal(c[..., 2], c[..., 3])
+        assert (c[:, 0, 1] - fx.out[f"{t}/tr_m{m}"] / N).abs().max().item() <= 1e-5 * m / N
+        assert (c[:, 0, 4] - fx.out[f"{t}/tot_m{m}"] / N ** 2).abs().max().item() <= 1e-6 * m / N
+        # and they agree with the contraction kernel applied to the device-built projectors
+        c2 = ops.ign_contract_2to1(P).double().cpu()
+        assert (c - c2).abs().max().item() <= 2e-6 * dscale
+
+
+def test_basisnet_from_eigenvectors_equals_projector_path():
+    """IGNBasisInv.forward_eigvecs (contractions from V alone) against the reference API on the stacked projectors."""
+    from signnet_basisnet_amd import basisnet as BN
+    fx = G.load("basisnet_grouping")
+    D, V = fx.inp["s12/eigvals"].to(DEV), fx.inp["s12/eigvecs"].to(DEV)
+    groups, plan = BN.group_eigenspaces(D, V, return_plan=True)
+    torch.manual_seed(0)
+    net = BN.IGNBasisInv(plan.mults, 1, hidden_channels=16)
+    PU.bn_randomize(net, 3)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        fast = net.forward_eigvecs(V, plan)
+        for m in plan.mults:
+            close(fast[m], net(groups[m], m), f"forward_eigvecs mult {m}", rel=1e-5)

@@ -154,3 +154,22 @@ def test_dgl_gatedgcn_base_net(name, mode):
     torch.testing.assert_close(p, fx.out[f"{mode}/p"], **tol)
     torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **tol)
     torch.testing.assert_close(y, fx.out[f"{mode}/y"], **tol)
+
+
+@pytest.mark.parametrize("side", [6, 12, 32])
+def test_oracle_grouping_vs_reference_statements(side):
+    """oracle.basisnet.group_eigenspaces against the fixture produced by executing LearningFilters/training.py:47-73 itself
+    (tests/golden/make_golden.py::reference_grouping): multiplicities and stacking order exactly, projectors to fp32 rounding."""
+    fx = G.load("basisnet_grouping")
+    t = f"s{side}"
+    D, V = fx.inp[f"{t}/eigvals"], fx.inp[f"{t}/eigvecs"]
+    groups, counts = OB.group_eigenspaces(D, V)
+    assert counts.tolist() == fx.out[f"{t}/counts"].tolist()
+    assert sorted(groups) == fx.out[f"{t}/mults"].tolist()
+    for m, P in groups.items():
+        if f"{t}/proj_m{m}" in fx.out:
+            assert torch.equal(P, fx.out[f"{t}/proj_m{m}"])        # same torch ops in the same order: bit-identical
+        sig = fx.out[f"{t}/sig_m{m}"]
+        Pd = P[:, 0].double()
+        torch.testing.assert_close(torch.diagonal(Pd, dim1=1, dim2=2).float(), sig[..., 0], rtol=0, atol=0)
+        torch.testing.assert_close(Pd.sum(2).float(), sig[..., 1], rtol=0, atol=0)
