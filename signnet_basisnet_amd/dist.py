@@ -14,19 +14,47 @@ import types
 import torch
 
 
-def shard_range(num_graphs: int, rank: int, world: int):
-    """Contiguous, balanced [lo, hi) range of graph ids owned by `rank`."""
-    base, rem = divmod(num_graphs, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+def shard_range(num_graphs: int, rank: int, world: int, work=None):
+    """Contiguous [lo, hi) range of graph ids owned by `rank`.  Without `work`: balanced graph COUNT.  With `work` (one non-negative
+    number per graph, e.g. n_b * min(n_b, k) — the phi / rho rows a graph contributes, n_b^2 in the reference's all-eigenvector
+    mode): contiguous ranges whose work sums are as equal as a prefix split allows (boundary r = the first
+    graph at which the running sum reaches r/world of the total; ranges stay contiguous so that no collation is needed)."""
+    if work is None:
+        base, rem = divmod(num_graphs, world)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+    w = [float(v) for v in work]
+    if len(w) != num_graphs:
+        raise ValueError("shard_range: one work value per graph expected")
+    total = sum(w)
+    if total <= 0:
+        return shard_range(num_graphs, rank, world)
+    bounds, run, r = [0], 0.0, 1
+    for i, v in enumerate(w):
+        run += v
+        while r < world and run >= total * r / world - 1e-9:
+            # graph i closes range r-1 unless leaving it to the next range is closer to the target
+            cut = i + 1 if (run - total * r / world) <= (total * r / world - (run - v)) else i
+            bounds.append(max(cut, bounds[-1]))
+            r += 1
+    while len(bounds) < world:
+        bounds.append(num_graphs)
+    bounds.append(num_graphs)
+    return bounds[rank], bounds[rank + 1]
 
 
-def shard_batch(data, rank: int, world: int):
+def shard_batch(data, rank: int, world: int, balance: str = "count", max_k=None):
     """Slice a collated batch (the duck-typed layout of SURVEY.md §8(b)) down to this rank's graphs.
-    Pure indexing on the host; node / edge ids are re-based to the shard."""
+    Pure indexing on the host; node / edge ids are re-based to the shard.  balance="rows": ranges of equal phi / rho work
+    (sum of n_b * min(n_b, max_k), i.e. n_b^2 with all eigenvectors) instead of equal graph count."""
     B = int(data.num_graphs)
-    lo, hi = shard_range(B, rank, world)
     sizes = list(data.sizes) if hasattr(data, "sizes") else torch.bincount(data.batch, minlength=B).tolist()
+    if balance == "rows":
+        lo, hi = shard_range(B, rank, world, [n * (min(n, int(max_k)) if max_k else n) for n in sizes])
+    elif balance == "count":
+        lo, hi = shard_range(B, rank, world)
+    else:
+        raise ValueError("balance must be 'count' or 'rows'")
     nstart = sum(sizes[:lo])
     nend = nstart + sum(sizes[lo:hi])
     vstart = sum(s * s for s in sizes[:lo])

@@ -69,6 +69,29 @@ def test_shard_ranges_cover_everything():
             assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
 
 
+def test_work_balanced_shard_ranges():
+    """ranks get contiguous graph ranges of (nearly) equal phi work sum n_b * min(n_b, k), not equal graph count."""
+    import numpy as np
+    from signnet_basisnet_amd import dist, synth
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(9, 38, size=1024).tolist()
+    for k in (None, 16):
+        work = [n * (min(n, k) if k else n) for n in sizes]
+        for W in (2, 4, 8):
+            rs = [dist.shard_range(len(sizes), r, W, work) for r in range(W)]
+            assert rs[0][0] == 0 and rs[-1][1] == len(sizes) and all(rs[i][1] == rs[i + 1][0] for i in range(W - 1))
+            loads = [sum(work[l:h]) for l, h in rs]
+            assert max(loads) - min(loads) <= 2 * max(work), (k, W, loads)
+            by_count = [sum(work[l:h]) for l, h in (dist.shard_range(len(sizes), r, W) for r in range(W))]
+            assert max(loads) <= max(by_count) + max(work)
+    # degenerate inputs
+    assert dist.shard_range(3, 0, 8, [5, 1, 1])[0] == 0
+    assert [dist.shard_range(3, r, 8, [5, 1, 1]) for r in range(8)][-1][1] == 3
+    data = synth.make_batch(12, seed=3)
+    parts = [dist.shard_batch(data, r, 3, balance="rows", max_k=8) for r in range(3)]
+    assert sum(p.num_graphs for p in parts) == 12 and sum(p.num_nodes for p in parts) == data.num_nodes
+
+
 def test_dropin_import_paths(monkeypatch):
     """The dotted names the reference's entry scripts import resolve to the HIP modules."""
     import importlib
