@@ -296,6 +296,25 @@ int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scr
 int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, void* stream);
 
+/* Message passing of the DGL tree's PNA and sparse-Transformer base networks, over the destination-sorted CSR
+ * of sn_batch_plan (in-edges in edge-id order: no atomics, reproducible sums).
+ * sn_pna_aggregate_f32: PNATower.reduce_func_for_h (GraphPrediction/layers/pna_layer.py:50-56) with aggregators 'mean max min std'
+ *   (pna_utils.py:13-36) and scalers 'identity amplification attenuation' (:68-81, avg_log = avg_d['log']): msg [E, ldm] in edge-id
+ *   order -> out[n, off + (4*s + a)*C + c]; with `hself` the node's own C-channel row is copied to out[n, 0:C] first (off = C: the
+ *   tower's torch.cat([h, aggregated]), :69), else off = 0.  Nodes without in-edges get zeros.
+ * sn_edge_attention_f32: MultiHeadAttentionLayer.propagate_attention (layers/transformer.py:150-195; full_graph False, edge features):
+ *   out[i,h,:] = sum_{j->i} s V[j,h,:] / (sum s + 1e-6), s = exp(clamp(sum_c K[j,h,c] Q[i,h,c] / sqrt(dk) * E[e,h,c], -5, 5)); Q/K/V
+ *   [N, heads*dk], Ee [E, heads*dk] in edge-id order, dk <= 32.
+ * sn_pointwise_f32: y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual, act 0 none / 1 ReLU / 2 LeakyReLU(slope); rowscale,
+ *   (scale, shift) and residual are optional — PNA's graph_norm (h * snorm_n, pna_layer.py:75-76) + BatchNorm, and the LeakyReLU of
+ *   its mixing FCLayer (:126). */
+int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hself, int ldh, int C, int64_t N, const int32_t* rowptr,
+                         const int32_t* eperm, float avg_log, float* out, int ldo, void* stream);
+int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const float* Ee, int64_t N, int heads, int dk,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream);
+int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,
+                     float slope, const float* residual, int ldr, float* y, int ldy, void* stream);
+
 /* BasisNet preprocessing on the device — replaces the module-level code of LearningFilters/training.py:47-73.
  * sn_eigenspace_group: `around(eigvals, decimals)` (round-half-even of x*10^decimals, fp32 as torch evaluates it), `unique(...,
  *   return_counts)` as run-length grouping (eigvals ascending, what eigh returns; else meta[2] bit 0), and the order in which the

@@ -1,0 +1,149 @@
+// dgl_layers.hip — message passing of the two remaining DGL base networks that consume the sign-invariant positional encoding
+// (SURVEY.md §8 row f3): PNA (GraphPrediction/layers/pna_layer.py + pna_utils.py) and the sparse graph Transformer
+// (GraphPrediction/layers/transformer.py).  Both reduce per-edge quantities over each node's in-edges; the destination-sorted
+// CSR of sn_batch_plan (in-edges in edge-id order, the order DGL's reduce sees them) is the iteration space, so there are no
+// atomics and the sums are reproducible.  HBM-bound gathers over small feature rows; one thread per (node, channel) /
+// (node, head).
+#include "common.hpp"
+
+namespace sn {
+
+// PNATower.reduce_func_for_h (pna_layer.py:50-56) with aggregators 'mean max min std' (pna_utils.py:13-36, EPS 1e-5) and scalers
+// 'identity amplification attenuation' (:68-81): out[n, C0 + (3*s... ] — layout = cat_scalers(cat_aggregators):
+//   out[n, off + (4*s + a)*C + c],  a in {mean, max, min, std},  s in {1, log(D+1)/avg_log, avg_log/log(D+1)}
+// plus (optional) the node's own row in the first C columns — the tower's `torch.cat([h, g.ndata['h']], dim=1)` (:69).
+// A node without in-edges gets zeros (DGL does not call the reduce function for it).
+__global__ __launch_bounds__(256) void k_pna_aggregate(const float* __restrict__ msg, int ldm, const float* __restrict__ hself, int ldh,
+                                                       int C, int64_t N, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ eperm, float avg_log, float* __restrict__ out,
+                                                       int ldo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int64_t n = i / C;
+  const int c = (int)(i - n * C);
+  const int lo = rowptr[n], hi = rowptr[n + 1];
+  float s1 = 0.f, s2 = 0.f, mx = -INFINITY, mn = INFINITY;
+  for (int e = lo; e < hi; ++e) {
+    const float v = msg[(int64_t)eperm[e] * ldm + c];
+    s1 += v;
+    s2 += v * v;
+    mx = fmaxf(mx, v);
+    mn = fminf(mn, v);
+  }
+  float* o = out + n * ldo;
+  int off = 0;
+  if (hself != nullptr) { o[c] = hself[n * ldh + c]; off = C; }
+  const int D = hi - lo;
+  if (D == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[off + k * C + c] = 0.f;
+    return;
+  }
+  const float inv = 1.0f / (float)D;
+  const float mean = s1 * inv;
+  const float var = fmaxf(s2 * inv - mean * mean, 0.f);          // torch.relu(E[x^2] - E[x]^2)
+  const float sd = sqrtf(var + 1e-5f);
+  const float logd = logf((float)D + 1.0f);
+  const float amp = logd / avg_log, att = avg_log / logd;
+  const float a[4] = {mean, mx, mn, sd};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[off + k * C + c] = a[k];
+    o[off + (4 + k) * C + c] = a[k] * amp;
+    o[off + (8 + k) * C + c] = a[k] * att;
+  }
+}
+
+// MultiHeadAttentionLayer.propagate_attention (transformer.py:150-195, full_graph False, edge features): per in-edge (j -> i, id e)
+// and head h:  score = sum_c K[j,h,c] * Q[i,h,c] / sqrt(dk) * E[e,h,c];  s = exp(clamp(score, -5, 5));
+// out[i,h,:] = sum_e s * V[j,h,:] / (sum_e s + 1e-6).  One thread per (node, head); dk <= 32.
+__global__ __launch_bounds__(256) void k_edge_attention(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                        const float* __restrict__ Ee, int64_t N, int H, int dk,
+                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                        const int32_t* __restrict__ eperm, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * dk;
+  const float root = sqrtf((float)dk);
+  float q[32], acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) { q[c] = c < dk ? Q[n * d + h * dk + c] : 0.f; acc[c] = 0.f; }
+  float z = 0.f;
+  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+    const int64_t j = col[e], eid = eperm[e];
+    const float* kr = K + j * d + h * dk;
+    const float* er = Ee + eid * d + h * dk;
+    const float* vr = V + j * d + h * dk;
+    float sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < dk) sc += ((kr[c] * q[c]) / root) * er[c];              // src_dot_dst, scaling, imp_exp_attn — in the reference's order
+    const float s = expf(fminf(fmaxf(sc, -5.f), 5.f));
+    z += s;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < dk) acc[c] += vr[c] * s;
+  }
+  const float r = 1.0f / (z + 1e-6f);
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    if (c < dk) out[n * d + h * dk + c] = acc[c] * r;
+}
+
+// y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual    (any of rowscale / scale+shift / residual may be absent)
+// act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  Covers PNA's graph_norm (h * snorm_n) + BatchNorm and its mixing FCLayer's LeakyReLU.
+__global__ __launch_bounds__(256) void k_pointwise(const float* __restrict__ x, int ldx, int64_t R, int C, const float* __restrict__ rowscale,
+                                                   const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope,
+                                                   const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  float v = x[r * ldx + c];
+  if (rowscale) v *= rowscale[r];
+  if (scale) v = v * scale[c] + shift[c];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = v > 0.f ? v : v * slope;
+  if (res) v += res[r * ldr + c];
+  y[r * ldy + c] = v;
+}
+
+}  // namespace sn
+
+using namespace sn;
+
+extern "C" int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hself, int ldh, int C, int64_t N, const int32_t* rowptr,
+                                    const int32_t* eperm, float avg_log, float* out, int ldo, void* stream) {
+  SN_REQUIRE(msg && rowptr && eperm && out && C > 0 && N >= 0 && ldm >= C && avg_log > 0.f, "sn_pna_aggregate_f32: bad arguments");
+  SN_REQUIRE(ldo >= (hself ? 13 : 12) * C && (!hself || ldh >= C), "sn_pna_aggregate_f32: output rows too narrow");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_pna_aggregate, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, msg, ldm, hself, ldh, C, N,
+                     rowptr, eperm, avg_log, out, ldo);
+  SN_CHECK_LAUNCH("sn_pna_aggregate_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const float* Ee, int64_t N, int heads, int dk,
+                                     const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream) {
+  SN_REQUIRE(Q && K && V && Ee && rowptr && col && eperm && out && N >= 0 && heads > 0, "sn_edge_attention_f32: bad arguments");
+  SN_REQUIRE(dk >= 1 && dk <= 32, "sn_edge_attention_f32: head width %d not in [1, 32]", dk);
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_edge_attention, dim3((unsigned)cdiv(N * heads, 256)), dim3(256), 0, (hipStream_t)stream, Q, K, V, Ee, N, heads, dk,
+                     rowptr, col, eperm, out);
+  SN_CHECK_LAUNCH("sn_edge_attention_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift,
+                                int act, float slope, const float* residual, int ldr, float* y, int ldy, void* stream) {
+  SN_REQUIRE(x && y && C > 0 && R >= 0 && ldx >= C && ldy >= C && act >= 0 && act <= 2, "sn_pointwise_f32: bad arguments");
+  SN_REQUIRE((scale == nullptr) == (shift == nullptr), "sn_pointwise_f32: scale and shift come together");
+  SN_REQUIRE(!residual || ldr >= C, "sn_pointwise_f32: residual rows too narrow");
+  if (R == 0) return SN_OK;
+  hipLaunchKernelGGL(k_pointwise, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, rowscale, scale, shift,
+                     act, slope, residual, ldr, y, ldy);
+  SN_CHECK_LAUNCH("sn_pointwise_f32");
+  return SN_OK;
+}

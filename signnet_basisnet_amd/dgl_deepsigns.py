@@ -91,7 +91,7 @@ class GIN(nn.Module):
 
 def _pack(lin):
     w = lin.weight.detach()
-    return ops.PackedLinear(ops.pack_weight(w), w.shape[0], w.shape[1], lin.bias.detach().contiguous())
+    return ops.PackedLinear(ops.pack_weight(w), w.shape[0], w.shape[1], None if lin.bias is None else lin.bias.detach().contiguous())
 
 
 class _BNSite:

@@ -307,3 +307,256 @@ class GatedGCNNet(_PackCache, nn.Module):
     def loss(self, scores, targets):
         """gatedgcn_net.py:150-152 (use_lapeig_loss = False): the L1 task loss."""
         return (scores - targets).abs().mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PNA (SURVEY.md §8 f3): layers/pna_layer.py:16-160, layers/pna_utils.py, nets/ZINC_graph_regression/pna_net.py:19-170
+class FCLayer(nn.Module):
+    """layers/pna_utils.py:170-243 (parameters only): `linear` (+ the activation name; no dropout, no b_norm in the shipped nets)."""
+
+    def __init__(self, in_size, out_size, activation="relu"):
+        super().__init__()
+        self.in_size, self.out_size, self.activation = in_size, out_size, activation
+        self.linear = nn.Linear(in_size, out_size, bias=True)
+        nn.init.xavier_uniform_(self.linear.weight, 1 / in_size)       # FCLayer.reset_parameters (:223-228)
+        self.linear.bias.data.zero_()
+
+
+class _PnaMLP(nn.Module):
+    """layers/pna_utils.py:246-279 with layers = 1 (pretrans_layers = posttrans_layers = 1 in every shipped PNA config)."""
+
+    def __init__(self, in_size, hidden_size, out_size, layers, mid_activation="relu", last_activation="none"):
+        super().__init__()
+        if layers != 1:
+            raise NotImplementedError("HIP PNA: pretrans_layers = posttrans_layers = 1 (the shipped configs)")
+        self.fully_connected = nn.ModuleList([FCLayer(in_size, out_size, activation=last_activation)])
+
+
+class PNATower(nn.Module):
+    def __init__(self, in_dim, out_dim, edge_dim):
+        super().__init__()
+        self.batchnorm_h = nn.BatchNorm1d(out_dim)
+        self.pretrans_h = _PnaMLP(2 * in_dim + edge_dim, in_dim, in_dim, 1)
+        self.posttrans_h = _PnaMLP(13 * in_dim, out_dim, out_dim, 1)          # (4 aggregators x 3 scalers + 1) * in_dim
+
+
+class PNALayer(nn.Module):
+    def __init__(self, in_dim, out_dim, towers, edge_dim, residual):
+        super().__init__()
+        if in_dim % towers or out_dim % towers:
+            raise ValueError("the number of towers has to divide in_dim and out_dim")
+        self.in_dim, self.out_dim, self.n_towers = in_dim, out_dim, towers
+        self.residual = residual and in_dim == out_dim
+        self.towers = nn.ModuleList([PNATower(in_dim // towers, out_dim // towers, edge_dim) for _ in range(towers)])
+        self.mixing_network_h = FCLayer(out_dim, out_dim, activation="LeakyReLU")
+
+
+class PNANet(_PackCache, nn.Module):
+    """nets/ZINC_graph_regression/pna_net.py:19-170 for the configuration PNA_ZINC_LapPE_signinv_GIN[_mask].json selects: pe_init
+    'lap_pe', lap_lspe False, aggregators 'mean max min std', scalers 'identity amplification attenuation', towers with divided
+    input, edge features, graph_norm + batch_norm, residual, no GRU, sum / mean readout.  Same constructor (`net_params`), forward
+    contract `model(g, h, p, e, snorm_n) -> (scores, g)`, state_dict keys and attached `sign_inv_net`.  Per layer and tower:
+    gather cat[h_src, h_dst, e] -> pretrans Linear -> sn_pna_aggregate_f32 -> posttrans Linear -> sn_pointwise_f32 (snorm_n and
+    BatchNorm); then the mixing Linear + LeakyReLU + residual.  Eval and train-mode VALUE (batch-statistic BatchNorm, running
+    statistics updated); no autograd through these layers."""
+
+    def __init__(self, net_params):
+        super().__init__()
+        p = net_params
+        hidden, out_dim = p["hidden_dim"], p["out_dim"]
+        self.n_layers, self.readout = p["L"], p["readout"]
+        self.pe_init, self.lap_method, self.lap_lspe = p["pe_init"], p["lap_method"], p["lap_lspe"]
+        self.use_lapeig_loss, self.lambda_loss, self.alpha_loss = p["use_lapeig_loss"], p["lambda_loss"], p["alpha_loss"]
+        self.pos_enc_dim, self.device = p["pos_enc_dim"], p["device"]
+        self.graph_norm, self.batch_norm, self.residual = p["graph_norm"], p["batch_norm"], p["residual"]
+        self.aggregators, self.scalers, self.avg_d, self.towers = p["aggregators"], p["scalers"], p["avg_d"], p["towers"]
+        self.edge_feat = p["edge_feat"]
+        if self.pe_init != "lap_pe" or self.lap_lspe or self.use_lapeig_loss:
+            raise NotImplementedError("HIP PNANet covers pe_init='lap_pe' / lap_lspe=False (the sign-invariant PE configs)")
+        if self.aggregators.split() != ["mean", "max", "min", "std"] or self.scalers.split() != ["identity", "amplification", "attenuation"]:
+            raise NotImplementedError("HIP PNANet: aggregators 'mean max min std', scalers 'identity amplification attenuation'")
+        if not (self.graph_norm and self.batch_norm and self.edge_feat) or p["gru"] or self.readout == "max":
+            raise NotImplementedError("HIP PNANet: graph_norm, batch_norm, edge_feat True; gru False; readout sum / mean")
+        if not (p["divide_input_first"] and p["divide_input_last"]):
+            raise NotImplementedError("HIP PNANet: divide_input_first / _last True (the shipped configs)")
+        if p.get("in_feat_dropout", 0.0) or p.get("dropout", 0.0):
+            raise NotImplementedError("HIP PNANet: dropout 0.0 (as in the shipped configs)")
+        edge_dim = p["edge_dim"]
+        self.embedding_p = nn.Linear(self.pos_enc_dim, hidden)
+        self.in_feat_dropout = nn.Dropout(0.0)
+        self.embedding_h = nn.Embedding(p["num_atom_type"], hidden)
+        self.embedding_e = nn.Embedding(p["num_bond_type"], edge_dim)
+        self.layers = nn.ModuleList([PNALayer(hidden, hidden, self.towers, edge_dim, self.residual) for _ in range(self.n_layers - 1)] +
+                                    [PNALayer(hidden, out_dim, self.towers, edge_dim, self.residual)])
+        if p["pretrans_layers"] != 1 or p["posttrans_layers"] != 1:
+            raise NotImplementedError("HIP PNANet: pretrans_layers = posttrans_layers = 1")
+        self.MLP_layer = MLPReadout(out_dim, 1)
+        self.g = None
+        if self.lap_method == "sign_inv":
+            self.sign_inv_net = get_sign_inv_net(net_params)
+
+    _plan = GINNet._plan
+
+    def forward(self, g, h, p, e, snorm_n):
+        ops.require_cuda(h)
+        if p is None or snorm_n is None:
+            raise NotImplementedError("HIP PNANet needs the positional encoding p and snorm_n (graph_norm)")
+        N = h.shape[0]
+        batch, ei, B = self._plan(g, N)
+        plan = ops.build_plan(batch, ei, B, 0)
+        src, dst = ei[0], ei[1]
+        train = self.training
+        avg_log = float(self.avg_d["log"])
+        sn = snorm_n.reshape(N).contiguous().float()
+        with torch.no_grad():
+            x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])
+            x = ops.masked_linear(p.contiguous().float(), self._pk(self.embedding_p), residual=x)                 # h + embedding_p(p)  (:124-126)
+            ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
+            for L in self.layers:
+                it = L.in_dim // L.n_towers
+                outs = []
+                for t, T in enumerate(L.towers):
+                    ht = x[:, t * it:(t + 1) * it].contiguous()                                                       # copies / concats: plumbing
+                    z = torch.cat([ht.index_select(0, src), ht.index_select(0, dst), ef], dim=1)                      # pretrans_edges (:38-44)
+                    m = ops.masked_linear(z, self._pk(T.pretrans_h.fully_connected[0].linear))
+                    a = ops.pna_aggregate(m, ht, plan, avg_log)                                                       # (:50-56, :69)
+                    y = ops.masked_linear(a, self._pk(T.posttrans_h.fully_connected[0].linear))
+                    site = self._bn(T.batchnorm_h, train)
+                    if not train:
+                        y = ops.pointwise(y, rowscale=sn, scale=site.scale, shift=site.shift)                          # * snorm_n, BatchNorm (:75-79)
+                    else:
+                        y = ops.pointwise(y, rowscale=sn)
+                        sc, sh = site.affine(y, True)
+                        y = ops.pointwise(y, scale=sc, shift=sh)
+                    outs.append(y)
+                hc = torch.cat(outs, dim=1)
+                mix = ops.masked_linear(hc, self._pk(L.mixing_network_h.linear))
+                x = ops.pointwise(mix, act="leaky", slope=0.01, residual=x if L.residual else None)                  # FCLayer LeakyReLU + residual
+            hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+            fcs = self.MLP_layer.FC_layers
+            for i, fc in enumerate(fcs):
+                hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
+        self.g = g
+        self._h_last = x
+        return hg, g
+
+    def loss(self, scores, targets):
+        return (scores - targets).abs().mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Sparse graph Transformer (SURVEY.md §8 f3): layers/transformer.py:112-317, nets/ZINC_graph_regression/transformer_net.py:21-150
+class MultiHeadAttentionLayer(nn.Module):
+    def __init__(self, gamma, in_dim, out_dim, num_heads):
+        super().__init__()
+        self.out_dim, self.num_heads, self.gamma = out_dim, num_heads, gamma        # gamma: the owner's Parameter, registered here too
+        self.Q = nn.Linear(in_dim, out_dim * num_heads, bias=False)
+        self.K = nn.Linear(in_dim, out_dim * num_heads, bias=False)
+        self.E = nn.Linear(in_dim, out_dim * num_heads, bias=False)
+        self.V = nn.Linear(in_dim, out_dim * num_heads, bias=False)
+
+
+class BatchedTransformerLayer(nn.Module):
+    """layers/transformer.py:234-317 with the arguments transformer_net.py:69-70 passes (the rest at their defaults: residual,
+    batch_norm, no layer_norm, use_bias False, dropout 0)."""
+
+    def __init__(self, in_dim, out_dim, num_heads, full_graph, use_edge=True):
+        super().__init__()
+        if full_graph or not use_edge:
+            raise NotImplementedError("HIP graph Transformer: full_graph False with edge features (the shipped sign_inv configs)")
+        if out_dim % num_heads or out_dim // num_heads > 32:
+            raise ValueError("num_heads must divide out_dim and the head width must be <= 32")
+        self.in_channels, self.out_channels, self.num_heads = in_dim, out_dim, num_heads
+        self.gamma = nn.Parameter(torch.FloatTensor([0.1]))          # unused when full_graph is False, but part of the state_dict
+        self.attention_h = MultiHeadAttentionLayer(self.gamma, in_dim, out_dim // num_heads, num_heads)
+        self.O_h = nn.Linear(out_dim, out_dim)
+        self.batch_norm1_h = nn.BatchNorm1d(out_dim)
+        self.FFN_h_layer1 = nn.Linear(out_dim, out_dim * 2)
+        self.FFN_h_layer2 = nn.Linear(out_dim * 2, out_dim)
+        self.batch_norm2_h = nn.BatchNorm1d(out_dim)
+
+
+class TransformerNet(_PackCache, nn.Module):
+    """nets/ZINC_graph_regression/transformer_net.py:21-150 for pe_init 'lap_pe', lap_lspe False, edge_feat True, full_graph False
+    (Transformer_ZINC_LapPE_signinv_GIN[_masked].json): embedding_h / embedding_p with `add` or `concat` + pe_proj, edge
+    embedding, L x [Q/K/V/E projections -> sn_edge_attention_f32 -> O_h + residual -> BatchNorm -> FFN + residual -> BatchNorm],
+    sum / mean readout, MLPReadout.  Same constructor, forward contract, state_dict keys and attached `sign_inv_net`.
+    Eval and train-mode VALUE; no autograd through the attention."""
+
+    def __init__(self, net_params):
+        super().__init__()
+        p = net_params
+        hidden, out_dim = p["hidden_dim"], p["out_dim"]
+        self.n_layers, self.readout, self.batch_norm, self.layer_norm = p["L"], p["readout"], p["batch_norm"], p["layer_norm"]
+        self.residual, self.edge_feat, self.device = p["residual"], p["edge_feat"], p["device"]
+        self.pe_init, self.lap_method, self.lap_lspe = p["pe_init"], p["lap_method"], p["lap_lspe"]
+        self.use_lapeig_loss, self.lambda_loss, self.alpha_loss = p["use_lapeig_loss"], p["lambda_loss"], p["alpha_loss"]
+        self.pos_enc_dim, self.pe_aggregate = p["pos_enc_dim"], p["pe_aggregate"]
+        if self.pe_init != "lap_pe" or self.lap_lspe or self.use_lapeig_loss:
+            raise NotImplementedError("HIP TransformerNet covers pe_init='lap_pe' / lap_lspe=False (the sign-invariant PE configs)")
+        if self.readout == "max" or not self.edge_feat:
+            raise NotImplementedError("HIP TransformerNet: readout sum / mean, edge_feat True")
+        if p.get("in_feat_dropout", 0.0) or p.get("dropout", 0.0):
+            raise NotImplementedError("HIP TransformerNet: dropout 0.0 (as in the shipped configs)")
+        self.embedding_p = nn.Linear(self.pos_enc_dim, hidden)
+        self.embedding_h = nn.Embedding(p["num_atom_type"], hidden)
+        self.embedding_e = nn.Embedding(p["num_bond_type"], hidden)
+        self.in_feat_dropout = nn.Dropout(0.0)
+        self.layers = nn.ModuleList([BatchedTransformerLayer(hidden, hidden, p["n_heads"], p["full_graph"], use_edge=True)
+                                     for _ in range(self.n_layers - 1)] +
+                                    [BatchedTransformerLayer(hidden, out_dim, p["n_heads"], p["full_graph"], use_edge=True)])
+        self.MLP_layer = MLPReadout(out_dim, 1)
+        self.g = None
+        if self.lap_method == "sign_inv":
+            self.sign_inv_net = get_sign_inv_net(net_params)
+        if self.pe_aggregate == "concat":
+            self.pe_proj = nn.Linear(2 * hidden, hidden)
+
+    _plan = GINNet._plan
+
+    def _bn_res(self, y, res, bn, train):
+        """BatchNorm1d(res + y): eval folded into one pointwise pass; train: batch statistics of the sum."""
+        site = self._bn(bn, train)
+        if not train:
+            s = ops.pointwise(y, residual=res)
+            return ops.pointwise(s, scale=site.scale, shift=site.shift)
+        s = ops.pointwise(y, residual=res)
+        sc, sh = site.affine(s, True)
+        return ops.pointwise(s, scale=sc, shift=sh)
+
+    def forward(self, g, h, p, e, snorm_n=None):
+        ops.require_cuda(h)
+        if p is None:
+            raise NotImplementedError("HIP TransformerNet needs the positional encoding p")
+        N = h.shape[0]
+        batch, ei, B = self._plan(g, N)
+        plan = ops.build_plan(batch, ei, B, 0)
+        train = self.training
+        with torch.no_grad():
+            x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])
+            pp = p.contiguous().float()
+            if self.pe_aggregate == "concat":
+                pe = ops.masked_linear(pp, self._pk(self.embedding_p))
+                x = ops.masked_linear(torch.cat([x, pe], dim=1), self._pk(self.pe_proj))                              # (:96-99)
+            else:
+                x = ops.masked_linear(pp, self._pk(self.embedding_p), residual=x)                                     # (:101-102)
+            ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
+            for L in self.layers:
+                A = L.attention_h
+                Q, K, V = (ops.masked_linear(x, self._pk(getattr(A, n))) for n in "QKV")
+                Ee = ops.masked_linear(ef, self._pk(A.E))
+                a = ops.edge_attention(Q, K, V, Ee, plan, L.num_heads)                                                # (:150-228)
+                o = ops.masked_linear(a, self._pk(L.O_h))
+                x1 = self._bn_res(o, x, L.batch_norm1_h, train)                                                       # residual, BatchNorm (:283-290)
+                f = ops.masked_linear(ops.masked_linear(x1, self._pk(L.FFN_h_layer1), relu=True), self._pk(L.FFN_h_layer2))
+                x = self._bn_res(f, x1, L.batch_norm2_h, train)                                                       # (:300-308)
+            hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+            fcs = self.MLP_layer.FC_layers
+            for i, fc in enumerate(fcs):
+                hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
+        self.g = g
+        self._h_last = x
+        return hg, g
+
+    def loss(self, scores, targets):
+        return (scores - targets).abs().mean()

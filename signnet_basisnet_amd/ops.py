@@ -512,6 +512,51 @@ def ign_contract_2to1(X):
     return out
 
 
+def pna_aggregate(msg, hself, plan: GraphPlan, avg_log: float):
+    """PNA tower aggregation (pna_layer.py:50-56,69): msg [E, C] per-edge messages in edge-id order, hself [N, C] the tower's
+    input rows -> [N, 13*C] = cat[hself, scalers(aggregators(msg over in-edges))]."""
+    require_cuda(msg)
+    msg, hself = _f32c(msg, "msg"), _f32c(hself, "hself")
+    Cc = msg.shape[1]
+    out = torch.empty(plan.N, 13 * Cc, dtype=torch.float32, device=msg.device)
+    with _span("sn_pna_aggregate_f32"):
+        check(lib().sn_pna_aggregate_f32(ptr(msg), Cc, ptr(hself), Cc, Cc, plan.N, ptr(plan.rowptr), ptr(plan.eperm), float(avg_log),
+                                         ptr(out), 13 * Cc, stream()), "sn_pna_aggregate_f32")
+    return out
+
+
+def edge_attention(Q, K, V, Ee, plan: GraphPlan, heads: int):
+    """Sparse multi-head attention over the graph's edges with edge features (layers/transformer.py:150-228) -> [N, heads*dk]."""
+    require_cuda(Q)
+    Q, K, V, Ee = (_f32c(t, n) for t, n in ((Q, "Q"), (K, "K"), (V, "V"), (Ee, "E")))
+    d = Q.shape[1]
+    if d % heads or d // heads > 32:
+        raise ValueError("edge_attention: heads must divide the width and the head width must be <= 32")
+    out = torch.empty(plan.N, d, dtype=torch.float32, device=Q.device)
+    with _span("sn_edge_attention_f32"):
+        check(lib().sn_edge_attention_f32(ptr(Q), ptr(K), ptr(V), ptr(Ee), plan.N, int(heads), d // heads, ptr(plan.rowptr), ptr(plan.col),
+                                          ptr(plan.eperm), ptr(out), stream()), "sn_edge_attention_f32")
+    return out
+
+
+def pointwise(x, *, rowscale=None, scale=None, shift=None, act="none", slope=0.01, residual=None):
+    """y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual, act in none / relu / leaky."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Cc = x.shape[-1]
+    R = x.numel() // Cc
+    out = torch.empty_like(x)
+    a = {"none": 0, "relu": 1, "leaky": 2}[act]
+    if rowscale is not None:
+        rowscale = _f32c(rowscale.reshape(-1), "rowscale")
+        if rowscale.numel() != R:
+            raise ValueError("pointwise: one row scale per row expected")
+    check(lib().sn_pointwise_f32(ptr(x), Cc, R, Cc, ptr(rowscale), ptr(scale), ptr(shift), a, float(slope),
+                                 ptr(None if residual is None else _f32c(residual, "residual")), Cc, ptr(out), Cc, stream()),
+          "sn_pointwise_f32")
+    return out
+
+
 class EigenspacePlan:
     """Device-side result of sn_eigenspace_group (LearningFilters/training.py:47-61 without the projectors) + the few numbers the
     host needs to size tensors (read back once: this is a per-graph one-off, as in the reference).

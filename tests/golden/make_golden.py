@@ -211,6 +211,69 @@ def dgl_gatedgcn_case(name, hidden, L, k, sizes, seed, pe_aggregate):
     save(name, **arrays)
 
 
+def _run_dgl_net(name, net, data, k, extra, snorm=False):
+    """Shared tail of the DGL base-net cases: eval- and train-mode forward through the reference module (driven as
+    train_ZINC_graph_regression.py:20-25,77-80 drives it) and the fixture arrays."""
+    import dgl  # the shim
+    pe = synth.dgl_pos_enc(data, k)
+    g = dgl.Graph(data.edge_index[0], data.edge_index[1], torch.tensor(data.sizes))
+    sn = torch.cat([torch.full((n, 1), 1.0 / n) for n in data.sizes]).sqrt() if snorm else None     # data/molecules.py:307-308
+    arrays = {**sd_arrays(net), **data_arrays(data), "in/pos_enc": pe.numpy(), **extra}
+    if snorm:
+        arrays["in/snorm_n"] = sn.numpy()
+    for mode in ("eval", "train"):
+        net.train(mode == "train")
+        with torch.no_grad():
+            p = net.sign_inv_net(g, pe.unsqueeze(-1).clone()).squeeze(-1)
+            y, _ = net(g, data.x.squeeze(-1), p, data.edge_attr, sn)
+        arrays[f"out/{mode}/p"] = p.numpy()
+        arrays[f"out/{mode}/y"] = y.numpy()
+        arrays[f"out/{mode}/h_last"] = g.ndata["h"].numpy()
+    save(name, **arrays)
+
+
+def dgl_pna_case(name, hidden, L, k, towers, edge_dim, sizes, seed):
+    """The DGL tree's PNA base network (nets/ZINC_graph_regression/pna_net.py + layers/pna_layer.py, pna_utils.py; config
+    PNA_ZINC_LapPE_signinv_GIN.json scaled down: 4 aggregators x 3 scalers, towers, edge features, graph_norm, no GRU)."""
+    mods = _fresh_import("GraphPrediction", ["nets.ZINC_graph_regression.pna_net"])
+    avg_d = dict(lin=torch.tensor(2.2), exp=torch.tensor(0.6), log=torch.tensor(1.1))       # main_ZINC_graph_regression.py:400-405
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  readout="sum", graph_norm=True, batch_norm=True, residual=True, aggregators="mean max min std",
+                  scalers="identity amplification attenuation", avg_d=avg_d, towers=towers, divide_input_first=True,
+                  divide_input_last=True, edge_feat=True, edge_dim=edge_dim, pretrans_layers=1, posttrans_layers=1, gru=False,
+                  device="cpu", pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1000,
+                  alpha_loss=1e-4, pos_enc_dim=k, sign_inv_net="gin", sign_inv_layers=3, sign_inv_activation="relu",
+                  pe_aggregate="add", phi_out_dim=4)
+    torch.manual_seed(seed)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = mods[0].PNANet(params)
+    randomise(net, seed + 1)
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes)
+    extra = {"meta/params": np.array([hidden, L, k, towers, edge_dim], dtype=np.int64),
+             "meta/avg_d": np.array([float(avg_d["lin"]), float(avg_d["exp"]), float(avg_d["log"])], dtype=np.float64)}
+    _run_dgl_net(name, net, data, k, extra, snorm=True)
+
+
+def dgl_transformer_case(name, hidden, L, k, heads, sizes, seed, pe_aggregate):
+    """The DGL tree's sparse graph Transformer (nets/ZINC_graph_regression/transformer_net.py + layers/transformer.py; config
+    Transformer_ZINC_LapPE_signinv_GIN.json scaled down: full_graph False, edge features, attention over the graph's edges)."""
+    mods = _fresh_import("GraphPrediction", ["nets.ZINC_graph_regression.transformer_net"])
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  n_heads=heads, full_graph=False, readout="sum", batch_norm=True, layer_norm=True, residual=True, edge_feat=True,
+                  device="cpu", pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1,
+                  alpha_loss=1e-4, pos_enc_dim=k, sign_inv_net="gin", sign_inv_layers=3, sign_inv_activation="relu",
+                  pe_aggregate=pe_aggregate, phi_out_dim=4)
+    torch.manual_seed(seed)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = mods[0].TransformerNet(params)
+    randomise(net, seed + 1)
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes)
+    extra = {"meta/params": np.array([hidden, L, k, heads], dtype=np.int64), "meta/pe_aggregate": np.array(pe_aggregate)}
+    _run_dgl_net(name, net, data, k, extra)
+
+
 # ------------------------------------------------------------------ LearningFilters
 def reference_grouping(eigvals, eigvecs):
     """Eigenspace grouping by EXECUTING the reference's own statements: LearningFilters/training.py is a script (argparse and
@@ -358,6 +421,9 @@ def main():
     dgl_ginnet_case("dgl_ginnet_k6", 24, 3, 6, [5, 9, 12, 7, 3], 33)
     dgl_gatedgcn_case("dgl_gatedgcn_concat_k6", 20, 3, 6, [5, 9, 12, 7, 3], 34, "concat")
     dgl_gatedgcn_case("dgl_gatedgcn_add_k8", 28, 2, 8, [6, 4, 11, 2], 35, "add")
+    dgl_pna_case("dgl_pna_k6", 20, 3, 6, 5, 8, [5, 9, 12, 7, 3], 36)
+    dgl_transformer_case("dgl_transformer_concat_k6", 24, 3, 6, 4, [5, 9, 12, 7, 3], 37, "concat")
+    dgl_transformer_case("dgl_transformer_add_k8", 32, 2, 8, 8, [6, 4, 11, 2], 38, "add")
     # BasisNet on a small grid
     basisnet_case("basisnet_grid6", 6, 8, 41)
     grouping_case("basisnet_grouping", [6, 12, 32])

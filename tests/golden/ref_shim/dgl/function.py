@@ -16,3 +16,15 @@ def copy_e(e, out):
 
 def sum(msg, out):  # noqa: A001
     return ("reduce_sum", msg, out)
+
+
+def copy_u(u, out):
+    return ("edge", lambda g: g.ndata[u][g.src], out)
+
+
+def copy_edge(e, out):          # older name of copy_e (layers/transformer.py:97)
+    return copy_e(e, out)
+
+
+def src_mul_edge(src, edge, out):    # older name of u_mul_e (layers/transformer.py:96)
+    return u_mul_e(src, edge, out)

@@ -331,3 +331,117 @@ def test_basisnet_from_eigenvectors_equals_projector_path():
         fast = net.forward_eigvecs(V, plan)
         for m in plan.mults:
             close(fast[m], net(groups[m], m), f"forward_eigvecs mult {m}", rel=1e-5)
+
+
+def _base_params(fx, hidden, L, k, **kw):
+    p = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L, readout="sum",
+             batch_norm=True, residual=True, edge_feat=True, device=DEV, pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False,
+             use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k, sign_inv_net="gin", sign_inv_layers=3,
+             sign_inv_activation="relu", pe_aggregate="add", phi_out_dim=4)
+    p.update(kw)
+    return p
+
+
+def _drive(net, fx, snorm=False):
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    sn = fx.inp["snorm_n"].to(DEV) if snorm else None
+    with torch.no_grad():
+        p = net.sign_inv_net(g, fx.inp["pos_enc"].unsqueeze(-1).to(DEV)).squeeze(-1)          # handle_lap, sign_inv branch
+        y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p, fx.inp["edge_attr"].to(DEV), sn)
+    return p, y, net._h_last
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_pna_base_net_golden(mode):
+    """GraphPrediction tree, PNA_ZINC_LapPE_signinv_GIN.json's model scaled down (4 aggregators x 3 scalers, 5 towers, edge features,
+    graph_norm): GINDeepSigns -> PNANet (pna_net.py + pna_layer.py + pna_utils.py) against the reference's own outputs."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_nets
+    fx = G.load("dgl_pna_k6")
+    hidden, L, k, towers, edge_dim = (int(v) for v in fx.meta["params"])
+    avg = fx.meta["avg_d"]
+    net = dgl_nets.PNANet(_base_params(fx, hidden, L, k, graph_norm=True, aggregators="mean max min std",
+                                       scalers="identity amplification attenuation",
+                                       avg_d=dict(lin=float(avg[0]), exp=float(avg[1]), log=float(avg[2])), towers=towers,
+                                       divide_input_first=True, divide_input_last=True, edge_dim=edge_dim, pretrans_layers=1,
+                                       posttrans_layers=1, gru=False))
+    assert sorted(net.state_dict().keys()) == sorted(fx.sd.keys())
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train(mode == "train")
+    p, y, h_last = _drive(net, fx, snorm=True)
+    if mode == "eval":
+        ei = fx.inp["edge_index"]
+        with torch.no_grad():
+            y64 = ON.pna_net(PU.to_f64(fx.sd), ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out["eval/p"].double(),
+                             fx.inp["edge_attr"], fx.inp["snorm_n"].double(), L, towers, float(avg[2]), "sum")
+        close(p, fx.out["eval/p"], "sign_inv_net output")
+        close(h_last, fx.out["eval/h_last"], "PNA node features")
+        close(y, fx.out["eval/y"], "PNANet scores", ref64=y64)
+    else:
+        torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=5e-4, atol=5e-5)
+        torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["dgl_transformer_concat_k6", "dgl_transformer_add_k8"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_transformer_base_net_golden(name, mode):
+    """GraphPrediction tree, Transformer_ZINC_LapPE_signinv_GIN.json's model scaled down: GINDeepSigns -> TransformerNet
+    (transformer_net.py + layers/transformer.py: attention over the graph's edges with edge features) vs the reference's outputs."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_nets
+    fx = G.load(name)
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    agg = str(fx.meta["pe_aggregate"])
+    net = dgl_nets.TransformerNet(_base_params(fx, hidden, L, k, n_heads=heads, full_graph=False, layer_norm=True, pe_aggregate=agg))
+    assert sorted(net.state_dict().keys()) == sorted(fx.sd.keys())
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train(mode == "train")
+    p, y, h_last = _drive(net, fx)
+    if mode == "eval":
+        ei = fx.inp["edge_index"]
+        with torch.no_grad():
+            y64 = ON.transformer_net(PU.to_f64(fx.sd), ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out["eval/p"].double(),
+                                     fx.inp["edge_attr"], L, heads, agg, "sum")
+        close(p, fx.out["eval/p"], "sign_inv_net output")
+        close(h_last, fx.out["eval/h_last"], "Transformer node features")
+        close(y, fx.out["eval/y"], "TransformerNet scores", ref64=y64)
+    else:
+        torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=5e-4, atol=5e-5)
+        torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=1e-3, atol=1e-4)
+
+
+def test_pna_aggregate_and_edge_attention_vs_fp64():
+    """The two new message-passing kernels against float64 restatements on a larger random batch (degrees 1..7)."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import ops, synth
+    data = synth.make_batch(40, seed=13)
+    d = synth.batch_to(data, DEV)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 0)
+    g = torch.Generator().manual_seed(0)
+    src, dst = data.edge_index
+    E, N = src.numel(), data.num_nodes
+    m, hs = torch.randn(E, 14, generator=g), torch.randn(N, 14, generator=g)
+    out = ops.pna_aggregate(m.to(DEV), hs.to(DEV), plan, 1.3).cpu().double()
+    ref = torch.cat([hs.double(), ON.pna_aggregate(m.double(), dst, N, 1.3)], dim=1)
+    C = 14
+    std_cols = torch.zeros(13 * C, dtype=torch.bool)
+    for s_ in range(3):
+        std_cols[C + (4 * s_ + 3) * C:C + (4 * s_ + 4) * C] = True
+    torch.testing.assert_close(out[:, ~std_cols], ref[:, ~std_cols], rtol=1e-5, atol=1e-5)
+    # std = sqrt(relu(E[x^2] - E[x]^2) + 1e-5) (pna_utils.py:28-36) cancels in fp32 — in the reference too: the variance carries an
+    # absolute error of a few fp32 roundings of E[x^2], which the square root near 1e-5 amplifies; compare at that level
+    deg = torch.bincount(dst, minlength=N).clamp(min=1).double().unsqueeze(1)
+    ex2 = torch.zeros(N, C, dtype=torch.float64).index_add_(0, dst, m.double() ** 2) / deg
+    tol = (4e-7 * ex2 / (2 * ref[:, 4 * C:5 * C]) + 1e-6).repeat(1, 3) * 2.0
+    assert ((out[:, std_cols] - ref[:, std_cols]).abs() <= tol).all()
+    H, dk = 8, 8
+    Q, K, V = (torch.randn(N, H * dk, generator=g) for _ in range(3))
+    Ee = torch.randn(E, H * dk, generator=g)
+    a = ops.edge_attention(Q.to(DEV), K.to(DEV), V.to(DEV), Ee.to(DEV), plan, H).cpu().double()
+    Qd, Kd, Vd, Ed = (t.double().view(-1, H, dk) for t in (Q, K, V, Ee))
+    s = torch.exp(((Kd[src] * Qd[dst]) / dk ** 0.5 * Ed).sum(-1, keepdim=True).clamp(-5, 5))
+    wV = torch.zeros(N, H, dk, dtype=torch.float64).index_add_(0, dst, Vd[src] * s)
+    z = torch.zeros(N, H, 1, dtype=torch.float64).index_add_(0, dst, s)
+    torch.testing.assert_close(a, (wV / (z + 1e-6)).reshape(N, -1), rtol=1e-5, atol=1e-5)

@@ -102,6 +102,10 @@ def test_dropin_import_paths(monkeypatch):
                             ("gine_pyg", "core.sign_net", ["SignNetGNN"]), ("gine_pyg", "core.transform", ["EVDTransform"]),
                             ("graphprediction", "layers.deepsigns", ["GINDeepSigns", "MaskedGINDeepSigns"]),
                             ("graphprediction", "nets.ZINC_graph_regression.sign_inv_net", ["get_sign_inv_net"]),
+                            ("graphprediction", "nets.ZINC_graph_regression.gin_net", ["GINNet"]),
+                            ("graphprediction", "nets.ZINC_graph_regression.gatedgcn_net", ["GatedGCNNet"]),
+                            ("graphprediction", "nets.ZINC_graph_regression.pna_net", ["PNANet"]),
+                            ("graphprediction", "nets.ZINC_graph_regression.transformer_net", ["TransformerNet"]),
                             ("learningfilters", "signbasisnet", ["SignPlus", "IGNBasisInv"]), ("learningfilters", "ign", ["IGN2to1"])):
         for m in list(sys.modules):
             if m.split(".")[0] in ("sign_net", "core", "layers", "nets", "signbasisnet", "ign"):

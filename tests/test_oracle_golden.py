@@ -173,3 +173,45 @@ def test_oracle_grouping_vs_reference_statements(side):
         Pd = P[:, 0].double()
         torch.testing.assert_close(torch.diagonal(Pd, dim1=1, dim2=2).float(), sig[..., 0], rtol=0, atol=0)
         torch.testing.assert_close(Pd.sum(2).float(), sig[..., 1], rtol=0, atol=0)
+
+
+def _sign_inv_p(fx, kind, layers, k, mode):
+    ssd = {kk[len("sign_inv_net."):]: v for kk, v in fx.sd.items() if kk.startswith("sign_inv_net.")}
+    ei = fx.inp["edge_index"]
+    x = fx.inp["pos_enc"].unsqueeze(-1)
+    if kind == "gin":
+        return OD.gin_deepsigns(ssd, ei[0], ei[1], x, layers, k, training=(mode == "train")).squeeze(-1)
+    return OD.masked_gin_deepsigns(ssd, ei[0], ei[1], fx.inp["sizes"], x, layers, k, training=(mode == "train")).squeeze(-1)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_pna_base_net(mode):
+    """oracle/dgl_nets.py (PNA tower / layer / net) against the reference's PNANet + GINDeepSigns fixture."""
+    from oracle import dgl_nets as ON
+    fx = G.load("dgl_pna_k6")
+    hidden, L, k, towers, edge_dim = (int(v) for v in fx.meta["params"])
+    ei = fx.inp["edge_index"]
+    p = _sign_inv_p(fx, "gin", 3, k, mode)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **TOL_BS)
+    out = {}
+    y = ON.pna_net(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out[f"{mode}/p"], fx.inp["edge_attr"],
+                   fx.inp["snorm_n"], L, towers, float(fx.meta["avg_d"][2]), "sum", training=(mode == "train"), out=out)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **TOL_BS)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+
+
+@pytest.mark.parametrize("name", ["dgl_transformer_concat_k6", "dgl_transformer_add_k8"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_transformer_base_net(name, mode):
+    """oracle/dgl_nets.py (edge attention + transformer layer + net) against the reference's TransformerNet fixture."""
+    from oracle import dgl_nets as ON
+    fx = G.load(name)
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    ei = fx.inp["edge_index"]
+    p = _sign_inv_p(fx, "gin", 3, k, mode)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **TOL_BS)
+    out = {}
+    y = ON.transformer_net(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out[f"{mode}/p"], fx.inp["edge_attr"],
+                           L, heads, str(fx.meta["pe_aggregate"]), "sum", training=(mode == "train"), out=out)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **TOL_BS)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
