@@ -305,7 +305,8 @@ int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  * sn_edge_attention_f32: MultiHeadAttentionLayer.propagate_attention (layers/transformer.py:150-195; full_graph False, edge features):
  *   out[i,h,:] = sum_{j->i} s V[j,h,:] / (sum s + 1e-6), s = exp(clamp(sum_c K[j,h,c] Q[i,h,c] / sqrt(dk) * E[e,h,c], -5, 5)); Q/K/V
  *   [N, heads*dk], Ee [E, heads*dk] in edge-id order, dk <= 32.
- * sn_pointwise_f32: y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual, act 0 none / 1 ReLU / 2 LeakyReLU(slope); rowscale,
+ * sn_pointwise_f32: y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual, act 0 none / 1 ReLU / 2 LeakyReLU(slope) / 3 ReLU
+ *   applied after the residual add; rowscale,
  *   (scale, shift) and residual are optional — PNA's graph_norm (h * snorm_n, pna_layer.py:75-76) + BatchNorm, and the LeakyReLU of
  *   its mixing FCLayer (:126). */
 int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hself, int ldh, int C, int64_t N, const int32_t* rowptr,
@@ -314,6 +315,16 @@ int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const 
                           const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream);
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,
                      float slope, const float* residual, int ldr, float* y, int ldy, void* stream);
+
+/* Dense multi-head softmax attention over whole sequences, forward and backward — the attention inside the
+ * nn.TransformerEncoderLayer stack of LearningFilters/models.py:115-135 (`Transformer`; sequences = the graph's N nodes, head width 3-8).
+ * q, k, v, out, dout, dq, dk, dv: [Bt, L, heads*dk] row-major (batch_first; head h owns columns h*dk..); lse, delta: [Bt, heads, L].
+ * out[b,i,h,:] = sum_j softmax_j(q_i . k_j / sqrt(dk)) v_j (online softmax); lse = the row's log-sum-exp, kept for the backward, which
+ * recomputes the probabilities (dq per query, dk / dv per key: no atomics, reproducible); delta is scratch (dout . out).  dk <= 32. */
+int sn_dense_attention_f32(const float* q, const float* k, const float* v, int64_t Bt, int L, int heads, int dk, float* out, float* lse,
+                           void* stream);
+int sn_dense_attention_bwd_f32(const float* q, const float* k, const float* v, const float* out, const float* lse, const float* dout,
+                               int64_t Bt, int L, int heads, int dk, float* dq, float* dk_out, float* dv, float* delta, void* stream);
 
 /* BasisNet preprocessing on the device — replaces the module-level code of LearningFilters/training.py:47-73.
  * sn_eigenspace_group: `around(eigvals, decimals)` (round-half-even of x*10^decimals, fp32 as torch evaluates it), `unique(...,

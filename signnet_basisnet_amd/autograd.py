@@ -79,6 +79,8 @@ class _Linear(Function):
 
 def linear(x, W, b=None, nvalid=None, K=0, relu=False):
     """y = [relu](x @ W^T + b) on valid rows, 0 elsewhere (nn.Linear + the reference's mask)."""
+    if W.stride(-1) != 1 or (W.shape[0] > 1 and W.stride(0) < W.shape[1]):
+        W = W.contiguous()                       # a transposed / strided view of a parameter: autograd routes the gradient back
     return _Linear.apply(x, W, b, nvalid, K, relu)
 
 
@@ -314,6 +316,62 @@ class _SegmentPool(Function):
 
 def segment_pool(h, plan, mode="add"):
     return _SegmentPool.apply(h, plan, mode)
+
+
+class _SegmentBcastAdd(Function):
+    """y = act(x1 + x2[graph(row)]): the `x1 + x2` of the DeepSets / IGN layers (x2 = a per-graph row broadcast over the graph's
+    nodes; LearningFilters/models.py:74-77, ign.py:330-335).  d x1 = dy', d x2 = segment sum of dy' (dy' = dy masked by the ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, plan, relu):
+        x2 = _c(x2)
+        xb = torch.empty_like(x1)
+        check(lib().sn_segment_broadcast_f32(ptr(x2), plan.B, x2.shape[-1], ptr(plan.graph_ptr), 0, ptr(xb), stream()),
+              "sn_segment_broadcast_f32")
+        y = ops.pointwise(_c(x1), act="relu_sum" if relu else "none", residual=xb)
+        ctx.meta = (plan, relu)
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, relu = ctx.meta
+        (y,) = ctx.saved_tensors
+        g = _c(g)
+        if relu:
+            g = relu_bwd(y, g, None, 0)
+        return g, ops.segment_pool(g, plan, "add"), None, None
+
+
+def segment_bcast_add(x1, x2, plan, relu=False):
+    return _SegmentBcastAdd.apply(x1, x2, plan, relu)
+
+
+class _DenseAttention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        q, k, v = _c(q), _c(k), _c(v)
+        out, lse = ops.dense_attention(q, k, v, heads, want_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, out, lse = ctx.saved_tensors
+        g = _c(g)
+        Bt, L, d = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        with ops._span("sn_dense_attention_bwd_f32"):
+            check(lib().sn_dense_attention_bwd_f32(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(g), Bt, L, ctx.heads, d // ctx.heads,
+                                                   ptr(dq), ptr(dk), ptr(dv), ptr(delta), stream()), "sn_dense_attention_bwd_f32")
+        return dq, dk, dv, None
+
+
+def dense_attention(q, k, v, heads):
+    """softmax(q k^T / sqrt(dk)) v per head over whole sequences; q, k, v [Bt, L, heads*dk]."""
+    return _DenseAttention.apply(q, k, v, heads)
 
 
 # ----------------------------------------------------------------------------- GatedGCN edge-gated aggregation

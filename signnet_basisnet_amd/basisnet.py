@@ -8,7 +8,10 @@ same forward contracts:
     SignPlus(model).forward(v) = model(v) + model(-v)
 All arithmetic runs in libsignnet_hip.so (the 2->1 contractions in sn_ign_contract_2to1_f32, every Linear in
 sn_masked_linear_f32, means / BatchNorm statistics in the segment / column-statistics kernels).  No CPU path.
-IGN2to1 in train mode gives the forward VALUE with batch-statistic BatchNorm (running statistics updated; no autograd).
+In train mode with gradients enabled every module here builds its forward from the differentiable device ops of autograd.py
+(linear, segment mean / broadcast-add, batch-statistic BatchNorm), so `loss.backward()` fills the parameter gradients the
+reference's 2 000-epoch loop uses (training.py:132-143) — no ATen arithmetic; torch only routes views, concatenations and
+gradient accumulation.  Under torch.no_grad() train mode gives the same forward value (running statistics updated).
 
 Difference from the reference worth knowing: the reference's equivariant-layer
 coefficients are `nn.Parameter(...).to(device)`, i.e. NOT registered parameters when the device differs from
@@ -109,7 +112,9 @@ class IGN2to1(nn.Module):
     def forward_contractions(self, o):
         """Everything after the 2->1 contractions: o [b, n, 5] = contractions_2_to_1 of the input stack (ign.py:344-374), from
         sn_ign_contract_2to1_f32 (the projectors) or sn_ign_contract_eigvecs_f32 (the eigenvectors alone)."""
-        train = self.training     # forward VALUE with batch statistics (no autograd)
+        train = self.training
+        if train and torch.is_grad_enabled():
+            return self._forward_autograd(o)
         if train:
             P = self._prepare(True)
         else:
@@ -127,6 +132,24 @@ class IGN2to1(nn.Module):
         h = ops.masked_linear(h, P["fc1"], relu=True)
         y = ops.masked_linear(h, P["fc2"])                                                 # [b*n, out]
         return y.view(b, n, -1).transpose(2, 1).contiguous()                               # [b, out, n]
+
+
+    def _forward_autograd(self, o):
+        """The same network from differentiable ops (train mode): equivariant layer = Linear over the contraction basis
+        (identity block on the rows + mean block on the per-matrix mean, broadcast back), ReLU, batch-statistic BatchNorm."""
+        from . import autograd as AG
+        e0, e1, e2 = self.equi_layers
+        b, n = o.shape[0], o.shape[1]
+        seg = _SegPlan(b, torch.arange(0, b * n + 1, n, dtype=torch.int32, device=o.device))
+        h = AG.linear(o.reshape(b * n, 5), e0.coeffs[0], e0.bias.reshape(-1), relu=True)
+        h = AG.bn_act(h, self.bns[0], relu=False)
+        for i, e in ((1, e1), (2, e2)):
+            x1 = AG.linear(h, e.coeffs[:, :, 0].t(), e.bias.reshape(-1))
+            x2 = AG.linear(AG.segment_pool(h, seg, "mean"), e.coeffs[:, :, 1].t(), None)
+            h = AG.bn_act(AG.segment_bcast_add(x1, x2, seg, relu=True), self.bns[i], relu=False)
+        h = AG.linear(h, self.fc1.weight, self.fc1.bias, relu=True)
+        y = AG.linear(h, self.fc2.weight, self.fc2.bias)
+        return y.view(b, n, -1).transpose(2, 1).contiguous()
 
 
 class _SegPlan:
@@ -150,6 +173,10 @@ class IGNBasisInv(nn.Module):
     def forward(self, proj, mult):
         return self.encs[self.mult_to_idx[mult]](proj)
 
+    def forward_contractions(self, o, mult):
+        """forward(proj, mult) from the 2->1 contractions o [b, N, 5] of `proj` (constants of the graph: computed once)."""
+        return self.encs[self.mult_to_idx[mult]].forward_contractions(o)
+
     def forward_eigvecs(self, eigvecs, plan, contractions=None):
         """Extension (not in the reference): every multiplicity group evaluated from the eigenvectors alone — the 2->1
         contractions of P = V V^T are computed from V (4*N*mult bytes per eigenspace instead of the 4*N^2 of the projector;
@@ -172,9 +199,17 @@ class IGNShared(nn.Module):
             self.mult_to_idx[mult] = i
 
     def forward(self, proj, mult):
-        fc = self.fcs[self.mult_to_idx[mult]]
-        x = self.enc(proj)                                                   # [b, 1, n]
+        return self._head(self.enc(proj), mult)
+
+    def forward_contractions(self, o, mult):
+        return self._head(self.enc.forward_contractions(o), mult)
+
+    def _head(self, x, mult):
+        fc = self.fcs[self.mult_to_idx[mult]]                                # x: [b, 1, n]
         b, n = x.shape[0], x.shape[2]
+        if self.training and torch.is_grad_enabled():
+            from . import autograd as AG
+            return AG.linear(x.reshape(b * n, 1), fc.weight, fc.bias).view(b, n, -1).transpose(2, 1).contiguous()
         y = ops.masked_linear(x.reshape(b * n, 1), _lin(fc.weight, fc.bias))   # transpose(2,1) . Linear(1, mult)   (:60-62)
         return y.view(b, n, -1).transpose(2, 1).contiguous()                # [b, mult, n]
 
@@ -188,6 +223,8 @@ class EqDeepSetsEncoder(nn.Module):
         super().__init__()
         if use_ln or activation != "relu":
             raise ValueError("HIP EqDeepSetsEncoder: relu / no LayerNorm only (what the reference instantiates)")
+        if dropout:
+            raise NotImplementedError("HIP EqDeepSetsEncoder: dropout > 0 is not built (the reference never sets it)")
         self.lins1, self.lins2 = nn.ModuleList(), nn.ModuleList()
         if use_bn:
             self.bns = nn.ModuleList()
@@ -209,6 +246,16 @@ class EqDeepSetsEncoder(nn.Module):
         h = x.contiguous().float().view(b * n, shp[-1])
         seg = _SegPlan(b, torch.arange(0, b * n + 1, n, dtype=torch.int32, device=x.device))
         L = len(self.lins1)
+        if self.training and torch.is_grad_enabled():
+            from . import autograd as AG
+            for i in range(L):
+                l1, l2 = self.lins1[i], self.lins2[i]
+                last = i == L - 1
+                x2 = AG.linear(AG.segment_pool(h, seg, "mean"), l2.weight, l2.bias)          # lin2(x.mean(dim=-2))
+                h = AG.segment_bcast_add(AG.linear(h, l1.weight, l1.bias), x2, seg, relu=not last)
+                if self.use_bn and not last:
+                    h = AG.bn_act(h, self.bns[i], relu=False)
+            return h.view(*shp[:-1], -1)
         for i in range(L):
             l1, l2 = self.lins1[i], self.lins2[i]
             m = ops.segment_pool(h, seg, "mean")                                              # x.mean(dim=-2)
@@ -241,6 +288,9 @@ class SignPlus(nn.Module):
         neg = ops.masked_affine(v.view(-1, v.shape[-1]), scale=torch.full((v.shape[-1],), -1.0, device=v.device),
                                 shift=torch.zeros(v.shape[-1], device=v.device)).view(v.shape)
         a, b = self.model(v), self.model(neg)
+        if a.requires_grad or b.requires_grad:
+            from . import autograd as AG
+            return AG.masked_add(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])).view(a.shape)
         return ops.masked_affine(a.contiguous().view(-1, a.shape[-1]), residual=b.contiguous().view(-1, b.shape[-1])).view(a.shape)
 
 

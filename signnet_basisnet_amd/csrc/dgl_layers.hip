@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_edge_attention(const float* __restrict_
 }
 
 // y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual    (any of rowscale / scale+shift / residual may be absent)
-// act: 0 none, 1 ReLU, 2 LeakyReLU(slope).  Covers PNA's graph_norm (h * snorm_n) + BatchNorm and its mixing FCLayer's LeakyReLU.
+// act: 0 none, 1 ReLU, 2 LeakyReLU(slope), 3 ReLU after the residual add (the DeepSets / IGN `relu(x1 + x2)`).  Covers PNA's graph_norm (h * snorm_n) + BatchNorm and its mixing FCLayer's LeakyReLU.
 __global__ __launch_bounds__(256) void k_pointwise(const float* __restrict__ x, int ldx, int64_t R, int C, const float* __restrict__ rowscale,
                                                    const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope,
                                                    const float* __restrict__ res, int ldr, float* __restrict__ y, int ldy) {
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void k_pointwise(const float* __restrict__ x, 
   if (act == 1) v = fmaxf(v, 0.f);
   else if (act == 2) v = v > 0.f ? v : v * slope;
   if (res) v += res[r * ldr + c];
+  if (act == 3) v = fmaxf(v, 0.f);
   y[r * ldy + c] = v;
 }
 
@@ -138,7 +139,7 @@ extern "C" int sn_edge_attention_f32(const float* Q, const float* K, const float
 
 extern "C" int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift,
                                 int act, float slope, const float* residual, int ldr, float* y, int ldy, void* stream) {
-  SN_REQUIRE(x && y && C > 0 && R >= 0 && ldx >= C && ldy >= C && act >= 0 && act <= 2, "sn_pointwise_f32: bad arguments");
+  SN_REQUIRE(x && y && C > 0 && R >= 0 && ldx >= C && ldy >= C && act >= 0 && act <= 3, "sn_pointwise_f32: bad arguments");
   SN_REQUIRE((scale == nullptr) == (shift == nullptr), "sn_pointwise_f32: scale and shift come together");
   SN_REQUIRE(!residual || ldr >= C, "sn_pointwise_f32: residual rows too narrow");
   if (R == 0) return SN_OK;

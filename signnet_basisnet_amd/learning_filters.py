@@ -1,0 +1,305 @@
+"""LearningFilters: the spectral-filter regression workload that trains BasisNet / SignNet on one N-node grid graph
+ — base networks, model factories, feature assembly and the training step.
+
+Mirrors, on the device ops of this package:
+  models.py:18-56     MLP                      -> MLP
+  models.py:115-135   Transformer              -> Transformer (nn.TransformerEncoderLayer used as the PARAMETER container, so the
+                                                  state_dict keys are the reference's; the forward is ours: pre-norm encoder layers
+                                                  with sn_dense_attention_f32 over the whole node sequence)
+  training.py:152-222 gen_model / gen_sign_inv / gen_basis_inv / gen_rho   -> same names; the reference reads module globals
+                                                  (args, N, PE_DIM, uniq_mults, NUM_EIGENSPACES, device) — here they travel in a
+                                                  FilterArgs and a GridEigen
+  training.py:87-130  get_lap_feat             -> get_lap_feat
+  training.py:132-150 train                    -> train_step;  :224-246 the epoch loop -> fit
+The graph-convolution baselines of gen_model (ChebNet, BernNet, GcnNet, GatNet, ARMANet, GPRNet) and the 'abs_val' / 'sign_flip'
+feature variants are the paper's comparison rows, not the sign/basis-invariant path: they raise NotImplementedError.
+
+Everything is differentiable in train mode (autograd.py ops; backward kernels in csrc/backward.hip and csrc/dense_attention.hip).
+One thing is done differently on purpose: the reference re-contracts the 2.15 GB projector stack in every epoch
+(IGN2to1.forward, ign.py:29-31); the projectors are constants, so GridEigen computes the [n_spaces, N, 5] contractions ONCE
+(from the eigenvectors, or from the projector stack) and every epoch starts from them — same values, 2 GB less HBM traffic per
+step.  `GridEigen(..., keep_projectors=True)` keeps the reference's `same_size_projs` for callers that want that path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+
+from . import autograd as AG
+from . import ops
+from .basisnet import EqDeepSetsEncoder, IGNBasisInv, IGNShared, SignPlus
+
+GRAPH_CONV_BASELINES = ("ChebNet", "BernNet", "GcnNet", "GatNet", "ARMANet", "GPRNet")
+
+
+class MLP(nn.Module):
+    """models.py:18-56: Linear -> ReLU -> [BatchNorm1d(track_running_stats=False)] -> [LayerNorm] per hidden layer, then a Linear.
+    2-D [rows, F] or 3-D [b, n, F] input (the BatchNorm statistics run over all b*n rows, as bn(x.transpose(2,1)) does)."""
+
+    def __init__(self, in_channels, hidden_channels=32, out_channels=1, num_layers=3, use_bn=False, use_ln=False, dropout=0.0,
+                 activation="relu"):
+        super().__init__()
+        if activation != "relu":
+            raise ValueError("MLP: relu only (models.py:16 defines nothing else)")
+        if dropout:
+            raise NotImplementedError("MLP: dropout > 0 is not built (the reference never sets it)")
+        self.lins = nn.ModuleList()
+        if use_bn:
+            self.bns = nn.ModuleList()
+        if use_ln:
+            self.lns = nn.ModuleList()
+        dims = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        for i in range(num_layers):
+            self.lins.append(nn.Linear(dims[i], dims[i + 1]))
+            if i < num_layers - 1:
+                if use_bn:
+                    self.bns.append(nn.BatchNorm1d(hidden_channels, track_running_stats=False))
+                if use_ln:
+                    self.lns.append(nn.LayerNorm(hidden_channels))
+        self.use_bn, self.use_ln, self.dropout = use_bn, use_ln, dropout
+
+    def forward(self, x, *args):
+        ops.require_cuda(x)
+        if x.dim() not in (2, 3):
+            raise ValueError("invalid dimension of x")
+        shp = x.shape
+        h = x.float().reshape(-1, shp[-1])
+        for i, lin in enumerate(self.lins[:-1]):
+            h = AG.linear(h, lin.weight, lin.bias, relu=True)
+            if self.use_bn:
+                h = AG.bn_act(h, self.bns[i], relu=False)
+            if self.use_ln:
+                ln = self.lns[i]
+                h = AG.masked_layernorm(h, None, ln.weight, ln.bias, ln.eps)
+        h = AG.linear(h, self.lins[-1].weight, self.lins[-1].bias)
+        return h.view(*shp[:-1], -1)
+
+
+class Transformer(nn.Module):
+    """models.py:115-135: fc1 -> num_layers x TransformerEncoderLayer(d_model = dim_feedforward = hidden, norm_first, batch_first,
+    ReLU, dropout 0) -> fc2.  2-D input [n, F] is one sequence of the n nodes; 3-D [b, n, F] is b sequences."""
+
+    def __init__(self, in_channels, hidden_channels=32, out_channels=1, num_layers=2, num_heads=4, dropout=0):
+        super().__init__()
+        if dropout:
+            raise NotImplementedError("Transformer: dropout > 0 is not built (the reference leaves it at 0)")
+        if hidden_channels % num_heads or hidden_channels // num_heads > 32:
+            raise ValueError("Transformer: hidden_channels must be a multiple of num_heads with head width <= 32")
+        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.encs = nn.ModuleList()
+        for _ in range(num_layers):
+            self.encs.append(nn.TransformerEncoderLayer(d_model=hidden_channels, dim_feedforward=hidden_channels, nhead=num_heads,
+                                                        dropout=dropout, norm_first=True, batch_first=True))
+        self.fc2 = nn.Linear(hidden_channels, out_channels)
+
+    def forward(self, x, *args):
+        ops.require_cuda(x)
+        if x.dim() not in (2, 3):
+            raise ValueError("invalid dimension of x")
+        shp = x.shape
+        Bt, L = (1, shp[0]) if x.dim() == 2 else (shp[0], shp[1])
+        h = AG.linear(x.float().reshape(Bt * L, shp[-1]), self.fc1.weight, self.fc1.bias)
+        d = h.shape[-1]
+        for enc in self.encs:
+            att = enc.self_attn
+            # x = x + self_attn(norm1(x))        (TransformerEncoderLayer, norm_first)
+            u = AG.masked_layernorm(h, None, enc.norm1.weight, enc.norm1.bias, enc.norm1.eps)
+            qkv = AG.linear(u, att.in_proj_weight, att.in_proj_bias)                          # [Bt*L, 3d]: q | k | v
+            q, k, v = (qkv[:, i * d:(i + 1) * d].contiguous().view(Bt, L, d) for i in range(3))
+            o = AG.dense_attention(q, k, v, att.num_heads).view(Bt * L, d)
+            h = AG.masked_add(h, AG.linear(o, att.out_proj.weight, att.out_proj.bias))
+            # x = x + linear2(relu(linear1(norm2(x))))
+            u = AG.masked_layernorm(h, None, enc.norm2.weight, enc.norm2.bias, enc.norm2.eps)
+            f = AG.linear(AG.linear(u, enc.linear1.weight, enc.linear1.bias, relu=True), enc.linear2.weight, enc.linear2.bias)
+            h = AG.masked_add(h, f)
+        y = AG.linear(h, self.fc2.weight, self.fc2.bias)
+        return y.view(*shp[:-1], -1)
+
+
+@dataclass
+class FilterArgs:
+    """The argparse namespace of training.py:12-24 (defaults included)."""
+    epochs: int = 2000
+    lr: float = 0.01
+    filter_type: str = "band"
+    net: str = "BernNet"
+    img_num: int = 3
+    use_eig: bool = False
+    lap_method: str = "none"
+    sign_inv_net: str = "DS"
+    basis_inv_net: str = "IGN"
+    hidden_channels: int = 32
+    num_layers: int = 2
+
+    def __post_init__(self):
+        if self.lap_method != "none" and not self.use_eig:
+            raise AssertionError("Specified lap method but not using eigs")          # training.py:84-85
+
+
+class GridEigen:
+    """The per-graph constants the script prepares at module level (training.py:41-82): eigenpairs on the device, and for
+    lap_method 'basis_inv' the eigenspace grouping and the 2->1 contractions of every projector."""
+
+    def __init__(self, eigvals, eigvecs, args: FilterArgs, decimals=5, from_eigenvectors=True, keep_projectors=False):
+        ops.require_cuda(eigvecs)
+        self.eigvals, self.eigvecs = eigvals.float().contiguous(), eigvecs.float().contiguous()
+        self.N = self.eigvecs.shape[0]
+        self.plan = self.contractions = self.same_size_projs = None
+        self.uniq_mults, self.num_eigenspaces = [], 0
+        if args.lap_method == "basis_inv":
+            self.plan = ops.eigenspace_group(self.eigvals, decimals)
+            self.uniq_mults, self.num_eigenspaces = list(self.plan.mults), self.plan.n_spaces
+            if keep_projectors or not from_eigenvectors:
+                stack = ops.eigenspace_projectors(self.eigvecs, self.plan)
+                if keep_projectors:
+                    self.same_size_projs = {m: self.plan.group(stack, m).view(-1, 1, self.N, self.N) for m in self.plan.mults}
+            if from_eigenvectors:
+                self.contractions = ops.ign_contract_eigvecs(self.eigvecs, self.plan)            # [n_spaces, N, 5]
+            else:
+                self.contractions = ops.ign_contract_2to1(stack)
+        if not args.use_eig:
+            self.pe_dim = 0
+        elif "sign_inv" in args.lap_method or "basis_inv" in args.lap_method:
+            self.pe_dim = 32                                                                     # training.py:75-80
+        else:
+            self.pe_dim = 2 * self.eigvecs.shape[1]
+        # eigvals.unsqueeze(0).repeat(n, 1): a constant of the graph (training.py:90)
+        self.eigvals_mat = self.eigvals.unsqueeze(0).repeat(self.N, 1).contiguous()
+
+
+def gen_sign_inv(args: FilterArgs):
+    """training.py:183-199."""
+    if "eigval" in args.lap_method:
+        raise NotImplementedError("Eigval in sign inv net not yet implemented")                 # the reference's own message
+    if args.sign_inv_net == "DS":
+        return SignPlus(EqDeepSetsEncoder(1, num_layers=3, use_bn=True))
+    if args.sign_inv_net == "MLP":
+        return SignPlus(MLP(1, num_layers=args.num_layers, use_bn=True))
+    if args.sign_inv_net == "Transformer":
+        return SignPlus(Transformer(1, num_layers=2))
+    raise ValueError("Invalid sign inv net")
+
+
+def gen_basis_inv(args: FilterArgs, eig: GridEigen):
+    """training.py:201-209."""
+    if args.basis_inv_net == "IGN":
+        return IGNBasisInv(eig.uniq_mults, 1, hidden_channels=32)
+    if args.basis_inv_net == "IGNShared":
+        return IGNShared(eig.uniq_mults, 1, hidden_channels=16)
+    raise ValueError("Invalid basis invariant network")
+
+
+def gen_rho(args: FilterArgs, eig: GridEigen):
+    """training.py:212-218."""
+    rho = EqDeepSetsEncoder(2 * eig.N, hidden_channels=10, num_layers=3, out_channels=eig.pe_dim, use_bn=True)
+    if "basis_inv" in args.lap_method and args.basis_inv_net == "IGNv2":
+        rho = EqDeepSetsEncoder(eig.N + eig.num_eigenspaces, hidden_channels=12, num_layers=3, out_channels=eig.pe_dim, use_bn=True)
+    return rho
+
+
+def gen_model(args: FilterArgs, eig: GridEigen, device="cuda"):
+    """training.py:152-181: the base network, with `sign_inv_net` / `basis_inv_net` and `rho` attached as attributes."""
+    d_in = 1 + eig.pe_dim
+    if args.net in GRAPH_CONV_BASELINES:
+        raise NotImplementedError(f"{args.net}: the graph-convolution baselines of the filter table are not part of the "
+                                  "sign / basis invariant path (SURVEY.md §8 'out of scope')")
+    if args.net == "MLP":
+        model = MLP(d_in, hidden_channels=args.hidden_channels, num_layers=args.num_layers)
+    elif args.net == "DS":
+        model = EqDeepSetsEncoder(d_in, hidden_channels=args.hidden_channels, num_layers=args.num_layers)
+    elif args.net == "Linear":
+        model = MLP(d_in, num_layers=1)
+    elif args.net == "Transformer":
+        model = Transformer(d_in, hidden_channels=args.hidden_channels, num_layers=args.num_layers)
+    else:
+        raise ValueError("Invalid model")
+    if "sign_inv" in args.lap_method:
+        model.sign_inv_net = gen_sign_inv(args)
+        model.rho = gen_rho(args, eig)
+    elif "basis_inv" in args.lap_method:
+        model.basis_inv_net = gen_basis_inv(args, eig)
+        model.rho = gen_rho(args, eig)
+    return model.to(device)
+
+
+def basis_inv_outputs(model, eig: GridEigen):
+    """[basis_inv_net(projs, mult) for mult, projs in same_size_projs.items()] (training.py:120) from the cached contractions:
+    a list of [b_mult, mult, N] in ascending multiplicity."""
+    net = model.basis_inv_net
+    outs = []
+    for m in eig.plan.mults:
+        o = eig.plan.group(eig.contractions, m)
+        outs.append(net.forward_contractions(o, m))
+    return outs
+
+
+def get_lap_feat(use_eig, eig: GridEigen, feat, lap_method, model):
+    """training.py:87-130 ('none', 'sign_inv', 'basis_inv').  feat [N, 1] -> [N, 1 + PE_DIM]."""
+    if not use_eig:
+        return feat
+    N = eig.N
+    if lap_method == "none":
+        return torch.cat((feat, eig.eigvecs, eig.eigvals_mat), dim=-1).to(feat)
+    if lap_method in ("abs_val", "sign_flip"):
+        raise NotImplementedError(f"lap_method {lap_method}: a baseline of the filter table, not the sign / basis invariant path")
+    if "sign_inv" in lap_method:
+        if "eigval" in lap_method:
+            raise NotImplementedError("Eigval in sign inv not done yet")                       # the reference's own message
+        v = eig.eigvecs.transpose(1, 0).unsqueeze(-1)                                          # n x k -> k x n x 1
+        eig_feats = model.sign_inv_net(v)
+        eig_feats = eig_feats.transpose(1, 0).reshape(feat.shape[0], -1)                       # n x d
+    elif "basis_inv" in lap_method:
+        phi_outs = basis_inv_outputs(model, eig)
+        eig_feats = torch.cat([p.reshape(N, -1) for p in phi_outs], dim=-1)                    # b x d x n -> n x bd  (:122; a raw reshape)
+    else:
+        raise ValueError("Invalid eigvec operation")
+    eig_feats = torch.cat((eig_feats, eig.eigvals_mat), dim=-1)
+    if hasattr(model, "rho"):
+        eig_feats = model.rho(eig_feats)
+    return torch.cat((feat, eig_feats), dim=-1).to(feat)
+
+
+def masked_square_loss(pre, y, m):
+    """training.py:139: torch.square(data.m * (pre - y)).sum() — the script's own line; N scalars."""
+    return torch.square(m * (pre - y)).sum()
+
+
+def train_step(model, optimizer, args: FilterArgs, eig: GridEigen, x, y, m):
+    """One epoch of training.py:132-150 for one image: x [N, 1] the signal, y [N, 1] the filtered target, m [N, 1] the boundary
+    mask.  Returns (loss tensor on the device, prediction)."""
+    model.train()
+    optimizer.zero_grad()
+    feat = get_lap_feat(args.use_eig, eig, x, args.lap_method, model)
+    pre = model(feat, None)
+    loss = masked_square_loss(pre, y, m)
+    loss.backward()
+    optimizer.step()
+    return loss.detach(), pre.detach()
+
+
+def r2_score(target, pred):
+    """sklearn.metrics.r2_score for one output column (training.py:147), on host copies."""
+    t, p = target.detach().double().cpu().reshape(-1), pred.detach().double().cpu().reshape(-1)
+    ss_res = ((t - p) ** 2).sum()
+    ss_tot = ((t - t.mean()) ** 2).sum()
+    return float(1.0 - ss_res / ss_tot) if ss_tot > 0 else 0.0
+
+
+def fit(args: FilterArgs, eig: GridEigen, x, y, m, epochs=None, model=None, optimizer=None, log=None):
+    """The per-image loop of training.py:229-250: a fresh model, Adam(lr), `epochs` steps; keeps the minimum loss and its r2.
+    Returns {'min_loss', 'best_r2', 'epoch', 'model'}.  The loss is read back once per epoch, as the reference's loss.item() does."""
+    from .optim import Adam
+    model = model if model is not None else gen_model(args, eig, x.device)
+    optimizer = optimizer if optimizer is not None else Adam(model.parameters(), lr=args.lr)
+    best = {"min_loss": float("inf"), "best_r2": 0.0, "epoch": 0, "model": model}
+    keep = m.reshape(-1) == 1
+    for epoch in range(args.epochs if epochs is None else epochs):
+        loss, pre = train_step(model, optimizer, args, eig, x, y, m)
+        lv = loss.item()
+        if best["min_loss"] > lv:
+            best.update(min_loss=lv, best_r2=r2_score(y[keep], pre[keep]), epoch=epoch)
+        if log is not None and epoch % 100 == 0:
+            log(f"Epoch: {epoch}, Min loss {best['min_loss']:.6f}, Best r2 {best['best_r2']:.4f}")
+    return best

@@ -546,7 +546,7 @@ def pointwise(x, *, rowscale=None, scale=None, shift=None, act="none", slope=0.0
     Cc = x.shape[-1]
     R = x.numel() // Cc
     out = torch.empty_like(x)
-    a = {"none": 0, "relu": 1, "leaky": 2}[act]
+    a = {"none": 0, "relu": 1, "leaky": 2, "relu_sum": 3}[act]
     if rowscale is not None:
         rowscale = _f32c(rowscale.reshape(-1), "rowscale")
         if rowscale.numel() != R:
@@ -555,6 +555,22 @@ def pointwise(x, *, rowscale=None, scale=None, shift=None, act="none", slope=0.0
                                  ptr(None if residual is None else _f32c(residual, "residual")), Cc, ptr(out), Cc, stream()),
           "sn_pointwise_f32")
     return out
+
+
+def dense_attention(q, k, v, heads, want_lse=False):
+    """softmax(q k^T / sqrt(dk)) v per head over whole sequences (LearningFilters/models.py:115-135's encoder attention).
+    q, k, v: [Bt, L, heads*dk] (batch_first), dk <= 32."""
+    require_cuda(q)
+    q, k, v = _f32c(q, "q"), _f32c(k, "k"), _f32c(v, "v")
+    if q.dim() != 3 or k.shape != q.shape or v.shape != q.shape or q.shape[-1] % heads:
+        raise ValueError("dense_attention: q, k, v must be [Bt, L, heads*dk] of one shape")
+    Bt, L, d = q.shape
+    out = torch.empty_like(q)
+    lse = torch.empty(Bt, heads, L, dtype=torch.float32, device=q.device)
+    with _span("sn_dense_attention_f32"):
+        check(lib().sn_dense_attention_f32(ptr(q), ptr(k), ptr(v), Bt, L, heads, d // heads, ptr(out), ptr(lse), stream()),
+              "sn_dense_attention_f32")
+    return (out, lse) if want_lse else out
 
 
 class EigenspacePlan:

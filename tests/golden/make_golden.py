@@ -374,6 +374,85 @@ def basisnet_case(name, side, hidden, seed):
     save(name, **arrays)
 
 
+def reference_filter_script(args, eigvals, eigvecs, data, y):
+    """The LearningFilters entry script from `around()` to `gen_rho` (training.py:47-223: eigenspace grouping, PE_DIM, get_lap_feat,
+    train, gen_model and the other factories) EXECUTED from the reference file at generation time, in a namespace holding what the
+    script has defined by then (args, data, y, eigvals, eigvecs, N, device, the imported model classes, r2_score).  As in
+    reference_grouping nothing of that source is stored here.  IGNBasisInv builds its IGN2to1 with device='cuda'
+    (signbasisnet.py:33, ign.py:12): on this CPU-only box the name is bound to the same class with device='cpu'.
+    Returns the namespace (gen_model, get_lap_feat, train, same_size_projs, ...)."""
+    import contextlib
+    import functools
+    import io
+    ign, sbn, models = _fresh_import("LearningFilters", ["ign", "signbasisnet", "models"])
+    sbn.IGN2to1 = functools.partial(ign.IGN2to1, device="cpu")
+    lines = open(os.path.join(REF, "LearningFilters", "training.py")).read().splitlines()
+    block = "\n".join(lines[46:223])                  # 1-based lines 47..223
+    assert block.lstrip().startswith("def around(") and block.rstrip().endswith("return rho"), \
+        "the reference file moved: re-check the line range of the script block"
+    from sklearn.metrics import r2_score
+    ns = {"torch": torch, "np": np, "eigvals": eigvals, "eigvecs": eigvecs, "N": eigvecs.shape[0], "args": args, "data": data, "y": y,
+          "device": torch.device("cpu"), "r2_score": r2_score, "SignPlus": sbn.SignPlus, "IGNBasisInv": sbn.IGNBasisInv,
+          "IGNShared": sbn.IGNShared}
+    for n in ("ChebNet", "BernNet", "GcnNet", "GatNet", "ARMANet", "GPRNet", "MLP", "EqDeepSetsEncoder", "Transformer"):
+        ns[n] = getattr(models, n)
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(block, "reference:LearningFilters/training.py:47-223", "exec"), ns)
+    return ns
+
+
+def filters_case(name, side, cases, seed):
+    """the LearningFilters training workload on a side x side grid.  Per case (an argparse namespace of
+    training.py:12-24): the model from the reference's gen_model, its prediction, then `train()` (training.py:132-150) called
+    four times — the loss of every step, the parameter gradients of the first step (from the reference's loss.backward()) and the
+    parameters after the first torch.optim.Adam step."""
+    ei, N, D, V = grid_eig(side)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 2, generator=g)
+    yv = torch.randn(N, 2, generator=g)
+    m = torch.ones(N, 1)
+    idx = np.arange(N)
+    r, c = idx // side, idx % side
+    m[(r == 0) | (c == 0) | (r == side - 1) | (c == side - 1)] = 0.0        # the boundary mask of utils.py's TwoDGrid (data.m)
+    arrays = {"in/eigvals": D.numpy(), "in/eigvecs": V.numpy(), "in/x": x.numpy(), "in/y": yv.numpy(), "in/m": m.numpy(),
+              "meta/side": np.array(side), "meta/cases": np.array([c["name"] for c in cases])}
+    for ci, c in enumerate(cases):
+        a = dict(epochs=4, lr=0.01, filter_type="band", net="DS", img_num=1, use_eig=True, lap_method="none", sign_inv_net="DS",
+                 basis_inv_net="IGN", hidden_channels=32, num_layers=2)
+        a.update({k: v for k, v in c.items() if k != "name"})
+        args = types.SimpleNamespace(**a)
+        data = types.SimpleNamespace(x=x.clone(), m=m.clone(), edge_index=torch.from_numpy(ei))
+        ns = reference_filter_script(args, D, V, data, yv.clone())
+        torch.manual_seed(seed + ci)
+        model = ns["gen_model"](args)
+        randomise(model, seed + 10 + ci)
+        t = "c/" + c["name"] + "/"
+        for k, v in a.items():
+            arrays[t + "args/" + k] = np.array(v)
+        if a["lap_method"] == "basis_inv":
+            arrays[t + "mults"] = np.array(sorted(ns["same_size_projs"]), dtype=np.int64)
+        for k, v in model.state_dict().items():
+            arrays[t + "sd/" + k] = v.detach().clone().numpy()
+        model.train()
+        with torch.no_grad():
+            feat = ns["get_lap_feat"](args.use_eig, D, V, x[:, 0:1], args.lap_method, model)
+            arrays[t + "feat"] = feat.numpy()
+            arrays[t + "pre"] = model(feat, data.edge_index).numpy()
+        opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+        losses = []
+        for step in range(4):
+            loss, r2 = ns["train"](0, model, opt)
+            losses.append(loss)
+            if step == 0:
+                arrays[t + "r2"] = np.array(r2)
+                for k, p_ in model.named_parameters():
+                    arrays[t + "grad/" + k] = (torch.zeros_like(p_) if p_.grad is None else p_.grad).detach().clone().numpy()
+                for k, v in model.state_dict().items():
+                    arrays[t + "sd1/" + k] = v.detach().clone().numpy()
+        arrays[t + "losses"] = np.array(losses, dtype=np.float64)
+    save(name, **arrays)
+
+
 # ------------------------------------------------------------------ eigendecomposition transform (SURVEY.md §8 f2)
 def evd_case(name, sizes, seed):
     """The reference's own EVDTransform (Alchemy/sign_net/transform.py:7-23) per sample, both normalisations.
@@ -427,6 +506,16 @@ def main():
     # BasisNet on a small grid
     basisnet_case("basisnet_grid6", 6, 8, 41)
     grouping_case("basisnet_grouping", [6, 12, 32])
+    filters_case("learning_filters_grid6", 6, [
+        dict(name="ds_signinv_ds", net="DS", hidden_channels=32, num_layers=3, lap_method="sign_inv", sign_inv_net="DS"),
+        dict(name="ds_basisinv_ign", net="DS", hidden_channels=16, num_layers=2, lap_method="basis_inv", basis_inv_net="IGN"),
+        dict(name="tf_signinv_ds", net="Transformer", hidden_channels=16, num_layers=2, lap_method="sign_inv", sign_inv_net="DS"),
+        dict(name="tf_basisinv_ign", net="Transformer", hidden_channels=12, num_layers=2, lap_method="basis_inv", basis_inv_net="IGN"),
+        dict(name="mlp_signinv_mlp", net="MLP", hidden_channels=24, num_layers=3, lap_method="sign_inv", sign_inv_net="MLP"),
+        dict(name="linear_signinv_tf", net="Linear", lap_method="sign_inv", sign_inv_net="Transformer"),
+        dict(name="ds_basisinv_shared", net="DS", hidden_channels=16, num_layers=2, lap_method="basis_inv", basis_inv_net="IGNShared"),
+        dict(name="tf_eig_none", net="Transformer", hidden_channels=20, num_layers=3, lap_method="none"),
+    ], 61)
     # eigendecomposition transform: sizes across the kernel's 16 / 32 / 64-lane classes, odd and even, 1- and 2-node graphs
     evd_case("evd_transform", [1, 2, 3, 8, 15, 16, 17, 23, 31, 32, 33, 37, 48, 63, 64], 51)
 

@@ -55,3 +55,24 @@ def pyg_cfg(fx):
     from oracle import pyg_signnet as O
     c = [None if v < 0 else int(v) for v in fx.meta["ctor"]]
     return O.make_cfg(str(fx.meta["variant"]), *c)
+
+
+def load_filters(name="learning_filters_grid6"):
+    """The LearningFilters training fixture: shared inputs + per case {args, sd, sd1, grad, feat, pre, losses}."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    inp = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in/")}
+    cases = {}
+    for k in z.files:
+        if not k.startswith("c/"):
+            continue
+        _, cname, rest = k.split("/", 2)
+        c = cases.setdefault(cname, {"args": {}, "sd": {}, "sd1": {}, "grad": {}})
+        a = z[k]
+        if "/" in rest and rest.split("/", 1)[0] in c:
+            grp, key = rest.split("/", 1)
+            c[grp][key] = a.item() if grp == "args" else torch.from_numpy(a)
+        else:
+            c[rest] = torch.from_numpy(a) if a.ndim else a.item()
+    for c in cases.values():
+        c["cfg"] = dict(c["args"], mults=[int(m) for m in c["mults"]] if "mults" in c else [])
+    return types.SimpleNamespace(inp=inp, cases=cases, side=int(z["meta/side"]))

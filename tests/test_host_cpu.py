@@ -200,3 +200,28 @@ def test_unimplemented_dropout_is_refused_not_ignored():
         dgl_deepsigns.GINDeepSigns(1, 8, 4, 3, 6, use_bn=True)                 # the reference's default dropout=0.5
     with pytest.raises(NotImplementedError, match="dropout"):
         dgl_deepsigns.MaskedGINDeepSigns(1, 8, 4, 3, 6, use_bn=True, dropout=0.1)
+
+
+def test_learning_filters_factories_have_the_reference_state_dict_keys():
+    """gen_model (training.py:152-181) builds modules whose state_dict keys are exactly the reference's, for
+    every configuration of the fixture (DS / MLP / Linear / Transformer bases; DS / MLP / Transformer sign-invariant nets; IGN and
+    IGNShared basis-invariant nets) — checked by a strict load of the reference's own tensors."""
+    import types
+
+    import golden_util as G
+    from signnet_basisnet_amd import learning_filters as LF
+    from signnet_basisnet_amd.dropin.learningfilters import models as dropin_models
+    assert dropin_models.Transformer is LF.Transformer and dropin_models.MLP is LF.MLP
+    fx = G.load_filters()
+    for name, c in fx.cases.items():
+        args = LF.FilterArgs(**c["args"])
+        eig = types.SimpleNamespace(N=36, pe_dim=32 if args.lap_method != "none" else 72, uniq_mults=c["cfg"]["mults"], num_eigenspaces=0)
+        model = LF.gen_model(args, eig, "cpu")
+        model.load_state_dict(c["sd"], strict=True)
+        assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for k, v in c["grad"].items()), name
+    with pytest.raises(NotImplementedError):
+        LF.gen_model(LF.FilterArgs(net="BernNet"), types.SimpleNamespace(N=36, pe_dim=0, uniq_mults=[], num_eigenspaces=0), "cpu")
+    with pytest.raises(NotImplementedError):
+        LF.Transformer(4, dropout=0.1)
+    with pytest.raises(RuntimeError):            # no CPU path: the forward needs the HIP library and device tensors
+        LF.MLP(3)(torch.zeros(5, 3))
