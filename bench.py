@@ -332,6 +332,35 @@ def basisnet_bench(args, dev):
                                 "max_abs_diff_vs_projector_path": float((y2 - y).abs().max()), "output_scale": float(y.abs().max()),
                                 "note": "IGNBasisInv.forward_eigvecs: contractions of P = V V^T computed from V (4*N*sum(mult) = "
                                         f"{4 * N * N} bytes instead of {int(proj_bytes)}); an extension, the reference API takes projectors"}
+    # the training workload the reference runs on this graph (scripts/sign_basis_inv.sh): epochs of
+    # training.py:132-150 — get_lap_feat (basis_inv) -> base net -> masked square loss -> backward -> Adam
+    from signnet_basisnet_amd import learning_filters as LF
+    from signnet_basisnet_amd.optim import Adam
+    out["training"] = {"what": "one epoch = training.py:132-150 (forward of every IGN2to1 + rho + base net, loss, backward, Adam) on "
+                               "the 32x32 grid; contractions of the constant projectors computed once (GridEigen)", "configs": {}}
+    gen = torch.Generator().manual_seed(5)
+    xs, ys = torch.randn(N, 1, generator=gen).to(dev), torch.randn(N, 1, generator=gen).to(dev)
+    ms = torch.ones(N, 1, device=dev)
+    for label, fa in (("DS h16 + basis_inv IGN", LF.FilterArgs(net="DS", hidden_channels=16, use_eig=True, lap_method="basis_inv")),
+                      ("Transformer h12 + basis_inv IGN", LF.FilterArgs(net="Transformer", hidden_channels=12, use_eig=True,
+                                                                         lap_method="basis_inv")),
+                      ("DS h32 L3 + sign_inv DS", LF.FilterArgs(net="DS", hidden_channels=32, num_layers=3, use_eig=True,
+                                                                 lap_method="sign_inv", sign_inv_net="DS"))):
+        geig = LF.GridEigen(val_dev, ev_dev, fa)
+        torch.manual_seed(0)
+        fmodel = LF.gen_model(fa, geig, dev)
+        fopt = Adam(fmodel.parameters(), lr=fa.lr)
+        for _ in range(max(3, args.warmup // 4)):
+            LF.train_step(fmodel, fopt, fa, geig, xs, ys, ms)
+        torch.cuda.synchronize()
+        nst = max(5, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(nst):
+            floss, _ = LF.train_step(fmodel, fopt, fa, geig, xs, ys, ms)
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / nst
+        out["training"]["configs"][label] = {"ms_per_epoch": 1e3 * dte, "epochs_per_s": 1.0 / dte, "loss_after": float(floss),
+                                             "parameters": sum(p.numel() for p in fmodel.parameters())}
     if not args.no_cpu_baseline:
         sdphi = [{k: v.detach().cpu() for k, v in phi.encs[phi.mult_to_idx[m]].state_dict().items()} for m in mults]
         eqs = [[(e.coeffs.detach().cpu(), e.bias.detach().cpu()) for e in phi.encs[phi.mult_to_idx[m]].equi_layers] for m in mults]
