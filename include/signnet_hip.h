@@ -265,7 +265,8 @@ int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* gr
  *   (dee, [E,C] in edge-id order) over the REVERSE CSR (rows = source nodes, rev_col = destination, rev_eperm = edge id:
  *   sn_batch_plan on the flipped edge_index).  (GIN's adjoint is sn_gin_aggregate_f32 itself on the reverse CSR.)
  * sn_slot_broadcast_f32 / sn_segment_broadcast_f32: adjoints of sn_slot_sum_f32 (valid slots only) / sn_segment_pool_f32.
- * sn_embedding_sum_bwd_f32: dtables[f][v,:] += sum_{r: idx[r,f] = v} g[r,:] in row order (no atomics: bitwise reproducible; C <= 512);
+ * sn_embedding_sum_bwd_f32: dtables[f][v,:] += sum_{r: idx[r,f] = v} g[r,:] (no atomics: per-chunk partial sums in row order, then
+ *   the chunks in order — bitwise reproducible; C <= 512; scratch: float[sn_embedding_bwd_scratch_floats(R, nf, table_rows, C)]);
  *   out-of-range indices contribute nothing and set bit 0 of *status (device int32, may be NULL); table_rows as in the forward.
  * sn_dot_f32: out[0] = sum a[i] b[i] (the GIN / GINE eps gradients).  scratch: float[256].
  * sn_adam_step_f32: one torch.optim.Adam step (no amsgrad; weight_decay added to the gradient) on a flat tensor; the gradient is
@@ -290,8 +291,9 @@ int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, i
                               void* stream);
 int sn_slot_broadcast_f32(const float* g, int64_t N, int K, int C, const int32_t* nvalid, float* dx, void* stream);
 int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const int32_t* graph_ptr, int mode, float* dx, void* stream);
+int64_t sn_embedding_bwd_scratch_floats(int64_t R, int nf, const int64_t* table_rows, int C);
 int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, const int64_t* table_rows,
-                             int C, const float* g, int32_t* status, void* stream);
+                             int C, const float* g, int32_t* status, float* scratch, void* stream);
 int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch, void* stream);
 int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, float grad_scale, void* stream);

@@ -54,7 +54,7 @@ SIGNATURES = {
     "sn_gine_aggregate_bwd_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
     "sn_slot_broadcast_f32": [_p, _l, _i, _i, _p, _p, _p],
     "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],
-    "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, C.POINTER(C.c_int64), _i, _p, _p, _p],
+    "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, C.POINTER(C.c_int64), _i, _p, _p, _p, _p],
     "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
     "sn_pna_aggregate_f32": [_p, _i, _p, _i, _i, _l, _p, _p, _f, _p, _i, _p],
     "sn_edge_attention_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p],
@@ -100,6 +100,8 @@ def lib():
         L.sn_bn_act_bwd_scratch_floats.restype = C.c_int64
         L.sn_layernorm_bwd_scratch_floats.argtypes = [_l, _i]
         L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
+        L.sn_embedding_bwd_scratch_floats.argtypes = [_l, _i, C.POINTER(C.c_int64), _i]
+        L.sn_embedding_bwd_scratch_floats.restype = C.c_int64
         L.sn_evd_work_ints.argtypes = [_l]
         L.sn_evd_work_ints.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]

@@ -288,7 +288,9 @@ class _EmbeddingSum(Function):
         arr = (C.c_void_p * nf)(*[grads[f].data_ptr() for f in range(nf)])
         rows = (C.c_int64 * nf)(*[ctx.shapes[f][0] for f in range(nf)])
         # (out-of-range indices were reported by the forward; the backward skips them — deterministic, no atomics)
-        check(lib().sn_embedding_sum_bwd_f32(ptr(idx), nf, nf, R, arr, rows, g.shape[-1], ptr(g), None, stream()), "sn_embedding_sum_bwd_f32")
+        scratch = torch.empty(int(lib().sn_embedding_bwd_scratch_floats(R, nf, rows, g.shape[-1])), dtype=torch.float32, device=g.device)
+        check(lib().sn_embedding_sum_bwd_f32(ptr(idx), nf, nf, R, arr, rows, g.shape[-1], ptr(g), None, ptr(scratch), stream()),
+              "sn_embedding_sum_bwd_f32")
         return (None, None, *grads)
 
 

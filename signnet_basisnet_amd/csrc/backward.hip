@@ -367,28 +367,71 @@ __global__ __launch_bounds__(256) void k_segment_bcast(const float* __restrict__
     dx[(int64_t)lo * C + i] = g[(int64_t)b * C + c] * w;
   }
 }
-// dT_f[v, :] = sum over the rows r with idx[r,f] == v of g[r, :], in row order — one workgroup per table row v: no atomics, so
-// the embedding gradients are bitwise reproducible (nn.Embedding's own backward is not).  The index column is re-read by every
-// workgroup (wave-uniform scalar loads, V*R*8 bytes of L2 traffic): V <= 500 in the reference (elements.py:22).  An index outside
-// [0, V) contributes nothing and raises bit 0 of *status (workgroup 0 checks the whole column).
-__global__ __launch_bounds__(256) void k_embedding_bwd(const int64_t* __restrict__ idx, int ldi, int f, int64_t R, int64_t V,
-                                                       float* __restrict__ dT, int C, const float* __restrict__ g,
-                                                       int32_t* __restrict__ status) {
-  const int64_t v = blockIdx.x;
-  const int c0 = threadIdx.x, c1 = threadIdx.x + 256;
+// dT_f[v, :] += sum over the rows r with idx[r,f] == v of g[r, :] — deterministic (no atomics: nn.Embedding's own backward is not),
+// in two phases so that the work spreads over the chip and no thread walks a dependent chain of R loads:
+//   partial: workgroup (chunk, v) takes `rpc` consecutive rows, compacts the rows whose index is v into an ordered LDS list (wave
+//            ballots), then sums their g rows four loads at a time                               -> part[chunk][v][C]
+//   reduce : dT[v][c] += part[0][v][c] + part[1][v][c] + ...   (chunk order)
+// rpc is a function of (R, V) only, so the summation order — and every bit of the result — is fixed for a given input.
+// An index outside [0, V) contributes nothing and raises bit 0 of *status.
+__global__ __launch_bounds__(256) void k_embedding_bwd_partial(const int64_t* __restrict__ idx, int ldi, int f, int64_t R, int64_t V,
+                                                               int rpc, int C, const float* __restrict__ g,
+                                                               float* __restrict__ part, int32_t* __restrict__ status) {
+  __shared__ int32_t list[256];
+  __shared__ int32_t wcount[4];
+  const int64_t v = blockIdx.y, chunk = blockIdx.x;
+  const int64_t r0 = chunk * rpc, r1 = r0 + rpc < R ? r0 + rpc : R;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c0 = tid, c1 = tid + 256;
   float a0 = 0.f, a1 = 0.f;
   bool bad = false;
-  for (int64_t r = 0; r < R; ++r) {
-    const int64_t id = idx[r * ldi + f];                     // uniform across the workgroup
-    if (id == v) {
-      if (c0 < C) a0 += g[r * C + c0];
-      if (c1 < C) a1 += g[r * C + c1];
+  for (int64_t base = r0; base < r1; base += 256) {
+    const int64_t r = base + tid;
+    const int64_t id = r < r1 ? idx[r * ldi + f] : -1;
+    const bool hit = id == v;
+    bad = bad || (r < r1 && (uint64_t)id >= (uint64_t)V);
+    const unsigned long long mask = __ballot(hit);
+    if (lane == 0) wcount[w] = __popcll(mask);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { off += i < w ? wcount[i] : 0; total += wcount[i]; }
+    if (hit) list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(r - r0);
+    __syncthreads();
+    int i = 0;
+    for (; i + 4 <= total; i += 4) {
+      const float* p0 = g + (r0 + list[i]) * C;
+      const float* p1 = g + (r0 + list[i + 1]) * C;
+      const float* p2 = g + (r0 + list[i + 2]) * C;
+      const float* p3 = g + (r0 + list[i + 3]) * C;
+      if (c0 < C) { const float x0 = p0[c0], x1 = p1[c0], x2 = p2[c0], x3 = p3[c0]; a0 = (((a0 + x0) + x1) + x2) + x3; }
+      if (c1 < C) { const float x0 = p0[c1], x1 = p1[c1], x2 = p2[c1], x3 = p3[c1]; a1 = (((a1 + x0) + x1) + x2) + x3; }
     }
-    bad = bad || (uint64_t)id >= (uint64_t)V;
+    for (; i < total; ++i) {
+      const float* p0 = g + (r0 + list[i]) * C;
+      if (c0 < C) a0 += p0[c0];
+      if (c1 < C) a1 += p0[c1];
+    }
+    __syncthreads();
   }
-  if (c0 < C) dT[v * C + c0] += a0;
-  if (c1 < C) dT[v * C + c1] += a1;
-  if (bad && v == 0 && threadIdx.x == 0 && status != nullptr) atomicOr(status, 1);
+  float* o = part + (chunk * V + v) * C;
+  if (c0 < C) o[c0] = a0;
+  if (c1 < C) o[c1] = a1;
+  if (v == 0 && status != nullptr && __syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
+}
+__global__ __launch_bounds__(256) void k_embedding_bwd_reduce(const float* __restrict__ part, int nchunks, int64_t V, int C,
+                                                              float* __restrict__ dT) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= V * C) return;
+  float a = 0.f;
+  for (int k = 0; k < nchunks; ++k) a += part[(int64_t)k * V * C + i];
+  dT[i] += a;
+}
+// rows per chunk: 256 unless that makes more than ~4096 workgroups for this table
+inline int embedding_bwd_rpc(int64_t R, int64_t V) {
+  int64_t rpc = 256;
+  while (cdiv(R, rpc) * V > 4096) rpc *= 2;
+  return (int)rpc;
 }
 // out[0] = sum_i a[i]*b[i]   (two stages, deterministic)
 __global__ __launch_bounds__(256) void k_dot_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
@@ -567,15 +610,31 @@ extern "C" int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const 
   return SN_OK;
 }
 
+extern "C" int64_t sn_embedding_bwd_scratch_floats(int64_t R, int nf, const int64_t* table_rows, int C) {
+  int64_t need = 1;
+  for (int f = 0; f < nf; ++f) {
+    const int64_t V = table_rows[f] > 0 ? table_rows[f] : 1;
+    const int64_t n = cdiv(R > 0 ? R : 1, embedding_bwd_rpc(R, V)) * V * C;
+    need = n > need ? n : need;
+  }
+  return need;
+}
+
 extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables,
-                                        const int64_t* table_rows, int C, const float* g, int32_t* status, void* stream) {
-  SN_REQUIRE(idx && dtables && table_rows && g && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && C <= 512 && R >= 0,
+                                        const int64_t* table_rows, int C, const float* g, int32_t* status, float* scratch,
+                                        void* stream) {
+  SN_REQUIRE(idx && dtables && table_rows && g && scratch && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && C <= 512 && R >= 0,
              "sn_embedding_sum_bwd_f32: bad arguments (C <= 512)");
   if (R == 0) return SN_OK;
   for (int f = 0; f < nf; ++f) {
-    SN_REQUIRE(dtables[f] && table_rows[f] > 0, "sn_embedding_sum_bwd_f32: table %d missing or empty", f);
-    hipLaunchKernelGGL(k_embedding_bwd, dim3((unsigned)table_rows[f]), dim3(256), 0, (hipStream_t)stream, idx, ldi, f, R,
-                       table_rows[f], dtables[f], C, g, status);
+    SN_REQUIRE(dtables[f] && table_rows[f] > 0 && table_rows[f] <= 65535, "sn_embedding_sum_bwd_f32: table %d missing, empty or > 65535 rows", f);
+    const int64_t V = table_rows[f];
+    const int rpc = embedding_bwd_rpc(R, V);
+    const int nchunks = (int)cdiv(R, rpc);
+    hipLaunchKernelGGL(k_embedding_bwd_partial, dim3((unsigned)nchunks, (unsigned)V), dim3(256), 0, (hipStream_t)stream, idx, ldi, f, R, V,
+                       rpc, C, g, scratch, status);
+    hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3((unsigned)cdiv(V * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)scratch, nchunks, V, C, dtables[f]);
   }
   SN_CHECK_LAUNCH("sn_embedding_sum_bwd_f32");
   return SN_OK;

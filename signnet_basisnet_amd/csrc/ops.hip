@@ -405,6 +405,99 @@ __global__ __launch_bounds__(256) void k_colstats_final(const float* __restrict_
   }
 }
 
+// One-pass column moments for the train-mode BatchNorm: every block writes (count, mean, M2) of its rows per column — sums of
+// d = x - s and d^2 around a shift s taken from the block's first valid row (a sample of the column, so the subtraction
+// S2 - S1^2/n loses at most a small constant factor) — and k_bn_train_finish1 merges the blocks with Chan's pairwise update.
+// x is read ONCE (the two-pass form read it twice and took six launches).
+__global__ __launch_bounds__(256) void k_colstats_moments(const float* __restrict__ x, int ldx, int64_t R, int C,
+                                                          const int32_t* __restrict__ nvalid, int K, int64_t rows_per_block,
+                                                          float* __restrict__ pmean, float* __restrict__ pm2,
+                                                          float* __restrict__ pcnt) {
+  __shared__ float red1[4][64], red2[4][64];
+  __shared__ int cred[4];
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  int64_t rs = r0;                                             // first valid row of the block (uniform)
+  if (nvalid && r0 < r1) {
+    const unsigned node = (unsigned)r0 / (unsigned)K;
+    if ((int)((unsigned)r0 - node * (unsigned)K) >= nvalid[node]) {
+      int64_t nd = (int64_t)node + 1;
+      while (nd * K < r1 && nvalid[nd] <= 0) ++nd;
+      rs = nd * K;
+    }
+  }
+  const bool any = rs < r1;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
+    const float sh = (any && c < C) ? x[rs * ldx + c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    int cnt = 0;
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      bool ok = true;
+      if (nvalid) { unsigned node = (unsigned)r / (unsigned)K; ok = (int)((unsigned)r - node * (unsigned)K) < nvalid[node]; }
+      if (ok) {
+        ++cnt;
+        if (c < C) { const float d = x[r * ldx + c] - sh; s1 += d; s2 += d * d; }
+      }
+    }
+    red1[rl][cl] = s1;
+    red2[rl][cl] = s2;
+    if (cl == 0) cred[rl] = cnt;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      const float n = (float)(cred[0] + cred[1] + cred[2] + cred[3]);
+      const float t1 = (red1[0][cl] + red1[1][cl]) + (red1[2][cl] + red1[3][cl]);
+      const float t2 = (red2[0][cl] + red2[1][cl]) + (red2[2][cl] + red2[3][cl]);
+      pmean[(int64_t)blockIdx.x * C + c] = n > 0.f ? sh + t1 / n : 0.f;
+      pm2[(int64_t)blockIdx.x * C + c] = n > 0.f ? fmaxf(t2 - t1 * t1 / n, 0.f) : 0.f;
+    }
+    if (threadIdx.x == 0 && c0 == 0) pcnt[blockIdx.x] = (float)(cred[0] + cred[1] + cred[2] + cred[3]);
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+  if (nb <= 0.f) return;
+  const float n = na + nb, d = mb - ma;
+  ma += d * (nb / n);
+  qa += qb + d * d * (na * nb / n);
+  na = n;
+}
+// merges the per-block moments (4 lanes per column, then across the lanes) and finishes the BatchNorm: mean, biased variance, rstd,
+// folded (scale, shift), count, running statistics.  grid cdiv(C, 64), 256 threads.
+__global__ __launch_bounds__(256) void k_bn_train_finish1(const float* __restrict__ pmean, const float* __restrict__ pm2,
+                                                          const float* __restrict__ pcnt, int nblk, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float momentum, float* __restrict__ mean, float* __restrict__ var,
+                                                          float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ count, float* __restrict__ rmean, float* __restrict__ rvar) {
+  __shared__ float ln[4][64], lm[4][64], lq[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (nblk + 3) / 4, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  float n = 0.f, m = 0.f, q = 0.f;
+  if (c < C)
+    for (int b = b0; b < b1; ++b) chan_merge(n, m, q, pcnt[b], pmean[(int64_t)b * C + c], pm2[(int64_t)b * C + c]);
+  ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int i = 1; i < 4; ++i) chan_merge(n, m, q, ln[i][cl], lm[i][cl], lq[i][cl]);
+  const float v = n > 0.f ? q / n : 0.f;
+  const float rs = 1.0f / sqrtf(v + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * rs;
+  mean[c] = m;
+  var[c] = v;
+  rstd[c] = rs;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - m * sc;
+  if (c == 0) count[0] = n;
+  if (rmean) {
+    const float unb = n > 1.f ? v * (n / (n - 1.f)) : v;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
 // Second-pass finish of a train-mode BatchNorm in ONE launch: variance from the partial sums of (x-mean)^2, then
 // rstd, the folded (scale, shift) and the running-statistics update (what k_colstats_final + two k_bn_fold + k_bn_running_update did).
 __global__ __launch_bounds__(256) void k_bn_train_finish(const float* __restrict__ part, int nblk, int C, const float* __restrict__ count,
@@ -822,26 +915,17 @@ extern "C" int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, 
   SN_REQUIRE((running_mean != nullptr) == (running_var != nullptr), "sn_bn_train_stats_f32: running_mean / running_var go together");
   SN_REQUIRE(R < (1ll << 31), "sn_bn_train_stats_f32: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  const int ntot = sn_colstats_blocks(R), nblk = ntot - CS_SPLIT;
-  int64_t rpb = cdiv(R > 0 ? R : 1, nblk);
-  float* part = scratch;
-  float* part2 = scratch + (int64_t)nblk * C;
-  float* cnt = scratch + (int64_t)ntot * C;
-  float* cnt2 = cnt + nblk;
-  const bool two = nblk > 2 * CS_SPLIT;
-  const dim3 rgrid((unsigned)cdiv(C + 1, 256), CS_SPLIT);
-  hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)nullptr, 0,
-                     rpb, part, cnt);
-  if (two) hipLaunchKernelGGL(k_colstats_reduce, rgrid, dim3(256), 0, st, (const float*)part, (const float*)cnt, nblk, C, part2, cnt2);
-  hipLaunchKernelGGL(k_colstats_final, dim3(1), dim3(256), 0, st, two ? part2 : part, two ? cnt2 : cnt, two ? CS_SPLIT : nblk, C,
-                     mean, count, 0);
-  hipLaunchKernelGGL(k_colstats_partial, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, (const float*)mean, 1,
-                     rpb, part, (float*)nullptr);
-  if (two) hipLaunchKernelGGL(k_colstats_reduce, rgrid, dim3(256), 0, st, (const float*)part, (const float*)nullptr, nblk, C, part2,
-                              (float*)nullptr);
-  hipLaunchKernelGGL(k_bn_train_finish, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, (const float*)(two ? part2 : part),
-                     two ? CS_SPLIT : nblk, C, (const float*)count, (const float*)mean, gamma, beta, eps, momentum, var, rstd, scale,
-                     shift, running_mean, running_var);
+  // scratch is sized for the two-pass form ((nblk + CS_SPLIT) * (C + 1) floats): half as many blocks, two moment planes + counts
+  const int nfull = sn_colstats_blocks(R) - CS_SPLIT;
+  const int nblk = nfull > 1 ? nfull / 2 : 1;
+  const int64_t rpb = cdiv(R > 0 ? R : 1, nblk);
+  float* pmean = scratch;
+  float* pm2 = scratch + (int64_t)nblk * C;
+  float* pcnt = scratch + (int64_t)2 * nblk * C;
+  hipLaunchKernelGGL(k_colstats_moments, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, rpb, pmean, pm2, pcnt);
+  hipLaunchKernelGGL(k_bn_train_finish1, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)pmean, (const float*)pm2,
+                     (const float*)pcnt, nblk, C, gamma, beta, eps, momentum, mean, var, rstd, scale, shift, count, running_mean,
+                     running_var);
   SN_CHECK_LAUNCH("sn_bn_train_stats_f32");
   return SN_OK;
 }
