@@ -48,7 +48,8 @@ int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz);
  * Inputs : batch[N] int64 ascending; edge_index[2,E] int64 (row 0 = source, row 1 = target).
  * Outputs (int32, caller-allocated):
  *   graph_ptr[B+1]  first node of each graph;        node_graph[N]  graph id per node
- *   nvalid[N]       min(n_graph, kmax) per node (kmax<=0: n_graph) — number of valid slots
+ *   nvalid[N]       min(n_graph, |kmax|) per node (kmax = 0: n_graph) — number of valid slots.  kmax < 0 ("full slots", the DGL
+ *                   tree's dense [N, K] encodings): same nvalid, but the phi work bins cover all |kmax| slots of every graph
  *   evoff[B+1]      prefix of n_b^2   (offset of graph b's eigenvector block, int64)
  *   rowptr[N+1], col[E] (source node of each in-edge), eperm[E] (edge id, for edge_attr)
  *     — in-edges of a node are ordered by edge id (deterministic summation order)
@@ -400,7 +401,7 @@ typedef struct {
 
 #define SN_PHI_MAX_LAYERS 16
 typedef struct {
-  int d, n_layers, hid0, reserved;
+  int d, n_layers, hid0, reserved; /* reserved: 0 for sn_phi_fused_f32; sn_deepsigns_phi_f32: the output width (phi_out_dim) */
   const float* l0_w1;        /* [hid0_pad] : Linear(1 -> hid0).weight[:, 0] */
   const float* l0_bn0_scale; /* [hid0_pad] */
   const float* l0_bn0_shift;
@@ -419,6 +420,29 @@ int sn_phi_fused_f32(const sn_phi_params* params /* host struct of device pointe
                      const int32_t* rowptr, const int32_t* col, const sn_plan_bins* bins,
                      int kmax /* as given to sn_batch_plan */, int K /* row stride of out in slots */,
                      float* out, void* stream);
+
+/* The sign-invariant encoder of the DGL tree, enc(g, x) + enc(g, -x) with enc = GIN (GraphPrediction/layers/deepsigns.py:45-46 /
+ * :72-73, layers/gnns.py:81-114, layers/mlp.py:37-56), eval mode, ONE launch — the same stage kernel as sn_phi_fused_f32 with the
+ * DGL layer order.  Per GIN layer l the caller folds the eval BatchNorms at pack time and passes, all split-packed on widths
+ * zero-padded to d (a multiple of 16, 48..112):
+ *   layer 0:   l0_w1 = lins.0.weight[:, 0] (Linear(1 -> hidden)), (l0_bn0_scale, l0_bn0_shift) = (1, lins.0.bias): relu(a*w + b);
+ *              l0_w2 = lins.1 with the MLP's BatchNorm (after the ReLU) folded in, (e0, e1, e2) = (bias', s, t) where (s, t) is the
+ *              folded enc.bns[0] (applied in front of layer 1; (1, 0) after the last layer):  out = (W1' h + e0) * e1 + e2
+ *   layer l>0: w1s = lins.0 with (e0, e1) = (1, bias);  w2s as l0_w2 above.           No ReLU and no residual after the second Linear.
+ * x: the dense positional encodings [N, ldx] (row = node, K columns used).  All K slots of every node are evaluated (zero-padded
+ * columns of small graphs included): sn_batch_plan must have been called with kmax = -K ("full slots").  out: [N*K, params->reserved]
+ * (row = node*K + slot), reserved = phi_out_dim <= d.  Graphs of more than 64 nodes: meta[1] != 0, nothing is written. */
+int sn_deepsigns_phi_f32(const sn_phi_params* params, const float* x, int ldx, const int32_t* graph_ptr, const int32_t* rowptr,
+                         const int32_t* col, const sn_plan_bins* bins, int K, float* out, void* stream);
+
+/* A whole MLP over matrix rows in one launch: y = W_{L-1} relu(... relu(W_0 x + b_0) ...) + b_{L-1} — rho of the DGL sign-invariant
+ * nets (layers/deepsigns.py:47-49 and :81-84 with layers/mlp.py:37-56; eval BatchNorms, which sit between a ReLU and the next
+ * Linear, folded into that Linear by the caller).  weights: host array of n_layers device pointers, each sn_pack_split_f32 of the
+ * [d_pad, d_pad] zero-padded matrix with e0 = bias.  nvalid == NULL: row r of the input is x[r*ldx + 0..d_in); else (masked
+ * variant) it is sum_{s < nvalid[r]} x[(r*K + s)*ldx + 0..d_in) — the masked sum over the slot axis (deepsigns.py:76-81). */
+#define SN_MLP_MAX_LAYERS 16
+int sn_mlp_chain_f32(const float* x, int ldx, int64_t R, int d_in, const int32_t* nvalid, int K, const void* const* weights,
+                     int n_layers, int d_pad, float* y, int ldy, int d_out, void* stream);
 
 /* rho: the set-transformer encoder layers over each node's valid slots and the sum over slots, one launch.
  * Replaces SetTransformer.forward up to torch.sum(x, dim=1) (sign_net.py:60-70 / core/sign_net.py:64-75)

@@ -47,13 +47,19 @@ struct PhiStruct {
   int kmax;
   int K;
   float* out;
+  int dense_ld;              // DGL variant: the input is a dense [N, dense_ld] matrix of positional encodings (row = node), not eigenvectors
 };
 
 constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
 
 // HID1: layer 0 is Linear(1->1).BN.ReLU.Linear(1->d) (GINESignNetPyG) — no [d,d] GEMM in layer 0; else Linear(1->d)...Linear(d->d)
 // (Alchemy).  A template parameter so that the variant without the layer-0 GEMM does not carry its registers.
-template <int NT, bool HID1>
+// DGL: the GraphPrediction tree's GIN (layers/gnns.py:81-114 inside deepsigns.py:33-86) with eval-mode BatchNorms folded at pack
+// time: per layer  aggregate -> relu(W0 a + b0) -> (W1' h + b1') * s + t   (no ReLU, no residual after the second Linear; the
+// BatchNorm that follows the ReLU is folded into W1', b1', the one in front of the next layer is (s, t)); all |kmax| slots of every
+// node are evaluated (zero-padded eigenvector columns included), the input is a dense [N, K] matrix, and the output rows are
+// P.reserved (= phi_out_dim) wide.  Instantiated separately so that the PyG kernels carry none of it.
+template <int NT, bool HID1, bool DGL = false>
 __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn_phi_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;  // +4 floats: conflict-free ds_write_b128 of 8 consecutive rows
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       const int gi = gi_raw < 0 ? 0 : gi_raw;
       const int off = S.col_off[colid * 8 + k];
       const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
-      const int kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
+      const int kg = DGL ? S.kmax : ((S.kmax > 0 && n > S.kmax) ? S.kmax : n);
       if (gi_raw >= 0 && r >= off && r < off + n && slot < kg) {
         node = g0 + (r - off);
         gs = g0;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
     if (node >= 0) {
       e_lo = S.rowptr[node];
       e_hi = S.rowptr[node + 1];
-      xval = S.ev[S.evoff[gsel] + (int64_t)(node - gs) * nsel + slot];
+      xval = DGL ? S.ev[(int64_t)node * S.dense_ld + slot] : S.ev[S.evoff[gsel] + (int64_t)(node - gs) * nsel + slot];
     }
     const bool valid = node >= 0;
     const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all MFMAs (keeps barriers + DMA)
@@ -178,7 +184,10 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         }
         const void* nxt = P.n_layers > 1 ? P.layers[0].w1s : wfirst;
         wg_gemm_split<NT, NT, false>(ring, P.l0_w2, nxt, wave_live, sp, NoPre(),
-                                     [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4) { in[ot] = relu4((acc + b2) * s1 + h1); });
+                                     [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4) {
+                                       const f32x4 v = (acc + b2) * s1 + h1;
+                                       in[ot] = DGL ? v : relu4(v);
+                                     });
       }
       if (!valid) {
 #pragma unroll
@@ -263,7 +272,10 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         // GNN3d: mask . BN . ReLU . + previous_x
         wg_gemm_split<NT, NT, false>(
             ring, Lp.w2s, nxt, wave_live, sp, [&](int ot) { return lds_ld4(XR + 16 * ot + 4 * g); },
-            [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4 prev) { in[ot] = relu4((acc + b2) * s1 + h1) + prev; });
+            [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4 prev) {
+              const f32x4 v = (acc + b2) * s1 + h1;
+              in[ot] = DGL ? v : relu4(v) + prev;
+            });
         if (!valid) {
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
       }
       lds_barrier();
-      if (valid) {
+      if (valid && !DGL) {
         float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;     // the same row in the other sign's image
         constexpr int H = (NT + 1) / 2;
@@ -303,6 +315,24 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
           }
         }
       }
+      if (valid && DGL) {
+        const int dout = P.reserved;                               // phi_out_dim: any width <= d (rows are not float4-aligned)
+        float* orow = S.out + ((int64_t)node * S.K + slot) * dout;
+        const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;
+        constexpr int H = (NT + 1) / 2;
+#pragma unroll
+        for (int kk = 0; kk < NT; ++kk) {
+          const bool mine = sg ? (kk >= H) : (kk < H);
+          const int c = 16 * kk + 4 * g;
+          if (mine && c < dout) {
+            const f32x4 o4 = lds_ld4(XO + c);
+            const f32x4 v = sg ? o4 + in[kk] : in[kk] + o4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (c + t < dout) orow[c + t] = v[t];
+          }
+        }
+      }
       SN_ACCUM(14, pt);
     }
     SN_STAMP(11);
@@ -311,14 +341,14 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   ring.drain();
 }
 
-template <int NT, bool HID1>
+template <int NT, bool HID1, bool DGL = false>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   const size_t lds = (size_t)WRing<NT, PHI_WAVES>::BYTES + (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_phi_fused<NT, HID1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_phi_fused<NT, HID1, DGL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_phi_fused_f32: cannot raise the dynamic LDS limit to %zu", lds);
     int dev = 0, n = 256;
@@ -327,7 +357,7 @@ static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st
   }
   int64_t grid = S.max_bins < (int64_t)cus ? S.max_bins : (int64_t)cus;   // one 8-wave workgroup per CU (113 KB of LDS)
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_phi_fused<NT, HID1>), dim3((unsigned)grid), dim3(PHI_WAVES * 64), lds, st, S, P);
+  hipLaunchKernelGGL((k_phi_fused<NT, HID1, DGL>), dim3((unsigned)grid), dim3(PHI_WAVES * 64), lds, st, S, P);
   return SN_OK;
 }
 
@@ -349,6 +379,7 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
   SN_REQUIRE(P.d > 0 && P.d <= 128 && (P.d & 3) == 0, "sn_phi_fused_f32: hidden width %d must be a multiple of 4 in (0, 128]", P.d);
   SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS, "sn_phi_fused_f32: %d layers unsupported", P.n_layers);
   SN_REQUIRE(P.hid0 == 1 || P.hid0 == P.d, "sn_phi_fused_f32: first hidden width must be 1 or d");
+  SN_REQUIRE(kmax >= 0, "sn_phi_fused_f32: kmax < 0 (full slots) belongs to sn_deepsigns_phi_f32");
   SN_REQUIRE(P.l0_w1 && P.l0_bn0_scale && P.l0_bn0_shift && P.l0_w2 && P.l0_eps, "sn_phi_fused_f32: layer-0 parameters missing");
   SN_REQUIRE(P.hid0 != 1 || (P.l0_bn_scale && P.l0_bn_shift), "sn_phi_fused_f32: layer-0 BatchNorm vectors missing");
   for (int l = 1; l < P.n_layers; ++l) {
@@ -358,7 +389,7 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
   SN_REQUIRE(K > 0 && bins->phi_max_bins >= 0, "sn_phi_fused_f32: bad K / max_bins");
   if (bins->phi_max_bins == 0) return SN_OK;
   PhiStruct S{eigen_vectors, graph_ptr, evoff, rowptr, col, bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem,
-              bins->phi_col_off, bins->meta, bins->phi_max_bins, kmax, K, out};
+              bins->phi_col_off, bins->meta, bins->phi_max_bins, kmax, K, out, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   const int nt = (P.d + 15) / 16;
@@ -387,5 +418,39 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
   }
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_phi_fused_f32");
+  return SN_OK;
+}
+
+/* The DGL tree's GIN sign-invariant encoder, both signs and their sum, one launch (see sn_deepsigns_phi_f32 in signnet_hip.h). */
+extern "C" int sn_deepsigns_phi_f32(const sn_phi_params* params, const float* x, int ldx, const int32_t* graph_ptr,
+                                    const int32_t* rowptr, const int32_t* col, const sn_plan_bins* bins, int K, float* out,
+                                    void* stream) {
+  SN_REQUIRE(params && x && graph_ptr && rowptr && bins && out, "sn_deepsigns_phi_f32: null pointer");
+  SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->meta,
+             "sn_deepsigns_phi_f32: incomplete sn_plan_bins");
+  const sn_phi_params& P = *params;
+  SN_REQUIRE(P.d >= 48 && P.d <= 112 && (P.d & 15) == 0, "sn_deepsigns_phi_f32: padded hidden width %d must be a multiple of 16 in [48, 112]", P.d);
+  SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS && P.hid0 == P.d, "sn_deepsigns_phi_f32: bad layer count / hid0");
+  SN_REQUIRE(P.reserved >= 1 && P.reserved <= P.d, "sn_deepsigns_phi_f32: output width (params->reserved) %d not in [1, d]", P.reserved);
+  SN_REQUIRE(P.l0_w1 && P.l0_bn0_scale && P.l0_bn0_shift && P.l0_w2 && P.l0_eps, "sn_deepsigns_phi_f32: layer-0 parameters missing");
+  for (int l = 1; l < P.n_layers; ++l) {
+    const sn_phi_layer& L = P.layers[l - 1];
+    SN_REQUIRE(L.w1s && L.w2s && L.eps, "sn_deepsigns_phi_f32: layer %d parameters missing", l);
+  }
+  SN_REQUIRE(K > 0 && K <= 64 && ldx >= K && bins->phi_max_bins >= 0, "sn_deepsigns_phi_f32: bad K / ldx / max_bins");
+  if (bins->phi_max_bins == 0) return SN_OK;
+  PhiStruct S{x, graph_ptr, nullptr, rowptr, col, bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem,
+              bins->phi_col_off, bins->meta, bins->phi_max_bins, K, K, out, ldx};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = SN_OK;
+  switch (P.d / 16) {
+    case 3: rc = launch_phi<3, false, true>(S, P, st); break;
+    case 4: rc = launch_phi<4, false, true>(S, P, st); break;
+    case 5: rc = launch_phi<5, false, true>(S, P, st); break;
+    case 6: rc = launch_phi<6, false, true>(S, P, st); break;
+    default: rc = launch_phi<7, false, true>(S, P, st); break;
+  }
+  if (rc != SN_OK) return rc;
+  SN_CHECK_LAUNCH("sn_deepsigns_phi_f32");
   return SN_OK;
 }

@@ -54,7 +54,11 @@ __device__ __forceinline__ int block_exscan(int v, int* wsum, int t, int* total)
   return r;
 }
 
-__device__ __forceinline__ int slots_of(int n, int kmax) { return (kmax > 0 && n > kmax) ? kmax : n; }
+// kmax > 0: at most kmax eigenvector slots per node; 0: all n of them; kmax < 0 ("full slots", the DGL tree's dense [N, K] positional
+// encodings): the valid-slot count is still min(n, |kmax|), but the phi work bins cover all |kmax| slots of every graph (zero-padded
+// eigenvectors go through GINDeepSigns like any other column, deepsigns.py:45-51).
+__device__ __forceinline__ int slots_of(int n, int kmax) { const int k = kmax < 0 ? -kmax : kmax; return (k > 0 && n > k) ? k : n; }
+__device__ __forceinline__ int phi_slots_of(int n, int kmax) { return kmax < 0 ? -kmax : slots_of(n, kmax); }
 
 // ---------------------------------------------------------------------------- work bins (one workgroup)
 // phi: a unit is one (graph, slot) slab of n rows; graphs are packed into COLUMNS by best-fit-decreasing on n
@@ -202,7 +206,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     while (avail) {
       const int s = 64 - __clzll(avail);
       int cap = 64 - s, members = 0, off = 0;
-      const int H = slots_of(s, kmax);
+      const int H = phi_slots_of(s, kmax);
       int cls = s;
       if (lane == (ncol & 63)) colb = bin;
       while (true) {
@@ -219,7 +223,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
           rec_col[base] = recB & 8191;
           rec_off[base] = (((recB >> 13) & 7) << 8) | (recB >> 16);
         }
-        rows += cls * slots_of(cls, kmax);
+        rows += cls * phi_slots_of(cls, kmax);
         off += cls;
         ++members;
         if (members == 1) cap = 64 - s; else cap -= cls;
@@ -711,7 +715,8 @@ extern "C" int sn_prof_read_plan(long long* host) { return (int)hipMemcpyFromSym
 
 extern "C" int64_t sn_phi_bins_bound(int64_t B, int kmax) {
   // every column has height <= min(kmax, 64); at worst one graph per column
-  const int64_t h = (kmax > 0 && kmax < 64) ? kmax : 64;
+  const int k = kmax < 0 ? -kmax : kmax;          // (full-slot mode: exactly |kmax| bins per column)
+  const int64_t h = kmax < 0 ? k : ((k > 0 && k < 64) ? k : 64);
   return B * h + 1;
 }
 

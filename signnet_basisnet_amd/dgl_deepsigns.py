@@ -149,6 +149,120 @@ def _no_dropout(dropout, who):
                                   "pass dropout=0.0")
 
 
+def _pad_mat(W, dp):
+    out = torch.zeros(dp, dp, dtype=torch.float32, device=W.device)
+    out[:W.shape[0], :W.shape[1]].copy_(W.detach())
+    return out
+
+
+def _fold_bn_before(lin, site):
+    """Linear(BatchNorm(h)) with an eval BatchNorm (scale, shift) -> one Linear: W' = W diag(scale), b' = b + W shift.  On the device
+    ops (a column scaling and one [1, d] GEMM), run once per parameter version."""
+    W, b = lin.weight.detach().contiguous(), lin.bias.detach().contiguous()
+    if site is None:
+        return W, b
+    Wf = ops.masked_affine(W, scale=site.scale, shift=torch.zeros_like(site.shift))
+    bf = ops.masked_linear(site.shift.view(1, -1).contiguous(), ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], b)).view(-1)
+    return Wf, bf
+
+
+class _FusedDeepSigns:
+    """Packed eval-mode parameters of a (Masked)GINDeepSigns for the two stage kernels: sn_deepsigns_phi_f32 (enc(g,x) + enc(g,-x),
+    all GIN layers, one launch) and sn_mlp_chain_f32 (rho, with the masked slot sum in front for the masked variant).  With
+    sn_batch_plan that is three launches per forward (deepsigns.py:45-51 / :72-86).  `ok` is False for shapes the stage kernels do
+    not take (hidden > 112, k > 64, k * phi_out > 128, MLPs that are not the reference's 2-layer GIN MLP): the layer path serves those."""
+
+    def __init__(self, mod):
+        from .fused import _PhiParams
+        import ctypes as C
+        enc, rho, K = mod.enc, mod.rho, mod.k
+        self.ok = False
+        L = len(enc.layers)
+        mlps = [c.apply_func for c in enc.layers]
+        if any(len(m.lins) != 2 for m in mlps) or mlps[0].lins[0].weight.shape[1] != 1:
+            return
+        hidden = mlps[0].lins[0].weight.shape[0]
+        out = mlps[-1].lins[1].weight.shape[0]
+        dp = 16 * ((max(hidden, out) + 15) // 16)
+        dp = max(dp, 48)
+        d_in = out if mod.masked else K * out
+        rdims = [d_in] + [l.weight.shape[0] for l in rho.lins]
+        rp = max(48, 16 * ((max(rdims) + 15) // 16))
+        if not (dp <= 112 and rp <= 128 and 1 <= L <= 16 and K <= 64 and len(rho.lins) <= 16):
+            return
+        keep = self._keep = []
+
+        def hold(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        dev = mlps[0].lins[0].weight.device
+        ones = ops.pad_vec(torch.ones(hidden, device=dev), dp)
+        P = _PhiParams()
+        P.d, P.n_layers, P.hid0, P.reserved = dp, L, dp, out
+        for l, m in enumerate(mlps):
+            site_mid = _BNSite(m.bns[0], False) if m.use_bn else None                       # after the ReLU, before lins[1]
+            site_out = _BNSite(enc.bns[l], False) if (enc.use_bn and l < L - 1) else None   # in front of layer l + 1 (gnns.py:105-110)
+            W1, b1 = _fold_bn_before(m.lins[1], site_mid)
+            no = W1.shape[0]
+            e1 = ops.pad_vec(site_out.scale if site_out is not None else torch.ones(no, device=dev), dp)
+            e2 = ops.pad_vec(site_out.shift if site_out is not None else torch.zeros(no, device=dev), dp)
+            w2 = ops.pack_split(_pad_mat(W1, dp), ops.pad_vec(b1, dp), e1, e2)
+            b0 = ops.pad_vec(m.lins[0].bias, dp)
+            if l == 0:
+                P.l0_w1 = hold(ops.pad_vec(m.lins[0].weight[:, 0], dp))
+                P.l0_bn0_scale, P.l0_bn0_shift = hold(ones), hold(b0)
+                P.l0_w2 = hold(w2)
+                P.l0_eps = hold(enc.layers[0].eps.detach().float().contiguous())
+            else:
+                Lp = P.layers[l - 1]
+                Lp.w1s = hold(ops.pack_split(_pad_mat(m.lins[0].weight, dp), ones, b0, None))
+                Lp.w2s = hold(w2)
+                Lp.eps = hold(enc.layers[l].eps.detach().float().contiguous())
+        self.phi = P
+        # rho: relu(W0 x + b0), then every later Linear with the BatchNorm in front of it folded in
+        ws = []
+        for i, lin in enumerate(rho.lins):
+            site = _BNSite(rho.bns[i - 1], False) if (rho.use_bn and i > 0) else None
+            W, b = _fold_bn_before(lin, site)
+            ws.append(hold(ops.pack_split(_pad_mat(W, rp), ops.pad_vec(b, rp), None, None)))
+        self.rho_w = (C.c_void_p * len(ws))(*ws)
+        self.n_rho, self.rp, self.d_in, self.out, self.K, self.masked = len(ws), rp, d_in, out, K, mod.masked
+        self.ok = True
+
+    def run(self, plan, x, N):
+        import ctypes as C
+        from ._lib import check, lib, ptr, stream
+        K, out = self.K, self.out
+        z = torch.empty(N * K, out, dtype=torch.float32, device=x.device)
+        with ops._span("sn_deepsigns_phi_f32"):
+            check(lib().sn_deepsigns_phi_f32(C.byref(self.phi), ptr(x), K, ptr(plan.graph_ptr), ptr(plan.rowptr), ptr(plan.col),
+                                             C.byref(plan.bins.cstruct), K, ptr(z), stream()), "sn_deepsigns_phi_f32")
+        y = torch.empty(N, K, dtype=torch.float32, device=x.device)
+        with ops._span("sn_mlp_chain_f32"):
+            if self.masked:
+                check(lib().sn_mlp_chain_f32(ptr(z), out, N, out, ptr(plan.nvalid), K, self.rho_w, self.n_rho, self.rp, ptr(y), K, K,
+                                             stream()), "sn_mlp_chain_f32")
+            else:
+                check(lib().sn_mlp_chain_f32(ptr(z), K * out, N, K * out, None, 0, self.rho_w, self.n_rho, self.rp, ptr(y), K, K,
+                                             stream()), "sn_mlp_chain_f32")
+        return y, z
+
+
+def _max_nodes(g):
+    """Largest graph of the batch (the stage kernels keep a whole graph in one 64-row bin column).  One scalar read per graph
+    object, cached on it."""
+    m = getattr(g, "_sn_max_nodes", None)
+    if m is None:
+        bnn = g.batch_num_nodes()
+        m = int(bnn.max()) if bnn.numel() else 0
+        try:
+            g._sn_max_nodes = m
+        except Exception:
+            pass
+    return m
+
+
 class _DeepSignsBase(nn.Module):
     masked = False
 
@@ -157,19 +271,22 @@ class _DeepSignsBase(nn.Module):
         # fires also when a PARENT module's load_state_dict recurses into this one (its own override below does not)
         self.register_load_state_dict_post_hook(lambda m, keys=None: m._invalidate())
 
+    fused_stages = True      # eval: the two stage kernels (3 launches); False forces the layer-at-a-time path
+
     def _invalidate(self):
         self._prep = None
+        self._fused = None
 
     def train(self, mode=True):
-        self._prep = None
+        self._invalidate()
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
-        self._prep = None
+        self._invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._prep = None
+        self._invalidate()
         return super().load_state_dict(*a, **k)
 
     def _prepare(self, train=False):
@@ -181,13 +298,15 @@ class _DeepSignsBase(nn.Module):
             P["gin"].append(dict(eps=conv.eps, mlp=_prep_mlp(conv.apply_func, train), next_bn=nxt))
         return P
 
-    def _plan(self, g, N):
+    def _plan(self, g, N, fused=False):
         src, dst = g.edges()
         bnn = g.batch_num_nodes().to(src.device)
         B = int(bnn.numel())
         batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn)      # index plumbing only
         if batch.numel() != N:
             raise ValueError("batch_num_nodes does not sum to the number of feature rows")
+        if fused:     # kmax = -k: work bins over all k slots of every graph (zero-padded columns are evaluated like any other)
+            return ops.build_plan(batch.long(), torch.stack([src.long(), dst.long()]), B, -self.k, bins=True)
         return ops.build_plan(batch.long(), torch.stack([src.long(), dst.long()]), B, self.k)
 
     def _phi(self, P, plan, x, N, K, train=False):
@@ -267,6 +386,12 @@ class _DeepSignsBase(nn.Module):
                 self._prep = self._prepare()
             P = self._prep
         N, K = x.shape[0], self.k
+        if not train and self.fused_stages:
+            if getattr(self, "_fused", None) is None:
+                self._fused = _FusedDeepSigns(self)
+            if self._fused.ok and N > 0 and _max_nodes(g) <= ops.PHI_BIN_ROWS and int(g.batch_num_nodes().numel()) <= 6144:
+                y, _ = self._fused.run(self._plan(g, N, fused=True), x.contiguous().float().view(N, K), N)
+                return y.view(N, K, 1)
         plan = self._plan(g, N)
         if not train:
             z = self._phi_eval_merged(P, plan, x.contiguous().float(), N, K)
