@@ -406,10 +406,14 @@ def dgl_bench(args, dev):
     host = synth.make_batch(128, seed=1236)
     pe = synth.dgl_pos_enc(host, k)
     ei = host.edge_index
-    g = DS.Graph(ei[0].to(dev), ei[1].to(dev), torch.tensor(host.sizes))
+    src_d, dst_d, bnn = ei[0].to(dev), ei[1].to(dev), torch.tensor(host.sizes)
+    g = DS.Graph(src_d, dst_d, bnn)
     hx, ex, ped = host.x.squeeze(-1).to(dev), host.edge_attr.to(dev), pe.unsqueeze(-1).to(dev)
 
     def step():
+        # a NEW graph object every step, as a data loader hands over: the per-graph plan (sn_batch_plan) and size limits that the
+        # modules keep on the graph object are rebuilt inside the timed region
+        g = DS.Graph(src_d, dst_d, bnn)
         p = net.sign_inv_net(g, ped).squeeze(-1)
         return net(g, hx, p, ex, None)[0]
     with torch.no_grad():

@@ -319,6 +319,36 @@ int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const 
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,
                      float slope, const float* residual, int ldr, float* y, int ldy, void* stream);
 
+/* The GatedGCN network of the DGL tree from its first GatedGCNLayer to the scores, ONE launch, eval mode:
+ * replaces the layer loop, readout and MLPReadout of GatedGCNNet.forward (nets/ZINC_graph_regression/gatedgcn_net.py:105-148) and
+ * GatedGCNLayer.forward (layers/gatedgcn_layer.py:36-81; batch_norm, no dropout, no graph_norm).  One workgroup per graph
+ * (<= 64 nodes, <= sn_gatedgcn_max_edges(d) in-edges: other graphs get a NaN score and status[3] |= 1 / 2 — the caller then uses the
+ * layer-at-a-time entry points; status[5] != 0 on entry — an embedding id out of range upstream — makes every score NaN).  d: a multiple of 4 in [4, 96]; dp = max(48, 16*ceil(d/16)); every matrix is sn_pack_split_f32 of its zero-padded form:
+ *   wabde: [4*dp, dp] = A | B | D | E stacked (each padded to dp rows), e0 = the four biases
+ *   wc:    [dp, dp] = C, (e0, e1, e2) = (bias, folded bn_node_e scale, shift)
+ *   h_scale / h_shift: [dp] folded bn_node_h;  residual: 1 when the layer adds its input (gatedgcn_layer.py:29-31,70-72)
+ * h [N, d]: embedded node features (read only); e [E, d]: embedded edge features, UPDATED IN PLACE layer by layer (edge-id order);
+ * readout: mean (readout_mean = 1) or sum over the nodes, then Linear(d_out, ro_d1) ReLU Linear(ro_d1, ro_d2) ReLU Linear(ro_d2, 1)
+ * with plain row-major fp32 weights (layers/mlp_readout_layer.py).  y: [B]. */
+typedef struct {
+  const void* wabde;
+  const void* wc;
+  const float* h_scale;
+  const float* h_shift;
+  int residual, reserved;
+} sn_gatedgcn_layer;
+
+#define SN_GATED_MAX_LAYERS 32
+typedef struct {
+  int d, d_out, n_layers, readout_mean, ro_d1, ro_d2;
+  const float *ro_w0, *ro_b0, *ro_w1, *ro_b1, *ro_w2, *ro_b2;
+  sn_gatedgcn_layer layers[SN_GATED_MAX_LAYERS];
+} sn_gatedgcn_params;
+
+int sn_gatedgcn_max_edges(int d);
+int sn_gatedgcn_fused_f32(const sn_gatedgcn_params* params, const float* h, float* e, const int32_t* graph_ptr, int64_t B,
+                          const int32_t* rowptr, const int32_t* col, const int32_t* eperm, int32_t* status, float* y, void* stream);
+
 /* Dense multi-head softmax attention over whole sequences, forward and backward — the attention inside the
  * nn.TransformerEncoderLayer stack of LearningFilters/models.py:115-135 (`Transformer`; sequences = the graph's N nodes, head width 3-8).
  * q, k, v, out, dout, dq, dk, dv: [Bt, L, heads*dk] row-major (batch_first; head h owns columns h*dk..); lse, delta: [Bt, heads, L].

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sn_pointwise_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _f, _p, _i, _p, _i, _p],
     "sn_deepsigns_phi_f32": [_p, _p, _i, _p, _p, _p, _p, _i, _p, _p],
     "sn_mlp_chain_f32": [_p, _i, _l, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p],
+    "sn_gatedgcn_fused_f32": [_p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p],
     "sn_dense_attention_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p],
     "sn_dense_attention_bwd_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p],
     "sn_eigenspace_group": [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -104,6 +105,8 @@ def lib():
         L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
         L.sn_embedding_bwd_scratch_floats.argtypes = [_l, _i, C.POINTER(C.c_int64), _i]
         L.sn_embedding_bwd_scratch_floats.restype = C.c_int64
+        L.sn_gatedgcn_max_edges.argtypes = [_i]
+        L.sn_gatedgcn_max_edges.restype = C.c_int
         L.sn_evd_work_ints.argtypes = [_l]
         L.sn_evd_work_ints.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]

@@ -135,13 +135,17 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <int NT, int NW = 4>     // NW: waves of the workgroup (all of them share the DMA of every chunk)
+// NW: waves of the workgroup (all of them share the DMA of every chunk).  RING: chunks of LDS the stream cycles through — RING - 1
+// chunks are in flight while one is being consumed; the latency-bound per-graph kernels (few rows, long chains) use a deeper ring
+// than the throughput kernels, whose default of 3 leaves the LDS to the activation images.
+template <int NT, int NW = 4, int RING = SPLIT_RING>
 struct WRing {
   static constexpr int NKB = (NT + 1) / 2;
   static constexpr int NF = 3 * NKB;                 // weight fragments per chunk
   static constexpr int NFE = NF + SPLIT_EPI;         // + epilogue fragments
   static constexpr int CHUNK = NFE * 1024;           // bytes
-  static constexpr int BYTES = SPLIT_RING * CHUNK;
+  static constexpr int BYTES = RING * CHUNK;
+  static constexpr int DEPTH = RING;
   static constexpr int LPC = (NFE + NW - 1) / NW;    // DMA instructions every wave issues per chunk
   lds_char_t* base;   // LDS
   int pos;            // ring slot of chunk 0 of the current GEMM (wave-uniform)
@@ -150,7 +154,11 @@ struct WRing {
   __device__ __forceinline__ void init(void* lds_base, int wave_, int lane_) {
     base = (lds_char_t*)lds_base; pos = 0; wave = wave_; lane = lane_;
   }
-  __device__ __forceinline__ int slot_of(int c) const { const int x = pos + c; return x - SPLIT_RING * ((x * 43) >> 7); }   // x mod 3, x < 128
+  __device__ __forceinline__ int slot_of(int c) const {
+    const int x = pos + c;
+    if (RING == 3) return x - 3 * ((x * 43) >> 7);       // x mod 3, x < 128
+    return x % RING;
+  }
   // this wave's share of the DMA of chunk `c` of packed matrix `w` into ring slot `slot`.  Buffer form: the matrix
   // base lives in an SGPR descriptor, the chunk / fragment offset in an SGPR, lane*16 in one VGPR — no 64-bit
   // per-lane address per DMA (which the compiler would precompute for every chunk of every matrix and spill).
@@ -179,9 +187,9 @@ struct WRing {
     lds_barrier();   // nobody still reads the ring
     pos = 0;
 #pragma unroll
-    for (int c = 0; c < SPLIT_RING; ++c)
+    for (int c = 0; c < RING; ++c)
       if (c < nchunks) issue(w, c, c);
-    if (nchunks >= SPLIT_RING) wait_vmcnt<(SPLIT_RING - 1) * LPC>(); else wait_vmcnt<0>();
+    if (nchunks >= RING) wait_vmcnt<(RING - 1) * LPC>(); else wait_vmcnt<0>();
     lds_barrier();
   }
   // before the kernel exits: no LDS-DMA of this wave may still be in flight (the LDS would be handed to another workgroup)
@@ -196,20 +204,22 @@ struct WFrag { u32x4 h, m, l; };
 // `live` = this wave has rows (a dead wave only keeps the stream going).  `wnext` (never null): the matrix whose
 // first chunks are staged behind this one's — the next wg_gemm_split() of the workgroup must be on `wnext`; the
 // kernel starts the stream with WRing::prologue(first matrix) and ends with WRing::drain().  SWAP: operands exchanged -> acc[r] = Y[row = 4g + r][out = 16*ot + (l&15)].
-template <int NT, int NTO, bool SWAP, bool EPIV = true, int NW = 4, typename Pre, typename Epi>
-__device__ __forceinline__ void wg_gemm_split(WRing<NT, NW>& ring, const void* w, const void* wnext, bool live,
+template <int NT, int NTO, bool SWAP, bool EPIV = true, int NW = 4, int RING = SPLIT_RING, typename Pre, typename Epi>
+__device__ __forceinline__ void wg_gemm_split(WRing<NT, NW, RING>& ring, const void* w, const void* wnext, bool live,
                                               const Split8 (&xs)[(NT + 1) / 2], Pre pre, Epi epi) {
-  using R = WRing<NT, NW>;
+  using R = WRing<NT, NW, RING>;
   constexpr int NKB = R::NKB;
-  constexpr bool CHAIN = NTO >= SPLIT_RING;     // the stream runs on into the next matrix; else: one prologue per GEMM
+  constexpr bool CHAIN = NTO >= RING;     // the stream runs on into the next matrix; else: one prologue per GEMM
   if (!CHAIN) ring.prologue(w, NTO);
   typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
   typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
-  const int s0 = ring.slot_of(0), s1 = ring.slot_of(1), s2 = ring.slot_of(2);
-  auto slot = [&](int c) { return (c % 3 == 0) ? s0 : ((c % 3 == 1) ? s1 : s2); };   // c is a compile-time constant
+  int sl[RING];
+#pragma unroll
+  for (int i = 0; i < RING; ++i) sl[i] = ring.slot_of(i);
+  auto slot = [&](int c) { return sl[c % RING]; };   // c is a compile-time constant
   auto stage = [&](int ot) {   // after the barrier of step ot: refill the slot of chunk ot with chunk ot + RING
     if (CHAIN) {
-      const int pc = ot + SPLIT_RING;
+      const int pc = ot + RING;
       if (pc < NTO) ring.issue(w, pc, slot(ot)); else ring.issue(wnext, pc - NTO, slot(ot));
     }
   };
@@ -264,7 +274,7 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW>& ring, const void* w
       if (CHAIN) {
         // all my reads of chunk ot are complete and my share of chunk ot+1 has landed -> barrier -> refill the slot
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<(SPLIT_RING - 2) * R::LPC>();
+        wait_vmcnt<(RING - 2) * R::LPC>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stage(ot);
@@ -279,7 +289,7 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW>& ring, const void* w
   } else if (CHAIN) {
 #pragma unroll
     for (int ot = 0; ot < NTO; ++ot) {
-      wait_vmcnt<(SPLIT_RING - 2) * R::LPC>();
+      wait_vmcnt<(RING - 2) * R::LPC>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       stage(ot);

@@ -250,8 +250,8 @@ class _FusedDeepSigns:
 
 
 def _max_nodes(g):
-    """Largest graph of the batch (the stage kernels keep a whole graph in one 64-row bin column).  One scalar read per graph
-    object, cached on it."""
+    """Largest graph of the batch (the stage kernels keep a whole graph in one 64-row bin column).  Free when batch_num_nodes() is a
+    host tensor, one scalar read otherwise; cached on the graph object."""
     m = getattr(g, "_sn_max_nodes", None)
     if m is None:
         bnn = g.batch_num_nodes()
@@ -261,6 +261,34 @@ def _max_nodes(g):
         except Exception:
             pass
     return m
+
+
+def cached_plan(g, N, k=None):
+    """The CSR / graph_ptr plan of a batched graph (sn_batch_plan), built once per graph OBJECT and kept on it — as DGL keeps a
+    graph's sparse formats on the graph.  k: also lay out the stage kernels' work bins over all k eigenvector slots (kmax = -k);
+    a request without k is served by any plan already on the graph (the CSR arrays do not depend on k), so the sign-invariant net
+    and the base network that consumes its output share ONE launch per batch."""
+    cache = getattr(g, "_sn_plans", None)
+    if cache is None:
+        cache = {}
+        try:
+            g._sn_plans = cache
+        except Exception:
+            pass
+    key = ("bins", int(k)) if k else ("csr",)
+    if key in cache:
+        return cache[key]
+    if k is None and cache:
+        return next(iter(cache.values()))
+    src, dst = g.edges()
+    bnn = g.batch_num_nodes().to(src.device)
+    B = int(bnn.numel())
+    # index plumbing only; output_size spares the host read of sum(bnn) (a wrong N shows up as status bits of the plan)
+    batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn, output_size=N)
+    ei = torch.stack([src.long(), dst.long()])
+    plan = ops.build_plan(batch.long(), ei, B, -int(k), bins=True) if k else ops.build_plan(batch.long(), ei, B, 0)
+    cache[key] = plan
+    return plan
 
 
 class _DeepSignsBase(nn.Module):
@@ -390,7 +418,7 @@ class _DeepSignsBase(nn.Module):
             if getattr(self, "_fused", None) is None:
                 self._fused = _FusedDeepSigns(self)
             if self._fused.ok and N > 0 and _max_nodes(g) <= ops.PHI_BIN_ROWS and int(g.batch_num_nodes().numel()) <= 6144:
-                y, _ = self._fused.run(self._plan(g, N, fused=True), x.contiguous().float().view(N, K), N)
+                y, _ = self._fused.run(cached_plan(g, N, K), x.contiguous().float().view(N, K), N)
                 return y.view(N, K, 1)
         plan = self._plan(g, N)
         if not train:

@@ -11,11 +11,14 @@ The LSPE / random-walk variants (p_out, Whp, lapeig loss) are not built and rais
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
 from . import ops
-from .dgl_deepsigns import MLP, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
+from ._lib import check, lib, ptr, stream
+from .dgl_deepsigns import MLP, cached_plan, _max_nodes, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
 
 
 class MLPReadout(nn.Module):
@@ -194,6 +197,80 @@ class GatedGCNLayer(nn.Module):
         self.bn_node_e = nn.BatchNorm1d(output_dim)
 
 
+GATED_MAX_LAYERS = 32
+
+
+class _GatedLayerC(C.Structure):
+    _fields_ = [("wabde", C.c_void_p), ("wc", C.c_void_p), ("h_scale", C.c_void_p), ("h_shift", C.c_void_p), ("residual", C.c_int),
+                ("reserved", C.c_int)]
+
+
+class _GatedParamsC(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("d", "d_out", "n_layers", "readout_mean", "ro_d1", "ro_d2")] + \
+               [(n, C.c_void_p) for n in ("ro_w0", "ro_b0", "ro_w1", "ro_b1", "ro_w2", "ro_b2")] + \
+               [("layers", _GatedLayerC * GATED_MAX_LAYERS)]
+
+
+class _FusedGated:
+    """Packed eval-mode parameters of a GatedGCNNet's layer stack + readout for sn_gatedgcn_fused_f32 (one launch).  `ok` False:
+    shapes the stage kernel does not take (hidden not a multiple of 4 in [4, 96], a readout other than the 3-Linear MLPReadout,
+    differing layer widths) — the layer path serves those."""
+
+    def __init__(self, net):
+        self.ok = False
+        Ls = list(net.layers)
+        d = Ls[0].in_channels
+        fcs = list(net.MLP_layer.FC_layers)
+        if not (4 <= d <= 96 and d % 4 == 0 and len(Ls) <= GATED_MAX_LAYERS and len(fcs) == 3 and fcs[2].weight.shape[0] == 1):
+            return
+        dp = max(48, 16 * ((d + 15) // 16))
+        if any(L.in_channels != d for L in Ls) or any(L.out_channels != d for L in Ls[:-1]) or Ls[-1].out_channels > dp:
+            return
+        if fcs[0].weight.shape[0] > 128 or fcs[1].weight.shape[0] > 128 or fcs[0].weight.shape[1] != Ls[-1].out_channels:
+            return
+        keep = self._keep = []
+
+        def hold(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        dev = Ls[0].A.weight.device
+        P = _GatedParamsC()
+        P.d, P.d_out, P.n_layers, P.readout_mean = d, Ls[-1].out_channels, len(Ls), 0 if net.readout == "sum" else 1
+        P.ro_d1, P.ro_d2 = fcs[0].weight.shape[0], fcs[1].weight.shape[0]
+        for i, fc in enumerate(fcs):
+            setattr(P, f"ro_w{i}", hold(fc.weight.detach().float().contiguous()))
+            setattr(P, f"ro_b{i}", hold(fc.bias.detach().float().contiguous()))
+        rows_a, rows_c = 4 * dp, dp
+        for l, L in enumerate(Ls):
+            W = torch.zeros(rows_a, dp, dtype=torch.float32, device=dev)
+            b = torch.zeros(rows_a, dtype=torch.float32, device=dev)
+            for k, nme in enumerate("ABDE"):
+                lin = getattr(L, nme)
+                W[k * dp:k * dp + lin.weight.shape[0], :lin.weight.shape[1]].copy_(lin.weight.detach())
+                b[k * dp:k * dp + lin.bias.shape[0]].copy_(lin.bias.detach())
+            Wc = torch.zeros(rows_c, dp, dtype=torch.float32, device=dev)
+            Wc[:L.C.weight.shape[0], :L.C.weight.shape[1]].copy_(L.C.weight.detach())
+            hs, ht = ops.bn_fold(L.bn_node_h, dp)
+            es, et = ops.bn_fold(L.bn_node_e, rows_c)
+            Lp = P.layers[l]
+            Lp.wabde = hold(ops.pack_split(W, b, None, None))
+            Lp.wc = hold(ops.pack_split(Wc, ops.pad_vec(L.C.bias, rows_c), es, et))
+            Lp.h_scale, Lp.h_shift = hold(hs), hold(ht)
+            Lp.residual = 1 if L.residual else 0
+        self.params, self.d = P, d
+        self.max_edges = int(lib().sn_gatedgcn_max_edges(d))
+        self.ok = True
+
+    def run(self, plan, h0, e0):
+        """h0 [N, d], e0 [E, d] (e0 is consumed: updated in place) -> scores [B, 1]"""
+        y = torch.empty(plan.B, dtype=torch.float32, device=h0.device)
+        with ops._span("sn_gatedgcn_fused_f32"):
+            check(lib().sn_gatedgcn_fused_f32(C.byref(self.params), ptr(h0), ptr(e0), ptr(plan.graph_ptr), plan.B, ptr(plan.rowptr),
+                                              ptr(plan.col), ptr(plan.eperm), ptr(plan.status), ptr(y), stream()), "sn_gatedgcn_fused_f32")
+        return y.view(-1, 1)
+
+
 class GatedGCNNet(_PackCache, nn.Module):
     """nets/ZINC_graph_regression/gatedgcn_net.py:18-148 for pe_init = 'lap_pe', lap_lspe = False (the sign-invariant PE configs
     GatedGCN_ZINC_LapPE_signinv_GIN[_mask].json): embedding_h / embedding_p with `add` or `concat` + pe_proj (:93-103), edge
@@ -235,20 +312,69 @@ class GatedGCNNet(_PackCache, nn.Module):
         if p is None:
             raise NotImplementedError("HIP GatedGCNNet needs the positional encoding p")
         N = h.shape[0]
-        batch, ei, B = self._plan(g, N)
-        plan = ops.build_plan(batch, ei, B, 0)
         hidx, eidx = h.long().reshape(N), e.long().reshape(-1)
         p = p.contiguous().float()
         train = self.training
         if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
-            y = self._forward_grad(plan, batch, ei, B, hidx, p, eidx)
+            batch, ei, B = self._plan(g, N)
+            y = self._forward_grad(ops.build_plan(batch, ei, B, 0), batch, ei, B, hidx, p, eidx)
         else:
             with torch.no_grad():
-                y = self._forward_value(plan, hidx, p, eidx, train)
+                plan = cached_plan(g, N)
+                y = self._forward_value(plan, hidx, p, eidx, train, self._fused_gated(g))
         self.g = g
         return y, g
 
-    def _forward_value(self, plan, hidx, p, eidx, train):
+    fused_stages = True      # eval: layers + readout in ONE launch (sn_gatedgcn_fused_f32); False forces the layer path
+
+    def _fused_gated(self, g):
+        """The packed stage-kernel parameters if this batch can take the one-launch path, else None."""
+        if self.training or not self.fused_stages:
+            return None
+        c = self.__dict__.setdefault("_cache", {})
+        if "fused_gated" not in c:
+            c["fused_gated"] = _FusedGated(self)
+        fz = c["fused_gated"]
+        if not fz.ok:
+            return None
+        # (a graph with more in-edges than the kernel's LDS image holds — sn_gatedgcn_max_edges(d), 176 at hidden 68 — is flagged on
+        #  the device and gets a NaN score: check_last())
+        return fz if 0 < _max_nodes(g) <= 64 else None
+
+    def check_last(self):
+        """Raise what the last one-launch eval forward flagged on the device (its scores are NaN in that case): a node / edge type
+        outside the embedding tables (IndexError, as nn.Embedding) or a graph the stage kernel could not hold.  One host sync; also
+        run by train().  The layer-at-a-time path (fused_stages = False, train mode) raises immediately instead."""
+        plan, self._last_plan = getattr(self, "_last_plan", None), None
+        if plan is not None:
+            st = plan.status.tolist()
+            if st[0]:
+                raise ValueError("GatedGCNNet: the last batch is malformed (batch_num_nodes / edges do not describe a batched graph; "
+                                 f"sn_batch_plan status {st[0]})")
+            if st[5]:
+                raise IndexError(ops.EMBEDDING_INDEX_ERROR)
+            if st[3] & 3:
+                raise RuntimeError("GatedGCNNet: a graph of the last batch has more than 64 nodes or more in-edges than the one-launch "
+                                   "kernel holds; its score is NaN — set fused_stages = False for such batches")
+
+    def train(self, mode=True):
+        self.check_last()
+        return super().train(mode)
+
+    def _forward_value(self, plan, hidx, p, eidx, train, fused=None):
+        if fused is not None:
+            # no host sync on this path: out-of-range ids are flagged in the plan's status block, the stage kernel then returns NaN
+            # scores, check_last() raises
+            st5 = plan.status[5:6]
+            x = ops.embedding_sum(hidx, [self.embedding_h.weight], status=st5)
+            if self.pe_aggregate == "concat":
+                pp = ops.masked_linear(p, self._pk(self.embedding_p))
+                x = ops.masked_linear(torch.cat([x, pp], dim=1), self._pk(self.pe_proj))
+            else:
+                x = ops.masked_linear(p, self._pk(self.embedding_p), residual=x)
+            e = ops.embedding_sum(eidx, [self.embedding_e.weight], status=st5)
+            self._last_plan = plan
+            return fused.run(plan, x, e)
         x = ops.embedding_sum(hidx, [self.embedding_h.weight])
         if self.pe_aggregate == "concat":
             pp = ops.masked_linear(p, self._pk(self.embedding_p))
