@@ -100,7 +100,9 @@ __device__ __forceinline__ float tile_rowsum(float v) {
 // input rows are then still in the input buffer when the residual needs them, so they are not kept in registers across
 // the q / k / v projections and the attention but re-read right before the output projection.
 template <int NT, bool REGATTN, bool ONE, bool HP = false>
-__global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_params P) {
+// (the LDS-attention variants hold two 64-row images beside the weight ring: one workgroup per CU fits, so they may use the whole
+//  register file of a SIMD — 512 registers per lane, no private segment)
+__global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStruct S, sn_rho_params P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
   constexpr int DKMAX = (D + 3) / 4;   // heads = 4: dk <= D/4
@@ -279,7 +281,38 @@ __global__ __launch_bounds__(RHO_R * 4, 2) void k_rho_fused(RhoStruct S, sn_rho_
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c) oh[c] = 0.f;
         float z = 0.f;
-        if ((dk & 3) == 0) {
+        constexpr int DKF = D / 4;      // head width when d fills the padded width (d = 128: 32; d = 64: 16)
+        if (dk == DKF) {
+          // Compile-time head width: a key's (and value's) DKF floats are NT ds_read_b128 issued back to back and ONE wait, the dot
+          // product and the P.V update are straight FMA runs.  (The runtime-width loops below compile to one ds_read + s_waitcnt per
+          // 4 channels behind a uniform branch each — ~1.5 k cycles per key and pass; this path made the all-eigenvector rho 2x faster.)
+          const float* kb = Bm + u0 * LD + hc;
+          const float* vb = A + u0 * LD + hc;
+          // one pass over the keys (running maximum, rescaled accumulators): the K rows are read once — this loop is bound by LDS
+          // delivery (every lane fetches its own copy of the key / value slice: 16 ds_read_b128 per key and wave)
+#pragma unroll 1
+          for (int j = 0; j < kv; ++j) {
+            f32x4 k4[NT], v4[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) { k4[i] = lds_ld4(kb + j * LD + 4 * i); v4[i] = lds_ld4(vb + j * LD + 4 * i); }
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+              s0 += qh[4 * i] * k4[i][0] + qh[4 * i + 1] * k4[i][1];
+              s1 += qh[4 * i + 2] * k4[i][2] + qh[4 * i + 3] * k4[i][3];
+            }
+            const float sj = s0 + s1;
+            const float mn = fmaxf(m, sj);
+            const float corr = expf(m - mn), pj = expf(sj - mn);      // (first key: m = -inf -> corr = 0)
+            z = z * corr + pj;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) oh[4 * i + t] = oh[4 * i + t] * corr + pj * v4[i][t];
+            }
+            m = mn;
+          }
+        } else if ((dk & 3) == 0) {
           for (int j = 0; j < kv; ++j) {
             const float* kr = Bm + (u0 + j) * LD + hc;
             float s = 0.f;
