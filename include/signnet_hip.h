@@ -319,6 +319,25 @@ int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const 
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,
                      float slope, const float* residual, int ldr, float* y, int ldy, void* stream);
 
+/* Adjoints of the f3 message-passing ops (the reference obtains them from torch.autograd through DGL); CSR walks with one owner per
+ * output element — no atomics, bitwise reproducible.
+ * sn_edge_rows_sum_f32: out[n,:] = sum over n's CSR range of g[eperm[p],:] — the adjoint of gathering node rows onto edges (h[dst] with
+ *   the plan, h[src] with the plan of the flipped edge list: pna_layer.py:38-44 `pretrans_edges`).
+ * sn_pna_aggregate_bwd_f32: dout [N, ldo] (layout of sn_pna_aggregate_f32) -> dmsg [E, C], dself [N, C] (NULL when the forward had no
+ *   hself); the first maximum / minimum in edge order takes the max / min gradient, the clamped variance passes none.
+ * sn_edge_attention_bwd_f32: dQ, dK, dV [N, heads*dk], dE [E, heads*dk]; `out` is the forward result; scratch: float[2*E*heads];
+ *   rev_*: the CSR of the flipped edge list (source-side sums).
+ * sn_act_bwd_f32: dx = dy * act'(x) [* rowscale[r]], x the pre-activation; act 0 none / 1 ReLU / 2 LeakyReLU(slope). */
+int sn_edge_rows_sum_f32(const float* g, int ldg, int C, int64_t N, const int32_t* rowptr, const int32_t* eperm, float* out, int ldo,
+                         void* stream);
+int sn_pna_aggregate_bwd_f32(const float* msg, int ldm, int C, int64_t N, const int32_t* rowptr, const int32_t* eperm, float avg_log,
+                             const float* dout, int ldo, float* dmsg, float* dself, void* stream);
+int sn_edge_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* Ee, const float* out, const float* dout,
+                              int64_t N, int64_t E, int heads, int dk, const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                              const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm, float* dQ, float* dK, float* dV,
+                              float* dE, float* scratch, void* stream);
+int sn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, const float* rowscale, int act, float slope, float* dx, void* stream);
+
 /* The GatedGCN network of the DGL tree from its first GatedGCNLayer to the scores, ONE launch, eval mode:
  * replaces the layer loop, readout and MLPReadout of GatedGCNNet.forward (nets/ZINC_graph_regression/gatedgcn_net.py:105-148) and
  * GatedGCNLayer.forward (layers/gatedgcn_layer.py:36-81; batch_norm, no dropout, no graph_norm).  One workgroup per graph

@@ -376,6 +376,112 @@ def dense_attention(q, k, v, heads):
     return _DenseAttention.apply(q, k, v, heads)
 
 
+# ----------------------------------------------------------------------------- PNA / sparse graph Transformer
+class _GatherRows(Function):
+    """h[idx] with idx = one row of the edge list: node rows copied onto edges (pna_layer.py:38-44).  `plan`: the CSR that groups the
+    edges by that row (the batch plan for dst, the plan of the flipped edge list for src): the adjoint is a CSR walk, no atomics."""
+
+    @staticmethod
+    def forward(ctx, h, idx, plan):
+        ctx.plan, ctx.shape = plan, h.shape
+        return h.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        plan = ctx.plan
+        N, Cc = ctx.shape
+        out = torch.empty(N, Cc, dtype=torch.float32, device=g.device)
+        check(lib().sn_edge_rows_sum_f32(ptr(g), Cc, Cc, N, ptr(plan.rowptr), ptr(plan.eperm), ptr(out), Cc, stream()), "sn_edge_rows_sum_f32")
+        return out, None, None
+
+
+def gather_rows(h, idx, plan):
+    return _GatherRows.apply(h, idx, plan)
+
+
+class _PnaAggregate(Function):
+    @staticmethod
+    def forward(ctx, msg, hself, plan, avg_log):
+        msg, hself = _c(msg), _c(hself)
+        ctx.save_for_backward(msg)
+        ctx.meta = (plan, float(avg_log))
+        return ops.pna_aggregate(msg, hself, plan, avg_log)
+
+    @staticmethod
+    def backward(ctx, g):
+        (msg,) = ctx.saved_tensors
+        plan, avg_log = ctx.meta
+        g = _c(g)
+        Cc = msg.shape[1]
+        dmsg = torch.zeros_like(msg)                  # (every edge has a destination: all rows are written; zeros guard malformed plans)
+        dself = torch.empty(plan.N, Cc, dtype=torch.float32, device=g.device)
+        check(lib().sn_pna_aggregate_bwd_f32(ptr(msg), Cc, Cc, plan.N, ptr(plan.rowptr), ptr(plan.eperm), avg_log, ptr(g), 13 * Cc, ptr(dmsg),
+                                             ptr(dself), stream()), "sn_pna_aggregate_bwd_f32")
+        return dmsg, dself, None, None
+
+
+def pna_aggregate(msg, hself, plan, avg_log):
+    return _PnaAggregate.apply(msg, hself, plan, avg_log)
+
+
+class _EdgeAttention(Function):
+    @staticmethod
+    def forward(ctx, Q, K, V, Ee, plan, rplan, heads):
+        Q, K, V, Ee = _c(Q), _c(K), _c(V), _c(Ee)
+        out = ops.edge_attention(Q, K, V, Ee, plan, heads)
+        ctx.save_for_backward(Q, K, V, Ee, out)
+        ctx.meta = (plan, rplan, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, K, V, Ee, out = ctx.saved_tensors
+        plan, rp, heads = ctx.meta
+        g = _c(g)
+        E = Ee.shape[0]
+        dQ, dK, dV, dE = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V), torch.zeros_like(Ee)
+        scratch = torch.empty(2 * max(E, 1) * heads, dtype=torch.float32, device=g.device)
+        with ops._span("sn_edge_attention_bwd_f32"):
+            check(lib().sn_edge_attention_bwd_f32(ptr(Q), ptr(K), ptr(V), ptr(Ee), ptr(out), ptr(g), plan.N, E, heads, Q.shape[1] // heads,
+                                                  ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm), ptr(rp.rowptr), ptr(rp.col), ptr(rp.eperm),
+                                                  ptr(dQ), ptr(dK), ptr(dV), ptr(dE), ptr(scratch), stream()), "sn_edge_attention_bwd_f32")
+        return dQ, dK, dV, dE, None, None, None
+
+
+def edge_attention(Q, K, V, Ee, plan, rplan, heads):
+    return _EdgeAttention.apply(Q, K, V, Ee, plan, rplan, heads)
+
+
+class _ActResidual(Function):
+    """act(x [* rowscale]) + residual with act in none / relu / leaky: FCLayer's LeakyReLU + the layer residual (pna_layer.py:126-134),
+    graph_norm's row scaling (:75-76)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, rowscale, act, slope):
+        x = _c(x)
+        ctx.save_for_backward(x if act != "none" and rowscale is None else None, rowscale)
+        ctx.meta = (act, slope, residual is not None)
+        if act != "none" and rowscale is not None:
+            raise ValueError("act_residual: a row scale combines with act = none only")
+        return ops.pointwise(x, rowscale=rowscale, act=act, slope=slope, residual=None if residual is None else _c(residual))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, rowscale = ctx.saved_tensors
+        act, slope, has_res = ctx.meta
+        g = _c(g)
+        Cc = g.shape[-1]
+        dx = torch.empty_like(g)
+        check(lib().sn_act_bwd_f32(ptr(x), ptr(g), g.numel() // Cc, Cc, ptr(rowscale), {"none": 0, "relu": 1, "leaky": 2}[act], float(slope),
+                                   ptr(dx), stream()), "sn_act_bwd_f32")
+        return dx, (g if has_res else None), None, None, None
+
+
+def act_residual(x, residual=None, rowscale=None, act="none", slope=0.01):
+    return _ActResidual.apply(x, residual, rowscale, act, slope)
+
+
 # ----------------------------------------------------------------------------- GatedGCN edge-gated aggregation
 class _Gated(Function):
     @staticmethod

@@ -111,6 +111,173 @@ __global__ __launch_bounds__(256) void k_pointwise(const float* __restrict__ x, 
   y[r * ldy + c] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- adjoints
+// (SURVEY.md §8 f1 for the f3 nets: the reference gets these from torch.autograd through DGL's message passing.)  All by CSR walks
+// with one owner per output element: no atomics, bitwise reproducible.
+
+// out[n, :] = sum over the CSR range of n of g[eperm[p], :]: the adjoint of gathering node rows onto edges (h[dst] with the
+// destination-sorted plan, h[src] with the plan of the flipped edge list).
+__global__ __launch_bounds__(256) void k_edge_rows_sum(const float* __restrict__ g, int ldg, int C, int64_t N, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ eperm, float* __restrict__ out, int ldo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int64_t n = i / C;
+  const int c = (int)(i - n * C);
+  float a = 0.f;
+  for (int p = rowptr[n]; p < rowptr[n + 1]; ++p) a += g[(int64_t)eperm[p] * ldg + c];
+  out[n * ldo + c] = a;
+}
+
+// adjoint of k_pna_aggregate: dmsg [E, C] (every message row belongs to exactly one destination) and dself [N, C]
+__global__ __launch_bounds__(256) void k_pna_aggregate_bwd(const float* __restrict__ msg, int ldm, int C, int64_t N,
+                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ eperm,
+                                                           float avg_log, const float* __restrict__ dout, int ldo, int has_self,
+                                                           float* __restrict__ dmsg, float* __restrict__ dself) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int64_t n = i / C;
+  const int c = (int)(i - n * C);
+  const int lo = rowptr[n], hi = rowptr[n + 1];
+  const float* go = dout + n * ldo;
+  int off = 0;
+  if (has_self) { dself[n * C + c] = go[c]; off = C; }
+  const int D = hi - lo;
+  if (D == 0) return;
+  float s1 = 0.f, s2 = 0.f, mx = -INFINITY, mn = INFINITY;
+  int imx = lo, imn = lo;
+  for (int e = lo; e < hi; ++e) {
+    const float v = msg[(int64_t)eperm[e] * ldm + c];
+    s1 += v;
+    s2 += v * v;
+    if (v > mx) { mx = v; imx = e; }            // the first maximum / minimum in edge order takes the gradient (torch.max / min)
+    if (v < mn) { mn = v; imn = e; }
+  }
+  const float inv = 1.0f / (float)D;
+  const float mean = s1 * inv;
+  const float vraw = s2 * inv - mean * mean;
+  const float sd = sqrtf(fmaxf(vraw, 0.f) + 1e-5f);
+  const float logd = logf((float)D + 1.0f);
+  const float amp = logd / avg_log, att = avg_log / logd;
+  float da[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) da[k] = go[off + k * C + c] + go[off + (4 + k) * C + c] * amp + go[off + (8 + k) * C + c] * att;
+  const float dvar = vraw > 0.f ? da[3] / (2.0f * sd) : 0.f;       // relu(E[x^2] - E[x]^2) passes no gradient where it clamps
+  for (int e = lo; e < hi; ++e) {
+    const int64_t row = eperm[e];
+    const float v = msg[row * ldm + c];
+    float d = da[0] * inv + dvar * 2.0f * inv * (v - mean);
+    if (e == imx) d += da[1];
+    if (e == imn) d += da[2];
+    dmsg[row * C + c] = d;
+  }
+}
+
+// adjoint of k_edge_attention, destination side: dQ [N, H*dk], dE [E, H*dk] and the per-(edge, head) scalars the source side needs —
+// wv = s / (z + 1e-6) and dsc = d(score) — one thread per (node, head)
+__global__ __launch_bounds__(256) void k_edge_attention_bwd_dst(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                                const float* __restrict__ Ee, const float* __restrict__ out,
+                                                                const float* __restrict__ dout, int64_t N, int H, int dk,
+                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const int32_t* __restrict__ eperm, float* __restrict__ dQ,
+                                                                float* __restrict__ dE, float* __restrict__ wv, float* __restrict__ dsc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * dk;
+  const float root = sqrtf((float)dk);
+  float q[32], go[32], aq[32];
+  float gdo = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const bool ok = c < dk;
+    q[c] = ok ? Q[n * d + h * dk + c] : 0.f;
+    go[c] = ok ? dout[n * d + h * dk + c] : 0.f;
+    gdo += ok ? go[c] * out[n * d + h * dk + c] : 0.f;
+    aq[c] = 0.f;
+  }
+  float z = 0.f;
+  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+    const int64_t j = col[e], eid = eperm[e];
+    const float* kr = K + j * d + h * dk;
+    const float* er = Ee + eid * d + h * dk;
+    float sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < dk) sc += ((kr[c] * q[c]) / root) * er[c];
+    z += expf(fminf(fmaxf(sc, -5.f), 5.f));
+  }
+  const float r = 1.0f / (z + 1e-6f);
+  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+    const int64_t j = col[e], eid = eperm[e];
+    const float* kr = K + j * d + h * dk;
+    const float* er = Ee + eid * d + h * dk;
+    const float* vr = V + j * d + h * dk;
+    float sc = 0.f, gv = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < dk) { sc += ((kr[c] * q[c]) / root) * er[c]; gv += go[c] * vr[c]; }
+    const bool inside = sc > -5.f && sc < 5.f;
+    const float s = expf(fminf(fmaxf(sc, -5.f), 5.f));
+    const float ds = r * (gv - gdo);                              // d s_e
+    const float dscore = inside ? ds * s : 0.f;
+    wv[eid * H + h] = s * r;
+    dsc[eid * H + h] = dscore;
+    float* der = dE + eid * d + h * dk;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < dk) {
+        const float kq = kr[c] / root;
+        aq[c] += dscore * kq * er[c];
+        der[c] = dscore * kq * q[c];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    if (c < dk) dQ[n * d + h * dk + c] = aq[c];
+}
+// source side over the reverse CSR (rcol = destination node, rperm = edge id): dK[j] = sum_out dsc * Q[dst] * E[e] / sqrt(dk),
+// dV[j] = sum_out wv * dout[dst]
+__global__ __launch_bounds__(256) void k_edge_attention_bwd_src(const float* __restrict__ Q, const float* __restrict__ Ee, const float* __restrict__ dout,
+                                                                const float* __restrict__ wv, const float* __restrict__ dsc, int64_t N,
+                                                                int H, int dk, const int32_t* __restrict__ rrow, const int32_t* __restrict__ rcol,
+                                                                const int32_t* __restrict__ rperm, float* __restrict__ dK, float* __restrict__ dV) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * dk;
+  const float root = sqrtf((float)dk);
+  float ak[32], av[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) { ak[c] = 0.f; av[c] = 0.f; }
+  for (int e = rrow[n]; e < rrow[n + 1]; ++e) {
+    const int64_t t = rcol[e], eid = rperm[e];
+    const float w = wv[eid * H + h], ds = dsc[eid * H + h];
+    const float* qr = Q + t * d + h * dk;
+    const float* er = Ee + eid * d + h * dk;
+    const float* gr = dout + t * d + h * dk;
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < dk) { ak[c] += ds * (qr[c] / root) * er[c]; av[c] += w * gr[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 32; ++c)
+    if (c < dk) { dK[n * d + h * dk + c] = ak[c]; dV[n * d + h * dk + c] = av[c]; }
+}
+
+// dx = dy * act'(x): act 1 ReLU, 2 LeakyReLU(slope) (x = the PRE-activation), times an optional row scale
+__global__ __launch_bounds__(256) void k_act_bwd(const float* __restrict__ x, const float* __restrict__ dy, int64_t R, int C,
+                                                 const float* __restrict__ rowscale, int act, float slope, float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * C) return;
+  float g = dy[i];
+  if (act == 1) g = x[i] > 0.f ? g : 0.f;
+  else if (act == 2) g = x[i] > 0.f ? g : g * slope;
+  if (rowscale) g *= rowscale[i / C];
+  dx[i] = g;
+}
+
 }  // namespace sn
 
 using namespace sn;
@@ -146,5 +313,54 @@ extern "C" int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const
   hipLaunchKernelGGL(k_pointwise, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, R, C, rowscale, scale, shift,
                      act, slope, residual, ldr, y, ldy);
   SN_CHECK_LAUNCH("sn_pointwise_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_edge_rows_sum_f32(const float* g, int ldg, int C, int64_t N, const int32_t* rowptr, const int32_t* eperm, float* out, int ldo,
+                                    void* stream) {
+  SN_REQUIRE(g && rowptr && eperm && out && C > 0 && N >= 0 && ldg >= C && ldo >= C, "sn_edge_rows_sum_f32: bad arguments");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_edge_rows_sum, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, g, ldg, C, N, rowptr, eperm, out, ldo);
+  SN_CHECK_LAUNCH("sn_edge_rows_sum_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_pna_aggregate_bwd_f32(const float* msg, int ldm, int C, int64_t N, const int32_t* rowptr, const int32_t* eperm, float avg_log,
+                                        const float* dout, int ldo, float* dmsg, float* dself, void* stream) {
+  SN_REQUIRE(msg && rowptr && eperm && dout && dmsg && C > 0 && N >= 0 && ldm >= C && avg_log > 0.f, "sn_pna_aggregate_bwd_f32: bad arguments");
+  SN_REQUIRE(ldo >= (dself ? 13 : 12) * C, "sn_pna_aggregate_bwd_f32: gradient rows too narrow");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_pna_aggregate_bwd, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, msg, ldm, C, N, rowptr, eperm,
+                     avg_log, dout, ldo, dself ? 1 : 0, dmsg, dself);
+  SN_CHECK_LAUNCH("sn_pna_aggregate_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_edge_attention_bwd_f32(const float* Q, const float* K, const float* V, const float* Ee, const float* out, const float* dout,
+                                         int64_t N, int64_t E, int heads, int dk, const int32_t* rowptr, const int32_t* col,
+                                         const int32_t* eperm, const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm,
+                                         float* dQ, float* dK, float* dV, float* dE, float* scratch /* [2*E*heads] */, void* stream) {
+  SN_REQUIRE(Q && K && V && Ee && out && dout && rowptr && rev_rowptr && dQ && dK && dV && dE && scratch && N >= 0 && E >= 0 && heads > 0,
+             "sn_edge_attention_bwd_f32: bad arguments");
+  SN_REQUIRE(dk >= 1 && dk <= 32, "sn_edge_attention_bwd_f32: head width %d not in [1, 32]", dk);
+  if (N == 0) return SN_OK;
+  SN_REQUIRE(E == 0 || (col && eperm && rev_col && rev_eperm), "sn_edge_attention_bwd_f32: null edge arrays");
+  hipStream_t st = (hipStream_t)stream;
+  float* wv = scratch;
+  float* dsc = scratch + E * heads;
+  const dim3 grid((unsigned)cdiv(N * heads, 256));
+  hipLaunchKernelGGL(k_edge_attention_bwd_dst, grid, dim3(256), 0, st, Q, K, V, Ee, out, dout, N, heads, dk, rowptr, col, eperm, dQ, dE, wv, dsc);
+  hipLaunchKernelGGL(k_edge_attention_bwd_src, grid, dim3(256), 0, st, Q, Ee, dout, (const float*)wv, (const float*)dsc, N, heads, dk, rev_rowptr,
+                     rev_col, rev_eperm, dK, dV);
+  SN_CHECK_LAUNCH("sn_edge_attention_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, const float* rowscale, int act, float slope, float* dx,
+                              void* stream) {
+  SN_REQUIRE(dy && dx && R >= 0 && C > 0 && act >= 0 && act <= 2 && (act == 0 || x), "sn_act_bwd_f32: bad arguments");
+  if (R == 0) return SN_OK;
+  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, R, C, rowscale, act, slope, dx);
+  SN_CHECK_LAUNCH("sn_act_bwd_f32");
   return SN_OK;
 }

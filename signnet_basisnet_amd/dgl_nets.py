@@ -483,8 +483,8 @@ class PNANet(_PackCache, nn.Module):
     input, edge features, graph_norm + batch_norm, residual, no GRU, sum / mean readout.  Same constructor (`net_params`), forward
     contract `model(g, h, p, e, snorm_n) -> (scores, g)`, state_dict keys and attached `sign_inv_net`.  Per layer and tower:
     gather cat[h_src, h_dst, e] -> pretrans Linear -> sn_pna_aggregate_f32 -> posttrans Linear -> sn_pointwise_f32 (snorm_n and
-    BatchNorm); then the mixing Linear + LeakyReLU + residual.  Eval and train-mode VALUE (batch-statistic BatchNorm, running
-    statistics updated); no autograd through these layers."""
+    BatchNorm); then the mixing Linear + LeakyReLU + residual.  Eval, train-mode value (batch-statistic BatchNorm, running statistics
+    updated) and — with gradients enabled — the differentiable path (`_forward_grad`)."""
 
     def __init__(self, net_params):
         super().__init__()
@@ -534,6 +534,10 @@ class PNANet(_PackCache, nn.Module):
         train = self.training
         avg_log = float(self.avg_d["log"])
         sn = snorm_n.reshape(N).contiguous().float()
+        if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            hg = self._forward_grad(plan, batch, ei, B, h.long().reshape(N), p.contiguous().float(), e.long().reshape(-1), sn, avg_log)
+            self.g = g
+            return hg, g
         with torch.no_grad():
             x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])
             x = ops.masked_linear(p.contiguous().float(), self._pk(self.embedding_p), residual=x)                 # h + embedding_p(p)  (:124-126)
@@ -565,6 +569,35 @@ class PNANet(_PackCache, nn.Module):
         self.g = g
         self._h_last = x
         return hg, g
+
+    def _forward_grad(self, plan, batch, ei, B, hidx, p, eidx, sn, avg_log):
+        """Differentiable train-mode forward (SURVEY.md §8 f1 for this net): the same ops as autograd nodes with hand-written adjoints
+        (csrc/dgl_layers.hip: CSR walks, no atomics); towers' column slices and concatenations are torch views / copies."""
+        from . import autograd as AG
+        rplan = ops.build_plan(batch, ei.flip(0).contiguous(), B, 0)           # edges grouped by SOURCE: adjoint of h[src]
+        src, dst = ei[0], ei[1]
+        x = AG.masked_add(AG.linear(p, self.embedding_p.weight, self.embedding_p.bias), AG.embedding_sum(hidx, [self.embedding_h.weight]))
+        ef = AG.embedding_sum(eidx, [self.embedding_e.weight])
+        for L in self.layers:
+            it = L.in_dim // L.n_towers
+            outs = []
+            for t, T in enumerate(L.towers):
+                ht = x[:, t * it:(t + 1) * it].contiguous()
+                z = torch.cat([AG.gather_rows(ht, src, rplan), AG.gather_rows(ht, dst, plan), ef], dim=1)
+                pre, post = T.pretrans_h.fully_connected[0].linear, T.posttrans_h.fully_connected[0].linear
+                m = AG.linear(z, pre.weight, pre.bias)
+                a = AG.pna_aggregate(m, ht, plan, avg_log)
+                y = AG.act_residual(AG.linear(a, post.weight, post.bias), rowscale=sn)             # graph_norm: h * snorm_n
+                outs.append(AG.bn_act(y, T.batchnorm_h, relu=False))
+            mixl = L.mixing_network_h.linear
+            mix = AG.linear(torch.cat(outs, dim=1), mixl.weight, mixl.bias)
+            x = AG.act_residual(mix, residual=x if L.residual else None, act="leaky", slope=0.01)
+        hg = AG.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+        fcs = self.MLP_layer.FC_layers
+        for i, fc in enumerate(fcs):
+            hg = AG.linear(hg, fc.weight, fc.bias, relu=i < len(fcs) - 1)
+        self._h_last = x.detach()
+        return hg
 
     def loss(self, scores, targets):
         return (scores - targets).abs().mean()
@@ -607,7 +640,7 @@ class TransformerNet(_PackCache, nn.Module):
     (Transformer_ZINC_LapPE_signinv_GIN[_masked].json): embedding_h / embedding_p with `add` or `concat` + pe_proj, edge
     embedding, L x [Q/K/V/E projections -> sn_edge_attention_f32 -> O_h + residual -> BatchNorm -> FFN + residual -> BatchNorm],
     sum / mean readout, MLPReadout.  Same constructor, forward contract, state_dict keys and attached `sign_inv_net`.
-    Eval and train-mode VALUE; no autograd through the attention."""
+    Eval, train-mode value and — with gradients enabled — the differentiable path (`_forward_grad`)."""
 
     def __init__(self, net_params):
         super().__init__()
@@ -658,6 +691,10 @@ class TransformerNet(_PackCache, nn.Module):
         batch, ei, B = self._plan(g, N)
         plan = ops.build_plan(batch, ei, B, 0)
         train = self.training
+        if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            hg = self._forward_grad(plan, batch, ei, B, h.long().reshape(N), p.contiguous().float(), e.long().reshape(-1))
+            self.g = g
+            return hg, g
         with torch.no_grad():
             x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])
             pp = p.contiguous().float()
@@ -683,6 +720,34 @@ class TransformerNet(_PackCache, nn.Module):
         self.g = g
         self._h_last = x
         return hg, g
+
+    def _forward_grad(self, plan, batch, ei, B, hidx, p, eidx):
+        """Differentiable train-mode forward: the sparse attention's adjoint is sn_edge_attention_bwd_f32 (destination pass + source
+        pass over the reverse CSR, no atomics); BatchNorm with batch statistics, residuals, FFN as in the value path."""
+        from . import autograd as AG
+        rplan = ops.build_plan(batch, ei.flip(0).contiguous(), B, 0)
+        x = AG.embedding_sum(hidx, [self.embedding_h.weight])
+        pe = AG.linear(p, self.embedding_p.weight, self.embedding_p.bias)
+        if self.pe_aggregate == "concat":
+            x = AG.linear(torch.cat([x, pe], dim=1), self.pe_proj.weight, self.pe_proj.bias)
+        else:
+            x = AG.masked_add(pe, x)
+        ef = AG.embedding_sum(eidx, [self.embedding_e.weight])
+        for L in self.layers:
+            A = L.attention_h
+            Q, K, V = (AG.linear(x, getattr(A, n).weight, None) for n in "QKV")
+            Ee = AG.linear(ef, A.E.weight, None)
+            a = AG.edge_attention(Q, K, V, Ee, plan, rplan, L.num_heads)
+            o = AG.linear(a, L.O_h.weight, L.O_h.bias)
+            x1 = AG.bn_act(AG.masked_add(o, x), L.batch_norm1_h, relu=False)
+            f = AG.linear(AG.linear(x1, L.FFN_h_layer1.weight, L.FFN_h_layer1.bias, relu=True), L.FFN_h_layer2.weight, L.FFN_h_layer2.bias)
+            x = AG.bn_act(AG.masked_add(f, x1), L.batch_norm2_h, relu=False)
+        hg = AG.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+        fcs = self.MLP_layer.FC_layers
+        for i, fc in enumerate(fcs):
+            hg = AG.linear(hg, fc.weight, fc.bias, relu=i < len(fcs) - 1)
+        self._h_last = x.detach()
+        return hg
 
     def loss(self, scores, targets):
         return (scores - targets).abs().mean()

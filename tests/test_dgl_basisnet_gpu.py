@@ -561,3 +561,150 @@ def test_gatedgcn_one_launch_bad_type_id_gives_nan_and_raises_at_check():
     net.fused_stages = False                           # the layer path raises on the spot
     with pytest.raises(IndexError):
         net(g2, h, pp, e)
+
+
+# ------------------------------------------------------------------------------------------ adjoints of the f3 message-passing ops
+def test_pna_and_edge_attention_adjoints_vs_fp64_autograd():
+    """sn_pna_aggregate_bwd_f32, sn_edge_attention_bwd_f32, sn_edge_rows_sum_f32, sn_act_bwd_f32 against torch.autograd on the float64
+    oracle restatements (the reference obtains these gradients from autograd through DGL's message passing), and reproducibility."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import autograd as AG
+    from signnet_basisnet_amd import ops, synth
+    data = synth.make_batch(24, seed=17)
+    d = synth.batch_to(data, DEV)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 0)
+    rplan = ops.build_plan(d.batch, d.edge_index.flip(0).contiguous(), d.num_graphs, 0)
+    gen = torch.Generator().manual_seed(1)
+    src, dst = data.edge_index
+    E, N, C = src.numel(), data.num_nodes, 10
+    # ---- PNA aggregation
+    m, hs = torch.randn(E, C, generator=gen), torch.randn(N, C, generator=gen)
+    cot = torch.randn(N, 13 * C, generator=gen)
+    hm, hh = m.clone().to(DEV).requires_grad_(True), hs.clone().to(DEV).requires_grad_(True)
+    AG.pna_aggregate(hm, hh, plan, 1.3).backward(cot.to(DEV))
+    rm, rh = m.double().requires_grad_(True), hs.double().requires_grad_(True)
+    torch.cat([rh, ON.pna_aggregate(rm, dst, N, 1.3)], dim=1).backward(cot.double())
+    close(hh.grad, rh.grad, "pna d hself", rel=1e-6)
+    # the std columns divide by 2*std with std^2 = relu(E[x^2]-E[x]^2)+1e-5 computed in fp32: compare at the level that cancellation allows
+    scale = rm.grad.abs().max().item()
+    assert (hm.grad.cpu().double() - rm.grad).abs().max().item() <= 2e-3 * scale
+    deg = torch.bincount(dst, minlength=N)
+    well = (deg[dst] >= 3)                                   # edges into nodes whose variance is not a difference of near-equal numbers
+    if well.any():
+        assert (hm.grad.cpu().double() - rm.grad)[well].abs().max().item() <= 5e-4 * scale
+    # ---- sparse edge attention
+    H, dk = 4, 6
+    Q, K, V = (torch.randn(N, H * dk, generator=gen) for _ in range(3))
+    Ee = torch.randn(E, H * dk, generator=gen)
+    cot = torch.randn(N, H * dk, generator=gen)
+    hv = [t.clone().to(DEV).requires_grad_(True) for t in (Q, K, V, Ee)]
+    out = AG.edge_attention(*hv, plan, rplan, H)
+    out.backward(cot.to(DEV))
+    rv = [t.double().requires_grad_(True) for t in (Q, K, V, Ee)]
+    Qh, Kh, Vh, Eh = (t.view(-1, H, dk) for t in rv)
+    score = ((Kh[src] * Qh[dst]) / dk ** 0.5 * Eh).sum(-1)
+    s_ = torch.exp(score.clamp(-5, 5))
+    z = torch.zeros(N, H, dtype=torch.float64).index_add_(0, dst, s_)
+    wV = torch.zeros(N, H, dk, dtype=torch.float64).index_add_(0, dst, s_.unsqueeze(-1) * Vh[src])
+    ref = (wV / (z.unsqueeze(-1) + 1e-6)).reshape(N, H * dk)
+    close(out, ref.detach(), "edge attention forward", rel=1e-5)
+    ref.backward(cot.double())
+    for a, b, n in zip(hv, rv, ("dQ", "dK", "dV", "dE")):
+        close(a.grad, b.grad, "edge attention " + n, rel=2e-5)
+    hv2 = [t.clone().to(DEV).requires_grad_(True) for t in (Q, K, V, Ee)]
+    AG.edge_attention(*hv2, plan, rplan, H).backward(cot.to(DEV))
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(hv, hv2))            # no atomics: bitwise reproducible
+    # ---- rows gathered onto edges, LeakyReLU + residual, row scaling
+    h0 = torch.randn(N, C, generator=gen)
+    cot = torch.randn(E, C, generator=gen)
+    for idx, pl in ((dst, plan), (src, rplan)):
+        a = h0.clone().to(DEV).requires_grad_(True)
+        AG.gather_rows(a, idx.to(DEV), pl).backward(cot.to(DEV))
+        b = h0.double().requires_grad_(True)
+        b[idx].backward(cot.double())
+        close(a.grad, b.grad, "gather adjoint", rel=1e-6)
+    x, r, sn = torch.randn(N, C, generator=gen), torch.randn(N, C, generator=gen), torch.rand(N, generator=gen) + 0.5
+    cot = torch.randn(N, C, generator=gen)
+    a, ar = x.clone().to(DEV).requires_grad_(True), r.clone().to(DEV).requires_grad_(True)
+    AG.act_residual(a, residual=ar, act="leaky", slope=0.01).backward(cot.to(DEV))
+    b, br = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    (torch.nn.functional.leaky_relu(b, 0.01) + br).backward(cot.double())
+    close(a.grad, b.grad, "leaky adjoint", rel=1e-6)
+    close(ar.grad, br.grad, "residual adjoint", rel=1e-6)
+    a = x.clone().to(DEV).requires_grad_(True)
+    AG.act_residual(a, rowscale=sn.to(DEV)).backward(cot.to(DEV))
+    close(a.grad, cot.double() * sn.double().unsqueeze(1), "row-scale adjoint", rel=1e-6)
+
+
+def _oracle_grads(fn, sd):
+    sd64 = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    y = fn(sd64)
+    cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    (y * cot).sum().backward()
+    return sd64, y.detach(), cot
+
+
+def _check_param_grads(net, sd64, what, tol=2e-3):
+    gmax = max(v.grad.abs().max().item() for v in sd64.values() if torch.is_tensor(v) and v.requires_grad and v.grad is not None)
+    seen = 0
+    for k, p in net.named_parameters():
+        if k.startswith("sign_inv_net.") or k not in sd64:
+            continue
+        g64 = sd64[k].grad if sd64[k].grad is not None else torch.zeros_like(sd64[k])
+        ours = p.grad if p.grad is not None else torch.zeros_like(p)
+        scale = max(g64.abs().max().item(), 1e-2 * gmax)
+        err = (ours.detach().cpu().double() - g64).abs().max().item()
+        assert err <= tol * scale + 1e-7, (what, k, err, scale)
+        seen += 1
+    assert seen > 10
+
+
+def test_dgl_pna_net_parameter_gradients_match_oracle_autograd():
+    """Train mode with gradients enabled: every PNANet parameter gradient against torch.autograd over the float64 oracle on the
+    reference's fixture (same state_dict, same batch, the fixture's own sign-invariant encoding as input)."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets
+    fx = G.load("dgl_pna_k6")
+    hidden, L, k, towers, edge_dim = (int(v) for v in fx.meta["params"])
+    avg = fx.meta["avg_d"]
+    net = dgl_nets.PNANet(_base_params(fx, hidden, L, k, graph_norm=True, aggregators="mean max min std",
+                                       scalers="identity amplification attenuation",
+                                       avg_d=dict(lin=float(avg[0]), exp=float(avg[1]), log=float(avg[2])), towers=towers,
+                                       divide_input_first=True, divide_input_last=True, edge_dim=edge_dim, pretrans_layers=1,
+                                       posttrans_layers=1, gru=False))
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train()
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    p_in = fx.out["train/p"]
+    sd64, y64, cot = _oracle_grads(lambda sd: ON.pna_net(sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), p_in.double(), fx.inp["edge_attr"],
+                                                          fx.inp["snorm_n"].double(), L, towers, float(avg[2]), "sum", training=True), fx.sd)
+    y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p_in.to(DEV), fx.inp["edge_attr"].to(DEV), fx.inp["snorm_n"].to(DEV))
+    assert y.requires_grad
+    torch.testing.assert_close(y.detach().cpu().double(), y64, rtol=2e-3, atol=2e-4)
+    (y * cot.float().to(DEV)).sum().backward()
+    _check_param_grads(net, sd64, "PNANet", tol=5e-3)
+
+
+@pytest.mark.parametrize("name", ["dgl_transformer_concat_k6", "dgl_transformer_add_k8"])
+def test_dgl_transformer_net_parameter_gradients_match_oracle_autograd(name):
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets
+    fx = G.load(name)
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    agg = str(fx.meta["pe_aggregate"])
+    net = dgl_nets.TransformerNet(_base_params(fx, hidden, L, k, n_heads=heads, full_graph=False, layer_norm=True, pe_aggregate=agg))
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train()
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    p_in = fx.out["train/p"]
+    sd64, y64, cot = _oracle_grads(lambda sd: ON.transformer_net(sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), p_in.double(),
+                                                                  fx.inp["edge_attr"], L, heads, agg, "sum", training=True), fx.sd)
+    y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p_in.to(DEV), fx.inp["edge_attr"].to(DEV))
+    assert y.requires_grad
+    torch.testing.assert_close(y.detach().cpu().double(), y64, rtol=2e-3, atol=2e-4)
+    (y * cot.float().to(DEV)).sum().backward()
+    _check_param_grads(net, sd64, "TransformerNet")
