@@ -359,8 +359,24 @@ def basisnet_bench(args, dev):
             floss, _ = LF.train_step(fmodel, fopt, fa, geig, xs, ys, ms)
         torch.cuda.synchronize()
         dte = (time.perf_counter() - t0) / nst
+        # the same epoch captured once as a HIP graph and replayed (learning_filters.GraphedEpoch: fixed graph, fixed shapes, 2 000
+        # epochs per image — one graph launch + one Adam launch per epoch; bit-identical losses, tests/test_learning_filters_gpu.py)
+        from signnet_basisnet_amd.optim import FlatAdam
+        torch.manual_seed(0)
+        gmodel = LF.gen_model(fa, geig, dev)
+        gepoch = LF.GraphedEpoch(gmodel, FlatAdam(gmodel.parameters(), lr=fa.lr), fa, geig, xs, ys, ms)
+        for _ in range(5):
+            gepoch.step()
+        torch.cuda.synchronize()
+        ng = max(20, args.steps)
+        t0 = time.perf_counter()
+        for _ in range(ng):
+            gloss, _ = gepoch.step()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / ng
         out["training"]["configs"][label] = {"ms_per_epoch": 1e3 * dte, "epochs_per_s": 1.0 / dte, "loss_after": float(floss),
-                                             "parameters": sum(p.numel() for p in fmodel.parameters())}
+                                             "parameters": sum(p.numel() for p in fmodel.parameters()),
+                                             "hip_graph": {"ms_per_epoch": 1e3 * dtg, "epochs_per_s": 1.0 / dtg, "loss_after": float(gloss)}}
     if not args.no_cpu_baseline:
         sdphi = [{k: v.detach().cpu() for k, v in phi.encs[phi.mult_to_idx[m]].state_dict().items()} for m in mults]
         eqs = [[(e.coeffs.detach().cpu(), e.bias.detach().cpu()) for e in phi.encs[phi.mult_to_idx[m]].equi_layers] for m in mults]

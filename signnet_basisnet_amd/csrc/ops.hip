@@ -463,25 +463,32 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, floa
   qa += qb + d * d * (na * nb / n);
   na = n;
 }
-// merges the per-block moments (4 lanes per column, then across the lanes) and finishes the BatchNorm: mean, biased variance, rstd,
-// folded (scale, shift), count, running statistics.  grid cdiv(C, 64), 256 threads.
+// merges the per-block moments (16 lanes per column, then a tree across the lanes) and finishes the BatchNorm: mean, biased variance,
+// rstd, folded (scale, shift), count, running statistics.  grid cdiv(C, 16), 256 threads = 16 columns x 16 lanes.  (With 4 lanes per
+// column the merge of the 1024 partial blocks of a million-row input — the LearningFilters epochs — was an 88 us serial chain.)
 __global__ __launch_bounds__(256) void k_bn_train_finish1(const float* __restrict__ pmean, const float* __restrict__ pm2,
                                                           const float* __restrict__ pcnt, int nblk, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ var,
                                                           float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
                                                           float* __restrict__ count, float* __restrict__ rmean, float* __restrict__ rvar) {
-  __shared__ float ln[4][64], lm[4][64], lq[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int per = (nblk + 3) / 4, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  __shared__ float ln[16][17], lm[16][17], lq[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int per = (nblk + 15) / 16, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   float n = 0.f, m = 0.f, q = 0.f;
   if (c < C)
     for (int b = b0; b < b1; ++b) chan_merge(n, m, q, pcnt[b], pmean[(int64_t)b * C + c], pm2[(int64_t)b * C + c]);
   ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
   __syncthreads();
+  for (int step = 8; step >= 1; step >>= 1) {          // pairwise tree in a fixed order
+    if (rl < step) {
+      chan_merge(n, m, q, ln[rl + step][cl], lm[rl + step][cl], lq[rl + step][cl]);
+      ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
+    }
+    __syncthreads();
+  }
   if (rl != 0 || c >= C) return;
-  for (int i = 1; i < 4; ++i) chan_merge(n, m, q, ln[i][cl], lm[i][cl], lq[i][cl]);
   const float v = n > 0.f ? q / n : 0.f;
   const float rs = 1.0f / sqrtf(v + eps);
   const float sc = (gamma ? gamma[c] : 1.f) * rs;
@@ -923,7 +930,7 @@ extern "C" int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, 
   float* pm2 = scratch + (int64_t)nblk * C;
   float* pcnt = scratch + (int64_t)2 * nblk * C;
   hipLaunchKernelGGL(k_colstats_moments, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, rpb, pmean, pm2, pcnt);
-  hipLaunchKernelGGL(k_bn_train_finish1, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)pmean, (const float*)pm2,
+  hipLaunchKernelGGL(k_bn_train_finish1, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const float*)pmean, (const float*)pm2,
                      (const float*)pcnt, nblk, C, gamma, beta, eps, momentum, mean, var, rstd, scale, shift, count, running_mean,
                      running_var);
   SN_CHECK_LAUNCH("sn_bn_train_stats_f32");

@@ -279,6 +279,52 @@ def train_step(model, optimizer, args: FilterArgs, eig: GridEigen, x, y, m):
     return loss.detach(), pre.detach()
 
 
+class GraphedEpoch:
+    """One epoch of training.py:132-150 (feature assembly, forward, loss, backward) captured ONCE as a HIP graph and replayed: the graph
+    of this workload never changes — one fixed N-node graph, fixed shapes, 2 000 epochs per image — so the ~300 small launches of an
+    epoch collapse into one graph launch plus the single Adam launch of optim.FlatAdam (whose bias correction depends on the step
+    count and therefore stays outside the graph).  Parameters, gradients (the optimiser's flat buffers), inputs and outputs are static
+    device tensors; `step()` returns the same (loss, prediction) tensors every time, refreshed in place.
+    Same arithmetic, same kernels, same order as the eager train_step: the loss trajectory is bitwise identical."""
+
+    def __init__(self, model, optimizer, args: FilterArgs, eig: GridEigen, x, y, m, warmup=2):
+        from .optim import FlatAdam
+        if not isinstance(optimizer, FlatAdam):
+            raise TypeError("GraphedEpoch needs optim.FlatAdam (static flat parameter / gradient buffers)")
+        self.model, self.optimizer = model, optimizer
+        model.train()
+
+        def fwd_bwd():
+            optimizer.flat_g.zero_()
+            feat = get_lap_feat(args.use_eig, eig, x, args.lap_method, model)
+            pre = model(feat, None)
+            loss = masked_square_loss(pre, y, m)
+            loss.backward()
+            return loss, pre
+
+        # warm-up on a side stream (library handles, allocator pools) without touching the model's state: no optimiser step, and the
+        # BatchNorm buffers the warm-up forwards advance are put back
+        saved = [b.detach().clone() for b in model.buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss, pre = fwd_bwd()
+        with torch.no_grad():
+            for b, sv in zip(model.buffers(), saved):
+                b.copy_(sv)
+        self.loss, self.pre = loss.detach(), pre.detach()
+
+    def step(self):
+        self.graph.replay()
+        self.optimizer.step()
+        return self.loss, self.pre
+
+
 def r2_score(target, pred):
     """sklearn.metrics.r2_score for one output column (training.py:147), on host copies."""
     t, p = target.detach().double().cpu().reshape(-1), pred.detach().double().cpu().reshape(-1)
@@ -287,16 +333,19 @@ def r2_score(target, pred):
     return float(1.0 - ss_res / ss_tot) if ss_tot > 0 else 0.0
 
 
-def fit(args: FilterArgs, eig: GridEigen, x, y, m, epochs=None, model=None, optimizer=None, log=None):
+def fit(args: FilterArgs, eig: GridEigen, x, y, m, epochs=None, model=None, optimizer=None, log=None, use_graph=False):
     """The per-image loop of training.py:229-250: a fresh model, Adam(lr), `epochs` steps; keeps the minimum loss and its r2.
-    Returns {'min_loss', 'best_r2', 'epoch', 'model'}.  The loss is read back once per epoch, as the reference's loss.item() does."""
-    from .optim import Adam
+    Returns {'min_loss', 'best_r2', 'epoch', 'model'}.  The loss is read back once per epoch, as the reference's loss.item() does.
+    use_graph: replay the epoch as a captured HIP graph (GraphedEpoch; optimiser = optim.FlatAdam)."""
+    from .optim import Adam, FlatAdam
     model = model if model is not None else gen_model(args, eig, x.device)
-    optimizer = optimizer if optimizer is not None else Adam(model.parameters(), lr=args.lr)
+    if optimizer is None:
+        optimizer = FlatAdam(model.parameters(), lr=args.lr) if use_graph else Adam(model.parameters(), lr=args.lr)
+    graphed = GraphedEpoch(model, optimizer, args, eig, x, y, m) if use_graph else None
     best = {"min_loss": float("inf"), "best_r2": 0.0, "epoch": 0, "model": model}
     keep = m.reshape(-1) == 1
     for epoch in range(args.epochs if epochs is None else epochs):
-        loss, pre = train_step(model, optimizer, args, eig, x, y, m)
+        loss, pre = graphed.step() if graphed is not None else train_step(model, optimizer, args, eig, x, y, m)
         lv = loss.item()
         if best["min_loss"] > lv:
             best.update(min_loss=lv, best_r2=r2_score(y[keep], pre[keep]), epoch=epoch)

@@ -244,3 +244,26 @@ def test_full_size_sign_invariance():
     assert torch.equal(p0, p1)
     # and with gradients enabled (the differentiable composition)
     close(net(v).detach(), p0, "differentiable composition vs the fused forward")
+
+
+@pytest.mark.parametrize("case", ["ds_basisinv_ign", "tf_signinv_ds"])
+def test_graphed_epoch_replays_the_eager_training_step_bit_for_bit(case):
+    """The epoch captured as a HIP graph (GraphedEpoch) against the eager train_step with the same optimiser: identical losses and
+    parameters after several steps (same kernels, same order), and the BatchNorm buffers are not advanced by the capture."""
+    import copy
+    from signnet_basisnet_amd import learning_filters as LF
+    from signnet_basisnet_amd.optim import FlatAdam
+    fx, c, args, eig, model, x, y, m = _setup(case)
+    model_g = copy.deepcopy(model)
+    opt_e, opt_g = FlatAdam(model.parameters(), lr=args.lr), FlatAdam(model_g.parameters(), lr=args.lr)
+    ge = LF.GraphedEpoch(model_g, opt_g, args, eig, x, y, m)
+    for (k1, b1), (k2, b2) in zip(model.named_buffers(), model_g.named_buffers()):
+        assert torch.equal(b1, b2), k1
+    le, lg = [], []
+    for _ in range(5):
+        le.append(LF.train_step(model, opt_e, args, eig, x, y, m)[0].item())
+        lg.append(ge.step()[0].item())
+    assert le == lg, (le, lg)
+    for (k1, p1), (k2, p2) in zip(model.named_parameters(), model_g.named_parameters()):
+        assert torch.equal(p1, p2), k1
+    assert abs(le[0] - float(c["losses"][0])) <= 1e-3 * abs(float(c["losses"][0]))
