@@ -44,17 +44,26 @@ __global__ __launch_bounds__(MLP_R * 4, 2) void k_mlp_chain(MlpStruct S) {
     f32x4 in[NT];
 #pragma unroll
     for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool vec4 = ((S.d_in | S.ldx) & 3) == 0;          // whole float4 groups, 16-byte aligned rows
     if (valid) {
       const int ns = S.nvalid ? S.nvalid[row] : 1;
       const float* base = S.x + (S.nvalid ? row * S.K : row) * (int64_t)S.ldx;
       for (int s = 0; s < ns; ++s) {
         const float* xr = base + (int64_t)s * S.ldx;
+        if (vec4) {
 #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) {
+          for (int kk = 0; kk < NT; ++kk) {
+            const int c = 16 * kk + 4 * g;
+            if (c < S.d_in) in[kk] += ld4(xr + c);
+          }
+        } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int c = 16 * kk + 4 * g + t;
-            if (c < S.d_in) in[kk][t] += xr[c];
+          for (int kk = 0; kk < NT; ++kk) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int c = 16 * kk + 4 * g + t;
+              if (c < S.d_in) in[kk][t] += xr[c];
+            }
           }
         }
       }
