@@ -51,6 +51,11 @@ struct PhiStruct {
 };
 
 constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
+// Row descriptors of PHI_GB bins at a time: a bin's decode (bin -> column -> member graph -> node -> CSR range, eigenvector entry, first
+// in-neighbours) is a chain of five dependent global loads, ~7 k cycles when done per bin (7.5 % of a bin); the eight waves of the
+// workgroup decode the next eight bins of the workgroup in one pass instead — one wave per bin — and park the result in LDS.
+constexpr int PHI_GB = PHI_WAVES;
+constexpr int PHI_DESC_BYTES = 5 * PHI_GB * PHI_R * 4 + PHI_GB * 4 + PHI_GB * PHI_R + PHI_GB * PHI_R * PHI_NBR;
 
 // HID1: layer 0 is Linear(1->1).BN.ReLU.Linear(1->d) (GINESignNetPyG) — no [d,d] GEMM in layer 0; else Linear(1->d)...Linear(d->d)
 // (Alchemy).  A template parameter so that the variant without the layer-0 GEMM does not carry its registers.
@@ -67,8 +72,14 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   using Ring = WRing<NT, PHI_WAVES>;
   extern __shared__ __align__(1024) unsigned char lds_raw[];
   float* X2 = reinterpret_cast<float*>(lds_raw + Ring::BYTES);  // [2 signs][PHI_R][LD]  x_l
-  float* xs = X2 + 2 * PHI_R * LD;                              // [PHI_R] scalar eigenvector entries (layer 0)
-  unsigned char* nbr = reinterpret_cast<unsigned char*>(xs + PHI_R);   // [PHI_R][PHI_NBR] bin rows of the first in-neighbours
+  float* dxs = X2 + 2 * PHI_R * LD;                             // [GB][PHI_R] scalar eigenvector entries (layer 0)
+  int* dnode = reinterpret_cast<int*>(dxs + PHI_GB * PHI_R);    // [GB][PHI_R] node of the row, -1 = no row
+  int* delo = dnode + PHI_GB * PHI_R;                           // [GB][PHI_R] first in-edge (CSR position)
+  int* ddeg = delo + PHI_GB * PHI_R;                            // [GB][PHI_R] in-degree
+  int* dgs = ddeg + PHI_GB * PHI_R;                             // [GB][PHI_R] first node of the row's graph
+  int* dslot = dgs + PHI_GB * PHI_R;                            // [GB] eigenvector slot of the bin
+  unsigned char* drow0 = reinterpret_cast<unsigned char*>(dslot + PHI_GB);   // [GB][PHI_R] bin row of the graph's first node
+  unsigned char* dnbr = drow0 + PHI_GB * PHI_R;                 // [GB][PHI_R][PHI_NBR] bin rows of the first in-neighbours
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sg = wave >> 2;                                     // 0: phi(+x), 1: phi(-x)   (wave-uniform)
   float* X = X2 + sg * PHI_R * LD;                              // the image of my sign
@@ -85,55 +96,74 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   const void* wfirst = !HID1 ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
   if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
 
-  for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
+  for (int base = blockIdx.x; base < nbins; base += gridDim.x * PHI_GB) {
+    // ------------------------------------------------------------------ decode pass: wave w -> bin base + w * gridDim.x, lane -> row
+    __syncthreads();   // the previous group is done with the descriptors
+    {
+      const int dbin = base + wave * (int)gridDim.x;
+      if (dbin < nbins) {
+        const int rr = lane;
+        const int colid = S.bin_col[dbin];
+        const int slot = dbin - S.col_bin0[colid];       // every member contributes its slab of eigenvector `slot`
+        // (all eight member slots are decoded at once — wave-uniform scalar loads with no serial dependence between
+        //  members; an empty slot (-1) reads graph 0 and is masked out)
+        int node = -1, gs = 0, row0 = 0, gsel = 0, nsel = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int gi_raw = S.col_mem[colid * 8 + k];
+          const int gi = gi_raw < 0 ? 0 : gi_raw;
+          const int off = S.col_off[colid * 8 + k];
+          const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
+          const int kg = DGL ? S.kmax : ((S.kmax > 0 && n > S.kmax) ? S.kmax : n);
+          if (gi_raw >= 0 && rr >= off && rr < off + n && slot < kg) {
+            node = g0 + (rr - off);
+            gs = g0;
+            row0 = off;
+            gsel = gi;
+            nsel = n;
+          }
+        }
+        int e_lo = 0, e_hi = 0;
+        float xval = 0.f;
+        if (node >= 0) {
+          e_lo = S.rowptr[node];
+          e_hi = S.rowptr[node + 1];
+          xval = DGL ? S.ev[(int64_t)node * S.dense_ld + slot] : S.ev[S.evoff[gsel] + (int64_t)(node - gs) * nsel + slot];
+        }
+        const int deg = e_hi - e_lo;
+        int o = wave * PHI_R + rr;
+        asm volatile("" : "+v"(o));      // (else the six descriptor addresses are hoisted out of the bin loop and one of them spills)
+        dxs[o] = xval; dnode[o] = node; delo[o] = e_lo; ddeg[o] = deg; dgs[o] = gs; drow0[o] = (unsigned char)row0;
+        for (int e = 0; e < deg && e < PHI_NBR; ++e) dnbr[o * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
+        if (lane == 0) dslot[wave] = slot;
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int lb = 0; lb < PHI_GB; ++lb) {
+    const int bin = base + lb * (int)gridDim.x;
+    if (bin >= nbins) break;
     SN_PROF_ON(bin == (int)blockIdx.x);
     SN_STAMP(0);
 #ifdef SN_PROFILE
     long long pt = 0;
 #endif
-    // ---------------------------------------------------------------- my row: bin -> column -> member graph
-    const int colid = S.bin_col[bin];
-    const int slot = bin - S.col_bin0[colid];       // every member contributes its slab of eigenvector `slot`
-    // (all eight member slots are decoded at once — wave-uniform scalar loads with no serial dependence between
-    //  members; an empty slot (-1) reads graph 0 and is masked out)
-    int node = -1, gs = 0, row0 = 0, gsel = 0, nsel = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int gi_raw = S.col_mem[colid * 8 + k];
-      const int gi = gi_raw < 0 ? 0 : gi_raw;
-      const int off = S.col_off[colid * 8 + k];
-      const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
-      const int kg = DGL ? S.kmax : ((S.kmax > 0 && n > S.kmax) ? S.kmax : n);
-      if (gi_raw >= 0 && r >= off && r < off + n && slot < kg) {
-        node = g0 + (r - off);
-        gs = g0;
-        row0 = off;
-        gsel = gi;
-        nsel = n;
-      }
-    }
-    int e_lo = 0, e_hi = 0;
-    float xval = 0.f;
-    if (node >= 0) {
-      e_lo = S.rowptr[node];
-      e_hi = S.rowptr[node + 1];
-      xval = DGL ? S.ev[(int64_t)node * S.dense_ld + slot] : S.ev[S.evoff[gsel] + (int64_t)(node - gs) * nsel + slot];
-    }
-    const bool valid = node >= 0;
+    // ---------------------------------------------------------------- my row, from the descriptors
+    const float* xs = dxs + lb * PHI_R;
+    const unsigned char* nbr = dnbr + lb * PHI_R * PHI_NBR;
+    const int e_lo = delo[lb * PHI_R + r], deg = ddeg[lb * PHI_R + r];
+    // (bin row of in-neighbour number e >= PHI_NBR: rare — read from the CSR, with the graph's first node / first bin row from LDS)
+    auto far_nbr = [&](int e) { return (int)drow0[lb * PHI_R + r] + S.col[e_lo + e] - dgs[lb * PHI_R + r]; };
+    const float xval = xs[r];
+    const bool valid = dnode[lb * PHI_R + r] >= 0;
     const bool wave_live = __ballot(valid) != 0ull;   // a 16-row tile without rows skips all MFMAs (keeps barriers + DMA)
-    const int deg = e_hi - e_lo;
-    __syncthreads();   // previous bin is done with xs / nbr / X
-    if (g == 0 && sg == 0) {
-      xs[r] = xval;
-      for (int e = 0; e < deg && e < PHI_NBR; ++e) nbr[r * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
-    }
+    lds_barrier();   // the previous bin is done with X
     float* XR = X + r * LD;                 // my row
     SN_STAMP(1);
     // ---------------------------------------------------------------- layer 0 aggregate (scalar input, sign-free)
-    __syncthreads();
     const uint2 nb8 = *reinterpret_cast<const uint2*>(nbr + r * PHI_NBR);   // my first 8 in-neighbours (bin rows), read once
     float a0 = 0.f;
-    for (int e = 0; e < deg; ++e) a0 += xs[e < PHI_NBR ? (int)(((e < 4 ? nb8.x : nb8.y) >> (8 * (e & 3))) & 255u) : row0 + S.col[e_lo + e] - gs];
+    for (int e = 0; e < deg; ++e) a0 += xs[e < PHI_NBR ? (int)(((e < 4 ? nb8.x : nb8.y) >> (8 * (e & 3))) & 255u) : far_nbr(e)];
     {
 #pragma clang fp contract(off)
       const float sc = 1.f + *P.l0_eps;
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
             o[kk] = a;
           }
           for (int e = 4; e < deg; ++e) {
-            const int nb = e < PHI_NBR ? (int)((nb8.y >> (8 * (e - 4))) & 255u) : row0 + S.col[e_lo + e] - gs;
+            const int nb = e < PHI_NBR ? (int)((nb8.y >> (8 * (e - 4))) & 255u) : far_nbr(e);
             const float* np = X + nb * LD + 4 * g;
 #pragma unroll
             for (int kk = 0; kk < NT; ++kk) o[kk] += lds_ld4(np + 16 * kk);
@@ -305,7 +335,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       }
       lds_barrier();
       if (valid && !DGL) {
-        float* orow = S.out + ((int64_t)node * S.K + slot) * P.d;
+        float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb]) * P.d;       // (re-read: not kept live across the layers)
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;     // the same row in the other sign's image
         constexpr int H = (NT + 1) / 2;
         // (d % 4 == 0 is an entry-point requirement: whole float4 per lane; only the last 16-channel tile can be partial)
@@ -322,7 +352,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       }
       if (valid && DGL) {
         const int dout = P.reserved;                               // phi_out_dim: any width <= d (rows are not float4-aligned)
-        float* orow = S.out + ((int64_t)node * S.K + slot) * dout;
+        float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb]) * dout;
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;
         constexpr int H = (NT + 1) / 2;
 #pragma unroll
@@ -341,6 +371,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       SN_ACCUM(14, pt);
     }
     SN_STAMP(11);
+    }
   }
   { SN_PROF_ON(true); SN_STAMP(13); }
   ring.drain();
@@ -349,7 +380,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
 template <int NT, bool HID1, bool DGL = false>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)WRing<NT, PHI_WAVES>::BYTES + (size_t)(2 * PHI_R * LD + PHI_R) * sizeof(float) + (size_t)PHI_R * PHI_NBR;
+  const size_t lds = (size_t)WRing<NT, PHI_WAVES>::BYTES + (size_t)(2 * PHI_R * LD) * sizeof(float) + (size_t)PHI_DESC_BYTES;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
