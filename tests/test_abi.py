@@ -58,6 +58,37 @@ def test_version_and_error_string(lib):
     assert lib.sn_phi_bins_bound(128, 16) == 128 * 16 + 1 and lib.sn_phi_bins_bound(10, 0) == 641
 
 
+def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
+    """Every entry point added in round 2 rejects null / out-of-range arguments before any launch (rc -1, message naming the function):
+    callable without a GPU."""
+    import ctypes as C
+    i64 = (C.c_int64 * 1)(4)
+    cases = {
+        "sn_dense_attention_f32": (None, None, None, 1, 8, 2, 4, None, None, None),
+        "sn_dense_attention_bwd_f32": (None,) * 6 + (1, 8, 2, 4) + (None,) * 5,
+        "sn_deepsigns_phi_f32": (None, None, 8, None, None, None, None, 8, None, None),
+        "sn_mlp_chain_f32": (None, 8, 4, 8, None, 0, None, 2, 64, None, 8, 8, None),
+        "sn_gatedgcn_fused_f32": (None,) * 4 + (1,) + (None,) * 6,
+        "sn_eigenspace_group": (None, 4, 5) + (None,) * 8,
+        "sn_eigenspace_projectors_f32": (None, 4, 4, None, None, 1, None, None),
+        "sn_ign_contract_eigvecs_f32": (None, 4, 4, None, None, 1, 1, None, None),
+        "sn_pna_aggregate_f32": (None, 4, None, 4, 4, 2, None, None, 1.0, None, 52, None),
+        "sn_pna_aggregate_bwd_f32": (None, 4, 4, 2, None, None, 1.0, None, 52, None, None, None),
+        "sn_edge_attention_f32": (None,) * 4 + (2, 2, 4) + (None,) * 5,
+        "sn_edge_attention_bwd_f32": (None,) * 6 + (2, 2, 2, 4) + (None,) * 12,
+        "sn_edge_rows_sum_f32": (None, 4, 4, 2, None, None, None, 4, None),
+        "sn_act_bwd_f32": (None, None, 2, 4, None, 1, 0.01, None, None),
+        "sn_pointwise_f32": (None, 4, 2, 4, None, None, None, 0, 0.0, None, 4, None, 4, None),
+        "sn_embedding_sum_bwd_f32": (None, 1, 1, 4, None, i64, 8, None, None, None, None),
+    }
+    for name, args in cases.items():
+        rc = getattr(lib, name)(*args)
+        assert rc == -1 and name.encode() in lib.sn_last_error(), (name, rc, lib.sn_last_error())
+    assert lib.sn_gatedgcn_max_edges(68) == 176 and lib.sn_gatedgcn_max_edges(128) == 0
+    assert lib.sn_embedding_bwd_scratch_floats(1000, 1, i64, 8) == 4 * 4 * 8          # ceil(1000/256) chunks x 4 table rows x 8 channels
+    assert lib.sn_phi_bins_bound(128, -8) == 128 * 8 + 1                              # full-slot mode: |kmax| bins per column
+
+
 def test_struct_layouts_match_the_header():
     """sizeof/offsetof of the parameter structs, C compiler vs ctypes."""
     from signnet_basisnet_amd import fused, ops
