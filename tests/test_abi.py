@@ -91,7 +91,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
 
 def test_struct_layouts_match_the_header():
     """sizeof/offsetof of the parameter structs, C compiler vs ctypes."""
-    from signnet_basisnet_amd import fused, ops
+    from signnet_basisnet_amd import dgl_nets, fused, ops
     prog = r'''
 #include <stdio.h>
 #include <stddef.h>
@@ -101,6 +101,8 @@ int main(void) {
          sizeof(sn_rho_layer), sizeof(sn_rho_params), sizeof(sn_gnn_layer), sizeof(sn_gnn_params),
          offsetof(sn_gnn_params, layers));
   printf("%zu %zu %zu\n", offsetof(sn_phi_params, layers), offsetof(sn_rho_params, layers), offsetof(sn_rho_params, pe_w1));
+  printf("%zu %zu %zu %zu\n", sizeof(sn_gatedgcn_layer), sizeof(sn_gatedgcn_params), offsetof(sn_gatedgcn_params, layers),
+         offsetof(sn_gatedgcn_params, ro_w0));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -113,7 +115,8 @@ int main(void) {
     S = ctypes.sizeof
     want = [S(ops._PlanBinsC), S(fused._PhiLayer), S(fused._PhiParams), S(fused._RhoLayer), S(fused._RhoParams),
             S(fused._GnnLayer), S(fused._GnnParams), fused._GnnParams.layers.offset,
-            fused._PhiParams.layers.offset, fused._RhoParams.layers.offset, fused._RhoParams.pe_w1.offset]
+            fused._PhiParams.layers.offset, fused._RhoParams.layers.offset, fused._RhoParams.pe_w1.offset,
+            S(dgl_nets._GatedLayerC), S(dgl_nets._GatedParamsC), dgl_nets._GatedParamsC.layers.offset, dgl_nets._GatedParamsC.ro_w0.offset]
     assert got == want
 
 
