@@ -708,3 +708,94 @@ def test_dgl_transformer_net_parameter_gradients_match_oracle_autograd(name):
     torch.testing.assert_close(y.detach().cpu().double(), y64, rtol=2e-3, atol=2e-4)
     (y * cot.float().to(DEV)).sum().backward()
     _check_param_grads(net, sd64, "TransformerNet")
+
+
+# ------------------------------------------------------------------------------------------ edge cases of the DGL stage kernels
+def _gated_net(hidden=52, L=3, k=6):
+    from signnet_basisnet_amd import dgl_nets as DN
+    torch.manual_seed(7)
+    p = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, L=L, readout="mean", batch_norm=True, residual=True,
+             edge_feat=True, device=DEV, pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=0.0,
+             alpha_loss=0.0, pos_enc_dim=k, pe_aggregate="add", in_feat_dropout=0.0, dropout=0.0, sign_inv_net="masked_gin",
+             sign_inv_layers=3, phi_out_dim=20, sign_inv_activation="relu")
+    net = DN.GatedGCNNet(p)
+    PU.bn_randomize(net, 9)
+    return net.to(DEV).eval()
+
+
+def _run_both(net, data, k):
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import synth
+    ei = data.edge_index
+    h, e = data.x.reshape(-1).to(DEV), data.edge_attr.reshape(-1).to(DEV)
+    pe = synth.dgl_pos_enc(data, k).to(DEV)
+    outs = []
+    for fused in (True, False):
+        net.fused_stages = net.sign_inv_net.fused_stages = fused
+        g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), torch.tensor(data.sizes))
+        pp = net.sign_inv_net(g, pe.unsqueeze(-1)).squeeze(-1)
+        outs.append((pp, net(g, h, pp, e)[0]))
+    net.fused_stages = net.sign_inv_net.fused_stages = True
+    return outs
+
+
+def test_dgl_stage_kernels_ragged_batch_one_node_graphs_and_the_64_node_limit():
+    """Sizes 1, 2, 3 (fewer nodes than eigenvector slots: zero-padded columns, a graph without edges), the 64-node maximum of the
+    one-workgroup-per-graph kernels, and ordinary sizes in one batch: stage kernels == layer path for the masked sign-invariant net
+    and the GatedGCN stack."""
+    from signnet_basisnet_amd import synth
+    k = 6
+    net = _gated_net(k=k)
+    data = synth.make_batch(9, seed=51, sizes=[1, 2, 3, 64, 17, 1, 40, 5, 64])
+    (p_f, y_f), (p_l, y_l) = _run_both(net, data, k)
+    assert torch.isfinite(y_f).all() and y_f.shape == (9, 1)
+    close(p_f, p_l, "MaskedGINDeepSigns stage kernels vs layer path (ragged)")
+    close(y_f, y_l, "GatedGCN one launch vs layer path (ragged)")
+    net.check_last()
+
+
+def test_dgl_stage_kernels_oversize_graph_falls_back_to_the_layer_path():
+    """A 70-node graph: the modules see it in batch_num_nodes and use the layer-at-a-time kernels for the whole batch."""
+    from signnet_basisnet_amd import ops, synth
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    k = 6
+    net = _gated_net(k=k)
+    data = synth.make_batch(3, seed=52, sizes=[12, 70, 9])
+    ei = data.edge_index
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), torch.tensor(data.sizes))
+    pe = synth.dgl_pos_enc(data, k).to(DEV)
+    rec = ops.KernelTimer()
+    with rec:
+        pp = net.sign_inv_net(g, pe.unsqueeze(-1)).squeeze(-1)
+        y = net(g, data.x.reshape(-1).to(DEV), pp, data.edge_attr.reshape(-1).to(DEV))[0]
+    names = {n for n, _, _ in rec.spans}
+    assert "sn_gatedgcn_fused_f32" not in names and "sn_deepsigns_phi_f32" not in names and "sn_gated_aggregate_f32" in names
+    assert torch.isfinite(y).all()
+
+
+def test_gatedgcn_one_launch_flags_a_graph_with_too_many_edges():
+    """A dense 40-node graph (more in-edges than the kernel's LDS image holds): NaN score for that graph only, the rest unaffected,
+    check_last() raises."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import synth
+    k = 6
+    net = _gated_net(k=k)
+    data = synth.make_batch(3, seed=53, sizes=[10, 40, 8])
+    n0, n1 = 10, 40
+    ii, jj = torch.meshgrid(torch.arange(n1), torch.arange(n1), indexing="ij")
+    keep = ii != jj
+    dense = torch.stack([ii[keep], jj[keep]]) + n0                       # 1560 directed edges inside graph 1
+    ei = torch.cat([data.edge_index, dense], dim=1)
+    e = torch.cat([data.edge_attr.reshape(-1), torch.ones(dense.shape[1], dtype=torch.long)])
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), torch.tensor(data.sizes))
+    pe = synth.dgl_pos_enc(data, k).to(DEV)
+    net.sign_inv_net.fused_stages = False
+    pp = net.sign_inv_net(g, pe.unsqueeze(-1)).squeeze(-1)
+    y = net(g, data.x.reshape(-1).to(DEV), pp, e.to(DEV))[0]
+    assert torch.isnan(y[1]).all() and torch.isfinite(y[0]).all() and torch.isfinite(y[2]).all()
+    with pytest.raises(RuntimeError):
+        net.check_last()
+    net.fused_stages = False
+    y_l = net(g, data.x.reshape(-1).to(DEV), pp, e.to(DEV))[0]
+    assert torch.isfinite(y_l).all()
+    close(y[[0, 2]], y_l[[0, 2]], "graphs beside the flagged one")
