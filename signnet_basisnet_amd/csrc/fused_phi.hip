@@ -257,12 +257,20 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
 #endif
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
-            const f32x4 v0 = lds_ld4(n0 + 16 * kk), v1 = lds_ld4(n1 + 16 * kk), v2 = lds_ld4(n2 + 16 * kk), v3 = lds_ld4(n3 + 16 * kk);
+            const f32x4 v0 = lds_ld4(n0 + 16 * kk), v1 = lds_ld4(n1 + 16 * kk);
             f32x4 a = deg > 0 ? v0 : zero4;
             a += deg > 1 ? v1 : zero4;
-            a += deg > 2 ? v2 : zero4;
-            a += deg > 3 ? v3 : zero4;
             o[kk] = a;
+          }
+          // third and fourth neighbour: only the lanes that have one read (this loop is bound by LDS delivery, and on molecular
+          // graphs most rows have degree <= 2)
+          if (deg > 2) {
+#pragma unroll
+            for (int kk = 0; kk < NT; ++kk) o[kk] += lds_ld4(n2 + 16 * kk);
+          }
+          if (deg > 3) {
+#pragma unroll
+            for (int kk = 0; kk < NT; ++kk) o[kk] += lds_ld4(n3 + 16 * kk);
           }
           for (int e = 4; e < deg; ++e) {
             const int nb = e < PHI_NBR ? (int)((nb8.y >> (8 * (e - 4))) & 255u) : far_nbr(e);
