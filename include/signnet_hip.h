@@ -319,6 +319,14 @@ int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const 
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,
                      float slope, const float* residual, int ldr, float* y, int ldy, void* stream);
 
+/* dgl.nn.pytorch.GATConv after its fc Linear, as GATNet builds it (nets/ZINC_graph_regression/gat_net.py:62-66: feat_drop = attn_drop = 0,
+ * negative_slope 0.2, no residual, bias, ReLU) — DGL is absent and unpinned by the reference; semantics restated from its published
+ * definition: feat [N, heads*C] = fc(h); e_ij = leaky_relu(feat_j . attn_l[h] + feat_i . attn_r[h], slope) over the in-edges j -> i;
+ * a = softmax over a node's in-edges; out[i,h,:] = [relu](sum_j a_ij feat[j,h,:] + bias[h,:]).  attn_l / attn_r: [heads*C]; bias may be
+ * NULL; C <= 64; in-edges in edge-id order (no atomics).  lse [N, heads] (may be NULL): log-sum-exp of each (node, head), for a backward. */
+int sn_gat_aggregate_f32(const float* feat, const float* attn_l, const float* attn_r, const float* bias, int64_t N, int heads, int C,
+                         float negative_slope, int relu, const int32_t* rowptr, const int32_t* col, float* out, float* lse, void* stream);
+
 /* Adjoints of the f3 message-passing ops (the reference obtains them from torch.autograd through DGL); CSR walks with one owner per
  * output element — no atomics, bitwise reproducible.
  * sn_edge_rows_sum_f32: out[n,:] = sum over n's CSR range of g[eperm[p],:] — the adjoint of gathering node rows onto edges (h[dst] with
@@ -337,6 +345,15 @@ int sn_edge_attention_bwd_f32(const float* Q, const float* K, const float* V, co
                               const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm, float* dQ, float* dK, float* dV,
                               float* dE, float* scratch, void* stream);
 int sn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C, const float* rowscale, int act, float slope, float* dx, void* stream);
+/* sn_gat_aggregate_bwd_f32: adjoint of sn_gat_aggregate_f32 (out, lse from the forward call).  dfeat [N, heads*C]; dbias_rows [N, heads*C] =
+ *   dout masked by the ReLU (its column sums are the bias gradient); d_el, d_er [N, heads]: gradients of feat . attn_l (as a source) and
+ *   feat . attn_r (as a destination) — the attn_l / attn_r gradients are sum_n d_el[n,h] feat[n,h,:] and sum_n d_er[n,h] feat[n,h,:].
+ *   rev_*: the CSR of the flipped edge list (edges grouped by source).  scratch: 2 * E * heads floats. */
+int sn_gat_aggregate_bwd_f32(const float* feat, const float* attn_l, const float* attn_r, const float* bias, const float* out,
+                             const float* lse, const float* dout, int64_t N, int64_t E, int heads, int C, float negative_slope, int relu,
+                             const int32_t* rowptr, const int32_t* col, const int32_t* eperm, const int32_t* rev_rowptr,
+                             const int32_t* rev_col, const int32_t* rev_eperm, float* dfeat, float* dbias_rows, float* d_el, float* d_er,
+                             float* scratch, void* stream);
 
 /* The GatedGCN network of the DGL tree from its first GatedGCNLayer to the scores, ONE launch, eval mode:
  * replaces the layer loop, readout and MLPReadout of GatedGCNNet.forward (nets/ZINC_graph_regression/gatedgcn_net.py:105-148) and

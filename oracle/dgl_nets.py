@@ -215,3 +215,33 @@ def transformer_net(sd, src, dst, batch_num_nodes, h_idx, p, e_idx, n_layers, he
     if out is not None:
         out["h_last"] = h
     return _mlp_readout(sd, _readout(h, batch_num_nodes, readout))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GAT: /root/reference/GraphPrediction/nets/ZINC_graph_regression/gat_net.py:19-148 (GATNet, lap_pe / lap_lspe = False) on
+# dgl.nn.pytorch.GATConv — third-party, absent and unpinned by the reference; restated from its published definition:
+# fc without bias, e_ij = leaky_relu(feat_j . attn_l + feat_i . attn_r, 0.2), softmax over a node's in-edges, sum, + bias, ReLU.
+def gat_conv(sd, pfx, src, dst, h, heads, slope=0.2):
+    N = h.shape[0]
+    f = F.linear(h, sd[f"{pfx}.fc.weight"]).view(N, heads, -1)
+    el = (f * sd[f"{pfx}.attn_l"]).sum(-1)
+    er = (f * sd[f"{pfx}.attn_r"]).sum(-1)
+    e = F.leaky_relu(el[src] + er[dst], slope)
+    m = torch.full((N, heads), float("-inf"), dtype=e.dtype).scatter_reduce(0, dst.unsqueeze(1).expand(-1, heads), e, reduce="amax")
+    w = torch.exp(e - m[dst])
+    z = torch.zeros(N, heads, dtype=e.dtype).index_add_(0, dst, w)
+    rst = torch.zeros_like(f).index_add_(0, dst, (w / z[dst]).unsqueeze(-1) * f[src])
+    return torch.relu(rst + sd[f"{pfx}.bias"].view(1, heads, -1))
+
+
+def gat_net(sd, src, dst, batch_num_nodes, h_idx, p, n_layers, heads, readout="mean", out=None):
+    """GATNet.forward (gat_net.py:89-148) for pe_init='lap_pe', lap_lspe=False: h = embedding_h(h) + embedding_p(p); L-1 GATConv layers
+    with the heads flattened, the last one averaged over the heads (:108-110); readout; MLPReadout.  (The edge embedding is computed
+    and never used: 'GAT (no edge feature)', :10-13.)"""
+    h = sd["embedding_h.weight"][h_idx] + F.linear(p, sd["embedding_p.weight"], sd["embedding_p.bias"])
+    for l in range(n_layers - 1):
+        h = gat_conv(sd, f"layers.{l}", src, dst, h, heads).flatten(1)
+    h = gat_conv(sd, f"layers.{n_layers - 1}", src, dst, h, heads).mean(1)
+    if out is not None:
+        out["h_last"] = h
+    return _mlp_readout(sd, _readout(h, batch_num_nodes, readout))

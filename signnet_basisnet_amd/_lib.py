@@ -61,6 +61,8 @@ SIGNATURES = {
     "sn_pointwise_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _f, _p, _i, _p, _i, _p],
     "sn_deepsigns_phi_f32": [_p, _p, _i, _p, _p, _p, _p, _i, _p, _p],
     "sn_mlp_chain_f32": [_p, _i, _l, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p],
+    "sn_gat_aggregate_f32": [_p, _p, _p, _p, _l, _i, _i, _f, _i, _p, _p, _p, _p, _p],
+    "sn_gat_aggregate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _l, _i, _i, _f, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_edge_rows_sum_f32": [_p, _i, _i, _l, _p, _p, _p, _i, _p],
     "sn_pna_aggregate_bwd_f32": [_p, _i, _i, _l, _p, _p, _f, _p, _i, _p, _p, _p],
     "sn_edge_attention_bwd_f32": [_p, _p, _p, _p, _p, _p, _l, _l, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -453,6 +453,53 @@ def edge_attention(Q, K, V, Ee, plan, rplan, heads):
     return _EdgeAttention.apply(Q, K, V, Ee, plan, rplan, heads)
 
 
+class _GatAggregate(Function):
+    """dgl GATConv after its fc (gat_net.py:62-66): edge softmax of leaky_relu(el[src] + er[dst]) + weighted sum + bias + ReLU."""
+
+    @staticmethod
+    def forward(ctx, feat, attn_l, attn_r, bias, plan, rplan, heads, slope, relu):
+        feat = _c(feat)
+        out, lse = ops.gat_aggregate(feat, attn_l, attn_r, bias, plan, heads, slope, relu=relu, want_lse=True)
+        ctx.save_for_backward(feat, attn_l, attn_r, bias, out, lse)
+        ctx.meta = (plan, rplan, heads, slope, relu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, attn_l, attn_r, bias, out, lse = ctx.saved_tensors
+        plan, rp, H, slope, relu = ctx.meta
+        g = _c(g)
+        N, d = feat.shape
+        Cc = d // H
+        E = plan.col.numel()
+        al, ar = _c(attn_l.reshape(-1)), _c(attn_r.reshape(-1))
+        dfeat, gob = torch.empty_like(feat), torch.empty_like(feat)
+        dlr = torch.empty(2, N, H, dtype=torch.float32, device=g.device)                 # d el | d er
+        scratch = torch.empty(2 * max(E, 1) * H, dtype=torch.float32, device=g.device)
+        with ops._span("sn_gat_aggregate_bwd_f32"):
+            check(lib().sn_gat_aggregate_bwd_f32(ptr(feat), ptr(al), ptr(ar), ptr(None if bias is None else _c(bias.reshape(-1))), ptr(out), ptr(lse),
+                                                 ptr(g), N, E, H, Cc, float(slope), int(relu), ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm),
+                                                 ptr(rp.rowptr), ptr(rp.col), ptr(rp.eperm), ptr(dfeat), ptr(gob), ptr(dlr[0]), ptr(dlr[1]),
+                                                 ptr(scratch), stream()), "sn_gat_aggregate_bwd_f32")
+        # attn_l / attn_r gradients: the diagonal [h, h*C:(h+1)*C] blocks of (d el | d er)^T feat — one weight-gradient reduction; the
+        # bias gradient is the column sum of the masked cotangent (the same reduction's bias output)
+        lr = torch.cat([dlr[0], dlr[1]], dim=1)                                          # [N, 2H]
+        dW, _ = linear_wgrad(feat, lr, None, 0, want_bias=False)                         # [2H, H*C]
+        blocks = dW.view(2, H, H, Cc)
+        idx = torch.arange(H, device=g.device)
+        dal = blocks[0, idx, idx].reshape(attn_l.shape)
+        dar = blocks[1, idx, idx].reshape(attn_r.shape)
+        db = None
+        if bias is not None:
+            _, db = linear_wgrad(lr, gob, None, 0, want_bias=True)
+            db = db.reshape(bias.shape)
+        return dfeat, dal, dar, db, None, None, None, None, None
+
+
+def gat_aggregate(feat, attn_l, attn_r, bias, plan, rplan, heads, slope=0.2, relu=True):
+    return _GatAggregate.apply(feat, attn_l, attn_r, bias, plan, rplan, heads, slope, relu)
+
+
 class _ActResidual(Function):
     """act(x [* rowscale]) + residual with act in none / relu / leaky: FCLayer's LeakyReLU + the layer residual (pna_layer.py:126-134),
     graph_norm's row scaling (:75-76)."""

@@ -111,6 +111,66 @@ __global__ __launch_bounds__(256) void k_pointwise(const float* __restrict__ x, 
   y[r * ldy + c] = v;
 }
 
+// dgl.nn.pytorch.GATConv as gat_net.py:62-66 builds it (feat_drop = attn_drop = 0, negative_slope 0.2, no residual, bias, ReLU):
+//   feat = fc(h) [N, H, C];  el_j = feat_j . attn_l[h], er_i = feat_i . attn_r[h];  e_ij = leaky_relu(el_j + er_i, 0.2) over in-edges j -> i;
+//   a = edge_softmax (max-subtracted);  out[i,h,:] = act(sum_j a_ij feat[j,h,:] + bias[h,:]).
+// One thread per (node, head), C <= 64: the in-edge rows are walked twice (scores / maximum, then weights and the sum) in edge-id
+// order; a node without in-edges gets act(bias) (DGL raises for such graphs unless allow_zero_in_degree).  lse (optional, [N, H]) keeps
+// max + log(sum) for the backward.
+__global__ __launch_bounds__(256) void k_gat_aggregate(const float* __restrict__ feat, const float* __restrict__ attn_l,
+                                                       const float* __restrict__ attn_r, const float* __restrict__ bias, int64_t N, int H,
+                                                       int C, float slope, int relu, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, float* __restrict__ out, float* __restrict__ lse) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * C;
+  const float* al = attn_l + h * C;
+  const float* ar = attn_r + h * C;
+  float er = 0.f;
+  {
+    const float* fi = feat + n * d + h * C;
+    for (int c = 0; c < C; ++c) er += fi[c] * ar[c];
+  }
+  const int lo = rowptr[n], hi = rowptr[n + 1];
+  float m = -INFINITY;
+  for (int e = lo; e < hi; ++e) {
+    const float* fj = feat + (int64_t)col[e] * d + h * C;
+    float el = 0.f;
+    for (int c = 0; c < C; ++c) el += fj[c] * al[c];
+    float s = el + er;
+    s = s > 0.f ? s : s * slope;
+    m = fmaxf(m, s);
+  }
+  float acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  float z = 0.f;
+  for (int e = lo; e < hi; ++e) {
+    const float* fj = feat + (int64_t)col[e] * d + h * C;
+    float el = 0.f;
+    for (int c = 0; c < C; ++c) el += fj[c] * al[c];
+    float s = el + er;
+    s = s > 0.f ? s : s * slope;
+    const float w = expf(s - m);
+    z += w;
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (c < C) acc[c] += w * fj[c];
+  }
+  const float r = hi > lo ? 1.0f / z : 0.f;
+  float* o = out + n * d + h * C;
+#pragma unroll
+  for (int c = 0; c < 64; ++c)
+    if (c < C) {
+      float v = acc[c] * r + (bias ? bias[h * C + c] : 0.f);
+      if (relu) v = fmaxf(v, 0.f);
+      o[c] = v;
+    }
+  if (lse) lse[i] = hi > lo ? m + logf(z) : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- adjoints
 // (SURVEY.md §8 f1 for the f3 nets: the reference gets these from torch.autograd through DGL's message passing.)  All by CSR walks
 // with one owner per output element: no atomics, bitwise reproducible.
@@ -170,6 +230,90 @@ __global__ __launch_bounds__(256) void k_pna_aggregate_bwd(const float* __restri
     if (e == imn) d += da[2];
     dmsg[row * C + c] = d;
   }
+}
+
+// adjoint of k_gat_aggregate, destination side — one thread per (node, head): with go = dout * [out > 0] and a_e = exp(s_e - lse),
+//   d s_e = a_e (go . f_src(e) - go . (out - bias)),   d pre_e = d s_e * leaky'(pre_e),   d er_n = sum_e d pre_e.
+// Writes go [N, H*C] (the bias gradient's rows, and what the source side needs), a_e and d pre_e per (edge id, head), d er [N, H].
+__global__ __launch_bounds__(256) void k_gat_bwd_dst(const float* __restrict__ feat, const float* __restrict__ attn_l,
+                                                     const float* __restrict__ attn_r, const float* __restrict__ bias,
+                                                     const float* __restrict__ out, const float* __restrict__ lse,
+                                                     const float* __restrict__ dout, int64_t N, int H, int C, float slope, int relu,
+                                                     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ eperm, float* __restrict__ gob, float* __restrict__ alpha,
+                                                     float* __restrict__ dpre, float* __restrict__ der) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * C;
+  const float* al = attn_l + h * C;
+  const float* ar = attn_r + h * C;
+  const float* fi = feat + n * d + h * C;
+  float go[64];
+  float gdo = 0.f, er = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    go[c] = 0.f;
+    if (c < C) {
+      const float o = out[n * d + h * C + c];
+      const float g = (!relu || o > 0.f) ? dout[n * d + h * C + c] : 0.f;
+      go[c] = g;
+      gob[n * d + h * C + c] = g;
+      gdo += g * (o - (bias ? bias[h * C + c] : 0.f));
+      er += fi[c] * ar[c];
+    }
+  }
+  const float L = lse[n * H + h];
+  float sum = 0.f;
+  for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+    const int64_t eid = eperm[e];
+    const float* fj = feat + (int64_t)col[e] * d + h * C;
+    float el = 0.f, gv = 0.f;
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (c < C) { el += fj[c] * al[c]; gv += go[c] * fj[c]; }
+    const float pre = el + er;
+    const float sc = pre > 0.f ? pre : pre * slope;
+    const float a = expf(sc - L);
+    const float dp = a * (gv - gdo) * (pre > 0.f ? 1.0f : slope);
+    alpha[eid * H + h] = a;
+    dpre[eid * H + h] = dp;
+    sum += dp;
+  }
+  der[n * H + h] = sum;
+}
+
+// source side: d feat[j] = sum_{e: j -> i} a_e go_i + (sum_e d pre_e) attn_l + d er_j attn_r; d el [N, H] is kept for the attn_l gradient
+__global__ __launch_bounds__(256) void k_gat_bwd_src(const float* __restrict__ attn_l, const float* __restrict__ attn_r,
+                                                     const float* __restrict__ gob, const float* __restrict__ alpha,
+                                                     const float* __restrict__ dpre, const float* __restrict__ der, int64_t N, int H, int C,
+                                                     const int32_t* __restrict__ rev_rowptr, const int32_t* __restrict__ rev_col,
+                                                     const int32_t* __restrict__ rev_eperm, float* __restrict__ dfeat,
+                                                     float* __restrict__ del) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * C;
+  float acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  float sum = 0.f;
+  for (int e = rev_rowptr[n]; e < rev_rowptr[n + 1]; ++e) {
+    const int64_t eid = rev_eperm[e];
+    const float* g = gob + (int64_t)rev_col[e] * d + h * C;
+    const float a = alpha[eid * H + h];
+    sum += dpre[eid * H + h];
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (c < C) acc[c] += a * g[c];
+  }
+  const float r = der[n * H + h];
+  del[n * H + h] = sum;
+#pragma unroll
+  for (int c = 0; c < 64; ++c)
+    if (c < C) dfeat[n * d + h * C + c] = acc[c] + sum * attn_l[h * C + c] + r * attn_r[h * C + c];
 }
 
 // adjoint of k_edge_attention, destination side: dQ [N, H*dk], dE [E, H*dk] and the per-(edge, head) scalars the source side needs —
@@ -362,5 +506,40 @@ extern "C" int sn_act_bwd_f32(const float* x, const float* dy, int64_t R, int C,
   if (R == 0) return SN_OK;
   hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, R, C, rowscale, act, slope, dx);
   SN_CHECK_LAUNCH("sn_act_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gat_aggregate_f32(const float* feat, const float* attn_l, const float* attn_r, const float* bias, int64_t N, int heads, int C,
+                                    float negative_slope, int relu, const int32_t* rowptr, const int32_t* col, float* out, float* lse,
+                                    void* stream) {
+  SN_REQUIRE(feat && attn_l && attn_r && rowptr && out && N >= 0 && heads > 0, "sn_gat_aggregate_f32: bad arguments");
+  SN_REQUIRE(C >= 1 && C <= 64, "sn_gat_aggregate_f32: head width %d not in [1, 64]", C);
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_gat_aggregate, dim3((unsigned)cdiv(N * heads, 256)), dim3(256), 0, (hipStream_t)stream, feat, attn_l, attn_r, bias, N,
+                     heads, C, negative_slope, relu, rowptr, col, out, lse);
+  SN_CHECK_LAUNCH("sn_gat_aggregate_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gat_aggregate_bwd_f32(const float* feat, const float* attn_l, const float* attn_r, const float* bias, const float* out,
+                                        const float* lse, const float* dout, int64_t N, int64_t E, int heads, int C, float negative_slope,
+                                        int relu, const int32_t* rowptr, const int32_t* col, const int32_t* eperm, const int32_t* rev_rowptr,
+                                        const int32_t* rev_col, const int32_t* rev_eperm, float* dfeat, float* dbias_rows, float* d_el,
+                                        float* d_er, float* scratch, void* stream) {
+  SN_REQUIRE(feat && attn_l && attn_r && out && lse && dout && rowptr && rev_rowptr && dfeat && dbias_rows && d_el && d_er && scratch &&
+                 N >= 0 && E >= 0 && heads > 0,
+             "sn_gat_aggregate_bwd_f32: bad arguments");
+  SN_REQUIRE(C >= 1 && C <= 64, "sn_gat_aggregate_bwd_f32: head width %d not in [1, 64]", C);
+  if (N == 0) return SN_OK;
+  SN_REQUIRE(E == 0 || (col && eperm && rev_col && rev_eperm), "sn_gat_aggregate_bwd_f32: null edge arrays");
+  hipStream_t st = (hipStream_t)stream;
+  float* alpha = scratch;
+  float* dpre = scratch + E * heads;
+  const dim3 grid((unsigned)cdiv(N * heads, 256));
+  hipLaunchKernelGGL(k_gat_bwd_dst, grid, dim3(256), 0, st, feat, attn_l, attn_r, bias, out, lse, dout, N, heads, C, negative_slope, relu, rowptr,
+                     col, eperm, dbias_rows, alpha, dpre, d_er);
+  hipLaunchKernelGGL(k_gat_bwd_src, grid, dim3(256), 0, st, attn_l, attn_r, (const float*)dbias_rows, (const float*)alpha, (const float*)dpre,
+                     (const float*)d_er, N, heads, C, rev_rowptr, rev_col, rev_eperm, dfeat, d_el);
+  SN_CHECK_LAUNCH("sn_gat_aggregate_bwd_f32");
   return SN_OK;
 }

@@ -751,3 +751,139 @@ class TransformerNet(_PackCache, nn.Module):
 
     def loss(self, scores, targets):
         return (scores - targets).abs().mean()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GAT: nets/ZINC_graph_regression/gat_net.py:19-148 on dgl.nn.pytorch.GATConv
+class GATConv(nn.Module):
+    """Parameter container with dgl.nn.pytorch.GATConv's names and initialisation (fc without bias, attn_l / attn_r [1, heads, out],
+    bias [heads*out]; xavier_normal with the ReLU gain, zero bias); the arithmetic is sn_masked_linear_f32 + sn_gat_aggregate_f32."""
+
+    def __init__(self, in_feats, out_feats, num_heads, negative_slope=0.2):
+        super().__init__()
+        if out_feats > 64:
+            raise ValueError("HIP GATConv: head width <= 64")
+        self.in_feats, self.out_feats, self.num_heads, self.negative_slope = in_feats, out_feats, num_heads, negative_slope
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        self.bias = nn.Parameter(torch.zeros(num_heads * out_feats))
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        nn.init.xavier_normal_(self.attn_r, gain=gain)
+
+
+class GATNet(_PackCache, nn.Module):
+    """nets/ZINC_graph_regression/gat_net.py:19-148 for pe_init = 'lap_pe', lap_lspe = False (GAT_ZINC_LapPE_signinv_GIN.json):
+    h = embedding_h(h) + embedding_p(p), L GATConv(ReLU) layers — the first L-1 with their heads flattened, the last averaged over the
+    heads (:108-110) — mean / sum readout, MLPReadout.  'GAT (no edge feature)': the edge embedding is a parameter of the
+    state_dict only.  Same constructor, forward contract `model(g, h, p, e, snorm_n) -> (scores, g)`, state_dict keys and attached
+    `sign_inv_net`.  No BatchNorm / dropout in this net: eval and train mode compute the same value; with gradients enabled in train
+    mode the differentiable path (`_forward_grad`)."""
+
+    def __init__(self, net_params):
+        super().__init__()
+        p = net_params
+        hidden, out_dim = p["hidden_dim"], p["out_dim"]
+        self.n_layers, self.readout, self.n_heads = p["L"], p["readout"], p["n_heads"]
+        self.pe_init, self.lap_method, self.lap_lspe = p["pe_init"], p["lap_method"], p["lap_lspe"]
+        self.use_lapeig_loss, self.lambda_loss, self.alpha_loss = p["use_lapeig_loss"], p["lambda_loss"], p["alpha_loss"]
+        self.pos_enc_dim, self.device, self.edge_feat = p["pos_enc_dim"], p["device"], p["edge_feat"]
+        self.batch_norm, self.residual = p["batch_norm"], p["residual"]              # read and ignored by the reference too
+        if self.pe_init != "lap_pe" or self.lap_lspe or self.use_lapeig_loss:
+            raise NotImplementedError("HIP GATNet covers pe_init='lap_pe' / lap_lspe=False (the sign-invariant PE configs)")
+        if self.readout == "max":
+            raise NotImplementedError("HIP GATNet: readout sum / mean")
+        if p.get("in_feat_dropout", 0.0) or p.get("dropout", 0.0):
+            raise NotImplementedError("HIP GATNet: dropout 0.0 (as in the shipped configs)")
+        if self.n_layers < 2:
+            raise ValueError("GATNet: L >= 2 (gat_net.py:62-66 always builds a first and a last layer)")
+        H = self.n_heads
+        self.embedding_p = nn.Linear(self.pos_enc_dim, hidden)
+        self.embedding_h = nn.Embedding(p["num_atom_type"], hidden)
+        self.embedding_e = nn.Embedding(p["num_bond_type"], hidden) if self.edge_feat else nn.Linear(1, hidden)
+        self.in_feat_dropout = nn.Dropout(0.0)
+        self.layers = nn.ModuleList([GATConv(hidden, hidden, H)] + [GATConv(H * hidden, hidden, H) for _ in range(1, self.n_layers - 1)] +
+                                    [GATConv(H * hidden, out_dim, H)])
+        self.MLP_layer = MLPReadout(out_dim, 1)
+        self.g = None
+        if self.lap_method == "sign_inv":
+            self.sign_inv_net = get_sign_inv_net(net_params)
+
+    def forward(self, g, h, p, e, snorm_n=None):
+        ops.require_cuda(h)
+        if p is None:
+            raise NotImplementedError("HIP GATNet needs the positional encoding p")
+        N = h.shape[0]
+        if self.training and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            batch, ei, B = self._plan(g, N)
+            hg = self._forward_grad(ops.build_plan(batch, ei, B, 0), batch, ei, B, h.long().reshape(N), p.contiguous().float())
+            self.g = g
+            return hg, g
+        plan = cached_plan(g, N)
+        with torch.no_grad():
+            zero_deg = (plan.rowptr[1:] == plan.rowptr[:-1]).any()
+            x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])     # raises IndexError as nn.Embedding (one host read)
+            x = ops.masked_linear(p.contiguous().float(), self._pk(self.embedding_p), residual=x)                 # h + embedding_p(p)  (:97-99)
+            H = self.n_heads
+            for i, L in enumerate(self.layers):
+                f = ops.masked_linear(x, self._fc(L))
+                x = ops.gat_aggregate(f, L.attn_l.detach(), L.attn_r.detach(), L.bias.detach(), plan, H, L.negative_slope, relu=True)
+            # the last layer's heads are averaged (:110): sum over the head axis, then 1/H
+            x = ops.slot_sum(x.view(N * H, -1), N, H)
+            x = ops.pointwise(x, scale=self._const(1.0 / H, x.shape[1]), shift=self._const(0.0, x.shape[1]))
+            hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+            fcs = self.MLP_layer.FC_layers
+            for i, fc in enumerate(fcs):
+                hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
+        plan.check()                     # malformed batch
+        if bool(zero_deg):
+            raise ValueError("There are 0-in-degree nodes in the graph: GATConv's edge softmax is undefined for them (DGL raises "
+                             "DGLError here unless allow_zero_in_degree is set, which gat_net.py:62-66 leaves at False)")
+        self.g = g
+        self._h_last = x
+        return hg, g
+
+    _plan = GINNet._plan
+
+    def _forward_grad(self, plan, batch, ei, B, hidx, p):
+        """Differentiable train-mode forward (SURVEY.md §8 f1 for this net): the same ops as autograd nodes; the GATConv adjoint is
+        sn_gat_aggregate_bwd_f32 (CSR walks over the in-edges, then over the out-edges; no atomics)."""
+        from . import autograd as AG
+        plan.check()
+        if bool((plan.rowptr[1:] == plan.rowptr[:-1]).any()):
+            raise ValueError("There are 0-in-degree nodes in the graph: GATConv's edge softmax is undefined for them")
+        rplan = ops.build_plan(batch, ei.flip(0).contiguous(), B, 0)           # edges grouped by SOURCE
+        N, H = hidx.shape[0], self.n_heads
+        x = AG.masked_add(AG.linear(p, self.embedding_p.weight, self.embedding_p.bias), AG.embedding_sum(hidx, [self.embedding_h.weight]))
+        for L in self.layers:
+            x = AG.gat_aggregate(AG.linear(x, L.fc.weight), L.attn_l, L.attn_r, L.bias, plan, rplan, H, L.negative_slope, True)
+        x = AG.slot_sum(x.view(N * H, -1), N, H)                               # mean over the heads (:110)
+        x = AG.act_residual(x, rowscale=torch.full((N,), 1.0 / H, dtype=torch.float32, device=x.device))
+        hg = AG.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+        fcs = self.MLP_layer.FC_layers
+        for i, fc in enumerate(fcs):
+            hg = AG.linear(hg, fc.weight, fc.bias, relu=i < len(fcs) - 1)
+        self._h_last = x.detach()
+        return hg
+
+    def _fc(self, L):
+        c = self.__dict__.setdefault("_cache", {})
+        if self.training or ("fc", id(L)) not in c:
+            w = L.fc.weight.detach()
+            pl = ops.PackedLinear(ops.pack_weight(w), w.shape[0], w.shape[1], None)
+            if self.training:
+                return pl
+            c[("fc", id(L))] = pl
+        return c[("fc", id(L))]
+
+    def _const(self, v, n):
+        c = self.__dict__.setdefault("_cache", {})
+        key = ("const", float(v), int(n))
+        if key not in c:
+            c[key] = torch.full((n,), float(v), dtype=torch.float32, device=self.embedding_p.weight.device)
+        return c[key]
+
+    def loss(self, scores, targets):
+        return (scores - targets).abs().mean()

@@ -539,6 +539,23 @@ def edge_attention(Q, K, V, Ee, plan: GraphPlan, heads: int):
     return out
 
 
+def gat_aggregate(feat, attn_l, attn_r, bias, plan: GraphPlan, heads: int, negative_slope=0.2, relu=True, want_lse=False):
+    """DGL GATConv after its fc (gat_net.py:62-66): feat [N, heads*C] -> [N, heads*C]; see sn_gat_aggregate_f32."""
+    require_cuda(feat)
+    feat = _f32c(feat, "feat")
+    d = feat.shape[1]
+    if d % heads or d // heads > 64:
+        raise ValueError("gat_aggregate: heads must divide the width and the head width must be <= 64")
+    al, ar = _f32c(attn_l.reshape(-1), "attn_l"), _f32c(attn_r.reshape(-1), "attn_r")
+    b = None if bias is None else _f32c(bias.reshape(-1), "bias")
+    out = torch.empty(plan.N, d, dtype=torch.float32, device=feat.device)
+    lse = torch.empty(plan.N, heads, dtype=torch.float32, device=feat.device) if want_lse else None
+    with _span("sn_gat_aggregate_f32"):
+        check(lib().sn_gat_aggregate_f32(ptr(feat), ptr(al), ptr(ar), ptr(b), plan.N, int(heads), d // heads, float(negative_slope), int(relu),
+                                         ptr(plan.rowptr), ptr(plan.col), ptr(out), ptr(lse), stream()), "sn_gat_aggregate_f32")
+    return (out, lse) if want_lse else out
+
+
 def pointwise(x, *, rowscale=None, scale=None, shift=None, act="none", slope=0.01, residual=None):
     """y = act((x * rowscale[r]) * scale[c] + shift[c]) + residual, act in none / relu / leaky."""
     require_cuda(x)

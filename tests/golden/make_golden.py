@@ -275,6 +275,27 @@ def dgl_transformer_case(name, hidden, L, k, heads, sizes, seed, pe_aggregate):
 
 
 # ------------------------------------------------------------------ LearningFilters
+def dgl_gat_case(name, hidden, L, k, heads, sizes, seed):
+    """The DGL tree's GAT base network with a sign-invariant PE (nets/ZINC_graph_regression/gat_net.py on dgl GATConv, config
+    GAT_ZINC_LapPE_signinv_GIN.json scaled down)."""
+    mods = _fresh_import("GraphPrediction", ["nets.ZINC_graph_regression.gat_net"])
+    params = dict(num_atom_type=28, num_bond_type=4, hidden_dim=hidden, out_dim=hidden, in_feat_dropout=0.0, dropout=0.0, L=L,
+                  readout="mean", batch_norm=True, residual=True, edge_feat=True, device="cpu", pe_init="lap_pe",
+                  lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4, pos_enc_dim=k,
+                  sign_inv_net="gin", sign_inv_layers=3, sign_inv_activation="relu", pe_aggregate="concat", phi_out_dim=4, n_heads=heads)
+    torch.manual_seed(seed)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = mods[0].GATNet(params)
+    randomise(net, seed + 1)
+    with torch.no_grad():
+        for n_, p_ in net.named_parameters():
+            if n_.startswith("layers.") and n_.endswith(".bias") and n_.count(".") == 2:
+                p_.copy_(0.1 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(seed + 2)))     # GATConv.bias (zero-initialised)
+    data = synth.make_batch(len(sizes), seed=seed, sizes=sizes)
+    _run_dgl_net(name, net, data, k, {"meta/params": np.array([hidden, L, k, heads], dtype=np.int64)})
+
+
 def reference_grouping(eigvals, eigvecs):
     """Eigenspace grouping by EXECUTING the reference's own statements: LearningFilters/training.py is a script (argparse and
     dataset loading at module level), so lines 47-73 — `around()` and the whole `if args.lap_method == 'basis_inv':` block — are read
@@ -503,6 +524,7 @@ def main():
     dgl_pna_case("dgl_pna_k6", 20, 3, 6, 5, 8, [5, 9, 12, 7, 3], 36)
     dgl_transformer_case("dgl_transformer_concat_k6", 24, 3, 6, 4, [5, 9, 12, 7, 3], 37, "concat")
     dgl_transformer_case("dgl_transformer_add_k8", 32, 2, 8, 8, [6, 4, 11, 2], 38, "add")
+    dgl_gat_case("dgl_gat_k6", 12, 3, 6, 4, [5, 9, 12, 7, 3], 39)
     # BasisNet on a small grid
     basisnet_case("basisnet_grid6", 6, 8, 41)
     grouping_case("basisnet_grouping", [6, 12, 32])

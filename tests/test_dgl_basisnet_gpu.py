@@ -497,6 +497,89 @@ def test_dgl_transformer_base_net_golden(name, mode):
         torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gat_base_net_golden(mode):
+    """GraphPrediction tree, GAT_ZINC_LapPE_signinv_GIN.json's model scaled down: GINDeepSigns -> GATNet (gat_net.py on DGL's GATConv:
+    per-head additive attention over the in-edges) against the reference's own outputs.  The net has no BatchNorm / dropout, so the
+    train-mode value differs from eval only through the sign-invariant network's batch statistics."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_nets
+    fx = G.load("dgl_gat_k6")
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    net = dgl_nets.GATNet(_base_params(fx, hidden, L, k, n_heads=heads, readout="mean", pe_aggregate="concat"))
+    assert sorted(net.state_dict().keys()) == sorted(fx.sd.keys())
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train(mode == "train")
+    p, y, h_last = _drive(net, fx)
+    if mode == "eval":
+        ei = fx.inp["edge_index"]
+        with torch.no_grad():
+            y64 = ON.gat_net(PU.to_f64(fx.sd), ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out["eval/p"].double(), L, heads, "mean")
+        close(p, fx.out["eval/p"], "sign_inv_net output")
+        close(h_last, fx.out["eval/h_last"], "GAT node features")
+        close(y, fx.out["eval/y"], "GATNet scores", ref64=y64)
+    else:
+        torch.testing.assert_close(p.cpu(), fx.out["train/p"], rtol=5e-4, atol=5e-5)
+        torch.testing.assert_close(y.cpu(), fx.out["train/y"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("heads,C", [(4, 12), (1, 1), (4, 59), (3, 64), (8, 7)])
+def test_gat_aggregate_vs_fp64(heads, C):
+    """sn_gat_aggregate_f32 against the float64 restatement of GATConv's edge softmax + weighted sum on a random batch (in-degrees
+    1..7), at the shipped head width (59), the kernel's maximum (64) and degenerate widths; lse = max + log(sum exp)."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import ops, synth
+    data = synth.make_batch(40, seed=17)
+    d = synth.batch_to(data, DEV)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 0)
+    g = torch.Generator().manual_seed(heads * 100 + C)
+    src, dst = data.edge_index
+    N = data.num_nodes
+    f = torch.randn(N, heads * C, generator=g)
+    al, ar = torch.randn(1, heads, C, generator=g), torch.randn(1, heads, C, generator=g)
+    b = torch.randn(heads * C, generator=g)
+    out, lse = ops.gat_aggregate(f.to(DEV), al.to(DEV), ar.to(DEV), b.to(DEV), plan, heads, 0.2, relu=True, want_lse=True)
+    sd = {"l.fc.weight": torch.eye(heads * C, dtype=torch.float64), "l.attn_l": al.double(), "l.attn_r": ar.double(), "l.bias": b.double()}
+    ref = ON.gat_conv(sd, "l", src, dst, f.double(), heads).flatten(1)
+    close(out, ref, "gat_aggregate")
+    fd = f.double().view(N, heads, C)
+    e = torch.nn.functional.leaky_relu((fd * al.double()).sum(-1)[src] + (fd * ar.double()).sum(-1)[dst], 0.2)
+    ref_lse = torch.stack([torch.logsumexp(e[dst == n], 0) for n in range(N)])
+    close(lse, ref_lse, "gat_aggregate lse")
+    # without the activation and the bias: the plain attention-weighted sum
+    out2 = ops.gat_aggregate(f.to(DEV), al.to(DEV), ar.to(DEV), None, plan, heads, 0.2, relu=False)
+    sd["l.bias"] = torch.zeros(heads * C, dtype=torch.float64)
+    z = fd.new_zeros(N, heads, C)
+    w = torch.exp(e - ref_lse[dst])
+    z.index_add_(0, dst, w.unsqueeze(-1) * fd[src])
+    close(out2, z.flatten(1), "gat_aggregate (no bias, no relu)")
+
+
+def test_gat_net_rejects_zero_in_degree_and_bad_atom_type():
+    """DGL's GATConv raises on a graph with a node without in-edges (allow_zero_in_degree False, gat_net.py:62-66 keeps the default);
+    an atom type outside the embedding table raises IndexError as nn.Embedding does."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS, dgl_nets
+    fx = G.load("dgl_gat_k6")
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    net = dgl_nets.GATNet(_base_params(fx, hidden, L, k, n_heads=heads, readout="mean", pe_aggregate="concat"))
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).eval()
+    ei = fx.inp["edge_index"]
+    x = fx.inp["x"].squeeze(-1).to(DEV)
+    p = fx.out["eval/p"].to(DEV)
+    keep = ei[1] != 0                                             # node 0 loses its in-edges
+    g = DS.Graph(ei[0][keep].to(DEV), ei[1][keep].to(DEV), fx.inp["sizes"])
+    with pytest.raises(ValueError, match="0-in-degree"):
+        net(g, x, p, fx.inp["edge_attr"][keep].to(DEV))
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    bad = x.clone()
+    bad[3] = 28
+    with pytest.raises(IndexError):
+        net(g, bad, p, fx.inp["edge_attr"].to(DEV))
+    y, _ = net(g, x, p, fx.inp["edge_attr"].to(DEV))
+    close(y, fx.out["eval/y"], "GATNet scores after the rejected calls")
+
+
 def test_pna_aggregate_and_edge_attention_vs_fp64():
     """The two new message-passing kernels against float64 restatements on a larger random batch (degrees 1..7)."""
     from oracle import dgl_nets as ON
@@ -685,6 +768,62 @@ def test_dgl_pna_net_parameter_gradients_match_oracle_autograd():
     torch.testing.assert_close(y.detach().cpu().double(), y64, rtol=2e-3, atol=2e-4)
     (y * cot.float().to(DEV)).sum().backward()
     _check_param_grads(net, sd64, "PNANet", tol=5e-3)
+
+
+def test_dgl_gat_net_parameter_gradients_match_oracle_autograd():
+    """Train mode with gradients enabled: every GATNet parameter gradient (fc, attn_l, attn_r, bias of each GATConv, the embeddings,
+    the readout) against torch.autograd over the float64 oracle on the reference's fixture."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets
+    fx = G.load("dgl_gat_k6")
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    net = dgl_nets.GATNet(_base_params(fx, hidden, L, k, n_heads=heads, readout="mean", pe_aggregate="concat"))
+    net.load_state_dict(fx.sd)
+    net = net.to(DEV).train()
+    ei = fx.inp["edge_index"]
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), fx.inp["sizes"])
+    p_in = fx.out["train/p"]
+    sd64, y64, cot = _oracle_grads(lambda sd: ON.gat_net(sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), p_in.double(), L, heads,
+                                                          "mean"), fx.sd)
+    y, _ = net(g, fx.inp["x"].squeeze(-1).to(DEV), p_in.to(DEV), fx.inp["edge_attr"].to(DEV))
+    assert y.requires_grad
+    close(y.detach(), y64, "GATNet train-mode scores")
+    (y * cot.float().to(DEV)).sum().backward()
+    _check_param_grads(net, sd64, "GATNet", tol=1e-4)
+
+
+@pytest.mark.parametrize("heads,C,relu", [(4, 12, True), (4, 59, True), (2, 64, False), (3, 1, True)])
+def test_gat_aggregate_adjoint_vs_fp64_autograd(heads, C, relu):
+    """sn_gat_aggregate_bwd_f32 (+ the attn_l / attn_r / bias reductions) against torch.autograd on the float64 restatement."""
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import autograd as AG, ops, synth
+    data = synth.make_batch(30, seed=19)
+    d = synth.batch_to(data, DEV)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 0)
+    rplan = ops.build_plan(d.batch, d.edge_index.flip(0).contiguous(), d.num_graphs, 0)
+    g = torch.Generator().manual_seed(heads * 100 + C)
+    src, dst = data.edge_index
+    N = data.num_nodes
+    f = torch.randn(N, heads * C, generator=g)
+    al, ar = torch.randn(1, heads, C, generator=g), torch.randn(1, heads, C, generator=g)
+    b = torch.randn(heads * C, generator=g)
+    cot = torch.randn(N, heads * C, generator=g)
+    ours = [t.clone().to(DEV).requires_grad_(True) for t in (f, al, ar, b)]
+    AG.gat_aggregate(ours[0], ours[1], ours[2], ours[3], plan, rplan, heads, 0.2, relu).backward(cot.to(DEV))
+    ref = [t.double().requires_grad_(True) for t in (f, al, ar, b)]
+    sd = {"l.fc.weight": torch.eye(heads * C, dtype=torch.float64), "l.attn_l": ref[1], "l.attn_r": ref[2], "l.bias": ref[3]}
+    if relu:
+        out = ON.gat_conv(sd, "l", src, dst, ref[0], heads).flatten(1)
+    else:
+        fd = ref[0].view(N, heads, C)
+        e = torch.nn.functional.leaky_relu((fd * ref[1]).sum(-1)[src] + (fd * ref[2]).sum(-1)[dst], 0.2)
+        lse = torch.stack([torch.logsumexp(e[dst == n], 0) for n in range(N)])
+        out = (torch.zeros(N, heads, C, dtype=torch.float64).index_add(0, dst, torch.exp(e - lse[dst]).unsqueeze(-1) * fd[src])
+               + ref[3].view(1, heads, C)).flatten(1)
+    out.backward(cot.double())
+    for o, r, what in zip(ours, ref, ("d feat", "d attn_l", "d attn_r", "d bias")):
+        close(o.grad, r.grad, f"gat {what}", rel=1e-5)
 
 
 @pytest.mark.parametrize("name", ["dgl_transformer_concat_k6", "dgl_transformer_add_k8"])

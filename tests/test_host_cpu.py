@@ -106,6 +106,7 @@ def test_dropin_import_paths(monkeypatch):
                             ("graphprediction", "nets.ZINC_graph_regression.gatedgcn_net", ["GatedGCNNet"]),
                             ("graphprediction", "nets.ZINC_graph_regression.pna_net", ["PNANet"]),
                             ("graphprediction", "nets.ZINC_graph_regression.transformer_net", ["TransformerNet"]),
+                            ("graphprediction", "nets.ZINC_graph_regression.gat_net", ["GATNet"]),
                             ("learningfilters", "signbasisnet", ["SignPlus", "IGNBasisInv"]), ("learningfilters", "ign", ["IGN2to1"])):
         for m in list(sys.modules):
             if m.split(".")[0] in ("sign_net", "core", "layers", "nets", "signbasisnet", "ign"):

@@ -244,6 +244,21 @@ def test_dgl_pna_base_net(mode):
     torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
 
 
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_dgl_gat_base_net(mode):
+    """oracle/dgl_nets.py (GATConv restatement + net) against the reference's GATNet + GINDeepSigns fixture."""
+    from oracle import dgl_nets as ON
+    fx = G.load("dgl_gat_k6")
+    hidden, L, k, heads = (int(v) for v in fx.meta["params"])
+    ei = fx.inp["edge_index"]
+    p = _sign_inv_p(fx, "gin", 3, k, mode)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **TOL_BS)
+    out = {}
+    y = ON.gat_net(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out[f"{mode}/p"], L, heads, "mean", out=out)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **TOL_BS)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+
+
 @pytest.mark.parametrize("name", ["dgl_transformer_concat_k6", "dgl_transformer_add_k8"])
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_dgl_transformer_base_net(name, mode):
