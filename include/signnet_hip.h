@@ -179,6 +179,19 @@ int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, const int32
                           const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
                           float* var, float* rstd, float* scale, float* shift, float* count, float* scratch, void* stream);
 
+/* A masked Linear followed by a train-mode BatchNorm1d's statistics, the pattern of every MLP layer of the reference in training
+ * (GINESignNetPyG/core/model_utils/elements.py MLP: `x = norm(lin(x))`): z = x W^T + b on the valid rows (0 elsewhere), exactly as
+ * sn_masked_linear_f32 with SN_EPI_BIAS, and mean / var / rstd / folded (scale, shift) / count / running statistics of z as
+ * sn_bn_train_stats_f32 would return them (same values up to the summation order of the moments).  For >= 32 rows, d_out <= 128 and
+ * 16-byte-aligned rows the column moments are taken from the accumulators of the Linear kernel (one partial per wave, Chan's
+ * update): z is not read again; other shapes run the two entry points one after the other.  scratch:
+ * sn_linear_bn_scratch_floats(R, d_in, d_out) floats. */
+int64_t sn_linear_bn_scratch_floats(int64_t R, int d_in, int d_out);
+int sn_linear_bn_train_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out, const float* bias,
+                           const int32_t* nvalid, int K, float* z, int ldz, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* mean, float* var, float* rstd,
+                           float* scale, float* shift, float* count, float* scratch, void* stream);
+
 /* Elementwise y = [relu]( [relu_pre](x) * scale + shift ) [+ residual] on valid rows, 0 elsewhere
  * (the un-fused BatchNorm apply used by the train-mode forward). */
 int sn_masked_affine_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K,

@@ -45,6 +45,8 @@ SIGNATURES = {
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],
     "sn_laplacian_evd_f32": [_p, _l, _p, _l, _l, _i, _p, _p, _p, _l, _p, _i, _i, _p, _p, _p],
+    "sn_linear_bn_scratch_floats": [_l, _i, _i],
+    "sn_linear_bn_train_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _p, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_bn_train_stats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_linear_wgrad_f32": [_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _p, _p],
     "sn_bn_act_bwd_f32": [_p, _i, _p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _i, _p, _p],
@@ -107,6 +109,7 @@ def lib():
         L.sn_linear_wgrad_scratch_floats.restype = C.c_int64
         L.sn_bn_act_bwd_scratch_floats.argtypes = [_l, _i]
         L.sn_bn_act_bwd_scratch_floats.restype = C.c_int64
+        L.sn_linear_bn_scratch_floats.restype = C.c_int64
         L.sn_layernorm_bwd_scratch_floats.argtypes = [_l, _i]
         L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
         L.sn_embedding_bwd_scratch_floats.argtypes = [_l, _i, C.POINTER(C.c_int64), _i]

@@ -51,6 +51,29 @@ def dot(a, b):
 
 
 # ----------------------------------------------------------------------------- Linear (+ mask, optional ReLU)
+def _linear_adjoint(x, W, dy, nvalid, K, has_b, want_dx):
+    dx = None
+    if want_dx:
+        wt = torch.empty(W.shape[1], W.shape[0], dtype=torch.float32, device=W.device).copy_(W.detach().t())
+        plt = ops.PackedLinear(ops.pack_weight(wt), wt.shape[0], wt.shape[1], None)
+        dx = ops.masked_linear(dy, plt, nvalid, K, use_bias=False).view(x.shape)
+    dW, db = linear_wgrad(x, dy, nvalid, K, has_b)
+    return dx, dW, db
+
+
+def _bn_act_adjoint(z, dy, mean, rstd, scale, shift, count, nvalid, K, relu):
+    Cc = z.shape[-1]
+    R = z.numel() // Cc
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z)
+    scratch = torch.empty(int(lib().sn_bn_act_bwd_scratch_floats(R, Cc)), dtype=torch.float32, device=z.device)
+    with ops._span("sn_bn_act_bwd_f32"):
+        check(lib().sn_bn_act_bwd_f32(ptr(z), Cc, ptr(dy), Cc, R, Cc, ptr(nvalid), int(K), ptr(mean), ptr(rstd), ptr(scale),
+                                      ptr(shift), int(relu), ptr(count), ptr(sums), ptr(dz), Cc, ptr(scratch), stream()),
+              "sn_bn_act_bwd_f32")
+    return dz, sums
+
+
 class _Linear(Function):
     @staticmethod
     def forward(ctx, x, W, b, nvalid, K, relu):
@@ -68,12 +91,7 @@ class _Linear(Function):
         dy = _c(dy)
         if relu:
             dy = relu_bwd(y, dy, nvalid, K)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            wt = torch.empty(W.shape[1], W.shape[0], dtype=torch.float32, device=W.device).copy_(W.detach().t())
-            plt = ops.PackedLinear(ops.pack_weight(wt), wt.shape[0], wt.shape[1], None)
-            dx = ops.masked_linear(dy, plt, nvalid, K, use_bias=False).view(x.shape)
-        dW, db = linear_wgrad(x, dy, nvalid, K, has_b)
+        dx, dW, db = _linear_adjoint(x, W, dy, nvalid, K, has_b, ctx.needs_input_grad[0])
         return dx, dW, db, None, None, None
 
 
@@ -102,18 +120,46 @@ class _BnAct(Function):
         nvalid, K, relu, affine, has_res = ctx.meta
         dy = _c(dy)
         Cc = z.shape[-1]
-        R = z.numel() // Cc
-        sums = torch.empty(2 * Cc, dtype=torch.float32, device=z.device)
-        dz = torch.empty_like(z)
-        scratch = torch.empty(int(lib().sn_bn_act_bwd_scratch_floats(R, Cc)), dtype=torch.float32, device=z.device)
-        with ops._span("sn_bn_act_bwd_f32"):
-            check(lib().sn_bn_act_bwd_f32(ptr(z), Cc, ptr(dy), Cc, R, Cc, ptr(nvalid), int(K), ptr(mean), ptr(rstd), ptr(scale),
-                                          ptr(shift), int(relu), ptr(count), ptr(sums), ptr(dz), Cc, ptr(scratch), stream()),
-                  "sn_bn_act_bwd_f32")
+        dz, sums = _bn_act_adjoint(z, dy, mean, rstd, scale, shift, count, nvalid, K, relu)
         dres = None
         if has_res:
             dres = dy if nvalid is None else ops.masked_affine(dy, nvalid, K)      # the output is 0 on invalid rows
         return dz, sums[Cc:] if affine else None, sums[:Cc] if affine else None, dres, None, None, None, None
+
+
+class _LinearBnAct(Function):
+    """[relu](BatchNorm1d_train(x @ W^T + b)) [+ residual] — the composition of _Linear and _BnAct with the Linear and the batch
+    statistics in ONE forward launch (sn_linear_bn_train_f32); the backward is the two adjoints back to back."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, residual, bn, nvalid, K, relu):
+        x = _c(x)
+        pl = ops.PackedLinear(ops.pack_weight(W.detach()), W.shape[0], W.shape[1], None if b is None else _c(b.detach()))
+        z, mean, _, rstd, scale, shift, count = ops.linear_bn_train(x, pl, bn, nvalid, K)
+        res = None if residual is None else _c(residual)
+        y = ops.masked_affine(z, nvalid, K, scale=scale, shift=shift, relu=relu, residual=res)
+        ctx.save_for_backward(x, W, z, mean, rstd, scale, shift, count)
+        ctx.meta = (nvalid, K, relu, b is not None, gamma is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, z, mean, rstd, scale, shift, count = ctx.saved_tensors
+        nvalid, K, relu, has_b, affine, has_res = ctx.meta
+        dy = _c(dy)
+        Cc = z.shape[-1]
+        dz, sums = _bn_act_adjoint(z, dy, mean, rstd, scale, shift, count, nvalid, K, relu)
+        dx, dW, db = _linear_adjoint(x, W, dz, nvalid, K, has_b, ctx.needs_input_grad[0])
+        dres = None
+        if has_res:
+            dres = dy if nvalid is None else ops.masked_affine(dy, nvalid, K)      # the output is 0 on invalid rows
+        return dx, dW, db, sums[Cc:] if affine else None, sums[:Cc] if affine else None, dres, None, None, None, None
+
+
+def linear_bn_act(x, W, b, bn, nvalid=None, K=0, relu=True, residual=None):
+    if W.stride(-1) != 1 or (W.shape[0] > 1 and W.stride(0) < W.shape[1]):
+        W = W.contiguous()
+    return _LinearBnAct.apply(x, W, b, bn.weight, bn.bias, residual, bn, nvalid, K, relu)
 
 
 def bn_act(z, bn, nvalid=None, K=0, relu=True, residual=None):

@@ -104,6 +104,15 @@ struct LinArgs {
   float* y; int ldy;
 };
 
+// sum over the 16 lanes of a DPP row (the 16 rows of a tile for one lane group): four VALU+DPP steps
+__device__ __forceinline__ float tile16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));   // row_mirror
+  return v;
+}
+
 template <bool VEC>
 __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, int c0, int C) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -203,6 +212,219 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
       if (a.flags & SN_EPI_RESIDUAL) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
     }
     if (inr) store4<YV>(yr, o0, a.d_out, v);
+  }
+}
+
+// Large row counts: the packed weight is staged ONCE per workgroup in LDS (k_linear fetches it from L2 per wave and per output
+// tile: at 47 k rows x 128 x 128 the fp32 matrix pipe was a third busy) and every wave walks a grid-stride sequence of 16-row tiles
+// with the whole tile's operand in registers; two output tiles are accumulated at a time (two independent MFMA chains).  The
+// products, their order and the epilogue are those of k_linear: results are bit-identical.  Vector path only (XV && YV), nti <= NTI.
+// STATS: per-workgroup column moments (count, mean, M2) of the OUTPUT rows the workgroup produced, for the train-mode BatchNorm that
+// follows a Linear (k_bn_train_finish1 merges them): the separate pass over z disappears.  stat: [nblk][C] means, [nblk][C] M2, [nblk]
+// counts.
+constexpr int LIN_W = 8;      // waves per workgroup of k_linear_lds (one workgroup per CU: two waves per SIMD)
+template <int NTI, int NTO, bool STATS>
+__global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t ntiles, float* __restrict__ stat) {
+  extern __shared__ __align__(16) unsigned char lin_lds[];
+  float4* wl = reinterpret_cast<float4*>(lin_lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nw4 = a.nto * a.nti * 64;
+  const int g = lane >> 4;
+  // a contiguous, balanced range of tiles per workgroup, dealt round-robin to its waves (waves w and w + 4 share a SIMD)
+  const int64_t t_lo = ntiles * blockIdx.x / gridDim.x, t_hi = ntiles * (blockIdx.x + 1) / gridDim.x;
+  const int64_t gw = t_lo + wave, nwv = LIN_W;
+  ntiles = t_hi;
+  // running moments of this wave's rows (STATS): every lane keeps the statistics of its own 4 columns per output tile
+  float rn = 0.f;
+  f32x4 rmean[STATS ? NTO : 1], rm2[STATS ? NTO : 1];
+  if (STATS) {
+#pragma unroll
+    for (int ot = 0; ot < NTO; ++ot) { rmean[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; rm2[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  // the next tile's operand rows are fetched while the current tile is in the matrix pipe (register double buffer)
+  auto row_valid = [&](int64_t row) {
+    bool v = row < a.R;
+    if (v && a.nvalid) {
+      const int64_t node = row / a.K;
+      v = (int)(row - node * a.K) < a.nvalid[node];
+    }
+    return v;
+  };
+  auto fetch = [&](int64_t tile, bool v, f32x4 (&buf)[NTI]) {
+    const float* xr = a.x + (tile * 16 + (lane & 15)) * a.ldx;
+#pragma unroll
+    for (int kk = 0; kk < NTI; ++kk) {
+      buf[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kk < a.nti && v) buf[kk] = load4<true>(xr, 16 * kk + 4 * g, a.d_in);
+    }
+  };
+  constexpr bool PF = !(STATS && NTI > 8);     // (the 256-channel operand, its copy and the moments do not fit together)
+  f32x4 in[NTI], nx[PF ? NTI : 1];
+  bool valid = false, nvalid_next = false;
+  if (gw < ntiles) {                      // the first tile's rows are on their way while the weight is staged
+    valid = row_valid(gw * 16 + (lane & 15));
+    fetch(gw, valid, in);
+  }
+#ifndef SN_EXP_LIN_NOSTAGE
+  for (int i = threadIdx.x; i < nw4; i += 64 * LIN_W) wl[i] = a.wp[i];
+#endif
+  __syncthreads();
+  for (int64_t tile = gw; tile < ntiles; tile += nwv) {
+    const int64_t row = tile * 16 + (lane & 15);
+    const bool inr = row < a.R;
+    const bool more = tile + nwv < ntiles;
+    if (more) {
+      nvalid_next = row_valid((tile + nwv) * 16 + (lane & 15));
+      if constexpr (PF) fetch(tile + nwv, nvalid_next, nx);
+    }
+    float* yr = a.y + row * a.ldy;
+    const unsigned long long vb = __ballot(valid);
+    if (vb == 0ull) {  // nothing valid in this tile: zeros
+      if (inr) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (int ot = 0; ot < a.nto; ++ot) store4<true>(yr, 16 * ot + 4 * g, a.d_out, z);
+      }
+      if (more) {
+        if constexpr (PF) {
+#pragma unroll
+          for (int kk = 0; kk < NTI; ++kk) in[kk] = nx[kk];
+        } else {
+          fetch(tile + nwv, nvalid_next, in);
+        }
+        valid = nvalid_next;
+      }
+      continue;
+    }
+    const float nt = (float)__popcll(vb & 0xffffull);                  // valid rows of the tile (STATS)
+    float inv_nt = 0.f, wa = 0.f, wb = 0.f;
+    if (STATS) {
+      const float n = rn + nt;
+      inv_nt = 1.0f / nt;                                              // nt >= 1 here
+      wb = nt / n;                                                     // Chan's update: mean += d * nb/n, M2 += M2b + d^2 * na*nb/n
+      wa = rn * wb;
+    }
+    auto epilogue = [&](int ot, f32x4 acc) {
+      const int o0 = 16 * ot + 4 * g;
+      f32x4 v = acc;
+      if (!valid) {
+        v = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        if (a.flags & SN_EPI_BIAS) v += load4<true>(a.bias, o0, a.d_out);
+        if (a.flags & SN_EPI_RELU_PRE) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        if (a.flags & SN_EPI_AFFINE) {
+          const f32x4 sc = load4<true>(a.scale, o0, a.d_out), sh = load4<true>(a.shift, o0, a.d_out);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+        }
+        if (a.flags & SN_EPI_RELU) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        if (a.flags & SN_EPI_RESIDUAL) v += load4<true>(a.res + row * a.ldr, o0, a.d_out);
+      }
+#ifdef SN_EXP_LIN_NOSTORE
+      if (inr && v[0] == 1.2345f) store4<true>(yr, o0, a.d_out, v);
+#else
+      if (inr) store4<true>(yr, o0, a.d_out, v);
+#endif
+      if (STATS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mt = tile16_sum(v[r]) * inv_nt;                  // tile mean of the column (invalid rows hold 0)
+          const float d = valid ? v[r] - mt : 0.f;
+          const float qt = tile16_sum(d * d);
+          const float dm = mt - rmean[ot][r];
+          rmean[ot][r] += dm * wb;
+          rm2[ot][r] += qt + dm * dm * wa;
+        }
+      }
+    };
+#pragma unroll
+    for (int ot = 0; ot < NTO; ot += 2) {          // fully unrolled (compile-time register indices); guards are wave-uniform
+      if (ot + 1 < a.nto) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const float4* w0 = wl + (ot * a.nti) * 64 + lane;
+        const float4* w1 = w0 + a.nti * 64;
+#pragma unroll
+        for (int kk = 0; kk < NTI; ++kk) {
+          if (kk < a.nti) {
+            const float4 p = w0[kk * 64], q = w1[kk * 64];
+            acc0 = mfma16(p.x, in[kk][0], acc0);
+            acc1 = mfma16(q.x, in[kk][0], acc1);
+            acc0 = mfma16(p.y, in[kk][1], acc0);
+            acc1 = mfma16(q.y, in[kk][1], acc1);
+            acc0 = mfma16(p.z, in[kk][2], acc0);
+            acc1 = mfma16(q.z, in[kk][2], acc1);
+            acc0 = mfma16(p.w, in[kk][3], acc0);
+            acc1 = mfma16(q.w, in[kk][3], acc1);
+          }
+        }
+        epilogue(ot, acc0);
+        epilogue(ot + 1, acc1);
+      } else if (ot < a.nto) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+        const float4* w0 = wl + (ot * a.nti) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < NTI; ++kk) {
+          if (kk < a.nti) {
+            const float4 p = w0[kk * 64];
+            acc0 = mfma16(p.x, in[kk][0], acc0);
+            acc0 = mfma16(p.y, in[kk][1], acc0);
+            acc0 = mfma16(p.z, in[kk][2], acc0);
+            acc0 = mfma16(p.w, in[kk][3], acc0);
+          }
+        }
+        epilogue(ot, acc0);
+      }
+    }
+    if (STATS) rn += nt;
+    if (more) {
+      if constexpr (PF) {
+#pragma unroll
+        for (int kk = 0; kk < NTI; ++kk) in[kk] = nx[kk];
+      } else {
+        fetch(tile + nwv, nvalid_next, in);
+      }
+      valid = nvalid_next;
+    }
+  }
+  if (STATS) {
+    // one partial per WORKGROUP: the waves' moments meet in LDS (the weight image is dead by now) and are merged in wave order
+    __syncthreads();
+    float* sm = reinterpret_cast<float*>(lin_lds);          // [LIN_W waves][mean 16*NTO | M2 16*NTO], counts behind
+    float* sc = sm + LIN_W * 2 * 16 * NTO;
+    if ((lane & 15) == 0) {
+#pragma unroll
+      for (int ot = 0; ot < NTO; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sm[(wave * 2 + 0) * 16 * NTO + 16 * ot + 4 * g + r] = rmean[ot][r];
+          sm[(wave * 2 + 1) * 16 * NTO + 16 * ot + 4 * g + r] = rm2[ot][r];
+        }
+      }
+    }
+    if (lane == 0) sc[wave] = rn;
+    __syncthreads();
+    const int nblk = gridDim.x;
+    for (int c = threadIdx.x; c < a.d_out; c += 64 * LIN_W) {
+      float n = 0.f, m = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < LIN_W; ++w) {
+        const float nb = sc[w];
+        if (nb > 0.f) {
+          const float mb = sm[(w * 2 + 0) * 16 * NTO + c], qb = sm[(w * 2 + 1) * 16 * NTO + c];
+          const float nn = n + nb, d = mb - m;
+          m += d * (nb / nn);
+          q += qb + d * d * (n * nb / nn);
+          n = nn;
+        }
+      }
+      stat[(int64_t)blockIdx.x * a.d_out + c] = m;
+      stat[((int64_t)nblk + blockIdx.x) * a.d_out + c] = q;
+    }
+    if (threadIdx.x == 0) {
+      float n = 0.f;
+#pragma unroll
+      for (int w = 0; w < LIN_W; ++w) n += sc[w];       // integers < 2^24: exact in any order
+      stat[2 * (int64_t)nblk * a.d_out + blockIdx.x] = n;
+    }
   }
 }
 
@@ -466,22 +688,24 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, floa
 // merges the per-block moments (16 lanes per column, then a tree across the lanes) and finishes the BatchNorm: mean, biased variance,
 // rstd, folded (scale, shift), count, running statistics.  grid cdiv(C, 16), 256 threads = 16 columns x 16 lanes.  (With 4 lanes per
 // column the merge of the 1024 partial blocks of a million-row input — the LearningFilters epochs — was an 88 us serial chain.)
+template <int LP>   // lanes per column: 16 (few partials) or 64 (the thousands of per-wave partials of k_linear_lds)
 __global__ __launch_bounds__(256) void k_bn_train_finish1(const float* __restrict__ pmean, const float* __restrict__ pm2,
                                                           const float* __restrict__ pcnt, int nblk, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float momentum, float* __restrict__ mean, float* __restrict__ var,
                                                           float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift,
                                                           float* __restrict__ count, float* __restrict__ rmean, float* __restrict__ rvar) {
-  __shared__ float ln[16][17], lm[16][17], lq[16][17];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  const int per = (nblk + 15) / 16, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  constexpr int COLS = 256 / LP;
+  __shared__ float ln[LP][COLS + 1], lm[LP][COLS + 1], lq[LP][COLS + 1];
+  const int cl = threadIdx.x % COLS, rl = threadIdx.x / COLS;
+  const int c = blockIdx.x * COLS + cl;
+  const int per = (nblk + LP - 1) / LP, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   float n = 0.f, m = 0.f, q = 0.f;
   if (c < C)
     for (int b = b0; b < b1; ++b) chan_merge(n, m, q, pcnt[b], pmean[(int64_t)b * C + c], pm2[(int64_t)b * C + c]);
   ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
   __syncthreads();
-  for (int step = 8; step >= 1; step >>= 1) {          // pairwise tree in a fixed order
+  for (int step = LP / 2; step >= 1; step >>= 1) {     // pairwise tree in a fixed order
     if (rl < step) {
       chan_merge(n, m, q, ln[rl + step][cl], lm[rl + step][cl], lq[rl + step][cl]);
       ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
@@ -781,6 +1005,60 @@ extern "C" int sn_bn_running_update_f32(const float* mean, const float* var, con
   return SN_OK;
 }
 
+// the LDS-resident-weight form also shortens the latency chain of small launches (128 rows: 26 -> 12 us); below two row tiles the
+// per-wave kernel has less to stage
+constexpr int64_t LIN_LDS_MIN_ROWS = 32;
+static int lin_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  return cus;
+}
+// workgroups (= moment partials with STATS) a k_linear_lds launch over R rows uses; 0: the shape does not take that path
+static int64_t lin_lds_blocks(int64_t R, int d_in, int d_out) {
+  const int nti = (int)cdiv(d_in, 16), nto = (int)cdiv(d_out, 16);
+  if (nti > 16 || nto > 16 || (size_t)nti * nto * 1024 > 128 * 1024) return 0;
+  const int64_t ntiles = cdiv(R, 16), want = cdiv(ntiles, 4), cap = lin_cus();     // small inputs: one tile per SIMD, spread over the CUs
+  return want < cap ? want : cap;
+}
+template <int NTI, int NTO>
+static int launch_linear_lds_t(const LinArgs& a, float* stat, int64_t blocks, size_t lds, hipStream_t st) {
+  constexpr bool CAN_STAT = NTO <= 8;        // the moments of 16 output tiles do not fit the register file beside the operand
+  const void* fn = reinterpret_cast<const void*>(k_linear_lds<NTI, NTO, false>);
+  if constexpr (CAN_STAT) { if (stat) fn = reinterpret_cast<const void*>(k_linear_lds<NTI, NTO, true>); }
+  else if (stat) return fail(SN_ERR_ARG, "linear + statistics: d_out > 128");
+  static bool raised[2] = {false, false};
+  if (lds > 64 * 1024 && !raised[stat ? 1 : 0]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return fail(SN_ERR_LAUNCH, "sn_masked_linear_f32: cannot raise the dynamic LDS limit");
+    raised[stat ? 1 : 0] = true;
+  }
+  const int64_t ntiles = cdiv(a.R, 16);
+  if constexpr (CAN_STAT) {
+    if (stat) {
+      hipLaunchKernelGGL((k_linear_lds<NTI, NTO, true>), dim3((unsigned)blocks), dim3(64 * LIN_W), lds, st, a, ntiles, stat);
+      return SN_OK;
+    }
+  }
+  hipLaunchKernelGGL((k_linear_lds<NTI, NTO, false>), dim3((unsigned)blocks), dim3(64 * LIN_W), lds, st, a, ntiles, stat);
+  return SN_OK;
+}
+// returns 1 when the shape does not take the LDS path (caller falls back), SN_OK / an error otherwise
+static int launch_linear_lds(const LinArgs& a, float* stat, hipStream_t st) {
+  const int64_t blocks = lin_lds_blocks(a.R, a.d_in, a.d_out);
+  if (blocks == 0) return 1;
+  size_t lds = (size_t)a.nti * a.nto * 1024;
+  const size_t xch = (size_t)(LIN_W * 2 * 16 * 8 + LIN_W) * sizeof(float);                      // the workgroup's moment exchange
+  if (stat && lds < xch) lds = xch;
+  if (a.nti <= 8 && a.nto <= 8) return launch_linear_lds_t<8, 8>(a, stat, blocks, lds, st);
+  if (a.nti <= 16 && a.nto <= 8) return launch_linear_lds_t<16, 8>(a, stat, blocks, lds, st);
+  if (a.nti <= 8) return launch_linear_lds_t<8, 16>(a, stat, blocks, lds, st);
+  return launch_linear_lds_t<16, 16>(a, stat, blocks, lds, st);
+}
+
 extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
                                     const float* bias, const int32_t* nvalid, int K, int flags,
                                     const float* scale, const float* shift, const float* residual, int ldr,
@@ -800,6 +1078,10 @@ extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in
                   (!shift || al16(shift)) && (!residual || (al16(residual) && ldr % 4 == 0));
   dim3 grid((unsigned)cdiv(R, 64)), block(256);
   hipStream_t st = (hipStream_t)stream;
+  if (xv && yv && R >= LIN_LDS_MIN_ROWS) {
+    const int rc = launch_linear_lds(a, nullptr, st);
+    if (rc != 1) { if (rc != SN_OK) return rc; SN_CHECK_LAUNCH("sn_masked_linear_f32"); return SN_OK; }
+  }
   if (xv && yv) hipLaunchKernelGGL((k_linear<true, true>), grid, block, 0, st, a);
   else if (xv) hipLaunchKernelGGL((k_linear<true, false>), grid, block, 0, st, a);
   else if (yv) hipLaunchKernelGGL((k_linear<false, true>), grid, block, 0, st, a);
@@ -912,6 +1194,17 @@ extern "C" int sn_masked_colstats_f32(const float* x, int ldx, int64_t R, int C,
   return SN_OK;
 }
 
+static void launch_bn_finish(const float* pmean, const float* pm2, const float* pcnt, int nblk, int C, const float* gamma, const float* beta,
+                             float eps, float momentum, float* mean, float* var, float* rstd, float* scale, float* shift, float* count,
+                             float* running_mean, float* running_var, hipStream_t st) {
+  if (nblk > 256)
+    hipLaunchKernelGGL(k_bn_train_finish1<64>, dim3((unsigned)cdiv(C, 4)), dim3(256), 0, st, pmean, pm2, pcnt, nblk, C, gamma, beta, eps,
+                       momentum, mean, var, rstd, scale, shift, count, running_mean, running_var);
+  else
+    hipLaunchKernelGGL(k_bn_train_finish1<16>, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, pmean, pm2, pcnt, nblk, C, gamma, beta, eps,
+                       momentum, mean, var, rstd, scale, shift, count, running_mean, running_var);
+}
+
 extern "C" int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, const int32_t* nvalid, int K, const float* gamma,
                                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                      float* mean, float* var, float* rstd, float* scale, float* shift, float* count,
@@ -930,10 +1223,48 @@ extern "C" int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, 
   float* pm2 = scratch + (int64_t)nblk * C;
   float* pcnt = scratch + (int64_t)2 * nblk * C;
   hipLaunchKernelGGL(k_colstats_moments, dim3(nblk), dim3(256), 0, st, x, ldx, R, C, nvalid, K, rpb, pmean, pm2, pcnt);
-  hipLaunchKernelGGL(k_bn_train_finish1, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, st, (const float*)pmean, (const float*)pm2,
-                     (const float*)pcnt, nblk, C, gamma, beta, eps, momentum, mean, var, rstd, scale, shift, count, running_mean,
-                     running_var);
+  launch_bn_finish(pmean, pm2, pcnt, nblk, C, gamma, beta, eps, momentum, mean, var, rstd, scale, shift, count, running_mean, running_var, st);
   SN_CHECK_LAUNCH("sn_bn_train_stats_f32");
+  return SN_OK;
+}
+
+extern "C" int64_t sn_linear_bn_scratch_floats(int64_t R, int d_in, int d_out) {
+  const int64_t a = (int64_t)sn_colstats_blocks(R) * (d_out + 1);
+  const int64_t w = (d_out <= 128) ? lin_lds_blocks(R, d_in, d_out) : 0;
+  const int64_t b = w * (2 * (int64_t)d_out + 1);
+  return a > b ? a : b;
+}
+
+extern "C" int sn_linear_bn_train_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out, const float* bias,
+                                      const int32_t* nvalid, int K, float* z, int ldz, const float* gamma, const float* beta, float eps,
+                                      float momentum, float* running_mean, float* running_var, float* mean, float* var, float* rstd,
+                                      float* scale, float* shift, float* count, float* scratch, void* stream) {
+  SN_REQUIRE(x && Wp && z && mean && var && rstd && scale && shift && count && scratch && R >= 0 && d_in > 0 && d_out > 0,
+             "sn_linear_bn_train_f32: bad arguments");
+  SN_REQUIRE(ldx >= d_in && ldz >= d_out, "sn_linear_bn_train_f32: leading dimension too small");
+  SN_REQUIRE(!nvalid || K > 0, "sn_linear_bn_train_f32: nvalid needs K > 0");
+  SN_REQUIRE((running_mean != nullptr) == (running_var != nullptr), "sn_linear_bn_train_f32: running_mean / running_var go together");
+  SN_REQUIRE(al16(Wp), "sn_linear_bn_train_f32: Wp must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (d_in % 4 == 0) && (ldx % 4 == 0) && al16(x) && (d_out % 4 == 0) && (ldz % 4 == 0) && al16(z) && (!bias || al16(bias));
+  const int64_t nblk = (vec && d_out <= 128 && R >= LIN_LDS_MIN_ROWS) ? lin_lds_blocks(R, d_in, d_out) : 0;
+  if (nblk == 0) {     // small / unaligned / wide: the Linear, then the one-pass statistics
+    const int rc = sn_masked_linear_f32(x, ldx, R, d_in, Wp, d_out, bias, nvalid, K, bias ? SN_EPI_BIAS : 0, nullptr, nullptr, nullptr, 0, z,
+                                        ldz, stream);
+    if (rc != SN_OK) return rc;
+    return sn_bn_train_stats_f32(z, ldz, R, d_out, nvalid, K, gamma, beta, eps, momentum, running_mean, running_var, mean, var, rstd, scale,
+                                 shift, count, scratch, stream);
+  }
+  LinArgs a{x, ldx, R, d_in, reinterpret_cast<const float4*>(Wp), (int)cdiv(d_in, 16), d_out, (int)cdiv(d_out, 16),
+            bias, nvalid, K, bias ? SN_EPI_BIAS : 0, nullptr, nullptr, nullptr, 0, z, ldz};
+  const int rc = launch_linear_lds(a, scratch, st);
+  if (rc != SN_OK) return rc == 1 ? fail(SN_ERR_LAUNCH, "sn_linear_bn_train_f32: internal path selection") : rc;
+  const float* pmean = scratch;
+  const float* pm2 = scratch + nblk * d_out;
+  const float* pcnt = scratch + 2 * nblk * d_out;
+  launch_bn_finish(pmean, pm2, pcnt, (int)nblk, d_out, gamma, beta, eps, momentum, mean, var, rstd, scale, shift, count, running_mean,
+                   running_var, st);
+  SN_CHECK_LAUNCH("sn_linear_bn_train_f32");
   return SN_OK;
 }
 

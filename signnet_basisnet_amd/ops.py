@@ -397,6 +397,37 @@ def bn_train_stats(x, bn, nvalid=None, K=0):
     return mean, var, rstd, scale, shift, count
 
 
+def linear_bn_train(x, pl: PackedLinear, bn, nvalid=None, K=0):
+    """z = x @ W^T + b (masked) and the train-mode BatchNorm1d statistics of z in one C call (sn_linear_bn_train_f32): for large row
+    counts the moments come out of the Linear kernel's accumulators.  -> (z, mean, var, rstd, scale, shift, count); updates bn's
+    running statistics like bn_train_stats."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    if x.shape[-1] != pl.d_in:
+        raise ValueError(f"linear_bn_train: x has {x.shape[-1]} channels, weight expects {pl.d_in}")
+    R = x.numel() // pl.d_in
+    Cc = pl.d_out
+    z = torch.empty(*x.shape[:-1], Cc, dtype=torch.float32, device=x.device)
+    out = torch.empty(5 * Cc + 1, dtype=torch.float32, device=x.device)
+    mean, var, rstd, scale, shift = (out[i * Cc:(i + 1) * Cc] for i in range(5))
+    count = out[5 * Cc:]
+    scratch = torch.empty(max(int(lib().sn_linear_bn_scratch_floats(R, pl.d_in, Cc)), 1), dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    if track and bn.momentum is None:
+        raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not supported")
+    g = None if bn.weight is None else bn.weight.detach()
+    b = None if bn.bias is None else bn.bias.detach()
+    with _span("sn_linear_bn_train_f32"):
+        check(lib().sn_linear_bn_train_f32(ptr(x), pl.d_in, R, pl.d_in, ptr(pl.wp), Cc, ptr(pl.bias), ptr(nvalid), int(K), ptr(z), Cc,
+                                           ptr(g), ptr(b), float(bn.eps), float(bn.momentum or 0.0),
+                                           ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None, ptr(mean),
+                                           ptr(var), ptr(rstd), ptr(scale), ptr(shift), ptr(count), ptr(scratch), stream()),
+              "sn_linear_bn_train_f32")
+    if track:
+        bn.num_batches_tracked += 1
+    return z, mean, var, rstd, scale, shift, count
+
+
 def masked_affine(x, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False, residual=None):
     require_cuda(x)
     x = _f32c(x, "x")

@@ -550,7 +550,7 @@ class SignNetGNN(nn.Module):
                 y = AG.linear(x, lin.weight, lin.bias, nvalid, K_, relu=relu)
                 return y if residual is None else AG.masked_add(y, residual, nvalid, K_)
             bn = norm.bn if isinstance(norm, MaskedBN) else norm
-            return AG.bn_act(AG.linear(x, lin.weight, lin.bias, nvalid, K_), bn, nvalid, K_, relu=relu, residual=residual)
+            return AG.linear_bn_act(x, lin.weight, lin.bias, bn, nvalid, K_, relu=relu, residual=residual)
 
         if self.variant != "alchemy":      # computed and discarded by the reference (core/sign_net.py:111-112): side effects only
             with torch.no_grad():

@@ -6,6 +6,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from signnet_basisnet_amd import synth  # noqa: E402
+from parity_util import close  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -157,6 +158,80 @@ def test_masked_linear(batch, dev, d_in, d_out):
     y32 = F.linear(x, W)
     yk = ops.masked_linear(x.to(dev), pl, use_bias=False).cpu()
     assert (yk - y32).abs().max() <= 1e-5 * max(1.0, y32.abs().max().item())
+
+
+@pytest.mark.parametrize("d_in,d_out", [(128, 128), (64, 128), (256, 96), (128, 256), (200, 44)])
+def test_masked_linear_lds_resident_weight_path_is_bit_identical(dev, d_in, d_out):
+    """From 32 rows on sn_masked_linear_f32 stages the packed weight once per workgroup in LDS (k_linear_lds): the same products in
+    the same order as the per-wave kernel — the first rows of a long input equal, bit for bit, the result of a short launch over
+    those rows alone (which takes the other kernel) — with and without the full epilogue and the slot mask; and against float64."""
+    from signnet_basisnet_amd import ops
+    K, N = 16, 700                                    # 11200 rows; the short launch takes rows [0, 16)
+    g = torch.Generator().manual_seed(d_in + 7 * d_out)
+    x = torch.randn(N, K, d_in, generator=g)
+    W, b = torch.randn(d_out, d_in, generator=g) / d_in ** 0.5, torch.randn(d_out, generator=g)
+    sc, sh = torch.rand(d_out, generator=g) + 0.5, torch.randn(d_out, generator=g)
+    res = torch.randn(N, K, d_out, generator=g)
+    nv = torch.randint(0, K + 1, (N,), generator=g)
+    nv[4:8] = 0                                       # a whole 64-row block without a valid row
+    nv[0] = 7
+    pl = ops.PackedLinear(ops.pack_weight(W.to(dev)), d_out, d_in, b.to(dev))
+    xd, nvd, resd = x.to(dev), nv.to(dev).int(), res.to(dev)
+    n0 = 1
+    for kw in (dict(use_bias=False), dict(nvalid=nvd, K=K, scale=sc.to(dev), shift=sh.to(dev), relu=True, residual=resd),
+               dict(nvalid=nvd, K=K)):
+        kw_short = dict(kw)
+        if "nvalid" in kw:
+            kw_short["nvalid"] = nvd[:n0].contiguous()
+        if "residual" in kw:
+            kw_short["residual"] = resd[:n0].contiguous()
+        full = ops.masked_linear(xd, pl, **kw)
+        short = ops.masked_linear(xd[:n0].contiguous(), pl, **kw_short)
+        assert torch.equal(full[:n0], short), kw.keys()
+    mask = (torch.arange(K)[None, :] < nv[:, None]).unsqueeze(-1)
+    y = ops.masked_linear(xd, pl, nvd, K, scale=sc.to(dev), shift=sh.to(dev), relu=True, residual=resd)
+    ref = (torch.relu((x.double() @ W.double().T + b.double()) * sc.double() + sh.double()) + res.double()) * mask
+    torch.testing.assert_close(y.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,K,d_in,d_out,masked", [(3000, 16, 128, 128, True), (800, 8, 64, 96, True), (5000, 1, 128, 128, False),
+                                                     (300, 16, 256, 128, True), (40, 16, 128, 128, True), (600, 16, 128, 200, True),
+                                                     (700, 8, 1, 64, True), (90, 9, 12, 12, True), (1, 16, 128, 128, True),
+                                                     (2, 8, 16, 4, False)])
+def test_linear_bn_train_one_pass(dev, N, K, d_in, d_out, masked):
+    """sn_linear_bn_train_f32 (Linear + train-mode BatchNorm statistics from the Linear's accumulators): z equals sn_masked_linear_f32
+    bit for bit; mean / var / count / folded scale, shift and the running statistics agree with sn_bn_train_stats_f32 on z and with
+    float64 moments of the valid rows."""
+    from signnet_basisnet_amd import ops
+    g = torch.Generator().manual_seed(N + d_in)
+    x = torch.randn(N, K, d_in, generator=g) * 1.5 + 0.3
+    W, b = torch.randn(d_out, d_in, generator=g) / d_in ** 0.5, torch.randn(d_out, generator=g) * 3
+    nv = torch.randint(0, K + 1, (N,), generator=g) if masked else None
+    nvd = None if nv is None else nv.to(dev).int()
+    pl = ops.PackedLinear(ops.pack_weight(W.to(dev)), d_out, d_in, b.to(dev))
+    bn1, bn2 = (torch.nn.BatchNorm1d(d_out).to(dev).train() for _ in range(2))
+    with torch.no_grad():
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.rand(d_out, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(d_out, generator=torch.Generator().manual_seed(2)))
+    z, mean, var, rstd, scale, shift, count = ops.linear_bn_train(x.to(dev), pl, bn1, nvd, K if masked else 0)
+    z_ref = ops.masked_linear(x.to(dev), pl, nvd, K if masked else 0)
+    assert torch.equal(z, z_ref)
+    m2, v2, r2, sc2, sh2, c2 = ops.bn_train_stats(z_ref, bn2, nvd, K if masked else 0)
+    assert float(count) == float(c2)
+    rows = z.cpu().double().reshape(N * K, d_out)
+    if masked:
+        rows = rows[(torch.arange(K)[None, :] < nv[:, None]).reshape(-1)]
+    assert float(count) == rows.shape[0]
+    mu, va = rows.mean(0), rows.var(0, unbiased=False)
+    close(mean, mu, "mean", rel=2e-6)
+    close(var, va, "biased variance", rel=1e-5)
+    close(rstd, 1.0 / torch.sqrt(va + bn1.eps), "rstd", rel=1e-5)
+    close(scale, sc2, "scale vs the two-call form")
+    close(shift, sh2, "shift vs the two-call form")
+    close(bn1.running_mean, bn2.running_mean, "running mean")
+    close(bn1.running_var, bn2.running_var, "running var")
+    assert int(bn1.num_batches_tracked) == 1
 
 
 def test_colstats_affine(batch, dev):
