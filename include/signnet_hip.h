@@ -93,6 +93,9 @@ int sn_pack_eig_f32(const float* eigen_vectors, const float* eigen_values, const
  * sn_packed_weight_floats(d_out, d_in) floats. */
 int64_t sn_packed_weight_floats(int d_out, int d_in);
 int sn_pack_weight_f32(const float* W, int d_out, int d_in, int ldw, float* Wp, void* stream);
+/* the same packing of W^T, read in place from the row-major [rows, cols] matrix W (the backward's dX = dY W is a Linear whose weight is
+ * the forward weight transposed: no transposed copy); Wp: sn_packed_weight_floats(cols, rows) floats. */
+int sn_pack_weight_t_f32(const float* W, int rows, int cols, int ldw, float* Wp, void* stream);
 
 /* Split-packed linear for the fused phi / rho stages, which evaluate their fp32 GEMMs on the bf16 matrix pipe:
  * every fp32 weight is split EXACTLY into three bf16 pieces (8 significand bits each) and every product x*w is

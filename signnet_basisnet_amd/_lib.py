@@ -25,6 +25,7 @@ SIGNATURES = {
     "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_pack_eig_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
     "sn_pack_weight_f32": [_p, _i, _i, _i, _p, _p],
+    "sn_pack_weight_t_f32": [_p, _i, _i, _i, _p, _p],
     "sn_pack_split_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p],
     "sn_gin_aggregate_f32": [_p, _p, _l, _i, _p, _p, _p, _i, _p],
     "sn_gin_aggregate_slab_f32": [_p, _p, _l, _i, _l, _p, _p, _p, _p, _i, _p],

@@ -54,8 +54,7 @@ def dot(a, b):
 def _linear_adjoint(x, W, dy, nvalid, K, has_b, want_dx):
     dx = None
     if want_dx:
-        wt = torch.empty(W.shape[1], W.shape[0], dtype=torch.float32, device=W.device).copy_(W.detach().t())
-        plt = ops.PackedLinear(ops.pack_weight(wt), wt.shape[0], wt.shape[1], None)
+        plt = ops.PackedLinear(ops.pack_weight_t(W.detach()), W.shape[1], W.shape[0], None)      # W^T packed in place
         dx = ops.masked_linear(dy, plt, nvalid, K, use_bias=False).view(x.shape)
     dW, db = linear_wgrad(x, dy, nvalid, K, has_b)
     return dx, dW, db

@@ -6,8 +6,9 @@
 namespace sn {
 
 // ============================================================================ weight packing
+// trans: W is the [d_in, d_out] matrix whose TRANSPOSE is packed (the input-gradient Linear dX = dY W reads the forward weight in place)
 __global__ void k_pack_weight(const float* __restrict__ W, int d_out, int d_in, int ldw, int nto, int nti,
-                              float* __restrict__ Wp) {
+                              float* __restrict__ Wp, int trans) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t total = (int64_t)nto * nti * 256;
   if (idx >= total) return;
@@ -17,7 +18,7 @@ __global__ void k_pack_weight(const float* __restrict__ W, int d_out, int d_in, 
   int kk = (int)(blk % nti), ot = (int)(blk / nti);
   int o = 16 * ot + (lane & 15);
   int k = 16 * kk + 4 * (lane >> 4) + t;
-  Wp[idx] = (o < d_out && k < d_in) ? W[(int64_t)o * ldw + k] : 0.f;
+  Wp[idx] = (o < d_out && k < d_in) ? (trans ? W[(int64_t)k * ldw + o] : W[(int64_t)o * ldw + k]) : 0.f;
 }
 
 // ============================================================================ split-packed linear (bf16 x 3 + epilogue vectors)
@@ -964,8 +965,19 @@ extern "C" int sn_pack_weight_f32(const float* W, int d_out, int d_in, int ldw, 
   int nto = (int)cdiv(d_out, 16), nti = (int)cdiv(d_in, 16);
   int64_t total = (int64_t)nto * nti * 256;
   hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, d_out,
-                     d_in, ldw, nto, nti, Wp);
+                     d_in, ldw, nto, nti, Wp, 0);
   SN_CHECK_LAUNCH("sn_pack_weight_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_pack_weight_t_f32(const float* W, int rows, int cols, int ldw, float* Wp, void* stream) {
+  SN_REQUIRE(W && Wp && rows > 0 && cols > 0 && ldw >= cols, "sn_pack_weight_t_f32: bad arguments");
+  const int d_out = cols, d_in = rows;                 // the packed matrix is W^T: [cols, rows]
+  int nto = (int)cdiv(d_out, 16), nti = (int)cdiv(d_in, 16);
+  int64_t total = (int64_t)nto * nti * 256;
+  hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, W, d_out,
+                     d_in, ldw, nto, nti, Wp, 1);
+  SN_CHECK_LAUNCH("sn_pack_weight_t_f32");
   return SN_OK;
 }
 

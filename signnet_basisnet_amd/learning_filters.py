@@ -271,8 +271,9 @@ def train_step(model, optimizer, args: FilterArgs, eig: GridEigen, x, y, m):
     mask.  Returns (loss tensor on the device, prediction)."""
     model.train()
     optimizer.zero_grad()
-    feat = get_lap_feat(args.use_eig, eig, x, args.lap_method, model)
-    pre = model(feat, None)
+    with ops.batched_bn_counters():
+        feat = get_lap_feat(args.use_eig, eig, x, args.lap_method, model)
+        pre = model(feat, None)
     loss = masked_square_loss(pre, y, m)
     loss.backward()
     optimizer.step()

@@ -241,6 +241,17 @@ def pack_weight(W: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tenso
     return out
 
 
+def pack_weight_t(W: torch.Tensor) -> torch.Tensor:
+    """Packed W^T of a [rows, cols] matrix, read in place (no transposed copy): the weight of dX = dY @ W."""
+    require_cuda(W)
+    if W.dtype != torch.float32 or W.dim() != 2 or W.stride(1) != 1:
+        raise ValueError("pack_weight_t: expected a float32 matrix with unit inner stride")
+    rows, cols = W.shape
+    out = torch.empty(packed_floats(cols, rows), dtype=torch.float32, device=W.device)
+    check(lib().sn_pack_weight_t_f32(ptr(W), rows, cols, W.stride(0), ptr(out), stream()), "sn_pack_weight_t_f32")
+    return out
+
+
 def pack_split(W: torch.Tensor, e0=None, e1=None, e2=None) -> torch.Tensor:
     """nn.Linear weight [d_out, d_in] (+ up to three per-output-channel epilogue vectors) -> the split-packed buffer
     of sn_pack_split_f32: exact 3 x bf16 significand split of every weight, fragment order of the fused phi / rho
@@ -371,6 +382,36 @@ def masked_colstats(x, nvalid=None, K=0):
     return mean, var, count
 
 
+# `num_batches_tracked += 1` is one tiny launch per BatchNorm site; a training forward touches dozens.  Inside `batched_bn_counters()`
+# the increments are collected and applied by one multi-tensor add at exit (same buffers, same values).
+_BN_PENDING = None
+
+
+def _count_batch(bn):
+    if _BN_PENDING is None:
+        bn.num_batches_tracked += 1
+    else:
+        _BN_PENDING.append(bn.num_batches_tracked)
+
+
+class batched_bn_counters:
+    def __enter__(self):
+        global _BN_PENDING
+        self._outer = _BN_PENDING
+        if self._outer is None:
+            _BN_PENDING = []
+        return self
+
+    def __exit__(self, *exc):
+        global _BN_PENDING
+        if self._outer is None:
+            pending, _BN_PENDING = _BN_PENDING, None
+            if pending:
+                with torch.no_grad():
+                    torch._foreach_add_(pending, 1)       # a tensor listed twice is incremented twice
+        return False
+
+
 def bn_train_stats(x, bn, nvalid=None, K=0):
     """Batch statistics of a train-mode BatchNorm1d over the valid rows of x, the folded (scale, shift), rstd, and the
     running-statistics side effect on `bn` — one C call (sn_bn_train_stats_f32).  -> (mean, var, rstd, scale, shift, count)."""
@@ -393,7 +434,7 @@ def bn_train_stats(x, bn, nvalid=None, K=0):
                                       ptr(bn.running_var) if track else None, ptr(mean), ptr(var), ptr(rstd), ptr(scale), ptr(shift),
                                       ptr(count), ptr(scratch), stream()), "sn_bn_train_stats_f32")
     if track:
-        bn.num_batches_tracked += 1
+        _count_batch(bn)
     return mean, var, rstd, scale, shift, count
 
 
@@ -424,7 +465,7 @@ def linear_bn_train(x, pl: PackedLinear, bn, nvalid=None, K=0):
                                            ptr(var), ptr(rstd), ptr(scale), ptr(shift), ptr(count), ptr(scratch), stream()),
               "sn_linear_bn_train_f32")
     if track:
-        bn.num_batches_tracked += 1
+        _count_batch(bn)
     return z, mean, var, rstd, scale, shift, count
 
 
@@ -736,7 +777,7 @@ def bn_running_update(bn, mean, var, count):
         raise NotImplementedError("BatchNorm1d(momentum=None) (cumulative moving average) is not supported")
     check(lib().sn_bn_running_update_f32(ptr(mean), ptr(var), ptr(count), float(bn.momentum), bn.num_features,
                                          ptr(bn.running_mean), ptr(bn.running_var), stream()), "sn_bn_running_update_f32")
-    bn.num_batches_tracked += 1
+    _count_batch(bn)
 
 
 # ----------------------------------------------------------------------------- roofline accounting (bench.py)

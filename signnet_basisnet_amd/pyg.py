@@ -492,10 +492,12 @@ class SignNetGNN(nn.Module):
             # train mode: BatchNorm with batch statistics over the valid rows and the running-statistics update, layer by
             # layer, and the attention dropout the reference leaves active (self.attn_dropout; the fixtures use 0).
             if torch.is_grad_enabled() and not return_stages and any(p.requires_grad for p in self.parameters()):
-                return self._forward_grad(data)    # differentiable: autograd.Function per layer op (csrc/backward.hip)
+                with ops.batched_bn_counters():
+                    return self._forward_grad(data)    # differentiable: autograd.Function per layer op (csrc/backward.hip)
             self._prep = None                      # parameters may have changed since the last call
             try:
-                return self._forward(data, return_stages, train=True)
+                with ops.batched_bn_counters():
+                    return self._forward(data, return_stages, train=True)
             finally:
                 self._prep = None
         if self.use_fused and not return_stages and int(data.num_graphs) > MAX_FUSED_GRAPHS:

@@ -234,6 +234,16 @@ def test_linear_bn_train_one_pass(dev, N, K, d_in, d_out, masked):
     assert int(bn1.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("rows,cols", [(128, 128), (44, 16), (7, 200), (2, 3)])
+def test_pack_weight_transposed_in_place(dev, rows, cols):
+    """sn_pack_weight_t_f32 (the backward's dX = dY W reads the forward weight in place) == sn_pack_weight_f32 of the transposed copy."""
+    from signnet_basisnet_amd import ops
+    W = torch.randn(rows, cols, generator=torch.Generator().manual_seed(rows + cols)).to(dev)
+    assert torch.equal(ops.pack_weight_t(W), ops.pack_weight(W.t().contiguous()))
+    Wv = torch.randn(rows, cols + 3, generator=torch.Generator().manual_seed(1)).to(dev)[:, :cols]      # a strided view
+    assert torch.equal(ops.pack_weight_t(Wv), ops.pack_weight(Wv.t().contiguous()))
+
+
 def test_colstats_affine(batch, dev):
     from signnet_basisnet_amd import ops
     data, d, plan = batch
