@@ -120,3 +120,81 @@ def test_basisnet_real_grid_all_multiplicity_groups():
                 y1 = net(P[j:j + 1].cuda(), mult).cpu()
             assert torch.equal(y1[0], y[j]), "projector output depends on the rest of the group"
     print(f"\nBasisNet 32x32 grid: worst max|hip - cpu32| / max|cpu32| = {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SURVEY.md §8 f3 at the SHIPPED sizes: the net_params of GraphPrediction/configs/*/*_ZINC_LapPE_signinv_GIN.json (hidden width, depth,
+# heads / towers, k, readout, pe_aggregate; sign_inv_net = GINDeepSigns with 8 layers, phi_out 4) on a 128-graph ZINC-like batch
+# (train_ZINC_graph_regression.py:20-25,77-80: sign_inv_net, then the base net).
+_COMMON = dict(num_atom_type=28, num_bond_type=4, in_feat_dropout=0.0, dropout=0.0, batch_norm=True, residual=True, edge_feat=True,
+               pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4,
+               sign_inv_net="gin", sign_inv_layers=8, sign_inv_activation="relu", phi_out_dim=4)
+SHIPPED = {
+    "gin": dict(cls="GINNet", hidden_dim=95, out_dim=95, L=16, readout="mean", pos_enc_dim=8, pe_aggregate="concat"),
+    "gatedgcn": dict(cls="GatedGCNNet", hidden_dim=68, out_dim=68, L=16, readout="mean", pos_enc_dim=8, pe_aggregate="concat"),
+    "gat": dict(cls="GATNet", hidden_dim=59, out_dim=59, L=8, n_heads=4, readout="mean", pos_enc_dim=8, pe_aggregate="concat"),
+    "pna": dict(cls="PNANet", hidden_dim=70, out_dim=70, L=16, readout="sum", pos_enc_dim=8, pe_aggregate="add", graph_norm=True,
+                aggregators="mean max min std", scalers="identity amplification attenuation", towers=5, divide_input_first=True,
+                divide_input_last=True, edge_dim=40, pretrans_layers=1, posttrans_layers=1, gru=False,
+                avg_d=dict(lin=2.2, exp=0.6, log=1.1)),
+    "transformer": dict(cls="TransformerNet", hidden_dim=64, out_dim=64, L=10, n_heads=8, readout="sum", pos_enc_dim=16,
+                        pe_aggregate="concat", full_graph=False, layer_norm=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SHIPPED))
+def test_dgl_base_nets_at_the_shipped_configs_vs_oracle_fp32_and_fp64(name):
+    from oracle import dgl_deepsigns as OD
+    from oracle import dgl_nets as ON
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets, synth
+    cfg = dict(SHIPPED[name])
+    cls = getattr(dgl_nets, cfg.pop("cls"))
+    params = dict(_COMMON, device="cuda:0", **cfg)
+    torch.manual_seed(3)
+    net = cls(params)
+    PU.bn_randomize(net, 2)
+    with torch.no_grad():                                   # GATConv's bias is zero-initialised: make it count
+        for n_, p_ in net.named_parameters():
+            if name == "gat" and n_.startswith("layers.") and n_.endswith(".bias") and n_.count(".") == 2:
+                p_.copy_(0.1 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(5)))
+    sd32 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    sd64 = PU.to_f64(sd32)
+    data = synth.make_batch(128, seed=4321)
+    k, L = cfg["pos_enc_dim"], cfg["L"]
+    pe = synth.dgl_pos_enc(data, k)
+    src, dst = data.edge_index
+    hx, ex, sizes = data.x.squeeze(-1), data.edge_attr, data.sizes
+    sn = torch.cat([torch.full((n, 1), 1.0 / n) for n in sizes]).sqrt()          # data/molecules.py:307-308 (PNA's graph_norm)
+
+    def oracle(sd, dt):
+        ssd = {kk[len("sign_inv_net."):]: v for kk, v in sd.items() if kk.startswith("sign_inv_net.")}
+        p = OD.gin_deepsigns(ssd, src, dst, pe.to(dt).unsqueeze(-1), 8, k).squeeze(-1)
+        out = {}
+        if name == "gin":
+            y = ON.gin_net(sd, src, dst, sizes, hx, p, L, "mean")
+        elif name == "gatedgcn":
+            y = ON.gatedgcn_net(sd, src, dst, sizes, hx, p, ex, L, "concat", "mean", out=out)
+        elif name == "gat":
+            y = ON.gat_net(sd, src, dst, sizes, hx, p, L, cfg["n_heads"], "mean", out=out)
+        elif name == "pna":
+            y = ON.pna_net(sd, src, dst, sizes, hx, p, ex, sn.to(dt), L, cfg["towers"], float(cfg["avg_d"]["log"]), "sum", out=out)
+        else:
+            y = ON.transformer_net(sd, src, dst, sizes, hx, p, ex, L, cfg["n_heads"], "concat", "sum", out=out)
+        return p, out.get("h_last"), y
+    with torch.no_grad():
+        p32, h32, y32 = oracle(sd32, torch.float32)
+        p64, h64, y64 = oracle(sd64, torch.float64)
+    net = net.cuda().eval()
+    g = DS.Graph(src.cuda(), dst.cuda(), sizes)
+    with torch.no_grad():
+        p = net.sign_inv_net(g, pe.unsqueeze(-1).cuda()).squeeze(-1)
+        y, _ = net(g, hx.cuda(), p, ex.cuda(), sn.cuda() if name == "pna" else None)
+    if hasattr(net, "check_last"):
+        net.check_last()
+    stages = [("sign_inv_net output", p, p32, p64), ("scores", y, y32, y64)]
+    if h32 is not None and getattr(net, "_h_last", None) is not None:
+        stages.insert(1, ("node features after the last layer", net._h_last, h32, h64))
+    for what, hip, r32, r64 in stages:
+        e = PU.close(hip, r32, f"{name}: {what}", ref64=r64)
+        print(f"\n{name}: {what}: max|hip - cpu32| / max|cpu32| = {e:.2e}, |hip - f64| {PU.relerr(hip, r64):.2e}, |cpu32 - f64| {PU.relerr(r32, r64):.2e}")
