@@ -185,7 +185,7 @@ int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, const int32
 /* A masked Linear followed by a train-mode BatchNorm1d's statistics, the pattern of every MLP layer of the reference in training
  * (GINESignNetPyG/core/model_utils/elements.py MLP: `x = norm(lin(x))`): z = x W^T + b on the valid rows (0 elsewhere), exactly as
  * sn_masked_linear_f32 with SN_EPI_BIAS, and mean / var / rstd / folded (scale, shift) / count / running statistics of z as
- * sn_bn_train_stats_f32 would return them (same values up to the summation order of the moments).  For >= 32 rows, d_out <= 128 and
+ * sn_bn_train_stats_f32 would return them (same values up to the summation order of the moments).  For >= 32 rows, d_in, d_out <= 128 and
  * 16-byte-aligned rows the column moments are taken from the accumulators of the Linear kernel (one partial per wave, Chan's
  * update): z is not read again; other shapes run the two entry points one after the other.  scratch:
  * sn_linear_bn_scratch_floats(R, d_in, d_out) floats. */

@@ -140,6 +140,10 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
     if (next_wsp && !next_tr.empty()) wload<NKB>(pre, next_wsp, next_tr.first_ot(), lane);   // idle here: keep the chain going
     return;
   }
+  // (the range is laundered per call: its decoded (output tile, row tile) pairs and every LDS address derived from them are wave
+  //  constants the compiler would otherwise compute once and keep in registers across all the Linears of the kernel — at NT = 7 they
+  //  did not fit and 28 of them lived in a private segment)
+  asm volatile("" : "+v"(tr.t_lo), "+v"(tr.t_hi), "+v"(tr.T));
   int ot0, rt0;
   tr.decode(tr.t_lo, ot0, rt0);
   int otl, rtl;

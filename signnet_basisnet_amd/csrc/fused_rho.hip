@@ -183,10 +183,14 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
     // branch-free (clamped addresses + selects): per-element branches here would turn x[] into a web of phi copies
     f32x4 x[NT];
     auto load_x = [&]() {
-      const float* xr = S.x + (valid ? ((int64_t)node * S.K + slot) : (int64_t)0) * d;
+      // (slot and g are laundered: otherwise the compiler keeps the 64-bit row / column offsets of every tile — loop-invariant lane
+      //  constants — alive across the whole bin loop, and in the 256-register multi-layer variants they were what spilled)
+      int slot_ = slot, g_ = g;
+      asm volatile("" : "+v"(slot_), "+v"(g_));
+      const float* xr = S.x + (valid ? ((int64_t)node * S.K + slot_) : (int64_t)0) * d;
 #pragma unroll
       for (int kk = 0; kk < NT; ++kk) {      // d % 4 == 0 (entry-point requirement); only the last tile can be partial
-        const int c = 16 * kk + 4 * g;
+        const int c = 16 * kk + 4 * g_;
         const bool inb = HP ? c < d : (kk + 1 < NT || c < d);
         const f32x4 v = ld4(xr + (inb ? c : 0));
         x[kk] = (valid && inb) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -376,7 +380,9 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
       if (wave_live) {
-        masked_layernorm<NT, HP>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, g, valid);
+        int gl = g;
+        asm volatile("" : "+v"(gl));      // (the lane's LDS address of the gamma / beta rows is not worth a register across the layer)
+        masked_layernorm<NT, HP>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, gl, valid);
         split_rows<NT>(x, sp);
       }
       SN_STAMP(7);
@@ -390,19 +396,25 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       SN_STAMP(14);
       wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + x[ot]; });
       SN_STAMP(9);
-      if (wave_live) masked_layernorm<NT, HP>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, g, valid);
+      if (wave_live) {
+        int gl = g;
+        asm volatile("" : "+v"(gl));
+        masked_layernorm<NT, HP>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, gl, valid);
+      }
       SN_STAMP(10);
     }
     // ---------------------------------------------------------------- sum over the node's slots -> out_sum[node, :]
     if (mfma_attn) {
       if (wave_live) {
         float* orow = S.out_sum + (int64_t)node * d;    // `node` is the same for the 16 rows of the tile
+        int g_ = g;
+        asm volatile("" : "+v"(g_));                    // (see load_x)
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) {
           f32x4 s;
 #pragma unroll
           for (int t = 0; t < 4; ++t) s[t] = tile_rowsum(valid ? x[kk][t] : 0.f);
-          const int c = 16 * kk + 4 * g;
+          const int c = 16 * kk + 4 * g_;
           if (li == 0 && unit_ok && (HP ? c < d : (kk + 1 < NT || c < d))) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
         }
       }

@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t
       if (kk < a.nti && v) buf[kk] = load4<true>(xr, 16 * kk + 4 * g, a.d_in);
     }
   };
-  constexpr bool PF = !(STATS && NTI > 8);     // (the 256-channel operand, its copy and the moments do not fit together)
+  constexpr bool PF = !STATS;                  // (the operand, its copy and the running moments do not fit in 256 registers together)
   f32x4 in[NTI], nx[PF ? NTI : 1];
   bool valid = false, nvalid_next = false;
   if (gw < ntiles) {                      // the first tile's rows are on their way while the weight is staged
@@ -1038,7 +1038,7 @@ static int64_t lin_lds_blocks(int64_t R, int d_in, int d_out) {
 }
 template <int NTI, int NTO>
 static int launch_linear_lds_t(const LinArgs& a, float* stat, int64_t blocks, size_t lds, hipStream_t st) {
-  constexpr bool CAN_STAT = NTO <= 8;        // the moments of 16 output tiles do not fit the register file beside the operand
+  constexpr bool CAN_STAT = NTO <= 8 && NTI <= 8;   // (wider shapes: the moments do not fit the register file beside the operand)
   const void* fn = reinterpret_cast<const void*>(k_linear_lds<NTI, NTO, false>);
   if constexpr (CAN_STAT) { if (stat) fn = reinterpret_cast<const void*>(k_linear_lds<NTI, NTO, true>); }
   else if (stat) return fail(SN_ERR_ARG, "linear + statistics: d_out > 128");
@@ -1242,7 +1242,7 @@ extern "C" int sn_bn_train_stats_f32(const float* x, int ldx, int64_t R, int C, 
 
 extern "C" int64_t sn_linear_bn_scratch_floats(int64_t R, int d_in, int d_out) {
   const int64_t a = (int64_t)sn_colstats_blocks(R) * (d_out + 1);
-  const int64_t w = (d_out <= 128) ? lin_lds_blocks(R, d_in, d_out) : 0;
+  const int64_t w = (d_out <= 128 && d_in <= 128) ? lin_lds_blocks(R, d_in, d_out) : 0;
   const int64_t b = w * (2 * (int64_t)d_out + 1);
   return a > b ? a : b;
 }
@@ -1259,7 +1259,7 @@ extern "C" int sn_linear_bn_train_f32(const float* x, int ldx, int64_t R, int d_
   SN_REQUIRE(al16(Wp), "sn_linear_bn_train_f32: Wp must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (d_in % 4 == 0) && (ldx % 4 == 0) && al16(x) && (d_out % 4 == 0) && (ldz % 4 == 0) && al16(z) && (!bias || al16(bias));
-  const int64_t nblk = (vec && d_out <= 128 && R >= LIN_LDS_MIN_ROWS) ? lin_lds_blocks(R, d_in, d_out) : 0;
+  const int64_t nblk = (vec && d_out <= 128 && d_in <= 128 && R >= LIN_LDS_MIN_ROWS) ? lin_lds_blocks(R, d_in, d_out) : 0;
   if (nblk == 0) {     // small / unaligned / wide: the Linear, then the one-pass statistics
     const int rc = sn_masked_linear_f32(x, ldx, R, d_in, Wp, d_out, bias, nvalid, K, bias ? SN_EPI_BIAS : 0, nullptr, nullptr, nullptr, 0, z,
                                         ldz, stream);
