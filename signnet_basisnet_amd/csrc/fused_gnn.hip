@@ -90,8 +90,16 @@ __device__ __forceinline__ void wload(WSplit<NKB>& p, const void* wsp, int ot, i
   (void)rs; (void)voff; (void)base;
   return;
 #endif
+#ifdef SN_EXP_W23          // timing experiment: two thirds of the fragment bytes (the l plane is not fetched)
+#pragma unroll
+  for (int i = 0; i < 3 * NKB; ++i)
+    if (i % 3 != 2) p.f[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + i * 1024, 0);
+#pragma unroll
+  for (int i = 2; i < 3 * NKB; i += 3) p.f[i] = p.f[i - 1];
+#else
 #pragma unroll
   for (int i = 0; i < 3 * NKB; ++i) p.f[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + i * 1024, 0);
+#endif
 #pragma unroll
   for (int j = 0; j < SPLIT_EPI; ++j) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (3 * NKB + j) * 1024, 0);
