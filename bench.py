@@ -218,7 +218,7 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
                         "achieved": 3 * fl["total"] / dt / 1e12, "frac": 3 * fl["total"] / dt / 1e12 / MFMA_F32_PEAK_TF,
                         "note": "whole step, ~3x the forward's dense flops (forward + dX + dW), layer-at-a-time fp32-MFMA kernels; "
                                 "this path is launch/HBM bound (one kernel per op), not matrix-pipe bound"},
-           "distributed": {"world_size": world, "backend": "nccl (RCCL)" if dist is not None else None,
+           "distributed": {"world_size": world, "backend": dist.get_backend() if dist is not None else None,
                            "gradient_allreduce": rccl,
                            "note": "one SUM all-reduce of the flat gradient per step (optim.FlatAdam), 1/world folded into the Adam kernel"},
            "kernels": dict(sorted(per.items(), key=lambda kv: -kv[1]["us_per_step"]))}
@@ -631,7 +631,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     from signnet_basisnet_amd import dist as D
     from signnet_basisnet_amd import ops, synth
-    dist = D.init_process_group("nccl") if world > 1 else None      # "nccl" is RCCL on ROCm
+    # (test hooks, never set by the driver: SN_BENCH_BACKEND=gloo + SN_BENCH_SHARE_DEVICE=1 run the N > 1 code path — barriers, the
+    #  max-over-ranks time, the all-reduce probe, rank 0's JSON line — with every rank on cuda:0 of a one-GPU box, where RCCL refuses
+    #  two ranks on one device: tests/test_bench_multirank_gpu.py)
+    backend = os.environ.get("SN_BENCH_BACKEND", "nccl")
+    if os.environ.get("SN_BENCH_SHARE_DEVICE", "0") == "1":
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
+    dist = D.init_process_group(backend) if world > 1 else None      # "nccl" is RCCL on ROCm
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -746,7 +753,7 @@ def main():
     if dist is not None:
         rccl = rccl_allreduce_probe(dist, dev, sum(p.numel() for p in model.parameters()))
     if rank == 0:
-        out["distributed"] = {"world_size": world, "backend": "nccl (RCCL)" if dist is not None else None,
+        out["distributed"] = {"world_size": world, "backend": (f"{backend} (RCCL)" if backend == "nccl" else backend) if dist is not None else None,
                               "data_path_collectives": 0, "gradient_allreduce": rccl}
         if args.config == 1 and not args.no_scatter:
             out["scatter_roofline"] = scatter_roofline(dev)

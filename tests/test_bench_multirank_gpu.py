@@ -1,0 +1,40 @@
+"""-m gpu: bench.py's N > 1 path (one process per rank under torch.distributed.run: barriers, max-over-ranks step time, the gradient
+all-reduce probe, rank 0's single JSON line) executed end to end on the one-GPU test box — both ranks on cuda:0 over gloo (RCCL refuses
+two ranks on one device; the driver's real launch uses RCCL, one rank per GPU).  The kernels, the sharding by rank and the timing
+protocol are the ones the driver's scaling run uses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, port):
+    env = dict(os.environ, SN_BENCH_BACKEND="gloo", SN_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_forward_bench_two_ranks():
+    d = _run(["--no-cpu-baseline", "--no-scatter", "--streams", "1"], 29731)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 256 and d["config"]["graphs_per_gpu"] == 128
+    assert d["value"] > 0 and abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
+    assert d["distributed"]["world_size"] == 2 and d["distributed"]["data_path_collectives"] == 0
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_train_bench_two_ranks_allreduces_the_flat_gradient():
+    d = _run(["--workload", "train", "--no-cpu-baseline"], 29733)
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    g = d["distributed"]
+    assert g["world_size"] == 2
