@@ -313,18 +313,23 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   auto ee_fetch = [&](int l) {
     if (!use_ee || l >= P.n_layers) return;
     const sn_gnn_layer& Lq = P.layers[l];
+    int t0 = threadIdx.x;
+    asm volatile("" : "+v"(t0));      // (per call: the (edge, channel) pair of every slot is a lane constant the compiler would otherwise
+                                      //  keep in registers across the layers — with D/4 not a power of two it is not rematerialised)
 #pragma unroll
     for (int i = 0; i < GNN_EEPF; ++i) {
-      const int idx = threadIdx.x + i * GNN_WAVES * 64;
+      const int idx = t0 + i * GNN_WAVES * 64;
       eepf[i] = zero4;
       if (idx < ne * (D / 4)) eepf[i] = edge_embed(Lq, idx / (D / 4), 4 * (idx % (D / 4)));
     }
   };
   auto ee_store = [&]() {
     if (!use_ee) return;
+    int t0 = threadIdx.x;
+    asm volatile("" : "+v"(t0));
 #pragma unroll
     for (int i = 0; i < GNN_EEPF; ++i) {
-      const int idx = threadIdx.x + i * GNN_WAVES * 64;
+      const int idx = t0 + i * GNN_WAVES * 64;
       if (idx < ne * (D / 4)) lds_st4(EE + (idx / (D / 4)) * LD + 4 * (idx % (D / 4)), eepf[i]);
     }
   };
