@@ -54,6 +54,34 @@ __device__ __forceinline__ int block_exscan(int v, int* wsum, int t, int* total)
   return r;
 }
 
+// the same over 64-bit values (several packed counters in one pass); wsum64: LDS long long[32]
+__device__ __forceinline__ long long block_exscan64(long long v, long long* wsum64, int t, long long* total) {
+  const int lane = t & 63, w = t >> 6;
+  long long x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const long long y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum64[w] = x;
+  __syncthreads();
+  if (w == 0) {
+    long long s = (lane < PLAN_T / 64) ? wsum64[lane] : 0;
+    long long inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const long long y = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += y;
+    }
+    if (lane < PLAN_T / 64) wsum64[lane] = inc - s;
+    if (lane == PLAN_T / 64 - 1) wsum64[31] = inc;
+  }
+  __syncthreads();
+  const long long r = x - v + wsum64[w];
+  *total = wsum64[31];
+  return r;
+}
+
 // kmax > 0: at most kmax eigenvector slots per node; 0: all n of them; kmax < 0 ("full slots", the DGL tree's dense [N, K] positional
 // encodings): the valid-slot count is still min(n, |kmax|), but the phi work bins cover all |kmax| slots of every graph (zero-padded
 // eigenvectors go through GINDeepSigns like any other column, deepsigns.py:45-51).
@@ -66,7 +94,7 @@ __device__ __forceinline__ int phi_slots_of(int n, int kmax) { return kmax < 0 ?
 //      of height max_g K_g covers all slabs of its graphs and every bin is (nearly) full.
 // rho: a unit is one node's K_g slot rows, padded to p = 16*ceil(K_g/16) so that a unit never straddles a 16-row
 //      tile; 64/p units per bin, bins never mix graphs -> closed form, no sequential pass.
-// gp: graph_ptr in LDS ([B+1]); lds: int scratch [5*B + 3*66 + 32].
+// gp: graph_ptr in LDS ([B+1]); lds: int scratch [5*B + 3*66 + 32 + 4].
 #ifdef SN_PROFILE
 static __device__ long long g_pprof[32];
 #define PL_STAMP(i) do { if (threadIdx.x == 0) g_pprof[(i) + 16 * blockIdx.x] = clock64(); } while (0)
@@ -82,7 +110,8 @@ __device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* 
   __shared__ int s_rerr;
   if (t == 0) s_rerr = 0;
   __syncthreads();
-  int rows = 0;
+  int rows = 0, prows = 0;      // rho rows (meta[6]); phi rows (meta[2]: graphs of <= 64 nodes x their phi slots — the column planner's
+                                //  block leaves this total to this one, which is off the critical path)
   const int per = (B + PLAN_T - 1) / PLAN_T;
   const int lo = t * per, hi = (lo + per < B) ? lo + per : B;
   int mine = 0;
@@ -90,6 +119,7 @@ __device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* 
     const int n = gp[g + 1] - gp[g];
     const int K = slots_of(n, kmax);
     int nb = 0;
+    if (n > 0 && n <= 64) prows += n * phi_slots_of(n, kmax);
     if (n > 0) {
       if (K > 64) atomicOr(&s_rerr, 2);
       else {
@@ -105,16 +135,25 @@ __device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* 
   int total;
   int run = block_exscan(mine, wsum, t, &total);
   for (int g = lo; g < hi; ++g) { bd.rho_bin0[g] = run; run += nbv[g]; }
-  int rtot;
+  int rtot, ptot;
   block_exscan(rows, wsum, t, &rtot);
+  block_exscan(prows, wsum, t, &ptot);
   __syncthreads();
   if (t == 0) {
     bd.rho_bin0[B] = total;
+    bd.meta[2] = ptot;
     bd.meta[4] = total;
     bd.meta[5] = (s_rerr & 2);
     bd.meta[6] = rtot;
     bd.meta[7] = 0;
   }
+}
+
+// vec with lane `lane` replaced by the wave-uniform `val` (v_writelane_b32: value and lane select are scalar operands)
+__device__ __forceinline__ int writelane(int vec, int val, int lane) {
+  // (gfx9 encodes one scalar register per VALU instruction: the lane select goes through M0)
+  asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane) : "m0");
+  return vec;
 }
 
 __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
@@ -125,9 +164,10 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* bstart = hist + 66;      // [66]
   int* bcur = bstart + 66;      // [66]
   int* wsum = bcur + 66;        // [32]
-  __shared__ int s_err, s_ncol, s_nbins, s_nrec, s_maxcls;
+  __shared__ int s_err, s_nrec, s_maxcls;
+  __shared__ long long wsum64[32];
   if (t < 66) { hist[t] = 0; bcur[t] = 0; }
-  if (t == 0) { s_err = 0; s_ncol = 0; s_nbins = 0; s_nrec = 0; }
+  if (t == 0) { s_err = 0; s_nrec = 0; }
   __syncthreads();
   PL_STAMP(3);
   // ---- phi: group graphs by size
@@ -185,99 +225,107 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       }
     }
   }
-  // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers:
-  //      lane s-1 owns size class s (remaining count, items taken); the loop-carried chain is scalar/readlane
-  //      arithmetic only.  It emits (class, rank) records; the graph ids are resolved in parallel afterwards.
-  int* rec_cls = nbv;            // [B] reuse (rho is done with nbv): size class of the r-th placed graph
-  int* rec_rank = lds + 2 * B + 3 * 66 + 32;   // [B] rank inside its class          (extra [3*B] ints of scratch)
-  int* rec_col = rec_rank + B;   // [B] column
-  int* rec_off = rec_col + B;    // [B] (member index << 8) | row offset
+  // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers: lane s-1 holds the
+  //      remaining count of size class s; the loop-carried chain is scalar arithmetic, one readlane and two writelanes per item, and
+  //      all it emits per placed graph is ONE word (class | first-of-column flag | graphs of the class still unplaced).  Everything
+  //      else — rank inside the class, column, member index, row offset, the columns' first bins — follows from that sequence by
+  //      workgroup-wide scans afterwards (the chain used to keep those records itself: ~335 cycles per graph, the longest phase of
+  //      the plan).
+  int* rec = nbv;                              // [B] reuse (rho is done with nbv): the chain's word of the r-th placed graph
+  int* rec_pre = lds + 2 * B + 3 * 66 + 32;    // [B] exclusive prefix of the classes (rows) over the records   (extra [3*B] ints)
+  int* col_start = rec_pre + B;                // [B] record index of every column's first member
+  int* col_bin = col_start + B;                // [B + 1] first bin of every column
   __syncthreads();
   PL_STAMP(4);
   if (t < 64) {
     const int lane = t;
     int cnt = hist[lane + 1];                       // class s = lane + 1
-    int used = 0;
     unsigned long long avail = __ballot(cnt > 0);
-    int ncol = 0, bin = 0, rows = 0, nrec = 0;
-    // records and column starts are captured in registers (lane r & 63 keeps record r) and flushed 64 at a time:
-    // no LDS / global store sits on the loop-carried scalar chain
-    int recA = 0, recB = 0, colb = 0;
+    int nrec = 0, recv = 0;
     while (avail) {
-      const int s = 64 - __clzll(avail);
-      int cap = 64 - s, members = 0, off = 0;
-      const int H = phi_slots_of(s, kmax);
-      int cls = s;
-      if (lane == (ncol & 63)) colb = bin;
+      int cls = 64 - __clzll(avail);
+      int cap = 64, members = 0, first = 1 << 7;
       while (true) {
-        const int rank = __builtin_amdgcn_readlane(used, cls - 1);
         const int left = __builtin_amdgcn_readlane(cnt, cls - 1) - 1;
-        if (lane == cls - 1) { ++used; --cnt; }
+        cnt = writelane(cnt, left, cls - 1);
         if (left == 0) avail &= ~(1ull << (cls - 1));
-        if (lane == (nrec & 63)) { recA = cls | (rank << 8); recB = ncol | (members << 13) | (off << 16); }
+        recv = writelane(recv, cls | first | (left << 8), nrec & 63);
         ++nrec;
-        if ((nrec & 63) == 0) {                        // flush 64 records
-          const int base = nrec - 64 + lane;
-          rec_cls[base] = recA & 255;
-          rec_rank[base] = recA >> 8;
-          rec_col[base] = recB & 8191;
-          rec_off[base] = (((recB >> 13) & 7) << 8) | (recB >> 16);
-        }
-        rows += cls * phi_slots_of(cls, kmax);
-        off += cls;
+        if ((nrec & 63) == 0) rec[nrec - 64 + lane] = recv;      // flush 64 records
+        first = 0;
         ++members;
-        if (members == 1) cap = 64 - s; else cap -= cls;
+        cap -= cls;
         if (members >= 8 || cap <= 0) break;
-        const unsigned long long m = (cap >= 64) ? avail : (avail & ((1ull << cap) - 1ull));
+        const unsigned long long m = avail & ((1ull << cap) - 1ull);      // 0 < cap < 64
         if (!m) break;
         cls = 64 - __clzll(m);
       }
-      bin += H;
-      ++ncol;
-      if ((ncol & 63) == 0) bd.phi_col_bin0[ncol - 64 + lane] = colb;
     }
-    if (lane < (nrec & 63)) {                          // flush the partial groups
-      const int base = (nrec & ~63) + lane;
-      rec_cls[base] = recA & 255;
-      rec_rank[base] = recA >> 8;
-      rec_col[base] = recB & 8191;
-      rec_off[base] = (((recB >> 13) & 7) << 8) | (recB >> 16);
-    }
-    if (lane < (ncol & 63)) bd.phi_col_bin0[(ncol & ~63) + lane] = colb;
-    if (lane == 0) {
-      bd.phi_col_bin0[ncol] = bin;
-      s_ncol = ncol;
-      s_nbins = bin;
-      s_nrec = nrec;
-      bd.meta[0] = bin;
-      bd.meta[2] = rows;
-      bd.meta[3] = ncol;
-    }
+    if (lane < (nrec & 63)) rec[(nrec & ~63) + lane] = recv;     // the partial group
+    if (lane == 0) s_nrec = nrec;
   }
   __syncthreads();
   PL_STAMP(5);
   {
-    const int ncol_ = s_ncol, nrec = s_nrec;
-    for (int i = t; i < ncol_ * 8; i += PLAN_T) { bd.phi_col_mem[i] = -1; bd.phi_col_off[i] = 0; }
-    __syncthreads();
-    for (int r = t; r < nrec; r += PLAN_T) {
-      const int cls = rec_cls[r];
-      const int g = bucket[bstart[cls] + rec_rank[r]];
-      const int slot = rec_col[r] * 8 + (rec_off[r] >> 8);
-      bd.phi_col_mem[slot] = g;
-      bd.phi_col_off[slot] = rec_off[r] & 255;
+    // records -> (column, member, row offset, graph id); columns -> first bins.  ONE scan of three packed counters per PLAN_T records
+    // (rows placed: bits 0-23, columns opened: bits 24-39, bins of the opened columns: bits 40-63), running carries between rounds.
+    // Results stay in LDS until every barrier is behind us: a workgroup barrier also drains the outstanding global stores.
+    const int nrec = s_nrec;
+    long long carry = 0;
+    for (int r0 = 0; r0 < nrec; r0 += PLAN_T) {
+      const int r = r0 + t;
+      const int w = r < nrec ? rec[r] : 0;
+      const int cls = w & 127, first = (w >> 7) & 1;
+      const int h = first ? phi_slots_of(cls, kmax) : 0;
+      long long tot;
+      const long long ex = block_exscan64((long long)cls | ((long long)first << 24) | ((long long)h << 40), wsum64, t, &tot) + carry;
+      if (r < nrec) {
+        rec_pre[r] = (int)(ex & 0xffffff);
+        if (first) {
+          const int c = (int)((ex >> 24) & 0xffff);
+          col_start[c] = r;
+          col_bin[c] = (int)(ex >> 40);
+        }
+      }
+      carry += tot;
     }
-  }
-  __syncthreads();
-  const int ncol = s_ncol, nbins = s_nbins;
-  const bool over = nbins > bd.phi_max_bins;
-  if (t == 0) {
-    bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
-  }
-  if (!over) {
-    for (int c = t; c < ncol; c += PLAN_T) {
-      const int lo = bd.phi_col_bin0[c], hi = bd.phi_col_bin0[c + 1];
-      for (int j = lo; j < hi; ++j) bd.phi_bin_col[j] = c;
+    const int ncol = (int)((carry >> 24) & 0xffff), nbins = (int)(carry >> 40);
+    if (t == 0) col_bin[ncol] = nbins;
+    __syncthreads();
+    // ---- write-out (no barrier from here on)
+    const bool over = nbins > bd.phi_max_bins;
+    if (t == 0) {
+      bd.meta[0] = nbins;
+      bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
+      bd.meta[3] = ncol;
+    }
+    for (int c = t; c <= ncol; c += PLAN_T) bd.phi_col_bin0[c] = col_bin[c];
+    // member records: the column of record r is the number of column starts <= r, found by bisection over col_start; the last member
+    // of a column also closes its unused slots
+    for (int r = t; r < nrec; r += PLAN_T) {
+      const int w = rec[r];
+      const int cls = w & 127, left = w >> 8;
+      int lo = 0, hi = ncol;                         // largest c with col_start[c] <= r
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (col_start[mid] <= r) lo = mid; else hi = mid;
+      }
+      const int cs = col_start[lo];
+      const int rank = hist[cls] - 1 - left;          // graphs of the class are taken in bucket order
+      const int g = bucket[bstart[cls] + rank];
+      const int mem = r - cs;
+      const int slot = lo * 8 + mem;
+      bd.phi_col_mem[slot] = g;
+      bd.phi_col_off[slot] = rec_pre[r] - rec_pre[cs];
+      if (r + 1 == nrec || ((rec[r + 1] >> 7) & 1)) {
+        for (int m = mem + 1; m < 8; ++m) { bd.phi_col_mem[lo * 8 + m] = -1; bd.phi_col_off[lo * 8 + m] = 0; }
+      }
+    }
+    if (!over) {
+      for (int c = t; c < ncol; c += PLAN_T) {
+        const int lo = col_bin[c], hi = col_bin[c + 1];
+        for (int j = lo; j < hi; ++j) bd.phi_bin_col[j] = c;
+      }
     }
   }
 }
@@ -412,43 +460,54 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
       const long long s = sv[u], d = dv[u];
       if (e < E && !(s < 0 || s >= N || d < 0 || d >= N)) {
         const int p = atomicAdd(&deg[d], 1);
-        lcol[p] = (int)s;
-        lperm[p] = e;
+        lperm[p] = (e << 12) | (int)s;          // one sort key per in-edge: edge id (< 2^14: E <= 12288) above the source node (< 2^12)
       }
     }
   }
   __syncthreads();
   PL_STAMP(4);
+  // every segment sorted by edge id: the keys are distinct, a comparator is one min and one max
   for (int i = t; i < N; i += PLAN_T) {
     const int lo = rp[i], hi = rp[i + 1], dg = hi - lo;
     if (dg <= 1) continue;
     if (dg <= 4) {
-      // up to four in-edges (molecular graphs: always): read, 5-comparator network on (edge id, source), write back
-      int ke[4], kc[4];
+      // up to four in-edges (molecular graphs: always): 5-comparator network on registers
+      int k[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { ke[u] = u < dg ? lperm[lo + u] : 0x7fffffff; kc[u] = u < dg ? lcol[lo + u] : 0; }
-      auto cx = [&](int a, int b) {
-        if (ke[a] > ke[b]) { const int te = ke[a]; ke[a] = ke[b]; ke[b] = te; const int tc = kc[a]; kc[a] = kc[b]; kc[b] = tc; }
-      };
+      for (int u = 0; u < 4; ++u) k[u] = u < dg ? lperm[lo + u] : 0x7fffffff;
+      auto cx = [&](int a, int b) { const int x = min(k[a], k[b]), y = max(k[a], k[b]); k[a] = x; k[b] = y; };
       cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (u < dg) { lperm[lo + u] = ke[u]; lcol[lo + u] = kc[u]; }
+        if (u < dg) lperm[lo + u] = k[u];
+      continue;
+    }
+    if (dg <= 8) {
+      // five to eight in-edges: the 19-comparator network (the insertion sort below walks LDS with a dependent access per move — a
+      // few nodes of degree 6-7 made this phase the longest of the CSR block)
+      int k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = u < dg ? lperm[lo + u] : 0x7fffffff;
+      auto cx = [&](int a, int b) { const int x = min(k[a], k[b]), y = max(k[a], k[b]); k[a] = x; k[b] = y; };
+      cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7); cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7); cx(1, 2); cx(5, 6); cx(0, 4); cx(3, 7);
+      cx(1, 5); cx(2, 6); cx(1, 4); cx(3, 6); cx(2, 4); cx(3, 5); cx(3, 4);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < dg) lperm[lo + u] = k[u];
       continue;
     }
     for (int a = lo + 1; a < hi; ++a) {
-      const int ke = lperm[a], kc = lcol[a];
+      const int ke = lperm[a];
       int b = a - 1;
-      while (b >= lo && lperm[b] > ke) { lperm[b + 1] = lperm[b]; lcol[b + 1] = lcol[b]; --b; }
+      while (b >= lo && lperm[b] > ke) { lperm[b + 1] = lperm[b]; --b; }
       lperm[b + 1] = ke;
-      lcol[b + 1] = kc;
     }
   }
   __syncthreads();
   PL_STAMP(5);
   // ---- write out
   for (int i = t; i <= N; i += PLAN_T) rowptr[i] = rp[i];
-  for (int i = t; i < E; i += PLAN_T) { col[i] = lcol[i]; eperm[i] = lperm[i]; }
+  for (int i = t; i < E; i += PLAN_T) { const int k = lperm[i]; col[i] = k & 4095; eperm[i] = k >> 12; }
   for (int i = t; i <= B; i += PLAN_T) graph_ptr[i] = gp[i];
   for (int i = t; i < N; i += PLAN_T) {
     const long long g = batch[i];
@@ -668,7 +727,7 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   hipStream_t st = (hipStream_t)stream;
   if (N > 0 && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX) {
     const size_t lds0 = (size_t)((PS_BMAX + 4) + PS_NMAX + (PS_NMAX + 4) + 2 * PS_EMAX + 32 + PS_NMAX) * sizeof(int);
-    const size_t lds1 = (size_t)((PS_BMAX + 4) + 5 * PS_BMAX + 3 * 66 + 32) * sizeof(int);
+    const size_t lds1 = (size_t)((PS_BMAX + 4) + 5 * PS_BMAX + 3 * 66 + 32 + 4) * sizeof(int);
     const size_t lds = lds0 > lds1 ? lds0 : lds1;
     static bool init = false;
     if (!init) {
@@ -689,12 +748,12 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   const int64_t ne = N > E ? N : E;
   hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(ne > 0 ? ne : 1, T)), dim3(T), 0, st, batch, edge_index, E, N, B, deg,
                      status);
-  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32) * sizeof(int) : 0;
+  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32 + 4) * sizeof(int) : 0;
   if (lds3 > 48 * 1024) {
     static bool init3 = false;
     if (!init3) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)(6 * BINS_BMAX + 4 + 3 * 66 + 32) * sizeof(int))) != hipSuccess)
+                              (int)((size_t)(6 * BINS_BMAX + 4 + 3 * 66 + 32 + 4) * sizeof(int))) != hipSuccess)
         return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit");
       init3 = true;
     }
