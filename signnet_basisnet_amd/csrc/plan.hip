@@ -193,11 +193,22 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     if (t == 0) s_maxcls = max(hm, hist[64]);
   }
   __syncthreads();
-  if (B <= 2048 && s_maxcls > 12) {
-    // crowded size classes (Alchemy: 256 graphs in 9 classes): rank inside the class = number of earlier graphs of the same
-    // size (LDS broadcast scan) — deterministic order without the per-class serial insertion sort (116 k cycles there);
-    // sparse classes (ZINC: ~4 graphs per class) keep the atomic placement + tiny sorts, which is cheaper
-    for (int g = t; g < B; g += PLAN_T) {
+  // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers: lane s-1 holds the
+  //      remaining count of size class s; the loop-carried chain is scalar arithmetic, one readlane and two writelanes per item, and
+  //      all it emits per placed graph is ONE word (class | first-of-column flag | graphs of the class still unplaced).  Everything
+  //      else — rank inside the class, column, member index, row offset, the columns' first bins — follows from that sequence by
+  //      workgroup-wide scans afterwards (the chain used to keep those records itself: ~335 cycles per graph, the longest phase of
+  //      the plan).
+  int* rec = nbv;                              // [B] reuse (rho is done with nbv): the chain's word of the r-th placed graph
+  int* rec_pre = lds + 2 * B + 3 * 66 + 32;    // [B] exclusive prefix of the classes (rows) over the records   (extra [3*B] ints)
+  int* col_start = rec_pre + B;                // [B] record index of every column's first member
+  int* col_bin = col_start + B;                // [B + 1] first bin of every column
+  PL_STAMP(4);
+  if (t >= 64) {
+    // ---- meanwhile, on the other 15 waves: the graphs of every size class in ascending id order (`bucket`; the packer only needs the
+    //      class counts, the ids are resolved after it).  Rank inside the class = number of earlier graphs of the same size (LDS
+    //      broadcast reads): deterministic without a sort, and off the critical path whatever it costs.
+    for (int g = t - 64; g < B; g += PLAN_T - 64) {
       const int n = gp[g + 1] - gp[g];
       if (n > 0 && n <= 64) {
         int rank = 0, prev = gp[0];
@@ -210,34 +221,6 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       }
     }
   } else {
-    for (int g = t; g < B; g += PLAN_T) {
-      const int n = gp[g + 1] - gp[g];
-      if (n > 0 && n <= 64) bucket[bstart[n] + atomicAdd(&bcur[n], 1)] = g;
-    }
-    __syncthreads();
-    if (t <= 64) {  // deterministic order inside a size class
-      const int lo = bstart[t], hi = bstart[t + 1];
-      for (int a = lo + 1; a < hi; ++a) {
-        const int k = bucket[a];
-        int b = a - 1;
-        while (b >= lo && bucket[b] > k) { bucket[b + 1] = bucket[b]; --b; }
-        bucket[b + 1] = k;
-      }
-    }
-  }
-  // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers: lane s-1 holds the
-  //      remaining count of size class s; the loop-carried chain is scalar arithmetic, one readlane and two writelanes per item, and
-  //      all it emits per placed graph is ONE word (class | first-of-column flag | graphs of the class still unplaced).  Everything
-  //      else — rank inside the class, column, member index, row offset, the columns' first bins — follows from that sequence by
-  //      workgroup-wide scans afterwards (the chain used to keep those records itself: ~335 cycles per graph, the longest phase of
-  //      the plan).
-  int* rec = nbv;                              // [B] reuse (rho is done with nbv): the chain's word of the r-th placed graph
-  int* rec_pre = lds + 2 * B + 3 * 66 + 32;    // [B] exclusive prefix of the classes (rows) over the records   (extra [3*B] ints)
-  int* col_start = rec_pre + B;                // [B] record index of every column's first member
-  int* col_bin = col_start + B;                // [B + 1] first bin of every column
-  __syncthreads();
-  PL_STAMP(4);
-  if (t < 64) {
     const int lane = t;
     int cnt = hist[lane + 1];                       // class s = lane + 1
     unsigned long long avail = __ballot(cnt > 0);
@@ -379,6 +362,23 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     int* gp = sm;
     lds_graph_ptr(batch, N, B, gp, nullptr);
     plan_rho_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
+    // evoff = exclusive scan of n^2 and the largest graph: nothing of the CSR block depends on them, so they are taken here
+    {
+      int* wsum2 = sm + (PS_BMAX + 4) + B;     // plan_rho_block's scan scratch
+      __shared__ int s_nmax2;
+      if (t == 0) s_nmax2 = 0;
+      __syncthreads();
+      const int perb = (B + PLAN_T - 1) / PLAN_T;
+      const int blo = t * perb, bhi = (blo + perb < B) ? blo + perb : B;
+      int q = 0, nmax = 0;
+      for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; q += n * n; nmax = nmax > n ? nmax : n; }
+      for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+      if ((t & 63) == 0) atomicMax(&s_nmax2, nmax);
+      int qtot;
+      int qrun = block_exscan(q, wsum2, t, &qtot);
+      for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; evoff[g] = qrun; qrun += n * n; }
+      if (t == 0) { evoff[B] = qtot; status[ST_NMAX] = s_nmax2; }
+    }
     return;
   }
   int* gp = sm;                        // [B+1]
@@ -432,16 +432,18 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     int run = block_exscan(s, wsum, t, &total);
     for (int i = lo; i < hi; ++i) { const int dg = deg[i]; rp[i] = run; deg[i] = run; run += dg; }
     if (t == 0) rp[N] = total;
-    const int perb = (B + PLAN_T - 1) / PLAN_T;
-    const int blo = t * perb, bhi = (blo + perb < B) ? blo + perb : B;
-    int q = 0, nmax = 0;
-    for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; q += n * n; nmax = nmax > n ? nmax : n; }
-    for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-    if ((t & 63) == 0) atomicMax(&s_nmax, nmax);
-    int qtot;
-    int qrun = block_exscan(q, wsum, t, &qtot);
-    for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; evoff[g] = qrun; qrun += n * n; }
-    if (t == 0) evoff[B] = qtot;
+    if (!do_bins) {     // (with the bin planner the third workgroup takes evoff and the largest graph)
+      const int perb = (B + PLAN_T - 1) / PLAN_T;
+      const int blo = t * perb, bhi = (blo + perb < B) ? blo + perb : B;
+      int q = 0, nmax = 0;
+      for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; q += n * n; nmax = nmax > n ? nmax : n; }
+      for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+      if ((t & 63) == 0) atomicMax(&s_nmax, nmax);
+      int qtot;
+      int qrun = block_exscan(q, wsum, t, &qtot);
+      for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; evoff[g] = qrun; qrun += n * n; }
+      if (t == 0) evoff[B] = qtot;
+    }
   }
   __syncthreads();
   PL_STAMP(3);
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     node_graph[i] = gi;
     nvalid[i] = nv;
   }
-  if (t == 0) { status[ST_ERR] = s_err; status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
+  if (t == 0) { status[ST_ERR] = s_err; if (!do_bins) status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
   if (t >= 4 && t < 8) status[t] = 0;
   PL_STAMP(6);
 }
