@@ -71,6 +71,64 @@ def test_plan_large_batch_multikernel_path(dev):
     assert err == 0 and rows == int((n * n.clamp(max=16)).sum()) and 0 < ncol <= 260 and nb <= plan.bins.phi_max_bins
 
 
+def _reference_columns(sizes, kmax):
+    """The planner's column packing restated on the host: graphs grouped by size (ascending id inside a size class); a column takes
+    the largest size still available, then repeatedly the largest size that fits the rows left (capacity 64 rows, at most 8 members);
+    a column's height is its first (largest) member's slot count."""
+    slots = (lambda n: -kmax) if kmax < 0 else (lambda n: min(n, kmax) if kmax > 0 else n)
+    classes = {}
+    for g, n in enumerate(sizes):
+        if 0 < n <= 64:
+            classes.setdefault(n, []).append(g)
+    cols = []
+    while classes:
+        s = max(classes)
+        cap, members, off = 64, [], 0
+        cls = s
+        while True:
+            g = classes[cls].pop(0)
+            if not classes[cls]:
+                del classes[cls]
+            members.append((g, off))
+            off += cls
+            cap -= cls
+            fit = [c for c in classes if c <= cap]
+            if len(members) >= 8 or cap <= 0 or not fit:
+                break
+            cls = max(fit)
+        cols.append((members, slots(s)))
+    return cols
+
+
+@pytest.mark.parametrize("B,kmax,seed,lo,hi", [(128, 16, 1236, 9, 37), (256, 0, 3, 6, 14), (37, 8, 5, 1, 64), (1500, 4, 7, 1, 5),
+                                                (2100, -3, 9, 1, 3), (1, 16, 2, 9, 9)])
+def test_plan_phi_columns_match_the_host_restatement(dev, B, kmax, seed, lo, hi):
+    """The work bins of the fused phi stage (sn_batch_plan with bins): member graphs, row offsets, first bins and the bin -> column
+    map equal the host restatement of the packing, on the one-launch path (N <= 4096) and the five-launch path, including more than
+    1024 graphs (several rounds of the planner's record scan) and the DGL mode (kmax < 0: a fixed slot count)."""
+    from signnet_basisnet_amd import ops
+    data = synth.make_batch(B, seed=seed, n_lo=lo, n_hi=hi)
+    d = synth.batch_to(data, dev)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True)
+    assert plan.check()[0] == 0
+    cols = _reference_columns(list(data.sizes), kmax)
+    nb, err, rows, ncol = plan.bins.meta.cpu().tolist()[:4]
+    assert err == 0 and ncol == len(cols)
+    mem = plan.bins.phi_col_mem.cpu().view(-1, 8)[:ncol].tolist()
+    off = plan.bins.phi_col_off.cpu().view(-1, 8)[:ncol].tolist()
+    bin0 = plan.bins.phi_col_bin0.cpu()[:ncol + 1].tolist()
+    exp_bin0 = [0]
+    for c, (members, h) in enumerate(cols):
+        assert mem[c] == [g for g, _ in members] + [-1] * (8 - len(members)), c
+        assert off[c][:len(members)] == [o for _, o in members], c
+        exp_bin0.append(exp_bin0[-1] + h)
+    assert bin0 == exp_bin0 and nb == exp_bin0[-1]
+    slots = (lambda n: -kmax) if kmax < 0 else (lambda n: min(n, kmax) if kmax > 0 else n)
+    assert rows == sum(n * slots(n) for n in data.sizes if 0 < n <= 64)
+    bc = plan.bins.phi_bin_col.cpu()[:nb].tolist()
+    assert bc == [c for c, (_, h) in enumerate(cols) for _ in range(h)]
+
+
 def test_plan_kmax_and_errors(dev):
     from signnet_basisnet_amd import ops
     data = synth.make_batch(4, seed=2, sizes=[3, 20, 7, 12])
