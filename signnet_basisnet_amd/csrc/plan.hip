@@ -162,11 +162,10 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* nbv = lds + B;           // [B]   (record scratch of the column packing)
   int* hist = lds + 2 * B;      // [66]
   int* bstart = hist + 66;      // [66]
-  int* bcur = bstart + 66;      // [66]
-  int* wsum = bcur + 66;        // [32]
-  __shared__ int s_err, s_nrec, s_maxcls;
+  int* wsum = bstart + 2 * 66;  // [32]  (66 ints behind bstart are spare)
+  __shared__ int s_err, s_nrec;
   __shared__ long long wsum64[32];
-  if (t < 66) { hist[t] = 0; bcur[t] = 0; }
+  if (t < 66) hist[t] = 0;
   if (t == 0) { s_err = 0; s_nrec = 0; }
   __syncthreads();
   PL_STAMP(3);
@@ -187,10 +186,6 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     }
     bstart[t] = x - h;
     if (t == 63) { bstart[64] = x; bstart[65] = x + hist[64]; }
-    int hm = h;                                        // largest size class (hist[64] joins below)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) hm = max(hm, __shfl_xor(hm, off, 64));
-    if (t == 0) s_maxcls = max(hm, hist[64]);
   }
   __syncthreads();
   // ---- phi: best-fit-decreasing over the size classes.  Wave 0 walks the items with its state in registers: lane s-1 holds the
@@ -384,8 +379,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
   int* gp = sm;                        // [B+1]
   int* deg = gp + (PS_BMAX + 4);       // [N]  in-degree, then fill cursor
   int* rp = deg + PS_NMAX;             // [N+1]
-  int* lcol = rp + (PS_NMAX + 4);      // [E]
-  int* lperm = lcol + PS_EMAX;         // [E]
+  int* lperm = rp + (PS_NMAX + 4) + PS_EMAX;   // [E]  one packed key per in-edge: edge id << 12 | source  ([E] ints before it are spare)
   int* wsum = lperm + PS_EMAX;         // [32]
   int* ng = wsum + 32;                 // [N]  graph id of every node (edge validation without global gathers)
   __shared__ int s_err, s_nmax, s_dmax;
