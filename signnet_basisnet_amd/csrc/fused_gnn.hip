@@ -227,6 +227,38 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
   }
 }
 
+// NT >= 7 (d = 112, 128): every wave owns exactly ONE output tile of every Linear, so the two register tiles simply alternate
+// from stage to stage and each is refilled — with the tile of the stage AFTER the next — as soon as its last product and epilogue are
+// done.  A tile is then on its way for a whole stage (the barrier, the other register tile's Linear, possibly an aggregation) before
+// it is needed; with the ping-pong of coop_gemm it is needed one short stage (~1 us of work per wave) after its issue, and every one of
+// the 22 stages waited out most of a memory round trip (fetch-size sweep: DESIGN.md §8).
+template <int NKB, typename Epi>
+__device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned char* img, TileRange tr, int lane, Epi epi,
+                                               const void* nn_wsp, TileRange nn_tr) {
+  if (!tr.empty()) {
+    asm volatile("" : "+v"(tr.t_lo), "+v"(tr.t_hi), "+v"(tr.T));     // (see coop_gemm)
+    const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE + (lane >> 4) * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = tr.t_lo + i;
+      if (t < tr.t_hi) {
+        int ot, rt;
+        tr.decode(t, ot, rt);
+        Split8 in[NKB];
+        const unsigned char* p = rowbase + rt * 16 * SP_STRIDE;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          in[kb].h = *reinterpret_cast<const u32x4*>(p + kb * 64);
+          in[kb].m = *reinterpret_cast<const u32x4*>(p + kb * 64 + SP_PLANE);
+          in[kb].l = *reinterpret_cast<const u32x4*>(p + kb * 64 + 2 * SP_PLANE);
+        }
+        epi(rt, ot, mfma_split_tile<NKB>(cur, in), cur.e[0], cur.e[1], cur.e[2]);
+      }
+    }
+  }
+  if (nn_wsp != nullptr && !nn_tr.empty()) wload<NKB>(cur, nn_wsp, nn_tr.first_ot(), lane);
+}
+
 template <int NT>
 __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_params& P) {
   constexpr int D = 16 * NT;
@@ -335,7 +367,18 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   };
 
   WSplit<NKB> pre, alt;
-  if (!tr.empty()) wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);       // in flight while the inputs are staged
+  // one output tile per wave and Linear (the wave's share q = ceil(NT*T/8) of the (tile, row tile) pairs equals T): NT = 8 always,
+  // NT = 7 for every T <= 4 (T (8 - NT) < 8) -> coop_gemm_roll
+  constexpr bool ROLL = NT >= 7;
+  static_assert(GNN_WAVES == 8, "the ROLL condition assumes 8 waves");
+  TileRange h2;                               // my share of the last Linear (one tile: wave 0)
+  h2.T = 1;
+  h2.t_lo = 0;
+  h2.t_hi = wave == 0 ? 1 : 0;
+  if (!tr.empty()) {
+    wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);                      // in flight while the inputs are staged
+    if constexpr (ROLL) wload<NKB>(alt, P.lin_b, tr.first_ot(), lane);
+  }
   // ---------------------------------------------------------------- clear the split images (K padding must read as 0)
   for (int i = threadIdx.x; i < 2 * SP_IMAGE / 16; i += GNN_WAVES * 64)
     reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -464,14 +507,17 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     // rho.out folded into the pos half of `linear` by the caller (lin_b = W_pos . diag(bn scale) . W_out, bias' = W_pos . bn shift + b):
     // h = lin_a . x + lin_b . slot_sum + bias' — two GEMMs over two images that are both complete; each lane parks its own
     // tiles of the first product in X1 and reads them back itself: no barrier between the two
-    coop_gemm<NKB>(pre, alt, P.lin_a, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) {
-      lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc);
-    }, P.lin_b, tr);
-    SN_STAMP(20);
-    coop_gemm<NKB>(pre, alt, P.lin_b, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
+    auto epi_a = [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc); };
+    auto epi_b = [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
       float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
       lds_st4(o, (lds_ld4(o) + acc) + bias);
-    }, first_w, first_tr);
+    };
+    const bool hasl = P.n_layers > 0;
+    if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SB, tr, lane, epi_a, first_w, first_tr);
+    else coop_gemm<NKB>(pre, alt, P.lin_a, SB, tr, lane, epi_a, P.lin_b, tr);
+    SN_STAMP(20);
+    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SA, tr, lane, epi_b, hasl ? P.layers[0].w2s : P.head_w2, hasl ? tr : h2);
+    else coop_gemm<NKB>(pre, alt, P.lin_b, SA, tr, lane, epi_b, first_w, first_tr);
   }
   ee_store();
   lds_barrier();
@@ -535,20 +581,22 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
 #endif
     ee_store();        // every wave is done reading this layer's embeddings
     // nn: Linear . BN . ReLU : SA -> SB
-    coop_gemm<NKB>(pre, alt, Lp.w1s, SA, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
-      sp_store4(SB, rt * 16 + li, ot, g, relu4(acc * sc + sh));
-    }, Lp.w2s, tr);
+    const bool lastl = l + 1 == P.n_layers;
+    auto epi_1 = [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) { sp_store4(SB, rt * 16 + li, ot, g, relu4(acc * sc + sh)); };
+    if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, tr, lane, epi_1, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
+    else coop_gemm<NKB>(pre, alt, Lp.w1s, SA, tr, lane, epi_1, Lp.w2s, tr);
     lds_barrier();
     SN_ACCUM(11, pt);
 #ifdef SN_PROFILE
     pt = clock64();
 #endif
     // Linear ; BN . ReLU ; + previous_x : SB -> X1 (my tiles only: nobody else reads them at this point)
-    const bool lastl = l + 1 == P.n_layers;
-    coop_gemm<NKB>(pre, alt, Lp.w2s, SB, tr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
+    auto epi_2 = [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
       float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
       lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
-    }, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
+    };
+    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, tr, lane, epi_2, lastl ? P.head_w2 : P.layers[lastl ? l : l + 1].w2s, lastl ? h2 : tr);
+    else coop_gemm<NKB>(pre, alt, Lp.w2s, SB, tr, lane, epi_2, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
     lds_barrier();
     SN_ACCUM(12, pt);
     SN_STAMP(24 + l);
@@ -565,15 +613,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   lds_barrier();
   SN_STAMP(4);
   // ---------------------------------------------------------------- output encoder on the pooled row     (model.py:63)
-  TileRange h2;
-  h2.T = 1;
-  h2.t_lo = 0;
-  h2.t_hi = wave == 0 ? 1 : 0;
-  coop_gemm<NKB>(pre, alt, P.head_w1, SA, hr, lane, [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
-    sp_store4(SB, li, ot, g, relu4(acc * sc + sh));
-  }, wave == 0 ? P.head_w2 : nullptr, h2);
-  lds_barrier();
-  coop_gemm<NKB>(pre, alt, P.head_w2, SB, h2, lane, [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
+  auto epi_h1 = [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) { sp_store4(SB, li, ot, g, relu4(acc * sc + sh)); };
+  auto epi_h2 = [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) {
     if (li == 0) {
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
@@ -581,7 +622,12 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         if (c < P.n_out) S.y[(int64_t)gi * P.n_out + c] = graph_bad ? __uint_as_float(0x7fc00000u) : acc[qq] + bias[qq];
       }
     }
-  }, nullptr, h2);
+  };
+  if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, hr, lane, epi_h1, nullptr, h2);
+  else coop_gemm<NKB>(pre, alt, P.head_w1, SA, hr, lane, epi_h1, wave == 0 ? P.head_w2 : nullptr, h2);
+  lds_barrier();
+  if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, h2, lane, epi_h2, nullptr, h2);
+  else coop_gemm<NKB>(pre, alt, P.head_w2, SB, h2, lane, epi_h2, nullptr, h2);
   SN_STAMP(5);
 #ifdef SN_PROFILE
   if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) { g_prof[6] = n; g_prof[7] = ne; }
