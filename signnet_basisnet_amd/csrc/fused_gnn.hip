@@ -298,11 +298,20 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   const int d = P.d;
   const int T = (n + 15) >> 4;                               // row tiles (1..4)
   const int ntile = T * NT;
-  const int q = (ntile + GNN_WAVES - 1) / GNN_WAVES;          // pairs per wave (<= T since NT <= 8: at most 2 output tiles)
   TileRange tr;                                               // my share of every node-row Linear (output-tile major)
   tr.T = T;
-  tr.t_lo = wave * q < ntile ? wave * q : ntile;
-  tr.t_hi = tr.t_lo + q < ntile ? tr.t_lo + q : ntile;
+  if constexpr (GNN_WAVES % NT == 0) {
+    // NT divides the wave count: GNN_WAVES / NT waves share an output tile and split its row tiles — every wave stays on ONE output
+    // tile for any T (what coop_gemm_roll needs), with at most ceil(T / (GNN_WAVES / NT)) pairs
+    constexpr int WPO = GNN_WAVES / NT;
+    const int ot = wave / WPO, h = wave % WPO, per = (T + WPO - 1) / WPO;
+    tr.t_lo = ot * T + (h * per < T ? h * per : T);
+    tr.t_hi = ot * T + ((h + 1) * per < T ? (h + 1) * per : T);
+  } else {
+    const int q = (ntile + GNN_WAVES - 1) / GNN_WAVES;        // pairs per wave (<= T since NT <= 8: at most 2 output tiles)
+    tr.t_lo = wave * q < ntile ? wave * q : ntile;
+    tr.t_hi = tr.t_lo + q < ntile ? tr.t_lo + q : ntile;
+  }
   TileRange hr;                                               // my share of the output encoder (one pooled row tile)
   hr.T = 1;
   hr.t_lo = wave < NT ? wave : NT;
@@ -367,9 +376,9 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   };
 
   WSplit<NKB> pre, alt;
-  // one output tile per wave and Linear (the wave's share q = ceil(NT*T/8) of the (tile, row tile) pairs equals T): NT = 8 always,
-  // NT = 7 for every T <= 4 (T (8 - NT) < 8) -> coop_gemm_roll
-  constexpr bool ROLL = NT >= 7;
+  // one output tile per wave and Linear -> coop_gemm_roll: NT in {1, 2, 4, 8} by the range split above; NT = 7: the wave's share
+  // q = ceil(7 T / 8) of the (tile, row tile) pairs equals T for every T <= 4
+  constexpr bool ROLL = NT >= 7 || GNN_WAVES % NT == 0;
   static_assert(GNN_WAVES == 8, "the ROLL condition assumes 8 waves");
   TileRange h2;                               // my share of the last Linear (one tile: wave 0)
   h2.T = 1;
