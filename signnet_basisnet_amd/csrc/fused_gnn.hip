@@ -532,6 +532,33 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   lds_barrier();
   SN_STAMP(2);
   // ---------------------------------------------------------------- GINE layers: h lives in X1           (model.py:47-55)
+  // The in-edges of my pairs' rows do not change from layer to layer: degree, the first four source rows and their edge classes
+  // (or edge ids) are read ONCE — the aggregation of every layer then starts with its row reads instead of two dependent index
+  // round trips per pair.
+  int a_dg[4];
+  unsigned a_sr[4], a_er[4];       // four source rows (< 64) / four edge classes or edge ids (< 256), a byte each
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_dg[i] = -1;
+    a_sr[i] = 0u;
+    a_er[i] = 0u;
+    const int t = tr.t_lo + i;
+    if (t < tr.t_hi && (use_tab || use_ee)) {
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      const int row = rt * 16 + li;
+      if (row < n) {
+        const int e_lo = erow[row], dg = erow[row + 1] - e_lo;
+        a_dg[i] = dg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ei = k < dg ? e_lo + k : 0;
+          a_sr[i] |= (unsigned)(k < dg ? esrc[ei] : row) << (8 * k);
+          a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 0) << (8 * k);
+        }
+      }
+    }
+  }
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_gnn_layer& Lp = P.layers[l];
     // u = sum_{j->i} relu(h_j + e_ji) + (1+eps) h_i  for my (channel tile, row tile) pairs: X1 -> SA (split)
@@ -541,46 +568,61 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     ee_fetch(l + 1);   // next layer's edge embeddings: in flight during this aggregation
     {
       const float sc = 1.f + *Lp.eps;
-#pragma unroll 1
-      for (int t = tr.t_lo; t < tr.t_hi; ++t) {
-        int ot, rt;
-        tr.decode(t, ot, rt);
-        const int row = rt * 16 + li, c = 16 * ot + 4 * g;
-        if (row >= n) continue;
-        f32x4 u = zero4;
-        const int e_lo = erow[row], e_hi = erow[row + 1];
-
-        int e = e_lo;
-        if (use_tab || use_ee) {
-          // the first four in-edges (molecular graphs: all) with predicated, unrolled reads: index reads, then the
-          // eight row reads, then the adds in edge order (a missing edge adds +0)
-          const int dg = e_hi - e_lo;
-          int sr[4], er[4];
+      if (use_tab || use_ee) {
+        // my (up to four) pairs, one after the other; the in-edge indices of their rows were read once before the layer loop (a_*)
+        const int eoff = use_tab ? l * ncls : 0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int ei = i < dg ? e_lo + i : 0;
-            sr[i] = i < dg ? esrc[ei] : row;
-            er[i] = i < dg ? (use_tab ? l * ncls + ecls[ei] : ei) : 0;
-          }
-          f32x4 hv[4], ev[4];
+        for (int i = 0; i < 4; ++i) {
+          if (a_dg[i] >= 0) {
+            const int t = tr.t_lo + i;
+            int ot, rt;
+            tr.decode(t, ot, rt);
+            const int row = rt * 16 + li, c = 16 * ot + 4 * g, dg = a_dg[i];
+            // the first four in-edges (molecular graphs: all) with predicated, unrolled reads: the eight row reads, then the adds in
+            // edge order (a missing edge adds +0)
+            f32x4 hv[4], ev[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { hv[i] = lds_ld4(X1 + sr[i] * LD + c); ev[i] = lds_ld4(EE + er[i] * LD + c); }
-
+            for (int k = 0; k < 4; ++k) {
+              const int sr = (int)((a_sr[i] >> (8 * k)) & 255u), er = (int)((a_er[i] >> (8 * k)) & 255u);
+              hv[k] = lds_ld4(X1 + sr * LD + c);
+              ev[k] = lds_ld4(EE + (er + (k < dg ? eoff : 0)) * LD + c);
+            }
+            f32x4 u = zero4;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) u += i < dg ? relu4(hv[i] + ev[i]) : zero4;
-          e = e_lo + (dg < 4 ? dg : 4);
-        }
-        for (; e < e_hi; ++e) {
-          const f32x4 ef = use_tab ? lds_ld4(EE + (l * ncls + ecls[e]) * LD + c)
-                                   : (use_ee ? lds_ld4(EE + e * LD + c) : edge_embed(Lp, e, c));
-          u += relu4(lds_ld4(X1 + esrc[e] * LD + c) + ef);
-        }
-        {
+            for (int k = 0; k < 4; ++k) u += k < dg ? relu4(hv[k] + ev[k]) : zero4;
+            if (dg > 4) {
+              const int e_lo = erow[row], e_hi = e_lo + dg;
+              for (int e = e_lo + 4; e < e_hi; ++e) {
+                const f32x4 ef = use_tab ? lds_ld4(EE + (l * ncls + ecls[e]) * LD + c) : lds_ld4(EE + e * LD + c);
+                u += relu4(lds_ld4(X1 + esrc[e] * LD + c) + ef);
+              }
+            }
+            {
 #pragma clang fp contract(off)
-          const f32x4 self = lds_ld4(X1 + row * LD + c) * sc;
-          u = u + self;
+              const f32x4 self = lds_ld4(X1 + row * LD + c) * sc;
+              u = u + self;
+            }
+            sp_store4(SA, row, ot, g, u);
+          }
+          __builtin_amdgcn_sched_barrier(0);      // pairs stay sequential: four pairs' row reads at once would not fit the registers
         }
-        sp_store4(SA, row, ot, g, u);
+      } else {
+#pragma unroll 1
+        for (int t = tr.t_lo; t < tr.t_hi; ++t) {
+          int ot, rt;
+          tr.decode(t, ot, rt);
+          const int row = rt * 16 + li, c = 16 * ot + 4 * g;
+          if (row >= n) continue;
+          f32x4 u = zero4;
+          const int e_lo = erow[row], e_hi = erow[row + 1];
+          for (int e = e_lo; e < e_hi; ++e) u += relu4(lds_ld4(X1 + esrc[e] * LD + c) + edge_embed(Lp, e, c));
+          {
+#pragma clang fp contract(off)
+            const f32x4 self = lds_ld4(X1 + row * LD + c) * sc;
+            u = u + self;
+          }
+          sp_store4(SA, row, ot, g, u);
+        }
       }
     }
     lds_barrier();
