@@ -384,6 +384,25 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   h2.T = 1;
   h2.t_lo = 0;
   h2.t_hi = wave == 0 ? 1 : 0;
+  // The graph's own inputs are requested FIRST: the memory counter is in-order, so every later wait for one of them would also wait
+  // for whatever was issued before it — the two 15 KB weight tiles below.  One CSR row pointer, one in-edge (source, edge id) and up
+  // to four float4 of the slot sum per thread cover the whole graph (n <= 64, ne <= 192 < blockDim).
+  static_assert(GNN_EMAX <= GNN_WAVES * 64 && GNN_ROWS < GNN_WAVES * 64 && GNN_ROWS * (D / 4) <= 4 * GNN_WAVES * 64, "one pass of the block covers the graph");
+  const int tid = threadIdx.x;
+  const int rp_v = tid <= n ? S.rowptr[gs + tid] : 0;
+  const int src_v = tid < ne ? S.col[e_base + tid] : 0;
+  const int eid_v = tid < ne ? S.eperm[e_base + tid] : 0;
+  const bool rs_vec = (d & 3) == 0;
+  f32x4 rs_v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    rs_v[j] = zero4;
+    const int i = tid + j * GNN_WAVES * 64;
+    if (rs_vec && i < n * (D / 4)) {
+      const int rr = i / (D / 4), c4 = i % (D / 4);
+      if (4 * c4 < d) rs_v[j] = ld4(S.rho_sum + (int64_t)(gs + rr) * d + 4 * c4);
+    }
+  }
   if (!tr.empty()) {
     wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);                      // in flight while the inputs are staged
     if constexpr (ROLL) wload<NKB>(alt, P.lin_b, tr.first_ot(), lane);
@@ -395,10 +414,11 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   bool id_bad = false;        // a discrete feature value of this graph lies outside its embedding table
   {
     const int EF = P.edge_nf;
-    for (int k = threadIdx.x; k <= n; k += GNN_WAVES * 64) erow[k] = S.rowptr[gs + k] - e_base;
-    for (int k = threadIdx.x; k < ne; k += GNN_WAVES * 64) {
-      esrc[k] = S.col[e_base + k] - gs;
-      const int eid = S.eperm[e_base + k];
+    if (tid <= n) erow[tid] = rp_v - e_base;
+    if (tid < ne) {
+      const int k = tid;
+      esrc[k] = src_v - gs;
+      const int eid = eid_v;
       if (P.n_layers > 0) {
         if (P.edge_discrete) {
           const int64_t* ei = reinterpret_cast<const int64_t*>(S.edge_attr) + (int64_t)eid * S.lde;
@@ -420,23 +440,45 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
   if (P.n_layers > 0) {
     const int EF = P.edge_nf;
+    // lead = first edge with my feature tuple.  Every thread walks ALL the edges with block-uniform (broadcast) LDS reads and no
+    // early exit: the reads pipeline, where a scan that stops at the first match serialises one LDS round trip per candidate and
+    // the whole wave waits for the rarest class's first edge.  Leaders of the three edge waves are published as ballots; the dense
+    // class id of a leader is the number of leaders before it.
+    __shared__ unsigned long long lmask[(GNN_EMAX + 63) / 64];
     int lead = -1;
-    if ((int)threadIdx.x < ne) {
-      const int k = threadIdx.x;
-      lead = k;                                        // first edge with my feature tuple; with a handful of classes the
-      for (int j = 0; j < k; ++j) {                    // scan stops within the first few edges
-        bool same = true;
-        for (int f = 0; f < EF; ++f) same = same && (efeat[j * EF + f] == efeat[k * EF + f]);
-        if (same) { lead = j; break; }
+    if (tid < GNN_EMAX) {                              // whole waves: the ballot below needs every lane of an edge wave
+      if (tid < ne) {
+        lead = tid;
+        if (EF == 1) {
+          const int mine = efeat[tid];
+#pragma unroll 8
+          for (int j = 0; j < ne; ++j) lead = (efeat[j] == mine && j < lead) ? j : lead;
+        } else {
+          for (int j = 0; j < ne; ++j) {
+            bool same = true;
+            for (int f = 0; f < EF; ++f) same = same && (efeat[j * EF + f] == efeat[tid * EF + f]);
+            lead = (same && j < lead) ? j : lead;
+          }
+        }
+        elead[tid] = lead;
       }
-      elead[k] = lead;
+      const unsigned long long m = __ballot(tid < ne && lead == tid);
+      if (lane == 0) lmask[tid >> 6] = m;
     }
-    ncls = __syncthreads_count((int)threadIdx.x < ne && lead == (int)threadIdx.x);   // leaders = classes (ne <= 192 < blockDim)
-    if ((int)threadIdx.x < ne) {
+    __syncthreads();
+    ncls = 0;
+#pragma unroll
+    for (int w = 0; w < (GNN_EMAX + 63) / 64; ++w) ncls += __popcll(lmask[w]);
+    if (tid < ne) {
       int c = 0;
-      for (int j = 0; j < lead; ++j) c += (elead[j] == j);
-      ecls[threadIdx.x] = c;                           // dense class id = number of leaders before my leader
-      if (lead == (int)threadIdx.x && c < GNN_CLS) cedge[c] = lead;
+#pragma unroll
+      for (int w = 0; w < (GNN_EMAX + 63) / 64; ++w) {
+        const int below = lead - 64 * w;               // leaders of word w that precede my leader
+        const unsigned long long keep = below >= 64 ? ~0ull : (below > 0 ? (1ull << below) - 1 : 0ull);
+        c += __popcll(lmask[w] & keep);
+      }
+      ecls[tid] = c;                                   // dense class id = number of leaders before my leader
+      if (lead == tid && c < GNN_CLS) cedge[c] = lead;
     }
     use_tab = ncls <= GNN_CLS && P.n_layers * ncls <= S.ee_rows;
     if (use_tab) use_ee = false;
@@ -450,11 +492,14 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     }
   }
   // ---------------------------------------------------------------- stage the slot sum (rho output), split, in SA
-  if ((d & 3) == 0) {
-    for (int i = threadIdx.x; i < n * (D / 4); i += GNN_WAVES * 64) {
-      const int rr = i / (D / 4), c4 = i % (D / 4);
-      const f32x4 v = 4 * c4 < d ? ld4(S.rho_sum + (int64_t)(gs + rr) * d + 4 * c4) : zero4;
-      sp_store4(SA, rr, c4 >> 2, c4 & 3, v);
+  if (rs_vec) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + j * GNN_WAVES * 64;
+      if (i < n * (D / 4)) {
+        const int rr = i / (D / 4), c4 = i % (D / 4);
+        sp_store4(SA, rr, c4 >> 2, c4 & 3, rs_v[j]);
+      }
     }
   } else {
     for (int i = threadIdx.x; i < n * (D / 4); i += GNN_WAVES * 64) {
