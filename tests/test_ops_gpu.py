@@ -154,7 +154,7 @@ def test_pack_eig(batch):
     assert torch.equal(x0.cpu(), ev) and torch.equal(s0.cpu(), es)     # pure data movement: bit exact
 
 
-@pytest.mark.parametrize("F", [1, 37, 64, 16 * 128])
+@pytest.mark.parametrize("F", [1, 37, 64, 131, 400, 1300, 16 * 128])   # every column-group width of the gather kernel, float and float4
 @pytest.mark.parametrize("slab", [False, True])
 def test_gin_aggregate(batch, dev, F, slab):
     from oracle import pyg_signnet as O
