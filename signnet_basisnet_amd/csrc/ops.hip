@@ -465,6 +465,12 @@ __device__ __forceinline__ float4 self_term(float4 acc, float4 x, float s) {
 // thread's U nodes are issued together, neighbour k of every node in one go — with one node per workgroup the kernel was a chain
 // of dependent round trips (row pointer -> column -> row) with 4 KB in flight per workgroup and delivered 4.2 TB/s on [N, 2048]
 // (1.8 TB/s on [N, 128], where 7 of 8 threads had no column).  The additions stay in edge order per node, self term last.
+// consecutive workgroups that share an XCD (its L2 serves the neighbour reads): 128 nodes of wide rows, 512 of narrow ones
+// (measured: 32 / 128 / 512 nodes -> 5.13 / 5.18 / 4.59 TB/s on [N, 2048], 4.2 / 4.5 / 4.6 TB/s on [N, 128])
+constexpr int gin_xcd_chunk(int U, int CW) {
+  const int nodes = CW == 256 ? 128 : 512, per_wg = U * (256 / CW);
+  return nodes / per_wg > 0 ? nodes / per_wg : 1;
+}
 template <typename VT, int U, int CW>
 __global__ __launch_bounds__(256) void k_gin_gather(const VT* __restrict__ x, VT* __restrict__ out, int64_t N,
                                                     int FV, int P, const int32_t* __restrict__ rowptr,
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256) void k_gin_gather(const VT* __restrict__ x, VT
                                                     const float* __restrict__ eps, int negate) {
   constexpr int NSUB = 256 / CW;
   constexpr int KU = SN_GIN_KU;                  // neighbours of a node in flight
-  constexpr int CHUNK = (32 / (U * NSUB)) > 0 ? (32 / (U * NSUB)) : 1;
+  constexpr int CHUNK = gin_xcd_chunk(U, CW);
   const int64_t L = xcd_remap(blockIdx.x, CHUNK * P);
   const int64_t grp = L / P;
   const int part = (int)(L - grp * P);
@@ -522,7 +528,7 @@ template <typename VT, int U, int CW>
 static void launch_gin_gather(const VT* x, VT* out, int64_t N, int FV, const int32_t* rowptr, const int32_t* col, const float* eps,
                               int negate, hipStream_t st) {
   constexpr int NSUB = 256 / CW;
-  constexpr int CHUNK = (32 / (U * NSUB)) > 0 ? (32 / (U * NSUB)) : 1;
+  constexpr int CHUNK = gin_xcd_chunk(U, CW);
   const int P = CW == 256 ? (int)cdiv(FV, 256) : 1;
   const int64_t grp = (int64_t)8 * CHUNK * P;
   const int64_t nblk = cdiv(cdiv(N, (int64_t)U * NSUB) * P, grp) * grp;
