@@ -606,6 +606,9 @@ __device__ __forceinline__ float4 vrelu<float4>(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
+#ifndef SN_GINE_XCD_NODES
+#define SN_GINE_XCD_NODES 128
+#endif
 #ifndef SN_GINE_U
 #define SN_GINE_U 1
 #endif
@@ -622,8 +625,9 @@ __global__ __launch_bounds__(256) void k_gine_gather(const VT* __restrict__ x, c
                                                      const int32_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col,
                                                      const int32_t* __restrict__ eperm,
-                                                     const float* __restrict__ eps) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                     const float* __restrict__ eps, int xcd_chunk) {
+  // runs of xcd_chunk consecutive workgroups (128 / 512 consecutive nodes) share an XCD, whose L2 then serves the source rows
+  const int64_t idx = xcd_remap(blockIdx.x, xcd_chunk) * 256 + threadIdx.x;
   const int64_t ngrp = (N + GINE_U - 1) / GINE_U;
   if (idx >= ngrp * CV) return;
   const int64_t n0 = (idx / CV) * GINE_U;
@@ -1266,14 +1270,22 @@ extern "C" int sn_gine_aggregate_f32(const float* x, const float* ea, float* out
   SN_REQUIRE(x != out, "sn_gine_aggregate_f32: in-place aggregation is not supported");
   if (N == 0) return SN_OK;
   hipStream_t st = (hipStream_t)stream;
+  auto grid = [&](int cols, int& chunk) {       // workgroups, padded to whole XCD rounds (the kernel drops the tail)
+    const int64_t nodes = cols >= 64 ? SN_GINE_XCD_NODES : 4 * SN_GINE_XCD_NODES;
+    chunk = (int)std::max<int64_t>(1, nodes * cols / (256 * GINE_U));
+    const int64_t round = (int64_t)8 * chunk;
+    return dim3((unsigned)(cdiv(cdiv(cdiv(N, GINE_U) * cols, 256), round) * round));
+  };
+  int chunk = 1;
   if (C % 4 == 0 && al16(x) && al16(ea) && al16(out)) {
-    int CV = C / 4;
-    hipLaunchKernelGGL((k_gine_gather<float4>), dim3((unsigned)cdiv(cdiv(N, GINE_U) * CV, 256)), dim3(256), 0, st,
+    const int CV = C / 4;
+    const dim3 g = grid(CV, chunk);
+    hipLaunchKernelGGL((k_gine_gather<float4>), g, dim3(256), 0, st,
                        reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(ea),
-                       reinterpret_cast<float4*>(out), N, CV, rowptr, col, eperm, eps);
+                       reinterpret_cast<float4*>(out), N, CV, rowptr, col, eperm, eps, chunk);
   } else {
-    hipLaunchKernelGGL((k_gine_gather<float>), dim3((unsigned)cdiv(cdiv(N, GINE_U) * C, 256)), dim3(256), 0, st, x, ea, out, N, C,
-                       rowptr, col, eperm, eps);
+    const dim3 g = grid(C, chunk);
+    hipLaunchKernelGGL((k_gine_gather<float>), g, dim3(256), 0, st, x, ea, out, N, C, rowptr, col, eperm, eps, chunk);
   }
   SN_CHECK_LAUNCH("sn_gine_aggregate_f32");
   return SN_OK;
