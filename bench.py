@@ -525,7 +525,13 @@ def scatter_measure(dev, graphs, feat, kind, steps=20, warmup=5, base=None):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"kernel": name, "graphs": base.num_graphs * reps, "nodes": N, "edges": E, "mean_launch_us": 1e3 * ms,
+    traffic = None          # HBM bytes of this very launch from the committed PMC passes (profiles/hbm_traffic.json), if it is one of them
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
+            traffic = json.load(fh)["scatter"]["launches"][str(byt)]["bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"kernel": name, "graphs": base.num_graphs * reps, "nodes": N, "edges": E, "mean_launch_us": 1e3 * ms, "traffic": traffic,
             "algorithmic_bytes": byt, "working_set_mib": byt / 2 ** 20, "bound": "hbm", "achieved": byt / ms / 1e6, "unit": "GB/s",
             "peak": HBM_PEAK_GBS, "frac": byt / ms / 1e6 / HBM_PEAK_GBS}
 
@@ -540,7 +546,7 @@ def scatter_roofline(dev):
     gin = scatter_measure(dev, 1024, 2048, "gin", base=base)
     gine = scatter_measure(dev, 6144, 128, "gine", base=base)
     return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": gin["achieved"], "frac": gin["frac"],
-            "kernel": gin["kernel"], "target_frac": 0.40, "gin": gin, "gine": gine,
+            "traffic": gin["traffic"], "kernel": gin["kernel"], "target_frac": 0.40, "gin": gin, "gine": gine,
             "note": "achieved = algorithmic bytes / mean launch time (HIP events on the launch stream); working sets > 256 MiB so that "
                     "the Infinity Cache cannot serve them"}
 
