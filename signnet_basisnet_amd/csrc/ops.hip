@@ -1478,17 +1478,22 @@ extern "C" int sn_segment_pool_f32(const float* x, int64_t B, int C, const int32
 // Replaces contractions_2_to_1 (LearningFilters/ign.py:344-374, normalization 'inf') for X [b, n, n]:
 //   ops[b, i, :] = [ X_ii, tr(X)/n, rowsum_i/n, colsum_i/n, sum(X)/n^2 ]        (row-major [b, n, 5])
 // HBM-bound: every X element is read exactly once (4*b*n^2 bytes).  Stage A: one workgroup per (matrix,
-// 32-row strip) — row sums finished in the block, column sums as per-strip partials (deterministic, no float
+// 64- or 128-row strip) — row sums finished in the block, column sums as per-strip partials (deterministic, no float
 // atomics).  Stage B: one workgroup per matrix folds the partials.
 namespace sn {
-constexpr int IGN_STRIP = 32;
+// rows per workgroup: 128 for n >= 512, 64 below (the scratch is sized for 64).  A workgroup pays a fixed price — start-up, eight
+// barriers of the column fold, the partials' store — per strip: with 32-row strips the 2 GB launch of the grid ran at 4.5 TB/s,
+// with 64 / 128 rows 4.9-5.3 / 5.1-5.4 (64 x 1024^2: 3.4 / 4.2 / 4.8 TB/s; 2048 x 256^2: 4.4 / 4.5-4.7 / 4.2-4.3).
+constexpr int IGN_STRIP_MIN = 64;
+__host__ __device__ constexpr int ign_strip(int n) { return n >= 512 ? 128 : IGN_STRIP_MIN; }
 
 __global__ __launch_bounds__(256) void k_ign_rowcol(const float* __restrict__ X, int n, int nstrips,
                                                     float* __restrict__ rowsum /* [b,n] */, float* __restrict__ diag /* [b,n] */,
                                                     float* __restrict__ colpart /* [b,nstrips,n] */) {
   __shared__ float red[4];
   const int b = blockIdx.x / nstrips, st = blockIdx.x - b * nstrips;
-  const int r0 = st * IGN_STRIP, r1 = (r0 + IGN_STRIP < n) ? r0 + IGN_STRIP : n;
+  const int strip = ign_strip(n);
+  const int r0 = st * strip, r1 = (r0 + strip < n) ? r0 + strip : n;
   const float* Xb = X + (int64_t)b * n * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c0 = 0; c0 < n; c0 += 256 * 4) {          // column panels of 1024
@@ -1530,7 +1535,8 @@ __global__ __launch_bounds__(256) void k_ign_rowcol_v4(const float* __restrict__
                                                        float* __restrict__ colpart) {
   __shared__ float4 fold[4][256];
   const int b = blockIdx.x / nstrips, st = blockIdx.x - b * nstrips;
-  const int r0 = st * IGN_STRIP, r1 = (r0 + IGN_STRIP < n) ? r0 + IGN_STRIP : n;
+  const int strip = ign_strip(n);
+  const int r0 = st * strip, r1 = (r0 + strip < n) ? r0 + strip : n;
   const float* Xb = X + (int64_t)b * n * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c0 = 0; c0 < n; c0 += 1024) {
@@ -1634,13 +1640,13 @@ __global__ __launch_bounds__(256) void k_ign_finish(const float* __restrict__ ro
 }  // namespace sn
 
 extern "C" int64_t sn_ign_contract_scratch_floats(int64_t b, int n) {
-  return b * (2 * (int64_t)n + sn::cdiv(n, sn::IGN_STRIP) * (int64_t)n);
+  return b * (2 * (int64_t)n + sn::cdiv(n, sn::IGN_STRIP_MIN) * (int64_t)n);
 }
 
 extern "C" int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, float* scratch, void* stream) {
   SN_REQUIRE(X && ops_out && scratch && b >= 0 && n > 0, "sn_ign_contract_2to1_f32: bad arguments");
   if (b == 0) return SN_OK;
-  const int nstrips = (int)sn::cdiv(n, sn::IGN_STRIP);
+  const int nstrips = (int)sn::cdiv(n, sn::ign_strip(n));
   SN_REQUIRE(b * nstrips < (1ll << 31), "sn_ign_contract_2to1_f32: too many workgroups");
   float* rowsum = scratch;
   float* diag = scratch + b * n;
