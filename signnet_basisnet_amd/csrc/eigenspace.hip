@@ -94,7 +94,31 @@ __global__ __launch_bounds__(256) void k_eig_group(const float* __restrict__ eig
 constexpr int PROJ_TI = 64;     // rows of P per workgroup
 constexpr int PROJ_KC = 32;     // eigenvectors of an eigenspace per pass (held in registers)
 
-// P_s[i, j] = sum_k V[i, k0+k] V[j, k0+k]; grid (n_spaces, ceil(N / 64)); thread t owns columns j = j0 + t of a 256-wide strip
+// one pass over the tile with KCC <= PROJ_KC eigenvectors in registers
+template <int KCC>
+__device__ __forceinline__ void proj_pass(const float* __restrict__ V, int N, int ldv, int kbase, int mc, int i0, bool first,
+                                          const float (&A)[PROJ_TI][PROJ_KC + 1], float* __restrict__ P) {
+  for (int j0 = 0; j0 < N; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    float b[KCC];
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) b[k] = (j < N && k < mc) ? V[(int64_t)j * ldv + kbase + k] : 0.f;
+    if (j < N) {
+      for (int ii = 0; ii < PROJ_TI && i0 + ii < N; ++ii) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KCC; ++k) acc += A[ii][k] * b[k];
+        float* o = P + (int64_t)(i0 + ii) * N + j;
+        *o = first ? acc : *o + acc;       // eigenspaces wider than 32: later passes accumulate into the first one's tile
+      }
+    }
+  }
+}
+
+// P_s[i, j] = sum_k V[i, k0+k] V[j, k0+k]; grid (n_spaces, ceil(N / 64)); thread t owns columns j = j0 + t of a 256-wide strip.
+// The pass is instantiated for 2 / 4 / 8 / 32 eigenvectors and picked per eigenspace (block-uniform): the products of the zero
+// padding up to 32 cost 16x the useful work on a grid graph, whose eigenspaces have multiplicity 1-2 — the kernel then wrote its
+// 2 GB at 1.65 TB/s.
 __global__ __launch_bounds__(256) void k_eig_projectors(const float* __restrict__ V, int N, int ldv, const int32_t* __restrict__ space_start,
                                                         const int32_t* __restrict__ space_slot, float* __restrict__ out) {
   __shared__ float A[PROJ_TI][PROJ_KC + 1];
@@ -109,21 +133,10 @@ __global__ __launch_bounds__(256) void k_eig_projectors(const float* __restrict_
       A[ii][k] = (i0 + ii < N && k < mc) ? V[(int64_t)(i0 + ii) * ldv + k0 + kc + k] : 0.f;
     }
     __syncthreads();
-    for (int j0 = 0; j0 < N; j0 += 256) {
-      const int j = j0 + threadIdx.x;
-      float b[PROJ_KC];
-#pragma unroll
-      for (int k = 0; k < PROJ_KC; ++k) b[k] = (j < N && k < mc) ? V[(int64_t)j * ldv + k0 + kc + k] : 0.f;
-      if (j < N) {
-        for (int ii = 0; ii < PROJ_TI && i0 + ii < N; ++ii) {
-          float acc = 0.f;
-#pragma unroll
-          for (int k = 0; k < PROJ_KC; ++k) acc += A[ii][k] * b[k];
-          float* o = P + (int64_t)(i0 + ii) * N + j;
-          *o = kc == 0 ? acc : *o + acc;       // eigenspaces wider than 32: later passes accumulate into the first one's tile
-        }
-      }
-    }
+    if (mc <= 2) proj_pass<2>(V, N, ldv, k0 + kc, mc, i0, kc == 0, A, P);
+    else if (mc <= 4) proj_pass<4>(V, N, ldv, k0 + kc, mc, i0, kc == 0, A, P);
+    else if (mc <= 8) proj_pass<8>(V, N, ldv, k0 + kc, mc, i0, kc == 0, A, P);
+    else proj_pass<PROJ_KC>(V, N, ldv, k0 + kc, mc, i0, kc == 0, A, P);
   }
 }
 
