@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_embedding_bwd_reduce(const float* __res
 // rows per chunk: 256 unless that makes more than ~4096 workgroups for this table
 inline int embedding_bwd_rpc(int64_t R, int64_t V) {
   int64_t rpc = 256;
-  while (cdiv(R, rpc) * V > 4096) rpc *= 2;
+  while (rpc < R && cdiv(R, rpc) * V > 4096) rpc *= 2;   // rpc >= R: one chunk, V workgroups (V > 4096 never met the bound)
   return (int)rpc;
 }
 // out[0] = sum_i a[i]*b[i]   (two stages, deterministic)

@@ -44,10 +44,6 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 //   lane l supplies A[i = l&15][g = l>>4] and B[g = l>>4][j = l&15];
 //   lane l holds D[i = 4*(l>>4) + r][j = l&15] in acc[r].
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 acc) {
-#ifdef SN_EXP_LIN_NOMFMA      // timing experiments only: operands stay alive, no matrix work
-  acc[0] += a * b;
-  return acc;
-#endif
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 }
 

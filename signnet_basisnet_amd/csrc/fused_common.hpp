@@ -218,12 +218,10 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW, RING>& ring, const v
   for (int i = 0; i < RING; ++i) sl[i] = ring.slot_of(i);
   auto slot = [&](int c) { return sl[c % RING]; };   // c is a compile-time constant
   auto stage = [&](int ot) {   // after the barrier of step ot: refill the slot of chunk ot with chunk ot + RING
-#ifndef SN_EXP_NODMA
     if (CHAIN) {
       const int pc = ot + RING;
       if (pc < NTO) ring.issue(w, pc, slot(ot)); else ring.issue(wnext, pc - NTO, slot(ot));
     }
-#endif
   };
   if (live) {
     int ln16 = ring.lane * 16;
@@ -232,22 +230,12 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW, RING>& ring, const v
     auto rd = [&](int c, int kb) {
       const lds_char_t* p = lbase + slot(c) * R::CHUNK + kb * 3072;
       WFrag f;
-#ifdef SN_EXP_NORD
-      f.h = u32x4{(unsigned)c, (unsigned)kb, 1u, 2u}; f.m = f.h; f.l = f.h;      // no LDS traffic
-      asm volatile("" : "+v"(f.h), "+v"(f.m), "+v"(f.l));
-      (void)p;
-      return f;
-#endif
       f.h = *(lds_u32x4*)(p);
       f.m = *(lds_u32x4*)(p + 1024);
       f.l = *(lds_u32x4*)(p + 2048);
       return f;
     };
     auto mm = [&](const WFrag& f, const Split8& x, f32x4& a0, f32x4& a1) {
-#ifdef SN_EXP_NOMFMA
-      a0[0] += __uint_as_float(f.h[0] ^ x.h[0]);      // keeps the operands alive, no matrix work
-      return;
-#endif
       if (!SWAP) {
         a1 = mfma_bf(f.l, x.h, a1);
         a0 = mfma_bf(f.m, x.h, a0);
@@ -287,9 +275,7 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW, RING>& ring, const v
         // all my reads of chunk ot are complete and my share of chunk ot+1 has landed -> barrier -> refill the slot
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         wait_vmcnt<(RING - 2) * R::LPC>();
-#ifndef SN_EXP_NOBAR
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
         stage(ot);
       }

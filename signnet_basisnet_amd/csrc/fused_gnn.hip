@@ -86,20 +86,8 @@ __device__ __forceinline__ void wload(WSplit<NKB>& p, const void* wsp, int ot, i
   const __amdgpu_buffer_rsrc_t rs = weight_rsrc(reinterpret_cast<const float*>(wsp), 0x7fffffff);
   const int voff = lane * 16;
   const int base = __builtin_amdgcn_readfirstlane(ot * NFE * 1024);
-#ifdef SN_EXP_NOWLOAD
-  (void)rs; (void)voff; (void)base;
-  return;
-#endif
-#ifdef SN_EXP_W23          // timing experiment: two thirds of the fragment bytes (the l plane is not fetched)
-#pragma unroll
-  for (int i = 0; i < 3 * NKB; ++i)
-    if (i % 3 != 2) p.f[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + i * 1024, 0);
-#pragma unroll
-  for (int i = 2; i < 3 * NKB; i += 3) p.f[i] = p.f[i - 1];
-#else
 #pragma unroll
   for (int i = 0; i < 3 * NKB; ++i) p.f[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + i * 1024, 0);
-#endif
 #pragma unroll
   for (int j = 0; j < SPLIT_EPI; ++j) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (3 * NKB + j) * 1024, 0);
@@ -120,10 +108,6 @@ struct TileRange {
 template <int NKB>
 __device__ __forceinline__ f32x4 mfma_split_tile(const WSplit<NKB>& w, const Split8 (&x)[NKB]) {
   f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#ifdef SN_EXP_NOMFMA
-  a0[0] = __uint_as_float(w.f[0][0] ^ x[0].h[0]);     // timing experiments only: operands kept alive, no matrix work
-  return a0;
-#endif
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     const u32x4 wh = w.f[3 * kb], wm = w.f[3 * kb + 1], wl = w.f[3 * kb + 2];
@@ -159,9 +143,6 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
   const bool two_ots = otl != ot0;
   const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE + (lane >> 4) * 16;
   auto load_rows = [&](int rt, Split8 (&x)[NKB]) {
-#ifdef SN_EXP_NOROWS
-    return;
-#endif
     const unsigned char* p = rowbase + rt * 16 * SP_STRIDE;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {

@@ -250,11 +250,6 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
           const float* n2 = X + (deg > 2 ? (int)((nb8.x >> 16) & 255u) : r) * LD + 4 * g;
           const float* n3 = X + (deg > 3 ? (int)(nb8.x >> 24) : r) * LD + 4 * g;
           const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-#ifdef SN_EXP_NOGATHER
-#pragma unroll
-          for (int kk = 0; kk < NT; ++kk) o[kk] = zero4;
-          if (false)
-#endif
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
             const f32x4 v0 = lds_ld4(n0 + 16 * kk), v1 = lds_ld4(n1 + 16 * kk);

@@ -266,9 +266,7 @@ __global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t
     valid = row_valid(gw * 16 + (lane & 15));
     fetch(gw, valid, in);
   }
-#ifndef SN_EXP_LIN_NOSTAGE
   for (int i = threadIdx.x; i < nw4; i += 64 * LIN_W) wl[i] = a.wp[i];
-#endif
   __syncthreads();
   for (int64_t tile = gw; tile < ntiles; tile += nwv) {
     const int64_t row = tile * 16 + (lane & 15);
@@ -320,11 +318,7 @@ __global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t
         if (a.flags & SN_EPI_RELU) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         if (a.flags & SN_EPI_RESIDUAL) v += load4<true>(a.res + row * a.ldr, o0, a.d_out);
       }
-#ifdef SN_EXP_LIN_NOSTORE
-      if (inr && v[0] == 1.2345f) store4<true>(yr, o0, a.d_out, v);
-#else
       if (inr) store4<true>(yr, o0, a.d_out, v);
-#endif
       if (STATS) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -249,18 +249,23 @@ class _FusedDeepSigns:
         return y, z
 
 
-def _max_nodes(g):
-    """Largest graph of the batch (the stage kernels keep a whole graph in one 64-row bin column).  Free when batch_num_nodes() is a
-    host tensor, one scalar read otherwise; cached on the graph object."""
-    m = getattr(g, "_sn_max_nodes", None)
-    if m is None:
+def _node_counts(g):
+    """(largest graph, total nodes) of the batch, read ONCE per graph object — free when batch_num_nodes() is a host tensor, one
+    two-scalar read otherwise — and cached on it."""
+    mc = getattr(g, "_sn_node_counts", None)
+    if mc is None:
         bnn = g.batch_num_nodes()
-        m = int(bnn.max()) if bnn.numel() else 0
+        mc = tuple(int(v) for v in torch.stack([bnn.max(), bnn.sum()]).tolist()) if bnn.numel() else (0, 0)
         try:
-            g._sn_max_nodes = m
+            g._sn_node_counts = mc
         except Exception:
             pass
-    return m
+    return mc
+
+
+def _max_nodes(g):
+    """Largest graph of the batch (the stage kernels keep a whole graph in one 64-row bin column)."""
+    return _node_counts(g)[0]
 
 
 def cached_plan(g, N, k=None):
@@ -283,7 +288,9 @@ def cached_plan(g, N, k=None):
     src, dst = g.edges()
     bnn = g.batch_num_nodes().to(src.device)
     B = int(bnn.numel())
-    # index plumbing only; output_size spares the host read of sum(bnn) (a wrong N shows up as status bits of the plan)
+    total = _node_counts(g)[1]
+    if total != N:            # repeat_interleave(output_size=N) trusts N: a mismatch would be an uninitialised tail or a write past it
+        raise ValueError(f"batch_num_nodes() sums to {total} but the feature matrix has {N} rows")
     batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn, output_size=N)
     ei = torch.stack([src.long(), dst.long()])
     plan = ops.build_plan(batch.long(), ei, B, -int(k), bins=True) if k else ops.build_plan(batch.long(), ei, B, 0)

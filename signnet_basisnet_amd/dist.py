@@ -3,8 +3,8 @@
 The forward of SignNet+GINE never mixes graphs (every aggregation is within a graph, pooling is per
 graph, eval-mode BatchNorm uses fixed statistics — SURVEY.md §8(e)), so N ranks simply own disjoint
 contiguous ranges of graphs.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU) is used
-only for the start/stop barrier and the max-over-ranks step time; a gradient all-reduce would go here
-once the backward exists.
+only for the start/stop barrier and the max-over-ranks step time.  The training variant (BASELINE config 4) adds the
+gradient all-reduce of `optim.FlatAdam` (flat fp32 buckets, SUM over RCCL, overlapped with the rest of the backward).
 """
 from __future__ import annotations
 
@@ -40,6 +40,9 @@ def shard_range(num_graphs: int, rank: int, world: int, work=None):
     while len(bounds) < world:
         bounds.append(num_graphs)
     bounds.append(num_graphs)
+    if num_graphs >= world:       # never an empty rank when there is a graph for everyone (one heavy graph must not starve a rank)
+        for r in range(1, world):
+            bounds[r] = min(max(bounds[r], bounds[r - 1] + 1, r), num_graphs - (world - r))
     return bounds[rank], bounds[rank + 1]
 
 

@@ -45,11 +45,19 @@ class Adam:
 class FlatAdam:
     """Adam over ONE flat parameter buffer: every parameter's storage and gradient become views into two contiguous fp32
     buffers, so a step is a single kernel launch over the whole model and — with `dist` (torch.distributed, RCCL on ROCm) —
-    the data-parallel gradient exchange is a single SUM all-reduce of the flat gradient (the few MB of this model fit one
-    xGMI-friendly message; the 1/world averaging is folded into the Adam kernel's gradient read).
+    the data-parallel gradient exchange of BASELINE config 4 is a handful of SUM all-reduces over contiguous BUCKETS of the flat
+    gradient (`bucket_mb` each, parameter order), the 1/world averaging folded into the Adam kernel's gradient read.
+
+    Overlap with the backward: autograd finishes the gradients roughly in reverse parameter order — the
+    GINE stack and its embedding tables (most of the bytes) long before phi — so a bucket's all-reduce is issued, asynchronously
+    on RCCL's stream, by the post-accumulate hook of its LAST gradient while the rest of the backward is still running; `step()`
+    waits for all of them.  Which parameters receive a gradient is learned from the first step (the reference registers modules
+    its forward never uses: `GNN3d.edge_encoders`, `SetTransformer.pos_encoder`, core/sign_net.py:22,54); a bucket whose set is
+    not complete when `step()` is called is reduced there, so the result never depends on the overlap.  xGMI is point-to-point
+    (7 links x ~153 GB/s): a ring all-reduce of this model's 27.6 MB is ~0.3 ms per-link bound, hence few, large buckets.
     Build it AFTER `model.to(device)`; use its own `zero_grad()` (the .grad views must stay attached)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, dist=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, dist=None, bucket_mb=8.0, overlap=True):
         seen, self.params = set(), []
         for p in params:
             if p.requires_grad and id(p) not in seen:
@@ -63,25 +71,75 @@ class FlatAdam:
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m, self.v = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
         off = 0
+        cap = max(1, int(float(bucket_mb) * (1 << 20) / 4))
+        self.buckets, self._bucket_of = [[0, 0]], []          # [lo, hi) float ranges of the flat buffers, parameter order
         with torch.no_grad():
             for p in self.params:
                 n = p.numel()
                 self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[off:off + n].view(p.shape)
                 p.grad = self.flat_g[off:off + n].view(p.shape)
+                if self.buckets[-1][1] - self.buckets[-1][0] >= cap:
+                    self.buckets.append([off, off])
+                self.buckets[-1][1] = off + n
+                self._bucket_of.append(len(self.buckets) - 1)
                 off += n
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.dist, self.t = dist, 0
         self.param_groups = [{"params": self.params, "lr": self.lr}]
+        nb = len(self.buckets)
+        self._fired = [set() for _ in range(nb)]       # parameters of the bucket whose gradient has arrived in this backward
+        self._expect = [None] * nb                     # the set of the previous step (None: not learned yet)
+        self._work = [None] * nb                       # in-flight all-reduce of the bucket
+        self.early_launches = 0                        # buckets whose all-reduce was issued from inside the backward (last step)
+        self._hooks = []
+        if dist is not None and overlap and hasattr(self.params[0], "register_post_accumulate_grad_hook"):
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        b = self._bucket_of[i]
+
+        def hook(_param):
+            if self._work[b] is not None:
+                raise RuntimeError("FlatAdam: a gradient arrived in a bucket whose all-reduce was already issued (the set of "
+                                   "parameters used by the forward changed between steps); construct with overlap=False")
+            self._fired[b].add(i)
+            if self._expect[b] is not None and self._fired[b] == self._expect[b]:
+                self._launch(b)
+                self.early_launches += 1
+        return hook
+
+    def _launch(self, b):
+        lo, hi = self.buckets[b]
+        self._work[b] = self.dist.all_reduce(self.flat_g[lo:hi], async_op=True)
 
     def zero_grad(self, set_to_none=False):
+        self._finish()
         self.flat_g.zero_()
 
+    def _finish(self):
+        for b, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[b] = None
+
     def all_reduce_gradients(self):
-        """SUM over the data-parallel ranks; returns the scale that turns the sum into the mean."""
-        if self.dist is None or self.dist.get_world_size() == 1:
+        """SUM over the data-parallel ranks (buckets not yet issued by the backward hooks are issued here, then all are waited
+        for); returns the scale that turns the sum into the mean.  With a process group the collective always runs, also at
+        world size 1 (RCCL init and ncclAllReduce are then exercised on a one-GPU box)."""
+        if self.dist is None:
             return 1.0
-        self.dist.all_reduce(self.flat_g)
+        early = sum(w is not None for w in self._work)
+        for b in range(len(self.buckets)):
+            if self._work[b] is None:
+                self._launch(b)
+        self._finish()
+        for b in range(len(self.buckets)):
+            if self._hooks:
+                self._expect[b] = self._fired[b] if self._fired[b] else None
+            self._fired[b] = set()
+        self.early_launches = early
         return 1.0 / self.dist.get_world_size()
 
     @torch.no_grad()

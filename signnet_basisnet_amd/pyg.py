@@ -302,12 +302,14 @@ class SignNetGNN(nn.Module):
         self.use_fused = True       # whole-stage kernels (eval mode); False = layer-at-a-time kernels only
         # Fused stages require graphs of <= 64 nodes (and <= 192 edges for the GINE stage); a batch that violates this, a
         # malformed batch, or a discrete feature value outside its embedding table raises device-side flags.
-        #   strict=True : the flags are read after every forward (one host sync); an oversize batch is re-run on the layer
-        #                 path, anything else raises immediately — the reference's behaviour, at the price of the sync.
-        #   strict=False: (default) no sync.  The outputs of every graph that could not be evaluated are NaN (never
-        #                 uninitialised memory: the GINE kernel fills them), and the error itself is raised at the next
-        #                 forward, at check_last(), at train()/eval() or when the module is deleted, whichever comes first.
-        self.strict = False
+        #   strict=True : (default) the flags are read after every forward (the GINE kernel writes them to pinned memory: one
+        #                 host wait, no event); an oversize batch is re-run on the layer path, anything else raises on the
+        #                 spot — every input the reference evaluates is evaluated, errors are the reference's errors.
+        #   strict=False: the serving / throughput mode (bench.py): no host wait.  The outputs of every graph that could not
+        #                 be evaluated are NaN (never uninitialised memory: the GINE kernel fills them), and the error itself
+        #                 is raised at the next forward, at check_last() or at train()/eval(), whichever comes first (a
+        #                 module deleted with an unreported error warns).
+        self.strict = True
         # train-mode dropout of the attention probabilities (ScaledDotProductAttention's default attn_dropout=0.1,
         # transformer_module.py:46-55 — the only dropout the reference leaves active); 0.0 switches it off
         self.attn_dropout = 0.1
@@ -327,8 +329,9 @@ class SignNetGNN(nn.Module):
     # cache invalidation: packed weights depend on parameters, buffers, device and mode
     def train(self, mode=True):
         self._prep = None
+        out = super().train(mode)       # switch the whole tree first: a pending error must not leave it half-switched
         self._drain_status()
-        return super().train(mode)
+        return out
 
     def _apply(self, fn, *a, **k):
         self._prep = None
@@ -345,11 +348,16 @@ class SignNetGNN(nn.Module):
         self._prep = None
 
     def __del__(self):
+        # Python never propagates an exception out of __del__: an unreported error of the last batch is WARNED about here
         try:
             if self._pending:
                 self._drain_status()
-        except RuntimeError:
-            raise
+        except (RuntimeError, IndexError, ValueError) as e:
+            try:
+                import warnings
+                warnings.warn(f"SignNetGNN deleted with an unreported device error: {e}", RuntimeWarning)
+            except Exception:
+                pass
         except Exception:               # interpreter shutdown etc.
             pass
 
@@ -608,7 +616,8 @@ class SignNetGNN(nn.Module):
         oe = g.output_encoder
         y = lin_bn(pooled, oe.layers[0], oe.norms[0])
         y = AG.linear(y, oe.layers[1].weight, oe.layers[1].bias)
-        if isinstance(g.input_encoder, DiscreteEncoder) and int(plan.status[5]):     # one sync per training step
+        discrete = isinstance(g.input_encoder, DiscreteEncoder) or any(isinstance(e, DiscreteEncoder) for e in g.edge_encoders)
+        if discrete and int(plan.status[5]):     # one sync per training step; node OR edge tables (nn.Embedding raises for either)
             raise IndexError(ops.EMBEDDING_INDEX_ERROR)
         return y
 
@@ -714,7 +723,7 @@ class SignNetGNN(nn.Module):
         pooled = ops.segment_pool(h, plan, self.gnn.pooling)
         y = _lin_bn(pooled, P["head"]["l0"], P["head"]["bn0"], train, relu=True)
         y = ops.masked_linear(y, P["head"]["l1"])
-        if "in_tabs" in P and int(plan.status[5]):      # layer path only (train mode / return_stages / fallback): one host sync
+        if ("in_tabs" in P or any("tabs" in d for d in P["gine"])) and int(plan.status[5]):      # layer path only (train mode / return_stages / fallback): one host sync
             raise IndexError(ops.EMBEDDING_INDEX_ERROR)
         if return_stages:
             stages["y"] = y

@@ -247,6 +247,15 @@ def test_embedding_and_pool_backward():
     assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
     ref = torch.zeros(500, 128, dtype=torch.float64).index_add_(0, big[:, 0].cpu(), up.cpu().double())
     close(grads[0], ref, "embedding table gradient", 1e-5)
+    # a table with more rows than the workgroup budget of the chunking (vocab 5000 > 4096: the rows-per-chunk loop of
+    # embedding_bwd_rpc did not terminate there and divided by zero; the entry point accepts up to 65535 rows)
+    bigv = torch.randint(0, 5000, (1000, 1), generator=g).to(DEV)
+    tabv = torch.randn(5000, 12, generator=g)
+    upv = torch.randn(1000, 12, generator=g).to(DEV)
+    t = leaf(tabv, DEV)
+    (AG.embedding_sum(bigv, [t]) * upv).sum().backward()
+    refv = torch.zeros(5000, 12, dtype=torch.float64).index_add_(0, bigv[:, 0].cpu(), upv.cpu().double())
+    close(t.grad, refv, "embedding table gradient, vocabulary 5000", 1e-5)
     sizes = [5, 1, 17, 30, 9]
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     plan = ops.build_plan(batch.to(DEV), torch.zeros(2, 0, dtype=torch.int64, device=DEV), len(sizes), 0)

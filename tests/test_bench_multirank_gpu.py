@@ -38,3 +38,19 @@ def test_train_bench_two_ranks_allreduces_the_flat_gradient():
     assert d["n_gpus"] == 2 and d["value"] > 0
     g = d["distributed"]
     assert g["world_size"] == 2
+
+
+def test_plain_python_launch_reexecs_under_torchrun():
+    """`python bench.py --gpus 2` (no launcher, no WORLD_SIZE) re-executes itself under torch.distributed.run — the driver's
+    scaling run may start it either way.  Same one-GPU arrangement as above (gloo, both ranks on cuda:0)."""
+    env = dict(os.environ, SN_BENCH_BACKEND="gloo", SN_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+           "--no-scatter", "--streams", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["distributed"]["world_size"] == 2

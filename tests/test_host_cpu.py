@@ -84,6 +84,9 @@ def test_work_balanced_shard_ranges():
             assert max(loads) - min(loads) <= 2 * max(work), (k, W, loads)
             by_count = [sum(work[l:h]) for l, h in (dist.shard_range(len(sizes), r, W) for r in range(W))]
             assert max(loads) <= max(by_count) + max(work)
+    # one heavy graph must not starve a rank: no empty range while there is a graph for everyone
+    assert [dist.shard_range(4, r, 4, [100, 1, 1, 1]) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert all(h > l for l, h in (dist.shard_range(6, r, 3, [1, 1, 1, 1, 1, 100]) for r in range(3)))
     # degenerate inputs
     assert dist.shard_range(3, 0, 8, [5, 1, 1])[0] == 0
     assert [dist.shard_range(3, r, 8, [5, 1, 1]) for r in range(8)][-1][1] == 3

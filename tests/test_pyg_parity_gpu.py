@@ -153,9 +153,9 @@ def test_oversize_graph_is_flagged_and_served_by_the_layer_path():
     yref = O.signnet_gnn(sd, O.make_cfg("gine", *ctor), data, training=False, max_k=8)
     model = model.cuda().eval()
     dd = synth.batch_to(data, "cuda:0")
-    model.strict = True
+    assert model.strict, "the safe mode is the default: every input the reference evaluates is evaluated"
     close(model(dd), yref, "strict mode (layer-path fallback)")
-    model.strict = False
+    model.strict = False                        # the serving mode: no host wait
     y = model(dd)                               # flags raised on the device, reported late ...
     torch.cuda.synchronize()
     assert torch.isnan(y).all(), "a batch the fused kernels cannot serve must come back as NaN, never as uninitialised memory"
@@ -180,6 +180,7 @@ def test_feature_id_outside_the_embedding_table_raises_like_nn_embedding():
     from signnet_basisnet_amd.pyg import SignNetGNN
     torch.manual_seed(0)
     model = SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
+    model.strict = False
     host = synth.make_batch(5, seed=12)
     good = synth.batch_to(host, "cuda:0")
     with torch.no_grad():
@@ -225,6 +226,9 @@ def test_malformed_batch_comes_back_as_nan_and_raises():
     model = SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
     host = synth.make_batch(4, seed=3)
     host.batch = host.batch.flip(0).contiguous()               # not sorted
+    with pytest.raises(ValueError, match="malformed"), torch.no_grad():      # default (strict): on the spot
+        model(synth.batch_to(host, "cuda:0"))
+    model.strict = False
     with torch.no_grad():
         y = model(synth.batch_to(host, "cuda:0"))
     torch.cuda.synchronize()

@@ -88,22 +88,33 @@ def _grad_worker(rank, world, port, q):
     cfg = G.pyg_cfg(fx)
     data = synth.make_batch(6, seed=22, sizes=[5, 9, 4, 12, 6, 7])
 
-    def grads_of(batch):
+    def names_of(fx_):
+        return [k for k, v in fx_.sd.items() if v.is_floating_point() and "running" not in k]
+
+    def grads_of(batch, dist_=dist):
         sd = {k: (torch.nn.Parameter(v.clone()) if v.is_floating_point() and "running" not in k else v.clone())
               for k, v in fx.sd.items()}
         names = [k for k, v in sd.items() if isinstance(v, torch.nn.Parameter)]
-        opt = optim.FlatAdam([sd[k] for k in names], dist=dist)          # CPU tensors: only the gradient plumbing is used here
+        # CPU tensors: only the gradient plumbing is used here; small buckets so that this tiny model has several
+        opt = optim.FlatAdam([sd[k] for k in names], dist=dist_, bucket_mb=0.004)
         O.signnet_gnn(sd, cfg, batch, training=False).sum().backward()   # eval-mode BN: graphs do not interact
         return opt
 
     opt = grads_of(D.shard_batch(data, rank, world))
-    scale = opt.all_reduce_gradients()                                   # ONE all-reduce of the flat gradient
+    scale = opt.all_reduce_gradients()                                   # first step: every bucket reduced here (sets learned)
     summed = opt.flat_g.clone()
+    # second backward on the SAME optimiser: the hooks issue each bucket's all-reduce from inside the backward
+    sd2 = {k: v for k, v in zip(names_of(fx), opt.params)}
+    opt.zero_grad()
+    O.signnet_gnn({**fx.sd, **sd2}, cfg, D.shard_batch(data, rank, world), training=False).sum().backward()
+    early_before_step = sum(w is not None for w in opt._work)
+    opt.all_reduce_gradients()
+    summed2 = opt.flat_g.clone()
     dist.barrier()
     if rank == 0:
-        full = grads_of(data)                                            # single-rank gradient of the whole batch
-        err = float((summed - full.flat_g).abs().max())
-        q.put((err, float(full.flat_g.abs().max()), scale, summed.numel()))
+        full = grads_of(data, None)                                      # single-rank gradient of the whole batch, no collective
+        err = max(float((summed - full.flat_g).abs().max()), float((summed2 - full.flat_g).abs().max()))
+        q.put((err, float(full.flat_g.abs().max()), scale, summed.numel(), len(opt.buckets), early_before_step))
     dist.destroy_process_group()
 
 
@@ -117,9 +128,10 @@ def test_two_rank_gradient_allreduce_equals_full_batch_gradient():
     procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    err, gmax, scale, n = q.get(timeout=240)
+    err, gmax, scale, n, nbuckets, early = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert scale == 0.5 and n > 1000
     assert err <= 1e-4 * gmax, (err, gmax)
+    assert nbuckets >= 3 and early >= nbuckets - 1, (nbuckets, early)    # second step: all-reduces issued from inside the backward

@@ -243,3 +243,62 @@ def test_dgl_gatedgcn_training_step_gradients(name):
         assert e <= 3e-3 * gr.abs().max().item() + 2e-5 * gmax + 1e-7, f"{pname}: {e:.3e} vs {gr.abs().max().item():.3e} (max {gmax:.3e})"
         checked += 1
     assert checked >= 30, checked
+
+
+_RCCL_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["SN_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SN_ROOT"], "tests"))
+import torch
+import golden_util as G
+from test_pyg_parity_gpu import build
+from signnet_basisnet_amd import dist as D, optim, synth
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ["SN_PORT"])
+dist = D.init_process_group("nccl")                      # RCCL: communicator init + ncclAllReduce really execute, world size 1
+fx = G.load("gine_d16")
+data = synth.batch_to(G.as_data(fx.inp), "cuda:0")
+target = torch.randn(len(G.as_data(fx.inp).sizes), 1, generator=torch.Generator().manual_seed(4)).to("cuda:0")
+out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+finals, early = [], []
+for use_dist in (None, dist):
+    model = build(fx).train()
+    opt = optim.FlatAdam(model.parameters(), lr=2e-3, dist=use_dist, bucket_mb=0.05)
+    for _ in range(3):
+        opt.zero_grad()
+        (model(data) - target).abs().mean().backward()
+        n_early = sum(w is not None for w in opt._work)
+        opt.step()
+        early.append(n_early)
+    torch.cuda.synchronize()
+    finals.append(opt.flat_p.clone())
+out["buckets"] = len(opt.buckets)
+out["early"] = early[3:]
+out["equal"] = bool(torch.equal(finals[0], finals[1]))       # SUM over one rank, scale 1: bit-identical parameters
+probe = torch.ones(1 << 20, device="cuda:0")
+dist.all_reduce(probe); torch.cuda.synchronize()
+out["probe"] = float(probe.sum())
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_flat_adam_over_rccl_world_size_one(tmp_path):
+    """`FlatAdam.step()` with `backend="nccl"` (RCCL) on device buffers: communicator init and ncclAllReduce execute on the
+    one-GPU box (world size 1), the bucketed all-reduces are issued from inside the backward from the second step on, and the
+    trained parameters are bit-identical to the run without a process group."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SN_ROOT=root, SN_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["backend"] == "nccl" and out["world"] == 1
+    assert out["equal"], "all-reduce over one rank must not change the gradients"
+    assert out["probe"] == float(1 << 20)
+    assert out["buckets"] >= 3 and out["early"][0] == 0 and min(out["early"][1:]) >= out["buckets"] - 1, out
