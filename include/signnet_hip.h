@@ -616,6 +616,85 @@ int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const 
  * flags_host[n_flags] (so flags_host holds n_flags + 1 ints).  A caller that zeroed that word before the launch can poll
  * it from the host: once it reads 1 the flags are there; no event / marker packet on the stream is needed. */
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training-step stage kernels (BASELINE configs[3]).  They replace, for one "Linear -> BatchNorm1d(train) -> ReLU"
+ * link of a MaskedMLP / MLP (Alchemy/sign_net/model_utils/masked_layers.py:34-64, GINESignNetPyG/core/model_utils/elements.py:40-69),
+ * what loss.backward() (Alchemy/main_alchemy.py:108, GINESignNetPyG/core/train.py:62) runs through ATen: one pass over the rows per
+ * direction instead of ~10.  Rows come in G groups of R rows, group-major (the phi(+x) / phi(-x) passes of sign_net.py:113 share every
+ * weight but keep separate batch statistics); row r of a group is valid iff nvalid == NULL or (r % K) < nvalid[r / K].  Weights are the
+ * RAW nn.Linear parameters (row-major [d_out, d_in], any alignment): nothing is packed per step.  Widths: multiples of 4 up to 128.
+ *
+ * sn_train_linear_f32: y = [relu](x_hat W^T + b) on valid rows, 0 elsewhere, x_hat = [relu](x * in_scale[g] + in_shift[g]) (the
+ *   producer's train-mode BatchNorm folded to an affine, applied as the operand tile is loaded; NULL: x_hat = [relu] x).  With stat_part
+ *   (float[G * (2 * nblk * d_out + nblk)], nblk = sn_train_linear_blocks(R, G)) the batch moments of y over the valid rows of every
+ *   group are taken from the accumulators; sn_train_bn_finish_f32 merges them:
+ *     state[0..4][g][C] = mean, biased variance, rstd, scale = gamma * rstd, shift = beta - mean * scale (every component one
+ *     contiguous [G, C] block: state + 3*G*C is the in_scale of the consumer);  count[g] = valid rows;
+ *     running statistics updated once per group, in group order (momentum, unbiased variance), when given.
+ * sn_train_linear_bwd_f32: the adjoint of one link in one pass.
+ *     g  = dy * [mask_scale * zo + mask_shift > 0]     (the ReLU behind this Linear's BatchNorm; mask_* NULL: g = dy)
+ *     dz = coef_a * g - coef_b - coef_c * zo           (that BatchNorm's backward, sn_train_bn_bwd_finish_f32; coef_* NULL: dz = g)
+ *     x_hat = [relu](x * x_scale + x_shift) or x       (the operand the forward link formed on load)
+ *     gx = (dz W) * [x_hat > 0 if x_relu]              -> gx [G*R, d_in]  (NULL: no input gradient)
+ *     sums_part[g][blk][0][c] = sum gx, [1][c] = sum gx * (x - x_mean[g])   (x_mean != NULL; for the producer's BatchNorm backward)
+ *     dw_part[g*nblk + blk] = sum dz^T x_hat (d_out * d_in floats) followed by sum dz (d_out floats, want_db) — per-workgroup
+ *       partials, nblk = sn_train_linear_bwd_blocks(R, G); sn_train_reduce_parts_f32 adds them in block order.  No atomics anywhere.
+ * sn_train_bn_bwd_sums_f32: the same column sums for a BatchNorm whose upstream gradient does not come from
+ *   sn_train_linear_bwd_f32 (its output feeds an aggregation / a residual): g = dy * [scale * z + shift > 0 if relu];
+ *   sums_part: float[G * sn_train_bn_bwd_blocks(R, G) * 2 * C].
+ * sn_train_bn_bwd_finish_f32: coef[0..2][g][C] (a, b, c above) from the partial sums, and d gamma / d beta summed over the groups
+ *   (written, or added when accumulate != 0).
+ * sn_train_bn_apply_f32: y = [relu](z * scale[g] + shift[g]) [+ residual] on valid rows, 0 elsewhere (`state` as written by
+ *   sn_train_bn_finish_f32) — the last BatchNorm of a stack, whose output is materialised.
+ * sn_train_reduce_parts_f32: out[i] (+)= sum_b part[b * stride + i], i < n. */
+typedef struct {
+  const float* x; int ldx;
+  int64_t R; int G;
+  int d_in, d_out;
+  const float* W; int ldw;
+  const float* bias;
+  const int32_t* nvalid; int K;
+  const float* in_scale; const float* in_shift;   /* [G, d_in] or NULL */
+  int in_relu, out_relu;
+  float* y; int ldy;
+  float* stat_part;                               /* NULL: no statistics */
+} sn_train_linear_args;
+
+typedef struct {
+  int64_t R; int G;
+  const int32_t* nvalid; int K;
+  int d_in, d_out;
+  const float* dy; int lddy;
+  const float* zo; int ldzo;
+  const float* coef_a; const float* coef_b; const float* coef_c;   /* [G, d_out] or NULL */
+  const float* mask_scale; const float* mask_shift;                /* [G, d_out] or NULL */
+  const float* x; int ldx;
+  const float* x_scale; const float* x_shift;                      /* [G, d_in] or NULL */
+  int x_relu;
+  const float* x_mean;                                             /* [G, d_in] or NULL */
+  const float* W; int ldw;
+  float* gx; int ldgx;
+  float* sums_part;
+  float* dw_part;
+  int want_db;
+} sn_train_linear_bwd_args;
+
+int sn_train_linear_blocks(int64_t R, int G);
+int sn_train_linear_bwd_blocks(int64_t R, int G);
+int sn_train_bn_bwd_blocks(int64_t R, int G);
+int64_t sn_train_linear_bwd_part_floats(int64_t R, int G, int d_in, int d_out);
+int sn_train_linear_f32(const sn_train_linear_args* args, void* stream);
+int sn_train_bn_finish_f32(const float* stat_part, int nblk, int G, int C, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* state, float* count, void* stream);
+int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, void* stream);
+int sn_train_bn_bwd_sums_f32(const float* dy, int lddy, const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid,
+                             int K, const float* state, int relu, float* sums_part, void* stream);
+int sn_train_bn_bwd_finish_f32(const float* sums_part, int nblk, int G, int C, const float* state, const float* count,
+                               const float* gamma, float* coef, float* dgamma, float* dbeta, int accumulate, void* stream);
+int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K, const float* state,
+                          int relu, const float* residual, int ldr, float* y, int ldy, void* stream);
+int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int64_t n, float* out, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,16 @@ SIGNATURES = {
     "sn_gated_aggregate_f32": [_p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_gated_aggregate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_adam_step_f32": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
+    "sn_train_linear_blocks": [_l, _i],                  # (returns a count, not a status)
+    "sn_train_linear_bwd_blocks": [_l, _i],
+    "sn_train_bn_bwd_blocks": [_l, _i],
+    "sn_train_linear_f32": [_p, _p],
+    "sn_train_bn_finish_f32": [_p, _i, _i, _i, _p, _p, _f, _f, _p, _p, _p, _p, _p],
+    "sn_train_linear_bwd_f32": [_p, _p],
+    "sn_train_bn_bwd_sums_f32": [_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _i, _p, _p],
+    "sn_train_bn_bwd_finish_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
+    "sn_train_bn_apply_f32": [_p, _i, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
+    "sn_train_reduce_parts_f32": [_p, _i, _l, _l, _p, _i, _p],
 }
 _SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
 
@@ -121,6 +131,8 @@ def lib():
         L.sn_evd_work_ints.restype = C.c_int64
         L.sn_ign_contract_scratch_floats.argtypes = [_l, _i]
         L.sn_ign_contract_scratch_floats.restype = C.c_int64
+        L.sn_train_linear_bwd_part_floats.argtypes = [_l, _i, _i, _i]
+        L.sn_train_linear_bwd_part_floats.restype = C.c_int64
         if L.sn_version() != 1:
             raise RuntimeError("libsignnet_hip.so ABI version mismatch")
         _lib = L

@@ -300,6 +300,19 @@ def gin_aggregate(x, plan: GraphPlan, eps=None, negate=False, slab=False):
     return out
 
 
+def doubled_plan(plan: GraphPlan):
+    """The CSR of two disjoint copies of the batch (nodes N..2N-1 = the second copy): the phi(+x) / phi(-x) passes stacked group-major
+    aggregate in ONE launch over [2N, K*d].  Index plumbing only (two concatenations), kept on the plan."""
+    d = getattr(plan, "_doubled", None)
+    if d is None:
+        import types
+        E = plan.col.numel()
+        d = types.SimpleNamespace(N=2 * plan.N, B=2 * plan.B, E=2 * E, rowptr=torch.cat([plan.rowptr, plan.rowptr[1:] + E]),
+                                  col=torch.cat([plan.col, plan.col + plan.N]))
+        plan._doubled = d
+    return d
+
+
 def gine_aggregate(x, ea, plan: GraphPlan, eps=None):
     require_cuda(x, ea)
     x, ea = _f32c(x, "x"), _f32c(ea, "edge_attr")

@@ -300,6 +300,7 @@ class SignNetGNN(nn.Module):
         # nl_rho is fixed by the reference constructors (sign_net.py:123 ignores the argument)
         self.nl_rho = 4 if variant == "alchemy" else 1
         self.use_fused = True       # whole-stage kernels (eval mode); False = layer-at-a-time kernels only
+        self.train_stages = True    # training: the one-pass link kernels of train_stage.py; False = one launch per op (autograd.py)
         # Fused stages require graphs of <= 64 nodes (and <= 192 edges for the GINE stage); a batch that violates this, a
         # malformed batch, or a discrete feature value outside its embedding table raises device-side flags.
         #   strict=True : (default) the flags are read after every forward (the GINE kernel writes them to pinned memory: one
@@ -568,32 +569,52 @@ class SignNetGNN(nn.Module):
                 p2 = lin_bn(s0.view(N * K, 1), ee2.layers[0], ee2.norms[0], nv, K)
                 lin_bn(p2, ee2.layers[1], ee2.norms[1], nv, K)
         # ---- phi(x) + phi(-x)
-        phis = []
-        for sign in (0, 1):
-            x, prev = x0, None
-            for l, (conv, norm) in enumerate(zip(sn.phi.convs, sn.phi.norms)):
-                a = AG.gin_aggregate(x.view(N, -1), conv.layer.eps, plan, rplan, negate=(sign == 1 and l == 0))
-                h = lin_bn(a.view(N * K, -1), conv.nn.layers[0], conv.nn.norms[0], nv, K)
-                x = lin_bn(h, conv.nn.layers[1], norm, nv, K, residual=prev)
-                prev = x
-            phis.append(x)
-        x = AG.masked_add(phis[0], phis[1], nv, K)
+        from . import train_stage as T
+        d = self.cfg["n_hid"]
+        stage = self.train_stages and T.supported(d, d)
+        convs, norms = list(sn.phi.convs), list(sn.phi.norms)
+        if stage and len(convs) > 1:
+            # layers >= 1 (the [d,d] links): both sign passes stacked group-major [2, N*K, d] — shared weights, separate batch
+            # statistics — through the stage kernels: one pass over the rows per link and direction (train_stage.py)
+            xs = []
+            for sign in (0, 1):
+                a = AG.gin_aggregate(x0.view(N, -1), convs[0].layer.eps, plan, rplan, negate=(sign == 1))
+                h = lin_bn(a.view(N * K, -1), convs[0].nn.layers[0], convs[0].nn.norms[0], nv, K)
+                xs.append(lin_bn(h, convs[0].nn.layers[1], norms[0], nv, K))
+            x = torch.cat(xs, 0)
+            plan2, rplan2 = ops.doubled_plan(plan), ops.doubled_plan(rplan)
+            for conv, norm in zip(convs[1:], norms[1:]):
+                a = AG.gin_aggregate(x.view(2 * N, -1), conv.layer.eps, plan2, rplan2)
+                x = T.mlp2_bn(a.view(2 * N * K, d), conv.nn.layers[0], conv.nn.norms[0].bn, conv.nn.layers[1], norm.bn, nv, K, 2, residual=x)
+            x = AG.masked_add(x[:N * K], x[N * K:], nv, K)
+        else:
+            phis = []
+            for sign in (0, 1):
+                x, prev = x0, None
+                for l, (conv, norm) in enumerate(zip(convs, norms)):
+                    a = AG.gin_aggregate(x.view(N, -1), conv.layer.eps, plan, rplan, negate=(sign == 1 and l == 0))
+                    h = lin_bn(a.view(N * K, -1), conv.nn.layers[0], conv.nn.norms[0], nv, K)
+                    x = lin_bn(h, conv.nn.layers[1], norm, nv, K, residual=prev)
+                    prev = x
+                phis.append(x)
+            x = AG.masked_add(phis[0], phis[1], nv, K)
         # ---- rho
         if alchemy_eig:
             ee = sn.eigen_encoder
             p = lin_bn(s0.view(N * K, 1), ee.layers[0], ee.norms[0], nv, K)
             p = lin_bn(p, ee.layers[1], ee.norms[1], nv, K)
             x = AG.masked_add(x, p, nv, K)
+        lin = T.linear if stage else AG.linear
         for tl in sn.rho.transformer_layers:
             a, f = tl.slf_attn, tl.pos_ffn
-            q = AG.linear(x, a.w_qs.weight, None, nv, K)
-            k = AG.linear(x, a.w_ks.weight, None, nv, K)
-            v = AG.linear(x, a.w_vs.weight, None, nv, K)
+            q = lin(x, a.w_qs.weight, None, nv, K)
+            k = lin(x, a.w_ks.weight, None, nv, K)
+            v = lin(x, a.w_vs.weight, None, nv, K)
             o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device))
-            o = AG.linear(o, a.fc.weight, None, nv, K)
+            o = lin(o, a.fc.weight, None, nv, K)
             y = AG.masked_layernorm(o, x, a.norm.ln.weight, a.norm.ln.bias, LN_EPS, nv, K)
-            z = AG.linear(y, f.w_1.weight, f.w_1.bias, nv, K, relu=True)
-            z = AG.linear(z, f.w_2.weight, f.w_2.bias, nv, K)
+            z = lin(y, f.w_1.weight, f.w_1.bias, nv, K, relu=True)
+            z = lin(z, f.w_2.weight, f.w_2.bias, nv, K)
             x = AG.masked_layernorm(z, y, f.norm.ln.weight, f.norm.ln.bias, LN_EPS, nv, K)
         s = AG.slot_sum(x, N, K, nv)
         pe = lin_bn(s, sn.rho.out[0], sn.rho.out[1], relu=False)
@@ -610,8 +631,11 @@ class SignNetGNN(nn.Module):
             else:
                 e = lin_bn(data.edge_attr.contiguous(), enc.layers[0], enc.norms[0])
             u = AG.gine_aggregate(h, e, conv.layer.eps, plan, rplan)
-            u = lin_bn(u, conv.nn.layers[0], conv.nn.norms[0])
-            h = lin_bn(u, conv.nn.layers[1], norm, residual=h)
+            if stage and isinstance(conv.nn.norms[0], nn.BatchNorm1d) and isinstance(norm, nn.BatchNorm1d):
+                h = T.mlp2_bn(u, conv.nn.layers[0], conv.nn.norms[0], conv.nn.layers[1], norm, None, 0, 1, residual=h)
+            else:
+                u = lin_bn(u, conv.nn.layers[0], conv.nn.norms[0])
+                h = lin_bn(u, conv.nn.layers[1], norm, residual=h)
         pooled = AG.segment_pool(h, plan, g.pooling)
         oe = g.output_encoder
         y = lin_bn(pooled, oe.layers[0], oe.norms[0])

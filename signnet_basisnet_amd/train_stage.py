@@ -1,0 +1,226 @@
+"""Stage-level training ops: ONE pass over the rows per direction for a "Linear -> BatchNorm1d(train) -> ReLU" link (csrc/train.hip).
+
+What `loss.backward()` runs through ATen for a MaskedMLP / MLP of the reference (Alchemy/sign_net/model_utils/masked_layers.py:34-64,
+GINESignNetPyG/core/model_utils/elements.py:40-69; called from sign_net.py:28-44 for phi, model.py:36-64 for the GINE stack) is about ten
+launches and ten passes over the [rows, d] activations per Linear and direction.  Here
+
+    mlp2_bn : y = [relu](bn_b(W_b relu(bn_a(W_a x + b_a)) + b_b)) [+ residual]      forward 5 launches, backward 7
+    linear  : y = [relu](W x + b)                                                     forward 1 launch,   backward 2
+
+for G groups of rows at once (the phi(+x) / phi(-x) passes: shared weights, separate batch statistics).  Raw parameters go straight
+to the kernels (no per-step weight packing); gradients are bitwise reproducible (no atomics).  torch records the graph and owns the
+buffers; no arithmetic runs in ATen.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import check, lib, ptr, stream
+
+
+class _LinArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("R", C.c_int64), ("G", C.c_int), ("d_in", C.c_int), ("d_out", C.c_int),
+                ("W", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p), ("nvalid", C.c_void_p), ("K", C.c_int),
+                ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_relu", C.c_int), ("out_relu", C.c_int),
+                ("y", C.c_void_p), ("ldy", C.c_int), ("stat_part", C.c_void_p)]
+
+
+class _BwdArgs(C.Structure):
+    _fields_ = [("R", C.c_int64), ("G", C.c_int), ("nvalid", C.c_void_p), ("K", C.c_int), ("d_in", C.c_int), ("d_out", C.c_int),
+                ("dy", C.c_void_p), ("lddy", C.c_int), ("zo", C.c_void_p), ("ldzo", C.c_int),
+                ("coef_a", C.c_void_p), ("coef_b", C.c_void_p), ("coef_c", C.c_void_p),
+                ("mask_scale", C.c_void_p), ("mask_shift", C.c_void_p),
+                ("x", C.c_void_p), ("ldx", C.c_int), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_relu", C.c_int),
+                ("x_mean", C.c_void_p), ("W", C.c_void_p), ("ldw", C.c_int), ("gx", C.c_void_p), ("ldgx", C.c_int),
+                ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int)]
+
+
+def supported(d_in: int, d_out: int) -> bool:
+    return 0 < d_in <= 128 and 0 < d_out <= 128 and d_in % 4 == 0 and d_out % 4 == 0
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _w(W):
+    W = W.detach()
+    return W if W.stride(-1) == 1 else W.contiguous()
+
+
+class BNState:
+    """Batch statistics of one train-mode BatchNorm site: state[(mean, var, rstd, scale, shift)][g][C]; count[g]."""
+
+    def __init__(self, G, Cc, device):
+        self.G, self.C = G, Cc
+        self.state = torch.empty(5, G, Cc, dtype=torch.float32, device=device)
+        self.count = torch.empty(G, dtype=torch.float32, device=device)
+
+    mean = property(lambda s: s.state[0])
+    scale = property(lambda s: s.state[3])
+    shift = property(lambda s: s.state[4])
+
+
+# ----------------------------------------------------------------------------- raw launches
+def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=False, bn=None):
+    """x [G*R, d_in] -> y [G*R, d_out] (+ the BatchNorm state of `bn` over y's valid rows, running statistics updated)."""
+    W = _w(W)
+    d_out, d_in = W.shape
+    y = torch.empty(G * R, d_out, dtype=torch.float32, device=x.device)
+    stat = None
+    nblk = int(lib().sn_train_linear_blocks(R, G))
+    if bn is not None:
+        stat = torch.empty(G * (2 * nblk * d_out + nblk), dtype=torch.float32, device=x.device)
+    a = _LinArgs(ptr(x), x.stride(0), R, G, d_in, d_out, ptr(W), W.stride(0), ptr(None if b is None else b.detach()), ptr(nvalid), int(K),
+                 ptr(None if in_state is None else in_state.scale), ptr(None if in_state is None else in_state.shift),
+                 int(in_relu), int(out_relu), ptr(y), d_out, ptr(stat))
+    with ops._span("sn_train_linear_f32"):
+        check(lib().sn_train_linear_f32(C.byref(a), stream()), "sn_train_linear_f32")
+    st = None
+    if bn is not None:
+        st = BNState(G, d_out, x.device)
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = bn.track_running_stats and bn.running_mean is not None
+        with ops._span("sn_train_bn_finish_f32"):
+            check(lib().sn_train_bn_finish_f32(ptr(stat), nblk, G, d_out, ptr(None if bn.weight is None else bn.weight.detach()),
+                                               ptr(None if bn.bias is None else bn.bias.detach()), float(bn.eps), mom,
+                                               ptr(bn.running_mean if track else None), ptr(bn.running_var if track else None),
+                                               ptr(st.state), ptr(st.count), stream()), "sn_train_bn_finish_f32")
+        if track and bn.num_batches_tracked is not None:
+            for _ in range(G):
+                ops._count_batch(bn)
+    return y, st
+
+
+def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state=None, x_relu=False, want_sums=False,
+               want_dx=True, want_db=True):
+    """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h."""
+    W = _w(W)
+    d_out, d_in = W.shape
+    dev = dy.device
+    nblk = int(lib().sn_train_linear_bwd_blocks(R, G))
+    gx = torch.empty(G * R, d_in, dtype=torch.float32, device=dev) if want_dx else None
+    sums = torch.empty(G * nblk * 2 * d_in, dtype=torch.float32, device=dev) if want_sums else None
+    stride = d_out * d_in + (d_out if want_db else 0)
+    dwp = torch.empty(G * nblk * stride, dtype=torch.float32, device=dev)
+    a = _BwdArgs(R, G, ptr(nvalid), int(K), d_in, d_out, ptr(dy), dy.stride(0), ptr(zo), 0 if zo is None else zo.stride(0),
+                 ptr(None if coef is None else coef[0]), ptr(None if coef is None else coef[1]), ptr(None if coef is None else coef[2]),
+                 ptr(None if mask is None else mask[0]), ptr(None if mask is None else mask[1]),
+                 ptr(x), x.stride(0), ptr(None if x_state is None else x_state.scale), ptr(None if x_state is None else x_state.shift),
+                 int(x_relu), ptr(x_state.mean if (want_sums and x_state is not None) else None), ptr(W), W.stride(0),
+                 ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db))
+    with ops._span("sn_train_linear_bwd_f32"):
+        check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
+    out = torch.empty(stride, dtype=torch.float32, device=dev)
+    with ops._span("sn_train_reduce_parts_f32"):
+        check(lib().sn_train_reduce_parts_f32(ptr(dwp), G * nblk, stride, stride, ptr(out), 0, stream()), "sn_train_reduce_parts_f32")
+    dW = out[:d_out * d_in].view(d_out, d_in)
+    db = out[d_out * d_in:] if want_db else None
+    return gx, sums, nblk, dW, db
+
+
+def bn_bwd_sums(dy, z, R, G, nvalid, K, st, relu):
+    Cc = z.shape[-1]
+    nblk = int(lib().sn_train_bn_bwd_blocks(R, G))
+    sums = torch.empty(G * nblk * 2 * Cc, dtype=torch.float32, device=z.device)
+    with ops._span("sn_train_bn_bwd_sums_f32"):
+        check(lib().sn_train_bn_bwd_sums_f32(ptr(dy), dy.stride(0), ptr(z), z.stride(0), R, G, Cc, ptr(nvalid), int(K), ptr(st.state),
+                                             int(relu), ptr(sums), stream()), "sn_train_bn_bwd_sums_f32")
+    return sums, nblk
+
+
+def bn_bwd_finish(sums, nblk, st, gamma):
+    """coef [3, G, C] of dz = a*g - b - c*z, and (d gamma, d beta) summed over the groups."""
+    coef = torch.empty(3, st.G, st.C, dtype=torch.float32, device=sums.device)
+    dgb = torch.empty(2, st.C, dtype=torch.float32, device=sums.device)
+    with ops._span("sn_train_bn_bwd_finish_f32"):
+        check(lib().sn_train_bn_bwd_finish_f32(ptr(sums), nblk, st.G, st.C, ptr(st.state), ptr(st.count),
+                                               ptr(None if gamma is None else gamma.detach()), ptr(coef), ptr(dgb[0]), ptr(dgb[1]), 0,
+                                               stream()), "sn_train_bn_bwd_finish_f32")
+    return coef, dgb[0], dgb[1]
+
+
+def bn_apply(z, R, G, nvalid, K, st, relu, residual):
+    """y = [relu](z * scale[g] + shift[g]) [+ residual] on valid rows, 0 elsewhere."""
+    y = torch.empty_like(z)
+    Cc = z.shape[-1]
+    with ops._span("sn_train_bn_apply_f32"):
+        check(lib().sn_train_bn_apply_f32(ptr(z), z.stride(0), R, G, Cc, ptr(nvalid), int(K), ptr(st.state), int(relu),
+                                          ptr(residual), 0 if residual is None else residual.stride(0), ptr(y), Cc, stream()),
+              "sn_train_bn_apply_f32")
+    return y
+
+
+# ----------------------------------------------------------------------------- Functions
+class _Mlp2Bn(Function):
+    @staticmethod
+    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, residual, bn1, bn2, nvalid, K, G, relu_out):
+        x = _c(x)
+        R = x.shape[0] // G
+        z1, st1 = linear_fwd(x, R, G, W1, b1, nvalid, K, bn=bn1)
+        z2, st2 = linear_fwd(z1, R, G, W2, b2, nvalid, K, in_state=st1, in_relu=True, bn=bn2)
+        res = None if residual is None else _c(residual)
+        y = bn_apply(z2, R, G, nvalid, K, st2, relu_out, res) if bn2 is not None else z2
+        ctx.save_for_backward(x, W1, W2, z1, z2, g1, g2)
+        ctx.meta = (R, G, nvalid, K, relu_out, st1, st2, b1 is not None, b2 is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1, W2, z1, z2, g1, g2 = ctx.saved_tensors
+        R, G, nvalid, K, relu_out, st1, st2, has_b1, has_b2, has_res = ctx.meta
+        dy = _c(dy)
+        dg2 = dbe2 = coef2 = mask2 = None
+        if st2 is not None:
+            sums2, nb2 = bn_bwd_sums(dy, z2, R, G, nvalid, K, st2, relu_out)
+            coef2, dg2, dbe2 = bn_bwd_finish(sums2, nb2, st2, g2)
+            mask2 = (st2.scale, st2.shift) if relu_out else None
+        gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, W2, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
+                                               x_state=st1, x_relu=True, want_sums=True, want_db=has_b2)
+        coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, g1)
+        dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, W1, nvalid, K, x, zo=z1, coef=coef1, want_dx=ctx.needs_input_grad[0], want_db=has_b1)
+        return (dx, dW1, db1, dg1 if g1 is not None else None, dbe1 if g1 is not None else None, dW2, db2,
+                dg2 if g2 is not None else None, dbe2 if g2 is not None else None, dy if has_res else None,
+                None, None, None, None, None, None)
+
+
+def mlp2_bn(x, lin1, bn1, lin2, bn2, nvalid=None, K=0, G=1, residual=None, relu_out=True):
+    """[relu](bn2(lin2(relu(bn1(lin1(x)))))) [+ residual]; bn2 None: the second Linear's output as is (no ReLU, no residual)."""
+    if bn2 is None and (residual is not None):
+        raise ValueError("mlp2_bn: a residual needs the second BatchNorm")
+    return _Mlp2Bn.apply(x, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias,
+                         None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias, residual, bn1, bn2, nvalid, K, G,
+                         relu_out and bn2 is not None)
+
+
+class _Linear(Function):
+    @staticmethod
+    def forward(ctx, x, W, b, nvalid, K, relu):
+        x = _c(x)
+        R = x.shape[0]
+        y, _ = linear_fwd(x, R, 1, W, b, nvalid, K, out_relu=relu)
+        ctx.save_for_backward(x, W, y if relu else None)
+        ctx.meta = (R, nvalid, K, relu, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        R, nvalid, K, relu, has_b = ctx.meta
+        dy = _c(dy)
+        mask = None
+        if relu:           # g = dy * [y > 0]: the mask mechanism with scale 1, shift 0 on the saved output
+            one = torch.ones(1, y.shape[1], dtype=torch.float32, device=y.device)
+            mask = (one, torch.zeros_like(one))
+        dx, _, _, dW, db = linear_bwd(dy, R, 1, W, nvalid, K, x, zo=y if relu else None, mask=mask,
+                                      want_dx=ctx.needs_input_grad[0], want_db=has_b)
+        return dx, dW, db, None, None, None
+
+
+def linear(x, W, b=None, nvalid=None, K=0, relu=False):
+    """y = [relu](x W^T + b) on valid rows, 0 elsewhere."""
+    return _Linear.apply(x, W, b, nvalid, K, relu)

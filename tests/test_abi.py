@@ -39,7 +39,8 @@ def test_python_binding_covers_the_header(lib):
     bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_split_packed_bytes", "sn_phi_bins_bound",
                                      "sn_ign_contract_scratch_floats", "sn_evd_work_ints",
                                      "sn_linear_wgrad_scratch_floats", "sn_layernorm_bwd_scratch_floats",
-                                     "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_gatedgcn_max_edges"}
+                                     "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_gatedgcn_max_edges",
+                                     "sn_train_linear_bwd_part_floats"}
     assert set(declared_symbols()) == bound
 
 
