@@ -11,6 +11,7 @@
 // Rows come in G groups (the phi(+x) / phi(-x) passes share every weight but keep separate batch statistics: two calls of GNN3d,
 // sign_net.py:113).  fp32-input MFMA throughout (exact products, fp32 accumulate); no atomics: gradients are bitwise reproducible.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sn {
 
@@ -37,6 +38,10 @@ __device__ __forceinline__ f32x4 ld4a(const float* __restrict__ p, int c0, int C
   if (c0 < C) { const float4 t = *reinterpret_cast<const float4*>(p + c0); v = f32x4{t.x, t.y, t.z, t.w}; }
   return v;
 }
+__device__ __forceinline__ f32x4 lds4(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  return f32x4{t.x, t.y, t.z, t.w};
+}
 __device__ __forceinline__ void st4a(float* __restrict__ p, int c0, int C, f32x4 v) {
   if (c0 < C) *reinterpret_cast<float4*>(p + c0) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -51,16 +56,27 @@ __device__ __forceinline__ bool row_ok(int64_t r, int64_t R, const int32_t* __re
 //   wl[(ot*nk + kk)*64 + lane] = { M[16 ot + (lane&15)][16 kk + 4 (lane>>4) + t] }_t,  M = W (trans = 0: [n_o, n_k]) or W^T
 template <bool TRANS>
 __device__ __forceinline__ void stage_weight(float4* wl, const float* __restrict__ W, int ldw, int n_o, int n_k, int nto, int ntk) {
-  for (int i = threadIdx.x; i < nto * ntk * 64; i += 64 * TW) {
-    const int ln = i & 63, blk = i >> 6, kk = blk % ntk, ot = blk / ntk;
-    const int o = 16 * ot + (ln & 15), k = 16 * kk + 4 * (ln >> 4);
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (o < n_o) {
+  const int total = nto * ntk * 64;
+  // four entries (16 scalar loads) in flight per thread: one entry at a time the staging of a 128 x 128 matrix was a chain of 32
+  // dependent L2 round trips — most of a small launch
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 64 * TW) {
+    float v[4][4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (k + t < n_k) v[t] = TRANS ? W[(int64_t)(k + t) * ldw + o] : W[(int64_t)o * ldw + k + t];
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 * TW;
+      const int ln = i & 63, blk = i >> 6, kk = blk % ntk, ot = blk / ntk;
+      const int o = 16 * ot + (ln & 15), k = 16 * kk + 4 * (ln >> 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v[u][t] = 0.f;
+        if (i < total && o < n_o && k + t < n_k) v[u][t] = TRANS ? W[(int64_t)(k + t) * ldw + o] : W[(int64_t)o * ldw + k + t];
+      }
     }
-    wl[i] = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 * TW;
+      if (i < total) wl[i] = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+    }
   }
 }
 
@@ -79,6 +95,9 @@ template <int NTI, int NTO, bool STATS>
 __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   extern __shared__ __align__(16) unsigned char t_lds[];
   float4* wl = reinterpret_cast<float4*>(t_lds);
+  float* icol = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;     // [2][16*NTI] in_scale | in_shift of my group
+  float* piv = icol + 2 * 16 * NTI;                                             // [TW][16*NTO] per-wave pivots of the moment sums
+  constexpr int CI = 16 * NTI;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   const int nti = (a.d_in + 15) >> 4, nto = (a.d_out + 15) >> 4;
   const int grp = blockIdx.x / a.nblk, blk = blockIdx.x - grp * a.nblk;
@@ -88,12 +107,17 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   float* yg = a.y + (int64_t)grp * a.R * a.ldy;
   const float* isc = a.in_scale ? a.in_scale + (int64_t)grp * a.d_in : nullptr;
   const float* ish = a.in_scale ? a.in_shift + (int64_t)grp * a.d_in : nullptr;
+  // Batch moments of y (STATS): per lane the sums of (v - p) and (v - p)^2 of its rows and 4 columns per output tile, p = the column
+  // means of the wave's first tile (kept in LDS) — two VALU operations per value instead of a cross-lane Chan update per tile; the
+  // pivot keeps the final M2 = S2 - S1^2/n free of cancellation.  Reduced over the rows once, at the end.
   float rn = 0.f;
-  f32x4 rmean[STATS ? NTO : 1], rm2[STATS ? NTO : 1];
+  bool have_piv = false;
+  f32x4 s1[STATS ? NTO : 1], s2[STATS ? NTO : 1];
   if (STATS) {
 #pragma unroll
-    for (int ot = 0; ot < NTO; ++ot) { rmean[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; rm2[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int ot = 0; ot < NTO; ++ot) { s1[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
+  float* mypiv = piv + wave * 16 * NTO;
   auto fetch = [&](int64_t tile, bool v, f32x4 (&buf)[NTI]) {
     const float* xr = xg + (tile * 16 + (lane & 15)) * a.ldx;
 #pragma unroll
@@ -102,18 +126,27 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       if (kk < nti && v) buf[kk] = ld4a(xr, 16 * kk + 4 * g, a.d_in);
     }
   };
-  f32x4 in[NTI];
-  bool valid = false;
+  f32x4 in[NTI], nx[NTI];
+  bool valid = false, nvalid_next = false;
   int64_t tile = t_lo + wave;
   if (tile < t_hi) {
     valid = row_ok(tile * 16 + (lane & 15), a.R, a.nvalid, a.K);
     fetch(tile, valid, in);
   }
   stage_weight<false>(wl, a.W, a.ldw, a.d_out, a.d_in, nto, nti);
+  for (int i = threadIdx.x; i < CI; i += 64 * TW) {
+    icol[i] = (isc && i < a.d_in) ? isc[i] : 1.f;
+    icol[CI + i] = (isc && i < a.d_in) ? ish[i] : 0.f;
+  }
   __syncthreads();
   for (; tile < t_hi; tile += TW) {
     const int64_t row = tile * 16 + (lane & 15);
     const bool inr = row < a.R;
+    const bool more = tile + TW < t_hi;
+    if (more) {        // the next tile's rows are requested before this tile goes into the matrix pipe
+      nvalid_next = row_ok((tile + TW) * 16 + (lane & 15), a.R, a.nvalid, a.K);
+      fetch(tile + TW, nvalid_next, nx);
+    }
     float* yr = yg + row * a.ldy;
     const unsigned long long vb = __ballot(valid);
     if (vb != 0ull) {
@@ -121,7 +154,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
 #pragma unroll
         for (int kk = 0; kk < NTI; ++kk) {
           if (kk < nti) {
-            const f32x4 sc = ld4a(isc, 16 * kk + 4 * g, a.d_in), sh = ld4a(ish, 16 * kk + 4 * g, a.d_in);
+            const f32x4 sc = lds4(icol + 16 * kk + 4 * g), sh = lds4(icol + CI + 16 * kk + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float v = in[kk][r] * sc[r] + sh[r];
@@ -138,13 +171,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       }
     }
     const float nt = (float)__popcll(vb & 0xffffull);
-    float inv_nt = 0.f, wa = 0.f, wb = 0.f;
-    if (STATS && vb != 0ull) {
-      const float n = rn + nt;
-      inv_nt = 1.0f / nt;
-      wb = nt / n;
-      wa = rn * wb;
-    }
+    const bool first = STATS && vb != 0ull && !have_piv;      // wave-uniform
     auto epilogue = [&](int ot, f32x4 acc) {
       const int o0 = 16 * ot + 4 * g;
       f32x4 v = acc;
@@ -156,14 +183,20 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       }
       if (inr) st4a(yr, o0, a.d_out, v);
       if (STATS) {
+        f32x4 pv;
+        if (first) {
+          const float inv = 1.0f / nt;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = t16_sum(v[r]) * inv;      // invalid rows hold 0
+          if ((lane & 15) == 0) *reinterpret_cast<float4*>(mypiv + o0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        } else {
+          pv = lds4(mypiv + o0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float mt = t16_sum(v[r]) * inv_nt;
-          const float d = valid ? v[r] - mt : 0.f;
-          const float qt = t16_sum(d * d);
-          const float dm = mt - rmean[ot][r];
-          rmean[ot][r] += dm * wb;
-          rm2[ot][r] += qt + dm * dm * wa;
+          const float d = valid ? v[r] - pv[r] : 0.f;
+          s1[ot][r] += d;
+          s2[ot][r] += d * d;
         }
       }
     };
@@ -211,25 +244,32 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
           epilogue(ot, acc0);
         }
       }
-      if (STATS) rn += nt;
+      if (STATS) { rn += nt; have_piv = true; }
     }
-    if (tile + TW < t_hi) {
-      valid = row_ok((tile + TW) * 16 + (lane & 15), a.R, a.nvalid, a.K);
-      fetch(tile + TW, valid, in);
+    if (more) {
+#pragma unroll
+      for (int kk = 0; kk < NTI; ++kk) in[kk] = nx[kk];
+      valid = nvalid_next;
     }
   }
   if (STATS) {
+    // per-wave (n, mean, M2) from the pivoted sums, then one partial per WORKGROUP: the waves meet in LDS, merged in wave order (Chan)
     __syncthreads();
-    float* sm = reinterpret_cast<float*>(t_lds);          // [TW][mean 16*NTO | M2 16*NTO], counts behind
+    float* sm = reinterpret_cast<float*>(t_lds);          // [TW][mean 16*NTO | M2 16*NTO], counts behind  (the weight image is dead)
     float* sc = sm + TW * 2 * 16 * NTO;
-    if ((lane & 15) == 0) {
 #pragma unroll
-      for (int ot = 0; ot < NTO; ++ot)
+    for (int ot = 0; ot < NTO; ++ot) {
+      f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+      if (have_piv) pv = lds4(mypiv + 16 * ot + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sm[(wave * 2 + 0) * 16 * NTO + 16 * ot + 4 * g + r] = rmean[ot][r];
-          sm[(wave * 2 + 1) * 16 * NTO + 16 * ot + 4 * g + r] = rm2[ot][r];
+      for (int r = 0; r < 4; ++r) {
+        const float t1 = t16_sum(s1[ot][r]), t2 = t16_sum(s2[ot][r]);
+        if ((lane & 15) == 0) {
+          const float inv = rn > 0.f ? 1.0f / rn : 0.f;
+          sm[(wave * 2 + 0) * 16 * NTO + 16 * ot + 4 * g + r] = pv[r] + t1 * inv;
+          sm[(wave * 2 + 1) * 16 * NTO + 16 * ot + 4 * g + r] = fmaxf(t2 - t1 * t1 * inv, 0.f);
         }
+      }
     }
     if (lane == 0) sc[wave] = rn;
     __syncthreads();
@@ -324,6 +364,7 @@ struct TBwd {
   const float* W; int ldw;
   float* gx; int ldgx; float* sums; float* dwp; int want_db;
   int nblk;             // workgroups per group
+  int dbg;
 };
 
 __host__ __device__ constexpr int stage_ld(int ntiles) { return ((16 * ntiles + 63) / 64) * 64 + 16; }   // row stride = 16 mod 64 banks
@@ -337,7 +378,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   float* dzs = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;  // [TROWS][LDO]
   float* xsg = dzs + TROWS * LDO;                                          // [TROWS][LDI]  raw x (x_hat is re-formed at each use)
   float* red = xsg + TROWS * LDI;                                          // [2 sums][4 row tiles][16*NTI] running column sums of gx
-  float* xcol = red + 2 * 4 * 16 * NTI;                                    // [2][16*NTI] x_scale | x_shift of my group (phase 3)
+  float* xcol = red + 2 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
+  float* ocol = xcol + 3 * 16 * NTI;                                       // [5][16*NTO] coef a | b | c | mask scale | mask shift
+  constexpr int CI = 16 * NTI, CO = 16 * NTO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
   const int rt = wave & 3, half = wave >> 2;
   const int grp = blockIdx.x / a.nblk, blk = blockIdx.x - grp * a.nblk;
@@ -360,7 +403,16 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   for (int it = 0; it < NTI; ++it) dw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int i = threadIdx.x; i < 16 * NTI; i += 64 * TW) {
     xcol[i] = (xs && i < a.d_in) ? xs[i] : 1.f;
-    xcol[16 * NTI + i] = (xs && i < a.d_in) ? xt[i] : 0.f;
+    xcol[CI + i] = (xs && i < a.d_in) ? xt[i] : 0.f;
+    xcol[2 * CI + i] = (xmu && i < a.d_in) ? xmu[i] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 16 * NTO; i += 64 * TW) {     // (global / L1 round trips per tile and round cost ~20 us per launch)
+    const bool in = i < a.d_out;
+    ocol[i] = (cA && in) ? cA[i] : 1.f;
+    ocol[CO + i] = (cA && in) ? cB[i] : 0.f;
+    ocol[2 * CO + i] = (cA && in) ? cC[i] : 0.f;
+    ocol[3 * CO + i] = (ms && in) ? ms[i] : 0.f;
+    ocol[4 * CO + i] = (ms && in) ? mt[i] : 1.f;
   }
   float dbacc = 0.f;
   // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
@@ -395,6 +447,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     }
   };
   request(r_lo);
+  __syncthreads();          // the column constants (and the weight image) are published before phase 1 reads them
   for (int64_t round = r_lo; round < r_hi; ++round) {
     const int64_t row = round * TROWS + 16 * rt + lr;     // my row within the group (phases 1, 2)
     const bool valid = pvalid;
@@ -410,12 +463,12 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
           if (valid && a.zo) {
             const f32x4 z = pz[j];
             if (ms) {
-              const f32x4 m0 = ld4a(ms, c0, a.d_out), m1 = ld4a(mt, c0, a.d_out);
+              const f32x4 m0 = lds4(ocol + 3 * CO + c0), m1 = lds4(ocol + 4 * CO + c0);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (z[r] * m0[r] + m1[r] > 0.f) ? v[r] : 0.f;
             }
             if (cA) {
-              const f32x4 A = ld4a(cA, c0, a.d_out), B = ld4a(cB, c0, a.d_out), Cc = ld4a(cC, c0, a.d_out);
+              const f32x4 A = lds4(ocol + c0), B = lds4(ocol + CO + c0), Cc = lds4(ocol + 2 * CO + c0);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (A[r] * v[r] - B[r]) - Cc[r] * z[r];
             }
@@ -431,9 +484,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       }
     }
     __syncthreads();
-    if (round + 1 < r_hi) request(round + 1);
+    if (round + 1 < r_hi && !(a.dbg & 4)) request(round + 1);
     // ---------------------------------------------------------------- phase 2: gx = (dz W) * mask, column sums
-    if (want_dx) {
+    if (want_dx && !(a.dbg & 1)) {
       f32x4 fr[NTO];
       const float* src = dzs + (16 * rt + lr) * LDO;
 #pragma unroll
@@ -466,7 +519,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
           if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
           else if (a.xrelu) {
             if (xs) {
-              const f32x4 sc = ld4a(xs, c0, a.d_in), sh = ld4a(xt, c0, a.d_in);
+              const f32x4 sc = lds4(xcol + c0), sh = lds4(xcol + CI + c0);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (xv[r] * sc[r] + sh[r] > 0.f) ? v[r] : 0.f;
             } else {
@@ -476,7 +529,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
           }
           if (row < a.R) st4a(gr, c0, a.d_in, v);
           if (xmu) {
-            const f32x4 mu = ld4a(xmu, c0, a.d_in);
+            const f32x4 mu = lds4(xcol + 2 * CI + c0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float a1 = t16_sum(v[r]), a2 = t16_sum(v[r] * (xv[r] - mu[r]));
@@ -490,7 +543,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       }
     }
     // ---------------------------------------------------------------- phase 3: dW[tile `wave`] += dz^T x_hat over the round's rows
-    if (wave < nto && a.dwp) {
+    if (wave < nto && a.dwp && !(a.dbg & 2)) {
 #pragma unroll 1     // (unrolled by 2 the LDS reads of both steps are hoisted and the kernel spills)
       for (int q = 0; q < TROWS / 4; ++q) {
         const int rl = 4 * q + g;
@@ -501,7 +554,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
         for (int it = 0; it < NTI; ++it) {
           if (it < nti) {
             float bv = xr[16 * it];
-            if (xs) { bv = bv * xcol[16 * it + lr] + xcol[16 * NTI + 16 * it + lr]; if (a.xrelu) bv = fmaxf(bv, 0.f); }
+            if (xs) { bv = bv * xcol[16 * it + lr] + xcol[CI + 16 * it + lr]; if (a.xrelu) bv = fmaxf(bv, 0.f); }
             dw[it] = mfma16(av, bv, dw[it]);
           }
         }
@@ -734,9 +787,7 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   TLin a{p.x, p.ldx, p.R, p.G, p.d_in, p.d_out, p.W, p.ldw, p.bias, p.nvalid, p.K, p.in_scale, p.in_shift, p.in_relu, p.out_relu,
          p.y, p.ldy, p.stat_part, nblk};
   const int nti = (p.d_in + 15) / 16, nto = (p.d_out + 15) / 16;
-  size_t lds = (size_t)nti * nto * 1024;
-  const size_t xch = (size_t)(TW * 2 * 16 * 8 + TW) * sizeof(float);
-  if (p.stat_part && lds < xch) lds = xch;
+  const size_t lds = (size_t)8 * 8 * 1024 + (size_t)(2 * 16 * 8 + TW * 16 * 8) * sizeof(float);    // weight image + in_scale | in_shift + pivots
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (p.stat_part) {
@@ -784,8 +835,9 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   if (p.R == 0) return SN_OK;
   const int nblk = sn_train_linear_bwd_blocks(p.R, p.G);
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
-         p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db, nblk};
-  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(2 * 4 + 2) * 16 * 8 * sizeof(float);
+         p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db, nblk,
+         getenv("SN_TRAIN_DBG") ? atoi(getenv("SN_TRAIN_DBG")) : 0};
+  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(2 * 4 + 3 + 5) * 16 * 8 * sizeof(float);
   int rc;
   if ((rc = raise_lds(k_tlin_bwd<8, 8>, lds, "sn_train_linear_bwd_f32")) != SN_OK) return rc;
   hipLaunchKernelGGL((k_tlin_bwd<8, 8>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, (hipStream_t)stream, a);

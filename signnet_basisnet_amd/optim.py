@@ -96,6 +96,8 @@ class FlatAdam:
         if dist is not None and overlap and hasattr(self.params[0], "register_post_accumulate_grad_hook"):
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        for p in self.params:                    # .grad is a view of the zeroed flat buffer: `+=` inside an adjoint kernel IS AccumulateGrad
+            p._sn_direct_grad = True
 
     def _make_hook(self, i):
         b = self._bucket_of[i]

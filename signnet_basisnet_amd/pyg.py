@@ -604,17 +604,16 @@ class SignNetGNN(nn.Module):
             p = lin_bn(s0.view(N * K, 1), ee.layers[0], ee.norms[0], nv, K)
             p = lin_bn(p, ee.layers[1], ee.norms[1], nv, K)
             x = AG.masked_add(x, p, nv, K)
-        lin = T.linear if stage else AG.linear
+        def lin(x_, m, relu=False):
+            return T.linear_module(x_, m, nv, K, relu) if stage else AG.linear(x_, m.weight, m.bias, nv, K, relu=relu)
         for tl in sn.rho.transformer_layers:
             a, f = tl.slf_attn, tl.pos_ffn
-            q = lin(x, a.w_qs.weight, None, nv, K)
-            k = lin(x, a.w_ks.weight, None, nv, K)
-            v = lin(x, a.w_vs.weight, None, nv, K)
+            q, k, v = lin(x, a.w_qs), lin(x, a.w_ks), lin(x, a.w_vs)
             o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device))
-            o = lin(o, a.fc.weight, None, nv, K)
+            o = lin(o, a.fc)
             y = AG.masked_layernorm(o, x, a.norm.ln.weight, a.norm.ln.bias, LN_EPS, nv, K)
-            z = lin(y, f.w_1.weight, f.w_1.bias, nv, K, relu=True)
-            z = lin(z, f.w_2.weight, f.w_2.bias, nv, K)
+            z = lin(y, f.w_1, relu=True)
+            z = lin(z, f.w_2)
             x = AG.masked_layernorm(z, y, f.norm.ln.weight, f.norm.ln.bias, LN_EPS, nv, K)
         s = AG.slot_sum(x, N, K, nv)
         pe = lin_bn(s, sn.rho.out[0], sn.rho.out[1], relu=False)

@@ -52,6 +52,17 @@ def _w(W):
     return W if W.stride(-1) == 1 else W.contiguous()
 
 
+def direct_grad(p):
+    """The buffer a parameter's gradient may be accumulated into IN the adjoint kernels (`optim.FlatAdam` marks its parameters: their
+    .grad are views of one zeroed flat buffer, so `+=` in the kernel is exactly autograd's AccumulateGrad without the ~100 tiny add
+    launches per step); None: hand the gradient to autograd as usual.  (autograd still runs the parameter's post-accumulate hooks after
+    an adjoint that returned None for it — the bucketed all-reduce of FlatAdam needs no extra notification.)"""
+    if p is None or not getattr(p, "_sn_direct_grad", False):
+        return None
+    g = p.grad
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == p.device) else None
+
+
 class BNState:
     """Batch statistics of one train-mode BatchNorm site: state[(mean, var, rstd, scale, shift)][g][C]; count[g]."""
 
@@ -97,8 +108,9 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
 
 
 def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state=None, x_relu=False, want_sums=False,
-               want_dx=True, want_db=True):
-    """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h."""
+               want_dx=True, want_db=True, dW_acc=None, db_acc=None):
+    """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h.
+    dW_acc / db_acc: accumulate the weight / bias gradient into these buffers (returned dW / db are then None)."""
     W = _w(W)
     d_out, d_in = W.shape
     dev = dy.device
@@ -115,11 +127,19 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
                  ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db))
     with ops._span("sn_train_linear_bwd_f32"):
         check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
+    nw = d_out * d_in
+    if dW_acc is not None and (not want_db or db_acc is not None):
+        with ops._span("sn_train_reduce_parts_f32"):
+            check(lib().sn_train_reduce_parts_f32(ptr(dwp), G * nblk, stride, nw, ptr(dW_acc), 1, stream()), "sn_train_reduce_parts_f32")
+            if want_db:
+                check(lib().sn_train_reduce_parts_f32(dwp.data_ptr() + 4 * nw, G * nblk, stride, d_out, ptr(db_acc), 1, stream()),
+                      "sn_train_reduce_parts_f32")
+        return gx, sums, nblk, None, None
     out = torch.empty(stride, dtype=torch.float32, device=dev)
     with ops._span("sn_train_reduce_parts_f32"):
         check(lib().sn_train_reduce_parts_f32(ptr(dwp), G * nblk, stride, stride, ptr(out), 0, stream()), "sn_train_reduce_parts_f32")
-    dW = out[:d_out * d_in].view(d_out, d_in)
-    db = out[d_out * d_in:] if want_db else None
+    dW = out[:nw].view(d_out, d_in)
+    db = out[nw:] if want_db else None
     return gx, sums, nblk, dW, db
 
 
@@ -133,15 +153,18 @@ def bn_bwd_sums(dy, z, R, G, nvalid, K, st, relu):
     return sums, nblk
 
 
-def bn_bwd_finish(sums, nblk, st, gamma):
-    """coef [3, G, C] of dz = a*g - b - c*z, and (d gamma, d beta) summed over the groups."""
+def bn_bwd_finish(sums, nblk, st, gamma, dg_acc=None, db_acc=None):
+    """coef [3, G, C] of dz = a*g - b - c*z, and (d gamma, d beta) summed over the groups (accumulated into dg_acc / db_acc when
+    both are given: None is returned for them then)."""
     coef = torch.empty(3, st.G, st.C, dtype=torch.float32, device=sums.device)
-    dgb = torch.empty(2, st.C, dtype=torch.float32, device=sums.device)
+    acc = dg_acc is not None and db_acc is not None
+    dgb = None if acc else torch.empty(2, st.C, dtype=torch.float32, device=sums.device)
     with ops._span("sn_train_bn_bwd_finish_f32"):
         check(lib().sn_train_bn_bwd_finish_f32(ptr(sums), nblk, st.G, st.C, ptr(st.state), ptr(st.count),
-                                               ptr(None if gamma is None else gamma.detach()), ptr(coef), ptr(dgb[0]), ptr(dgb[1]), 0,
+                                               ptr(None if gamma is None else gamma.detach()), ptr(coef),
+                                               ptr(dg_acc if acc else dgb[0]), ptr(db_acc if acc else dgb[1]), int(acc),
                                                stream()), "sn_train_bn_bwd_finish_f32")
-    return coef, dgb[0], dgb[1]
+    return (coef, None, None) if acc else (coef, dgb[0], dgb[1])
 
 
 def bn_apply(z, R, G, nvalid, K, st, relu, residual):
@@ -158,7 +181,7 @@ def bn_apply(z, R, G, nvalid, K, st, relu, residual):
 # ----------------------------------------------------------------------------- Functions
 class _Mlp2Bn(Function):
     @staticmethod
-    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, residual, bn1, bn2, nvalid, K, G, relu_out):
+    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, residual, lin1, bn1, lin2, bn2, nvalid, K, G, relu_out):
         x = _c(x)
         R = x.shape[0] // G
         z1, st1 = linear_fwd(x, R, G, W1, b1, nvalid, K, bn=bn1)
@@ -166,61 +189,69 @@ class _Mlp2Bn(Function):
         res = None if residual is None else _c(residual)
         y = bn_apply(z2, R, G, nvalid, K, st2, relu_out, res) if bn2 is not None else z2
         ctx.save_for_backward(x, W1, W2, z1, z2, g1, g2)
-        ctx.meta = (R, G, nvalid, K, relu_out, st1, st2, b1 is not None, b2 is not None, residual is not None)
+        ctx.meta = (R, G, nvalid, K, relu_out, st1, st2, b1 is not None, b2 is not None, residual is not None, lin1, bn1, lin2, bn2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W1, W2, z1, z2, g1, g2 = ctx.saved_tensors
-        R, G, nvalid, K, relu_out, st1, st2, has_b1, has_b2, has_res = ctx.meta
+        R, G, nvalid, K, relu_out, st1, st2, has_b1, has_b2, has_res, lin1, bn1, lin2, bn2 = ctx.meta
         dy = _c(dy)
         dg2 = dbe2 = coef2 = mask2 = None
         if st2 is not None:
             sums2, nb2 = bn_bwd_sums(dy, z2, R, G, nvalid, K, st2, relu_out)
-            coef2, dg2, dbe2 = bn_bwd_finish(sums2, nb2, st2, g2)
+            coef2, dg2, dbe2 = bn_bwd_finish(sums2, nb2, st2, g2, direct_grad(bn2.weight), direct_grad(bn2.bias))
             mask2 = (st2.scale, st2.shift) if relu_out else None
         gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, W2, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
-                                               x_state=st1, x_relu=True, want_sums=True, want_db=has_b2)
-        coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, g1)
-        dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, W1, nvalid, K, x, zo=z1, coef=coef1, want_dx=ctx.needs_input_grad[0], want_db=has_b1)
+                                               x_state=st1, x_relu=True, want_sums=True, want_db=has_b2,
+                                               dW_acc=direct_grad(lin2.weight), db_acc=direct_grad(lin2.bias))
+        coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, g1, direct_grad(bn1.weight), direct_grad(bn1.bias))
+        dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, W1, nvalid, K, x, zo=z1, coef=coef1, want_dx=ctx.needs_input_grad[0], want_db=has_b1,
+                                        dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias))
         return (dx, dW1, db1, dg1 if g1 is not None else None, dbe1 if g1 is not None else None, dW2, db2,
                 dg2 if g2 is not None else None, dbe2 if g2 is not None else None, dy if has_res else None,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
 def mlp2_bn(x, lin1, bn1, lin2, bn2, nvalid=None, K=0, G=1, residual=None, relu_out=True):
-    """[relu](bn2(lin2(relu(bn1(lin1(x)))))) [+ residual]; bn2 None: the second Linear's output as is (no ReLU, no residual)."""
+    """[relu](bn2(lin2(relu(bn1(lin1(x)))))) [+ residual]; bn2 None: the second Linear's output as is (no ReLU, no residual).
+    Gradients flowing in must be zero on invalid rows (the convention of autograd.py: every producer masks them)."""
     if bn2 is None and (residual is not None):
         raise ValueError("mlp2_bn: a residual needs the second BatchNorm")
     return _Mlp2Bn.apply(x, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias,
-                         None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias, residual, bn1, bn2, nvalid, K, G,
-                         relu_out and bn2 is not None)
+                         None if bn2 is None else bn2.weight, None if bn2 is None else bn2.bias, residual, lin1, bn1, lin2, bn2,
+                         nvalid, K, G, relu_out and bn2 is not None)
 
 
 class _Linear(Function):
     @staticmethod
-    def forward(ctx, x, W, b, nvalid, K, relu):
+    def forward(ctx, x, W, b, nvalid, K, relu, owner):
         x = _c(x)
         R = x.shape[0]
         y, _ = linear_fwd(x, R, 1, W, b, nvalid, K, out_relu=relu)
         ctx.save_for_backward(x, W, y if relu else None)
-        ctx.meta = (R, nvalid, K, relu, b is not None)
+        ctx.meta = (R, nvalid, K, relu, b is not None, owner)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W, y = ctx.saved_tensors
-        R, nvalid, K, relu, has_b = ctx.meta
+        R, nvalid, K, relu, has_b, owner = ctx.meta
         dy = _c(dy)
         mask = None
         if relu:           # g = dy * [y > 0]: the mask mechanism with scale 1, shift 0 on the saved output
             one = torch.ones(1, y.shape[1], dtype=torch.float32, device=y.device)
             mask = (one, torch.zeros_like(one))
+        Wp, bp = (owner.weight, owner.bias) if owner is not None else (None, None)
         dx, _, _, dW, db = linear_bwd(dy, R, 1, W, nvalid, K, x, zo=y if relu else None, mask=mask,
-                                      want_dx=ctx.needs_input_grad[0], want_db=has_b)
-        return dx, dW, db, None, None, None
+                                      want_dx=ctx.needs_input_grad[0], want_db=has_b, dW_acc=direct_grad(Wp), db_acc=direct_grad(bp))
+        return dx, dW, db, None, None, None, None
 
 
-def linear(x, W, b=None, nvalid=None, K=0, relu=False):
-    """y = [relu](x W^T + b) on valid rows, 0 elsewhere."""
-    return _Linear.apply(x, W, b, nvalid, K, relu)
+def linear(x, W, b=None, nvalid=None, K=0, relu=False, owner=None):
+    """y = [relu](x W^T + b) on valid rows, 0 elsewhere.  owner: the nn.Linear holding W / b (enables in-kernel gradient accumulation)."""
+    return _Linear.apply(x, W, b, nvalid, K, relu, owner)
+
+
+def linear_module(x, lin, nvalid=None, K=0, relu=False):
+    return _Linear.apply(x, lin.weight, lin.bias, nvalid, K, relu, lin)
