@@ -695,6 +695,34 @@ int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, int C, cons
                           int relu, const float* residual, int ldr, float* y, int ldy, void* stream);
 int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int64_t n, float* out, int accumulate, void* stream);
 
+/* The 1 -> 1 -> d MaskedMLP whose input is one scalar per (node, slot) row — GINESignNetPyG's first phi layer
+ * (core/sign_net.py:20: MaskedGINConv(1, n_hid, ...) -> MaskedMLP(1, n_hid) with hidden width 1, masked_layers.py:37) and its
+ * eigen_encoder2 (core/sign_net.py:90,111) — in closed form (csrc/train.hip): every column of the second Linear's output is an affine
+ * image of the same scalar h = relu(bn_a(w1 a)), so the batch statistics of bn_b follow from the moments of h.
+ *   y[g][row][c] = [relu_b](bn_b(w2[c] h + b2[c])),   rows: G <= 2 groups of M, group 1 with a -> -a when negate_second (phi(-x)).
+ * sn_train_scalar_mlp_stats_f32: scalar_state[g][8] (float64: n, mean_a, rstd_a, scale_a, shift_a, mean_h, var_h, -), column_state[g][2][d]
+ *   (p_c = gamma_c w2_c / s_c, s_c = sqrt(w2_c^2 var_h + eps_b)); running statistics of both BatchNorms updated once per group in order.
+ * sn_train_scalar_mlp_apply_f32: one write of y [G*M, d] (0 on invalid rows).
+ * sn_train_scalar_mlp_bwd_f32: one read of dy -> d w1, d gamma_a, d beta_a (1 float each), d w2, d gamma_b, d beta_b (d floats each; the
+ *   bias of the second Linear sits in front of a batch-statistics BatchNorm: its gradient is 0) written, or added when accumulate != 0,
+ *   and da [M] (gradient of the scalar input, both groups).  part: float[G * sn_train_bn_bwd_blocks(M, G) * 2 * d]; row_sums: float[G * M]. */
+typedef struct {
+  const float* a; int64_t M; int G; int negate_second;
+  const int32_t* nvalid; int K; int d;
+  const float* w1; const float* gamma_a; const float* beta_a; float eps_a;
+  const float* w2; const float* b2; const float* gamma_b; const float* beta_b; float eps_b; int relu_b;
+  double* scalar_state;   /* float64: the scalar chain's biases are multiplied by the row count */
+  float* column_state;
+} sn_train_scalar_mlp_args;
+
+int64_t sn_train_scalar_mlp_work_doubles(int64_t M, int G, int d);   /* size of the `work` buffers below */
+int sn_train_scalar_mlp_stats_f32(const sn_train_scalar_mlp_args* args, float momentum_a, float* running_mean_a, float* running_var_a,
+                                  float momentum_b, float* running_mean_b, float* running_var_b, double* work, void* stream);
+int sn_train_scalar_mlp_apply_f32(const sn_train_scalar_mlp_args* args, float* y, void* stream);
+int sn_train_scalar_mlp_bwd_f32(const sn_train_scalar_mlp_args* args, const float* dy, float* part, float* row_sums, float* dw1,
+                                float* dgamma_a, float* dbeta_a, float* dw2, float* dgamma_b, float* dbeta_b, float* da,
+                                int accumulate, double* work, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,9 @@ SIGNATURES = {
     "sn_train_bn_bwd_finish_f32": [_p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "sn_train_bn_apply_f32": [_p, _i, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "sn_train_reduce_parts_f32": [_p, _i, _l, _l, _p, _i, _p],
+    "sn_train_scalar_mlp_stats_f32": [_p, _f, _p, _p, _f, _p, _p, _p, _p],
+    "sn_train_scalar_mlp_apply_f32": [_p, _p, _p],
+    "sn_train_scalar_mlp_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p],
 }
 _SPECIAL_RESTYPE = {"sn_last_error": C.c_char_p, "sn_packed_weight_floats": C.c_int64}
 
@@ -133,6 +136,8 @@ def lib():
         L.sn_ign_contract_scratch_floats.restype = C.c_int64
         L.sn_train_linear_bwd_part_floats.argtypes = [_l, _i, _i, _i]
         L.sn_train_linear_bwd_part_floats.restype = C.c_int64
+        L.sn_train_scalar_mlp_work_doubles.argtypes = [_l, _i, _i]
+        L.sn_train_scalar_mlp_work_doubles.restype = C.c_int64
         if L.sn_version() != 1:
             raise RuntimeError("libsignnet_hip.so ABI version mismatch")
         _lib = L

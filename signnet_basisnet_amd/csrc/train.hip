@@ -730,6 +730,344 @@ __global__ __launch_bounds__(256) void k_tbn_apply(const float* __restrict__ z, 
   st4a(y + row * ldy, c0, C, v);
 }
 
+// =====================================================================================================================
+// The 1 -> 1 -> d MaskedMLP in front of a GNN3d whose input is a scalar per (node, slot) row — GINESignNetPyG's first phi layer and
+// its eigen_encoder2 (core/sign_net.py:20-22, 90-112: Linear(1,1).BN.ReLU.Linear(1,d)[.BN.ReLU]) — in closed form.
+//   z_a = w1 a;  h = relu(bn_a(z_a));  z_b[c] = w2[c] h + b2[c];  y[c] = relu(bn_b(z_b)[c])
+// Every column of z_b is an affine image of the SAME scalar h, so its batch statistics follow from the moments of h
+// (mean_c = w2_c m_h + b2_c, var_c = w2_c^2 v_h) and y[row][c] = relu(p_c (h - m_h) + beta_c), p_c = gamma_c w2_c / sqrt(w2_c^2 v_h + eps):
+// the forward is ONE write of [G, M, d] (no [M, d] intermediate is ever read), the backward ONE read of dy: with g = dy [y > 0],
+//   d gamma_c = (w2_c/s_c) S2_c,  d beta_c = S1_c,  S1_c = sum g,  S2_c = sum g (h - m_h),  s_c = sqrt(w2_c^2 v_h + eps)
+//   d w2_c = (gamma_c/s_c) (S2_c - m2_c (w2_c/s_c) n v_h),  m1_c = S1_c/n,  m2_c = (w2_c/s_c) S2_c / n
+//   d h[row] = sum_c p_c g[row][c] - C1 - (h - m_h) C2,  C1 = sum_c p_c m1_c,  C2 = sum_c p_c (w2_c/s_c) m2_c
+// and the scalar chain (ReLU, one-channel BatchNorm, w1) runs on [G, M] scalars.  Rows: G groups of M (group 1 optionally -a: phi(-x)).
+struct SMlp {
+  const float* a; int64_t M; int G; int negate1; const int32_t* nvalid; int K; int d;
+  const float* w1; const float* ga; const float* ba; float eps_a;
+  const float* w2; const float* b2; const float* gb; const float* bb; float eps_b; int relu_b;
+  double* sst;          // [G][8] (float64: the scalar chain is kept exact to fp64 rounding — its biases are multiplied by the row count):
+                        //   n, mu_a, rstd_a, scale_a (= gamma_a rstd_a), shift_a, m_h, v_h, -
+  float* cst;           // [G][2][d]: p_c, s_c
+};
+// The scalar passes have global, sequential reductions (mean before variance, a's statistics before h's).  They run as a few short
+// multi-workgroup launches over row blocks: a block computes the exact local (n, mean, M2) of its rows — two passes over rows it has
+// just read — and the next kernel's blocks each merge the <= 256 block partials themselves (Chan), so no launch is a serial chain over
+// the rows (a single-workgroup version took 115 us forward and 275 us backward for 47 200 rows).
+constexpr int SM_T = 256;
+constexpr int SM_MAXB = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {      // all threads get the sum; red: SM_T/64 floats
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < SM_T / 64; ++w) s += red[w];
+  return s;
+}
+__device__ __forceinline__ double block_sum_d(double v, double* red) {      // the scalar chain's sums: float64 (a handful per block)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < SM_T / 64; ++w) s += red[w];
+  return s;
+}
+__device__ __forceinline__ int smlp_blocks(int64_t M) {
+  const int64_t want = (M + SM_T - 1) / SM_T;
+  return (int)(want < 1 ? 1 : (want < SM_MAXB ? want : SM_MAXB));
+}
+// local moments of f(row) over the valid rows [lo, hi) of this block: out = (n, mean, M2)
+template <typename F>
+__device__ __forceinline__ void local_moments(const SMlp& p, int64_t lo, int64_t hi, double* red, F&& f, double& n, double& mean, double& m2) {
+  double cn = 0.0, cs = 0.0;
+  for (int64_t r = lo + threadIdx.x; r < hi; r += SM_T)
+    if (row_ok(r, p.M, p.nvalid, p.K)) { cn += 1.0; cs += f(r); }
+  n = block_sum_d(cn, red);
+  mean = n > 0.0 ? block_sum_d(cs, red) / n : 0.0;
+  double cq = 0.0;
+  for (int64_t r = lo + threadIdx.x; r < hi; r += SM_T)
+    if (row_ok(r, p.M, p.nvalid, p.K)) { const double dl = f(r) - mean; cq += dl * dl; }
+  m2 = block_sum_d(cq, red);
+}
+__device__ __forceinline__ void chan_d(double& na, double& ma, double& qa, double nb, double mb, double qb) {
+  if (nb <= 0.0) return;
+  const double n = na + nb, d = mb - ma;
+  ma += d * (nb / n);
+  qa += qb + d * d * (na * nb / n);
+  na = n;
+}
+// every thread merges the nb block partials (n, mean, M2) in block order (<= 256 short steps, identical in every block)
+__device__ __forceinline__ void merge_moments(const double* __restrict__ part, int nb, double& n, double& mean, double& m2) {
+  n = 0.0; mean = 0.0; m2 = 0.0;
+  for (int b = 0; b < nb; ++b) chan_d(n, mean, m2, part[3 * b], part[3 * b + 1], part[3 * b + 2]);
+}
+
+__global__ __launch_bounds__(SM_T) void k_smlp_s1(SMlp p, double* __restrict__ p1) {
+  __shared__ double red[SM_T / 64];
+  const int nb = gridDim.x;
+  const int64_t lo = p.M * blockIdx.x / nb, hi = p.M * (blockIdx.x + 1) / nb;
+  double n, mean, m2;
+  local_moments(p, lo, hi, red, [&](int64_t r) { return (double)p.a[r]; }, n, mean, m2);
+  if (threadIdx.x == 0) { p1[3 * blockIdx.x] = n; p1[3 * blockIdx.x + 1] = mean; p1[3 * blockIdx.x + 2] = m2; }
+}
+// statistics of z_a = (+-w1) a from the moments of a; then the block moments of h per group
+__global__ __launch_bounds__(SM_T) void k_smlp_s2(SMlp p, const double* __restrict__ p1, double* __restrict__ p2, float mom_a, float* rm_a,
+                                                  float* rv_a) {
+  __shared__ double red[SM_T / 64];
+  const int nb = gridDim.x;
+  const int64_t lo = p.M * blockIdx.x / nb, hi = p.M * (blockIdx.x + 1) / nb;
+  double n, ma, qa;
+  merge_moments(p1, nb, n, ma, qa);
+  const double w1 = p.w1[0];
+  const double var = n > 0.0 ? w1 * w1 * qa / n : 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)p.eps_a);
+  const double gam = (p.ga ? p.ga[0] : 1.f), bet = (p.ba ? p.ba[0] : 0.f);
+  for (int grp = 0; grp < p.G; ++grp) {
+    const double sw = (grp == 1 && p.negate1) ? -w1 : w1;
+    const double mu = sw * ma, sc = gam * rstd, sh = bet - mu * sc;
+    double hn, hm, hq;
+    local_moments(p, lo, hi, red, [&](int64_t r) { return fmax(sw * (double)p.a[r] * sc + sh, 0.0); }, hn, hm, hq);
+    if (threadIdx.x == 0) {
+      double* o = p2 + ((int64_t)grp * nb + blockIdx.x) * 3;
+      o[0] = hn; o[1] = hm; o[2] = hq;
+      if (blockIdx.x == 0) {
+        double* s = p.sst + grp * 8;
+        s[0] = n; s[1] = mu; s[2] = rstd; s[3] = sc; s[4] = sh;
+        if (rm_a) {       // group order: two sequential calls of the module
+          const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+          rm_a[0] = (float)((1.0 - mom_a) * rm_a[0] + mom_a * mu);
+          rv_a[0] = (float)((1.0 - mom_a) * rv_a[0] + mom_a * unb);
+        }
+      }
+    }
+  }
+}
+// one workgroup, a thread per column: m_h, v_h of every group, the column constants, the running statistics of bn_b
+__global__ __launch_bounds__(SM_T) void k_smlp_s3(SMlp p, const double* __restrict__ p2, int nb, float mom_b, float* rm_b, float* rv_b) {
+  for (int grp = 0; grp < p.G; ++grp) {
+    double n, mh, qh;
+    merge_moments(p2 + (int64_t)grp * nb * 3, nb, n, mh, qh);
+    const double vh = n > 0.0 ? qh / n : 0.0;
+    if (threadIdx.x == 0) { p.sst[grp * 8 + 5] = mh; p.sst[grp * 8 + 6] = vh; p.sst[grp * 8 + 7] = 0.0; }
+    for (int c = threadIdx.x; c < p.d; c += SM_T) {
+      const double w2 = p.w2[c];
+      const double vc = w2 * w2 * vh;
+      const double s_c = sqrt(vc + (double)p.eps_b);
+      p.cst[(grp * 2 + 0) * p.d + c] = (float)((p.gb ? p.gb[c] : 1.f) * w2 / s_c);
+      p.cst[(grp * 2 + 1) * p.d + c] = (float)s_c;
+      if (rm_b) {
+        const double unb = n > 1.0 ? vc * (n / (n - 1.0)) : vc;
+        rm_b[c] = (float)((1.0 - mom_b) * rm_b[c] + mom_b * (w2 * mh + (p.b2 ? p.b2[c] : 0.f)));
+        rv_b[c] = (float)((1.0 - mom_b) * rv_b[c] + mom_b * unb);
+      }
+    }
+  }
+}
+
+// y[grp][row][c] = [relu](p_c (h - m_h) + beta_c), 0 on invalid rows; one float4 per thread
+__global__ __launch_bounds__(256) void k_smlp_apply(SMlp p, float* __restrict__ y) {
+  const int C4 = p.d >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)p.G * p.M * C4) return;
+  const int64_t row = idx / C4;
+  const int c0 = 4 * (int)(idx - row * C4);
+  const int grp = (int)(row / p.M);
+  const int64_t r = row - (int64_t)grp * p.M;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row_ok(r, p.M, p.nvalid, p.K)) {
+    const double* s = p.sst + grp * 8;
+    const float sg = (grp == 1 && p.negate1) ? -1.f : 1.f;
+    const float hc = fmaxf(sg * p.w1[0] * p.a[r] * (float)s[3] + (float)s[4], 0.f) - (float)s[5];
+    const f32x4 pc = ld4a(p.cst + (grp * 2) * p.d, c0, p.d), be = p.bb ? ldv(p.bb, c0, p.d) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float pre = pc[t] * hc + be[t];
+      v[t] = p.relu_b ? fmaxf(pre, 0.f) : pre;
+    }
+  }
+  st4a(y + row * p.d, c0, p.d, v);
+}
+
+// backward pass over dy: column partials part[grp][blk][0][c] = sum g, [1][c] = sum g (h - m_h), row sums t[grp][row] = sum_c p_c g
+__global__ __launch_bounds__(256) void k_smlp_bwd_pass(SMlp p, const float* __restrict__ dy, int nblk, float* __restrict__ part,
+                                                       float* __restrict__ trow) {
+  const int grp = blockIdx.x / nblk, blk = blockIdx.x - grp * nblk;
+  const int C4 = p.d >> 2, cg = threadIdx.x % C4, rg = threadIdx.x / C4, nrg = 256 / C4;
+  const int64_t r_lo = p.M * blk / nblk, r_hi = p.M * (blk + 1) / nblk;
+  __shared__ float red[2][256][4];
+  __shared__ float rsum[256];
+  const float s3 = (float)p.sst[grp * 8 + 3], s4 = (float)p.sst[grp * 8 + 4], s5 = (float)p.sst[grp * 8 + 5];
+  const float sg = (grp == 1 && p.negate1) ? -1.f : 1.f, w1 = p.w1[0];
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+  f32x4 pc = {0.f, 0.f, 0.f, 0.f}, be = pc;
+  if (rg < nrg) {
+    pc = ld4a(p.cst + (grp * 2) * p.d, 4 * cg, p.d);
+    if (p.bb) be = ldv(p.bb, 4 * cg, p.d);
+  }
+  for (int64_t r0 = r_lo; r0 < r_hi; r0 += nrg) {       // uniform trip count: the row sums go through LDS
+    const int64_t r = r0 + rg;
+    float tsum = 0.f;
+    if (rg < nrg && r < r_hi && row_ok(r, p.M, p.nvalid, p.K)) {
+      const float hc = fmaxf(sg * w1 * p.a[r] * s3 + s4, 0.f) - s5;
+      const f32x4 dv = ld4a(dy + ((int64_t)grp * p.M + r) * p.d, 4 * cg, p.d);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float gv = (!p.relu_b || pc[t] * hc + be[t] > 0.f) ? dv[t] : 0.f;
+        a1[t] += gv;
+        a2[t] += gv * hc;
+        tsum += pc[t] * gv;
+      }
+    }
+    rsum[threadIdx.x] = tsum;
+    __syncthreads();
+    if (threadIdx.x < nrg && r0 + threadIdx.x < r_hi) {
+      float acc = 0.f;
+      for (int q = 0; q < C4; ++q) acc += rsum[threadIdx.x * C4 + q];
+      trow[(int64_t)grp * p.M + r0 + threadIdx.x] = acc;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { red[0][threadIdx.x][t] = a1[t]; red[1][threadIdx.x][t] = a2[t]; }
+  __syncthreads();
+  float* S = part + (int64_t)blockIdx.x * 2 * p.d;
+  for (int i = threadIdx.x; i < 2 * p.d; i += 256) {
+    const int w = i / p.d, c = i - w * p.d;
+    float acc = 0.f;
+    for (int q = 0; q < nrg; ++q) acc += red[w][q * C4 + (c >> 2)][c & 3];
+    S[i] = acc;
+  }
+}
+
+// column finish (16 columns x 16 lanes per block): the closed-form gradients of w2 / gamma_b / beta_b, summed over the groups in order, and
+// the per-column terms of C1, C2: colc[grp][0][c] = p_c m1_c, colc[grp][1][c] = p_c (w2_c/s_c) m2_c
+__global__ __launch_bounds__(256) void k_smlp_b2(SMlp p, const float* __restrict__ part, int nblk, float* dw2, float* dgb, float* dbb,
+                                                 double* __restrict__ colc, int accumulate) {
+  __shared__ double l1[16][17], l2[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int per = (nblk + 15) / 16, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  double g_dgb = 0.0, g_dbb = 0.0, g_dw2 = 0.0;
+  for (int grp = 0; grp < p.G; ++grp) {
+    const float* P = part + (int64_t)grp * nblk * 2 * p.d;
+    double S1 = 0.0, S2 = 0.0;
+    if (c < p.d)
+      for (int b = b0; b < b1; ++b) { S1 += (double)P[(int64_t)b * 2 * p.d + c]; S2 += (double)P[(int64_t)b * 2 * p.d + p.d + c]; }
+    l1[rl][cl] = S1; l2[rl][cl] = S2;
+    __syncthreads();
+    for (int step = 8; step >= 1; step >>= 1) {
+      if (rl < step) {
+        S1 += l1[rl + step][cl]; S2 += l2[rl + step][cl];
+        l1[rl][cl] = S1; l2[rl][cl] = S2;
+      }
+      __syncthreads();
+    }
+    if (rl == 0 && c < p.d) {
+      const double* s = p.sst + grp * 8;
+      const double n = s[0], vh = s[6];
+      const double w2 = p.w2[c], gam = p.gb ? p.gb[c] : 1.f;
+      const double s_c = sqrt(w2 * w2 * vh + (double)p.eps_b), pc = gam * w2 / s_c;
+      const double u = w2 / s_c;                       // y_hat = u (h - m_h)
+      const double m1 = n > 0.0 ? S1 / n : 0.0, m2 = n > 0.0 ? u * S2 / n : 0.0;
+      g_dgb += u * S2;
+      g_dbb += S1;
+      g_dw2 += (gam / s_c) * (S2 - m2 * u * n * vh);
+      colc[(grp * 2 + 0) * p.d + c] = pc * m1;
+      colc[(grp * 2 + 1) * p.d + c] = pc * u * m2;
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && c < p.d) {
+    if (dgb) dgb[c] = (accumulate ? dgb[c] : 0.f) + (float)g_dgb;
+    if (dbb) dbb[c] = (accumulate ? dbb[c] : 0.f) + (float)g_dbb;
+    if (dw2) dw2[c] = (accumulate ? dw2[c] : 0.f) + (float)g_dw2;
+  }
+}
+struct SRow { double za, pre, gav; };
+__device__ __forceinline__ SRow smlp_row(const SMlp& p, const float* __restrict__ trow, int grp, int64_t r, double sw, const double* s,
+                                         double C1, double C2) {
+  SRow o;
+  o.za = sw * (double)p.a[r];
+  o.pre = o.za * s[3] + s[4];
+  const double dh = (double)trow[(int64_t)grp * p.M + r] - C1 - (fmax(o.pre, 0.0) - s[5]) * C2;
+  o.gav = o.pre > 0.0 ? dh : 0.0;
+  return o;
+}
+__device__ __forceinline__ void smlp_c12(const SMlp& p, const double* __restrict__ colc, int grp, double* red, double& C1, double& C2) {
+  double c1 = 0.0, c2 = 0.0;
+  for (int c = threadIdx.x; c < p.d; c += SM_T) { c1 += colc[(grp * 2) * p.d + c]; c2 += colc[(grp * 2 + 1) * p.d + c]; }
+  C1 = block_sum_d(c1, red);
+  C2 = block_sum_d(c2, red);
+}
+// row blocks: sums of the gradient at the one-channel BatchNorm's output: p3[grp][blk] = (sum g_a, sum g_a z_hat)
+__global__ __launch_bounds__(SM_T) void k_smlp_b3(SMlp p, const float* __restrict__ trow, const double* __restrict__ colc, double* __restrict__ p3) {
+  __shared__ double red[SM_T / 64];
+  const int nb = gridDim.x;
+  const int64_t lo = p.M * blockIdx.x / nb, hi = p.M * (blockIdx.x + 1) / nb;
+  const double w1 = p.w1[0];
+  for (int grp = 0; grp < p.G; ++grp) {
+    double C1, C2;
+    smlp_c12(p, colc, grp, red, C1, C2);
+    const double* s = p.sst + grp * 8;
+    const double sw = (grp == 1 && p.negate1) ? -w1 : w1;
+    double sga = 0.0, sgz = 0.0;
+    for (int64_t r = lo + threadIdx.x; r < hi; r += SM_T)
+      if (row_ok(r, p.M, p.nvalid, p.K)) {
+        const SRow q = smlp_row(p, trow, grp, r, sw, s, C1, C2);
+        sga += q.gav;
+        sgz += q.gav * (q.za - s[1]) * s[2];
+      }
+    const double A = block_sum_d(sga, red), Z = block_sum_d(sgz, red);
+    if (threadIdx.x == 0) { p3[((int64_t)grp * nb + blockIdx.x) * 2] = A; p3[((int64_t)grp * nb + blockIdx.x) * 2 + 1] = Z; }
+  }
+}
+// row blocks: d z_a per row -> da (both groups, with their signs) and the block sums of d z_a * a:  p4[grp][blk]
+__global__ __launch_bounds__(SM_T) void k_smlp_b4(SMlp p, const float* __restrict__ trow, const double* __restrict__ colc,
+                                                  const double* __restrict__ p3, double* __restrict__ p4, float* __restrict__ da) {
+  __shared__ double red[SM_T / 64];
+  const int nb = gridDim.x;
+  const int64_t lo = p.M * blockIdx.x / nb, hi = p.M * (blockIdx.x + 1) / nb;
+  const double w1 = p.w1[0];
+  for (int grp = 0; grp < p.G; ++grp) {
+    double C1, C2;
+    smlp_c12(p, colc, grp, red, C1, C2);
+    double A = 0.0, Z = 0.0;
+    for (int b = 0; b < nb; ++b) { A += p3[((int64_t)grp * nb + b) * 2]; Z += p3[((int64_t)grp * nb + b) * 2 + 1]; }
+    const double* s = p.sst + grp * 8;
+    const double n = s[0];
+    const double ma = n > 0.0 ? A / n : 0.0, mz = n > 0.0 ? Z / n : 0.0;
+    const double sgn = (grp == 1 && p.negate1) ? -1.0 : 1.0;
+    const double sw = sgn * w1;
+    double sw1 = 0.0;
+    for (int64_t r = lo + threadIdx.x; r < hi; r += SM_T) {
+      double dav = 0.0;
+      if (row_ok(r, p.M, p.nvalid, p.K)) {
+        const SRow q = smlp_row(p, trow, grp, r, sw, s, C1, C2);
+        const double dza = s[3] * (q.gav - ma - (q.za - s[1]) * s[2] * mz);
+        sw1 += dza * sgn * (double)p.a[r];
+        dav = dza * sw;
+      }
+      if (da) da[r] = (grp == 0 ? 0.f : da[r]) + (float)dav;
+    }
+    const double W = block_sum_d(sw1, red);
+    if (threadIdx.x == 0) p4[(int64_t)grp * nb + blockIdx.x] = W;
+  }
+}
+__global__ __launch_bounds__(64) void k_smlp_b5(int G, int nb, const double* __restrict__ p3, const double* __restrict__ p4, float* dw1, float* dga,
+                                                float* dba, int accumulate) {
+  if (threadIdx.x != 0) return;
+  double w = 0.0, a = 0.0, z = 0.0;
+  for (int grp = 0; grp < G; ++grp)
+    for (int b = 0; b < nb; ++b) { w += p4[(int64_t)grp * nb + b]; a += p3[((int64_t)grp * nb + b) * 2]; z += p3[((int64_t)grp * nb + b) * 2 + 1]; }
+  if (dw1) dw1[0] = (accumulate ? dw1[0] : 0.f) + (float)w;
+  if (dga) dga[0] = (accumulate ? dga[0] : 0.f) + (float)z;
+  if (dba) dba[0] = (accumulate ? dba[0] : 0.f) + (float)a;
+}
+
 int train_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -895,5 +1233,84 @@ extern "C" int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t 
   if (n == 0) return SN_OK;
   hipLaunchKernelGGL(k_tsum_parts, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride, n, out, accumulate);
   SN_CHECK_LAUNCH("sn_train_reduce_parts_f32");
+  return SN_OK;
+}
+
+static int smlp_check(const sn_train_scalar_mlp_args* args, const char* who) {
+  SN_REQUIRE(args, "%s: null arguments", who);
+  const sn_train_scalar_mlp_args& p = *args;
+  SN_REQUIRE(p.a && p.w1 && p.w2 && p.scalar_state && p.column_state && p.M >= 0 && p.G >= 1 && p.G <= 2 && p.d > 0 && p.d % 4 == 0 && p.d <= 1024,
+             "%s: bad arguments", who);
+  SN_REQUIRE(!p.nvalid || p.K > 0, "%s: nvalid needs K > 0", who);
+  SN_REQUIRE(al16(p.column_state), "%s: column_state must be 16-byte aligned", who);
+  return SN_OK;
+}
+static SMlp smlp_of(const sn_train_scalar_mlp_args& p) {
+  return SMlp{p.a, p.M, p.G, p.negate_second, p.nvalid, p.K, p.d, p.w1, p.gamma_a, p.beta_a, p.eps_a, p.w2, p.b2, p.gamma_b, p.beta_b,
+              p.eps_b, p.relu_b, p.scalar_state, p.column_state};
+}
+
+static int smlp_nb(int64_t M) {
+  const int64_t want = (M + SM_T - 1) / SM_T;
+  return (int)(want < 1 ? 1 : (want < SM_MAXB ? want : SM_MAXB));
+}
+extern "C" int64_t sn_train_scalar_mlp_work_doubles(int64_t M, int G, int d) {
+  const int64_t nb = smlp_nb(M);
+  if (G < 1) G = 1;
+  return 3 * nb + 3 * (int64_t)G * nb + 2 * (int64_t)G * d + 2 * (int64_t)G * nb + (int64_t)G * nb + 16;
+}
+
+extern "C" int sn_train_scalar_mlp_stats_f32(const sn_train_scalar_mlp_args* args, float momentum_a, float* running_mean_a,
+                                             float* running_var_a, float momentum_b, float* running_mean_b, float* running_var_b,
+                                             double* work, void* stream) {
+  int rc = smlp_check(args, "sn_train_scalar_mlp_stats_f32");
+  if (rc != SN_OK) return rc;
+  SN_REQUIRE(work, "sn_train_scalar_mlp_stats_f32: work buffer missing");
+  SN_REQUIRE((running_mean_a != nullptr) == (running_var_a != nullptr) && (running_mean_b != nullptr) == (running_var_b != nullptr),
+             "sn_train_scalar_mlp_stats_f32: running_mean / running_var go together");
+  const int nb = smlp_nb(args->M);
+  double* p1 = work;
+  double* p2 = work + 3 * nb;
+  hipStream_t st = (hipStream_t)stream;
+  const SMlp p = smlp_of(*args);
+  hipLaunchKernelGGL(k_smlp_s1, dim3(nb), dim3(SM_T), 0, st, p, p1);
+  hipLaunchKernelGGL(k_smlp_s2, dim3(nb), dim3(SM_T), 0, st, p, p1, p2, momentum_a, running_mean_a, running_var_a);
+  hipLaunchKernelGGL(k_smlp_s3, dim3(1), dim3(SM_T), 0, st, p, p2, nb, momentum_b, running_mean_b, running_var_b);
+  SN_CHECK_LAUNCH("sn_train_scalar_mlp_stats_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_train_scalar_mlp_apply_f32(const sn_train_scalar_mlp_args* args, float* y, void* stream) {
+  int rc = smlp_check(args, "sn_train_scalar_mlp_apply_f32");
+  if (rc != SN_OK) return rc;
+  SN_REQUIRE(y && al16(y), "sn_train_scalar_mlp_apply_f32: y must be 16-byte aligned");
+  const int64_t n = (int64_t)args->G * args->M * (args->d / 4);
+  if (n == 0) return SN_OK;
+  hipLaunchKernelGGL(k_smlp_apply, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, smlp_of(*args), y);
+  SN_CHECK_LAUNCH("sn_train_scalar_mlp_apply_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_train_scalar_mlp_bwd_f32(const sn_train_scalar_mlp_args* args, const float* dy, float* part, float* row_sums, float* dw1,
+                                           float* dgamma_a, float* dbeta_a, float* dw2, float* dgamma_b, float* dbeta_b, float* da,
+                                           int accumulate, double* work, void* stream) {
+  int rc = smlp_check(args, "sn_train_scalar_mlp_bwd_f32");
+  if (rc != SN_OK) return rc;
+  SN_REQUIRE(dy && part && row_sums && work && al16(dy) && args->d <= 1024, "sn_train_scalar_mlp_bwd_f32: bad arguments");
+  if (args->M == 0) return SN_OK;
+  const int nblk = sn_train_bn_bwd_blocks(args->M, args->G);
+  const int nb = smlp_nb(args->M);
+  const int G = args->G, d = args->d;
+  double* colc = work;
+  double* p3 = colc + 2 * (int64_t)G * d;
+  double* p4 = p3 + 2 * (int64_t)G * nb;
+  hipStream_t st = (hipStream_t)stream;
+  const SMlp p = smlp_of(*args);
+  hipLaunchKernelGGL(k_smlp_bwd_pass, dim3((unsigned)(nblk * G)), dim3(256), 0, st, p, dy, nblk, part, row_sums);
+  hipLaunchKernelGGL(k_smlp_b2, dim3((unsigned)cdiv(d, 16)), dim3(256), 0, st, p, part, nblk, dw2, dgamma_b, dbeta_b, colc, accumulate);
+  hipLaunchKernelGGL(k_smlp_b3, dim3(nb), dim3(SM_T), 0, st, p, row_sums, colc, p3);
+  hipLaunchKernelGGL(k_smlp_b4, dim3(nb), dim3(SM_T), 0, st, p, row_sums, colc, p3, p4, da);
+  hipLaunchKernelGGL(k_smlp_b5, dim3(1), dim3(64), 0, st, G, nb, p3, p4, dw1, dgamma_a, dbeta_a, accumulate);
+  SN_CHECK_LAUNCH("sn_train_scalar_mlp_bwd_f32");
   return SN_OK;
 }

@@ -563,25 +563,38 @@ class SignNetGNN(nn.Module):
             bn = norm.bn if isinstance(norm, MaskedBN) else norm
             return AG.linear_bn_act(x, lin.weight, lin.bias, bn, nvalid, K_, relu=relu, residual=residual)
 
-        if self.variant != "alchemy":      # computed and discarded by the reference (core/sign_net.py:111-112): side effects only
-            with torch.no_grad():
-                ee2 = sn.eigen_encoder2
-                p2 = lin_bn(s0.view(N * K, 1), ee2.layers[0], ee2.norms[0], nv, K)
-                lin_bn(p2, ee2.layers[1], ee2.norms[1], nv, K)
-        # ---- phi(x) + phi(-x)
         from . import train_stage as T
         d = self.cfg["n_hid"]
         stage = self.train_stages and T.supported(d, d)
+
+        def scalar_form(l0, l1):     # Linear(1, 1, bias=False) -> Linear(1, d): the closed-form 1 -> 1 -> d kernels apply
+            return stage and l0.weight.numel() == 1 and l0.bias is None and l1.weight.shape[1] == 1
+
+        if self.variant != "alchemy":      # computed and discarded by the reference (core/sign_net.py:111-112): side effects only
+            with torch.no_grad():
+                ee2 = sn.eigen_encoder2
+                if scalar_form(ee2.layers[0], ee2.layers[1]):
+                    T.scalar_mlp_stats(s0, ee2.layers[0], ee2.norms[0].bn, ee2.layers[1], ee2.norms[1].bn, nv, K)
+                else:
+                    p2 = lin_bn(s0.view(N * K, 1), ee2.layers[0], ee2.norms[0], nv, K)
+                    lin_bn(p2, ee2.layers[1], ee2.norms[1], nv, K)
+        # ---- phi(x) + phi(-x)
         convs, norms = list(sn.phi.convs), list(sn.phi.norms)
         if stage and len(convs) > 1:
             # layers >= 1 (the [d,d] links): both sign passes stacked group-major [2, N*K, d] — shared weights, separate batch
             # statistics — through the stage kernels: one pass over the rows per link and direction (train_stage.py)
-            xs = []
-            for sign in (0, 1):
-                a = AG.gin_aggregate(x0.view(N, -1), convs[0].layer.eps, plan, rplan, negate=(sign == 1))
-                h = lin_bn(a.view(N * K, -1), convs[0].nn.layers[0], convs[0].nn.norms[0], nv, K)
-                xs.append(lin_bn(h, convs[0].nn.layers[1], norms[0], nv, K))
-            x = torch.cat(xs, 0)
+            if scalar_form(convs[0].nn.layers[0], convs[0].nn.layers[1]):
+                # GINESignNetPyG's first layer, 1 -> 1 -> d on the scalar aggregate, both signs (aggregate(-x) = -aggregate(x)): closed form
+                a0 = AG.gin_aggregate(x0.view(N, -1), convs[0].layer.eps, plan, rplan)
+                x = T.scalar_mlp(a0.view(-1), convs[0].nn.layers[0], convs[0].nn.norms[0].bn, convs[0].nn.layers[1], norms[0].bn, nv, K,
+                                 G=2, negate_second=True)
+            else:
+                xs = []
+                for sign in (0, 1):
+                    a = AG.gin_aggregate(x0.view(N, -1), convs[0].layer.eps, plan, rplan, negate=(sign == 1))
+                    h = lin_bn(a.view(N * K, -1), convs[0].nn.layers[0], convs[0].nn.norms[0], nv, K)
+                    xs.append(lin_bn(h, convs[0].nn.layers[1], norms[0], nv, K))
+                x = torch.cat(xs, 0)
             plan2, rplan2 = ops.doubled_plan(plan), ops.doubled_plan(rplan)
             for conv, norm in zip(convs[1:], norms[1:]):
                 a = AG.gin_aggregate(x.view(2 * N, -1), conv.layer.eps, plan2, rplan2)

@@ -39,6 +39,13 @@ class _BwdArgs(C.Structure):
                 ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int)]
 
 
+class _SMlpArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("M", C.c_int64), ("G", C.c_int), ("negate_second", C.c_int), ("nvalid", C.c_void_p), ("K", C.c_int),
+                ("d", C.c_int), ("w1", C.c_void_p), ("gamma_a", C.c_void_p), ("beta_a", C.c_void_p), ("eps_a", C.c_float),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("gamma_b", C.c_void_p), ("beta_b", C.c_void_p), ("eps_b", C.c_float),
+                ("relu_b", C.c_int), ("scalar_state", C.c_void_p), ("column_state", C.c_void_p)]
+
+
 def supported(d_in: int, d_out: int) -> bool:
     return 0 < d_in <= 128 and 0 < d_out <= 128 and d_in % 4 == 0 and d_out % 4 == 0
 
@@ -255,3 +262,92 @@ def linear(x, W, b=None, nvalid=None, K=0, relu=False, owner=None):
 
 def linear_module(x, lin, nvalid=None, K=0, relu=False):
     return _Linear.apply(x, lin.weight, lin.bias, nvalid, K, relu, lin)
+
+
+# ----------------------------------------------------------------------------- the 1 -> 1 -> d MaskedMLP on a scalar input, closed form
+def _bn_run(bn):
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    return mom, (bn.running_mean if track else None), (bn.running_var if track else None), track
+
+
+def _smlp_args(a, M, G, negate, nvalid, K, lin1, bn1, lin2, bn2, relu_b, sst, cst):
+    d = lin2.weight.shape[0]
+    det = lambda t: None if t is None else t.detach()
+    return _SMlpArgs(ptr(a), M, G, int(negate), ptr(nvalid), int(K), d, ptr(det(lin1.weight)), ptr(det(bn1.weight)), ptr(det(bn1.bias)),
+                     float(bn1.eps), ptr(det(lin2.weight)), ptr(det(lin2.bias)), ptr(det(bn2.weight)), ptr(det(bn2.bias)), float(bn2.eps),
+                     int(relu_b), ptr(sst), ptr(cst))
+
+
+def scalar_mlp_stats(a, lin1, bn1, lin2, bn2, nvalid, K, G=1, negate_second=False):
+    """Only the side effects of the module call (running statistics of both BatchNorms) and the closed-form batch state:
+    GINESignNetPyG evaluates eigen_encoder2 and discards the value (core/sign_net.py:111-112)."""
+    a = _c(a.detach()).view(-1)
+    M, d = a.numel(), lin2.weight.shape[0]
+    sst = torch.empty(G, 8, dtype=torch.float64, device=a.device)
+    cst = torch.empty(G, 2, d, dtype=torch.float32, device=a.device)
+    args = _smlp_args(a, M, G, negate_second, nvalid, K, lin1, bn1, lin2, bn2, True, sst, cst)
+    ma, rma, rva, ta = _bn_run(bn1)
+    mb, rmb, rvb, tb = _bn_run(bn2)
+    work = torch.empty(int(lib().sn_train_scalar_mlp_work_doubles(M, G, d)), dtype=torch.float64, device=a.device)
+    with ops._span("sn_train_scalar_mlp_stats_f32"):
+        check(lib().sn_train_scalar_mlp_stats_f32(C.byref(args), ma, ptr(rma), ptr(rva), mb, ptr(rmb), ptr(rvb), ptr(work), stream()),
+              "sn_train_scalar_mlp_stats_f32")
+    for bn, t in ((bn1, ta), (bn2, tb)):
+        if t and bn.num_batches_tracked is not None:
+            for _ in range(G):
+                ops._count_batch(bn)
+    return a, sst, cst
+
+
+class _ScalarMlp(Function):
+    @staticmethod
+    def forward(ctx, a, w1, ga, ba, w2, b2, gb, bb, lin1, bn1, lin2, bn2, nvalid, K, G, negate_second):
+        a_, sst, cst = scalar_mlp_stats(a, lin1, bn1, lin2, bn2, nvalid, K, G, negate_second)
+        M, d = a_.numel(), lin2.weight.shape[0]
+        y = torch.empty(G * M, d, dtype=torch.float32, device=a.device)
+        args = _smlp_args(a_, M, G, negate_second, nvalid, K, lin1, bn1, lin2, bn2, True, sst, cst)
+        with ops._span("sn_train_scalar_mlp_apply_f32"):
+            check(lib().sn_train_scalar_mlp_apply_f32(C.byref(args), ptr(y), stream()), "sn_train_scalar_mlp_apply_f32")
+        ctx.save_for_backward(a_, sst, cst)
+        ctx.meta = (lin1, bn1, lin2, bn2, nvalid, K, G, negate_second, a.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a_, sst, cst = ctx.saved_tensors
+        lin1, bn1, lin2, bn2, nvalid, K, G, negate_second, ashape = ctx.meta
+        dy = _c(dy)
+        M, d = a_.numel(), lin2.weight.shape[0]
+        dev = dy.device
+        args = _smlp_args(a_, M, G, negate_second, nvalid, K, lin1, bn1, lin2, bn2, True, sst, cst)
+        nblk = int(lib().sn_train_bn_bwd_blocks(M, G))
+        part = torch.empty(G * nblk * 2 * d, dtype=torch.float32, device=dev)
+        trow = torch.empty(G * M, dtype=torch.float32, device=dev)
+        da = torch.empty(M, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        targets = [direct_grad(p) for p in (lin1.weight, bn1.weight, bn1.bias, lin2.weight, bn2.weight, bn2.bias)]
+        acc = all(t is not None for t in targets)
+        if not acc:
+            small = torch.empty(3 + 3 * d, dtype=torch.float32, device=dev)
+            targets = [small[0:1], small[1:2], small[2:3], small[3:3 + d], small[3 + d:3 + 2 * d], small[3 + 2 * d:]]
+        work = torch.empty(int(lib().sn_train_scalar_mlp_work_doubles(M, G, d)), dtype=torch.float64, device=dev)
+        with ops._span("sn_train_scalar_mlp_bwd_f32"):
+            check(lib().sn_train_scalar_mlp_bwd_f32(C.byref(args), ptr(dy), ptr(part), ptr(trow), *[ptr(t) for t in targets], ptr(da),
+                                                    int(acc), ptr(work), stream()), "sn_train_scalar_mlp_bwd_f32")
+        if acc:
+            gw1 = gga = gba = gw2 = ggb = gbb = None
+        else:
+            gw1, gga, gba = targets[0].view_as(lin1.weight), targets[1], targets[2]
+            gw2, ggb, gbb = targets[3].view_as(lin2.weight), targets[4], targets[5]
+        gb2 = None if lin2.bias is None else torch.zeros_like(lin2.bias)      # in front of a batch-statistics BatchNorm: exactly 0
+        return (None if da is None else da.view(ashape), gw1, gga, gba, gw2, gb2, ggb, gbb,
+                None, None, None, None, None, None, None, None)
+
+
+def scalar_mlp(a, lin1, bn1, lin2, bn2, nvalid, K, G=1, negate_second=False):
+    """relu(bn2(lin2(relu(bn1(lin1(a)))))) for a scalar input a [M] with lin1 = Linear(1, 1, bias=False): -> [G*M, d]; G = 2 with
+    negate_second evaluates a and -a (the two sign passes) with shared weights and separate batch statistics."""
+    if lin1.weight.numel() != 1 or lin1.bias is not None or lin2.weight.shape[1] != 1:
+        raise ValueError("scalar_mlp: needs Linear(1, 1, bias=False) -> Linear(1, d)")
+    return _ScalarMlp.apply(a, lin1.weight, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight, bn2.bias,
+                            lin1, bn1, lin2, bn2, nvalid, K, G, negate_second)

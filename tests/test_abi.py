@@ -40,7 +40,7 @@ def test_python_binding_covers_the_header(lib):
                                      "sn_ign_contract_scratch_floats", "sn_evd_work_ints",
                                      "sn_linear_wgrad_scratch_floats", "sn_layernorm_bwd_scratch_floats",
                                      "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_gatedgcn_max_edges",
-                                     "sn_train_linear_bwd_part_floats"}
+                                     "sn_train_linear_bwd_part_floats", "sn_train_scalar_mlp_work_doubles"}
     assert set(declared_symbols()) == bound
 
 

@@ -219,3 +219,59 @@ def test_headline_size_link_both_signs():
     for k, v in {"W1": lin1.weight.grad, "W2": lin2.weight.grad, "g1": bn1.weight.grad, "be1": bn1.bias.grad, "g2": bn2.weight.grad,
                  "be2": bn2.bias.grad, "x": xd.grad}.items():
         print(k, attributed(v, g32[k], g64[k], "d" + k))
+
+
+@pytest.mark.parametrize("d,N,K,G", [(128, 200, 16, 2), (64, 57, 8, 1), (36, 40, 6, 2)])
+def test_scalar_mlp_closed_form_vs_float64(d, N, K, G):
+    """The 1 -> 1 -> d MaskedMLP on a scalar input (GINESignNetPyG's first phi layer, both sign passes; eigen_encoder2) in closed form
+    against float64 autograd of the literal composition Linear(1,1).BN.ReLU.Linear(1,d).BN.ReLU over the valid rows."""
+    from signnet_basisnet_amd import train_stage as T
+    gen = torch.Generator().manual_seed(3)
+    torch.manual_seed(3)
+    M = N * K
+    nvalid = torch.randint(1, K + 1, (N,), generator=gen)
+    m = _mask(nvalid, K, M)
+    lin1, lin2 = torch.nn.Linear(1, 1, bias=False), torch.nn.Linear(1, d, bias=False)
+    bn1, bn2 = torch.nn.BatchNorm1d(1), torch.nn.BatchNorm1d(d)
+    with torch.no_grad():
+        lin1.weight.fill_(0.7)
+        for bn in (bn1, bn2):
+            bn.weight.copy_(torch.rand(bn.weight.shape, generator=gen) + 0.5)
+            bn.bias.copy_(torch.randn(bn.bias.shape, generator=gen) * 0.3)
+    a = torch.randn(M, generator=gen) * m
+    cot = torch.randn(G * M, d, generator=gen) * m.repeat(G)[:, None]
+
+    def run_ref(dt):
+        p = {"w1": lin1.weight, "w2": lin2.weight, "ga": bn1.weight, "ba": bn1.bias, "gb": bn2.weight, "bb": bn2.bias}
+        p = {k: v.detach().to(dt).requires_grad_(True) for k, v in p.items()}
+        aa = a.detach().clone().to(dt).requires_grad_(True)
+        ys = []
+        for g in range(G):
+            x = (aa if g == 0 else -aa)[:, None]
+            z = (x @ p["w1"].T) * m[:, None]
+            h, _, _ = _bn(z, m, p["ga"], p["ba"])
+            h = torch.relu(h) * m[:, None]
+            z2 = (h @ p["w2"].T) * m[:, None]
+            y, _, _ = _bn(z2, m, p["gb"], p["bb"])
+            ys.append(torch.relu(y) * m[:, None])
+        y = torch.cat(ys, 0)
+        (y * cot.to(dt)).sum().backward()
+        return y, {**{k: v.grad for k, v in p.items()}, "a": aa.grad}
+
+    y64, g64 = run_ref(torch.float64)
+    y32, g32 = run_ref(torch.float32)
+    torch.nn.ModuleList([lin1, bn1, lin2, bn2]).to(DEV).train()
+    ad = a.to(DEV).requires_grad_(True)
+    y = T.scalar_mlp(ad, lin1, bn1, lin2, bn2, nvalid.to(DEV).int(), K, G=G, negate_second=(G == 2))
+    (y * cot.to(DEV)).sum().backward()
+    attributed(y, y32, y64, "y")
+    hip = {"w1": lin1.weight.grad, "w2": lin2.weight.grad, "ga": bn1.weight.grad, "ba": bn1.bias.grad, "gb": bn2.weight.grad,
+           "bb": bn2.bias.grad, "a": ad.grad}
+    gmax = max(v.abs().max().item() for v in g64.values())
+    for k, v in hip.items():
+        assert v is not None, k
+        if g64[k].abs().max().item() <= 1e-9 * gmax:
+            assert v.abs().max().item() <= 1e-5 * gmax, k
+            continue
+        attributed(v, g32[k], g64[k], "d" + k)
+    assert int(bn1.num_batches_tracked) == G and int(bn2.num_batches_tracked) == G
