@@ -677,6 +677,8 @@ typedef struct {
   float* sums_part;
   float* dw_part;
   int want_db;
+  const float* dot_x; int lddot;   /* optional [G*R, d_in]: dot_part[g*nblk + blk] = sum over the block's rows of gx . dot_x — summed by the */
+  float* dot_part;                 /*   caller it is the eps gradient of the GIN / GINE aggregation that produced the operand */
 } sn_train_linear_bwd_args;
 
 int sn_train_linear_blocks(int64_t R, int G);
@@ -694,6 +696,16 @@ int sn_train_bn_bwd_finish_f32(const float* sums_part, int nblk, int G, int C, c
 int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K, const float* state,
                           int relu, const float* residual, int ldr, float* y, int ldy, void* stream);
 int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int64_t n, float* out, int accumulate, void* stream);
+
+/* Adjoints of the aggregations of a layer whose input also feeds a residual (x -> aggregate -> MLP, y = ... + x; GNN3d.forward
+ * sign_net.py:36-43, GNN.forward model.py:52-60): d x = aggregate^T(d a) + d y in ONE pass (`plus` = d y) instead of an extra elementwise add.
+ * sn_gin_aggregate_add_f32: out = sn_gin_aggregate_f32(x) + plus on the CSR given (the reverse CSR for an adjoint).
+ * sn_gine_aggregate_bwd_add_f32: sn_gine_aggregate_bwd_f32 with dh += plus. */
+int sn_gin_aggregate_add_f32(const float* x, const float* plus, float* out, int64_t N, int F, const int32_t* rowptr, const int32_t* col,
+                             const float* eps, void* stream);
+int sn_gine_aggregate_bwd_add_f32(const float* h, const float* ee, const float* g, const float* plus, int64_t N, int C,
+                                  const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm, const float* eps,
+                                  float* dh, float* dee, void* stream);
 
 /* The 1 -> 1 -> d MaskedMLP whose input is one scalar per (node, slot) row — GINESignNetPyG's first phi layer
  * (core/sign_net.py:20: MaskedGINConv(1, n_hid, ...) -> MaskedMLP(1, n_hid) with hidden width 1, masked_layers.py:37) and its

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void k_gine_bwd(const float* __restrict__ h, c
                                                   const float* __restrict__ g, int64_t N, int C,
                                                   const int32_t* __restrict__ rrow, const int32_t* __restrict__ rcol,
                                                   const int32_t* __restrict__ rperm, const float* __restrict__ eps,
-                                                  float* __restrict__ dh, float* __restrict__ dee) {
+                                                  float* __restrict__ dh, float* __restrict__ dee, const float* __restrict__ plus) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= N * C) return;
   const int64_t j = idx / C;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_gine_bwd(const float* __restrict__ h, c
     acc += gi;
     dee[e * C + c] = gi;
   }
-  dh[idx] = acc;
+  dh[idx] = plus ? acc + plus[idx] : acc;      // plus: the gradient of the residual branch of h, added in the same pass
 }
 
 // ============================================================================ broadcasts / scatters / reductions
@@ -588,8 +588,19 @@ extern "C" int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const 
   SN_REQUIRE(h && ee && g && rev_rowptr && dh && dee && N >= 0 && C > 0, "sn_gine_aggregate_bwd_f32: bad arguments");
   if (N == 0) return SN_OK;
   hipLaunchKernelGGL(k_gine_bwd, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, h, ee, g, N, C, rev_rowptr,
-                     rev_col, rev_eperm, eps, dh, dee);
+                     rev_col, rev_eperm, eps, dh, dee, (const float*)nullptr);
   SN_CHECK_LAUNCH("sn_gine_aggregate_bwd_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_gine_aggregate_bwd_add_f32(const float* h, const float* ee, const float* g, const float* plus, int64_t N, int C,
+                                             const int32_t* rev_rowptr, const int32_t* rev_col, const int32_t* rev_eperm, const float* eps,
+                                             float* dh, float* dee, void* stream) {
+  SN_REQUIRE(h && ee && g && plus && rev_rowptr && dh && dee && N >= 0 && C > 0, "sn_gine_aggregate_bwd_add_f32: bad arguments");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_gine_bwd, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, h, ee, g, N, C, rev_rowptr,
+                     rev_col, rev_eperm, eps, dh, dee, plus);
+  SN_CHECK_LAUNCH("sn_gine_aggregate_bwd_add_f32");
   return SN_OK;
 }
 

@@ -469,7 +469,7 @@ template <typename VT, int U, int CW>
 __global__ __launch_bounds__(256) void k_gin_gather(const VT* __restrict__ x, VT* __restrict__ out, int64_t N,
                                                     int FV, int P, const int32_t* __restrict__ rowptr,
                                                     const int32_t* __restrict__ col,
-                                                    const float* __restrict__ eps, int negate) {
+                                                    const float* __restrict__ eps, int negate, const VT* __restrict__ plus) {
   constexpr int NSUB = 256 / CW;
   constexpr int KU = SN_GIN_KU;                  // neighbours of a node in flight
   constexpr int CHUNK = gin_xcd_chunk(U, CW);
@@ -512,29 +512,31 @@ __global__ __launch_bounds__(256) void k_gin_gather(const VT* __restrict__ x, VT
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (n0 + u < N) {
-      const VT r = self_term(acc[u], self[u], sc);
-      out[(n0 + u) * FV + f] = negate ? zero - r : r;
+      VT r = self_term(acc[u], self[u], sc);
+      if (negate) r = zero - r;
+      if (plus) r = r + plus[(n0 + u) * FV + f];      // the adjoint's other branch (a residual's gradient), added in the same pass
+      out[(n0 + u) * FV + f] = r;
     }
   }
 }
 
 template <typename VT, int U, int CW>
 static void launch_gin_gather(const VT* x, VT* out, int64_t N, int FV, const int32_t* rowptr, const int32_t* col, const float* eps,
-                              int negate, hipStream_t st) {
+                              int negate, hipStream_t st, const VT* plus = nullptr) {
   constexpr int NSUB = 256 / CW;
   constexpr int CHUNK = gin_xcd_chunk(U, CW);
   const int P = CW == 256 ? (int)cdiv(FV, 256) : 1;
   const int64_t grp = (int64_t)8 * CHUNK * P;
   const int64_t nblk = cdiv(cdiv(N, (int64_t)U * NSUB) * P, grp) * grp;
-  hipLaunchKernelGGL((k_gin_gather<VT, U, CW>), dim3((unsigned)nblk), dim3(256), 0, st, x, out, N, FV, P, rowptr, col, eps, negate);
+  hipLaunchKernelGGL((k_gin_gather<VT, U, CW>), dim3((unsigned)nblk), dim3(256), 0, st, x, out, N, FV, P, rowptr, col, eps, negate, plus);
 }
 template <typename VT>
 static void dispatch_gin_gather(const VT* x, VT* out, int64_t N, int FV, const int32_t* rowptr, const int32_t* col, const float* eps,
-                                int negate, hipStream_t st) {
-  if (FV > 128) launch_gin_gather<VT, SN_GIN_UW, 256>(x, out, N, FV, rowptr, col, eps, negate, st);
-  else if (FV > 64) launch_gin_gather<VT, SN_GIN_UN, 128>(x, out, N, FV, rowptr, col, eps, negate, st);
-  else if (FV > 32) launch_gin_gather<VT, SN_GIN_UN, 64>(x, out, N, FV, rowptr, col, eps, negate, st);
-  else launch_gin_gather<VT, SN_GIN_UN, 32>(x, out, N, FV, rowptr, col, eps, negate, st);
+                                int negate, hipStream_t st, const VT* plus = nullptr) {
+  if (FV > 128) launch_gin_gather<VT, SN_GIN_UW, 256>(x, out, N, FV, rowptr, col, eps, negate, st, plus);
+  else if (FV > 64) launch_gin_gather<VT, SN_GIN_UN, 128>(x, out, N, FV, rowptr, col, eps, negate, st, plus);
+  else if (FV > 32) launch_gin_gather<VT, SN_GIN_UN, 64>(x, out, N, FV, rowptr, col, eps, negate, st, plus);
+  else launch_gin_gather<VT, SN_GIN_UN, 32>(x, out, N, FV, rowptr, col, eps, negate, st, plus);
 }
 
 // ============================================================================ GIN aggregate (LDS slab)
@@ -1229,6 +1231,20 @@ extern "C" int sn_gin_aggregate_f32(const float* x, float* out, int64_t N, int F
     dispatch_gin_gather<float>(x, out, N, F, rowptr, col, eps, negate, st);
   }
   SN_CHECK_LAUNCH("sn_gin_aggregate_f32");
+  return SN_OK;
+}
+
+/* out = aggregate(x) + plus: the adjoint of a GIN aggregation whose input also feeds a residual (x -> aggregate, x -> + y): the residual's
+ * gradient is added in the same pass instead of a separate elementwise launch.  F % 4 == 0, 16-byte aligned rows. */
+extern "C" int sn_gin_aggregate_add_f32(const float* x, const float* plus, float* out, int64_t N, int F, const int32_t* rowptr,
+                                        const int32_t* col, const float* eps, void* stream) {
+  SN_REQUIRE(x && plus && out && rowptr && N >= 0 && F > 0 && F % 4 == 0 && al16(x) && al16(out) && al16(plus),
+             "sn_gin_aggregate_add_f32: bad arguments (F % 4 == 0, 16-byte aligned rows)");
+  SN_REQUIRE(x != out, "sn_gin_aggregate_add_f32: in-place aggregation is not supported");
+  if (N == 0) return SN_OK;
+  dispatch_gin_gather<float4>(reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), N, F / 4, rowptr, col, eps, 0,
+                              (hipStream_t)stream, reinterpret_cast<const float4*>(plus));
+  SN_CHECK_LAUNCH("sn_gin_aggregate_add_f32");
   return SN_OK;
 }
 

@@ -363,6 +363,7 @@ struct TBwd {
   const float* x; int ldx; const float* xs; const float* xt; int xrelu; const float* xmu;   // [G][d_in]
   const float* W; int ldw;
   float* gx; int ldgx; float* sums; float* dwp; int want_db;
+  const float* dotx; int lddot; float* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
   int nblk;             // workgroups per group
   int dbg;
 };
@@ -377,8 +378,8 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   float4* wl = reinterpret_cast<float4*>(t_lds);                          // W^T image: [ot2 < nti][kk < nto][64] float4
   float* dzs = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;  // [TROWS][LDO]
   float* xsg = dzs + TROWS * LDO;                                          // [TROWS][LDI]  raw x (x_hat is re-formed at each use)
-  float* red = xsg + TROWS * LDI;                                          // [2 sums][4 row tiles][16*NTI] running column sums of gx
-  float* xcol = red + 2 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
+  float* red = xsg + TROWS * LDI;                                          // [3 sums][4 row tiles][16*NTI] running column sums of gx
+  float* xcol = red + 3 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
   float* ocol = xcol + 3 * 16 * NTI;                                       // [5][16*NTO] coef a | b | c | mask scale | mask shift
   constexpr int CI = 16 * NTI, CO = 16 * NTO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   float dbacc = 0.f;
   // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
   // with them the kernel spilled)
-  for (int i = threadIdx.x; i < 2 * 4 * 16 * NTI; i += 64 * TW) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 3 * 4 * 16 * NTI; i += 64 * TW) red[i] = 0.f;
 
   // The raw rows of round r+1 are requested (into registers) right after round r's tiles are published, so the HBM latency runs
   // under the round's 256 MFMAs per wave; a wave loads the column tiles kk = half, half+2, ... of its 16 rows.
@@ -528,6 +529,15 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
             }
           }
           if (row < a.R) st4a(gr, c0, a.d_in, v);
+          if (a.dotx) {
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (valid) q = ld4a(a.dotx + (goff + row) * a.lddot, c0, a.d_in);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a3 = t16_sum(v[r] * q[r]);
+              if (lr == 0) red[(2 * 4 + rt) * 16 * NTI + c0 + r] += a3;
+            }
+          }
           if (xmu) {
             const f32x4 mu = lds4(xcol + 2 * CI + c0);
 #pragma unroll
@@ -582,6 +592,21 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       s += __shfl_xor(s, 32, 64);
       const int o = 16 * wave + lr;
       if (g == 0 && o < a.d_out) P[(int64_t)a.d_out * a.d_in + o] = s;
+    }
+  }
+  if (want_dx && a.dotx) {        // (the last round's barrier has published the sums)
+    float t = 0.f;
+    for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) t += red[2 * 4 * 16 * NTI + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    __shared__ float wsum[TW];
+    if (lane == 0) wsum[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tt = 0.f;
+#pragma unroll
+      for (int w = 0; w < TW; ++w) tt += wsum[w];
+      a.dotp[blockIdx.x] = tt;
     }
   }
   if (want_dx && xmu) {
@@ -781,38 +806,34 @@ __device__ __forceinline__ int smlp_blocks(int64_t M) {
   return (int)(want < 1 ? 1 : (want < SM_MAXB ? want : SM_MAXB));
 }
 // local moments of f(row) over the valid rows [lo, hi) of this block: out = (n, mean, M2)
+// raw sums (n, sum f, sum f^2) of f(row) over the valid rows [lo, hi) of this block, in float64: with 53 bits the raw second moment
+// loses nothing to cancellation, and merging block partials is a plain sum (a block-parallel one: <= SM_T partials)
 template <typename F>
-__device__ __forceinline__ void local_moments(const SMlp& p, int64_t lo, int64_t hi, double* red, F&& f, double& n, double& mean, double& m2) {
-  double cn = 0.0, cs = 0.0;
+__device__ __forceinline__ void local_sums(const SMlp& p, int64_t lo, int64_t hi, double* red, F&& f, double& n, double& s1, double& s2) {
+  double cn = 0.0, cs = 0.0, cq = 0.0;
   for (int64_t r = lo + threadIdx.x; r < hi; r += SM_T)
-    if (row_ok(r, p.M, p.nvalid, p.K)) { cn += 1.0; cs += f(r); }
+    if (row_ok(r, p.M, p.nvalid, p.K)) { const double v = f(r); cn += 1.0; cs += v; cq += v * v; }
   n = block_sum_d(cn, red);
-  mean = n > 0.0 ? block_sum_d(cs, red) / n : 0.0;
-  double cq = 0.0;
-  for (int64_t r = lo + threadIdx.x; r < hi; r += SM_T)
-    if (row_ok(r, p.M, p.nvalid, p.K)) { const double dl = f(r) - mean; cq += dl * dl; }
-  m2 = block_sum_d(cq, red);
+  s1 = block_sum_d(cs, red);
+  s2 = block_sum_d(cq, red);
 }
-__device__ __forceinline__ void chan_d(double& na, double& ma, double& qa, double nb, double mb, double qb) {
-  if (nb <= 0.0) return;
-  const double n = na + nb, d = mb - ma;
-  ma += d * (nb / n);
-  qa += qb + d * d * (na * nb / n);
-  na = n;
-}
-// every thread merges the nb block partials (n, mean, M2) in block order (<= 256 short steps, identical in every block)
-__device__ __forceinline__ void merge_moments(const double* __restrict__ part, int nb, double& n, double& mean, double& m2) {
-  n = 0.0; mean = 0.0; m2 = 0.0;
-  for (int b = 0; b < nb; ++b) chan_d(n, mean, m2, part[3 * b], part[3 * b + 1], part[3 * b + 2]);
+// (n, mean, biased variance) from the nb <= SM_T block partials
+__device__ __forceinline__ void merge_sums(const double* __restrict__ part, int nb, double* red, double& n, double& mean, double& var) {
+  const bool in = (int)threadIdx.x < nb;
+  n = block_sum_d(in ? part[3 * threadIdx.x] : 0.0, red);
+  const double s1 = block_sum_d(in ? part[3 * threadIdx.x + 1] : 0.0, red);
+  const double s2 = block_sum_d(in ? part[3 * threadIdx.x + 2] : 0.0, red);
+  mean = n > 0.0 ? s1 / n : 0.0;
+  var = n > 0.0 ? fmax(s2 / n - mean * mean, 0.0) : 0.0;
 }
 
 __global__ __launch_bounds__(SM_T) void k_smlp_s1(SMlp p, double* __restrict__ p1) {
   __shared__ double red[SM_T / 64];
   const int nb = gridDim.x;
   const int64_t lo = p.M * blockIdx.x / nb, hi = p.M * (blockIdx.x + 1) / nb;
-  double n, mean, m2;
-  local_moments(p, lo, hi, red, [&](int64_t r) { return (double)p.a[r]; }, n, mean, m2);
-  if (threadIdx.x == 0) { p1[3 * blockIdx.x] = n; p1[3 * blockIdx.x + 1] = mean; p1[3 * blockIdx.x + 2] = m2; }
+  double n, s1, s2;
+  local_sums(p, lo, hi, red, [&](int64_t r) { return (double)p.a[r]; }, n, s1, s2);
+  if (threadIdx.x == 0) { p1[3 * blockIdx.x] = n; p1[3 * blockIdx.x + 1] = s1; p1[3 * blockIdx.x + 2] = s2; }
 }
 // statistics of z_a = (+-w1) a from the moments of a; then the block moments of h per group
 __global__ __launch_bounds__(SM_T) void k_smlp_s2(SMlp p, const double* __restrict__ p1, double* __restrict__ p2, float mom_a, float* rm_a,
@@ -820,17 +841,17 @@ __global__ __launch_bounds__(SM_T) void k_smlp_s2(SMlp p, const double* __restri
   __shared__ double red[SM_T / 64];
   const int nb = gridDim.x;
   const int64_t lo = p.M * blockIdx.x / nb, hi = p.M * (blockIdx.x + 1) / nb;
-  double n, ma, qa;
-  merge_moments(p1, nb, n, ma, qa);
+  double n, ma, va;
+  merge_sums(p1, nb, red, n, ma, va);
   const double w1 = p.w1[0];
-  const double var = n > 0.0 ? w1 * w1 * qa / n : 0.0;
+  const double var = w1 * w1 * va;
   const double rstd = 1.0 / sqrt(var + (double)p.eps_a);
   const double gam = (p.ga ? p.ga[0] : 1.f), bet = (p.ba ? p.ba[0] : 0.f);
   for (int grp = 0; grp < p.G; ++grp) {
     const double sw = (grp == 1 && p.negate1) ? -w1 : w1;
     const double mu = sw * ma, sc = gam * rstd, sh = bet - mu * sc;
     double hn, hm, hq;
-    local_moments(p, lo, hi, red, [&](int64_t r) { return fmax(sw * (double)p.a[r] * sc + sh, 0.0); }, hn, hm, hq);
+    local_sums(p, lo, hi, red, [&](int64_t r) { return fmax(sw * (double)p.a[r] * sc + sh, 0.0); }, hn, hm, hq);
     if (threadIdx.x == 0) {
       double* o = p2 + ((int64_t)grp * nb + blockIdx.x) * 3;
       o[0] = hn; o[1] = hm; o[2] = hq;
@@ -848,10 +869,10 @@ __global__ __launch_bounds__(SM_T) void k_smlp_s2(SMlp p, const double* __restri
 }
 // one workgroup, a thread per column: m_h, v_h of every group, the column constants, the running statistics of bn_b
 __global__ __launch_bounds__(SM_T) void k_smlp_s3(SMlp p, const double* __restrict__ p2, int nb, float mom_b, float* rm_b, float* rv_b) {
+  __shared__ double red[SM_T / 64];
   for (int grp = 0; grp < p.G; ++grp) {
-    double n, mh, qh;
-    merge_moments(p2 + (int64_t)grp * nb * 3, nb, n, mh, qh);
-    const double vh = n > 0.0 ? qh / n : 0.0;
+    double n, mh, vh;
+    merge_sums(p2 + (int64_t)grp * nb * 3, nb, red, n, mh, vh);
     if (threadIdx.x == 0) { p.sst[grp * 8 + 5] = mh; p.sst[grp * 8 + 6] = vh; p.sst[grp * 8 + 7] = 0.0; }
     for (int c = threadIdx.x; c < p.d; c += SM_T) {
       const double w2 = p.w2[c];
@@ -1035,8 +1056,9 @@ __global__ __launch_bounds__(SM_T) void k_smlp_b4(SMlp p, const float* __restric
   for (int grp = 0; grp < p.G; ++grp) {
     double C1, C2;
     smlp_c12(p, colc, grp, red, C1, C2);
-    double A = 0.0, Z = 0.0;
-    for (int b = 0; b < nb; ++b) { A += p3[((int64_t)grp * nb + b) * 2]; Z += p3[((int64_t)grp * nb + b) * 2 + 1]; }
+    const bool inb = (int)threadIdx.x < nb;       // nb <= SM_T
+    const double A = block_sum_d(inb ? p3[((int64_t)grp * nb + threadIdx.x) * 2] : 0.0, red);
+    const double Z = block_sum_d(inb ? p3[((int64_t)grp * nb + threadIdx.x) * 2 + 1] : 0.0, red);
     const double* s = p.sst + grp * 8;
     const double n = s[0];
     const double ma = n > 0.0 ? A / n : 0.0, mz = n > 0.0 ? Z / n : 0.0;
@@ -1057,12 +1079,13 @@ __global__ __launch_bounds__(SM_T) void k_smlp_b4(SMlp p, const float* __restric
     if (threadIdx.x == 0) p4[(int64_t)grp * nb + blockIdx.x] = W;
   }
 }
-__global__ __launch_bounds__(64) void k_smlp_b5(int G, int nb, const double* __restrict__ p3, const double* __restrict__ p4, float* dw1, float* dga,
-                                                float* dba, int accumulate) {
-  if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(SM_T) void k_smlp_b5(int G, int nb, const double* __restrict__ p3, const double* __restrict__ p4, float* dw1, float* dga,
+                                                  float* dba, int accumulate) {
+  __shared__ double red[SM_T / 64];
   double w = 0.0, a = 0.0, z = 0.0;
-  for (int grp = 0; grp < G; ++grp)
-    for (int b = 0; b < nb; ++b) { w += p4[(int64_t)grp * nb + b]; a += p3[((int64_t)grp * nb + b) * 2]; z += p3[((int64_t)grp * nb + b) * 2 + 1]; }
+  for (int i = threadIdx.x; i < G * nb; i += SM_T) { w += p4[i]; a += p3[2 * i]; z += p3[2 * i + 1]; }
+  w = block_sum_d(w, red); a = block_sum_d(a, red); z = block_sum_d(z, red);
+  if (threadIdx.x != 0) return;
   if (dw1) dw1[0] = (accumulate ? dw1[0] : 0.f) + (float)w;
   if (dga) dga[0] = (accumulate ? dga[0] : 0.f) + (float)z;
   if (dba) dba[0] = (accumulate ? dba[0] : 0.f) + (float)a;
@@ -1168,14 +1191,17 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   SN_REQUIRE((p.x_scale == nullptr) == (p.x_shift == nullptr), "sn_train_linear_bwd_f32: x_scale / x_shift go together");
   SN_REQUIRE(!p.x_mean || (p.gx && p.sums_part), "sn_train_linear_bwd_f32: x_mean needs gx and sums_part");
   SN_REQUIRE(!p.nvalid || p.K > 0, "sn_train_linear_bwd_f32: nvalid needs K > 0");
+  SN_REQUIRE(!p.dot_x || (p.dot_part && p.gx && p.lddot >= p.d_in && p.lddot % 4 == 0 && al16(p.dot_x)),
+             "sn_train_linear_bwd_f32: dot_x needs gx, dot_part and 16-byte aligned rows");
   for (const float* v : {p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift, p.x_scale, p.x_shift, p.x_mean})
     SN_REQUIRE(!v || al16(v), "sn_train_linear_bwd_f32: column vectors must be 16-byte aligned");
   if (p.R == 0) return SN_OK;
   const int nblk = sn_train_linear_bwd_blocks(p.R, p.G);
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
-         p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db, nblk,
+         p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
+         p.dot_x, p.lddot, p.dot_part, nblk,
          getenv("SN_TRAIN_DBG") ? atoi(getenv("SN_TRAIN_DBG")) : 0};
-  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(2 * 4 + 3 + 5) * 16 * 8 * sizeof(float);
+  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float);
   int rc;
   if ((rc = raise_lds(k_tlin_bwd<8, 8>, lds, "sn_train_linear_bwd_f32")) != SN_OK) return rc;
   hipLaunchKernelGGL((k_tlin_bwd<8, 8>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, (hipStream_t)stream, a);
@@ -1310,7 +1336,7 @@ extern "C" int sn_train_scalar_mlp_bwd_f32(const sn_train_scalar_mlp_args* args,
   hipLaunchKernelGGL(k_smlp_b2, dim3((unsigned)cdiv(d, 16)), dim3(256), 0, st, p, part, nblk, dw2, dgamma_b, dbeta_b, colc, accumulate);
   hipLaunchKernelGGL(k_smlp_b3, dim3(nb), dim3(SM_T), 0, st, p, row_sums, colc, p3);
   hipLaunchKernelGGL(k_smlp_b4, dim3(nb), dim3(SM_T), 0, st, p, row_sums, colc, p3, p4, da);
-  hipLaunchKernelGGL(k_smlp_b5, dim3(1), dim3(64), 0, st, G, nb, p3, p4, dw1, dgamma_a, dbeta_a, accumulate);
+  hipLaunchKernelGGL(k_smlp_b5, dim3(1), dim3(SM_T), 0, st, G, nb, p3, p4, dw1, dgamma_a, dbeta_a, accumulate);
   SN_CHECK_LAUNCH("sn_train_scalar_mlp_bwd_f32");
   return SN_OK;
 }

@@ -596,9 +596,8 @@ class SignNetGNN(nn.Module):
                     xs.append(lin_bn(h, convs[0].nn.layers[1], norms[0], nv, K))
                 x = torch.cat(xs, 0)
             plan2, rplan2 = ops.doubled_plan(plan), ops.doubled_plan(rplan)
-            for conv, norm in zip(convs[1:], norms[1:]):
-                a = AG.gin_aggregate(x.view(2 * N, -1), conv.layer.eps, plan2, rplan2)
-                x = T.mlp2_bn(a.view(2 * N * K, d), conv.nn.layers[0], conv.nn.norms[0].bn, conv.nn.layers[1], norm.bn, nv, K, 2, residual=x)
+            for conv, norm in zip(convs[1:], norms[1:]):     # aggregate -> link -> link -> + x, adjoints fused the same way
+                x = T.gin_layer(x, conv.layer.eps, conv.nn.layers[0], conv.nn.norms[0].bn, conv.nn.layers[1], norm.bn, plan2, rplan2, nv, K, 2)
             x = AG.masked_add(x[:N * K], x[N * K:], nv, K)
         else:
             phis = []
@@ -642,10 +641,10 @@ class SignNetGNN(nn.Module):
                 e = AG.embedding_sum(data.edge_attr, [t.weight for t in enc.embeddings], plan.status[5:6])
             else:
                 e = lin_bn(data.edge_attr.contiguous(), enc.layers[0], enc.norms[0])
-            u = AG.gine_aggregate(h, e, conv.layer.eps, plan, rplan)
             if stage and isinstance(conv.nn.norms[0], nn.BatchNorm1d) and isinstance(norm, nn.BatchNorm1d):
-                h = T.mlp2_bn(u, conv.nn.layers[0], conv.nn.norms[0], conv.nn.layers[1], norm, None, 0, 1, residual=h)
+                h = T.gine_layer(h, e, conv.layer.eps, conv.nn.layers[0], conv.nn.norms[0], conv.nn.layers[1], norm, plan, rplan)
             else:
+                u = AG.gine_aggregate(h, e, conv.layer.eps, plan, rplan)
                 u = lin_bn(u, conv.nn.layers[0], conv.nn.norms[0])
                 h = lin_bn(u, conv.nn.layers[1], norm, residual=h)
         pooled = AG.segment_pool(h, plan, g.pooling)

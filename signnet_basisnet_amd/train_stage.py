@@ -36,7 +36,8 @@ class _BwdArgs(C.Structure):
                 ("mask_scale", C.c_void_p), ("mask_shift", C.c_void_p),
                 ("x", C.c_void_p), ("ldx", C.c_int), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_relu", C.c_int),
                 ("x_mean", C.c_void_p), ("W", C.c_void_p), ("ldw", C.c_int), ("gx", C.c_void_p), ("ldgx", C.c_int),
-                ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int)]
+                ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int),
+                ("dot_x", C.c_void_p), ("lddot", C.c_int), ("dot_part", C.c_void_p)]
 
 
 class _SMlpArgs(C.Structure):
@@ -115,9 +116,10 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
 
 
 def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state=None, x_relu=False, want_sums=False,
-               want_dx=True, want_db=True, dW_acc=None, db_acc=None):
+               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None):
     """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h.
-    dW_acc / db_acc: accumulate the weight / bias gradient into these buffers (returned dW / db are then None)."""
+    dW_acc / db_acc: accumulate the weight / bias gradient into these buffers (returned dW / db are then None).
+    dot_x: also sum gx . dot_x over all rows (per-workgroup partials, left on `linear_bwd.dot_part` for the caller to add up)."""
     W = _w(W)
     d_out, d_in = W.shape
     dev = dy.device
@@ -131,7 +133,11 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
                  ptr(None if mask is None else mask[0]), ptr(None if mask is None else mask[1]),
                  ptr(x), x.stride(0), ptr(None if x_state is None else x_state.scale), ptr(None if x_state is None else x_state.shift),
                  int(x_relu), ptr(x_state.mean if (want_sums and x_state is not None) else None), ptr(W), W.stride(0),
-                 ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db))
+                 ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db), ptr(dot_x), 0 if dot_x is None else dot_x.stride(0), None)
+    linear_bwd.dot_part = None
+    if dot_x is not None:
+        linear_bwd.dot_part = torch.empty(G * nblk, dtype=torch.float32, device=dev)
+        a.dot_part = ptr(linear_bwd.dot_part)
     with ops._span("sn_train_linear_bwd_f32"):
         check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
     nw = d_out * d_in
@@ -186,38 +192,125 @@ def bn_apply(z, R, G, nvalid, K, st, relu, residual):
 
 
 # ----------------------------------------------------------------------------- Functions
+def _mlp2_forward(x, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, res):
+    W1, b1, W2, b2 = lin1.weight, lin1.bias, lin2.weight, lin2.bias
+    z1, st1 = linear_fwd(x, R, G, W1, b1, nvalid, K, bn=bn1)
+    z2, st2 = linear_fwd(z1, R, G, W2, b2, nvalid, K, in_state=st1, in_relu=True, bn=bn2)
+    y = bn_apply(z2, R, G, nvalid, K, st2, relu_out, res) if bn2 is not None else z2
+    return y, z1, z2, st1, st2
+
+
+def _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, want_dx, dot_x=None):
+    """-> (dx, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2); parameter gradients already accumulated in-kernel come back as None."""
+    dg2 = dbe2 = coef2 = mask2 = None
+    if st2 is not None:
+        sums2, nb2 = bn_bwd_sums(dy, z2, R, G, nvalid, K, st2, relu_out)
+        coef2, dg2, dbe2 = bn_bwd_finish(sums2, nb2, st2, bn2.weight, direct_grad(bn2.weight), direct_grad(bn2.bias))
+        mask2 = (st2.scale, st2.shift) if relu_out else None
+    gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, lin2.weight, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
+                                           x_state=st1, x_relu=True, want_sums=True, want_db=lin2.bias is not None,
+                                           dW_acc=direct_grad(lin2.weight), db_acc=direct_grad(lin2.bias))
+    coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, bn1.weight, direct_grad(bn1.weight), direct_grad(bn1.bias))
+    dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, lin1.weight, nvalid, K, x, zo=z1, coef=coef1, want_dx=want_dx, want_db=lin1.bias is not None,
+                                    dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias), dot_x=dot_x)
+    if bn1.weight is None:
+        dg1 = dbe1 = None
+    if bn2 is None or bn2.weight is None:
+        dg2 = dbe2 = None
+    return dx, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2
+
+
 class _Mlp2Bn(Function):
     @staticmethod
     def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, residual, lin1, bn1, lin2, bn2, nvalid, K, G, relu_out):
         x = _c(x)
         R = x.shape[0] // G
-        z1, st1 = linear_fwd(x, R, G, W1, b1, nvalid, K, bn=bn1)
-        z2, st2 = linear_fwd(z1, R, G, W2, b2, nvalid, K, in_state=st1, in_relu=True, bn=bn2)
         res = None if residual is None else _c(residual)
-        y = bn_apply(z2, R, G, nvalid, K, st2, relu_out, res) if bn2 is not None else z2
-        ctx.save_for_backward(x, W1, W2, z1, z2, g1, g2)
-        ctx.meta = (R, G, nvalid, K, relu_out, st1, st2, b1 is not None, b2 is not None, residual is not None, lin1, bn1, lin2, bn2)
+        y, z1, z2, st1, st2 = _mlp2_forward(x, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, res)
+        ctx.save_for_backward(x, z1, z2)
+        ctx.meta = (R, G, nvalid, K, relu_out, st1, st2, residual is not None, lin1, bn1, lin2, bn2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W1, W2, z1, z2, g1, g2 = ctx.saved_tensors
-        R, G, nvalid, K, relu_out, st1, st2, has_b1, has_b2, has_res, lin1, bn1, lin2, bn2 = ctx.meta
+        x, z1, z2 = ctx.saved_tensors
+        R, G, nvalid, K, relu_out, st1, st2, has_res, lin1, bn1, lin2, bn2 = ctx.meta
         dy = _c(dy)
-        dg2 = dbe2 = coef2 = mask2 = None
-        if st2 is not None:
-            sums2, nb2 = bn_bwd_sums(dy, z2, R, G, nvalid, K, st2, relu_out)
-            coef2, dg2, dbe2 = bn_bwd_finish(sums2, nb2, st2, g2, direct_grad(bn2.weight), direct_grad(bn2.bias))
-            mask2 = (st2.scale, st2.shift) if relu_out else None
-        gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, W2, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
-                                               x_state=st1, x_relu=True, want_sums=True, want_db=has_b2,
-                                               dW_acc=direct_grad(lin2.weight), db_acc=direct_grad(lin2.bias))
-        coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, g1, direct_grad(bn1.weight), direct_grad(bn1.bias))
-        dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, W1, nvalid, K, x, zo=z1, coef=coef1, want_dx=ctx.needs_input_grad[0], want_db=has_b1,
-                                        dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias))
-        return (dx, dW1, db1, dg1 if g1 is not None else None, dbe1 if g1 is not None else None, dW2, db2,
-                dg2 if g2 is not None else None, dbe2 if g2 is not None else None, dy if has_res else None,
-                None, None, None, None, None, None, None, None)
+        grads = _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, ctx.needs_input_grad[0])
+        return grads + (dy if has_res else None, None, None, None, None, None, None, None, None)
+
+
+class _GinLayer(Function):
+    """x -> a = (1+eps) x + sum_nbr x -> mlp2_bn(a) + x: one GNN3d layer (sign_net.py:36-43) for G stacked sign passes.  The adjoint of
+    the aggregation takes the residual's gradient in the same pass, and the eps gradient comes out of the first Linear's backward."""
+
+    @staticmethod
+    def forward(ctx, x, eps, W1, b1, g1, be1, W2, b2, g2, be2, lin1, bn1, lin2, bn2, plan, rplan, nvalid, K, G):
+        x = _c(x)
+        d = x.shape[1]
+        R = x.shape[0] // G
+        a = ops.gin_aggregate(x.view(-1, K * d), plan, eps.detach()).view(-1, d)
+        y, z1, z2, st1, st2 = _mlp2_forward(a, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, x)
+        ctx.save_for_backward(x, a, z1, z2, eps)
+        ctx.meta = (R, G, nvalid, K, st1, st2, lin1, bn1, lin2, bn2, rplan)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a, z1, z2, eps = ctx.saved_tensors
+        R, G, nvalid, K, st1, st2, lin1, bn1, lin2, bn2, rplan = ctx.meta
+        dy = _c(dy)
+        d = x.shape[1]
+        want_eps = ctx.needs_input_grad[1]
+        grads = _mlp2_backward(dy, a, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, True, dot_x=x if want_eps else None)
+        da = grads[0]
+        deps = linear_bwd.dot_part.sum().view(1) if want_eps else None
+        dx = torch.empty_like(x)
+        with ops._span("sn_gin_aggregate_add_f32"):
+            check(lib().sn_gin_aggregate_add_f32(ptr(da), ptr(dy), ptr(dx), x.shape[0] // K, K * d, ptr(rplan.rowptr), ptr(rplan.col),
+                                                 ptr(eps.detach()), stream()), "sn_gin_aggregate_add_f32")
+        return (dx, deps) + grads[1:] + (None,) * 9
+
+
+def gin_layer(x, conv_eps, lin1, bn1, lin2, bn2, plan, rplan, nvalid, K, G=1):
+    """One phi layer (l >= 1) on [G*N*K, d] rows: relu(bn2(lin2(relu(bn1(lin1(GIN-aggregate(x))))))) + x."""
+    return _GinLayer.apply(x, conv_eps, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight, bn2.bias,
+                           lin1, bn1, lin2, bn2, plan, rplan, nvalid, K, G)
+
+
+class _GineLayer(Function):
+    """h, e -> u = (1+eps) h + sum relu(h_j + e_ji) -> mlp2_bn(u) + h: one layer of GNN.forward (model.py:52-60, pyg_gnn_wrapper.py:19-28)."""
+
+    @staticmethod
+    def forward(ctx, h, e, eps, W1, b1, g1, be1, W2, b2, g2, be2, lin1, bn1, lin2, bn2, plan, rplan):
+        h, e = _c(h), _c(e)
+        u = ops.gine_aggregate(h, e, plan, eps.detach())
+        y, z1, z2, st1, st2 = _mlp2_forward(u, h.shape[0], 1, lin1, bn1, lin2, bn2, None, 0, True, h)
+        ctx.save_for_backward(h, e, u, z1, z2, eps)
+        ctx.meta = (st1, st2, lin1, bn1, lin2, bn2, rplan)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, e, u, z1, z2, eps = ctx.saved_tensors
+        st1, st2, lin1, bn1, lin2, bn2, rplan = ctx.meta
+        dy = _c(dy)
+        N, d = h.shape
+        want_eps = ctx.needs_input_grad[2]
+        grads = _mlp2_backward(dy, u, z1, z2, st1, st2, N, 1, lin1, bn1, lin2, bn2, None, 0, True, True, dot_x=h if want_eps else None)
+        du = grads[0]
+        deps = linear_bwd.dot_part.sum().view(1) if want_eps else None
+        dh, dee = torch.empty_like(h), torch.empty_like(e)
+        with ops._span("sn_gine_aggregate_bwd_add_f32"):
+            check(lib().sn_gine_aggregate_bwd_add_f32(ptr(h), ptr(e), ptr(du), ptr(dy), N, d, ptr(rplan.rowptr), ptr(rplan.col),
+                                                      ptr(rplan.eperm), ptr(eps.detach()), ptr(dh), ptr(dee), stream()),
+                  "sn_gine_aggregate_bwd_add_f32")
+        return (dh, dee, deps) + grads[1:] + (None,) * 6
+
+
+def gine_layer(h, e, conv_eps, lin1, bn1, lin2, bn2, plan, rplan):
+    return _GineLayer.apply(h, e, conv_eps, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight, bn2.bias,
+                            lin1, bn1, lin2, bn2, plan, rplan)
 
 
 def mlp2_bn(x, lin1, bn1, lin2, bn2, nvalid=None, K=0, G=1, residual=None, relu_out=True):
