@@ -678,7 +678,7 @@ typedef struct {
   float* dw_part;
   int want_db;
   const float* dot_x; int lddot;   /* optional [G*R, d_in]: dot_part[g*nblk + blk] = sum over the block's rows of gx . dot_x — summed by the */
-  float* dot_part;                 /*   caller it is the eps gradient of the GIN / GINE aggregation that produced the operand */
+  double* dot_part;                /*   caller it is the eps gradient of the GIN / GINE aggregation that produced the operand (float64: a cancelling sum) */
 } sn_train_linear_bwd_args;
 
 int sn_train_linear_blocks(int64_t R, int G);

@@ -363,7 +363,7 @@ struct TBwd {
   const float* x; int ldx; const float* xs; const float* xt; int xrelu; const float* xmu;   // [G][d_in]
   const float* W; int ldw;
   float* gx; int ldgx; float* sums; float* dwp; int want_db;
-  const float* dotx; int lddot; float* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
+  const float* dotx; int lddot; double* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
   int nblk;             // workgroups per group
   int dbg;
 };
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   float* red = xsg + TROWS * LDI;                                          // [3 sums][4 row tiles][16*NTI] running column sums of gx
   float* xcol = red + 3 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
   float* ocol = xcol + 3 * 16 * NTI;                                       // [5][16*NTO] coef a | b | c | mask scale | mask shift
+  double* redd = reinterpret_cast<double*>(ocol + 5 * 16 * NTO);           // [4 row tiles][16*NTI] float64 sums of gx . dot_x
   constexpr int CI = 16 * NTI, CO = 16 * NTO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
   const int rt = wave & 3, half = wave >> 2;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
   // with them the kernel spilled)
   for (int i = threadIdx.x; i < 3 * 4 * 16 * NTI; i += 64 * TW) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) redd[i] = 0.0;
 
   // The raw rows of round r+1 are requested (into registers) right after round r's tiles are published, so the HBM latency runs
   // under the round's 256 MFMAs per wave; a wave loads the column tiles kk = half, half+2, ... of its 16 rows.
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float a3 = t16_sum(v[r] * q[r]);
-              if (lr == 0) red[(2 * 4 + rt) * 16 * NTI + c0 + r] += a3;
+              if (lr == 0) redd[rt * 16 * NTI + c0 + r] += (double)a3;      // a cancelling scalar sum over all rows and columns: float64
             }
           }
           if (xmu) {
@@ -595,15 +597,15 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     }
   }
   if (want_dx && a.dotx) {        // (the last round's barrier has published the sums)
-    float t = 0.f;
-    for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) t += red[2 * 4 * 16 * NTI + i];
+    double t = 0.0;
+    for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) t += redd[i];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-    __shared__ float wsum[TW];
+    __shared__ double wsum[TW];
     if (lane == 0) wsum[wave] = t;
     __syncthreads();
     if (threadIdx.x == 0) {
-      float tt = 0.f;
+      double tt = 0.0;
 #pragma unroll
       for (int w = 0; w < TW; ++w) tt += wsum[w];
       a.dotp[blockIdx.x] = tt;
@@ -1201,7 +1203,7 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
          p.dot_x, p.lddot, p.dot_part, nblk,
          getenv("SN_TRAIN_DBG") ? atoi(getenv("SN_TRAIN_DBG")) : 0};
-  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float);
+  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
   int rc;
   if ((rc = raise_lds(k_tlin_bwd<8, 8>, lds, "sn_train_linear_bwd_f32")) != SN_OK) return rc;
   hipLaunchKernelGGL((k_tlin_bwd<8, 8>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, (hipStream_t)stream, a);

@@ -136,7 +136,7 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
                  ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db), ptr(dot_x), 0 if dot_x is None else dot_x.stride(0), None)
     linear_bwd.dot_part = None
     if dot_x is not None:
-        linear_bwd.dot_part = torch.empty(G * nblk, dtype=torch.float32, device=dev)
+        linear_bwd.dot_part = torch.empty(G * nblk, dtype=torch.float64, device=dev)
         a.dot_part = ptr(linear_bwd.dot_part)
     with ops._span("sn_train_linear_bwd_f32"):
         check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
@@ -264,7 +264,7 @@ class _GinLayer(Function):
         want_eps = ctx.needs_input_grad[1]
         grads = _mlp2_backward(dy, a, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, True, dot_x=x if want_eps else None)
         da = grads[0]
-        deps = linear_bwd.dot_part.sum().view(1) if want_eps else None
+        deps = linear_bwd.dot_part.sum().float().view(1) if want_eps else None
         dx = torch.empty_like(x)
         with ops._span("sn_gin_aggregate_add_f32"):
             check(lib().sn_gin_aggregate_add_f32(ptr(da), ptr(dy), ptr(dx), x.shape[0] // K, K * d, ptr(rplan.rowptr), ptr(rplan.col),
@@ -299,7 +299,7 @@ class _GineLayer(Function):
         want_eps = ctx.needs_input_grad[2]
         grads = _mlp2_backward(dy, u, z1, z2, st1, st2, N, 1, lin1, bn1, lin2, bn2, None, 0, True, True, dot_x=h if want_eps else None)
         du = grads[0]
-        deps = linear_bwd.dot_part.sum().view(1) if want_eps else None
+        deps = linear_bwd.dot_part.sum().float().view(1) if want_eps else None
         dh, dee = torch.empty_like(h), torch.empty_like(e)
         with ops._span("sn_gine_aggregate_bwd_add_f32"):
             check(lib().sn_gine_aggregate_bwd_add_f32(ptr(h), ptr(e), ptr(du), ptr(dy), N, d, ptr(rplan.rowptr), ptr(rplan.col),

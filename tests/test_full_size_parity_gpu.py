@@ -139,6 +139,17 @@ SHIPPED = {
                 avg_d=dict(lin=2.2, exp=0.6, log=1.1)),
     "transformer": dict(cls="TransformerNet", hidden_dim=64, out_dim=64, L=10, n_heads=8, readout="sum", pos_enc_dim=16,
                         pe_aggregate="concat", full_graph=False, layer_norm=True),
+    # the three shipped MASKED configs (k = 37 = every eigenvector of the largest ZINC graph, sign_inv_net = masked_gin):
+    # configs/gatedgcn/GatedGCN_ZINC_LapPE_signinv_GIN_mask.json, pna/PNA_ZINC_LapPE_signinv_GIN_mask.json,
+    # transformer/Transformer_ZINC_LapPE_signinv_GIN_masked.json
+    "gatedgcn_mask": dict(cls="GatedGCNNet", hidden_dim=67, out_dim=67, L=16, readout="mean", pos_enc_dim=37, pe_aggregate="concat",
+                          sign_inv_net="masked_gin", phi_out_dim=67),
+    "pna_mask": dict(cls="PNANet", hidden_dim=70, out_dim=70, L=16, readout="sum", pos_enc_dim=37, pe_aggregate="concat", graph_norm=True,
+                     aggregators="mean max min std", scalers="identity amplification attenuation", towers=5, divide_input_first=True,
+                     divide_input_last=True, edge_dim=40, pretrans_layers=1, posttrans_layers=1, gru=False,
+                     avg_d=dict(lin=2.2, exp=0.6, log=1.1), sign_inv_net="masked_gin", phi_out_dim=70),
+    "transformer_mask": dict(cls="TransformerNet", hidden_dim=56, out_dim=56, L=10, n_heads=8, readout="sum", pos_enc_dim=37,
+                             pe_aggregate="concat", full_graph=False, layer_norm=True, sign_inv_net="masked_gin", phi_out_dim=16),
 }
 
 
@@ -150,13 +161,16 @@ def test_dgl_base_nets_at_the_shipped_configs_vs_oracle_fp32_and_fp64(name):
     from signnet_basisnet_amd import dgl_nets, synth
     cfg = dict(SHIPPED[name])
     cls = getattr(dgl_nets, cfg.pop("cls"))
-    params = dict(_COMMON, device="cuda:0", **cfg)
+    params = dict(_COMMON, device="cuda:0")
+    params.update(cfg)
+    masked = params["sign_inv_net"] == "masked_gin"
+    base = name.split("_")[0]
     torch.manual_seed(3)
     net = cls(params)
     PU.bn_randomize(net, 2)
     with torch.no_grad():                                   # GATConv's bias is zero-initialised: make it count
         for n_, p_ in net.named_parameters():
-            if name == "gat" and n_.startswith("layers.") and n_.endswith(".bias") and n_.count(".") == 2:
+            if base == "gat" and n_.startswith("layers.") and n_.endswith(".bias") and n_.count(".") == 2:
                 p_.copy_(0.1 * torch.randn(p_.shape, generator=torch.Generator().manual_seed(5)))
     sd32 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     sd64 = PU.to_f64(sd32)
@@ -169,15 +183,18 @@ def test_dgl_base_nets_at_the_shipped_configs_vs_oracle_fp32_and_fp64(name):
 
     def oracle(sd, dt):
         ssd = {kk[len("sign_inv_net."):]: v for kk, v in sd.items() if kk.startswith("sign_inv_net.")}
-        p = OD.gin_deepsigns(ssd, src, dst, pe.to(dt).unsqueeze(-1), 8, k).squeeze(-1)
+        if masked:
+            p = OD.masked_gin_deepsigns(ssd, src, dst, torch.tensor(sizes), pe.to(dt).unsqueeze(-1), 8, k).squeeze(-1)
+        else:
+            p = OD.gin_deepsigns(ssd, src, dst, pe.to(dt).unsqueeze(-1), 8, k).squeeze(-1)
         out = {}
-        if name == "gin":
+        if base == "gin":
             y = ON.gin_net(sd, src, dst, sizes, hx, p, L, "mean")
-        elif name == "gatedgcn":
+        elif base == "gatedgcn":
             y = ON.gatedgcn_net(sd, src, dst, sizes, hx, p, ex, L, "concat", "mean", out=out)
-        elif name == "gat":
+        elif base == "gat":
             y = ON.gat_net(sd, src, dst, sizes, hx, p, L, cfg["n_heads"], "mean", out=out)
-        elif name == "pna":
+        elif base == "pna":
             y = ON.pna_net(sd, src, dst, sizes, hx, p, ex, sn.to(dt), L, cfg["towers"], float(cfg["avg_d"]["log"]), "sum", out=out)
         else:
             y = ON.transformer_net(sd, src, dst, sizes, hx, p, ex, L, cfg["n_heads"], "concat", "sum", out=out)
@@ -189,7 +206,7 @@ def test_dgl_base_nets_at_the_shipped_configs_vs_oracle_fp32_and_fp64(name):
     g = DS.Graph(src.cuda(), dst.cuda(), sizes)
     with torch.no_grad():
         p = net.sign_inv_net(g, pe.unsqueeze(-1).cuda()).squeeze(-1)
-        y, _ = net(g, hx.cuda(), p, ex.cuda(), sn.cuda() if name == "pna" else None)
+        y, _ = net(g, hx.cuda(), p, ex.cuda(), sn.cuda() if base == "pna" else None)
     if hasattr(net, "check_last"):
         net.check_last()
     stages = [("sign_inv_net output", p, p32, p64), ("scores", y, y32, y64)]
