@@ -367,71 +367,128 @@ __global__ __launch_bounds__(256) void k_segment_bcast(const float* __restrict__
     dx[(int64_t)lo * C + i] = g[(int64_t)b * C + c] * w;
   }
 }
-// dT_f[v, :] += sum over the rows r with idx[r,f] == v of g[r, :] — deterministic (no atomics: nn.Embedding's own backward is not),
-// in two phases so that the work spreads over the chip and no thread walks a dependent chain of R loads:
-//   partial: workgroup (chunk, v) takes `rpc` consecutive rows, compacts the rows whose index is v into an ordered LDS list (wave
-//            ballots), then sums their g rows four loads at a time                               -> part[chunk][v][C]
-//   reduce : dT[v][c] += part[0][v][c] + part[1][v][c] + ...   (chunk order)
-// rpc is a function of (R, V) only, so the summation order — and every bit of the result — is fixed for a given input.
+// dT_f[v, :] += sum over the rows r with idx[r,f] == v of g[r, :] — deterministic (no atomics: nn.Embedding's own backward is not).
+//   chunk : a workgroup takes 256 consecutive rows, finds their DISTINCT table rows (a row leads if no earlier row of the chunk has its
+//           id), sorts the chunk's rows by distinct id (stable: row order inside a segment) and sums every segment   -> part[chunk][slot][C],
+//           vals[chunk][slot], nvals[chunk]
+//   gather: workgroup v looks its id up in every chunk's list (<= 256 ids per chunk) and adds the matching partial rows in chunk order.
+// Work is proportional to the rows, not to rows x table size (the first version launched a workgroup per (chunk, table row): 3 500
+// workgroups scanning 1 024 indices each for a 500-row table of which ZINC uses 4 to 28 rows: 40 us per table).
 // An index outside [0, V) contributes nothing and raises bit 0 of *status.
-__global__ __launch_bounds__(256) void k_embedding_bwd_partial(const int64_t* __restrict__ idx, int ldi, int f, int64_t R, int64_t V,
-                                                               int rpc, int C, const float* __restrict__ g,
-                                                               float* __restrict__ part, int32_t* __restrict__ status) {
-  __shared__ int32_t list[256];
-  __shared__ int32_t wcount[4];
-  const int64_t v = blockIdx.y, chunk = blockIdx.x;
-  const int64_t r0 = chunk * rpc, r1 = r0 + rpc < R ? r0 + rpc : R;
+constexpr int EMB_ROWS = 256;
+__global__ __launch_bounds__(256) void k_embedding_bwd_chunk(const int64_t* __restrict__ idx, int ldi, int f, int64_t R, int64_t V, int C,
+                                                             const float* __restrict__ g, float* __restrict__ part,
+                                                             int32_t* __restrict__ vals, int32_t* __restrict__ nvals,
+                                                             int32_t* __restrict__ status) {
+  __shared__ int32_t ids[EMB_ROWS], lead[EMB_ROWS], slot[EMB_ROWS], sorted[EMB_ROWS], seg0[EMB_ROWS + 1];
+  __shared__ int32_t wc[EMB_ROWS * 4];
+  __shared__ int32_t wlead[4], nlead_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int c0 = tid, c1 = tid + 256;
-  float a0 = 0.f, a1 = 0.f;
-  bool bad = false;
-  for (int64_t base = r0; base < r1; base += 256) {
-    const int64_t r = base + tid;
-    const int64_t id = r < r1 ? idx[r * ldi + f] : -1;
-    const bool hit = id == v;
-    bad = bad || (r < r1 && (uint64_t)id >= (uint64_t)V);
-    const unsigned long long mask = __ballot(hit);
-    if (lane == 0) wcount[w] = __popcll(mask);
-    __syncthreads();
-    int off = 0, total = 0;
+  const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS, r = r0 + tid;
+  int64_t id64 = r < R ? idx[r * ldi + f] : -1;
+  const bool bad = r < R && (uint64_t)id64 >= (uint64_t)V;
+  const int id = (r < R && !bad) ? (int)id64 : -1;
+  ids[tid] = id;
+  __syncthreads();
+  bool leader = id >= 0;
+  for (int j = 0; j < tid && leader; ++j) leader = ids[j] != id;
+  const unsigned long long lm = __ballot(leader);
+  if (lane == 0) wlead[w] = __popcll(lm);
+  __syncthreads();
+  int loff = 0, nlead = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { off += i < w ? wcount[i] : 0; total += wcount[i]; }
-    if (hit) list[off + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)(r - r0);
+  for (int i = 0; i < 4; ++i) { loff += i < w ? wlead[i] : 0; nlead += wlead[i]; }
+  if (leader) lead[loff + __popcll(lm & ((1ull << lane) - 1ull))] = id;
+  __syncthreads();
+  int my = -1;
+  for (int sidx = 0; sidx < nlead; ++sidx) my = (lead[sidx] == id) ? sidx : my;      // (ids are distinct among the leaders)
+  if (id < 0) my = -1;
+  int rank = 0;
+  for (int sidx = 0; sidx < nlead; ++sidx) {
+    const unsigned long long m = __ballot(my == sidx);
+    if (lane == 0) wc[sidx * 4 + w] = __popcll(m);
+    if (my == sidx) rank = __popcll(m & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int sidx = 0; sidx < nlead; ++sidx) { seg0[sidx] = acc; acc += wc[sidx * 4] + wc[sidx * 4 + 1] + wc[sidx * 4 + 2] + wc[sidx * 4 + 3]; }
+    seg0[nlead] = acc;
+    nvals[blockIdx.x] = nlead;
+  }
+  __syncthreads();
+  if (my >= 0) {
+    int before = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) before += i < w ? wc[my * 4 + i] : 0;
+    sorted[seg0[my] + before + rank] = tid;
+  }
+  if (tid < nlead) vals[(int64_t)blockIdx.x * EMB_ROWS + tid] = lead[tid];
+  __syncthreads();
+  // segment sums.  Vector path (C % 4 == 0, C <= 512, 16-byte aligned g): thread = (float4 column cv, row lane rl); a row lane takes
+  // every nrl-th row of a segment (in row order), the nrl partial sums meet in LDS and are added in lane order — a fixed order, and
+  // a chain of seg/nrl loads instead of seg.  Scalar path otherwise.
+  const int C4 = C >> 2;
+  if ((C & 3) == 0 && C4 <= 128 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    __shared__ float4 acc4[256];
+    const int nrl = 256 / C4 >= 1 ? 256 / C4 : 1;           // row lanes (C = 128: 8)
+    const int cv = tid % C4, rl = tid / C4;
+    for (int sidx = 0; sidx < nlead; ++sidx) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rl < nrl)
+        for (int i = seg0[sidx] + rl; i < seg0[sidx + 1]; i += nrl) {
+          const float4 x = *reinterpret_cast<const float4*>(g + (r0 + sorted[i]) * C + 4 * cv);
+          a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+        }
+      acc4[tid] = a;
+      __syncthreads();
+      if (tid < C4) {
+        float4 t = acc4[tid];
+        for (int q = 1; q < nrl; ++q) { const float4 u = acc4[q * C4 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * EMB_ROWS + sidx) * C + 4 * tid) = t;
+      }
+      __syncthreads();
+    }
+  } else {
+    for (int c0 = tid; c0 < C; c0 += 256) {
+      for (int sidx = 0; sidx < nlead; ++sidx) {
+        float a0 = 0.f;
+        for (int i = seg0[sidx]; i < seg0[sidx + 1]; ++i) a0 += g[(r0 + sorted[i]) * C + c0];
+        part[((int64_t)blockIdx.x * EMB_ROWS + sidx) * C + c0] = a0;
+      }
+    }
+  }
+  if (status != nullptr && __syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
+}
+__global__ __launch_bounds__(256) void k_embedding_bwd_gather(const float* __restrict__ part, const int32_t* __restrict__ vals,
+                                                              const int32_t* __restrict__ nvals, int nchunks, int C, float* __restrict__ dT) {
+  __shared__ int32_t hit[1024];
+  __shared__ int32_t any;
+  const int v = blockIdx.x;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nchunks; c0 += 1024) {          // (1024 chunks = 262 144 rows per pass)
+    const int nc = nchunks - c0 < 1024 ? nchunks - c0 : 1024;
+    for (int j = threadIdx.x; j < nc; j += 256) {
+      const int n = nvals[c0 + j];
+      int sidx = -1;
+      for (int q = 0; q < n; ++q) sidx = (vals[(int64_t)(c0 + j) * EMB_ROWS + q] == v) ? q : sidx;
+      hit[j] = sidx;
+      if (sidx >= 0) any = 1;
+    }
     __syncthreads();
-    int i = 0;
-    for (; i + 4 <= total; i += 4) {
-      const float* p0 = g + (r0 + list[i]) * C;
-      const float* p1 = g + (r0 + list[i + 1]) * C;
-      const float* p2 = g + (r0 + list[i + 2]) * C;
-      const float* p3 = g + (r0 + list[i + 3]) * C;
-      if (c0 < C) { const float x0 = p0[c0], x1 = p1[c0], x2 = p2[c0], x3 = p3[c0]; a0 = (((a0 + x0) + x1) + x2) + x3; }
-      if (c1 < C) { const float x0 = p0[c1], x1 = p1[c1], x2 = p2[c1], x3 = p3[c1]; a1 = (((a1 + x0) + x1) + x2) + x3; }
+    if (any) {
+      for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < nc; ++j)
+          if (hit[j] >= 0) a += part[((int64_t)(c0 + j) * EMB_ROWS + hit[j]) * C + c];
+        dT[(int64_t)v * C + c] += a;
+      }
     }
-    for (; i < total; ++i) {
-      const float* p0 = g + (r0 + list[i]) * C;
-      if (c0 < C) a0 += p0[c0];
-      if (c1 < C) a1 += p0[c1];
-    }
+    __syncthreads();
+    if (threadIdx.x == 0) any = 0;
     __syncthreads();
   }
-  float* o = part + (chunk * V + v) * C;
-  if (c0 < C) o[c0] = a0;
-  if (c1 < C) o[c1] = a1;
-  if (v == 0 && status != nullptr && __syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
-}
-__global__ __launch_bounds__(256) void k_embedding_bwd_reduce(const float* __restrict__ part, int nchunks, int64_t V, int C,
-                                                              float* __restrict__ dT) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= V * C) return;
-  float a = 0.f;
-  for (int k = 0; k < nchunks; ++k) a += part[(int64_t)k * V * C + i];
-  dT[i] += a;
-}
-// rows per chunk: 256 unless that makes more than ~4096 workgroups for this table
-inline int embedding_bwd_rpc(int64_t R, int64_t V) {
-  int64_t rpc = 256;
-  while (rpc < R && cdiv(R, rpc) * V > 4096) rpc *= 2;   // rpc >= R: one chunk, V workgroups (V > 4096 never met the bound)
-  return (int)rpc;
 }
 // out[0] = sum_i a[i]*b[i]   (two stages, deterministic)
 __global__ __launch_bounds__(256) void k_dot_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
@@ -622,13 +679,9 @@ extern "C" int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const 
 }
 
 extern "C" int64_t sn_embedding_bwd_scratch_floats(int64_t R, int nf, const int64_t* table_rows, int C) {
-  int64_t need = 1;
-  for (int f = 0; f < nf; ++f) {
-    const int64_t V = table_rows[f] > 0 ? table_rows[f] : 1;
-    const int64_t n = cdiv(R > 0 ? R : 1, embedding_bwd_rpc(R, V)) * V * C;
-    need = n > need ? n : need;
-  }
-  return need;
+  (void)nf; (void)table_rows;
+  const int64_t nchunks = cdiv(R > 0 ? R : 1, EMB_ROWS);
+  return nchunks * EMB_ROWS * (int64_t)C + nchunks * EMB_ROWS + nchunks + 16;      // partial rows | ids per chunk | counts
 }
 
 extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables,
@@ -637,15 +690,17 @@ extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int
   SN_REQUIRE(idx && dtables && table_rows && g && scratch && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && C <= 512 && R >= 0,
              "sn_embedding_sum_bwd_f32: bad arguments (C <= 512)");
   if (R == 0) return SN_OK;
+  const int nchunks = (int)cdiv(R, EMB_ROWS);
+  float* part = scratch;
+  int32_t* vals = reinterpret_cast<int32_t*>(scratch + (int64_t)nchunks * EMB_ROWS * C);
+  int32_t* nvals = vals + (int64_t)nchunks * EMB_ROWS;
   for (int f = 0; f < nf; ++f) {
     SN_REQUIRE(dtables[f] && table_rows[f] > 0 && table_rows[f] <= 65535, "sn_embedding_sum_bwd_f32: table %d missing, empty or > 65535 rows", f);
     const int64_t V = table_rows[f];
-    const int rpc = embedding_bwd_rpc(R, V);
-    const int nchunks = (int)cdiv(R, rpc);
-    hipLaunchKernelGGL(k_embedding_bwd_partial, dim3((unsigned)nchunks, (unsigned)V), dim3(256), 0, (hipStream_t)stream, idx, ldi, f, R, V,
-                       rpc, C, g, scratch, status);
-    hipLaunchKernelGGL(k_embedding_bwd_reduce, dim3((unsigned)cdiv(V * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)scratch, nchunks, V, C, dtables[f]);
+    hipLaunchKernelGGL(k_embedding_bwd_chunk, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, idx, ldi, f, R, V, C, g, part, vals,
+                       nvals, status);
+    hipLaunchKernelGGL(k_embedding_bwd_gather, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, (const float*)part,
+                       (const int32_t*)vals, (const int32_t*)nvals, nchunks, C, dtables[f]);
   }
   SN_CHECK_LAUNCH("sn_embedding_sum_bwd_f32");
   return SN_OK;

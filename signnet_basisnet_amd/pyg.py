@@ -598,7 +598,7 @@ class SignNetGNN(nn.Module):
             plan2, rplan2 = ops.doubled_plan(plan), ops.doubled_plan(rplan)
             for conv, norm in zip(convs[1:], norms[1:]):     # aggregate -> link -> link -> + x, adjoints fused the same way
                 x = T.gin_layer(x, conv.layer.eps, conv.nn.layers[0], conv.nn.norms[0].bn, conv.nn.layers[1], norm.bn, plan2, rplan2, nv, K, 2)
-            x = AG.masked_add(x[:N * K], x[N * K:], nv, K)
+            x = T.sign_sum(x, nv, K)
         else:
             phis = []
             for sign in (0, 1):

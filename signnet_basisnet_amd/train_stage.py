@@ -278,6 +278,27 @@ def gin_layer(x, conv_eps, lin1, bn1, lin2, bn2, plan, rplan, nvalid, K, G=1):
                            lin1, bn1, lin2, bn2, plan, rplan, nvalid, K, G)
 
 
+class _SignSum(Function):
+    """phi(x) + phi(-x) of the two stacked sign passes [2*M, d] -> [M, d] (sign_net.py:113).  The adjoint hands the SAME gradient to
+    both passes: one duplicating copy instead of what autograd builds for `x[:M] + x[M:]` (two zero-filled [2M, d] buffers, two slice
+    copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, x2, nvalid, K):
+        x2 = _c(x2)
+        M = x2.shape[0] // 2
+        ctx.meta = (M,)
+        return ops.masked_affine(x2[:M], nvalid, K, residual=x2[M:])
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _c(dy).repeat(2, 1), None, None           # (dy is zero on invalid rows: the consumer masks)
+
+
+def sign_sum(x2, nvalid, K):
+    return _SignSum.apply(x2, nvalid, K)
+
+
 class _GineLayer(Function):
     """h, e -> u = (1+eps) h + sum relu(h_j + e_ji) -> mlp2_bn(u) + h: one layer of GNN.forward (model.py:52-60, pyg_gnn_wrapper.py:19-28)."""
 
