@@ -86,13 +86,14 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         rc = getattr(lib, name)(*args)
         assert rc == -1 and name.encode() in lib.sn_last_error(), (name, rc, lib.sn_last_error())
     assert lib.sn_gatedgcn_max_edges(68) == 176 and lib.sn_gatedgcn_max_edges(128) == 0
-    assert lib.sn_embedding_bwd_scratch_floats(1000, 1, i64, 8) == 4 * 4 * 8          # ceil(1000/256) chunks x 4 table rows x 8 channels
+    # ceil(1000/256) = 4 chunks: 256 partial rows x 8 channels + 256 ids + 1 count each, + 16
+    assert lib.sn_embedding_bwd_scratch_floats(1000, 1, i64, 8) == 4 * 256 * 8 + 4 * 256 + 4 + 16
     assert lib.sn_phi_bins_bound(128, -8) == 128 * 8 + 1                              # full-slot mode: |kmax| bins per column
 
 
 def test_struct_layouts_match_the_header():
     """sizeof/offsetof of the parameter structs, C compiler vs ctypes."""
-    from signnet_basisnet_amd import dgl_nets, fused, ops
+    from signnet_basisnet_amd import dgl_nets, fused, ops, train_stage
     prog = r'''
 #include <stdio.h>
 #include <stddef.h>
@@ -104,6 +105,10 @@ int main(void) {
   printf("%zu %zu %zu\n", offsetof(sn_phi_params, layers), offsetof(sn_rho_params, layers), offsetof(sn_rho_params, pe_w1));
   printf("%zu %zu %zu %zu\n", sizeof(sn_gatedgcn_layer), sizeof(sn_gatedgcn_params), offsetof(sn_gatedgcn_params, layers),
          offsetof(sn_gatedgcn_params, ro_w0));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sn_train_linear_args), offsetof(sn_train_linear_args, in_scale),
+         offsetof(sn_train_linear_args, stat_part), sizeof(sn_train_linear_bwd_args), offsetof(sn_train_linear_bwd_args, x_mean),
+         offsetof(sn_train_linear_bwd_args, dot_part), sizeof(sn_train_scalar_mlp_args), offsetof(sn_train_scalar_mlp_args, w2),
+         offsetof(sn_train_scalar_mlp_args, column_state));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -117,7 +122,10 @@ int main(void) {
     want = [S(ops._PlanBinsC), S(fused._PhiLayer), S(fused._PhiParams), S(fused._RhoLayer), S(fused._RhoParams),
             S(fused._GnnLayer), S(fused._GnnParams), fused._GnnParams.layers.offset,
             fused._PhiParams.layers.offset, fused._RhoParams.layers.offset, fused._RhoParams.pe_w1.offset,
-            S(dgl_nets._GatedLayerC), S(dgl_nets._GatedParamsC), dgl_nets._GatedParamsC.layers.offset, dgl_nets._GatedParamsC.ro_w0.offset]
+            S(dgl_nets._GatedLayerC), S(dgl_nets._GatedParamsC), dgl_nets._GatedParamsC.layers.offset, dgl_nets._GatedParamsC.ro_w0.offset,
+            S(train_stage._LinArgs), train_stage._LinArgs.in_scale.offset, train_stage._LinArgs.stat_part.offset,
+            S(train_stage._BwdArgs), train_stage._BwdArgs.x_mean.offset, train_stage._BwdArgs.dot_part.offset,
+            S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset]
     assert got == want
 
 
