@@ -211,6 +211,27 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
         for _ in range(3):
             step()
     kt = rec.summary()
+    # the same step (fixed shape: this bench trains on one synthetic batch) captured once as a HIP graph and replayed: one graph launch
+    # + the Adam launch per step instead of ~350 launches issued from Python (train_graph.GraphedStep).  Single-rank only: the bucketed
+    # all-reduce of a process group is issued from autograd hooks, which a capture does not record.
+    final_loss = float(loss.detach())
+    del loss            # (a live loss keeps the eager step's autograd graph — and its default-stream AccumulateGrad nodes — alive: the
+                        #  capture below would then have to synchronise with the default stream, which a capturing stream must not)
+    graphed = None
+    if dist is None and not args.no_graph:
+        from signnet_basisnet_amd.train_graph import GraphedStep
+        gs = GraphedStep(model, opt, data, target)
+        for _ in range(max(2, args.warmup // 2)):
+            gs.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gloss = gs.step()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / args.steps
+        model.check_train()
+        graphed = {"value": WORKLOAD["B"] / dtg, "unit": "graphs/s", "ms_per_step": 1e3 * dtg, "final_loss": float(gloss),
+                   "note": "forward + loss + backward replayed as one captured HIP graph + one Adam launch (fixed batch shape)"}
     rccl = rccl_allreduce_probe(dist, dev, opt.flat_g.numel()) if dist is not None else None     # collective: every rank
     if rank != 0:
         return
@@ -218,16 +239,23 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
     fl = algorithmic_flops(host, WORKLOAD["k"], WORKLOAD["hidden"], WORKLOAD["nl_signnet"], WORKLOAD["nl_rho"], WORKLOAD["nl_gnn"])
     out = {"metric": "graphs/sec SignNet+GINE training step (forward + backward + Adam), ZINC batch=128 k=16", "unit": "graphs/s",
            "value": WORKLOAD["B"] * world / dt, "ms_per_step": 1e3 * dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic", "vs_baseline": None, "final_loss": float(loss.detach()),
+           "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic", "vs_baseline": None, "final_loss": final_loss,
            "config": {"workload": WORKLOAD["name"] + ", train step", "gflop_per_step": 3 * fl["total"] / 1e9},
            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF,
                         "achieved": 3 * fl["total"] / dt / 1e12, "frac": 3 * fl["total"] / dt / 1e12 / MFMA_F32_PEAK_TF,
-                        "note": "whole step, ~3x the forward's dense flops (forward + dX + dW), layer-at-a-time fp32-MFMA kernels; "
-                                "this path is launch/HBM bound (one kernel per op), not matrix-pipe bound"},
+                        "note": "whole step, ~3x the forward's dense flops (forward + dX + dW) on the fp32-input MFMA: one-pass link kernels "
+                                "(Linear + BatchNorm statistics forward; dX + dW + BatchNorm backward in one pass), csrc/train.hip"},
            "distributed": {"world_size": world, "backend": dist.get_backend() if dist is not None else None,
                            "gradient_allreduce": rccl,
                            "note": "one SUM all-reduce of the flat gradient per step (optim.FlatAdam), 1/world folded into the Adam kernel"},
+           "launches_per_step": sum(v["launches_per_step"] for v in per.values()),
            "kernels": dict(sorted(per.items(), key=lambda kv: -kv[1]["us_per_step"]))}
+    if graphed is not None:
+        out["eager"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "note": "the same step issued launch by launch from Python"}
+        out["graphed"] = graphed
+        out["value"], out["ms_per_step"] = graphed["value"], graphed["ms_per_step"]
+        out["roofline"]["achieved"] = 3 * fl["total"] / (graphed["ms_per_step"] * 1e-3) / 1e12
+        out["roofline"]["frac"] = out["roofline"]["achieved"] / MFMA_F32_PEAK_TF
     if world == 1 and not args.no_cpu_baseline:
         # the float32 CPU oracle under torch.autograd + torch.optim.Adam: what the reference's training loop does on the host
         from oracle import pyg_signnet as O
@@ -643,6 +671,7 @@ def main():
     ap.add_argument("--workload", default="forward", choices=["forward", "evd", "train", "dgl", "scatter"],
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
+    ap.add_argument("--no-graph", action="store_true", help="--workload train: skip the captured-HIP-graph replay of the step")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
     ap.add_argument("--no-scatter", action="store_true", help="skip the scatter_roofline block (standalone GIN / GINE aggregation on > 256 MiB)")
     ap.add_argument("--event-stride", type=int, default=0,

@@ -248,6 +248,64 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
     part[(int64_t)blockIdx.x * 2 * C + c] = sm[c] + sm[2 * C + c] + sm[4 * C + c] + sm[6 * C + c];
 }
 
+// The same for C = 4 * LPR with LPR (lanes per row) a power of two <= 64 and 16-byte aligned rows: a row lives in the registers of LPR
+// lanes (one float4 each of u = x + res and of dy: every operand is read ONCE — the kernel above re-reads the row four times with scalar
+// loads), row reductions are xor-shuffles inside the LPR lanes, and a thread keeps the d gamma / d beta partials of its own four columns
+// in registers over the LNV_ROWS rows of its workgroup.
+constexpr int LNV_ROWS = 64;       // = 4 * LN_ROWS: the scratch sized for the scalar kernel's partials fits
+template <int LPR>
+__global__ __launch_bounds__(256) void k_layernorm_bwd_v4(const float* __restrict__ x, const float* __restrict__ res,
+                                                          const float* __restrict__ dy, int64_t R, const float* __restrict__ gamma, float eps,
+                                                          const int32_t* __restrict__ nvalid, int K, float* __restrict__ du,
+                                                          float* __restrict__ part /* [nblk][2C] */) {
+  constexpr int C = 4 * LPR, RPP = 256 / LPR;          // rows per pass
+  __shared__ float4 accg[256], accb[256];
+  const int cv = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int64_t row0 = (int64_t)blockIdx.x * LNV_ROWS;
+  const float4 gm = make_float4(gamma[4 * cv], gamma[4 * cv + 1], gamma[4 * cv + 2], gamma[4 * cv + 3]);     // (a parameter: any alignment)
+  float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+  auto rsum = [](float v) {
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  for (int i = 0; i < LNV_ROWS / RPP; ++i) {
+    const int64_t row = row0 + (int64_t)i * RPP + rl;
+    if (row >= R) continue;                      // (uniform within the LPR lanes of a row: the shuffles below stay inside them)
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_ok(nvalid, K, row)) {
+      float4 u = *reinterpret_cast<const float4*>(x + row * C + 4 * cv);
+      if (res) { const float4 r4 = *reinterpret_cast<const float4*>(res + row * C + 4 * cv); u.x += r4.x; u.y += r4.y; u.z += r4.z; u.w += r4.w; }
+      const float4 g4 = *reinterpret_cast<const float4*>(dy + row * C + 4 * cv);
+      const float mean = rsum((u.x + u.y) + (u.z + u.w)) * (1.0f / C);
+      const float d0 = u.x - mean, d1 = u.y - mean, d2 = u.z - mean, d3 = u.w - mean;
+      const float rstd = 1.0f / sqrtf(rsum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / C) + eps);
+      const float x0 = d0 * rstd, x1 = d1 * rstd, x2 = d2 * rstd, x3 = d3 * rstd;
+      const float h0 = g4.x * gm.x, h1 = g4.y * gm.y, h2 = g4.z * gm.z, h3 = g4.w * gm.w;
+      const float m1 = rsum((h0 + h1) + (h2 + h3)) * (1.0f / C);
+      const float m2 = rsum((h0 * x0 + h1 * x1) + (h2 * x2 + h3 * x3)) * (1.0f / C);
+      ag.x += g4.x * x0; ag.y += g4.y * x1; ag.z += g4.z * x2; ag.w += g4.w * x3;
+      ab.x += g4.x; ab.y += g4.y; ab.z += g4.z; ab.w += g4.w;
+      o = make_float4(rstd * (h0 - m1 - x0 * m2), rstd * (h1 - m1 - x1 * m2), rstd * (h2 - m1 - x2 * m2), rstd * (h3 - m1 - x3 * m2));
+    }
+    *reinterpret_cast<float4*>(du + row * C + 4 * cv) = o;
+  }
+  accg[threadIdx.x] = ag;
+  accb[threadIdx.x] = ab;
+  __syncthreads();
+  if (threadIdx.x < LPR) {          // the RPP row lanes of a column group, in lane order
+    float4 tg = accg[threadIdx.x], tb = accb[threadIdx.x];
+    for (int q = 1; q < RPP; ++q) {
+      const float4 a = accg[q * LPR + threadIdx.x], b = accb[q * LPR + threadIdx.x];
+      tg.x += a.x; tg.y += a.y; tg.z += a.z; tg.w += a.w;
+      tb.x += b.x; tb.y += b.y; tb.z += b.z; tb.w += b.w;
+    }
+    float* P = part + (int64_t)blockIdx.x * 2 * C;
+    *reinterpret_cast<float4*>(P + 4 * threadIdx.x) = tg;
+    *reinterpret_cast<float4*>(P + C + 4 * threadIdx.x) = tb;
+  }
+}
+
 // ============================================================================ per-node set attention backward
 // One wave per (node, head), mirroring k_set_attention: P = softmax(q k^T / sqrt(dk)) over the valid slots, o = P v.
 __global__ __launch_bounds__(64) void k_set_attention_bwd(const float* __restrict__ q, const float* __restrict__ k,
@@ -435,11 +493,22 @@ __global__ __launch_bounds__(256) void k_embedding_bwd_chunk(const int64_t* __re
     const int cv = tid % C4, rl = tid / C4;
     for (int sidx = 0; sidx < nlead; ++sidx) {
       float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rl < nrl)
-        for (int i = seg0[sidx] + rl; i < seg0[sidx + 1]; i += nrl) {
+      if (rl < nrl) {
+        int i = seg0[sidx] + rl;
+        const int e = seg0[sidx + 1];
+        for (; i + 3 * nrl < e; i += 4 * nrl) {           // four rows in flight per lane
+          const float4 x0 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i]) * C + 4 * cv);
+          const float4 x1 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i + nrl]) * C + 4 * cv);
+          const float4 x2 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i + 2 * nrl]) * C + 4 * cv);
+          const float4 x3 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i + 3 * nrl]) * C + 4 * cv);
+          a.x = (((a.x + x0.x) + x1.x) + x2.x) + x3.x; a.y = (((a.y + x0.y) + x1.y) + x2.y) + x3.y;
+          a.z = (((a.z + x0.z) + x1.z) + x2.z) + x3.z; a.w = (((a.w + x0.w) + x1.w) + x2.w) + x3.w;
+        }
+        for (; i < e; i += nrl) {
           const float4 x = *reinterpret_cast<const float4*>(g + (r0 + sorted[i]) * C + 4 * cv);
           a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
         }
+      }
       acc4[tid] = a;
       __syncthreads();
       if (tid < C4) {
@@ -521,6 +590,10 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 }  // namespace
 }  // namespace sn
 
+namespace sn {
+bool attention16_backward(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K, int heads, int dk,
+                          const int32_t* nvalid, const float* prob_mask, float* dq, float* dkk, float* dv, hipStream_t st);   // attention16.hip
+}
 using namespace sn;
 
 static inline int64_t wgrad_rows_per_block(int64_t R) {
@@ -608,7 +681,16 @@ extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual
              "sn_masked_layernorm_bwd_f32: bad arguments");
   SN_REQUIRE((size_t)8 * C * sizeof(float) <= 64 * 1024, "sn_masked_layernorm_bwd_f32: C too large");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (int)cdiv(R > 0 ? R : 1, 4 * LN_ROWS);
+  int nblk = (int)cdiv(R > 0 ? R : 1, 4 * LN_ROWS);
+  auto a16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  const bool vec = (C == 32 || C == 64 || C == 128 || C == 256) && a16(x) && a16(dy) && a16(du) && (!residual || a16(residual));
+  if (vec) {
+    nblk = (int)cdiv(R > 0 ? R : 1, LNV_ROWS);                 // (fewer, larger partials: fits the scratch sized for 4 * LN_ROWS rows per block)
+    if (C == 32) hipLaunchKernelGGL(k_layernorm_bwd_v4<8>, dim3((unsigned)nblk), dim3(256), 0, st, x, residual, dy, R, gamma, eps, nvalid, K, du, scratch);
+    else if (C == 64) hipLaunchKernelGGL(k_layernorm_bwd_v4<16>, dim3((unsigned)nblk), dim3(256), 0, st, x, residual, dy, R, gamma, eps, nvalid, K, du, scratch);
+    else if (C == 128) hipLaunchKernelGGL(k_layernorm_bwd_v4<32>, dim3((unsigned)nblk), dim3(256), 0, st, x, residual, dy, R, gamma, eps, nvalid, K, du, scratch);
+    else hipLaunchKernelGGL(k_layernorm_bwd_v4<64>, dim3((unsigned)nblk), dim3(256), 0, st, x, residual, dy, R, gamma, eps, nvalid, K, du, scratch);
+  } else
   hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)8 * C * sizeof(float), st, x, residual, dy, R, C,
                      gamma, eps, nvalid, K, du, scratch);
   // scratch rows are [d gamma (C) | d beta (C)]; reduced into the row behind the partials and the two-stage temporaries
@@ -627,6 +709,10 @@ extern "C" int sn_set_attention_bwd_f32(const float* q, const float* k, const fl
   SN_REQUIRE(q && k && v && dout && dq && dk_out && dv && N >= 0 && K > 0 && heads > 0 && dk > 0,
              "sn_set_attention_bwd_f32: bad arguments");
   if (N == 0) return SN_OK;
+  if (sn::attention16_backward(q, k, v, dout, N, K, heads, dk, nvalid, prob_mask, dq, dk_out, dv, (hipStream_t)stream)) {   // K <= 16
+    SN_CHECK_LAUNCH("sn_set_attention_bwd_f32");
+    return SN_OK;
+  }
   const size_t lds = ((size_t)4 * K * dk + (size_t)2 * K * (K + 1)) * sizeof(float);
   SN_REQUIRE(lds <= 160 * 1024, "sn_set_attention_bwd_f32: K=%d dk=%d needs %zu B of LDS (> 160 KiB)", K, dk, lds);
   if (lds > 64 * 1024 &&

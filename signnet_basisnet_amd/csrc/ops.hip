@@ -1055,6 +1055,10 @@ __global__ __launch_bounds__(256) void k_segment_pool(const float* __restrict__ 
 
 }  // namespace sn
 
+namespace sn {
+bool attention16_forward(const float* q, const float* k, const float* v, int64_t N, int K, int heads, int dk, const int32_t* nvalid,
+                         const float* prob_mask, float* out, hipStream_t st);     // attention16.hip
+}
 using namespace sn;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1442,6 +1446,10 @@ extern "C" int sn_set_attention_f32(const float* q, const float* k, const float*
   size_t lds = ((size_t)3 * K * dk + (size_t)K * (K + 1)) * sizeof(float);
   SN_REQUIRE(lds <= 160 * 1024, "sn_set_attention_f32: K=%d dk=%d needs %zu B of LDS (> 160 KiB)", K, dk, lds);
   if (N == 0) return SN_OK;
+  if (sn::attention16_forward(q, k, v, N, K, heads, dk, nvalid, prob_mask, out, (hipStream_t)stream)) {     // K <= 16: matrix pipe
+    SN_CHECK_LAUNCH("sn_set_attention_f32");
+    return SN_OK;
+  }
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_set_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)

@@ -1106,6 +1106,14 @@ int train_cus() {
 template <typename KFn>
 int raise_lds(KFn fn, size_t lds, const char* who) {
   if (lds <= 64 * 1024) return SN_OK;
+  // once per kernel is enough, and nothing but launches may run while a stream is being captured into a HIP graph
+  static const void* seen[16];
+  static size_t seen_lds[16];
+  static int nseen = 0;
+  const void* key = reinterpret_cast<const void*>(fn);
+  for (int i = 0; i < nseen; ++i)
+    if (seen[i] == key && seen_lds[i] >= lds) return SN_OK;
+  if (nseen < 16) { seen[nseen] = key; seen_lds[nseen] = lds; ++nseen; }
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(SN_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit to %zu", who, lds);
   return SN_OK;

@@ -400,11 +400,16 @@ def masked_colstats(x, nvalid=None, K=0):
 _BN_PENDING = None
 
 
-def _count_batch(bn):
+def _count_batch(bn, n=1):
     if _BN_PENDING is None:
-        bn.num_batches_tracked += 1
+        bn.num_batches_tracked += n
     else:
-        _BN_PENDING.append(bn.num_batches_tracked)
+        t = bn.num_batches_tracked
+        ent = _BN_PENDING.get(id(t))
+        if ent is None:
+            _BN_PENDING[id(t)] = [t, n]
+        else:
+            ent[1] += n              # (one entry per buffer: a tensor listed twice in a foreach add is NOT reliably incremented twice)
 
 
 class batched_bn_counters:
@@ -412,7 +417,7 @@ class batched_bn_counters:
         global _BN_PENDING
         self._outer = _BN_PENDING
         if self._outer is None:
-            _BN_PENDING = []
+            _BN_PENDING = {}
         return self
 
     def __exit__(self, *exc):
@@ -421,7 +426,7 @@ class batched_bn_counters:
             pending, _BN_PENDING = _BN_PENDING, None
             if pending:
                 with torch.no_grad():
-                    torch._foreach_add_(pending, 1)       # a tensor listed twice is incremented twice
+                    torch._foreach_add_([e[0] for e in pending.values()], [e[1] for e in pending.values()])
         return False
 
 

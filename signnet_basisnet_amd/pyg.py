@@ -618,10 +618,12 @@ class SignNetGNN(nn.Module):
             x = AG.masked_add(x, p, nv, K)
         def lin(x_, m, relu=False):
             return T.linear_module(x_, m, nv, K, relu) if stage else AG.linear(x_, m.weight, m.bias, nv, K, relu=relu)
-        for tl in sn.rho.transformer_layers:
+        static_masks = getattr(self, "_attn_masks", None)       # train_graph.GraphedStep: masks drawn outside the captured step
+        for li, tl in enumerate(sn.rho.transformer_layers):
             a, f = tl.slf_attn, tl.pos_ffn
             q, k, v = lin(x, a.w_qs), lin(x, a.w_ks), lin(x, a.w_vs)
-            o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device))
+            pm = static_masks[li] if static_masks is not None else ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device)
+            o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, pm)
             o = lin(o, a.fc)
             y = AG.masked_layernorm(o, x, a.norm.ln.weight, a.norm.ln.bias, LN_EPS, nv, K)
             z = lin(y, f.w_1, relu=True)
@@ -652,9 +654,17 @@ class SignNetGNN(nn.Module):
         y = lin_bn(pooled, oe.layers[0], oe.norms[0])
         y = AG.linear(y, oe.layers[1].weight, oe.layers[1].bias)
         discrete = isinstance(g.input_encoder, DiscreteEncoder) or any(isinstance(e, DiscreteEncoder) for e in g.edge_encoders)
-        if discrete and int(plan.status[5]):     # one sync per training step; node OR edge tables (nn.Embedding raises for either)
-            raise IndexError(ops.EMBEDDING_INDEX_ERROR)
+        self._train_status = plan.status if discrete else None
+        if not getattr(self, "_defer_status", False):
+            self.check_train()                   # one sync per training step; node OR edge tables (nn.Embedding raises for either)
         return y
+
+    def check_train(self):
+        """The embedding-index flag of the last differentiable forward (read here, not inside the step, when `_defer_status` is set:
+        a captured step — train_graph.GraphedStep — must not synchronise)."""
+        st, self._train_status = getattr(self, "_train_status", None), None
+        if st is not None and int(st[5]):
+            raise IndexError(ops.EMBEDDING_INDEX_ERROR)
 
     # ------------------------------------------------------------------ forward
     def _forward(self, data, return_stages=False, train=False):

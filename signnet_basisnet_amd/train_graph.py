@@ -1,0 +1,108 @@
+"""A training step of fixed shape captured ONCE as a HIP graph and replayed (MI355X: HIP graphs instead of a tracing compiler).
+
+The differentiable forward of `SignNetGNN` + loss + backward is ~350 kernel launches whose order and shapes depend only on the batch
+SHAPE (nodes, edges, graphs, eigenvector entries): the kernels read graph sizes, CSR offsets and validity from device memory.  For a
+fixed shape — the bench's synthetic batch, a padded / bucketed loader — the step is recorded once (`torch.cuda.graph` over the same
+ctypes launches: the C ABI takes the capture stream) and replayed with ONE graph launch + the single Adam launch of
+`optim.FlatAdam` (its bias correction depends on the step count, so it stays outside, as in learning_filters.GraphedEpoch).  Same
+kernels, same order, same arithmetic as the eager step: bit-identical losses (tests/test_training_gpu.py).
+
+Before constructing a GraphedStep drop every reference to the results of earlier EAGER steps of the same model (`del loss`): a live
+loss keeps that step's autograd graph, and with it AccumulateGrad nodes bound to the default stream; the captured backward would then
+have to synchronise with the default stream, which a capturing stream must not do.
+
+What the reference does per step (Alchemy/main_alchemy.py:99-110, GINESignNetPyG/core/train.py:55-66): optimizer.zero_grad(),
+model(data), L1 loss, loss.backward(), optimizer.step().
+"""
+from __future__ import annotations
+
+import torch
+
+_FIELDS = ("x", "edge_index", "edge_attr", "batch", "eigen_values", "eigen_vectors")
+
+
+def l1_loss(y, target):
+    return (y - target).abs().mean()
+
+
+class GraphedStep:
+    def __init__(self, model, optimizer, data, target, loss_fn=l1_loss, warmup=2):
+        from .optim import FlatAdam
+        if not isinstance(optimizer, FlatAdam):
+            raise TypeError("GraphedStep needs optim.FlatAdam (static flat parameter / gradient buffers)")
+        if optimizer.dist is not None:
+            raise ValueError("GraphedStep: the bucketed all-reduce runs from autograd hooks and is not captured; use the eager step with a process group")
+        if not getattr(model, "max_k", None):
+            raise ValueError("GraphedStep: the number of eigenvector slots must be fixed (max_k): the all-eigenvector mode sizes tensors from the batch")
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.data, self.target = data, target
+        self.shapes = {f: tuple(getattr(data, f).shape) for f in _FIELDS}
+        model.train()
+        model._defer_status = True                  # no host read of the plan's status words inside the step: check_train() after it
+        # the attention dropout (transformer_module.py:46,55; the one dropout the reference leaves active) is random per step: its masks
+        # are drawn OUTSIDE the graph with torch's device generator — the same draws in the same order as the eager step — into static
+        # buffers the captured kernels read
+        self._masks = None
+        if getattr(model, "attn_dropout", 0.0):
+            from . import ops
+            from .pyg import N_HEAD
+            N, K = int(data.batch.numel()), int(model.max_k)
+            self._draw = lambda: [ops.attention_dropout_mask(N, K, N_HEAD, model.attn_dropout, data.batch.device)
+                                  for _ in model.sign_net.rho.transformer_layers]
+            st0 = torch.cuda.get_rng_state(data.batch.device)
+            self._masks = [torch.empty_like(m) for m in self._draw()]
+            torch.cuda.set_rng_state(st0, data.batch.device)       # (the sizing draw does not count)
+        model._attn_masks = self._masks
+
+        def fwd_bwd():
+            optimizer.flat_g.zero_()
+            y = model(self.data)
+            loss = loss_fn(y, self.target)
+            loss.backward()
+            return loss, y
+
+        # warm-up on a side stream (lazy one-time setup: LDS limits, allocator pools) without touching the model's state
+        saved = [b.detach().clone() for b in model.buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        rng = torch.cuda.get_rng_state(data.batch.device) if self._masks is not None else None
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._refresh_masks()
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        model.check_train()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            loss, y = fwd_bwd()
+        with torch.no_grad():
+            for b, sv in zip(model.buffers(), saved):
+                b.copy_(sv)
+        if rng is not None:
+            torch.cuda.set_rng_state(rng, data.batch.device)      # the warm-up's draws do not count: the first step draws what an eager one would
+        self.loss, self.y = loss.detach(), y.detach()
+
+    def _refresh_masks(self):
+        if self._masks is not None:
+            for dst, src in zip(self._masks, self._draw()):
+                dst.copy_(src)
+
+    def load(self, data=None, target=None):
+        """Copy a new batch of the SAME shape into the static input buffers."""
+        if data is not None:
+            for f in _FIELDS:
+                src, dst = getattr(data, f), getattr(self.data, f)
+                if tuple(src.shape) != self.shapes[f]:
+                    raise ValueError(f"GraphedStep: {f} has shape {tuple(src.shape)}, the captured step {self.shapes[f]}")
+                dst.copy_(src, non_blocking=True)
+            if int(data.num_graphs) != int(self.data.num_graphs):
+                raise ValueError("GraphedStep: number of graphs differs from the captured step")
+        if target is not None:
+            self.target.copy_(target, non_blocking=True)
+
+    def step(self, data=None, target=None):
+        self.load(data, target)
+        self._refresh_masks()
+        self.graph.replay()
+        self.optimizer.step()
+        return self.loss

@@ -110,8 +110,7 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
                                                ptr(bn.running_mean if track else None), ptr(bn.running_var if track else None),
                                                ptr(st.state), ptr(st.count), stream()), "sn_train_bn_finish_f32")
         if track and bn.num_batches_tracked is not None:
-            for _ in range(G):
-                ops._count_batch(bn)
+            ops._count_batch(bn, G)
     return y, st
 
 
@@ -409,8 +408,7 @@ def scalar_mlp_stats(a, lin1, bn1, lin2, bn2, nvalid, K, G=1, negate_second=Fals
               "sn_train_scalar_mlp_stats_f32")
     for bn, t in ((bn1, ta), (bn2, tb)):
         if t and bn.num_batches_tracked is not None:
-            for _ in range(G):
-                ops._count_batch(bn)
+            ops._count_batch(bn, G)
     return a, sst, cst
 
 

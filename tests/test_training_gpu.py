@@ -380,3 +380,43 @@ def test_parameter_gradients_at_baseline_size_vs_oracle_fp32_and_fp64(name):
     (y * cot.float().to(DEV)).sum().backward()
     PU_.close(y, y32, "train-mode forward at size", ref64=y64)
     _assert_gradient_population(m.named_parameters(), sd32, sd64, name, 60)
+
+
+def test_graphed_step_replays_the_eager_training_step_bit_for_bit():
+    """train_graph.GraphedStep: forward + L1 loss + backward captured once as a HIP graph (fixed batch shape) and replayed, Adam outside
+    — same kernels, same order: the loss trajectory and the parameters equal the eager loop's bit for bit; a batch of another shape is
+    refused; a new batch of the same shape is taken through the static input buffers."""
+    from signnet_basisnet_amd import optim, synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    from signnet_basisnet_amd.train_graph import GraphedStep
+    host = synth.make_batch(12, seed=5)
+    host2 = synth.make_batch(12, seed=5)
+    host2.x = (host2.x + 1) % 28                                   # same shape, other node types
+    target = torch.randn(12, 1, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def model_and_opt():
+        torch.manual_seed(7)
+        m = SignNetGNN(None, None, 32, 1, 3, 2, variant="gine", max_k=8).to(DEV).train()      # attention dropout 0.1 stays on
+        return m, optim.FlatAdam(m.parameters(), lr=2e-3)
+
+    m1, o1 = model_and_opt()
+    torch.manual_seed(11)
+    eager = []
+    for i in range(4):
+        d = synth.batch_to(host if i < 2 else host2, DEV)
+        o1.zero_grad()
+        loss = (m1(d) - target).abs().mean()
+        loss.backward()
+        o1.step()
+        eager.append(loss.item())
+    m2, o2 = model_and_opt()
+    torch.manual_seed(11)                                           # the same dropout draws as the eager loop
+    gs = GraphedStep(m2, o2, synth.batch_to(host, DEV), target.clone())
+    graphed = [gs.step().item(), gs.step().item(), gs.step(synth.batch_to(host2, DEV)).item(), gs.step().item()]
+    m2.check_train()
+    assert graphed == eager, (graphed, eager)
+    assert torch.equal(o1.flat_p, o2.flat_p)
+    for b1, b2 in zip(m1.buffers(), m2.buffers()):
+        assert torch.equal(b1, b2)                                 # running statistics / counters advanced by the same steps
+    with pytest.raises(ValueError, match="shape"):
+        gs.step(synth.batch_to(synth.make_batch(12, seed=6), DEV))
