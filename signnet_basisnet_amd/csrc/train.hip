@@ -11,7 +11,6 @@
 // Rows come in G groups (the phi(+x) / phi(-x) passes share every weight but keep separate batch statistics: two calls of GNN3d,
 // sign_net.py:113).  fp32-input MFMA throughout (exact products, fp32 accumulate); no atomics: gradients are bitwise reproducible.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace sn {
 
@@ -365,7 +364,6 @@ struct TBwd {
   float* gx; int ldgx; float* sums; float* dwp; int want_db;
   const float* dotx; int lddot; double* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
   int nblk;             // workgroups per group
-  int dbg;
 };
 
 __host__ __device__ constexpr int stage_ld(int ntiles) { return ((16 * ntiles + 63) / 64) * 64 + 16; }   // row stride = 16 mod 64 banks
@@ -487,9 +485,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       }
     }
     __syncthreads();
-    if (round + 1 < r_hi && !(a.dbg & 4)) request(round + 1);
+    if (round + 1 < r_hi) request(round + 1);
     // ---------------------------------------------------------------- phase 2: gx = (dz W) * mask, column sums
-    if (want_dx && !(a.dbg & 1)) {
+    if (want_dx) {
       f32x4 fr[NTO];
       const float* src = dzs + (16 * rt + lr) * LDO;
 #pragma unroll
@@ -555,7 +553,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       }
     }
     // ---------------------------------------------------------------- phase 3: dW[tile `wave`] += dz^T x_hat over the round's rows
-    if (wave < nto && a.dwp && !(a.dbg & 2)) {
+    if (wave < nto && a.dwp) {
 #pragma unroll 1     // (unrolled by 2 the LDS reads of both steps are hoisted and the kernel spills)
       for (int q = 0; q < TROWS / 4; ++q) {
         const int rl = 4 * q + g;
@@ -1209,8 +1207,7 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   const int nblk = sn_train_linear_bwd_blocks(p.R, p.G);
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
-         p.dot_x, p.lddot, p.dot_part, nblk,
-         getenv("SN_TRAIN_DBG") ? atoi(getenv("SN_TRAIN_DBG")) : 0};
+         p.dot_x, p.lddot, p.dot_part, nblk};
   constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
   int rc;
   if ((rc = raise_lds(k_tlin_bwd<8, 8>, lds, "sn_train_linear_bwd_f32")) != SN_OK) return rc;
