@@ -275,17 +275,110 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         lds_barrier();
         float qh[DKMAX];
         const int hc = g * dk;
+        constexpr int DKF = D / 4;      // head width when d fills the padded width (d = 128: 32; d = 64: 16)
+        constexpr bool MM_OK = (DKF % 16) == 0;                       // matrix-pipe attention: whole 16-channel tiles per head
+        const bool mm_attn = MM_OK && dk == DKF;                      // (uniform)
+        constexpr int QC = MM_OK ? DKF / 4 : 1;                       // channels of a head a lane group supplies to S = Q K^T
+        float qv[4][QC];                                              // q[my row][head h][QC g + s] / sqrt(dk)
+        if (mm_attn) {
 #pragma unroll
-        for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
+          for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int c = 0; c < QC; c += 4) {
+              const f32x4 t = wave_live ? lds_ld4(Ar + h * DKF + QC * g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+              qv[h][c] = t[0] * rtemp; qv[h][c + 1] = t[1] * rtemp; qv[h][c + 2] = t[2] * rtemp; qv[h][c + 3] = t[3] * rtemp;
+            }
+        } else {
+#pragma unroll
+          for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
+        }
         // (q rows are written and read by the same wave only: no barrier before A is reused for v)
         wg_gemm_split<NT, NT, false, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
         lds_barrier();
+        if (mm_attn) {
+          // ======== K > 16 on the fp32 matrix pipe (round 3).  A node's rows are `pad` = 16 * nkt consecutive bin rows (its slots, tile
+          // aligned), my wave holds one 16-query tile of it; k lives in Bm, v in A.  Operand roles as in attention16.hip:
+          //   S^T tile = K_tile Q^T : A[i = key li][k] = k[key][c], B[k][j = query li] = q[query][c], c = QC g + s  (both operands of a lane
+          //     are values of its OWN row li: no transposes) -> lane (li, g) holds S[query li][key 16 kt + 4g + r]
+          //   O = P V               : A[i = query li][k = key 4g + s] = P (its own register s), B[k][j = c] = v[key][16 t + li]
+          // The scalar loop this replaces read every key and value row once PER LANE (16 ds_read_b128 per key and wave, ~1.5 k cycles per
+          // key); here a key tile costs QC + 4 * DKF/16 MFMAs per head with one or two LDS reads each.
+          const int nkt = (kv + 15) >> 4;                               // key tiles of my node (<= 4)
+          f32x4 sc[4][4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+              if (kt < nkt) {
+                const float* kr = Bm + (u0 + 16 * kt + li) * LD + h * DKF + QC * g;
+#pragma unroll
+                for (int c = 0; c < QC; c += 4) {
+                  const f32x4 kq = lds_ld4(kr + c);
+                  acc = mfma16(kq[0], qv[h][c], acc);
+                  acc = mfma16(kq[1], qv[h][c + 1], acc);
+                  acc = mfma16(kq[2], qv[h][c + 2], acc);
+                  acc = mfma16(kq[3], qv[h][c + 3], acc);
+                }
+              }
+              sc[h][kt] = acc;
+            }
+          // masked softmax over the keys of my query (registers r, lane groups g, key tiles kt)
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if (16 * kt + 4 * g + t < kv) m = fmaxf(m, sc[h][kt][t]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float z = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float e = (16 * kt + 4 * g + t < kv) ? expf(sc[h][kt][t] - m) : 0.f;
+                sc[h][kt][t] = e;
+                z += e;
+              }
+            z += __shfl_xor(z, 16, 64);
+            z += __shfl_xor(z, 32, 64);
+            const float zi = (kv > 0 && z > 0.f) ? 1.0f / z : 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) sc[h][kt][t] *= zi;
+          }
+          lds_barrier();   // all reads of k (Bm) are done: Bm receives the attention output
+          float* Bt = Bm + (wave * 16) * LD;                            // my tile's rows
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int t = 0; t < DKF / 16; ++t) {
+              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int kt = 0; kt < 4; ++kt)
+                if (kt < nkt) {
+                  const float* vr = A + (u0 + 16 * kt + 4 * g) * LD + h * DKF + 16 * t + li;
+                  acc = mfma16(sc[h][kt][0], vr[0], acc);
+                  acc = mfma16(sc[h][kt][1], vr[LD], acc);
+                  acc = mfma16(sc[h][kt][2], vr[2 * LD], acc);
+                  acc = mfma16(sc[h][kt][3], vr[3 * LD], acc);
+                }
+#pragma unroll
+              for (int t2 = 0; t2 < 4; ++t2) Bt[(4 * g + t2) * LD + h * DKF + 16 * t + li] = acc[t2];      // O[query 4g + t2][channel]
+            }
+          // (the attention output rows are written and read back by the same wave: no barrier, LDS operations of a wave are ordered)
+#pragma unroll
+          for (int kk = 0; kk < NT; ++kk) o[kk] = lds_ld4(Br + 16 * kk + 4 * g);
+        } else {
         float m = -INFINITY;
         float oh[DKMAX];
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c) oh[c] = 0.f;
         float z = 0.f;
-        constexpr int DKF = D / 4;      // head width when d fills the padded width (d = 128: 32; d = 64: 16)
         if (dk == DKF) {
           // Compile-time head width: a key's (and value's) DKF floats are NT ds_read_b128 issued back to back and ONE wait, the dot
           // product and the P.V update are straight FMA runs.  (The runtime-width loops below compile to one ds_read + s_waitcnt per
@@ -372,6 +465,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         // (the attention output rows are written and read back by the same wave: no barrier)
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) o[kk] = lds_ld4(Br + 16 * kk + 4 * g);
+        }
       }
       SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
