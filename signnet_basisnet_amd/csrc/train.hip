@@ -56,8 +56,29 @@ __device__ __forceinline__ bool row_ok(int64_t r, int64_t R, const int32_t* __re
 template <bool TRANS>
 __device__ __forceinline__ void stage_weight(float4* wl, const float* __restrict__ W, int ldw, int n_o, int n_k, int nto, int ntk) {
   const int total = nto * ntk * 64;
-  // four entries (16 scalar loads) in flight per thread: one entry at a time the staging of a 128 x 128 matrix was a chain of 32
-  // dependent L2 round trips — most of a small launch
+  // A 128 x 128 matrix is 32 image entries per thread.  One entry at a time the staging was a chain of 32 dependent L2 round trips — most
+  // of a small launch.  Row-major parameter, 16-byte aligned with ldw % 4 == 0 (the usual case; FlatAdam's views are aligned when the
+  // preceding parameters' sizes are multiples of 4): ONE float4 per entry, eight entries in flight; otherwise (and for the transposed
+  // image, whose four values sit in four rows) scalar loads, four entries = 16 loads in flight.
+  if (!TRANS && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (ldw & 3) == 0 && (n_k & 3) == 0) {
+    for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 64 * TW) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64 * TW;
+        const int ln = i & 63, blk = i >> 6, kk = blk % ntk, ot = blk / ntk;
+        const int o = 16 * ot + (ln & 15), k = 16 * kk + 4 * (ln >> 4);
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total && o < n_o && k < n_k) v[u] = *reinterpret_cast<const float4*>(W + (int64_t)o * ldw + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64 * TW;
+        if (i < total) wl[i] = v[u];
+      }
+    }
+    return;
+  }
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 64 * TW) {
     float v[4][4];
 #pragma unroll

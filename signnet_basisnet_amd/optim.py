@@ -66,8 +66,10 @@ class FlatAdam:
         if not self.params:
             raise ValueError("FlatAdam: no parameters")
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        # every parameter starts on a 16-byte boundary of the flat buffers (4-float padding: zero parameters with zero gradients,
+        # which Adam leaves at zero): the kernels that read raw parameters can then use vector loads
+        total = sum((p.numel() + 3) // 4 * 4 for p in self.params)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m, self.v = torch.zeros_like(self.flat_p), torch.zeros_like(self.flat_p)
         off = 0
@@ -81,9 +83,9 @@ class FlatAdam:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
                 if self.buckets[-1][1] - self.buckets[-1][0] >= cap:
                     self.buckets.append([off, off])
-                self.buckets[-1][1] = off + n
+                self.buckets[-1][1] = off + (n + 3) // 4 * 4
                 self._bucket_of.append(len(self.buckets) - 1)
-                off += n
+                off += (n + 3) // 4 * 4
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.dist, self.t = dist, 0
         self.param_groups = [{"params": self.params, "lr": self.lr}]

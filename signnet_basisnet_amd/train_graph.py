@@ -106,3 +106,24 @@ class GraphedStep:
         self.graph.replay()
         self.optimizer.step()
         return self.loss
+
+
+class GraphedForward:
+    """A no-grad forward of FIXED shape captured once as a HIP graph: `fn` is a closure over static device tensors (BasisNet on the one
+    grid graph of LearningFilters, a serving loop with a padded batch); `replay()` re-runs its launches with one graph launch and
+    returns the same output tensors, refreshed in place.  Copy new inputs into the tensors `fn` closes over before replaying."""
+
+    def __init__(self, fn, warmup=2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
