@@ -300,6 +300,10 @@ int64_t sn_layernorm_bwd_scratch_floats(int64_t R, int C);
 int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const float* dy, int64_t R, int C, const float* gamma,
                                 float eps, const int32_t* nvalid, int K, float* du, float* dgamma, float* dbeta,
                                 float* scratch, void* stream);
+/* sn_masked_layernorm_bwd_f32 with d gamma / d beta ADDED to the given buffers (a parameter's .grad) */
+int sn_masked_layernorm_bwd_acc_f32(const float* x, const float* residual, const float* dy, int64_t R, int C, const float* gamma,
+                                    float eps, const int32_t* nvalid, int K, float* du, float* dgamma, float* dbeta,
+                                    float* scratch, void* stream);
 int sn_set_attention_bwd_f32(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K, int heads,
                              int dk, const int32_t* nvalid, const float* prob_mask, float* dq, float* dk_out, float* dv,
                              void* stream);
@@ -677,6 +681,7 @@ typedef struct {
   float* sums_part;
   float* dw_part;
   int want_db;
+  int gx_accumulate;               /* gx += instead of gx =: several Linears share one operand (q, k, v of the attention); excludes x_mean / dot_x */
   const float* dot_x; int lddot;   /* optional [G*R, d_in]: dot_part[g*nblk + blk] = sum over the block's rows of gx . dot_x — summed by the */
   double* dot_part;                /*   caller it is the eps gradient of the GIN / GINE aggregation that produced the operand (float64: a cancelling sum) */
 } sn_train_linear_bwd_args;
@@ -696,6 +701,8 @@ int sn_train_bn_bwd_finish_f32(const float* sums_part, int nblk, int G, int C, c
 int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K, const float* state,
                           int relu, const float* residual, int ldr, float* y, int ldy, void* stream);
 int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int64_t n, float* out, int accumulate, void* stream);
+/* out[0] (+)= (float) sum of n float64 partials (dot_part of sn_train_linear_bwd_f32: the eps gradient), one launch */
+int sn_train_dot_finish_f64(const double* part, int n, float* out, int accumulate, void* stream);
 
 /* Adjoints of the aggregations of a layer whose input also feeds a residual (x -> aggregate -> MLP, y = ... + x; GNN3d.forward
  * sign_net.py:36-43, GNN.forward model.py:52-60): d x = aggregate^T(d a) + d y in ONE pass (`plus` = d y) instead of an extra elementwise add.

@@ -270,6 +270,7 @@ class _LayerNorm(Function):
         res = None if residual is None else _c(residual)
         ctx.save_for_backward(x, res, gamma)
         ctx.meta = (eps, nvalid, K)
+        ctx.affine = (gamma, beta)
         return ops.masked_layernorm(x, res, gamma.detach(), beta.detach(), eps, nvalid, K)
 
     @staticmethod
@@ -280,14 +281,17 @@ class _LayerNorm(Function):
         Cc = x.shape[-1]
         R = x.numel() // Cc
         du = torch.empty_like(x)
-        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device)
-        dbeta = torch.empty_like(dgamma)
+        from .train_stage import direct_grad
+        tg, tb = direct_grad(ctx.affine[0]), direct_grad(ctx.affine[1])
+        acc = tg is not None and tb is not None
+        dgamma = tg if acc else torch.empty(Cc, dtype=torch.float32, device=x.device)
+        dbeta = tb if acc else torch.empty_like(dgamma)
         scratch = torch.empty(int(lib().sn_layernorm_bwd_scratch_floats(R, Cc)), dtype=torch.float32, device=x.device)
+        fn = lib().sn_masked_layernorm_bwd_acc_f32 if acc else lib().sn_masked_layernorm_bwd_f32
         with ops._span("sn_masked_layernorm_bwd_f32"):
-            check(lib().sn_masked_layernorm_bwd_f32(ptr(x), ptr(res), ptr(g), R, Cc, ptr(gamma.detach()), float(eps), ptr(nvalid),
-                                                    int(K), ptr(du), ptr(dgamma), ptr(dbeta), ptr(scratch), stream()),
-                  "sn_masked_layernorm_bwd_f32")
-        return du, (du if res is not None else None), dgamma, dbeta, None, None, None
+            check(fn(ptr(x), ptr(res), ptr(g), R, Cc, ptr(gamma.detach()), float(eps), ptr(nvalid),
+                     int(K), ptr(du), ptr(dgamma), ptr(dbeta), ptr(scratch), stream()), "sn_masked_layernorm_bwd_f32")
+        return du, (du if res is not None else None), (None if acc else dgamma), (None if acc else dbeta), None, None, None
 
 
 def masked_layernorm(x, residual, gamma, beta, eps, nvalid=None, K=0):
@@ -322,6 +326,7 @@ class _EmbeddingSum(Function):
         idx = idx.contiguous()
         ctx.idx = idx
         ctx.shapes = [t.shape for t in tables]
+        ctx.tables = tables
         return ops.embedding_sum(idx, [t.detach() for t in tables], status)
 
     @staticmethod
@@ -329,8 +334,13 @@ class _EmbeddingSum(Function):
         idx = ctx.idx
         g = _c(g)
         R, nf = idx.shape
-        grads = [torch.zeros(s, dtype=torch.float32, device=g.device) if f < nf else None for f, s in enumerate(ctx.shapes)]
-        arr = (C.c_void_p * nf)(*[grads[f].data_ptr() for f in range(nf)])
+        # the kernel ADDS into its target (dT[v] += ...): a table whose .grad the optimiser owns (optim.FlatAdam) is accumulated in place —
+        # no zero-filled [vocab, d] temporary and no elementwise add per table
+        from .train_stage import direct_grad
+        direct = [direct_grad(t) if f < nf else None for f, t in enumerate(ctx.tables)]
+        grads = [(None if direct[f] is not None else torch.zeros(s, dtype=torch.float32, device=g.device)) if f < nf else None
+                 for f, s in enumerate(ctx.shapes)]
+        arr = (C.c_void_p * nf)(*[(direct[f] if direct[f] is not None else grads[f]).data_ptr() for f in range(nf)])
         rows = (C.c_int64 * nf)(*[ctx.shapes[f][0] for f in range(nf)])
         # (out-of-range indices were reported by the forward; the backward skips them — deterministic, no atomics)
         scratch = torch.empty(int(lib().sn_embedding_bwd_scratch_floats(R, nf, rows, g.shape[-1])), dtype=torch.float32, device=g.device)

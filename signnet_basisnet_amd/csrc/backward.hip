@@ -306,6 +306,20 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_v4(const float* __restric
   }
 }
 
+// out[i] (+)= sum_b part[b * stride + i], i < n: 64 outputs per block, 4 lanes per output, partials added in a fixed order
+__global__ __launch_bounds__(256) void k_cols_reduce(const float* __restrict__ part, int nparts, int64_t stride, int n, float* __restrict__ out,
+                                                     int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  float acc = 0.f;
+  if (i < n)
+    for (int b = q; b < nparts; b += 4) acc += part[(int64_t)b * stride + i];
+  red[q][c] = acc;
+  __syncthreads();
+  if (q == 0 && i < n) out[i] = (accumulate ? out[i] : 0.f) + (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+}
+
 // ============================================================================ per-node set attention backward
 // One wave per (node, head), mirroring k_set_attention: P = softmax(q k^T / sqrt(dk)) over the valid slots, o = P v.
 __global__ __launch_bounds__(64) void k_set_attention_bwd(const float* __restrict__ q, const float* __restrict__ k,
@@ -673,10 +687,10 @@ extern "C" int sn_relu_bwd_f32(const float* y, const float* dy, int64_t R, int C
 }
 
 extern "C" int64_t sn_layernorm_bwd_scratch_floats(int64_t R, int C) { return (cdiv(R > 0 ? R : 1, 4 * LN_ROWS) + 17) * 2 * C; }
-extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const float* dy, int64_t R, int C,
-                                           const float* gamma, float eps, const int32_t* nvalid, int K, float* du,
-                                           float* dgamma, float* dbeta /* contiguous pair is NOT required */, float* scratch,
-                                           void* stream) {
+static int layernorm_bwd_impl(const float* x, const float* residual, const float* dy, int64_t R, int C,
+                              const float* gamma, float eps, const int32_t* nvalid, int K, float* du,
+                              float* dgamma, float* dbeta /* contiguous pair is NOT required */, float* scratch, int accumulate,
+                              void* stream) {
   SN_REQUIRE(x && dy && gamma && du && dgamma && dbeta && scratch && R >= 0 && C > 0 && (!nvalid || K > 0),
              "sn_masked_layernorm_bwd_f32: bad arguments");
   SN_REQUIRE((size_t)8 * C * sizeof(float) <= 64 * 1024, "sn_masked_layernorm_bwd_f32: C too large");
@@ -693,14 +707,24 @@ extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual
   } else
   hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)8 * C * sizeof(float), st, x, residual, dy, R, C,
                      gamma, eps, nvalid, K, du, scratch);
-  // scratch rows are [d gamma (C) | d beta (C)]; reduced into the row behind the partials and the two-stage temporaries
-  float* tot = scratch + (int64_t)(nblk + 16) * 2 * C;
-  sum_parts(scratch, nblk, (int64_t)2 * C, tot, scratch + (int64_t)nblk * 2 * C, st);
+  // scratch rows are [d gamma (C) | d beta (C)] per block: added in block order straight into the two outputs
+  hipLaunchKernelGGL(k_cols_reduce, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)scratch, nblk, (int64_t)2 * C, C, dgamma, accumulate);
+  hipLaunchKernelGGL(k_cols_reduce, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)scratch + C, nblk, (int64_t)2 * C, C, dbeta, accumulate);
   SN_CHECK_LAUNCH("sn_masked_layernorm_bwd_f32");
-  hipError_t e = hipMemcpyAsync(dgamma, tot, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(dbeta, tot + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
-  if (e != hipSuccess) return fail(SN_ERR_LAUNCH, "sn_masked_layernorm_bwd_f32: copy: %s", hipGetErrorString(e));
   return SN_OK;
+}
+
+extern "C" int sn_masked_layernorm_bwd_f32(const float* x, const float* residual, const float* dy, int64_t R, int C,
+                                           const float* gamma, float eps, const int32_t* nvalid, int K, float* du,
+                                           float* dgamma, float* dbeta /* contiguous pair is NOT required */, float* scratch,
+                                           void* stream) {
+  return layernorm_bwd_impl(x, residual, dy, R, C, gamma, eps, nvalid, K, du, dgamma, dbeta, scratch, 0, stream);
+}
+/* the same with d gamma / d beta ADDED to the given buffers (a parameter's .grad): no separate accumulation launch */
+extern "C" int sn_masked_layernorm_bwd_acc_f32(const float* x, const float* residual, const float* dy, int64_t R, int C,
+                                               const float* gamma, float eps, const int32_t* nvalid, int K, float* du,
+                                               float* dgamma, float* dbeta, float* scratch, void* stream) {
+  return layernorm_bwd_impl(x, residual, dy, R, C, gamma, eps, nvalid, K, du, dgamma, dbeta, scratch, 1, stream);
 }
 
 extern "C" int sn_set_attention_bwd_f32(const float* q, const float* k, const float* v, const float* dout, int64_t N, int K,

@@ -383,6 +383,7 @@ struct TBwd {
   const float* x; int ldx; const float* xs; const float* xt; int xrelu; const float* xmu;   // [G][d_in]
   const float* W; int ldw;
   float* gx; int ldgx; float* sums; float* dwp; int want_db;
+  int gx_acc;                                     // gx += (several Linears share one operand: q, k, v of the attention)
   const float* dotx; int lddot; double* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
   int nblk;             // workgroups per group
 };
@@ -549,6 +550,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
               for (int r = 0; r < 4; ++r) v[r] = xv[r] > 0.f ? v[r] : 0.f;
             }
           }
+          if (a.gx_acc && row < a.R) v += ld4a(gr, c0, a.d_in);
           if (row < a.R) st4a(gr, c0, a.d_in, v);
           if (a.dotx) {
             f32x4 q = {0.f, 0.f, 0.f, 0.f};
@@ -1219,6 +1221,7 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   SN_REQUIRE((!p.mask_scale && !p.mask_shift) || (p.mask_scale && p.mask_shift && p.zo), "sn_train_linear_bwd_f32: mask_scale/shift need zo");
   SN_REQUIRE((p.x_scale == nullptr) == (p.x_shift == nullptr), "sn_train_linear_bwd_f32: x_scale / x_shift go together");
   SN_REQUIRE(!p.x_mean || (p.gx && p.sums_part), "sn_train_linear_bwd_f32: x_mean needs gx and sums_part");
+  SN_REQUIRE(!p.gx_accumulate || (p.gx && !p.x_mean && !p.dot_x), "sn_train_linear_bwd_f32: gx_accumulate excludes the column sums");
   SN_REQUIRE(!p.nvalid || p.K > 0, "sn_train_linear_bwd_f32: nvalid needs K > 0");
   SN_REQUIRE(!p.dot_x || (p.dot_part && p.gx && p.lddot >= p.d_in && p.lddot % 4 == 0 && al16(p.dot_x)),
              "sn_train_linear_bwd_f32: dot_x needs gx, dot_part and 16-byte aligned rows");
@@ -1228,7 +1231,7 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   const int nblk = sn_train_linear_bwd_blocks(p.R, p.G);
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
-         p.dot_x, p.lddot, p.dot_part, nblk};
+         p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk};
   constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
   int rc;
   if ((rc = raise_lds(k_tlin_bwd<8, 8>, lds, "sn_train_linear_bwd_f32")) != SN_OK) return rc;
@@ -1279,6 +1282,24 @@ extern "C" int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, 
   hipLaunchKernelGGL(k_tbn_apply, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, z, ldz, R, G, C, nvalid, K, state, relu,
                      residual, ldr, y, ldy);
   SN_CHECK_LAUNCH("sn_train_bn_apply_f32");
+  return SN_OK;
+}
+
+// out[0] (+)= (float) sum of n float64 partials — the eps gradient of an aggregation (sn_train_linear_bwd_f32's dot_part), one launch
+__global__ __launch_bounds__(256) void k_tdot_finish(const double* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
+  __shared__ double red[4];
+  double t = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) t += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+extern "C" int sn_train_dot_finish_f64(const double* part, int n, float* out, int accumulate, void* stream) {
+  SN_REQUIRE(part && out && n >= 1, "sn_train_dot_finish_f64: bad arguments");
+  hipLaunchKernelGGL(k_tdot_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n, out, accumulate);
+  SN_CHECK_LAUNCH("sn_train_dot_finish_f64");
   return SN_OK;
 }
 

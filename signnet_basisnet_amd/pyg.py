@@ -621,7 +621,7 @@ class SignNetGNN(nn.Module):
         static_masks = getattr(self, "_attn_masks", None)       # train_graph.GraphedStep: masks drawn outside the captured step
         for li, tl in enumerate(sn.rho.transformer_layers):
             a, f = tl.slf_attn, tl.pos_ffn
-            q, k, v = lin(x, a.w_qs), lin(x, a.w_ks), lin(x, a.w_vs)
+            q, k, v = T.qkv(x, a.w_qs, a.w_ks, a.w_vs, nv, K) if stage else (lin(x, a.w_qs), lin(x, a.w_ks), lin(x, a.w_vs))
             pm = static_masks[li] if static_masks is not None else ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device)
             o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, pm)
             o = lin(o, a.fc)

@@ -36,7 +36,7 @@ class _BwdArgs(C.Structure):
                 ("mask_scale", C.c_void_p), ("mask_shift", C.c_void_p),
                 ("x", C.c_void_p), ("ldx", C.c_int), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_relu", C.c_int),
                 ("x_mean", C.c_void_p), ("W", C.c_void_p), ("ldw", C.c_int), ("gx", C.c_void_p), ("ldgx", C.c_int),
-                ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int),
+                ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int), ("gx_accumulate", C.c_int),
                 ("dot_x", C.c_void_p), ("lddot", C.c_int), ("dot_part", C.c_void_p)]
 
 
@@ -115,15 +115,16 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
 
 
 def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state=None, x_relu=False, want_sums=False,
-               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None):
+               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None, gx_into=None):
     """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h.
     dW_acc / db_acc: accumulate the weight / bias gradient into these buffers (returned dW / db are then None).
-    dot_x: also sum gx . dot_x over all rows (per-workgroup partials, left on `linear_bwd.dot_part` for the caller to add up)."""
+    dot_x: also sum gx . dot_x over all rows (per-workgroup partials, left on `linear_bwd.dot_part` for the caller to add up).
+    gx_into: ADD the input gradient to this buffer instead of allocating one (several Linears reading one operand)."""
     W = _w(W)
     d_out, d_in = W.shape
     dev = dy.device
     nblk = int(lib().sn_train_linear_bwd_blocks(R, G))
-    gx = torch.empty(G * R, d_in, dtype=torch.float32, device=dev) if want_dx else None
+    gx = (gx_into if gx_into is not None else torch.empty(G * R, d_in, dtype=torch.float32, device=dev)) if want_dx else None
     sums = torch.empty(G * nblk * 2 * d_in, dtype=torch.float32, device=dev) if want_sums else None
     stride = d_out * d_in + (d_out if want_db else 0)
     dwp = torch.empty(G * nblk * stride, dtype=torch.float32, device=dev)
@@ -132,7 +133,8 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
                  ptr(None if mask is None else mask[0]), ptr(None if mask is None else mask[1]),
                  ptr(x), x.stride(0), ptr(None if x_state is None else x_state.scale), ptr(None if x_state is None else x_state.shift),
                  int(x_relu), ptr(x_state.mean if (want_sums and x_state is not None) else None), ptr(W), W.stride(0),
-                 ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db), ptr(dot_x), 0 if dot_x is None else dot_x.stride(0), None)
+                 ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db), int(gx_into is not None), ptr(dot_x),
+                 0 if dot_x is None else dot_x.stride(0), None)
     linear_bwd.dot_part = None
     if dot_x is not None:
         linear_bwd.dot_part = torch.empty(G * nblk, dtype=torch.float64, device=dev)
@@ -153,6 +155,17 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
     dW = out[:nw].view(d_out, d_in)
     db = out[nw:] if want_db else None
     return gx, sums, nblk, dW, db
+
+
+def eps_grad(eps):
+    """The eps gradient of an aggregation from `linear_bwd.dot_part` (float64 partials): one launch, added straight into eps.grad
+    when the optimiser owns it (returns None then), else a [1] tensor for autograd."""
+    part = linear_bwd.dot_part
+    acc = direct_grad(eps)
+    out = acc if acc is not None else torch.empty(1, dtype=torch.float32, device=part.device)
+    with ops._span("sn_train_dot_finish_f64"):
+        check(lib().sn_train_dot_finish_f64(ptr(part), part.numel(), ptr(out), int(acc is not None), stream()), "sn_train_dot_finish_f64")
+    return None if acc is not None else out
 
 
 def bn_bwd_sums(dy, z, R, G, nvalid, K, st, relu):
@@ -251,6 +264,7 @@ class _GinLayer(Function):
         a = ops.gin_aggregate(x.view(-1, K * d), plan, eps.detach()).view(-1, d)
         y, z1, z2, st1, st2 = _mlp2_forward(a, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, x)
         ctx.save_for_backward(x, a, z1, z2, eps)
+        ctx.eps_param = eps
         ctx.meta = (R, G, nvalid, K, st1, st2, lin1, bn1, lin2, bn2, rplan)
         return y
 
@@ -263,7 +277,7 @@ class _GinLayer(Function):
         want_eps = ctx.needs_input_grad[1]
         grads = _mlp2_backward(dy, a, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, True, dot_x=x if want_eps else None)
         da = grads[0]
-        deps = linear_bwd.dot_part.sum().float().view(1) if want_eps else None
+        deps = eps_grad(ctx.eps_param) if want_eps else None
         dx = torch.empty_like(x)
         with ops._span("sn_gin_aggregate_add_f32"):
             check(lib().sn_gin_aggregate_add_f32(ptr(da), ptr(dy), ptr(dx), x.shape[0] // K, K * d, ptr(rplan.rowptr), ptr(rplan.col),
@@ -307,6 +321,7 @@ class _GineLayer(Function):
         u = ops.gine_aggregate(h, e, plan, eps.detach())
         y, z1, z2, st1, st2 = _mlp2_forward(u, h.shape[0], 1, lin1, bn1, lin2, bn2, None, 0, True, h)
         ctx.save_for_backward(h, e, u, z1, z2, eps)
+        ctx.eps_param = eps
         ctx.meta = (st1, st2, lin1, bn1, lin2, bn2, rplan)
         return y
 
@@ -319,7 +334,7 @@ class _GineLayer(Function):
         want_eps = ctx.needs_input_grad[2]
         grads = _mlp2_backward(dy, u, z1, z2, st1, st2, N, 1, lin1, bn1, lin2, bn2, None, 0, True, True, dot_x=h if want_eps else None)
         du = grads[0]
-        deps = linear_bwd.dot_part.sum().float().view(1) if want_eps else None
+        deps = eps_grad(ctx.eps_param) if want_eps else None
         dh, dee = torch.empty_like(h), torch.empty_like(e)
         with ops._span("sn_gine_aggregate_bwd_add_f32"):
             check(lib().sn_gine_aggregate_bwd_add_f32(ptr(h), ptr(e), ptr(du), ptr(dy), N, d, ptr(rplan.rowptr), ptr(rplan.col),
@@ -366,6 +381,38 @@ class _Linear(Function):
         dx, _, _, dW, db = linear_bwd(dy, R, 1, W, nvalid, K, x, zo=y if relu else None, mask=mask,
                                       want_dx=ctx.needs_input_grad[0], want_db=has_b, dW_acc=direct_grad(Wp), db_acc=direct_grad(bp))
         return dx, dW, db, None, None, None, None
+
+
+class _QKV(Function):
+    """q, k, v = x Wq^T, x Wk^T, x Wv^T (MultiHeadAttention's three bias-free projections of one operand, transformer_module.py:84-86):
+    the adjoint ADDS the three input gradients in the kernels' epilogues (gx +=) instead of two elementwise launches."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, Wk, Wv, mq, mk, mv, nvalid, K):
+        x = _c(x)
+        R = x.shape[0]
+        outs = tuple(linear_fwd(x, R, 1, m.weight, None, nvalid, K)[0] for m in (mq, mk, mv))
+        ctx.save_for_backward(x)
+        ctx.meta = (R, nvalid, K, mq, mk, mv)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        (x,) = ctx.saved_tensors
+        R, nvalid, K, mq, mk, mv = ctx.meta
+        gx, dWs = None, []
+        for i, (g, m) in enumerate(((dq, mq), (dk, mk), (dv, mv))):
+            r = linear_bwd(_c(g), R, 1, m.weight, nvalid, K, x, want_dx=ctx.needs_input_grad[0], want_db=False,
+                           dW_acc=direct_grad(m.weight), gx_into=gx)
+            gx = r[0]
+            dWs.append(r[3])
+        return (gx, *dWs, None, None, None, None, None)
+
+
+def qkv(x, mq, mk, mv, nvalid=None, K=0):
+    if any(m.bias is not None for m in (mq, mk, mv)):
+        raise ValueError("qkv: the attention projections have no bias")
+    return _QKV.apply(x, mq.weight, mk.weight, mv.weight, mq, mk, mv, nvalid, K)
 
 
 def linear(x, W, b=None, nvalid=None, K=0, relu=False, owner=None):
