@@ -59,7 +59,7 @@ __device__ __forceinline__ void stage_weight(float4* wl, const float* __restrict
   // A 128 x 128 matrix is 32 image entries per thread.  One entry at a time the staging was a chain of 32 dependent L2 round trips — most
   // of a small launch.  Row-major parameter, 16-byte aligned with ldw % 4 == 0 (the usual case; FlatAdam's views are aligned when the
   // preceding parameters' sizes are multiples of 4): ONE float4 per entry, eight entries in flight; otherwise (and for the transposed
-  // image, whose four values sit in four rows) scalar loads, four entries = 16 loads in flight.
+  // image, whose four values sit in four rows) scalar loads, eight entries = 32 loads in flight: ONE round trip for a 128 x 128 matrix.
   if (!TRANS && (reinterpret_cast<uintptr_t>(W) & 15) == 0 && (ldw & 3) == 0 && (n_k & 3) == 0) {
     for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 64 * TW) {
       float4 v[8];
@@ -79,10 +79,10 @@ __device__ __forceinline__ void stage_weight(float4* wl, const float* __restrict
     }
     return;
   }
-  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 64 * TW) {
-    float v[4][4];
+  for (int i0 = threadIdx.x; i0 < total; i0 += 8 * 64 * TW) {
+    float v[8][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 64 * TW;
       const int ln = i & 63, blk = i >> 6, kk = blk % ntk, ot = blk / ntk;
       const int o = 16 * ot + (ln & 15), k = 16 * kk + 4 * (ln >> 4);
@@ -93,7 +93,7 @@ __device__ __forceinline__ void stage_weight(float4* wl, const float* __restrict
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 64 * TW;
       if (i < total) wl[i] = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
     }
@@ -111,7 +111,10 @@ struct TLin {
   int nblk;             // workgroups per group
 };
 
-template <int NTI, int NTO, bool STATS>
+// FULL: d_in = 16 NTI and d_out = 16 NTO exactly (the 128-wide links) — the tile counts are compile-time constants, the per-tile guards
+// fold away and the MFMA loops are straight-line code the compiler can pipeline the LDS reads of (with the guards every 16-column
+// step was its own basic block: read, wait the LDS latency, 8 MFMAs — twice the MFMA time on a one-tile launch).
+template <int NTI, int NTO, bool STATS, bool FULL>
 __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   extern __shared__ __align__(16) unsigned char t_lds[];
   float4* wl = reinterpret_cast<float4*>(t_lds);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   float* piv = icol + 2 * 16 * NTI;                                             // [TW][16*NTO] per-wave pivots of the moment sums
   constexpr int CI = 16 * NTI;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int nti = (a.d_in + 15) >> 4, nto = (a.d_out + 15) >> 4;
+  const int nti = FULL ? NTI : (a.d_in + 15) >> 4, nto = FULL ? NTO : (a.d_out + 15) >> 4;
   const int grp = blockIdx.x / a.nblk, blk = blockIdx.x - grp * a.nblk;
   const int64_t ntiles_all = (a.R + 15) >> 4;
   const int64_t t_lo = ntiles_all * blk / a.nblk, t_hi = ntiles_all * (blk + 1) / a.nblk;
@@ -153,11 +156,12 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
     valid = row_ok(tile * 16 + (lane & 15), a.R, a.nvalid, a.K);
     fetch(tile, valid, in);
   }
+  // every global read of the prologue is in flight before the first wait: the tile above, the column constants, the weight image
+  static_assert(CI <= 64 * TW, "one column constant per thread");
+  float c_sc = 1.f, c_sh = 0.f;
+  if (isc && (int)threadIdx.x < a.d_in) { c_sc = isc[threadIdx.x]; c_sh = ish[threadIdx.x]; }
   stage_weight<false>(wl, a.W, a.ldw, a.d_out, a.d_in, nto, nti);
-  for (int i = threadIdx.x; i < CI; i += 64 * TW) {
-    icol[i] = (isc && i < a.d_in) ? isc[i] : 1.f;
-    icol[CI + i] = (isc && i < a.d_in) ? ish[i] : 0.f;
-  }
+  if (threadIdx.x < CI) { icol[threadIdx.x] = c_sc; icol[CI + threadIdx.x] = c_sh; }
   __syncthreads();
   for (; tile < t_hi; tile += TW) {
     const int64_t row = tile * 16 + (lane & 15);
@@ -232,10 +236,13 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
           f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
           const float4* w0 = wl + (ot * nti) * 64 + lane;
           const float4* w1 = w0 + nti * 64;
+          float4 pn = w0[0], qn = w1[0];        // the next step's fragments are read while this step's 8 MFMAs run
 #pragma unroll
           for (int kk = 0; kk < NTI; ++kk) {
             if (kk < nti) {
-              const float4 p = w0[kk * 64], q = w1[kk * 64];
+              const float4 p = pn, q = qn;
+              if (kk + 1 < nti) { pn = w0[(kk + 1) * 64]; qn = w1[(kk + 1) * 64]; }
+              __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler sinks the reads to just before their use)
               acc0 = mfma16(p.x, in[kk][0], acc0);
               acc1 = mfma16(q.x, in[kk][0], acc1);
               acc0 = mfma16(p.y, in[kk][1], acc0);
@@ -319,6 +326,90 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   }
 }
 
+// The same link for FEW rows (a batch of small graphs: 2 950 nodes = 185 row tiles).  The persistent kernel above gives such a launch one
+// tile per wave on a quarter of the SIMDs and a serial chain of 8 output tiles x (32 MFMAs + epilogue) behind a 64 KB weight staging:
+// 13 us of kernel for 3 us of arithmetic.  Here a workgroup is ONE 16-row tile and a wave ONE 16-column output tile: every wave reads
+// its 16 weight rows (8 KB, L2) and the tile's rows straight into registers (no LDS, no barrier), runs its 32 MFMAs in two accumulator
+// chains and writes its 16 output columns and their per-tile moments (mean, M2, count: the finish kernel merges them, Chan).
+// grid = G * ntiles (nblk = ntiles), 64 * TW threads; d_out <= 16 * TW.
+template <int NTI, bool STATS>
+__global__ __launch_bounds__(64 * TW) void k_tlin_fwd_tile(TLin a) {
+  const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
+  const int nti = (a.d_in + 15) >> 4, nto = (a.d_out + 15) >> 4;
+  if (ot >= nto) return;
+  const int grp = blockIdx.x / a.nblk, blk = blockIdx.x - grp * a.nblk;
+  const int64_t row = (int64_t)blk * 16 + lr;
+  const bool inr = row < a.R, valid = row_ok(row, a.R, a.nvalid, a.K);
+  const float* xr = a.x + ((int64_t)grp * a.R + row) * a.ldx;
+  const int o = 16 * ot + lr;
+  const float* wr = a.W + (int64_t)o * a.ldw;
+  const bool wvec = (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 && (a.ldw & 3) == 0 && (a.d_in & 3) == 0;
+  const float* isc = a.in_scale ? a.in_scale + (int64_t)grp * a.d_in : nullptr;
+  const float* ish = a.in_scale ? a.in_shift + (int64_t)grp * a.d_in : nullptr;
+  f32x4 in[NTI], wf[NTI], sc[NTI], sh[NTI];
+#pragma unroll
+  for (int kk = 0; kk < NTI; ++kk) {
+    const int c0 = 16 * kk + 4 * g;
+    in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wf[kk] = in[kk];
+    if (kk < nti) {
+      if (valid) in[kk] = ld4a(xr, c0, a.d_in);
+      if (o < a.d_out) wf[kk] = wvec ? ld4a(wr, c0, a.d_in) : ldv(wr, c0, a.d_in);
+      if (isc) { sc[kk] = ld4a(isc, c0, a.d_in); sh[kk] = ld4a(ish, c0, a.d_in); }
+    }
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+  for (int kk = 0; kk < NTI; ++kk) {
+    if (kk < nti) {
+      f32x4 v = in[kk];
+      if (isc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float t = v[r] * sc[kk][r] + sh[kk][r];
+          if (a.in_relu) t = fmaxf(t, 0.f);
+          v[r] = valid ? t : 0.f;
+        }
+      } else if (a.in_relu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (kk & 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc1 = mfma16(wf[kk][r], v[r], acc1);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0 = mfma16(wf[kk][r], v[r], acc0);
+      }
+    }
+  }
+  const int o0 = 16 * ot + 4 * g;
+  f32x4 v = acc0 + acc1;
+  if (!valid) {
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+  } else {
+    if (a.bias) v += ldv(a.bias, o0, a.d_out);
+    if (a.out_relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+  }
+  if (inr) st4a(a.y + ((int64_t)grp * a.R + row) * a.ldy, o0, a.d_out, v);
+  if (STATS) {
+    const float nt = (float)__popcll(__ballot(valid) & 0xffffull);
+    const float inv = nt > 0.f ? 1.0f / nt : 0.f;
+    float* stg = a.stat + (int64_t)grp * (2 * (int64_t)a.nblk * a.d_out + a.nblk);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float m = t16_sum(v[r]) * inv;                 // invalid rows hold 0
+      const float d = valid ? v[r] - m : 0.f;
+      const float q = t16_sum(d * d);
+      if (lr == 0 && o0 + r < a.d_out) {
+        stg[(int64_t)blk * a.d_out + o0 + r] = m;
+        stg[((int64_t)a.nblk + blk) * a.d_out + o0 + r] = q;
+      }
+    }
+    if (threadIdx.x == 0) stg[2 * (int64_t)a.nblk * a.d_out + blk] = nt;
+  }
+}
+
 // Finish of the train-mode BatchNorm(s) of one forward link: merges the per-workgroup moments of every group (Chan), writes the
 // state the consumers and the backward read — st[0..4][grp][C] = mean, var (biased), rstd, scale = gamma*rstd, shift = beta - mean*scale;
 // cnt[grp] — and applies the running-statistics updates in group order (two sequential calls of the module in the reference).
@@ -340,8 +431,18 @@ __global__ __launch_bounds__(256) void k_tbn_finish(const float* __restrict__ st
   for (int grp = 0; grp < G; ++grp) {
     const float* sg = stat + (int64_t)grp * (2 * (int64_t)nblk * C + nblk);
     float n = 0.f, m = 0.f, q = 0.f;
-    if (c < C)
-      for (int b = b0; b < b1; ++b) chan(n, m, q, sg[2 * (int64_t)nblk * C + b], sg[(int64_t)b * C + c], sg[((int64_t)nblk + b) * C + c]);
+    if (c < C) {
+      for (int b = b0; b < b1; b += 4) {        // four partials in flight (one at a time: a chain of L2 round trips per column)
+        float nb[4], mb[4], qb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
+          if (b + u < b1) { nb[u] = sg[2 * (int64_t)nblk * C + b + u]; mb[u] = sg[(int64_t)(b + u) * C + c]; qb[u] = sg[((int64_t)nblk + b + u) * C + c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) chan(n, m, q, nb[u], mb[u], qb[u]);
+      }
+    }
     ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
     __syncthreads();
     for (int step = 8; step >= 1; step >>= 1) {
@@ -390,23 +491,28 @@ struct TBwd {
 
 __host__ __device__ constexpr int stage_ld(int ntiles) { return ((16 * ntiles + 63) / 64) * 64 + 16; }   // row stride = 16 mod 64 banks
 
-template <int NTI, int NTO>
+// RT = row tiles per round (a round = 16 RT rows; the 8 waves are RT row tiles x 8/RT column parts): 4 for the persistent launch, 1 for
+// FEW rows (a batch of small graphs) — there a workgroup per CU gets one 64-row round, 64 MFMAs deep per phase and wave on a fifth of
+// the chip; with 16-row rounds the same rows are 4x the workgroups, each 4x shallower (the weight image is re-staged per workgroup
+// from L2 either way, and the dW partials — one 64 KB image per workgroup — grow 4x: 12 MB at 2 950 rows, read once by the reduce).
+template <int NTI, int NTO, bool FULL, int RT>
 __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   constexpr int LDO = stage_ld(NTO), LDI = stage_ld(NTI);
+  constexpr int TR = 16 * RT, NP = TW / RT;
   extern __shared__ __align__(16) unsigned char t_lds[];
-  const int nti = (a.d_in + 15) >> 4, nto = (a.d_out + 15) >> 4;
+  const int nti = FULL ? NTI : (a.d_in + 15) >> 4, nto = FULL ? NTO : (a.d_out + 15) >> 4;
   float4* wl = reinterpret_cast<float4*>(t_lds);                          // W^T image: [ot2 < nti][kk < nto][64] float4
-  float* dzs = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;  // [TROWS][LDO]
-  float* xsg = dzs + TROWS * LDO;                                          // [TROWS][LDI]  raw x (x_hat is re-formed at each use)
-  float* red = xsg + TROWS * LDI;                                          // [3 sums][4 row tiles][16*NTI] running column sums of gx
+  float* dzs = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;  // [TR][LDO]
+  float* xsg = dzs + TR * LDO;                                          // [TR][LDI]  raw x (x_hat is re-formed at each use)
+  float* red = xsg + TR * LDI;                                          // [3 sums][4 row tiles][16*NTI] running column sums of gx
   float* xcol = red + 3 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
   float* ocol = xcol + 3 * 16 * NTI;                                       // [5][16*NTO] coef a | b | c | mask scale | mask shift
   double* redd = reinterpret_cast<double*>(ocol + 5 * 16 * NTO);           // [4 row tiles][16*NTI] float64 sums of gx . dot_x
   constexpr int CI = 16 * NTI, CO = 16 * NTO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
-  const int rt = wave & 3, half = wave >> 2;
+  const int rt = wave % RT, part = wave / RT;
   const int grp = blockIdx.x / a.nblk, blk = blockIdx.x - grp * a.nblk;
-  const int64_t nrounds = (a.R + TROWS - 1) / TROWS;
+  const int64_t nrounds = (a.R + TR - 1) / TR;
   const int64_t r_lo = nrounds * blk / a.nblk, r_hi = nrounds * (blk + 1) / a.nblk;
   const int64_t goff = (int64_t)grp * a.R;
   const float* cA = a.cA ? a.cA + (int64_t)grp * a.d_out : nullptr;
@@ -418,47 +524,28 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   const float* xt = a.xs ? a.xt + (int64_t)grp * a.d_in : nullptr;
   const float* xmu = a.xmu ? a.xmu + (int64_t)grp * a.d_in : nullptr;
   const bool want_dx = a.gx != nullptr;
-  if (want_dx) stage_weight<true>(wl, a.W, a.ldw, a.d_in, a.d_out, nti, nto);
-  // dW accumulators of this wave: output tile `wave` (16 dz columns) x every operand tile; column constants of x_hat for my dW lanes
+  // dW accumulators of this wave: output tile `wave` (16 dz columns) x every operand tile
   f32x4 dw[NTI];
 #pragma unroll
   for (int it = 0; it < NTI; ++it) dw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < 16 * NTI; i += 64 * TW) {
-    xcol[i] = (xs && i < a.d_in) ? xs[i] : 1.f;
-    xcol[CI + i] = (xs && i < a.d_in) ? xt[i] : 0.f;
-    xcol[2 * CI + i] = (xmu && i < a.d_in) ? xmu[i] : 0.f;
-  }
-  for (int i = threadIdx.x; i < 16 * NTO; i += 64 * TW) {     // (global / L1 round trips per tile and round cost ~20 us per launch)
-    const bool in = i < a.d_out;
-    ocol[i] = (cA && in) ? cA[i] : 1.f;
-    ocol[CO + i] = (cA && in) ? cB[i] : 0.f;
-    ocol[2 * CO + i] = (cA && in) ? cC[i] : 0.f;
-    ocol[3 * CO + i] = (ms && in) ? ms[i] : 0.f;
-    ocol[4 * CO + i] = (ms && in) ? mt[i] : 1.f;
-  }
   float dbacc = 0.f;
-  // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
-  // with them the kernel spilled)
-  for (int i = threadIdx.x; i < 3 * 4 * 16 * NTI; i += 64 * TW) red[i] = 0.f;
-  for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) redd[i] = 0.0;
-
   // The raw rows of round r+1 are requested (into registers) right after round r's tiles are published, so the HBM latency runs
-  // under the round's 256 MFMAs per wave; a wave loads the column tiles kk = half, half+2, ... of its 16 rows.
-  constexpr int HO = (NTO + 1) / 2, HI = (NTI + 1) / 2;
+  // under the round's 256 MFMAs per wave; a wave loads the column tiles kk = part, part + NP, ... of its 16 rows.
+  constexpr int HO = (NTO + NP - 1) / NP, HI = (NTI + NP - 1) / NP;
   f32x4 pdy[HO], pz[HO], px[HI];
   bool pvalid = false;
   auto request = [&](int64_t round) {
-    const int64_t row = round * TROWS + 16 * rt + lr;
+    const int64_t row = round * TR + 16 * rt + lr;
     pvalid = row_ok(row, a.R, a.nvalid, a.K);
     const float* dyr = a.dy + (goff + row) * a.lddy;
     const float* zr = a.zo ? a.zo + (goff + row) * a.ldzo : nullptr;
     const float* xr = a.x + (goff + row) * a.ldx;
 #pragma unroll
     for (int j = 0; j < HO; ++j) {
-      const int c0 = 16 * (2 * j + half) + 4 * g;
+      const int c0 = 16 * (NP * j + part) + 4 * g;
       pdy[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       pz[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pvalid && 2 * j + half < nto) {
+      if (pvalid && NP * j + part < nto) {
         pdy[j] = ld4a(dyr, c0, a.d_out);
         if (zr) pz[j] = ld4a(zr, c0, a.d_out);
       }
@@ -466,20 +553,44 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
 #pragma unroll
     for (int j = 0; j < HI; ++j) {
       px[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (pvalid && 2 * j + half < nti) px[j] = ld4a(xr, 16 * (2 * j + half) + 4 * g, a.d_in);
+      if (pvalid && NP * j + part < nti) px[j] = ld4a(xr, 16 * (NP * j + part) + 4 * g, a.d_in);
     }
   };
+  // Prologue: every global read is in flight before the first wait — the first round's rows, the column constants (one per thread,
+  // held in registers), the weight image — then the LDS writes.  (One after the other these were five L2 round trips, ~6 us a launch.)
   request(r_lo);
+  static_assert(CI <= 64 * TW && CO <= 64 * TW, "one column constant per thread");
+  float c_x[3] = {1.f, 0.f, 0.f}, c_o[5] = {1.f, 0.f, 0.f, 0.f, 1.f};
+  {
+    const int i = threadIdx.x;
+    if (xs && i < a.d_in) { c_x[0] = xs[i]; c_x[1] = xt[i]; }
+    if (xmu && i < a.d_in) c_x[2] = xmu[i];
+    if (cA && i < a.d_out) { c_o[0] = cA[i]; c_o[1] = cB[i]; c_o[2] = cC[i]; }
+    if (ms && i < a.d_out) { c_o[3] = ms[i]; c_o[4] = mt[i]; }
+  }
+  if (want_dx) stage_weight<true>(wl, a.W, a.ldw, a.d_in, a.d_out, nti, nto);
+  if (threadIdx.x < CI) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) xcol[j * CI + threadIdx.x] = c_x[j];
+  }
+  if (threadIdx.x < CO) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) ocol[j * CO + threadIdx.x] = c_o[j];
+  }
+  // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
+  // with them the kernel spilled)
+  for (int i = threadIdx.x; i < 3 * 4 * 16 * NTI; i += 64 * TW) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) redd[i] = 0.0;
   __syncthreads();          // the column constants (and the weight image) are published before phase 1 reads them
   for (int64_t round = r_lo; round < r_hi; ++round) {
-    const int64_t row = round * TROWS + 16 * rt + lr;     // my row within the group (phases 1, 2)
+    const int64_t row = round * TR + 16 * rt + lr;     // my row within the group (phases 1, 2)
     const bool valid = pvalid;
     // ---------------------------------------------------------------- phase 1: dz and x of the round -> LDS
     {
       float* dst = dzs + (16 * rt + lr) * LDO;
 #pragma unroll
       for (int j = 0; j < HO; ++j) {
-        const int kk = 2 * j + half;
+        const int kk = NP * j + part;
         if (kk < nto) {
           const int c0 = 16 * kk + 4 * g;
           f32x4 v = pdy[j];
@@ -502,7 +613,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       float* dsx = xsg + (16 * rt + lr) * LDI;
 #pragma unroll
       for (int j = 0; j < HI; ++j) {
-        const int kk = 2 * j + half;
+        const int kk = NP * j + part;
         if (kk < nti) *reinterpret_cast<float4*>(dsx + 16 * kk + 4 * g) = make_float4(px[j][0], px[j][1], px[j][2], px[j][3]);
       }
     }
@@ -520,15 +631,18 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       float* gr = a.gx + (goff + row) * a.ldgx;
       const float* xrow = xsg + (16 * rt + lr) * LDI;
 #pragma unroll
-      for (int j = 0; j < (NTI + 1) / 2; ++j) {
-        const int ot = 2 * j + half;
+      for (int j = 0; j < HI; ++j) {
+        const int ot = NP * j + part;
         if (ot < nti) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
           const float4* w0 = wl + (ot * nto) * 64 + lane;
+          float4 pn = w0[0];
 #pragma unroll
           for (int kk = 0; kk < NTO; ++kk) {
             if (kk < nto) {
-              const float4 p = w0[kk * 64];
+              const float4 p = pn;
+              if (kk + 1 < nto) pn = w0[(kk + 1) * 64];
+              __builtin_amdgcn_sched_barrier(0);
               acc = mfma16(p.x, fr[kk][0], acc);
               acc = mfma16(p.y, fr[kk][1], acc);
               acc = mfma16(p.z, fr[kk][2], acc);
@@ -577,8 +691,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     }
     // ---------------------------------------------------------------- phase 3: dW[tile `wave`] += dz^T x_hat over the round's rows
     if (wave < nto && a.dwp) {
-#pragma unroll 1     // (unrolled by 2 the LDS reads of both steps are hoisted and the kernel spills)
-      for (int q = 0; q < TROWS / 4; ++q) {
+#pragma unroll 1     // (unrolled by 2 the LDS reads of both steps are hoisted and the kernel spills; a hand-made prefetch of the next
+                     //  step's operands measured slower)
+      for (int q = 0; q < TR / 4; ++q) {
         const int rl = 4 * q + g;
         const float av = dzs[rl * LDO + 16 * wave + lr];
         dbacc += av;
@@ -1148,15 +1263,22 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 using namespace sn;
 
 // workgroups per group of the forward link (= moment partials per group) / of the backward link (= dW, column-sum partials per group)
+// Few rows: one workgroup per 16-row tile (k_tlin_fwd_tile); otherwise the persistent kernel, a workgroup per CU, >= 4 tiles each.
+constexpr int64_t TILE_MODE_MAX = 512;          // row tiles, all groups together
+static bool tile_mode(int64_t R, int G) { return cdiv(R > 0 ? R : 1, 16) * (G < 1 ? 1 : G) <= TILE_MODE_MAX; }
 extern "C" int sn_train_linear_blocks(int64_t R, int G) {
   if (G < 1) G = 1;
+  if (tile_mode(R, G)) return (int)cdiv(R > 0 ? R : 1, 16);
   const int64_t want = cdiv(cdiv(R > 0 ? R : 1, 16), 4);
   int64_t cap = train_cus() / G;
   if (cap < 1) cap = 1;
   return (int)(want < cap ? want : cap);
 }
+// Few rows: 16-row rounds, one per workgroup (measured at 2 950 rows: 15.6 us; 32-row rounds 17.0; the persistent 64-row rounds 23.4)
+static int bwd_small_rt() { return 1; }
 extern "C" int sn_train_linear_bwd_blocks(int64_t R, int G) {
   if (G < 1) G = 1;
+  if (tile_mode(R, G)) return (int)cdiv(R > 0 ? R : 1, 16 * bwd_small_rt());       // one round per workgroup
   const int64_t want = cdiv(R > 0 ? R : 1, TROWS);
   int64_t cap = train_cus() / G;
   if (cap < 1) cap = 1;
@@ -1182,13 +1304,18 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   const size_t lds = (size_t)8 * 8 * 1024 + (size_t)(2 * 16 * 8 + TW * 16 * 8) * sizeof(float);    // weight image + in_scale | in_shift + pivots
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (p.stat_part) {
-    if ((rc = raise_lds(k_tlin_fwd<8, 8, true>, lds, "sn_train_linear_f32")) != SN_OK) return rc;
-    hipLaunchKernelGGL((k_tlin_fwd<8, 8, true>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, st, a);
-  } else {
-    if ((rc = raise_lds(k_tlin_fwd<8, 8, false>, lds, "sn_train_linear_f32")) != SN_OK) return rc;
-    hipLaunchKernelGGL((k_tlin_fwd<8, 8, false>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, st, a);
-  }
+  const bool full = p.d_in == 128 && p.d_out == 128;
+#define SN_TLIN_FWD(STATS, FULL)                                                                                             \
+  do {                                                                                                                        \
+    if ((rc = raise_lds(k_tlin_fwd<8, 8, STATS, FULL>, lds, "sn_train_linear_f32")) != SN_OK) return rc;                      \
+    hipLaunchKernelGGL((k_tlin_fwd<8, 8, STATS, FULL>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, st, a);             \
+  } while (0)
+  if (tile_mode(p.R, p.G)) {
+    if (p.stat_part) hipLaunchKernelGGL((k_tlin_fwd_tile<8, true>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), 0, st, a);
+    else hipLaunchKernelGGL((k_tlin_fwd_tile<8, false>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), 0, st, a);
+  } else if (p.stat_part) { if (full) SN_TLIN_FWD(true, true); else SN_TLIN_FWD(true, false); }
+  else { if (full) SN_TLIN_FWD(false, true); else SN_TLIN_FWD(false, false); }
+#undef SN_TLIN_FWD
   SN_CHECK_LAUNCH("sn_train_linear_f32");
   return SN_OK;
 }
@@ -1232,17 +1359,28 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
          p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk};
-  constexpr size_t lds = (size_t)8 * 8 * 1024 + (size_t)TROWS * (stage_ld(8) + stage_ld(8)) * sizeof(float) + (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
+  auto lds_of = [](int rt) {
+    return (size_t)8 * 8 * 1024 + (size_t)16 * rt * (stage_ld(8) + stage_ld(8)) * sizeof(float) +
+           (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
+  };
+  const bool full = p.d_in == 128 && p.d_out == 128;
+  const int rt = tile_mode(p.R, p.G) ? bwd_small_rt() : 4;
   int rc;
-  if ((rc = raise_lds(k_tlin_bwd<8, 8>, lds, "sn_train_linear_bwd_f32")) != SN_OK) return rc;
-  hipLaunchKernelGGL((k_tlin_bwd<8, 8>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, (hipStream_t)stream, a);
+#define SN_TLIN_BWD(FULL, RT)                                                                                                    \
+  do {                                                                                                                            \
+    if ((rc = raise_lds(k_tlin_bwd<8, 8, FULL, RT>, lds_of(RT), "sn_train_linear_bwd_f32")) != SN_OK) return rc;                  \
+    hipLaunchKernelGGL((k_tlin_bwd<8, 8, FULL, RT>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds_of(RT), (hipStream_t)stream, a); \
+  } while (0)
+  if (rt == 1) { if (full) SN_TLIN_BWD(true, 1); else SN_TLIN_BWD(false, 1); }
+  else { if (full) SN_TLIN_BWD(true, 4); else SN_TLIN_BWD(false, 4); }
+#undef SN_TLIN_BWD
   SN_CHECK_LAUNCH("sn_train_linear_bwd_f32");
   return SN_OK;
 }
 
 extern "C" int sn_train_bn_bwd_blocks(int64_t R, int G) {
   if (G < 1) G = 1;
-  const int64_t want = cdiv(R > 0 ? R : 1, 128);
+  const int64_t want = cdiv(R > 0 ? R : 1, tile_mode(R, G) ? 32 : 128);      // (few rows: the pass is a chain of row loads per thread)
   int64_t cap = 2 * train_cus() / G;
   if (cap < 1) cap = 1;
   return (int)(want < cap ? want : cap);
