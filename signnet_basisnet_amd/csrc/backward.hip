@@ -307,17 +307,36 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd_v4(const float* __restric
 }
 
 // out[i] (+)= sum_b part[b * stride + i], i < n: 64 outputs per block, 4 lanes per output, partials added in a fixed order
-__global__ __launch_bounds__(256) void k_cols_reduce(const float* __restrict__ part, int nparts, int64_t stride, int n, float* __restrict__ out,
-                                                     int accumulate) {
-  __shared__ float red[4][64];
+// out[y][i] (+)= sum_b part[b * stride + y * yoff + i]: 64 columns x 16 row lanes per block, a lane adds its partials b = q, q + 16, ... in
+// order with eight loads in flight (four lanes and one load at a time, 738 partials of a 47 200-row LayerNorm were a 45 us chain),
+// then the 16 lanes in order.  blockIdx.y picks the output (dgamma | dbeta in one launch).
+__global__ __launch_bounds__(1024) void k_cols_reduce(const float* __restrict__ part, int nparts, int64_t stride, int n, int64_t yoff,
+                                                      float* __restrict__ out0, float* __restrict__ out1, int accumulate) {
+  __shared__ float red[16][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + c;
+  const float* src = part + (int64_t)blockIdx.y * yoff + i;
+  float* out = blockIdx.y ? out1 : out0;
   float acc = 0.f;
-  if (i < n)
-    for (int b = q; b < nparts; b += 4) acc += part[(int64_t)b * stride + i];
+  if (i < n) {
+    int b = q;
+    for (; b + 7 * 16 < nparts; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 16 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nparts; b += 16) acc += src[(int64_t)b * stride];
+  }
   red[q][c] = acc;
   __syncthreads();
-  if (q == 0 && i < n) out[i] = (accumulate ? out[i] : 0.f) + (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+  if (q == 0 && i < n) {
+    float t = red[0][c];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += red[w][c];
+    out[i] = (accumulate ? out[i] : 0.f) + t;
+  }
 }
 
 // ============================================================================ per-node set attention backward
@@ -708,8 +727,8 @@ static int layernorm_bwd_impl(const float* x, const float* residual, const float
   hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)nblk), dim3(256), (size_t)8 * C * sizeof(float), st, x, residual, dy, R, C,
                      gamma, eps, nvalid, K, du, scratch);
   // scratch rows are [d gamma (C) | d beta (C)] per block: added in block order straight into the two outputs
-  hipLaunchKernelGGL(k_cols_reduce, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)scratch, nblk, (int64_t)2 * C, C, dgamma, accumulate);
-  hipLaunchKernelGGL(k_cols_reduce, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, (const float*)scratch + C, nblk, (int64_t)2 * C, C, dbeta, accumulate);
+  hipLaunchKernelGGL(k_cols_reduce, dim3((unsigned)cdiv(C, 64), 2), dim3(1024), 0, st, (const float*)scratch, nblk, (int64_t)2 * C, C, (int64_t)C,
+                     dgamma, dbeta, accumulate);
   SN_CHECK_LAUNCH("sn_masked_layernorm_bwd_f32");
   return SN_OK;
 }

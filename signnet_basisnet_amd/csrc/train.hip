@@ -432,15 +432,15 @@ __global__ __launch_bounds__(256) void k_tbn_finish(const float* __restrict__ st
     const float* sg = stat + (int64_t)grp * (2 * (int64_t)nblk * C + nblk);
     float n = 0.f, m = 0.f, q = 0.f;
     if (c < C) {
-      for (int b = b0; b < b1; b += 4) {        // four partials in flight (one at a time: a chain of L2 round trips per column)
-        float nb[4], mb[4], qb[4];
+      for (int b = b0; b < b1; b += 8) {        // eight partials in flight (one at a time: a chain of L2 round trips per column)
+        float nb[8], mb[8], qb[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
           if (b + u < b1) { nb[u] = sg[2 * (int64_t)nblk * C + b + u]; mb[u] = sg[(int64_t)(b + u) * C + c]; qb[u] = sg[((int64_t)nblk + b + u) * C + c]; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) chan(n, m, q, nb[u], mb[u], qb[u]);
+        for (int u = 0; u < 8; ++u) chan(n, m, q, nb[u], mb[u], qb[u]);
       }
     }
     ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
@@ -529,6 +529,10 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
 #pragma unroll
   for (int it = 0; it < NTI; ++it) dw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbacc = 0.f;
+  // column sums of gx over my rows (a wave's 16 rows x its column tiles), all rounds
+  f32x4 cs1[(NTI + TW / RT - 1) / (TW / RT)], cs2[(NTI + TW / RT - 1) / (TW / RT)];
+#pragma unroll
+  for (int j = 0; j < (NTI + TW / RT - 1) / (TW / RT); ++j) { cs1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; cs2[j] = cs1[j]; }
   // The raw rows of round r+1 are requested (into registers) right after round r's tiles are published, so the HBM latency runs
   // under the round's 256 MFMAs per wave; a wave loads the column tiles kk = part, part + NP, ... of its 16 rows.
   constexpr int HO = (NTO + NP - 1) / NP, HI = (NTI + NP - 1) / NP;
@@ -675,15 +679,12 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
               if (lr == 0) redd[rt * 16 * NTI + c0 + r] += (double)a3;      // a cancelling scalar sum over all rows and columns: float64
             }
           }
-          if (xmu) {
+          if (xmu) {        // my rows' share of the column sums, in registers over all rounds; across the 16 rows once, after the loop
             const f32x4 mu = lds4(xcol + 2 * CI + c0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float a1 = t16_sum(v[r]), a2 = t16_sum(v[r] * (xv[r] - mu[r]));
-              if (lr == 0) {
-                red[(0 * 4 + rt) * 16 * NTI + c0 + r] += a1;
-                red[(1 * 4 + rt) * 16 * NTI + c0 + r] += a2;
-              }
+              cs1[j][r] += v[r];
+              cs2[j][r] += v[r] * (xv[r] - mu[r]);
             }
           }
         }
@@ -691,6 +692,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     }
     // ---------------------------------------------------------------- phase 3: dW[tile `wave`] += dz^T x_hat over the round's rows
     if (wave < nto && a.dwp) {
+      float xsc[NTI], xsh[NTI];       // x_hat's column constants of my dW lanes, out of the step loop (16 LDS reads per step otherwise)
+#pragma unroll
+      for (int it = 0; it < NTI; ++it) { xsc[it] = xcol[16 * it + lr]; xsh[it] = xcol[CI + 16 * it + lr]; }
 #pragma unroll 1     // (unrolled by 2 the LDS reads of both steps are hoisted and the kernel spills; a hand-made prefetch of the next
                      //  step's operands measured slower)
       for (int q = 0; q < TR / 4; ++q) {
@@ -698,12 +702,34 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
         const float av = dzs[rl * LDO + 16 * wave + lr];
         dbacc += av;
         const float* xr = xsg + rl * LDI + lr;
+        float bv[NTI];
+#pragma unroll
+        for (int it = 0; it < NTI; ++it) bv[it] = (it < nti) ? xr[16 * it] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);      // all of the step's LDS reads in flight, ONE wait (the scheduler paired each read with
+                                                // its two MFMAs: four LDS round trips per step, ~2x the MFMA time)
 #pragma unroll
         for (int it = 0; it < NTI; ++it) {
           if (it < nti) {
-            float bv = xr[16 * it];
-            if (xs) { bv = bv * xcol[16 * it + lr] + xcol[CI + 16 * it + lr]; if (a.xrelu) bv = fmaxf(bv, 0.f); }
-            dw[it] = mfma16(av, bv, dw[it]);
+            float b = bv[it];
+            if (xs) { b = b * xsc[it] + xsh[it]; if (a.xrelu) b = fmaxf(b, 0.f); }
+            dw[it] = mfma16(av, b, dw[it]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (want_dx && xmu) {       // the waves' column sums meet in LDS: slot (row tile, column) has ONE owner
+#pragma unroll
+    for (int j = 0; j < HI; ++j) {
+      const int ot = NP * j + part;
+      if (ot < nti) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a1 = t16_sum(cs1[j][r]), a2 = t16_sum(cs2[j][r]);
+          if (lr == 0) {
+            red[(0 * 4 + rt) * 16 * NTI + 16 * ot + 4 * g + r] = a1;
+            red[(1 * 4 + rt) * 16 * NTI + 16 * ot + 4 * g + r] = a2;
           }
         }
       }
@@ -748,7 +774,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     }
   }
   if (want_dx && xmu) {
-    // the four row tiles' sums -> one partial per workgroup   (the last round's barrier has published them)
+    // the four row tiles' sums -> one partial per workgroup   (published by the barrier above)
     float* S = a.sums + (int64_t)blockIdx.x * 2 * a.d_in;
     for (int i = threadIdx.x; i < 2 * a.d_in; i += 64 * TW) {
       const int w = i / a.d_in, c = i - w * a.d_in;
@@ -812,8 +838,18 @@ __global__ __launch_bounds__(256) void k_tbn_bwd_finish(const float* __restrict_
   for (int grp = 0; grp < G; ++grp) {
     const float* S = sums + (int64_t)grp * nblk * 2 * C;
     float s1 = 0.f, s2 = 0.f;
-    if (c < C)
-      for (int b = b0; b < b1; ++b) { s1 += S[(int64_t)b * 2 * C + c]; s2 += S[(int64_t)b * 2 * C + C + c]; }
+    if (c < C) {
+      for (int b = b0; b < b1; b += 8) {        // eight partials in flight
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v1[u] = 0.f; v2[u] = 0.f;
+          if (b + u < b1) { v1[u] = S[(int64_t)(b + u) * 2 * C + c]; v2[u] = S[(int64_t)(b + u) * 2 * C + C + c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
+      }
+    }
     l1[rl][cl] = s1; l2[rl][cl] = s2;
     __syncthreads();
     for (int step = 8; step >= 1; step >>= 1) {
