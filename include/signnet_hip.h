@@ -284,6 +284,10 @@ int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const int32_t* gr
  * sn_slot_broadcast_f32 / sn_segment_broadcast_f32: adjoints of sn_slot_sum_f32 (valid slots only) / sn_segment_pool_f32.
  * sn_embedding_sum_bwd_f32: dtables[f][v,:] += sum_{r: idx[r,f] = v} g[r,:] (no atomics: per-chunk partial sums in row order, then
  *   the chunks in order — bitwise reproducible; C <= 512; scratch: float[sn_embedding_bwd_scratch_floats(R, nf, table_rows, C)]);
+ * sn_embedding_sum_bwd_layers_f32: the same for L <= 16 gradient planes g[l] ([L][R][C]) that share the index columns — the per-layer
+ *   edge encoders of a GINE stack (GNN.forward, model.py:52-60: every layer embeds the same edge_attr with its own table):
+ *   dtables[l * nf + f][v,:] += sum_{r: idx[r,f] = v} g[l][r,:], one launch pair for all planes;
+ *   scratch: float[sn_embedding_bwd_layers_scratch_floats(R, L, C)].
  *   out-of-range indices contribute nothing and set bit 0 of *status (device int32, may be NULL); table_rows as in the forward.
  * sn_dot_f32: out[0] = sum a[i] b[i] (the GIN / GINE eps gradients).  scratch: float[256].
  * sn_adam_step_f32: one torch.optim.Adam step (no amsgrad; weight_decay added to the gradient) on a flat tensor; the gradient is
@@ -313,6 +317,9 @@ int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, i
 int sn_slot_broadcast_f32(const float* g, int64_t N, int K, int C, const int32_t* nvalid, float* dx, void* stream);
 int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const int32_t* graph_ptr, int mode, float* dx, void* stream);
 int64_t sn_embedding_bwd_scratch_floats(int64_t R, int nf, const int64_t* table_rows, int C);
+int64_t sn_embedding_bwd_layers_scratch_floats(int64_t R, int L, int C);
+int sn_embedding_sum_bwd_layers_f32(const int64_t* idx, int ldi, int nf, int64_t R, int L, float* const* dtables,
+                                    const int64_t* table_rows, int C, const float* g, int32_t* status, float* scratch, void* stream);
 int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables, const int64_t* table_rows,
                              int C, const float* g, int32_t* status, float* scratch, void* stream);
 int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch, void* stream);

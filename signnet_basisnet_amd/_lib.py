@@ -58,6 +58,7 @@ SIGNATURES = {
     "sn_slot_broadcast_f32": [_p, _l, _i, _i, _p, _p, _p],
     "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, C.POINTER(C.c_int64), _i, _p, _p, _p, _p],
+    "sn_embedding_sum_bwd_layers_f32": [_p, _i, _i, _l, _i, _p, C.POINTER(C.c_int64), _i, _p, _p, _p, _p],
     "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
     "sn_pna_aggregate_f32": [_p, _i, _p, _i, _i, _l, _p, _p, _f, _p, _i, _p],
     "sn_edge_attention_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p],
@@ -132,6 +133,8 @@ def lib():
         L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
         L.sn_embedding_bwd_scratch_floats.argtypes = [_l, _i, C.POINTER(C.c_int64), _i]
         L.sn_embedding_bwd_scratch_floats.restype = C.c_int64
+        L.sn_embedding_bwd_layers_scratch_floats.argtypes = [_l, _i, _i]
+        L.sn_embedding_bwd_layers_scratch_floats.restype = C.c_int64
         L.sn_gatedgcn_max_edges.argtypes = [_i]
         L.sn_gatedgcn_max_edges.restype = C.c_int
         L.sn_evd_work_ints.argtypes = [_l]

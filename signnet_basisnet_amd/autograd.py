@@ -355,6 +355,69 @@ def embedding_sum(idx, tables, status=None):
     return _EmbeddingSum.apply(idx, status, *tables)
 
 
+class _EmbeddingSumLayers(Function):
+    """out[l] = sum_f tables[l][f][idx[:, f]] for L encoders over ONE index block (the per-layer edge encoders of GNN.forward,
+    model.py:52-60); the adjoint is one launch pair for all L planes (sn_embedding_sum_bwd_layers_f32)."""
+
+    @staticmethod
+    def forward(ctx, idx, status, L, *tables):
+        if idx.dim() == 1:
+            idx = idx.unsqueeze(1)
+        idx = idx.contiguous()
+        R, nf = idx.shape
+        nt = len(tables) // L
+        if nf > nt:
+            raise ValueError("embedding_sum_layers: more feature columns than embedding tables")
+        Cc = tables[0].shape[1]
+        out = torch.empty(L, R, Cc, dtype=torch.float32, device=idx.device)
+        rows = (C.c_int64 * nf)(*[tables[f].shape[0] for f in range(nf)])
+        for l in range(L):
+            tabs = [ops._f32c(tables[l * nt + f].detach(), "embedding table") for f in range(nf)]
+            if any(t.shape != tables[f].shape for f, t in enumerate(tabs)):
+                raise ValueError("embedding_sum_layers: the layers' tables must have one shape per feature column")
+            arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs])
+            with ops._span("sn_embedding_sum_f32"):
+                check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, rows, Cc, out[l].data_ptr(), ptr(status), stream()),
+                      "sn_embedding_sum_f32")
+        ctx.idx, ctx.L, ctx.nt, ctx.tables = idx, L, nt, tables
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, L, nt, tables = ctx.idx, ctx.L, ctx.nt, ctx.tables
+        g = _c(g)
+        R, nf = idx.shape
+        Cc = g.shape[-1]
+        from .train_stage import direct_grad
+        grads, ptrs = [], []
+        for l in range(L):
+            for f in range(nt):
+                t = tables[l * nt + f]
+                if f >= nf:
+                    grads.append(None)
+                    continue
+                d = direct_grad(t)
+                grads.append(None if d is not None else torch.zeros(t.shape, dtype=torch.float32, device=g.device))
+                ptrs.append((d if d is not None else grads[-1]).data_ptr())
+        arr = (C.c_void_p * (L * nf))(*ptrs)
+        rows = (C.c_int64 * nf)(*[tables[f].shape[0] for f in range(nf)])
+        scratch = torch.empty(int(lib().sn_embedding_bwd_layers_scratch_floats(R, L, Cc)), dtype=torch.float32, device=g.device)
+        with ops._span("sn_embedding_sum_bwd_layers_f32"):
+            check(lib().sn_embedding_sum_bwd_layers_f32(ptr(idx), nf, nf, R, L, arr, rows, Cc, ptr(g), None, ptr(scratch), stream()),
+                  "sn_embedding_sum_bwd_layers_f32")
+        return (None, None, None, *grads)
+
+
+def embedding_sum_layers(idx, layer_tables, status):
+    """[L, R, C]: plane l = sum_f layer_tables[l][f][idx[:, f]].  The block carries a gradient buffer (`_sn_gbuf`) that
+    train_stage.gine_layer(..., layer=l) fills plane by plane (see _GineLayer)."""
+    L = len(layer_tables)
+    flat = [t for tabs in layer_tables for t in tabs]
+    out = _EmbeddingSumLayers.apply(idx, status, L, *flat)
+    out._sn_gbuf = torch.empty_like(out)
+    return out
+
+
 class _SegmentPool(Function):
     @staticmethod
     def forward(ctx, h, plan, mode):

@@ -458,137 +458,151 @@ __global__ __launch_bounds__(256) void k_segment_bcast(const float* __restrict__
     dx[(int64_t)lo * C + i] = g[(int64_t)b * C + c] * w;
   }
 }
-// dT_f[v, :] += sum over the rows r with idx[r,f] == v of g[r, :] — deterministic (no atomics: nn.Embedding's own backward is not).
-//   chunk : a workgroup takes 256 consecutive rows, finds their DISTINCT table rows (a row leads if no earlier row of the chunk has its
-//           id), sorts the chunk's rows by distinct id (stable: row order inside a segment) and sums every segment   -> part[chunk][slot][C],
+// dT_f[v, :] += sum over the rows r with idx[r,f] == v of g[r, :] — deterministic (no atomics: nn.Embedding's own backward is not) —
+// for L gradient planes g[l] at once (the L layers' edge encoders of a GINE stack share their index column: one pair of launches
+// per step instead of one per layer).
+//   chunk : a workgroup takes 64 consecutive rows and one plane: the rows' DISTINCT table rows (a row leads if no earlier row of the
+//           chunk has its id) get a slot each; a thread owns one channel and — privately — that channel's column of an LDS table
+//           [slot][C]: tab[slot[r]][c] += g[r][c] in row order (no sorting, no cross-thread traffic)   -> part[l][chunk][slot][C],
 //           vals[chunk][slot], nvals[chunk]
-//   gather: workgroup v looks its id up in every chunk's list (<= 256 ids per chunk) and adds the matching partial rows in chunk order.
-// Work is proportional to the rows, not to rows x table size (the first version launched a workgroup per (chunk, table row): 3 500
-// workgroups scanning 1 024 indices each for a 500-row table of which ZINC uses 4 to 28 rows: 40 us per table).
+//   gather: workgroup (v, l) looks v up in every chunk's list (<= 64 ids per chunk), and — if it occurs at all — adds the matching
+//           partial rows in chunk order (float4 columns x row lanes, four loads in flight, the lanes added in order).
+// Work is proportional to the rows, not to rows x table size (a 500-row table of which ZINC uses 4 to 28 rows).  The first version
+// (256-row chunks sorted by id, a launch pair per table and layer) cost 26 us per call at 6 372 edges, 7 calls a training step.
 // An index outside [0, V) contributes nothing and raises bit 0 of *status.
-constexpr int EMB_ROWS = 256;
+constexpr int EMB_ROWS = 64;
+struct EmbPtrs { float* p[16]; };
 __global__ __launch_bounds__(256) void k_embedding_bwd_chunk(const int64_t* __restrict__ idx, int ldi, int f, int64_t R, int64_t V, int C,
-                                                             const float* __restrict__ g, float* __restrict__ part,
-                                                             int32_t* __restrict__ vals, int32_t* __restrict__ nvals,
+                                                             const float* __restrict__ g, int64_t g_plane, float* __restrict__ part,
+                                                             int64_t part_plane, int32_t* __restrict__ vals, int32_t* __restrict__ nvals,
                                                              int32_t* __restrict__ status) {
-  __shared__ int32_t ids[EMB_ROWS], lead[EMB_ROWS], slot[EMB_ROWS], sorted[EMB_ROWS], seg0[EMB_ROWS + 1];
-  __shared__ int32_t wc[EMB_ROWS * 4];
-  __shared__ int32_t wlead[4], nlead_s;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS, r = r0 + tid;
-  int64_t id64 = r < R ? idx[r * ldi + f] : -1;
-  const bool bad = r < R && (uint64_t)id64 >= (uint64_t)V;
-  const int id = (r < R && !bad) ? (int)id64 : -1;
-  ids[tid] = id;
+  extern __shared__ float eb_tab[];          // [EMB_ROWS][C]
+  __shared__ int32_t ids[EMB_ROWS], lead[EMB_ROWS], slot[EMB_ROWS];
+  __shared__ int32_t nlead_s;
+  const int tid = threadIdx.x, l = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * EMB_ROWS;
+  const int nr = (int)(R - r0 < EMB_ROWS ? R - r0 : EMB_ROWS);
+  bool bad = false;
+  int id = -1;
+  if (tid < EMB_ROWS) {
+    const int64_t id64 = tid < nr ? idx[(r0 + tid) * ldi + f] : -1;
+    bad = tid < nr && (uint64_t)id64 >= (uint64_t)V;
+    id = (tid < nr && !bad) ? (int)id64 : -1;
+    ids[tid] = id;
+  }
   __syncthreads();
-  bool leader = id >= 0;
-  for (int j = 0; j < tid && leader; ++j) leader = ids[j] != id;
-  const unsigned long long lm = __ballot(leader);
-  if (lane == 0) wlead[w] = __popcll(lm);
+  if (tid < EMB_ROWS) {                      // (wave 0)
+    bool leader = id >= 0;
+    for (int j = 0; j < tid && leader; ++j) leader = ids[j] != id;
+    const unsigned long long lm = __ballot(leader);
+    if (leader) lead[__popcll(lm & ((1ull << tid) - 1ull))] = id;
+    if (tid == 0) nlead_s = __popcll(lm);
+  }
   __syncthreads();
-  int loff = 0, nlead = 0;
+  const int nlead = nlead_s;
+  if (tid < EMB_ROWS) {
+    int my = -1;
+    for (int sidx = 0; sidx < nlead; ++sidx) my = (lead[sidx] == id) ? sidx : my;      // (ids are distinct among the leaders)
+    slot[tid] = id < 0 ? -1 : my;
+  }
+  for (int i = tid; i < nlead * C; i += blockDim.x) eb_tab[i] = 0.f;
+  __syncthreads();
+  const float* gl = g + (int64_t)l * g_plane + r0 * C;
+  float* P = part + (int64_t)l * part_plane + (int64_t)blockIdx.x * EMB_ROWS * C;
+  for (int c = tid; c < C; c += blockDim.x) {          // my channel: nobody else touches column c of the table
+    for (int j0 = 0; j0 < nr; j0 += 16) {
+      float gv[16]; int sl[16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { loff += i < w ? wlead[i] : 0; nlead += wlead[i]; }
-  if (leader) lead[loff + __popcll(lm & ((1ull << lane) - 1ull))] = id;
-  __syncthreads();
-  int my = -1;
-  for (int sidx = 0; sidx < nlead; ++sidx) my = (lead[sidx] == id) ? sidx : my;      // (ids are distinct among the leaders)
-  if (id < 0) my = -1;
-  int rank = 0;
-  for (int sidx = 0; sidx < nlead; ++sidx) {
-    const unsigned long long m = __ballot(my == sidx);
-    if (lane == 0) wc[sidx * 4 + w] = __popcll(m);
-    if (my == sidx) rank = __popcll(m & ((1ull << lane) - 1ull));
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int sidx = 0; sidx < nlead; ++sidx) { seg0[sidx] = acc; acc += wc[sidx * 4] + wc[sidx * 4 + 1] + wc[sidx * 4 + 2] + wc[sidx * 4 + 3]; }
-    seg0[nlead] = acc;
-    nvals[blockIdx.x] = nlead;
-  }
-  __syncthreads();
-  if (my >= 0) {
-    int before = 0;
+      for (int u = 0; u < 16; ++u) {
+        sl[u] = j0 + u < nr ? slot[j0 + u] : -1;
+        gv[u] = sl[u] >= 0 ? gl[(int64_t)(j0 + u) * C + c] : 0.f;
+      }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) before += i < w ? wc[my * 4 + i] : 0;
-    sorted[seg0[my] + before + rank] = tid;
+      for (int u = 0; u < 16; ++u)
+        if (sl[u] >= 0) eb_tab[sl[u] * C + c] += gv[u];
+    }
+    for (int sidx = 0; sidx < nlead; ++sidx) P[(int64_t)sidx * C + c] = eb_tab[sidx * C + c];
   }
-  if (tid < nlead) vals[(int64_t)blockIdx.x * EMB_ROWS + tid] = lead[tid];
-  __syncthreads();
-  // segment sums.  Vector path (C % 4 == 0, C <= 512, 16-byte aligned g): thread = (float4 column cv, row lane rl); a row lane takes
-  // every nrl-th row of a segment (in row order), the nrl partial sums meet in LDS and are added in lane order — a fixed order, and
-  // a chain of seg/nrl loads instead of seg.  Scalar path otherwise.
-  const int C4 = C >> 2;
-  if ((C & 3) == 0 && C4 <= 128 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
-    __shared__ float4 acc4[256];
-    const int nrl = 256 / C4 >= 1 ? 256 / C4 : 1;           // row lanes (C = 128: 8)
-    const int cv = tid % C4, rl = tid / C4;
-    for (int sidx = 0; sidx < nlead; ++sidx) {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rl < nrl) {
-        int i = seg0[sidx] + rl;
-        const int e = seg0[sidx + 1];
-        for (; i + 3 * nrl < e; i += 4 * nrl) {           // four rows in flight per lane
-          const float4 x0 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i]) * C + 4 * cv);
-          const float4 x1 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i + nrl]) * C + 4 * cv);
-          const float4 x2 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i + 2 * nrl]) * C + 4 * cv);
-          const float4 x3 = *reinterpret_cast<const float4*>(g + (r0 + sorted[i + 3 * nrl]) * C + 4 * cv);
-          a.x = (((a.x + x0.x) + x1.x) + x2.x) + x3.x; a.y = (((a.y + x0.y) + x1.y) + x2.y) + x3.y;
-          a.z = (((a.z + x0.z) + x1.z) + x2.z) + x3.z; a.w = (((a.w + x0.w) + x1.w) + x2.w) + x3.w;
-        }
-        for (; i < e; i += nrl) {
-          const float4 x = *reinterpret_cast<const float4*>(g + (r0 + sorted[i]) * C + 4 * cv);
-          a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
-        }
-      }
-      acc4[tid] = a;
-      __syncthreads();
-      if (tid < C4) {
-        float4 t = acc4[tid];
-        for (int q = 1; q < nrl; ++q) { const float4 u = acc4[q * C4 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-        *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.x * EMB_ROWS + sidx) * C + 4 * tid) = t;
-      }
-      __syncthreads();
-    }
-  } else {
-    for (int c0 = tid; c0 < C; c0 += 256) {
-      for (int sidx = 0; sidx < nlead; ++sidx) {
-        float a0 = 0.f;
-        for (int i = seg0[sidx]; i < seg0[sidx + 1]; ++i) a0 += g[(r0 + sorted[i]) * C + c0];
-        part[((int64_t)blockIdx.x * EMB_ROWS + sidx) * C + c0] = a0;
-      }
-    }
+  if (l == 0) {
+    if (tid < nlead) vals[(int64_t)blockIdx.x * EMB_ROWS + tid] = lead[tid];
+    if (tid == 0) nvals[blockIdx.x] = nlead;
   }
   if (status != nullptr && __syncthreads_or(bad) && tid == 0) atomicOr(status, 1);
 }
-__global__ __launch_bounds__(256) void k_embedding_bwd_gather(const float* __restrict__ part, const int32_t* __restrict__ vals,
-                                                              const int32_t* __restrict__ nvals, int nchunks, int C, float* __restrict__ dT) {
-  __shared__ int32_t hit[1024];
-  __shared__ int32_t any;
-  const int v = blockIdx.x;
-  if (threadIdx.x == 0) any = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < nchunks; c0 += 1024) {          // (1024 chunks = 262 144 rows per pass)
+
+__global__ __launch_bounds__(256) void k_embedding_bwd_gather(const float* __restrict__ part, int64_t part_plane,
+                                                              const int32_t* __restrict__ vals, const int32_t* __restrict__ nvals,
+                                                              int nchunks, int C, EmbPtrs dts) {
+  __shared__ int32_t hit[1024], list[1024];
+  __shared__ int32_t nlist_s;
+  __shared__ float4 acc4[256];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  float* dT = dts.p[blockIdx.y];
+  const float* pl = part + (int64_t)blockIdx.y * part_plane;
+  for (int c0 = 0; c0 < nchunks; c0 += 1024) {          // (1024 chunks = 65 536 rows per pass)
     const int nc = nchunks - c0 < 1024 ? nchunks - c0 : 1024;
-    for (int j = threadIdx.x; j < nc; j += 256) {
+    for (int j = tid; j < nc; j += 256) {
       const int n = nvals[c0 + j];
+      const int32_t* vl = vals + (int64_t)(c0 + j) * EMB_ROWS;
       int sidx = -1;
-      for (int q = 0; q < n; ++q) sidx = (vals[(int64_t)(c0 + j) * EMB_ROWS + q] == v) ? q : sidx;
+      for (int q0 = 0; q0 < n; q0 += 8) {                // eight ids in flight
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = q0 + u < n ? vl[q0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sidx = (t[u] == v) ? q0 + u : sidx;
+      }
       hit[j] = sidx;
-      if (sidx >= 0) any = 1;
     }
     __syncthreads();
-    if (any) {
-      for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f;
-        for (int j = 0; j < nc; ++j)
-          if (hit[j] >= 0) a += part[((int64_t)(c0 + j) * EMB_ROWS + hit[j]) * C + c];
-        dT[(int64_t)v * C + c] += a;
+    if (tid < 64) {                                      // the chunks that hold v, in chunk order (wave 0)
+      int cnt = 0;
+      for (int base = 0; base < nc; base += 64) {
+        const int h = base + tid < nc ? hit[base + tid] : -1;
+        const unsigned long long m = __ballot(h >= 0);
+        if (h >= 0) list[cnt + __popcll(m & ((1ull << tid) - 1ull))] = (c0 + base + tid) * EMB_ROWS + h;
+        cnt += __popcll(m);
+      }
+      if (tid == 0) nlist_s = cnt;
+    }
+    __syncthreads();
+    const int nl = nlist_s;
+    if (nl > 0) {
+      const int C4 = C >> 2;
+      if ((C & 3) == 0 && C4 <= 256) {
+        const int nql = 256 / C4, cv = tid % C4, ql = tid / C4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ql < nql) {
+          int e = ql;
+          for (; e + 3 * nql < nl; e += 4 * nql) {
+            const float4 x0 = *reinterpret_cast<const float4*>(pl + (int64_t)list[e] * C + 4 * cv);
+            const float4 x1 = *reinterpret_cast<const float4*>(pl + (int64_t)list[e + nql] * C + 4 * cv);
+            const float4 x2 = *reinterpret_cast<const float4*>(pl + (int64_t)list[e + 2 * nql] * C + 4 * cv);
+            const float4 x3 = *reinterpret_cast<const float4*>(pl + (int64_t)list[e + 3 * nql] * C + 4 * cv);
+            a.x = (((a.x + x0.x) + x1.x) + x2.x) + x3.x; a.y = (((a.y + x0.y) + x1.y) + x2.y) + x3.y;
+            a.z = (((a.z + x0.z) + x1.z) + x2.z) + x3.z; a.w = (((a.w + x0.w) + x1.w) + x2.w) + x3.w;
+          }
+          for (; e < nl; e += nql) {
+            const float4 x = *reinterpret_cast<const float4*>(pl + (int64_t)list[e] * C + 4 * cv);
+            a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+          }
+        }
+        acc4[tid] = a;
+        __syncthreads();
+        if (tid < C4) {
+          float4 t = acc4[tid];
+          for (int q = 1; q < nql; ++q) { const float4 u = acc4[q * C4 + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+          float* o = dT + (int64_t)v * C + 4 * tid;
+          o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w;
+        }
+      } else {
+        for (int c = tid; c < C; c += 256) {
+          float a = 0.f;
+          for (int e = 0; e < nl; ++e) a += pl[(int64_t)list[e] * C + c];
+          dT[(int64_t)v * C + c] += a;
+        }
       }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) any = 0;
     __syncthreads();
   }
 }
@@ -807,10 +821,49 @@ extern "C" int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const 
   return SN_OK;
 }
 
+extern "C" int64_t sn_embedding_bwd_layers_scratch_floats(int64_t R, int L, int C) {
+  const int64_t nchunks = cdiv(R > 0 ? R : 1, EMB_ROWS);
+  return (int64_t)(L > 0 ? L : 1) * nchunks * EMB_ROWS * C + nchunks * EMB_ROWS + nchunks + 16;      // partial rows per plane | ids per chunk | counts
+}
 extern "C" int64_t sn_embedding_bwd_scratch_floats(int64_t R, int nf, const int64_t* table_rows, int C) {
   (void)nf; (void)table_rows;
-  const int64_t nchunks = cdiv(R > 0 ? R : 1, EMB_ROWS);
-  return nchunks * EMB_ROWS * (int64_t)C + nchunks * EMB_ROWS + nchunks + 16;      // partial rows | ids per chunk | counts
+  return sn_embedding_bwd_layers_scratch_floats(R, 1, C);
+}
+
+extern "C" int sn_embedding_sum_bwd_layers_f32(const int64_t* idx, int ldi, int nf, int64_t R, int L, float* const* dtables,
+                                               const int64_t* table_rows, int C, const float* g, int32_t* status, float* scratch,
+                                               void* stream) {
+  SN_REQUIRE(idx && dtables && table_rows && g && scratch && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && C <= 512 && R >= 0 && L >= 1 && L <= 16,
+             "sn_embedding_sum_bwd_layers_f32: bad arguments (C <= 512, 1 <= L <= 16)");
+  if (R == 0) return SN_OK;
+  const int nchunks = (int)cdiv(R, EMB_ROWS);
+  const int64_t plane = (int64_t)nchunks * EMB_ROWS * C;
+  float* part = scratch;
+  int32_t* vals = reinterpret_cast<int32_t*>(scratch + (int64_t)L * plane);
+  int32_t* nvals = vals + (int64_t)nchunks * EMB_ROWS;
+  const size_t lds = (size_t)EMB_ROWS * C * sizeof(float);
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_embedding_bwd_chunk), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048) != hipSuccess)
+        return fail(SN_ERR_LAUNCH, "sn_embedding_sum_bwd_layers_f32: cannot raise the dynamic LDS limit");
+      raised = true;
+    }
+  }
+  const unsigned bs = (unsigned)(C >= 256 ? 256 : ((C + 63) / 64) * 64);
+  for (int f = 0; f < nf; ++f) {
+    EmbPtrs dts;
+    for (int l = 0; l < 16; ++l) dts.p[l] = l < L ? dtables[(int64_t)l * nf + f] : nullptr;
+    for (int l = 0; l < L; ++l) SN_REQUIRE(dts.p[l], "sn_embedding_sum_bwd_layers_f32: table %d of plane %d missing", f, l);
+    SN_REQUIRE(table_rows[f] > 0 && table_rows[f] <= 65535, "sn_embedding_sum_bwd_layers_f32: table %d empty or > 65535 rows", f);
+    const int64_t V = table_rows[f];
+    hipLaunchKernelGGL(k_embedding_bwd_chunk, dim3((unsigned)nchunks, (unsigned)L), dim3(bs), lds, (hipStream_t)stream, idx, ldi, f, R, V, C, g,
+                       R * (int64_t)C, part, plane, vals, nvals, status);
+    hipLaunchKernelGGL(k_embedding_bwd_gather, dim3((unsigned)V, (unsigned)L), dim3(256), 0, (hipStream_t)stream, (const float*)part, plane,
+                       (const int32_t*)vals, (const int32_t*)nvals, nchunks, C, dts);
+  }
+  SN_CHECK_LAUNCH("sn_embedding_sum_bwd_layers_f32");
+  return SN_OK;
 }
 
 extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int64_t R, float* const* dtables,
@@ -818,21 +871,9 @@ extern "C" int sn_embedding_sum_bwd_f32(const int64_t* idx, int ldi, int nf, int
                                         void* stream) {
   SN_REQUIRE(idx && dtables && table_rows && g && scratch && nf > 0 && nf <= 10 && ldi >= nf && C > 0 && C <= 512 && R >= 0,
              "sn_embedding_sum_bwd_f32: bad arguments (C <= 512)");
-  if (R == 0) return SN_OK;
-  const int nchunks = (int)cdiv(R, EMB_ROWS);
-  float* part = scratch;
-  int32_t* vals = reinterpret_cast<int32_t*>(scratch + (int64_t)nchunks * EMB_ROWS * C);
-  int32_t* nvals = vals + (int64_t)nchunks * EMB_ROWS;
-  for (int f = 0; f < nf; ++f) {
+  for (int f = 0; f < nf; ++f)
     SN_REQUIRE(dtables[f] && table_rows[f] > 0 && table_rows[f] <= 65535, "sn_embedding_sum_bwd_f32: table %d missing, empty or > 65535 rows", f);
-    const int64_t V = table_rows[f];
-    hipLaunchKernelGGL(k_embedding_bwd_chunk, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, idx, ldi, f, R, V, C, g, part, vals,
-                       nvals, status);
-    hipLaunchKernelGGL(k_embedding_bwd_gather, dim3((unsigned)V), dim3(256), 0, (hipStream_t)stream, (const float*)part,
-                       (const int32_t*)vals, (const int32_t*)nvals, nchunks, C, dtables[f]);
-  }
-  SN_CHECK_LAUNCH("sn_embedding_sum_bwd_f32");
-  return SN_OK;
+  return sn_embedding_sum_bwd_layers_f32(idx, ldi, nf, R, 1, dtables, table_rows, C, g, status, scratch, stream);
 }
 
 extern "C" int sn_dot_f32(const float* a, const float* b, int64_t n, float* out, float* scratch /* [256] */, void* stream) {

@@ -638,12 +638,21 @@ class SignNetGNN(nn.Module):
         else:
             h = lin_bn(xin.contiguous(), g.input_encoder.layers[0], g.input_encoder.norms[0])
         h = AG.linear(torch.cat([h, pe], dim=-1), g.linear.weight, g.linear.bias)
-        for enc, conv, norm in zip(g.edge_encoders, g.convs, g.norms):
+        staged = [stage and isinstance(conv.nn.norms[0], nn.BatchNorm1d) and isinstance(norm, nn.BatchNorm1d)
+                  for conv, norm in zip(g.convs, g.norms)]
+        # every layer embeds the same edge_attr with its own tables: one [L, E, C] block, one adjoint launch pair for all layers
+        e_all = None
+        if all(staged) and all(isinstance(enc, DiscreteEncoder) for enc in g.edge_encoders) and 1 < len(g.edge_encoders) <= 16:
+            e_all = AG.embedding_sum_layers(data.edge_attr, [[t.weight for t in enc.embeddings] for enc in g.edge_encoders], plan.status[5:6])
+        for li, (enc, conv, norm) in enumerate(zip(g.edge_encoders, g.convs, g.norms)):
+            if e_all is not None:
+                h = T.gine_layer(h, e_all, conv.layer.eps, conv.nn.layers[0], conv.nn.norms[0], conv.nn.layers[1], norm, plan, rplan, layer=li)
+                continue
             if isinstance(enc, DiscreteEncoder):
                 e = AG.embedding_sum(data.edge_attr, [t.weight for t in enc.embeddings], plan.status[5:6])
             else:
                 e = lin_bn(data.edge_attr.contiguous(), enc.layers[0], enc.norms[0])
-            if stage and isinstance(conv.nn.norms[0], nn.BatchNorm1d) and isinstance(norm, nn.BatchNorm1d):
+            if staged[li]:
                 h = T.gine_layer(h, e, conv.layer.eps, conv.nn.layers[0], conv.nn.norms[0], conv.nn.layers[1], norm, plan, rplan)
             else:
                 u = AG.gine_aggregate(h, e, conv.layer.eps, plan, rplan)

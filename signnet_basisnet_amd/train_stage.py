@@ -313,39 +313,50 @@ def sign_sum(x2, nvalid, K):
 
 
 class _GineLayer(Function):
-    """h, e -> u = (1+eps) h + sum relu(h_j + e_ji) -> mlp2_bn(u) + h: one layer of GNN.forward (model.py:52-60, pyg_gnn_wrapper.py:19-28)."""
+    """h, e -> u = (1+eps) h + sum relu(h_j + e_ji) -> mlp2_bn(u) + h: one layer of GNN.forward (model.py:52-60, pyg_gnn_wrapper.py:19-28).
+    lidx >= 0: `e` is the [L, E, C] block of autograd.embedding_sum_layers and this layer reads plane lidx; its adjoint writes the
+    plane's gradient into the block's shared buffer (e._sn_gbuf) and only layer 0 — the last to run backward — hands the buffer to
+    autograd, so the L edge encoders' table gradients are ONE launch pair (no slice / zero-fill / add per layer)."""
 
     @staticmethod
-    def forward(ctx, h, e, eps, W1, b1, g1, be1, W2, b2, g2, be2, lin1, bn1, lin2, bn2, plan, rplan):
-        h, e = _c(h), _c(e)
-        u = ops.gine_aggregate(h, e, plan, eps.detach())
+    def forward(ctx, h, e, eps, W1, b1, g1, be1, W2, b2, g2, be2, lin1, bn1, lin2, bn2, plan, rplan, lidx, gbuf):
+        h = _c(h)
+        ev = _c(e) if lidx < 0 else e[lidx]
+        u = ops.gine_aggregate(h, ev, plan, eps.detach())
         y, z1, z2, st1, st2 = _mlp2_forward(u, h.shape[0], 1, lin1, bn1, lin2, bn2, None, 0, True, h)
-        ctx.save_for_backward(h, e, u, z1, z2, eps)
+        ctx.save_for_backward(h, ev, u, z1, z2, eps)
         ctx.eps_param = eps
-        ctx.meta = (st1, st2, lin1, bn1, lin2, bn2, rplan)
+        ctx.meta = (st1, st2, lin1, bn1, lin2, bn2, rplan, lidx, gbuf)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         h, e, u, z1, z2, eps = ctx.saved_tensors
-        st1, st2, lin1, bn1, lin2, bn2, rplan = ctx.meta
+        st1, st2, lin1, bn1, lin2, bn2, rplan, lidx, gbuf = ctx.meta
         dy = _c(dy)
         N, d = h.shape
         want_eps = ctx.needs_input_grad[2]
         grads = _mlp2_backward(dy, u, z1, z2, st1, st2, N, 1, lin1, bn1, lin2, bn2, None, 0, True, True, dot_x=h if want_eps else None)
         du = grads[0]
         deps = eps_grad(ctx.eps_param) if want_eps else None
-        dh, dee = torch.empty_like(h), torch.empty_like(e)
+        dh = torch.empty_like(h)
+        dee = torch.empty_like(e) if lidx < 0 else gbuf[lidx]
         with ops._span("sn_gine_aggregate_bwd_add_f32"):
             check(lib().sn_gine_aggregate_bwd_add_f32(ptr(h), ptr(e), ptr(du), ptr(dy), N, d, ptr(rplan.rowptr), ptr(rplan.col),
                                                       ptr(rplan.eperm), ptr(eps.detach()), ptr(dh), ptr(dee), stream()),
                   "sn_gine_aggregate_bwd_add_f32")
-        return (dh, dee, deps) + grads[1:] + (None,) * 6
+        if lidx >= 0:
+            dee = gbuf if lidx == 0 else None
+        return (dh, dee, deps) + grads[1:] + (None,) * 8
 
 
-def gine_layer(h, e, conv_eps, lin1, bn1, lin2, bn2, plan, rplan):
+def gine_layer(h, e, conv_eps, lin1, bn1, lin2, bn2, plan, rplan, layer=-1):
+    """layer >= 0: e is the [L, E, C] block of autograd.embedding_sum_layers (see _GineLayer)."""
+    gbuf = getattr(e, "_sn_gbuf", None) if layer >= 0 else None
+    if layer >= 0 and gbuf is None:
+        raise ValueError("gine_layer: a layer index needs the block of embedding_sum_layers")
     return _GineLayer.apply(h, e, conv_eps, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias, bn2.weight, bn2.bias,
-                            lin1, bn1, lin2, bn2, plan, rplan)
+                            lin1, bn1, lin2, bn2, plan, rplan, layer, gbuf)
 
 
 def mlp2_bn(x, lin1, bn1, lin2, bn2, nvalid=None, K=0, G=1, residual=None, relu_out=True):

@@ -39,7 +39,8 @@ def test_python_binding_covers_the_header(lib):
     bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_split_packed_bytes", "sn_phi_bins_bound",
                                      "sn_ign_contract_scratch_floats", "sn_evd_work_ints",
                                      "sn_linear_wgrad_scratch_floats", "sn_layernorm_bwd_scratch_floats",
-                                     "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_gatedgcn_max_edges",
+                                     "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_embedding_bwd_layers_scratch_floats",
+                                     "sn_gatedgcn_max_edges",
                                      "sn_train_linear_bwd_part_floats", "sn_train_scalar_mlp_work_doubles"}
     assert set(declared_symbols()) == bound
 
@@ -81,13 +82,15 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_act_bwd_f32": (None, None, 2, 4, None, 1, 0.01, None, None),
         "sn_pointwise_f32": (None, 4, 2, 4, None, None, None, 0, 0.0, None, 4, None, 4, None),
         "sn_embedding_sum_bwd_f32": (None, 1, 1, 4, None, i64, 8, None, None, None, None),
+        "sn_embedding_sum_bwd_layers_f32": (None, 1, 1, 4, 2, None, i64, 8, None, None, None, None),
     }
     for name, args in cases.items():
         rc = getattr(lib, name)(*args)
         assert rc == -1 and name.encode() in lib.sn_last_error(), (name, rc, lib.sn_last_error())
     assert lib.sn_gatedgcn_max_edges(68) == 176 and lib.sn_gatedgcn_max_edges(128) == 0
-    # ceil(1000/256) = 4 chunks: 256 partial rows x 8 channels + 256 ids + 1 count each, + 16
-    assert lib.sn_embedding_bwd_scratch_floats(1000, 1, i64, 8) == 4 * 256 * 8 + 4 * 256 + 4 + 16
+    # ceil(1000/64) = 16 chunks: 64 partial rows x 8 channels (per gradient plane) + 64 ids + 1 count each, + 16
+    assert lib.sn_embedding_bwd_scratch_floats(1000, 1, i64, 8) == 16 * 64 * 8 + 16 * 64 + 16 + 16
+    assert lib.sn_embedding_bwd_layers_scratch_floats(1000, 6, 8) == 6 * 16 * 64 * 8 + 16 * 64 + 16 + 16
     assert lib.sn_phi_bins_bound(128, -8) == 128 * 8 + 1                              # full-slot mode: |kmax| bins per column
 
 

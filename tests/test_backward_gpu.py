@@ -256,6 +256,28 @@ def test_embedding_and_pool_backward():
     (AG.embedding_sum(bigv, [t]) * upv).sum().backward()
     refv = torch.zeros(5000, 12, dtype=torch.float64).index_add_(0, bigv[:, 0].cpu(), upv.cpu().double())
     close(t.grad, refv, "embedding table gradient, vocabulary 5000", 1e-5)
+    # L encoders over one index block (the per-layer edge encoders of the GINE stack): one adjoint launch pair for all planes
+    L, Re = 3, 700
+    idx2 = torch.stack([torch.randint(0, 4, (Re,), generator=g), torch.randint(0, 9, (Re,), generator=g)], 1)
+    tabs = [[torch.randn(500, 128, generator=g), torch.randn(40, 128, generator=g), torch.randn(6, 128, generator=g)] for _ in range(L)]
+    ups = torch.randn(L, Re, 128, generator=g)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    runs = []
+    for _ in range(2):
+        leaves = [[leaf(t, DEV) for t in ts] for ts in tabs]
+        blk = AG.embedding_sum_layers(idx2.to(DEV), leaves, status)
+        assert blk.shape == (L, Re, 128) and hasattr(blk, "_sn_gbuf")
+        for l in range(L):
+            close(blk[l], tabs[l][0][idx2[:, 0]] + tabs[l][1][idx2[:, 1]], f"embedding_sum_layers plane {l}", 1e-6)
+        (blk * ups.to(DEV)).sum().backward()
+        runs.append([[t.grad for t in ts] for ts in leaves])
+    assert int(status.item()) == 0
+    for l in range(L):
+        assert runs[0][l][2] is None                       # a table without a feature column
+        for f in range(2):
+            ref = torch.zeros(tabs[l][f].shape, dtype=torch.float64).index_add_(0, idx2[:, f], ups[l].double())
+            close(runs[0][l][f], ref, f"embedding_sum_layers table gradient {l}/{f}", 1e-5)
+            assert torch.equal(runs[0][l][f], runs[1][l][f])
     sizes = [5, 1, 17, 30, 9]
     batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     plan = ops.build_plan(batch.to(DEV), torch.zeros(2, 0, dtype=torch.int64, device=DEV), len(sizes), 0)
