@@ -561,6 +561,8 @@ class SignNetGNN(nn.Module):
                 y = AG.linear(x, lin.weight, lin.bias, nvalid, K_, relu=relu)
                 return y if residual is None else AG.masked_add(y, residual, nvalid, K_)
             bn = norm.bn if isinstance(norm, MaskedBN) else norm
+            if stage and isinstance(bn, nn.BatchNorm1d) and T.supported(lin.weight.shape[1], lin.weight.shape[0]):
+                return T.lin_bn(x, lin, bn, nvalid, K_, relu=relu, residual=residual)
             return AG.linear_bn_act(x, lin.weight, lin.bias, bn, nvalid, K_, relu=relu, residual=residual)
 
         from . import train_stage as T

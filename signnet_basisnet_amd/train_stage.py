@@ -252,6 +252,39 @@ class _Mlp2Bn(Function):
         return grads + (dy if has_res else None, None, None, None, None, None, None, None, None)
 
 
+class _LinBn(Function):
+    """[relu](bn(lin(x))) [+ residual]: one Linear -> train-mode BatchNorm link (rho's output projection, the read-out's first layer)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gam, bet, residual, lin, bn, nvalid, K, relu):
+        x = _c(x)
+        R = x.shape[0]
+        res = None if residual is None else _c(residual)
+        z, st = linear_fwd(x, R, 1, W, b, nvalid, K, bn=bn)
+        y = bn_apply(z, R, 1, nvalid, K, st, relu, res)
+        ctx.save_for_backward(x, z)
+        ctx.meta = (R, nvalid, K, relu, st, residual is not None, lin, bn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z = ctx.saved_tensors
+        R, nvalid, K, relu, st, has_res, lin, bn = ctx.meta
+        dy = _c(dy)
+        sums, nb = bn_bwd_sums(dy, z, R, 1, nvalid, K, st, relu)
+        coef, dg, dbe = bn_bwd_finish(sums, nb, st, bn.weight, direct_grad(bn.weight), direct_grad(bn.bias))
+        dx, _, _, dW, db = linear_bwd(dy, R, 1, lin.weight, nvalid, K, x, zo=z, coef=coef, mask=(st.scale, st.shift) if relu else None,
+                                      want_dx=ctx.needs_input_grad[0], want_db=lin.bias is not None,
+                                      dW_acc=direct_grad(lin.weight), db_acc=direct_grad(lin.bias))
+        if bn.weight is None:
+            dg = dbe = None
+        return dx, dW, db, dg, dbe, (dy if has_res else None), None, None, None, None, None
+
+
+def lin_bn(x, lin, bn, nvalid=None, K=0, relu=True, residual=None):
+    return _LinBn.apply(x, lin.weight, lin.bias, bn.weight, bn.bias, residual, lin, bn, nvalid, K, relu)
+
+
 class _GinLayer(Function):
     """x -> a = (1+eps) x + sum_nbr x -> mlp2_bn(a) + x: one GNN3d layer (sign_net.py:36-43) for G stacked sign passes.  The adjoint of
     the aggregation takes the residual's gradient in the same pass, and the eps gradient comes out of the first Linear's backward."""
