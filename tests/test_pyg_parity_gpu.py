@@ -416,3 +416,40 @@ def test_stream_pipeline_returns_the_same_outputs_in_order():
     assert len(outs) == len(ref)
     for a, b in zip(outs, ref):
         assert torch.equal(a, b)
+
+
+def test_overlap_front_mode_is_bit_identical_and_stream_ordered():
+    """SignNetGNN.overlap_front: plan + phi of a forward on the module's side stream, rho + GINE on the caller's stream.  Outputs of a
+    loop over different resident batches equal the sequential forwards bit for bit, consumed on the caller's stream without any extra
+    synchronisation (each output is read by a kernel queued right behind the forward), with batches dropped as soon as possible;
+    strict mode and batches whose inputs were just produced on the current stream (overlap_inputs_ready = False) stay correct."""
+    from signnet_basisnet_amd import pyg, synth
+    torch.manual_seed(0)
+    model = pyg.SignNetGNN(None, None, 128, 1, 4, 6, variant="gine", max_k=16).cuda().eval()
+    hosts = [synth.make_batch(128, seed=70 + i, n_lo=9, n_hi=37) for i in range(6)]
+    with torch.no_grad():
+        ref = [model(synth.batch_to(h, "cuda:0")).clone() for h in hosts]
+        model.strict = False
+        model.overlap_front = True
+        acc = []
+        for rep in range(5):
+            for i, h in enumerate(hosts):
+                b = synth.batch_to(h, "cuda:0")
+                torch.cuda.synchronize()                 # the batch is resident (the mode's precondition)
+                y = model(b)
+                acc.append((i, y * 1.0))                 # consumed on the caller's stream, no sync; `b` and `y` dropped right away
+                del b, y
+        model.check_last()
+        torch.cuda.synchronize()
+        for i, y in acc:
+            assert torch.equal(y, ref[i])
+        assert model._side_stream is not None
+        # inputs still in flight on the caller's stream: the side stream waits for it
+        model.overlap_inputs_ready = False
+        for i, h in enumerate(hosts[:3]):
+            b = synth.batch_to(h, "cuda:0")
+            b.eigen_vectors = b.eigen_vectors * 1.0      # produced by a kernel on the current stream, not yet complete
+            assert torch.equal(model(b), ref[i])
+        model.check_last()
+        model.strict = True                              # the default mode ignores the flag (one stream, host wait per forward)
+        assert torch.equal(model(synth.batch_to(hosts[0], "cuda:0")), ref[0])
