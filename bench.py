@@ -777,10 +777,11 @@ def main():
             model.check_last()               # every forward's status flags read and clean before the clock stops
         sync_all()
         dt_seq = time.perf_counter() - t0
-        # (2) `value`: the same loop, same call site, with the module's overlap mode (pyg.SignNetGNN.overlap_front): a forward's front
-        #     (batch plan + phi) is queued on the module's side stream, its back (rho + GINE) on the caller's stream behind an event,
-        #     so step i's back and step i+1's front share the GPU.  Outputs are bit-identical and ordered on the caller's stream;
-        #     the batch is resident (the mode's precondition).  No kernel events in this pass (concurrent kernels stretch each other).
+        # (2) `value`: the same loop, same call site, with the module's overlap mode (pyg.SignNetGNN.overlap_front): a forward is a
+        #     three-stage pipeline — batch plan + phi on side stream A, rho on side stream B, the GINE stage on the caller's stream,
+        #     chained by events — so the stages of consecutive steps share the GPU.  Outputs are bit-identical and ordered on the
+        #     caller's stream; the batch is resident (the mode's precondition).  No kernel events in this pass (concurrent kernels
+        #     stretch each other).
         overlap = bool(model.max_k) and not args.no_overlap
         dt = dt_seq
         if overlap:
@@ -865,8 +866,8 @@ def main():
                        "nodes": int(fl["N"]), "valid_rows": int(fl["M"]), "parallelism": f"graph-sharded dp{world}, no collective",
                        "gflop_per_step": fl["total"] / 1e9,
                        "module_mode": "strict=False (no host wait per forward; every forward's device flags checked inside the timed region)"
-                                      + ("; overlap_front=True (a forward's plan + phi on the module's side stream, rho + GINE on the caller's "
-                                         "stream behind an event: consecutive forwards of the one call site overlap; bit-identical outputs)"
+                                      + ("; overlap_front=True (a forward = plan + phi on side stream A -> rho on side stream B -> GINE on the caller's "
+                                         "stream, chained by events: consecutive forwards of the one call site overlap; bit-identical outputs)"
                                          if overlap else "")},
             "sequential": {"value": total_graphs / dt_seq, "unit": "graphs/s", "ms_per_step": 1e3 * dt_seq / args.steps,
                            "note": "overlap_front=False: a forward's kernels one after the other on one stream (rounds 1-2's `value`); "

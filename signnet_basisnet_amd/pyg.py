@@ -312,7 +312,7 @@ class SignNetGNN(nn.Module):
         #                 module deleted with an unreported error warns).
         self.strict = True
         # overlap_front: see _forward_overlapped (serving loops over resident batches; needs strict = False and max_k)
-        self.overlap_front, self.overlap_inputs_ready, self._side_stream = False, True, None
+        self.overlap_front, self.overlap_inputs_ready, self._side_streams = False, True, None
         # train-mode dropout of the attention probabilities (ScaledDotProductAttention's default attn_dropout=0.1,
         # transformer_module.py:46-55 — the only dropout the reference leaves active); 0.0 switches it off
         self.attn_dropout = 0.1
@@ -681,37 +681,50 @@ class SignNetGNN(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _forward_overlapped(self, data, P, B):
-        """The fused eval forward with its front (batch plan, phi) on a side stream and its back (rho, GINE stage) on the caller's
-        stream behind an event: the output is ordered on the caller's stream like any other op's, and the NEXT call's front — queued
-        while this call's back is still running (the GINE stage is one workgroup per graph: half the chip at 128 graphs; rho's
-        attention phases leave the matrix pipe idle) — shares the GPU with it.  Measured on the headline batch: 0.28 -> 0.23 ms per
-        forward (front = plan + phi + rho, back = GINE only: 0.25).  Bit-identical outputs.
-        Opt-in (`overlap_front = True`, async status mode, max_k set): the side stream does not wait for the caller's stream, so the
-        batch's tensors must be complete on the device when forward is called (the resident batches of a serving loop; NOT a batch
-        whose host-to-device copy was just queued on the current stream — `overlap_inputs_ready = False` covers that: correct, the
-        side stream then waits for the caller's stream and nothing overlaps)."""
+        """The fused eval forward as a three-stage pipeline over the module's two side streams and the caller's stream:
+            side A: batch plan + phi      -> event ->      side B: rho      -> event ->      caller's stream: GINE stage.
+        The output is ordered on the caller's stream like any other op's; the NEXT calls' earlier stages — queued while this call's
+        later ones are still running — share the GPU with them (the GINE stage is one workgroup per graph: half the chip at 128
+        graphs; rho's attention phases and phi's gathers leave the matrix pipe idle).  Measured on the headline batch, ms per forward:
+        0.27 on one stream, 0.25 with only the GINE stage behind an event, 0.23 with rho + GINE behind it, 0.197 with the three stages.
+        Bit-identical outputs.
+        Opt-in (`overlap_front = True`, async status mode, max_k set): side A does not wait for the caller's stream, so the batch's
+        tensors must be complete on the device when forward is called (the resident batches of a serving loop; NOT a batch whose
+        host-to-device copy was just queued on the current stream — `overlap_inputs_ready = False` covers that: correct, side A then
+        waits for the caller's stream and consecutive forwards no longer overlap)."""
         K, d = int(self.max_k), self.cfg["n_hid"]
         dev = data.batch.device
         cur = torch.cuda.current_stream(dev)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=dev)
-        side = self._side_stream
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        side_a, side_b = self._side_streams
         if not self.overlap_inputs_ready:
-            side.wait_stream(cur)
+            side_a.wait_stream(cur)
         want_vals = "eig" in P or "eig2" in P
-        with torch.cuda.stream(side), _lib_mod.stream_scope():
+        with torch.cuda.stream(side_a), _lib_mod.stream_scope():
             plan = ops.build_plan(data.batch, data.edge_index, B, K, bins=True)
             x = P["phi_fused"].run(plan, data.eigen_vectors, K, zero_invalid=False).view(plan.N * K, d)
-            ev = torch.cuda.Event()
-            ev.record(side)
+            ev_a = torch.cuda.Event()
+            ev_a.record(side_a)
+        side_b.wait_event(ev_a)
+        with torch.cuda.stream(side_b), _lib_mod.stream_scope():
+            s = P["rho_fused"].run(plan, x, data.eigen_values if want_vals else None, K)
+            ev_b = torch.cuda.Event()
+            ev_b.record(side_b)
+        cur.wait_event(ev_b)
+        # allocator bookkeeping: a tensor is recorded on every stream that reads it besides the one it was allocated on, so that
+        # dropping it (the caller its batch, this function its temporaries) never hands the memory out while a stage still reads it
         for t in (data.batch, data.edge_index, data.eigen_vectors):
-            t.record_stream(side)                 # the caller may drop the batch as soon as forward returns
-        cur.wait_event(ev)
-        for t in (plan.graph_ptr, plan.evoff, x):      # (the plan's arrays are views of one arena)
+            t.record_stream(side_a)
+        if want_vals:
+            data.eigen_values.record_stream(side_b)
+        for t in (plan.graph_ptr, plan.evoff):         # (the plan's arrays are views of one arena)
+            t.record_stream(side_b)
             t.record_stream(cur)
+        x.record_stream(side_b)
+        s.record_stream(cur)
         self._last_plan, self._used_fused = plan, True
         with _lib_mod.stream_scope():
-            s = P["rho_fused"].run(plan, x, data.eigen_values if want_vals else None, K)
             self._flags_host = self._host_flags() if (plan.bins is not None and not _NO_KERNEL_FLAGS) else None
             if self._flags_host is not None:
                 self._flags_host[1][:] = 0

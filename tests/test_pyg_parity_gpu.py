@@ -419,7 +419,7 @@ def test_stream_pipeline_returns_the_same_outputs_in_order():
 
 
 def test_overlap_front_mode_is_bit_identical_and_stream_ordered():
-    """SignNetGNN.overlap_front: plan + phi of a forward on the module's side stream, rho + GINE on the caller's stream.  Outputs of a
+    """SignNetGNN.overlap_front: plan + phi and rho of a forward on the module's two side streams, GINE on the caller's stream.  Outputs of a
     loop over different resident batches equal the sequential forwards bit for bit, consumed on the caller's stream without any extra
     synchronisation (each output is read by a kernel queued right behind the forward), with batches dropped as soon as possible;
     strict mode and batches whose inputs were just produced on the current stream (overlap_inputs_ready = False) stay correct."""
@@ -443,7 +443,7 @@ def test_overlap_front_mode_is_bit_identical_and_stream_ordered():
         torch.cuda.synchronize()
         for i, y in acc:
             assert torch.equal(y, ref[i])
-        assert model._side_stream is not None
+        assert model._side_streams is not None
         # inputs still in flight on the caller's stream: the side stream waits for it
         model.overlap_inputs_ready = False
         for i, h in enumerate(hosts[:3]):
