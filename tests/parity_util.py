@@ -41,12 +41,27 @@ def close(a, ref, what, rel=REL, ref64=None):
     return err / scale
 
 
-def elementwise(a, ref, what, rtol=REL):
+def elementwise(a, ref, what, rtol=REL, ref64=None):
     """torch.testing.assert_close at the stated tolerance: |a - ref| <= rtol*|ref| + rtol*rms(ref) per element
-    (the absolute term is the tolerance times the tensor's typical magnitude, not a fixed constant)."""
-    a, ref = _d(a), _d(ref)
+    (the absolute term is the tolerance times the tensor's typical magnitude, not a fixed constant).
+    ref64 (the float64 evaluation of the same function): an element that misses the bound must be attributable to the fp32 REFERENCE —
+    there, a may not be farther from the float64 value than the fp32 reference is, beyond the same absolute term (the element-wise
+    form of `close`'s attribution rule).  Returns the number of attributed elements."""
+    a, ref = _d(a).reshape(_d(ref).shape), _d(ref)
     atol = rtol * ref.pow(2).mean().sqrt().item()
-    torch.testing.assert_close(a, ref, rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+    if ref64 is None:
+        torch.testing.assert_close(a, ref, rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+        return 0
+    miss = (a - ref).abs() > rtol * ref.abs() + atol
+    n = int(miss.sum())
+    if n:
+        r64 = _d(ref64).reshape(ref.shape)
+        e_a, e_r = (a - r64).abs()[miss], (ref - r64).abs()[miss]
+        bad = e_a > e_r + atol
+        assert not bool(bad.any()), (f"{what}: {int(bad.sum())} of {a.numel()} elements differ from the fp32 reference by more than {rtol:g} "
+                                     f"AND are farther from the float64 value than it is (worst |a - f64| {float(e_a[bad].max()):.3e} vs "
+                                     f"|ref - f64| {float(e_r[bad].max()):.3e}, atol {atol:.3e})")
+    return n
 
 
 def to_f64(sd):

@@ -70,6 +70,11 @@ def test_full_batch_vs_oracle_fp32_and_fp64(name):
         if e > worst[1]:
             worst = (what, e)
     PU.elementwise(y_fused, y32, f"{name}: y element-wise")
+    # element-wise (not only in the max norm) for the intermediate stages too: phi(v) + phi(-v), the sign_net output, the layer-path y
+    for what, hip, r32, r64 in (("phi (fused stage)", st["phi_fused"], o32["phi"], o64["phi"]), ("sign_net output", st["pos"], o32["pos"], o64["pos"]),
+                                ("y (layer kernels)", y_layer, y32, y64)):
+        n_attr = PU.elementwise(hip, r32, f"{name}: {what} element-wise", ref64=r64)
+        print(f"\n{name}: {what}: {n_attr} of {r32.numel()} elements attributed to the fp32 reference")
     print(f"\n{name}: worst stage '{worst[0]}' max|hip - cpu32| / max|cpu32| = {worst[1]:.2e}")
 
 
@@ -110,6 +115,7 @@ def test_basisnet_real_grid_all_multiplicity_groups():
             r32 = OB.ign2to1(sub, eq, P[sel], training=False)
             r64 = OB.ign2to1(PU.to_f64(sub), [(a.double(), b.double()) for a, b in eq], P[sel].double(), training=False)
         e = PU.close(y[sel], r32, f"IGN2to1 mult {mult}", ref64=r64)
+        PU.elementwise(y[sel], r32, f"IGN2to1 mult {mult} element-wise", ref64=r64)
         e_hip, e_cpu = PU.relerr(y[sel], r64), PU.relerr(r32, r64)
         assert e_hip <= e_cpu + PU.ATTR, f"mult {mult}: |hip - f64| {e_hip:.2e} vs |cpu32 - f64| {e_cpu:.2e}"
         worst = max(worst, e)
@@ -214,4 +220,5 @@ def test_dgl_base_nets_at_the_shipped_configs_vs_oracle_fp32_and_fp64(name):
         stages.insert(1, ("node features after the last layer", net._h_last, h32, h64))
     for what, hip, r32, r64 in stages:
         e = PU.close(hip, r32, f"{name}: {what}", ref64=r64)
+        PU.elementwise(hip, r32, f"{name}: {what} element-wise", ref64=r64)
         print(f"\n{name}: {what}: max|hip - cpu32| / max|cpu32| = {e:.2e}, |hip - f64| {PU.relerr(hip, r64):.2e}, |cpu32 - f64| {PU.relerr(r32, r64):.2e}")
