@@ -782,7 +782,9 @@ def main():
         #     chained by events — so the stages of consecutive steps share the GPU.  Outputs are bit-identical and ordered on the
         #     caller's stream; the batch is resident (the mode's precondition).  No kernel events in this pass (concurrent kernels
         #     stretch each other).
-        overlap = bool(model.max_k) and not args.no_overlap
+        # (small batches — configs[0], 32 graphs — are bound by the host's ~0.1 ms of stream / event calls per overlapped forward: the
+        #  mode is used from 64 graphs per GPU on)
+        overlap = bool(model.max_k) and not args.no_overlap and WORKLOAD["B"] >= 64
         dt = dt_seq
         if overlap:
             model.overlap_front = True

@@ -4,10 +4,10 @@ export TMPDIR=/tmp
 O=gpurun_out/r03f
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 50 --warmup 10 --streams 1 --no-scatter --no-cpu-baseline > $O/bench_profiled.json 2> $O/trace.err
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python bench.py --steps 20 --warmup 5 --streams 1 --no-scatter --no-cpu-baseline > $O/pmc_sq.json 2> $O/pmc_sq.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 5 --streams 1 --no-scatter --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 5 --streams 1 --no-scatter --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --steps 50 --warmup 10 --streams 1 --no-overlap --no-scatter --no-cpu-baseline > $O/bench_profiled.json 2> $O/trace.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -- python bench.py --steps 20 --warmup 5 --streams 1 --no-overlap --no-scatter --no-cpu-baseline > $O/pmc_sq.json 2> $O/pmc_sq.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 20 --warmup 5 --streams 1 --no-overlap --no-scatter --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 20 --warmup 5 --streams 1 --no-overlap --no-scatter --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
 python bench.py --workload train --steps 30 --warmup 10 > $O/train.json 2> $O/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_trace -- python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline > $O/train_profiled.json 2> $O/train_trace.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $O/train_pmc_sq -- python bench.py --workload train --steps 8 --warmup 3 --no-cpu-baseline > $O/train_pmc.json 2> $O/train_pmc.err
