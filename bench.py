@@ -525,7 +525,7 @@ def dgl_bench(args, dev):
            "value": 128 / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "dtype": "f32", "data": "synthetic", "vs_baseline": None,
            "config": {"workload": "DGL tree: sign_inv_net gin (8 layers, k=8) + GatedGCNNet (L=16, hidden 68, concat), batch 128"},
-           "roofline": {"kernel": "sn_gated_aggregate_f32 (k_gated_fwd) on an 8192-graph batch", "bound": "hbm",
+           "roofline": {"kernel": "sn_gated_aggregate_f32 (k_gated_fwd_v4) on an 8192-graph batch", "bound": "hbm",
                         "achieved": gbytes / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbytes / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": gbytes,
                         "mean_launch_us": 1e3 * gms, "nodes": Nn, "edges": E,
