@@ -341,6 +341,12 @@ int sn_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   its mixing FCLayer (:126). */
 int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hself, int ldh, int C, int64_t N, const int32_t* rowptr,
                          const int32_t* eperm, float avg_log, float* out, int ldo, void* stream);
+/* The same reduction with the message formed on the fly: msg(j -> n, edge e) = Ps[j] + Pd[n] + Qe[e] — PNATower.pretrans_edges
+ * (pna_layer.py:38-44) is a Linear over cat[h_src, h_dst, e] = W_s h_src + W_d h_dst + (W_e e + b); Ps / Pd [N, >= C] node terms,
+ * Qe [E, >= C] the edge term with the bias, col = the CSR's source nodes.  All towers of a layer side by side (C = in_dim). */
+int sn_pna_aggregate_gather_f32(const float* Ps, int ldps, const float* Pd, int ldpd, const float* Qe, int ldq, const float* hself, int ldh,
+                                int C, int64_t N, const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float avg_log,
+                                float* out, int ldo, void* stream);
 int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const float* Ee, int64_t N, int heads, int dk,
                           const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream);
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,

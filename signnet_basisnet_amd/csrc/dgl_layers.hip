@@ -54,6 +54,64 @@ __global__ __launch_bounds__(256) void k_pna_aggregate(const float* __restrict__
   }
 }
 
+// The same reduction with the message formed on the fly:  msg(j -> n, edge e) = Ps[j] + Pd[n] + Qe[e]  — PNATower.pretrans_edges
+// (pna_layer.py:38-44) is a Linear over cat[h_src, h_dst, e], i.e. W_s h_src + W_d h_dst + (W_e e + b): the two node terms are
+// computed once per NODE and the [E, 2 C_in + C_e] gather / concatenation and its E-row Linear disappear.  All towers of a layer in one
+// launch (their channels side by side: C = in_dim).
+__global__ __launch_bounds__(256) void k_pna_aggregate_gather(const float* __restrict__ Ps, int ldps, const float* __restrict__ Pd, int ldpd,
+                                                              const float* __restrict__ Qe, int ldq, const float* __restrict__ hself, int ldh,
+                                                              int C, int64_t N, const int32_t* __restrict__ rowptr,
+                                                              const int32_t* __restrict__ col, const int32_t* __restrict__ eperm,
+                                                              float avg_log, float* __restrict__ out, int ldo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int64_t n = i / C;
+  const int c = (int)(i - n * C);
+  const int lo = rowptr[n], hi = rowptr[n + 1];
+  const float pd = Pd[n * ldpd + c];
+  float s1 = 0.f, s2 = 0.f, mx = -INFINITY, mn = INFINITY;
+  for (int e0 = lo; e0 < hi; e0 += 4) {          // four in-edges in flight
+    float a[4], q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = 0.f; q[u] = 0.f;
+      if (e0 + u < hi) { a[u] = Ps[(int64_t)col[e0 + u] * ldps + c]; q[u] = Qe[(int64_t)eperm[e0 + u] * ldq + c]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (e0 + u < hi) {
+        const float v = (a[u] + pd) + q[u];
+        s1 += v;
+        s2 += v * v;
+        mx = fmaxf(mx, v);
+        mn = fminf(mn, v);
+      }
+    }
+  }
+  float* o = out + n * ldo;
+  int off = 0;
+  if (hself != nullptr) { o[c] = hself[n * ldh + c]; off = C; }
+  const int D = hi - lo;
+  if (D == 0) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[off + k * C + c] = 0.f;
+    return;
+  }
+  const float inv = 1.0f / (float)D;
+  const float mean = s1 * inv;
+  const float var = fmaxf(s2 * inv - mean * mean, 0.f);
+  const float sd = sqrtf(var + 1e-5f);
+  const float logd = logf((float)D + 1.0f);
+  const float amp = logd / avg_log, att = avg_log / logd;
+  const float ag[4] = {mean, mx, mn, sd};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[off + k * C + c] = ag[k];
+    o[off + (4 + k) * C + c] = ag[k] * amp;
+    o[off + (8 + k) * C + c] = ag[k] * att;
+  }
+}
+
 // MultiHeadAttentionLayer.propagate_attention (transformer.py:150-195, full_graph False, edge features): per in-edge (j -> i, id e)
 // and head h:  score = sum_c K[j,h,c] * Q[i,h,c] / sqrt(dk) * E[e,h,c];  s = exp(clamp(score, -5, 5));
 // out[i,h,:] = sum_e s * V[j,h,:] / (sum_e s + 1e-6).  One thread per (node, head); dk <= 32.
@@ -434,6 +492,19 @@ extern "C" int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hsel
   hipLaunchKernelGGL(k_pna_aggregate, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, msg, ldm, hself, ldh, C, N,
                      rowptr, eperm, avg_log, out, ldo);
   SN_CHECK_LAUNCH("sn_pna_aggregate_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_pna_aggregate_gather_f32(const float* Ps, int ldps, const float* Pd, int ldpd, const float* Qe, int ldq, const float* hself,
+                                           int ldh, int C, int64_t N, const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                                           float avg_log, float* out, int ldo, void* stream) {
+  SN_REQUIRE(Ps && Pd && Qe && rowptr && col && eperm && out && C > 0 && N >= 0 && ldps >= C && ldpd >= C && ldq >= C && avg_log > 0.f,
+             "sn_pna_aggregate_gather_f32: bad arguments");
+  SN_REQUIRE(ldo >= (hself ? 13 : 12) * C && (!hself || ldh >= C), "sn_pna_aggregate_gather_f32: output rows too narrow");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_pna_aggregate_gather, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, Ps, ldps, Pd, ldpd, Qe, ldq,
+                     hself, ldh, C, N, rowptr, col, eperm, avg_log, out, ldo);
+  SN_CHECK_LAUNCH("sn_pna_aggregate_gather_f32");
   return SN_OK;
 }
 

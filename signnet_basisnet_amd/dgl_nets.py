@@ -483,7 +483,8 @@ class PNANet(_PackCache, nn.Module):
     input, edge features, graph_norm + batch_norm, residual, no GRU, sum / mean readout.  Same constructor (`net_params`), forward
     contract `model(g, h, p, e, snorm_n) -> (scores, g)`, state_dict keys and attached `sign_inv_net`.  Per layer and tower:
     gather cat[h_src, h_dst, e] -> pretrans Linear -> sn_pna_aggregate_f32 -> posttrans Linear -> sn_pointwise_f32 (snorm_n and
-    BatchNorm); then the mixing Linear + LeakyReLU + residual.  Eval, train-mode value (batch-statistic BatchNorm, running statistics
+    BatchNorm); then the mixing Linear + LeakyReLU + residual.  In eval mode the towers of a layer run side by side and the pretrans
+    gather is folded into the aggregation (sn_pna_aggregate_gather_f32, `_pna_fused`).  Eval, train-mode value (batch-statistic BatchNorm, running statistics
     updated) and — with gradients enabled — the differentiable path (`_forward_grad`)."""
 
     def __init__(self, net_params):
@@ -543,6 +544,19 @@ class PNANet(_PackCache, nn.Module):
             x = ops.masked_linear(p.contiguous().float(), self._pk(self.embedding_p), residual=x)                 # h + embedding_p(p)  (:124-126)
             ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
             for L in self.layers:
+                if not train:
+                    # eval: all towers of the layer side by side, the pretrans Linear split by operand (pna_layer.py:38-44 is a Linear over
+                    # cat[h_src, h_dst, e]): two per-NODE terms + one per-edge term summed inside the aggregation kernel — no [E, .]
+                    # gathers / concatenations, 6 launches per layer instead of 9 per tower
+                    F = self._pna_fused(L)
+                    psd = ops.masked_linear(x, F["sd"])                                                               # [N, 2C] = [W_s h | W_d h]
+                    qe = ops.masked_linear(ef, F["e"])                                                                # [E, C]  = W_e e + b
+                    a = ops.pna_aggregate_gather(psd, qe, x, plan, avg_log)                                           # (:50-56, :69)
+                    y = ops.masked_linear(a, F["post"])
+                    hc = ops.pointwise(y, rowscale=sn, scale=F["scale"], shift=F["shift"])                            # * snorm_n, BatchNorm (:75-79)
+                    mix = ops.masked_linear(hc, self._pk(L.mixing_network_h.linear))
+                    x = ops.pointwise(mix, act="leaky", slope=0.01, residual=x if L.residual else None)
+                    continue
                 it = L.in_dim // L.n_towers
                 outs = []
                 for t, T in enumerate(L.towers):
@@ -569,6 +583,47 @@ class PNANet(_PackCache, nn.Module):
         self.g = g
         self._h_last = x
         return hg, g
+
+    def _pna_fused(self, L):
+        """Eval cache: the layer's towers as block-structured matrices.  sd [2C, C]: rows t*it.. of the first / second half hold tower t's
+        pretrans weights for h_src / h_dst (block diagonal: a tower reads its own it input channels); e [C, edge_dim] + the pretrans
+        biases; post [C_out, 13 C]: tower t's posttrans Linear scattered to the columns the fused aggregation writes its channels to
+        (own rows at t*it + j, aggregate k at C + k*C + t*it + j); scale / shift: the towers' folded BatchNorms side by side."""
+        c = self.__dict__.setdefault("_cache", {})
+        key = ("pna", id(L))
+        if key in c:
+            return c[key]
+        nt, Cin, Cout = L.n_towers, L.in_dim, L.out_dim
+        it, ot = Cin // nt, Cout // nt
+        pre = [T.pretrans_h.fully_connected[0].linear for T in L.towers]
+        post = [T.posttrans_h.fully_connected[0].linear for T in L.towers]
+        dev = pre[0].weight.device
+        ed = pre[0].weight.shape[1] - 2 * it
+        Wsd = torch.zeros(2 * Cin, Cin, dtype=torch.float32, device=dev)
+        We = torch.zeros(Cin, ed, dtype=torch.float32, device=dev)
+        be = torch.zeros(Cin, dtype=torch.float32, device=dev)
+        Wp = torch.zeros(Cout, 13 * Cin, dtype=torch.float32, device=dev)
+        bp = torch.zeros(Cout, dtype=torch.float32, device=dev)
+        scs, shs = [], []
+        for t in range(nt):
+            W = pre[t].weight.detach().float()
+            r = slice(t * it, (t + 1) * it)
+            Wsd[r, r] = W[:, :it]
+            Wsd[Cin + t * it:Cin + (t + 1) * it, r] = W[:, it:2 * it]
+            We[r] = W[:, 2 * it:]
+            be[r] = pre[t].bias.detach().float()
+            P = post[t].weight.detach().float()                       # [ot, 13 it]: cat[h_t, (4 s + a) blocks of it]
+            ro = slice(t * ot, (t + 1) * ot)
+            Wp[ro, r] = P[:, :it]
+            for k in range(12):
+                Wp[ro, Cin + k * Cin + t * it:Cin + k * Cin + (t + 1) * it] = P[:, it + k * it:it + (k + 1) * it]
+            bp[ro] = post[t].bias.detach().float()
+            site = self._bn(L.towers[t].batchnorm_h, False)
+            scs.append(site.scale)
+            shs.append(site.shift)
+        mk = lambda W_, b_: ops.PackedLinear(ops.pack_weight(W_.contiguous()), W_.shape[0], W_.shape[1], b_)
+        c[key] = {"sd": mk(Wsd, None), "e": mk(We, be), "post": mk(Wp, bp), "scale": torch.cat(scs).contiguous(), "shift": torch.cat(shs).contiguous()}
+        return c[key]
 
     def _forward_grad(self, plan, batch, ei, B, hidx, p, eidx, sn, avg_log):
         """Differentiable train-mode forward (SURVEY.md §8 f1 for this net): the same ops as autograd nodes with hand-written adjoints

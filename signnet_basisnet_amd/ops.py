@@ -615,6 +615,22 @@ def pna_aggregate(msg, hself, plan: GraphPlan, avg_log: float):
     return out
 
 
+def pna_aggregate_gather(psd, qe, hself, plan: GraphPlan, avg_log: float):
+    """PNA aggregation with the pretrans message formed in the kernel: psd [N, 2C] = [W_s h | W_d h] per node, qe [E, C] = W_e e + b,
+    message (j -> n, e) = psd[j, :C] + psd[n, C:] + qe[e]; -> [N, 13*C] = cat[hself, scalers(aggregators(.))] (all towers side by side)."""
+    require_cuda(psd)
+    psd, qe, hself = _f32c(psd, "psd"), _f32c(qe, "qe"), _f32c(hself, "hself")
+    Cc = qe.shape[1]
+    if psd.shape[1] != 2 * Cc or hself.shape[1] != Cc:
+        raise ValueError("pna_aggregate_gather: psd must be [N, 2C], hself [N, C] for qe [E, C]")
+    out = torch.empty(plan.N, 13 * Cc, dtype=torch.float32, device=psd.device)
+    with _span("sn_pna_aggregate_gather_f32"):
+        check(lib().sn_pna_aggregate_gather_f32(psd.data_ptr(), 2 * Cc, psd.data_ptr() + 4 * Cc, 2 * Cc, ptr(qe), Cc, ptr(hself), Cc, Cc, plan.N,
+                                                ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm), float(avg_log), ptr(out), 13 * Cc, stream()),
+              "sn_pna_aggregate_gather_f32")
+    return out
+
+
 def edge_attention(Q, K, V, Ee, plan: GraphPlan, heads: int):
     """Sparse multi-head attention over the graph's edges with edge features (layers/transformer.py:150-228) -> [N, heads*dk]."""
     require_cuda(Q)
