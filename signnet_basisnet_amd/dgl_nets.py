@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import check, lib, ptr, stream
-from .dgl_deepsigns import MLP, cached_plan, _max_nodes, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
+from .dgl_deepsigns import MLP, cached_plan, _await_side, _max_nodes, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
 
 
 class MLPReadout(nn.Module):
@@ -130,6 +130,7 @@ class GINNet(_PackCache, nn.Module):
         return batch.long(), torch.stack([src.long(), dst.long()]), B
 
     def forward(self, g, h, p, e, snorm_n=None):
+        _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
         if p is None or self.pe_init != "lap_pe":
             raise NotImplementedError("HIP GINNet needs the positional encoding p (pe_init='lap_pe')")
@@ -308,6 +309,7 @@ class GatedGCNNet(_PackCache, nn.Module):
     _plan = GINNet._plan
 
     def forward(self, g, h, p, e, snorm_n=None):
+        _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
         if p is None:
             raise NotImplementedError("HIP GatedGCNNet needs the positional encoding p")
@@ -525,6 +527,7 @@ class PNANet(_PackCache, nn.Module):
     _plan = GINNet._plan
 
     def forward(self, g, h, p, e, snorm_n):
+        _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
         if p is None or snorm_n is None:
             raise NotImplementedError("HIP PNANet needs the positional encoding p and snorm_n (graph_norm)")
@@ -739,6 +742,7 @@ class TransformerNet(_PackCache, nn.Module):
         return ops.pointwise(s, scale=sc, shift=sh)
 
     def forward(self, g, h, p, e, snorm_n=None):
+        _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
         if p is None:
             raise NotImplementedError("HIP TransformerNet needs the positional encoding p")
@@ -867,6 +871,7 @@ class GATNet(_PackCache, nn.Module):
             self.sign_inv_net = get_sign_inv_net(net_params)
 
     def forward(self, g, h, p, e, snorm_n=None):
+        _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
         if p is None:
             raise NotImplementedError("HIP GATNet needs the positional encoding p")

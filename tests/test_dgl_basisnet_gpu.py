@@ -938,3 +938,39 @@ def test_gatedgcn_one_launch_flags_a_graph_with_too_many_edges():
     y_l = net(g, data.x.reshape(-1).to(DEV), pp, e.to(DEV))[0]
     assert torch.isfinite(y_l).all()
     close(y[[0, 2]], y_l[[0, 2]], "graphs beside the flagged one")
+
+
+def test_sign_inv_net_overlap_mode_hands_its_output_over_with_an_event():
+    """GINDeepSigns.overlap: plan + stage launches on the module's side stream, the result and the graph's plan picked up by the base
+    network behind an event kept on the graph object.  A loop over fresh graph objects gives the sequential outputs bit for bit."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets, synth
+    params = dict(num_atom_type=28, num_bond_type=4, in_feat_dropout=0.0, dropout=0.0, batch_norm=True, residual=True, edge_feat=True,
+                  pe_init="lap_pe", lap_method="sign_inv", lap_lspe=False, use_lapeig_loss=False, lambda_loss=1, alpha_loss=1e-4,
+                  sign_inv_net="gin", sign_inv_layers=8, sign_inv_activation="relu", phi_out_dim=4, device="cuda:0",
+                  hidden_dim=68, out_dim=68, L=4, readout="mean", pos_enc_dim=8, pe_aggregate="concat")
+    torch.manual_seed(0)
+    nets = {"gated": dgl_nets.GatedGCNNet(params).cuda().eval(), "gin": dgl_nets.GINNet(dict(params, hidden_dim=64, out_dim=64)).cuda().eval()}
+    hosts = [synth.make_batch(64 + 8 * i, seed=90 + i) for i in range(4)]
+    ins = []
+    for h in hosts:
+        pe = synth.dgl_pos_enc(h, 8).unsqueeze(-1).cuda()
+        ins.append((h.edge_index[0].cuda(), h.edge_index[1].cuda(), torch.tensor(h.sizes), h.x.squeeze(-1).cuda(), h.edge_attr.cuda(), pe))
+    for name, net in nets.items():
+        def run(i):
+            s, d, bnn, hx, ex, pe = ins[i]
+            g = DS.Graph(s, d, bnn)
+            p = net.sign_inv_net(g, pe).squeeze(-1)
+            return net(g, hx, p, ex, None)[0]
+        with torch.no_grad():
+            ref = [run(i).clone() for i in range(4)]
+            torch.cuda.synchronize()
+            net.sign_inv_net.overlap = True
+            outs = [(i % 4, run(i % 4) * 1.0) for i in range(12)]
+            if hasattr(net, "check_last"):
+                net.check_last()
+            torch.cuda.synchronize()
+            net.sign_inv_net.overlap = False
+        assert getattr(net.sign_inv_net, "_side_stream", None) is not None
+        for i, y in outs:
+            assert torch.equal(y, ref[i]), name
