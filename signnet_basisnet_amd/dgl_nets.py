@@ -308,7 +308,43 @@ class GatedGCNNet(_PackCache, nn.Module):
 
     _plan = GINNet._plan
 
+    def _forward_behind_side(self, g, h, p, e, fused):
+        """The sign-invariant net ran in overlap mode (its event is on the graph): the input encoders (embeddings, PE projection) are
+        queued on ITS side stream, right behind it, and only the one-launch GatedGCN stack waits for that stream on the caller's —
+        two balanced stages (plan + phi + rho + encoders | 16 layers + read-out) whose consecutive batches overlap."""
+        from . import _lib as _lib_mod
+        ev, side, tensors = g._sn_side
+        N = h.shape[0]
+        with torch.no_grad(), torch.cuda.stream(side), _lib_mod.stream_scope():
+            plan = cached_plan(g, N)
+            hidx, eidx = h.long().reshape(N), e.long().reshape(-1)
+            st5 = plan.status[5:6]
+            x = ops.embedding_sum(hidx, [self.embedding_h.weight], status=st5)
+            pf = p.contiguous().float()
+            if self.pe_aggregate == "concat":
+                pp = ops.masked_linear(pf, self._pk(self.embedding_p))
+                x = ops.masked_linear(torch.cat([x, pp], dim=1), self._pk(self.pe_proj))
+            else:
+                x = ops.masked_linear(pf, self._pk(self.embedding_p), residual=x)
+            ee = ops.embedding_sum(eidx, [self.embedding_e.weight], status=st5)
+            ev2 = torch.cuda.Event()
+            ev2.record(side)
+        for t in (h, e):
+            t.record_stream(side)
+        g._sn_side = (ev2, side, tuple(tensors) + (x, ee))
+        _await_side(g, plan)
+        self._last_plan = plan
+        with torch.no_grad(), _lib_mod.stream_scope():
+            return fused.run(plan, x, ee)
+
     def forward(self, g, h, p, e, snorm_n=None):
+        if getattr(g, "_sn_side", None) is not None and p is not None and not self.training:
+            fz = self._fused_gated(g)
+            if fz is not None:
+                ops.require_cuda(h)
+                y = self._forward_behind_side(g, h, p, e, fz)
+                self.g = g
+                return y, g
         _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
         if p is None:
