@@ -212,26 +212,28 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
             step()
     kt = rec.summary()
     # the same step (fixed shape: this bench trains on one synthetic batch) captured once as a HIP graph and replayed: one graph launch
-    # + the Adam launch per step instead of ~350 launches issued from Python (train_graph.GraphedStep).  Single-rank only: the bucketed
-    # all-reduce of a process group is issued from autograd hooks, which a capture does not record.
+    # + the Adam launch per step instead of ~350 launches issued from Python (train_graph.GraphedStep).
     final_loss = float(loss.detach())
     del loss            # (a live loss keeps the eager step's autograd graph — and its default-stream AccumulateGrad nodes — alive: the
                         #  capture below would then have to synchronise with the default stream, which a capturing stream must not)
     graphed = None
-    if dist is None and not args.no_graph:
+    if not args.no_graph:
+        # (with a process group: the replay per rank, then the flat gradient's all-reduce — all buckets, issued by step() — and Adam)
         from signnet_basisnet_amd.train_graph import GraphedStep
         gs = GraphedStep(model, opt, data, target)
         for _ in range(max(2, args.warmup // 2)):
             gs.step()
-        torch.cuda.synchronize()
+        sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             gloss = gs.step()
-        torch.cuda.synchronize()
-        dtg = (time.perf_counter() - t0) / args.steps
+        sync_all()
+        dtg = D.max_over_ranks(time.perf_counter() - t0, dist, dev) / args.steps
         model.check_train()
-        graphed = {"value": WORKLOAD["B"] / dtg, "unit": "graphs/s", "ms_per_step": 1e3 * dtg, "final_loss": float(gloss),
-                   "note": "forward + loss + backward replayed as one captured HIP graph + one Adam launch (fixed batch shape)"}
+        graphed = {"value": WORKLOAD["B"] * world / dtg, "unit": "graphs/s", "ms_per_step": 1e3 * dtg, "final_loss": float(gloss),
+                   "note": "forward + loss + backward replayed as one captured HIP graph" +
+                           (" + one Adam launch (fixed batch shape)" if dist is None else
+                            ", then the flat gradient's all-reduce (after the replay) + one Adam launch (fixed batch shape)")}
     rccl = rccl_allreduce_probe(dist, dev, opt.flat_g.numel()) if dist is not None else None     # collective: every rank
     if rank != 0:
         return

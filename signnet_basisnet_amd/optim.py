@@ -101,6 +101,15 @@ class FlatAdam:
         for p in self.params:                    # .grad is a view of the zeroed flat buffer: `+=` inside an adjoint kernel IS AccumulateGrad
             p._sn_direct_grad = True
 
+    def disable_overlap(self):
+        """Drop the post-accumulate hooks: every bucket's all-reduce is then issued by step() (one after the other, after the backward).
+        train_graph.GraphedStep does this — a captured backward cannot launch collectives from hooks."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self._expect = [None] * len(self.buckets)
+        self._fired = [set() for _ in self.buckets]
+
     def _make_hook(self, i):
         b = self._bucket_of[i]
 

@@ -261,6 +261,20 @@ for use_dist in (None, dist):
 out["buckets"] = len(opt.buckets)
 out["early"] = early[3:]
 out["equal"] = bool(torch.equal(finals[0], finals[1]))       # SUM over one rank, scale 1: bit-identical parameters
+# the captured step with a process group: replay, then step() all-reduces every bucket (RCCL) and launches Adam — the same trajectory
+from signnet_basisnet_amd.train_graph import GraphedStep
+model = build(fx).train(); model.max_k = 16
+opt = optim.FlatAdam(model.parameters(), lr=2e-3, dist=None)
+for _ in range(3):
+    opt.zero_grad(); torch.nn.functional.l1_loss(model(data), target).backward(); opt.step()
+torch.cuda.synchronize(); want = opt.flat_p.clone()
+model = build(fx).train(); model.max_k = 16
+opt = optim.FlatAdam(model.parameters(), lr=2e-3, dist=dist, bucket_mb=0.05)
+gs = GraphedStep(model, opt, data, target)
+for _ in range(3):
+    gs.step()
+torch.cuda.synchronize()
+out["graphed_equal"] = bool(torch.equal(opt.flat_p, want)) and not opt._hooks
 probe = torch.ones(1 << 20, device="cuda:0")
 dist.all_reduce(probe); torch.cuda.synchronize()
 out["probe"] = float(probe.sum())
@@ -289,6 +303,7 @@ def test_flat_adam_over_rccl_world_size_one(tmp_path):
     assert out["backend"] == "nccl" and out["world"] == 1
     assert out["equal"], "all-reduce over one rank must not change the gradients"
     assert out["probe"] == float(1 << 20)
+    assert out["graphed_equal"], "GraphedStep with a process group (replay, then the all-reduce + Adam) must follow the eager trajectory"
     # (buckets that hold only parameters the forward never uses — GNN3d.edge_encoders, pos_encoder, ... — have no last gradient to
     #  trigger them and are reduced in step(); every other bucket goes out from inside the backward from the second step on)
     assert out["buckets"] >= 3 and out["early"][0] == 0 and min(out["early"][1:]) >= out["buckets"] // 2, out
