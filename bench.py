@@ -804,7 +804,7 @@ def main():
         #     stretch each other).
         # (small batches — configs[0], 32 graphs — are bound by the host's ~0.1 ms of stream / event calls per overlapped forward: the
         #  mode is used from 64 graphs per GPU on)
-        overlap = bool(model.max_k) and not args.no_overlap and WORKLOAD["B"] >= 64
+        overlap = not args.no_overlap and WORKLOAD["B"] >= 64
         dt = dt_seq
         if overlap:
             model.overlap_front = True

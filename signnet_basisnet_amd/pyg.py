@@ -311,7 +311,7 @@ class SignNetGNN(nn.Module):
         #                 is raised at the next forward, at check_last() or at train()/eval(), whichever comes first (a
         #                 module deleted with an unreported error warns).
         self.strict = True
-        # overlap_front: see _forward_overlapped (serving loops over resident batches; needs strict = False and max_k)
+        # overlap_front: see _forward_overlapped (serving loops over resident batches; needs strict = False)
         self.overlap_front, self.overlap_inputs_ready, self._side_streams = False, True, None
         # train-mode dropout of the attention probabilities (ScaledDotProductAttention's default attn_dropout=0.1,
         # transformer_module.py:46-55 — the only dropout the reference leaves active); 0.0 switches it off
@@ -688,11 +688,11 @@ class SignNetGNN(nn.Module):
         graphs; rho's attention phases and phi's gathers leave the matrix pipe idle).  Measured on the headline batch, ms per forward:
         0.27 on one stream, 0.25 with only the GINE stage behind an event, 0.23 with rho + GINE behind it, 0.197 with the three stages.
         Bit-identical outputs.
-        Opt-in (`overlap_front = True`, async status mode, max_k set): side A does not wait for the caller's stream, so the batch's
+        Opt-in (`overlap_front = True`, async status mode): side A does not wait for the caller's stream, so the batch's
         tensors must be complete on the device when forward is called (the resident batches of a serving loop; NOT a batch whose
         host-to-device copy was just queued on the current stream — `overlap_inputs_ready = False` covers that: correct, side A then
         waits for the caller's stream and consecutive forwards no longer overlap)."""
-        K, d = int(self.max_k), self.cfg["n_hid"]
+        d = self.cfg["n_hid"]
         dev = data.batch.device
         cur = torch.cuda.current_stream(dev)
         if self._side_streams is None:
@@ -702,7 +702,10 @@ class SignNetGNN(nn.Module):
             side_a.wait_stream(cur)
         want_vals = "eig" in P or "eig2" in P
         with torch.cuda.stream(side_a), _lib_mod.stream_scope():
-            plan = ops.build_plan(data.batch, data.edge_index, B, K, bins=True)
+            plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=True)
+            # all-eigenvector mode (max_k None): K = the largest graph, read back as the reference's to_dense_EVD does — the host waits
+            # for side A only (the previous forward's rho / GINE keep running)
+            K = int(self.max_k) if self.max_k else plan.check()[1]
             x = P["phi_fused"].run(plan, data.eigen_vectors, K, zero_invalid=False).view(plan.N * K, d)
             ev_a = torch.cuda.Event()
             ev_a.record(side_a)
@@ -739,7 +742,7 @@ class SignNetGNN(nn.Module):
         use_phi_fused = P["phi_fused"] is not None
         use_rho_fused = P["rho_fused"] is not None
         use_gnn_fused = P["gnn_fused"] is not None
-        if (self.overlap_front and use_phi_fused and use_rho_fused and use_gnn_fused and self.max_k and not return_stages and not train
+        if (self.overlap_front and use_phi_fused and use_rho_fused and use_gnn_fused and not return_stages and not train
                 and not self.strict):
             return self._forward_overlapped(data, P, B)
         plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=use_phi_fused or use_rho_fused)

@@ -453,3 +453,20 @@ def test_overlap_front_mode_is_bit_identical_and_stream_ordered():
         model.check_last()
         model.strict = True                              # the default mode ignores the flag (one stream, host wait per forward)
         assert torch.equal(model(synth.batch_to(hosts[0], "cuda:0")), ref[0])
+    # all-eigenvector mode (max_k None: K = the batch's largest graph, read back on side stream A), Alchemy variant with eigenvalues
+    torch.manual_seed(1)
+    model = pyg.SignNetGNN(6, 4, 64, 12, 3, 4, variant="alchemy").cuda().eval()
+    hosts = [synth.make_batch(96, seed=80 + i, n_lo=6, n_hi=23, features="alchemy") for i in range(4)]
+    with torch.no_grad():
+        ref = [model(synth.batch_to(h, "cuda:0")).clone() for h in hosts]
+        model.strict, model.overlap_front = False, True
+        outs = []
+        for rep in range(3):
+            for i, h in enumerate(hosts):
+                b = synth.batch_to(h, "cuda:0")
+                torch.cuda.synchronize()
+                outs.append((i, model(b) * 1.0))
+        model.check_last()
+        torch.cuda.synchronize()
+    for i, y in outs:
+        assert torch.equal(y, ref[i])
