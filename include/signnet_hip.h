@@ -148,10 +148,17 @@ int sn_gine_aggregate_f32(const float* x, const float* ea, float* out, int64_t N
 #define SN_EPI_AFFINE 4     /* eval-mode BatchNorm folded to scale/shift */
 #define SN_EPI_RELU 8       /* activation after the affine (PyG-tree order) */
 #define SN_EPI_RESIDUAL 16
+#define SN_EPI_BLOCK_BIAS 32 /* + block_bias[row / rows_per_block][:] together with the bias (sn_masked_linear_blockbias_f32 sets it) */
 int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
                          const float* bias, const int32_t* nvalid, int K, int flags,
                          const float* scale, const float* shift, const float* residual, int ldr,
                          float* y, int ldy, void* stream);
+/* The same with a bias per BLOCK of rows_per_block consecutive rows: y = epilogue(x W^T + bias + block_bias[row / rows_per_block]) — the
+ * equivariant 1->1 layers of IGN2to1 / DeepSets (LearningFilters/ign.py:405-414, models.py:58-113: Linear over cat[x, mean over the
+ * matrix broadcast to its rows]) = W_a x + (W_b mean) per matrix, without materialising the concatenation. */
+int sn_masked_linear_blockbias_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out, const float* bias,
+                                   const float* block_bias, int64_t rows_per_block, int ldbb, int flags, const float* scale,
+                                   const float* shift, float* y, int ldy, void* stream);
 
 /* Eval-mode BatchNorm1d folded to an affine (nn.BatchNorm1d.forward with running statistics,
  * used at masked_layers.py:19, model.py:50, elements.py:64, sign_net.py:50):

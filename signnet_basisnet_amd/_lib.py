@@ -31,6 +31,7 @@ SIGNATURES = {
     "sn_gin_aggregate_slab_f32": [_p, _p, _l, _i, _l, _p, _p, _p, _p, _i, _p],
     "sn_gine_aggregate_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p],
     "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
+    "sn_masked_linear_blockbias_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _l, _i, _i, _p, _p, _p, _i, _p],
     "sn_bn_fold_f32": [_p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "sn_bn_running_update_f32": [_p, _p, _p, _f, _i, _p, _p, _p],
     "sn_colstats_blocks": [_l],

@@ -91,6 +91,9 @@ class IGN2to1(nn.Module):
             c = e.coeffs.detach()                                              # [D, S, 2]
             W = torch.cat([c[:, :, 0].t(), c[:, :, 1].t()], dim=1)             # [S, 2D]: [identity | mean] blocks
             P[name] = _lin(W, e.bias)
+            # eval: the two blocks apart — W_a on the rows, W_b on the per-matrix mean, which enters as a bias per block of n rows
+            P[name + "_a"] = _lin(c[:, :, 0].t(), e.bias)
+            P[name + "_b"] = _lin(c[:, :, 1].t(), None)
         P["bn"] = [_BNSite(self.bns[i], train) for i in range(3)]
         P["fc1"] = _lin(self.fc1.weight, self.fc1.bias)
         P["fc2"] = _lin(self.fc2.weight, self.fc2.bias)
@@ -127,6 +130,12 @@ class IGN2to1(nn.Module):
         segplan = _SegPlan(b, seg)
         for li, name in ((1, "l1"), (2, "l2")):
             m = ops.segment_pool(h, segplan, "mean")                                       # [b, H]   sum_n h / n (ign.py:405-414)
+            if not train:
+                # Linear over cat[h, mean broadcast] = W_a h + (W_b mean) per matrix: the [b*n, 2H] concatenation is never formed
+                site = P["bn"][li]
+                h = ops.linear_block_bias(h, P[name + "_a"], ops.masked_linear(m, P[name + "_b"]), n, relu_pre=True,
+                                          scale=site.scale, shift=site.shift)
+                continue
             cat = torch.cat([h.view(b, n, -1), m.unsqueeze(1).expand(b, n, m.shape[1])], dim=-1).contiguous()
             h = self._relu_bn(cat.view(b * n, -1), P[name], P["bn"][li], train)
         h = ops.masked_linear(h, P["fc1"], relu=True)

@@ -103,6 +103,7 @@ struct LinArgs {
   const float* bias; const int32_t* nvalid; int K; int flags;
   const float* scale; const float* shift; const float* res; int ldr;
   float* y; int ldy;
+  const float* bbias = nullptr; int64_t bb_rows = 0; int ldbb = 0;     // SN_EPI_BLOCK_BIAS: + bbias[row / bb_rows][:], with the bias
 };
 
 // sum over the 16 lanes of a DPP row (the 16 rows of a tile for one lane group): four VALU+DPP steps
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
       v = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
       if (a.flags & SN_EPI_BIAS) v += load4<YV>(a.bias, o0, a.d_out);
+      if (a.flags & SN_EPI_BLOCK_BIAS) v += load4<YV>(a.bbias + (row / a.bb_rows) * a.ldbb, o0, a.d_out);
       if (a.flags & SN_EPI_RELU_PRE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -309,6 +311,7 @@ __global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t
         v = f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
         if (a.flags & SN_EPI_BIAS) v += load4<true>(a.bias, o0, a.d_out);
+        if (a.flags & SN_EPI_BLOCK_BIAS) v += load4<true>(a.bbias + (row / a.bb_rows) * a.ldbb, o0, a.d_out);
         if (a.flags & SN_EPI_RELU_PRE) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         if (a.flags & SN_EPI_AFFINE) {
           const f32x4 sc = load4<true>(a.scale, o0, a.d_out), sh = load4<true>(a.shift, o0, a.d_out);
@@ -1192,11 +1195,12 @@ static int launch_linear_lds(const LinArgs& a, float* stat, hipStream_t st) {
   return launch_linear_lds_t<16, 16>(a, stat, blocks, lds, st);
 }
 
-extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
-                                    const float* bias, const int32_t* nvalid, int K, int flags,
-                                    const float* scale, const float* shift, const float* residual, int ldr,
-                                    float* y, int ldy, void* stream) {
+static int masked_linear_impl(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
+                              const float* bias, const int32_t* nvalid, int K, int flags,
+                              const float* scale, const float* shift, const float* residual, int ldr,
+                              float* y, int ldy, const float* bbias, int64_t bb_rows, int ldbb, void* stream) {
   SN_REQUIRE(x && Wp && y && R >= 0 && d_in > 0 && d_out > 0, "sn_masked_linear_f32: bad arguments");
+  SN_REQUIRE(!(flags & SN_EPI_BLOCK_BIAS) || (bbias && bb_rows > 0 && ldbb >= d_out), "sn_masked_linear_blockbias_f32: block bias missing");
   SN_REQUIRE(ldx >= d_in && ldy >= d_out, "sn_masked_linear_f32: leading dimension too small");
   SN_REQUIRE(!(flags & SN_EPI_BIAS) || bias, "sn_masked_linear_f32: BIAS without bias");
   SN_REQUIRE(!(flags & SN_EPI_AFFINE) || (scale && shift), "sn_masked_linear_f32: AFFINE without scale/shift");
@@ -1205,10 +1209,10 @@ extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in
   SN_REQUIRE(al16(Wp), "sn_masked_linear_f32: Wp must be 16-byte aligned");
   if (R == 0) return SN_OK;
   LinArgs a{x, ldx, R, d_in, reinterpret_cast<const float4*>(Wp), (int)cdiv(d_in, 16), d_out, (int)cdiv(d_out, 16),
-            bias, nvalid, K, flags, scale, shift, residual, ldr, y, ldy};
+            bias, nvalid, K, flags, scale, shift, residual, ldr, y, ldy, bbias, bb_rows, ldbb};
   const bool xv = (d_in % 4 == 0) && (ldx % 4 == 0) && al16(x);
   const bool yv = (d_out % 4 == 0) && (ldy % 4 == 0) && al16(y) && (!bias || al16(bias)) && (!scale || al16(scale)) &&
-                  (!shift || al16(shift)) && (!residual || (al16(residual) && ldr % 4 == 0));
+                  (!shift || al16(shift)) && (!residual || (al16(residual) && ldr % 4 == 0)) && (!bbias || (al16(bbias) && ldbb % 4 == 0));
   dim3 grid((unsigned)cdiv(R, 64)), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (xv && yv && R >= LIN_LDS_MIN_ROWS) {
@@ -1221,6 +1225,22 @@ extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in
   else hipLaunchKernelGGL((k_linear<false, false>), grid, block, 0, st, a);
   SN_CHECK_LAUNCH("sn_masked_linear_f32");
   return SN_OK;
+}
+
+extern "C" int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
+                                    const float* bias, const int32_t* nvalid, int K, int flags,
+                                    const float* scale, const float* shift, const float* residual, int ldr,
+                                    float* y, int ldy, void* stream) {
+  SN_REQUIRE(!(flags & SN_EPI_BLOCK_BIAS), "sn_masked_linear_f32: SN_EPI_BLOCK_BIAS needs sn_masked_linear_blockbias_f32");
+  return masked_linear_impl(x, ldx, R, d_in, Wp, d_out, bias, nvalid, K, flags, scale, shift, residual, ldr, y, ldy, nullptr, 0, 0, stream);
+}
+
+extern "C" int sn_masked_linear_blockbias_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
+                                              const float* bias, const float* block_bias, int64_t rows_per_block, int ldbb, int flags,
+                                              const float* scale, const float* shift, float* y, int ldy, void* stream) {
+  SN_REQUIRE(x && Wp && y && block_bias && rows_per_block > 0 && !(flags & SN_EPI_RESIDUAL), "sn_masked_linear_blockbias_f32: bad arguments");
+  return masked_linear_impl(x, ldx, R, d_in, Wp, d_out, bias, nullptr, 0, flags | SN_EPI_BLOCK_BIAS, scale, shift, nullptr, 0, y, ldy,
+                            block_bias, rows_per_block, ldbb, stream);
 }
 
 extern "C" int sn_gin_aggregate_f32(const float* x, float* out, int64_t N, int F, const int32_t* rowptr,

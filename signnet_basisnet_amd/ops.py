@@ -379,6 +379,24 @@ def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=No
     return out
 
 
+def linear_block_bias(x, pl: PackedLinear, block_bias, rows_per_block, *, scale=None, shift=None, relu_pre=False, relu=False):
+    """y = epilogue(x @ W^T + b + block_bias[row // rows_per_block]): a Linear whose bias differs per block of consecutive rows (the
+    equivariant 1->1 layers: Linear over cat[x, mean of the row's matrix] without the concatenation)."""
+    require_cuda(x)
+    x, block_bias = _f32c(x, "x"), _f32c(block_bias, "block_bias")
+    R = x.numel() // pl.d_in
+    if block_bias.shape[-1] != pl.d_out or block_bias.numel() // pl.d_out * int(rows_per_block) < R:
+        raise ValueError("linear_block_bias: one bias row per block of rows expected")
+    flags = (EPI_BIAS if pl.bias is not None else 0) | (EPI_RELU_PRE if relu_pre else 0) | (EPI_AFFINE if scale is not None else 0) | \
+            (EPI_RELU if relu else 0)
+    out = torch.empty(*x.shape[:-1], pl.d_out, dtype=torch.float32, device=x.device)
+    with _span("sn_masked_linear_f32"):
+        check(lib().sn_masked_linear_blockbias_f32(ptr(x), pl.d_in, R, pl.d_in, ptr(pl.wp), pl.d_out, ptr(pl.bias), ptr(block_bias),
+                                                   int(rows_per_block), pl.d_out, flags, ptr(scale), ptr(shift), ptr(out), pl.d_out, stream()),
+              "sn_masked_linear_blockbias_f32")
+    return out
+
+
 def masked_colstats(x, nvalid=None, K=0):
     """Per-channel mean / biased variance over the valid rows of a row matrix [..., C]."""
     require_cuda(x)

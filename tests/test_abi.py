@@ -75,6 +75,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_eigenspace_projectors_f32": (None, 4, 4, None, None, 1, None, None),
         "sn_ign_contract_eigvecs_f32": (None, 4, 4, None, None, 1, 1, None, None),
         "sn_pna_aggregate_f32": (None, 4, None, 4, 4, 2, None, None, 1.0, None, 52, None),
+        "sn_masked_linear_blockbias_f32": (None, 4, 4, 4, None, 4, None, None, 2, 4, 0, None, None, None, 4, None),
         "sn_pna_aggregate_gather_f32": (None, 4, None, 4, None, 4, None, 4, 4, 2, None, None, None, 1.0, None, 52, None),
         "sn_pna_aggregate_bwd_f32": (None, 4, 4, 2, None, None, 1.0, None, 52, None, None, None),
         "sn_edge_attention_f32": (None,) * 4 + (2, 2, 4) + (None,) * 5,
