@@ -762,6 +762,22 @@ int sn_train_scalar_mlp_bwd_f32(const sn_train_scalar_mlp_args* args, const floa
                                 float* dgamma_a, float* dbeta_a, float* dw2, float* dgamma_b, float* dbeta_b, float* da,
                                 int accumulate, double* work, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * IGN2to1.forward after the 2->1 contractions (LearningFilters/ign.py:29-39), eval mode, ONE launch: o [b, n, 5] ->
+ * bn0(relu(W0 o + b0)) -> two equivariant 1->1 layers bn(relu(Wa h + Wb mean_n(h) + b)) (:174-214) -> fc2(relu(fc1(.))) -> y [b, O, n]
+ * (already transposed as ign.py:36-39 leaves it).  One workgroup per matrix, the rows' H channels stay in registers (MFMA operand layout).
+ * s*, t*: the BatchNorms folded to scale / shift (sn_bn_fold_f32); w1a / w1b: coeffs[:, :, 0]^T / coeffs[:, :, 1]^T ([H_out, H_in]).
+ * sn_ign_mlp_supported: H in {16, 32}, n <= 1024, O <= 32 — otherwise the layer-at-a-time entry points serve the module.  Parameter
+ * arrays 16-byte aligned. */
+typedef struct sn_ign_mlp_params {
+  const float *w0, *b0, *s0, *t0;                 /* [H,5], [H], [H], [H] */
+  const float *w1a, *w1b, *b1, *s1, *t1;          /* [H,H], [H,H], [H] x3 */
+  const float *w2a, *w2b, *b2, *s2, *t2;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;     /* [H,H], [H], [O,H], [O] (fc2_b may be NULL) */
+} sn_ign_mlp_params;
+int sn_ign_mlp_supported(int n, int H, int O);
+int sn_ign_mlp_f32(const float* o, int64_t b, int n, int H, int O, const sn_ign_mlp_params* P, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,7 @@ SIGNATURES = {
     "sn_gin_aggregate_slab_f32": [_p, _p, _l, _i, _l, _p, _p, _p, _p, _i, _p],
     "sn_gine_aggregate_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p],
     "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
+    "sn_ign_mlp_f32": [_p, _l, _i, _i, _i, _p, _p, _p],
     "sn_masked_linear_blockbias_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _l, _i, _i, _p, _p, _p, _i, _p],
     "sn_bn_fold_f32": [_p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "sn_bn_running_update_f32": [_p, _p, _p, _f, _i, _p, _p, _p],
@@ -135,6 +136,8 @@ def lib():
         L.sn_layernorm_bwd_scratch_floats.restype = C.c_int64
         L.sn_embedding_bwd_scratch_floats.argtypes = [_l, _i, C.POINTER(C.c_int64), _i]
         L.sn_embedding_bwd_scratch_floats.restype = C.c_int64
+        L.sn_ign_mlp_supported.argtypes = [_i, _i, _i]
+        L.sn_ign_mlp_supported.restype = C.c_int
         L.sn_embedding_bwd_layers_scratch_floats.argtypes = [_l, _i, _i]
         L.sn_embedding_bwd_layers_scratch_floats.restype = C.c_int64
         L.sn_gatedgcn_max_edges.argtypes = [_i]

@@ -19,12 +19,14 @@ the default; here `coeffs` / `bias` are ordinary registered Parameters with the 
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 
 import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import check, lib, ptr, stream
 
 BN_EPS = 1e-5
 
@@ -47,6 +49,11 @@ class layer_1_to_1(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, output_depth, 1))
 
 
+class _IgnMlpParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w0", "b0", "s0", "t0", "w1a", "w1b", "b1", "s1", "t1", "w2a", "w2b", "b2", "s2", "t2",
+                                          "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
 def _lin(W, b):
     W = W.detach().contiguous()
     return ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], None if b is None else b.detach().reshape(-1).contiguous())
@@ -66,6 +73,7 @@ class IGN2to1(nn.Module):
         self.fc1 = nn.Linear(hidden_channels, hidden_channels)
         self.fc2 = nn.Linear(hidden_channels, out_channels)
         self._prep = None
+        self.fused_head = True       # eval: sn_ign_mlp_f32 where it applies (False: the layer-at-a-time entry points)
         # fires also when a PARENT module's (IGNBasisInv, a wrapper) load_state_dict recurses into this one
         self.register_load_state_dict_post_hook(lambda m, keys=None: setattr(m, "_prep", None))
 
@@ -97,6 +105,15 @@ class IGN2to1(nn.Module):
         P["bn"] = [_BNSite(self.bns[i], train) for i in range(3)]
         P["fc1"] = _lin(self.fc1.weight, self.fc1.bias)
         P["fc2"] = _lin(self.fc2.weight, self.fc2.bias)
+        if not train:
+            # the one-launch head (sn_ign_mlp_f32): raw row-major matrices and the folded BatchNorms, kept alive by the cache
+            f = lambda t: t.detach().float().contiguous()
+            keep = [f(e0.coeffs[0]), f(e0.bias.reshape(-1)), P["bn"][0].scale, P["bn"][0].shift]
+            for i, e in ((1, e1), (2, e2)):
+                keep += [f(e.coeffs[:, :, 0].t()), f(e.coeffs[:, :, 1].t()), f(e.bias.reshape(-1)), P["bn"][i].scale, P["bn"][i].shift]
+            keep += [f(self.fc1.weight), f(self.fc1.bias), f(self.fc2.weight), f(self.fc2.bias)]
+            P["mlp_keep"] = keep
+            P["mlp"] = _IgnMlpParams(*[t.data_ptr() for t in keep])
         return P
 
     def _relu_bn(self, x, pl, site, train):
@@ -125,6 +142,14 @@ class IGN2to1(nn.Module):
                 self._prep = self._prepare()
             P = self._prep
         b, n = o.shape[0], o.shape[1]
+        H, O = self.fc1.weight.shape[0], self.fc2.weight.shape[0]
+        if not train and self.fused_head and lib().sn_ign_mlp_supported(int(n), int(H), int(O)):
+            # eval: the whole head in ONE launch, a workgroup per matrix, the rows' channels in registers; y comes out as [b, O, n]
+            o = o.contiguous()
+            y = torch.empty(b, O, n, dtype=torch.float32, device=o.device)
+            with ops._span("sn_ign_mlp_f32"):
+                check(lib().sn_ign_mlp_f32(ptr(o), b, n, H, O, C.byref(P["mlp"]), ptr(y), stream()), "sn_ign_mlp_f32")
+            return y
         h = self._relu_bn(o.reshape(b * n, 5), P["l0"], P["bn"][0], train)
         seg = torch.arange(0, b * n + 1, n, dtype=torch.int32, device=o.device)             # rows of matrix i: [i*n, (i+1)*n)
         segplan = _SegPlan(b, seg)

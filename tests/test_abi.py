@@ -39,7 +39,7 @@ def test_python_binding_covers_the_header(lib):
     bound = set(_lib.SIGNATURES) | {"sn_last_error", "sn_packed_weight_floats", "sn_split_packed_bytes", "sn_phi_bins_bound",
                                      "sn_ign_contract_scratch_floats", "sn_evd_work_ints",
                                      "sn_linear_wgrad_scratch_floats", "sn_layernorm_bwd_scratch_floats",
-                                     "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_embedding_bwd_layers_scratch_floats",
+                                     "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_embedding_bwd_layers_scratch_floats", "sn_ign_mlp_supported",
                                      "sn_gatedgcn_max_edges",
                                      "sn_train_linear_bwd_part_floats", "sn_train_scalar_mlp_work_doubles"}
     assert set(declared_symbols()) == bound
@@ -75,6 +75,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_eigenspace_projectors_f32": (None, 4, 4, None, None, 1, None, None),
         "sn_ign_contract_eigvecs_f32": (None, 4, 4, None, None, 1, 1, None, None),
         "sn_pna_aggregate_f32": (None, 4, None, 4, 4, 2, None, None, 1.0, None, 52, None),
+        "sn_ign_mlp_f32": (None, 1, 8, 32, 1, None, None, None),
         "sn_masked_linear_blockbias_f32": (None, 4, 4, 4, None, 4, None, None, 2, 4, 0, None, None, None, 4, None),
         "sn_pna_aggregate_gather_f32": (None, 4, None, 4, None, 4, None, 4, 4, 2, None, None, None, 1.0, None, 52, None),
         "sn_pna_aggregate_bwd_f32": (None, 4, 4, 2, None, None, 1.0, None, 52, None, None, None),
@@ -98,7 +99,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
 
 def test_struct_layouts_match_the_header():
     """sizeof/offsetof of the parameter structs, C compiler vs ctypes."""
-    from signnet_basisnet_amd import dgl_nets, fused, ops, train_stage
+    from signnet_basisnet_amd import basisnet, dgl_nets, fused, ops, train_stage
     prog = r'''
 #include <stdio.h>
 #include <stddef.h>
@@ -110,6 +111,7 @@ int main(void) {
   printf("%zu %zu %zu\n", offsetof(sn_phi_params, layers), offsetof(sn_rho_params, layers), offsetof(sn_rho_params, pe_w1));
   printf("%zu %zu %zu %zu\n", sizeof(sn_gatedgcn_layer), sizeof(sn_gatedgcn_params), offsetof(sn_gatedgcn_params, layers),
          offsetof(sn_gatedgcn_params, ro_w0));
+  printf("%zu %zu\n", sizeof(sn_ign_mlp_params), offsetof(sn_ign_mlp_params, fc2_b));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sn_train_linear_args), offsetof(sn_train_linear_args, in_scale),
          offsetof(sn_train_linear_args, stat_part), sizeof(sn_train_linear_bwd_args), offsetof(sn_train_linear_bwd_args, x_mean),
          offsetof(sn_train_linear_bwd_args, dot_part), sizeof(sn_train_scalar_mlp_args), offsetof(sn_train_scalar_mlp_args, w2),
@@ -128,6 +130,7 @@ int main(void) {
             S(fused._GnnLayer), S(fused._GnnParams), fused._GnnParams.layers.offset,
             fused._PhiParams.layers.offset, fused._RhoParams.layers.offset, fused._RhoParams.pe_w1.offset,
             S(dgl_nets._GatedLayerC), S(dgl_nets._GatedParamsC), dgl_nets._GatedParamsC.layers.offset, dgl_nets._GatedParamsC.ro_w0.offset,
+            S(basisnet._IgnMlpParams), basisnet._IgnMlpParams.fc2_b.offset,
             S(train_stage._LinArgs), train_stage._LinArgs.in_scale.offset, train_stage._LinArgs.stat_part.offset,
             S(train_stage._BwdArgs), train_stage._BwdArgs.x_mean.offset, train_stage._BwdArgs.dot_part.offset,
             S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset]
