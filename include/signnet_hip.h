@@ -353,7 +353,14 @@ int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hself, int ldh,
  * Qe [E, >= C] the edge term with the bias, col = the CSR's source nodes.  All towers of a layer side by side (C = in_dim). */
 int sn_pna_aggregate_gather_f32(const float* Ps, int ldps, const float* Pd, int ldpd, const float* Qe, int ldq, const float* hself, int ldh,
                                 int C, int64_t N, const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float avg_log,
-                                float* out, int ldo, void* stream);
+                                float* out, int ldo, int tower_width, void* stream);
+/* tower_width = 0: the output layout of sn_pna_aggregate_f32 ([13 blocks][C]); tower_width = it > 0: tower-major — tower t = c / it owns the
+ * 13 * it contiguous columns [own it | 12 aggregate blocks of it], which is what the towers' posttrans Linears read:
+ * sn_grouped_linear_f32: y[:, g*dout..] = ((x[:, g*din..] W_g^T + b_g) * rowscale[row]) * scale + shift for G column groups (a block-
+ * diagonal Linear; W [G][dout][din] row-major, din % 4 == 0, din <= 256, dout <= 16; rowscale / scale+shift / bias optional):
+ * PNATower's posttrans Linear, graph_norm (h * snorm_n) and the folded BatchNorm of all towers in one launch (pna_layer.py:69-79). */
+int sn_grouped_linear_f32(const float* x, int ldx, int64_t R, int G, int din, int dout, const float* W, const float* bias,
+                          const float* rowscale, const float* scale, const float* shift, float* y, int ldy, void* stream);
 int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const float* Ee, int64_t N, int heads, int dk,
                           const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream);
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,

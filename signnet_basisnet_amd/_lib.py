@@ -63,7 +63,8 @@ SIGNATURES = {
     "sn_embedding_sum_bwd_layers_f32": [_p, _i, _i, _l, _i, _p, C.POINTER(C.c_int64), _i, _p, _p, _p, _p],
     "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
     "sn_pna_aggregate_f32": [_p, _i, _p, _i, _i, _l, _p, _p, _f, _p, _i, _p],
-    "sn_pna_aggregate_gather_f32": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _l, _p, _p, _p, _f, _p, _i, _p],
+    "sn_pna_aggregate_gather_f32": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _l, _p, _p, _p, _f, _p, _i, _i, _p],
+    "sn_grouped_linear_f32": [_p, _i, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "sn_edge_attention_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p],
     "sn_pointwise_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _f, _p, _i, _p, _i, _p],
     "sn_deepsigns_phi_f32": [_p, _p, _i, _p, _p, _p, _p, _i, _p, _p],

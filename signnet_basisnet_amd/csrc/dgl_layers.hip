@@ -62,13 +62,17 @@ __global__ __launch_bounds__(256) void k_pna_aggregate_gather(const float* __res
                                                               const float* __restrict__ Qe, int ldq, const float* __restrict__ hself, int ldh,
                                                               int C, int64_t N, const int32_t* __restrict__ rowptr,
                                                               const int32_t* __restrict__ col, const int32_t* __restrict__ eperm,
-                                                              float avg_log, float* __restrict__ out, int ldo) {
+                                                              float avg_log, float* __restrict__ out, int ldo, int tower) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= N * C) return;
   const int64_t n = i / C;
   const int c = (int)(i - n * C);
   const int lo = rowptr[n], hi = rowptr[n + 1];
   const float pd = Pd[n * ldpd + c];
+  // output column of (block j, channel c): j = 0 the node's own row, j = 1 + k the k-th scaled aggregate.  tower = 0: block-major
+  // [j][C]; tower = it > 0: TOWER-major — tower t = c / it owns the 13 it contiguous columns [t][j][it] (a grouped Linear reads them)
+  const int t_ = tower > 0 ? c / tower : 0, ct = tower > 0 ? c - t_ * tower : c;
+  const int base = tower > 0 ? t_ * 13 * tower + ct : c, jstride = tower > 0 ? tower : C;
   float s1 = 0.f, s2 = 0.f, mx = -INFINITY, mn = INFINITY;
   for (int e0 = lo; e0 < hi; e0 += 4) {          // four in-edges in flight
     float a[4], q[4];
@@ -88,13 +92,13 @@ __global__ __launch_bounds__(256) void k_pna_aggregate_gather(const float* __res
       }
     }
   }
-  float* o = out + n * ldo;
+  float* o = out + n * ldo + base;
   int off = 0;
-  if (hself != nullptr) { o[c] = hself[n * ldh + c]; off = C; }
+  if (hself != nullptr) { o[0] = hself[n * ldh + c]; off = jstride; }
   const int D = hi - lo;
   if (D == 0) {
 #pragma unroll
-    for (int k = 0; k < 12; ++k) o[off + k * C + c] = 0.f;
+    for (int k = 0; k < 12; ++k) o[off + k * jstride] = 0.f;
     return;
   }
   const float inv = 1.0f / (float)D;
@@ -106,9 +110,54 @@ __global__ __launch_bounds__(256) void k_pna_aggregate_gather(const float* __res
   const float ag[4] = {mean, mx, mn, sd};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    o[off + k * C + c] = ag[k];
-    o[off + (4 + k) * C + c] = ag[k] * amp;
-    o[off + (8 + k) * C + c] = ag[k] * att;
+    o[off + k * jstride] = ag[k];
+    o[off + (4 + k) * jstride] = ag[k] * amp;
+    o[off + (8 + k) * jstride] = ag[k] * att;
+  }
+}
+
+// y[:, g*dout .. ] = ((x[:, g*din ..] W_g^T + b_g) * rowscale[row]) * scale + shift  for G independent column groups (a block-diagonal
+// Linear: the towers' posttrans Linears of a PNA layer over the tower-major aggregation output, with graph_norm's snorm_n and the
+// folded BatchNorm as the epilogue; pna_layer.py:69-79).  A wave takes (16-row tile, group) pairs; the group's weight fragments
+// (dout <= 16, din <= 256: <= 16 float4 per lane, straight from the row-major [G][dout][din] array) are loaded per pair from L2.
+__global__ __launch_bounds__(256) void k_grouped_linear(const float* __restrict__ x, int ldx, int64_t R, int G, int din, int dout,
+                                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                                        const float* __restrict__ rowscale, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ y, int ldy) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, g = lane >> 4;
+  const int64_t ntiles = (R + 15) >> 4;
+  const int64_t task = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= ntiles * G) return;
+  const int grp = (int)(task % G);
+  const int64_t tile = task / G;
+  const int64_t row = tile * 16 + lr;
+  const bool inr = row < R;
+  const int nk = (din + 15) >> 4;
+  const float* xr = x + row * ldx + (int64_t)grp * din;
+  const float* wr = W + ((int64_t)grp * dout + lr) * din;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kk = 0; kk < nk; ++kk) {
+    const int k0 = 16 * kk + 4 * g;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a;
+    if (k0 < din) {           // din % 4 == 0
+      if (lr < dout) { const float4 t = *reinterpret_cast<const float4*>(wr + k0); a = f32x4{t.x, t.y, t.z, t.w}; }
+      if (inr) { const float4 t = *reinterpret_cast<const float4*>(xr + k0); b = f32x4{t.x, t.y, t.z, t.w}; }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = mfma16(a[t], b[t], acc);
+  }
+  if (!inr) return;
+  const float rs = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int oc = 4 * g + r;
+    if (oc < dout) {
+      const int c = grp * dout + oc;
+      float v = acc[r] + (bias ? bias[c] : 0.f);
+      v *= rs;
+      if (scale) v = v * scale[c] + shift[c];
+      y[row * ldy + c] = v;
+    }
   }
 }
 
@@ -497,14 +546,30 @@ extern "C" int sn_pna_aggregate_f32(const float* msg, int ldm, const float* hsel
 
 extern "C" int sn_pna_aggregate_gather_f32(const float* Ps, int ldps, const float* Pd, int ldpd, const float* Qe, int ldq, const float* hself,
                                            int ldh, int C, int64_t N, const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
-                                           float avg_log, float* out, int ldo, void* stream) {
+                                           float avg_log, float* out, int ldo, int tower_width, void* stream) {
   SN_REQUIRE(Ps && Pd && Qe && rowptr && col && eperm && out && C > 0 && N >= 0 && ldps >= C && ldpd >= C && ldq >= C && avg_log > 0.f,
              "sn_pna_aggregate_gather_f32: bad arguments");
   SN_REQUIRE(ldo >= (hself ? 13 : 12) * C && (!hself || ldh >= C), "sn_pna_aggregate_gather_f32: output rows too narrow");
+  SN_REQUIRE(tower_width == 0 || (tower_width > 0 && C % tower_width == 0 && hself), "sn_pna_aggregate_gather_f32: tower_width must divide C (and needs hself)");
   if (N == 0) return SN_OK;
   hipLaunchKernelGGL(k_pna_aggregate_gather, dim3((unsigned)cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, Ps, ldps, Pd, ldpd, Qe, ldq,
-                     hself, ldh, C, N, rowptr, col, eperm, avg_log, out, ldo);
+                     hself, ldh, C, N, rowptr, col, eperm, avg_log, out, ldo, tower_width);
   SN_CHECK_LAUNCH("sn_pna_aggregate_gather_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_grouped_linear_f32(const float* x, int ldx, int64_t R, int G, int din, int dout, const float* W, const float* bias,
+                                     const float* rowscale, const float* scale, const float* shift, float* y, int ldy, void* stream) {
+  SN_REQUIRE(x && W && y && R >= 0 && G >= 1 && din >= 4 && din <= 256 && din % 4 == 0 && dout >= 1 && dout <= 16,
+             "sn_grouped_linear_f32: bad arguments (din a multiple of 4 up to 256, dout <= 16)");
+  SN_REQUIRE(ldx >= G * din && ldx % 4 == 0 && ldy >= G * dout && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0,
+             "sn_grouped_linear_f32: rows must be 16-byte aligned");
+  SN_REQUIRE((scale != nullptr) == (shift != nullptr), "sn_grouped_linear_f32: scale / shift go together");
+  if (R == 0) return SN_OK;
+  const int64_t tasks = cdiv(R, 16) * G;
+  hipLaunchKernelGGL(k_grouped_linear, dim3((unsigned)cdiv(tasks, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, R, G, din, dout, W, bias, rowscale,
+                     scale, shift, y, ldy);
+  SN_CHECK_LAUNCH("sn_grouped_linear_f32");
   return SN_OK;
 }
 

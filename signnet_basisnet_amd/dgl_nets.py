@@ -522,7 +522,7 @@ class PNANet(_PackCache, nn.Module):
     contract `model(g, h, p, e, snorm_n) -> (scores, g)`, state_dict keys and attached `sign_inv_net`.  Per layer and tower:
     gather cat[h_src, h_dst, e] -> pretrans Linear -> sn_pna_aggregate_f32 -> posttrans Linear -> sn_pointwise_f32 (snorm_n and
     BatchNorm); then the mixing Linear + LeakyReLU + residual.  In eval mode the towers of a layer run side by side and the pretrans
-    gather is folded into the aggregation (sn_pna_aggregate_gather_f32, `_pna_fused`).  Eval, train-mode value (batch-statistic BatchNorm, running statistics
+    gather is folded into the aggregation, on activations padded to 16-byte rows (sn_pna_aggregate_gather_f32, `_forward_eval_padded`).  Eval, train-mode value (batch-statistic BatchNorm, running statistics
     updated) and — with gradients enabled — the differentiable path (`_forward_grad`)."""
 
     def __init__(self, net_params):
@@ -579,23 +579,14 @@ class PNANet(_PackCache, nn.Module):
             self.g = g
             return hg, g
         with torch.no_grad():
+            if not train and self._pna_padded()["ok"]:
+                hg = self._forward_eval_padded(plan, h, p, e, sn, avg_log)
+                self.g = g
+                return hg, g
             x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])
             x = ops.masked_linear(p.contiguous().float(), self._pk(self.embedding_p), residual=x)                 # h + embedding_p(p)  (:124-126)
             ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
             for L in self.layers:
-                if not train:
-                    # eval: all towers of the layer side by side, the pretrans Linear split by operand (pna_layer.py:38-44 is a Linear over
-                    # cat[h_src, h_dst, e]): two per-NODE terms + one per-edge term summed inside the aggregation kernel — no [E, .]
-                    # gathers / concatenations, 6 launches per layer instead of 9 per tower
-                    F = self._pna_fused(L)
-                    psd = ops.masked_linear(x, F["sd"])                                                               # [N, 2C] = [W_s h | W_d h]
-                    qe = ops.masked_linear(ef, F["e"])                                                                # [E, C]  = W_e e + b
-                    a = ops.pna_aggregate_gather(psd, qe, x, plan, avg_log)                                           # (:50-56, :69)
-                    y = ops.masked_linear(a, F["post"])
-                    hc = ops.pointwise(y, rowscale=sn, scale=F["scale"], shift=F["shift"])                            # * snorm_n, BatchNorm (:75-79)
-                    mix = ops.masked_linear(hc, self._pk(L.mixing_network_h.linear))
-                    x = ops.pointwise(mix, act="leaky", slope=0.01, residual=x if L.residual else None)
-                    continue
                 it = L.in_dim // L.n_towers
                 outs = []
                 for t, T in enumerate(L.towers):
@@ -623,46 +614,101 @@ class PNANet(_PackCache, nn.Module):
         self._h_last = x
         return hg, g
 
-    def _pna_fused(self, L):
-        """Eval cache: the layer's towers as block-structured matrices.  sd [2C, C]: rows t*it.. of the first / second half hold tower t's
-        pretrans weights for h_src / h_dst (block diagonal: a tower reads its own it input channels); e [C, edge_dim] + the pretrans
-        biases; post [C_out, 13 C]: tower t's posttrans Linear scattered to the columns the fused aggregation writes its channels to
-        (own rows at t*it + j, aggregate k at C + k*C + t*it + j); scale / shift: the towers' folded BatchNorms side by side."""
+    @staticmethod
+    def _pad_map(Cc, nt, dev):
+        """Tower t's channels [t*it, (t+1)*it) -> [t*it_p, t*it_p + it), it_p = it rounded up to a multiple of 4: every row of the padded
+        activations is 16-byte aligned and every Linear takes the vector / LDS-staged kernels (hidden 70 = 5 towers x 14 would fall back to
+        the scalar kernel: 73 % of the forward).  Pad channels are zero everywhere (zero weight rows / columns, BatchNorm scale 0)."""
+        it = Cc // nt
+        it_p = (it + 3) // 4 * 4
+        c = torch.arange(Cc, device=dev)
+        return (c // it) * it_p + c % it, nt * it_p, it, it_p
+
+    def _pna_padded(self):
+        """Eval cache: every parameter of the net re-laid-out for the padded, all-towers-side-by-side evaluation.  Per layer:
+        sd [2 Cin_p, Cin_p] — rows t*it_p.. of the first / second half hold tower t's pretrans weights for h_src / h_dst (block diagonal:
+        a tower reads its own input channels; pna_layer.py:38-44 is a Linear over cat[h_src, h_dst, e] = W_s h_src + W_d h_dst + W_e e + b);
+        e [Cin_p, edge_dim] + the pretrans biases; post_w [towers, ot_p, 13 it_p] — the towers' posttrans Linears as one grouped (block-diagonal) Linear over
+        the tower-major output of the aggregation kernel; the towers' folded BatchNorms side by side (its epilogue, with snorm_n); the mixing Linear in the padded channel order."""
         c = self.__dict__.setdefault("_cache", {})
-        key = ("pna", id(L))
-        if key in c:
-            return c[key]
-        nt, Cin, Cout = L.n_towers, L.in_dim, L.out_dim
-        it, ot = Cin // nt, Cout // nt
-        pre = [T.pretrans_h.fully_connected[0].linear for T in L.towers]
-        post = [T.posttrans_h.fully_connected[0].linear for T in L.towers]
-        dev = pre[0].weight.device
-        ed = pre[0].weight.shape[1] - 2 * it
-        Wsd = torch.zeros(2 * Cin, Cin, dtype=torch.float32, device=dev)
-        We = torch.zeros(Cin, ed, dtype=torch.float32, device=dev)
-        be = torch.zeros(Cin, dtype=torch.float32, device=dev)
-        Wp = torch.zeros(Cout, 13 * Cin, dtype=torch.float32, device=dev)
-        bp = torch.zeros(Cout, dtype=torch.float32, device=dev)
-        scs, shs = [], []
-        for t in range(nt):
-            W = pre[t].weight.detach().float()
-            r = slice(t * it, (t + 1) * it)
-            Wsd[r, r] = W[:, :it]
-            Wsd[Cin + t * it:Cin + (t + 1) * it, r] = W[:, it:2 * it]
-            We[r] = W[:, 2 * it:]
-            be[r] = pre[t].bias.detach().float()
-            P = post[t].weight.detach().float()                       # [ot, 13 it]: cat[h_t, (4 s + a) blocks of it]
-            ro = slice(t * ot, (t + 1) * ot)
-            Wp[ro, r] = P[:, :it]
-            for k in range(12):
-                Wp[ro, Cin + k * Cin + t * it:Cin + k * Cin + (t + 1) * it] = P[:, it + k * it:it + (k + 1) * it]
-            bp[ro] = post[t].bias.detach().float()
-            site = self._bn(L.towers[t].batchnorm_h, False)
-            scs.append(site.scale)
-            shs.append(site.shift)
-        mk = lambda W_, b_: ops.PackedLinear(ops.pack_weight(W_.contiguous()), W_.shape[0], W_.shape[1], b_)
-        c[key] = {"sd": mk(Wsd, None), "e": mk(We, be), "post": mk(Wp, bp), "scale": torch.cat(scs).contiguous(), "shift": torch.cat(shs).contiguous()}
-        return c[key]
+        if "pna_padded" in c:
+            return c["pna_padded"]
+        dev = self.embedding_h.weight.device
+        mk = lambda W_, b_: ops.PackedLinear(ops.pack_weight(W_.contiguous()), W_.shape[0], W_.shape[1], None if b_ is None else b_.contiguous())
+        z = lambda *shape: torch.zeros(*shape, dtype=torch.float32, device=dev)
+        nt = self.layers[0].n_towers
+        hid = self.embedding_h.weight.shape[1]
+        pos0, C0, _, _ = self._pad_map(hid, nt, dev)
+        P = {"pos_in": pos0, "C_in": C0}
+        E = z(self.embedding_h.weight.shape[0], C0)
+        E[:, pos0] = self.embedding_h.weight.detach().float()
+        Wp_, bp_ = z(C0, self.embedding_p.weight.shape[1]), z(C0)
+        Wp_[pos0], bp_[pos0] = self.embedding_p.weight.detach().float(), self.embedding_p.bias.detach().float()
+        P["emb_h"], P["emb_p"] = E, mk(Wp_, bp_)
+        layers = []
+        for L in self.layers:
+            Cin, Cout = L.in_dim, L.out_dim
+            pin, Cin_p, it, it_p = self._pad_map(Cin, nt, dev)
+            pout, Cout_p, ot, ot_p = self._pad_map(Cout, nt, dev)
+            pre = [T.pretrans_h.fully_connected[0].linear for T in L.towers]
+            post = [T.posttrans_h.fully_connected[0].linear for T in L.towers]
+            ed = pre[0].weight.shape[1] - 2 * it
+            Wsd, We, be = z(2 * Cin_p, Cin_p), z(Cin_p, ed), z(Cin_p)
+            Wpo, bpo = z(nt, ot_p, 13 * it_p), z(Cout_p)            # grouped: tower t reads its own 13 it_p tower-major columns
+            sc, sh = z(Cout_p), z(Cout_p)
+            for t in range(nt):
+                W = pre[t].weight.detach().float()
+                r = slice(t * it_p, t * it_p + it)
+                Wsd[r, r] = W[:, :it]
+                Wsd[Cin_p + t * it_p:Cin_p + t * it_p + it, r] = W[:, it:2 * it]
+                We[r] = W[:, 2 * it:]
+                be[r] = pre[t].bias.detach().float()
+                Q = post[t].weight.detach().float()                   # [ot, 13 it]: cat[h_t, (4 s + a) blocks of it]
+                ro = slice(t * ot_p, t * ot_p + ot)
+                for j in range(13):
+                    Wpo[t, :ot, j * it_p:j * it_p + it] = Q[:, j * it:(j + 1) * it]
+                bpo[ro] = post[t].bias.detach().float()
+                site = self._bn(L.towers[t].batchnorm_h, False)
+                sc[ro], sh[ro] = site.scale, site.shift
+            ml = L.mixing_network_h.linear
+            Wm, bm = z(Cout_p, Cout_p), z(Cout_p)
+            Wm[pout[:, None], pout[None, :]] = ml.weight.detach().float()
+            bm[pout] = ml.bias.detach().float()
+            layers.append({"sd": mk(Wsd, None), "e": mk(We, be), "post_w": Wpo.contiguous(), "post_b": bpo, "nt": nt, "it_p": it_p,
+                           "grouped": ot_p <= 16 and 13 * it_p <= 256, "scale": sc, "shift": sh, "mix": mk(Wm, bm),
+                           "residual": L.residual, "pos_out": pout, "C_out": Cout_p})
+        P["layers"] = layers
+        P["ok"] = all(F["grouped"] for F in layers)       # (wider towers: the per-tower layer path below serves the net)
+        fc0 = self.MLP_layer.FC_layers[0]
+        W0 = z(fc0.weight.shape[0], layers[-1]["C_out"])
+        W0[:, layers[-1]["pos_out"]] = fc0.weight.detach().float()
+        P["fc0"] = mk(W0, fc0.bias.detach().float())
+        c["pna_padded"] = P
+        return P
+
+    def _forward_eval_padded(self, plan, h, p, e, sn, avg_log):
+        """Eval forward on the padded layout (`_pna_padded`): all towers of a layer side by side, the pretrans gather folded into the
+        aggregation (sn_pna_aggregate_gather_f32): 7 launches per layer instead of 9 per tower, every Linear on the vector kernels."""
+        P = self._pna_padded()
+        N = h.shape[0]
+        x = ops.embedding_sum(h.long().reshape(N), [P["emb_h"]])
+        x = ops.masked_linear(p.contiguous().float(), P["emb_p"], residual=x)                                    # h + embedding_p(p)  (:124-126)
+        ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
+        for F in P["layers"]:
+            psd = ops.masked_linear(x, F["sd"])                                                                  # [N, 2C] = [W_s h | W_d h]
+            qe = ops.masked_linear(ef, F["e"])                                                                   # [E, C]  = W_e e + b
+            a = ops.pna_aggregate_gather(psd, qe, x, plan, avg_log, tower_width=F["it_p"])                       # (:50-56, :69), tower-major
+            hc = ops.grouped_linear(a, F["post_w"], F["post_b"], F["nt"], rowscale=sn, scale=F["scale"], shift=F["shift"])   # posttrans,
+            #                                                                                            * snorm_n, BatchNorm (:69-79)
+            mix = ops.masked_linear(hc, F["mix"])
+            x = ops.pointwise(mix, act="leaky", slope=0.01, residual=x if F["residual"] else None)               # FCLayer LeakyReLU + residual
+        self._h_last = x.index_select(1, P["layers"][-1]["pos_out"])
+        hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+        fcs = self.MLP_layer.FC_layers
+        hg = ops.masked_linear(hg, P["fc0"], relu=len(fcs) > 1)
+        for i, fc in enumerate(fcs[1:], 1):
+            hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
+        return hg
 
     def _forward_grad(self, plan, batch, ei, B, hidx, p, eidx, sn, avg_log):
         """Differentiable train-mode forward (SURVEY.md §8 f1 for this net): the same ops as autograd nodes with hand-written adjoints

@@ -633,9 +633,26 @@ def pna_aggregate(msg, hself, plan: GraphPlan, avg_log: float):
     return out
 
 
-def pna_aggregate_gather(psd, qe, hself, plan: GraphPlan, avg_log: float):
+def grouped_linear(x, W, bias, G, *, rowscale=None, scale=None, shift=None):
+    """y[:, g*dout:(g+1)*dout] = ((x[:, g*din:(g+1)*din] @ W[g]^T + b_g) * rowscale[row]) * scale + shift — G independent column groups
+    (a block-diagonal Linear); W [G, dout, din] float32 contiguous, dout <= 16, din % 4 == 0 and <= 256."""
+    require_cuda(x)
+    x = _f32c(x, "x")
+    Gn, dout, din = W.shape
+    if Gn != G or x.shape[-1] != G * din:
+        raise ValueError("grouped_linear: x must be [R, G*din] for W [G, dout, din]")
+    R = x.numel() // (G * din)
+    y = torch.empty(R, G * dout, dtype=torch.float32, device=x.device)
+    with _span("sn_grouped_linear_f32"):
+        check(lib().sn_grouped_linear_f32(ptr(x), G * din, R, G, din, dout, ptr(W), ptr(bias), ptr(rowscale), ptr(scale), ptr(shift), ptr(y),
+                                          G * dout, stream()), "sn_grouped_linear_f32")
+    return y
+
+
+def pna_aggregate_gather(psd, qe, hself, plan: GraphPlan, avg_log: float, tower_width: int = 0):
     """PNA aggregation with the pretrans message formed in the kernel: psd [N, 2C] = [W_s h | W_d h] per node, qe [E, C] = W_e e + b,
-    message (j -> n, e) = psd[j, :C] + psd[n, C:] + qe[e]; -> [N, 13*C] = cat[hself, scalers(aggregators(.))] (all towers side by side)."""
+    message (j -> n, e) = psd[j, :C] + psd[n, C:] + qe[e]; -> [N, 13*C] = cat[hself, scalers(aggregators(.))] (all towers side by side;
+    tower_width = it > 0: tower-major columns [tower][13 blocks][it], the input layout of grouped_linear)."""
     require_cuda(psd)
     psd, qe, hself = _f32c(psd, "psd"), _f32c(qe, "qe"), _f32c(hself, "hself")
     Cc = qe.shape[1]
@@ -644,7 +661,7 @@ def pna_aggregate_gather(psd, qe, hself, plan: GraphPlan, avg_log: float):
     out = torch.empty(plan.N, 13 * Cc, dtype=torch.float32, device=psd.device)
     with _span("sn_pna_aggregate_gather_f32"):
         check(lib().sn_pna_aggregate_gather_f32(psd.data_ptr(), 2 * Cc, psd.data_ptr() + 4 * Cc, 2 * Cc, ptr(qe), Cc, ptr(hself), Cc, Cc, plan.N,
-                                                ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm), float(avg_log), ptr(out), 13 * Cc, stream()),
+                                                ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm), float(avg_log), ptr(out), 13 * Cc, int(tower_width), stream()),
               "sn_pna_aggregate_gather_f32")
     return out
 

@@ -77,7 +77,8 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_pna_aggregate_f32": (None, 4, None, 4, 4, 2, None, None, 1.0, None, 52, None),
         "sn_ign_mlp_f32": (None, 1, 8, 32, 1, None, None, None),
         "sn_masked_linear_blockbias_f32": (None, 4, 4, 4, None, 4, None, None, 2, 4, 0, None, None, None, 4, None),
-        "sn_pna_aggregate_gather_f32": (None, 4, None, 4, None, 4, None, 4, 4, 2, None, None, None, 1.0, None, 52, None),
+        "sn_pna_aggregate_gather_f32": (None, 4, None, 4, None, 4, None, 4, 4, 2, None, None, None, 1.0, None, 52, 0, None),
+        "sn_grouped_linear_f32": (None, 8, 4, 2, 4, 4, None, None, None, None, None, None, 8, None),
         "sn_pna_aggregate_bwd_f32": (None, 4, 4, 2, None, None, 1.0, None, 52, None, None, None),
         "sn_edge_attention_f32": (None,) * 4 + (2, 2, 4) + (None,) * 5,
         "sn_edge_attention_bwd_f32": (None,) * 6 + (2, 2, 2, 4) + (None,) * 12,
