@@ -270,6 +270,28 @@ class EqDeepSetsEncoder(nn.Module):
                 self.bns.append(nn.BatchNorm1d(dims[i + 1], track_running_stats=False))
         self.use_bn = use_bn
 
+    def _packed(self):
+        """Eval cache: (lin1, lin2) of every layer as packed Linears (dropped by train(), .to(), load_state_dict())."""
+        if getattr(self, "_pk_cache", None) is None:
+            self._pk_cache = [(_lin(l1.weight, l1.bias), _lin(l2.weight, l2.bias)) for l1, l2 in zip(self.lins1, self.lins2)]
+        return self._pk_cache
+
+    def train(self, mode=True):
+        self._pk_cache = None
+        return super().train(mode)
+
+    def _apply(self, fn, *a, **k):
+        self._pk_cache = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._pk_cache = None
+        return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._pk_cache = None
+        return super()._load_from_state_dict(*a, **k)
+
     def forward(self, x, *args):
         ops.require_cuda(x)
         shp = x.shape
@@ -289,6 +311,20 @@ class EqDeepSetsEncoder(nn.Module):
                 h = AG.segment_bcast_add(AG.linear(h, l1.weight, l1.bias), x2, seg, relu=not last)
                 if self.use_bn and not last:
                     h = AG.bn_act(h, self.bns[i], relu=False)
+            return h.view(*shp[:-1], -1)
+        if not self.training:
+            # eval: lin1(x) + lin2(mean) as ONE Linear with a bias per block of n rows (the mean term), packed weights cached —
+            # no [b*n, 2 F] concatenation, no per-forward packing
+            P = self._packed()
+            for i in range(L):
+                last = i == L - 1
+                m = ops.segment_pool(h, seg, "mean")                                          # x.mean(dim=-2)
+                h = ops.linear_block_bias(h, P[i][0], ops.masked_linear(m, P[i][1]), n, relu=not last)
+                if self.use_bn and not last:
+                    bn = self.bns[i]
+                    mean, var, _ = ops.masked_colstats(h)                                     # stats over all b*n rows
+                    sc, sh = ops.bn_fold_stats(bn.weight.detach(), bn.bias.detach(), mean, var, bn.eps)
+                    h = ops.masked_affine(h, scale=sc, shift=sh)
             return h.view(*shp[:-1], -1)
         for i in range(L):
             l1, l2 = self.lins1[i], self.lins2[i]
