@@ -974,3 +974,56 @@ def test_sign_inv_net_overlap_mode_hands_its_output_over_with_an_event():
         assert getattr(net.sign_inv_net, "_side_stream", None) is not None
         for i, y in outs:
             assert torch.equal(y, ref[i]), name
+
+
+def test_round3_entry_points_against_float64():
+    """sn_grouped_linear_f32, sn_masked_linear_blockbias_f32, sn_pna_aggregate_gather_f32 (both output layouts) and sn_ign_mlp_f32 on their
+    own, against float64 restatements (the module tests above only see them through whole networks)."""
+    from signnet_basisnet_amd import basisnet as BNm
+    from signnet_basisnet_amd import ops, synth
+    g = torch.Generator().manual_seed(11)
+    # grouped (block-diagonal) Linear with row scale and affine epilogue
+    R, G, din, dout = 777, 5, 208, 14
+    x = torch.randn(R, G * din, generator=g)
+    W, b = torch.randn(G, dout, din, generator=g) / din ** 0.5, torch.randn(G * dout, generator=g)
+    rs, sc, sh = torch.rand(R, generator=g) + 0.5, torch.randn(G * dout, generator=g), torch.randn(G * dout, generator=g)
+    y = ops.grouped_linear(x.cuda(), W.cuda().contiguous(), b.cuda(), G, rowscale=rs.cuda(), scale=sc.cuda(), shift=sh.cuda()).cpu()
+    ref = torch.cat([x.double()[:, i * din:(i + 1) * din] @ W[i].double().t() for i in range(G)], 1)
+    ref = ((ref + b.double()) * rs.double()[:, None]) * sc.double() + sh.double()
+    close(y, ref, "grouped_linear", 2e-6)
+    # Linear with a bias per block of rows
+    nb, rpb, H = 7, 96, 32
+    h = torch.randn(nb * rpb, H, generator=g)
+    Wl, bl, bb = torch.randn(H, H, generator=g) / H ** 0.5, torch.randn(H, generator=g), torch.randn(nb, H, generator=g)
+    pl = ops.PackedLinear(ops.pack_weight(Wl.cuda().contiguous()), H, H, bl.cuda())
+    y = ops.linear_block_bias(h.cuda(), pl, bb.cuda(), rpb, relu_pre=True, scale=sc[:H].cuda().contiguous(), shift=sh[:H].cuda().contiguous()).cpu()
+    ref = torch.relu(h.double() @ Wl.double().t() + bl.double() + bb.double().repeat_interleave(rpb, 0)) * sc[:H].double() + sh[:H].double()
+    close(y, ref, "linear_block_bias", 2e-6)
+    # PNA aggregation with the message formed in the kernel == the message-array form on the summed messages
+    data = synth.make_batch(24, seed=8)
+    plan = ops.build_plan(data.batch.cuda(), data.edge_index.cuda(), 24, 0)
+    N, E, Cc = data.batch.numel(), data.edge_index.shape[1], 20
+    psd, qe, hs = torch.randn(N, 2 * Cc, generator=g), torch.randn(E, Cc, generator=g), torch.randn(N, Cc, generator=g)
+    src, dst = data.edge_index
+    msg = psd[src, :Cc] + psd[dst, Cc:] + qe
+    want = ops.pna_aggregate(msg.cuda(), hs.cuda(), plan, 1.3).cpu()
+    got = ops.pna_aggregate_gather(psd.cuda(), qe.cuda(), hs.cuda(), plan, 1.3).cpu()
+    close(got, want, "pna_aggregate_gather", 2e-6)
+    it = 5
+    tw = ops.pna_aggregate_gather(psd.cuda(), qe.cuda(), hs.cuda(), plan, 1.3, tower_width=it).cpu()
+    for t in range(Cc // it):
+        for j in range(13):
+            assert torch.equal(tw[:, t * 13 * it + j * it:t * 13 * it + (j + 1) * it], got[:, j * Cc + t * it:j * Cc + (t + 1) * it])
+    # the one-launch IGN head == the layer-at-a-time head (same module, fused_head off), several matrix sizes / widths
+    for (n, H, mult, bsz) in ((1024, 32, 2, 5), (100, 16, 1, 9), (333, 32, 32, 3)):
+        torch.manual_seed(n)
+        enc = BNm.IGN2to1(1, H, mult).cuda().eval()
+        with torch.no_grad():
+            for bn in enc.bns:
+                bn.running_mean.normal_(0, 0.1); bn.running_var.uniform_(0.5, 1.5)
+            o = torch.randn(bsz, n, 5, device="cuda")
+            y1 = enc.forward_contractions(o)
+            enc.fused_head = False
+            y0 = enc.forward_contractions(o)
+        assert y1.shape == y0.shape == (bsz, mult, n)
+        close(y1.cpu(), y0.cpu(), f"IGN head n={n} H={H}", 5e-6)
