@@ -129,6 +129,68 @@ class GINNet(_PackCache, nn.Module):
             raise ValueError("batch_num_nodes does not sum to the number of feature rows")
         return batch.long(), torch.stack([src.long(), dst.long()]), B
 
+    def _gin_padded(self):
+        """Eval cache: the net's parameters with every channel axis zero-padded to a multiple of 4 (pad rows / columns of the weights,
+        pad entries of biases and folded BatchNorms are zero, so pad channels stay exactly 0 through ReLU and the aggregations)."""
+        c = self.__dict__.setdefault("_cache", {})
+        if "gin_padded" in c:
+            return c["gin_padded"]
+        dev = self.embedding_h.weight.device
+        up = lambda k: (k + 3) // 4 * 4
+
+        def padw(W, b, rows, cols):
+            Wp = torch.zeros(rows, cols, dtype=torch.float32, device=dev)
+            Wp[:W.shape[0], :W.shape[1]] = W.detach().float()
+            bp = torch.zeros(rows, dtype=torch.float32, device=dev)
+            if b is not None:
+                bp[:b.shape[0]] = b.detach().float()
+            return ops.PackedLinear(ops.pack_weight(Wp), rows, cols, bp)
+
+        def padv(v, n_):
+            out = torch.zeros(n_, dtype=torch.float32, device=dev)
+            out[:v.shape[0]] = v
+            return out
+
+        class _Site:          # a folded BatchNorm on the padded channels (what _run_mlp reads)
+            def __init__(self, sc, sh):
+                self.scale, self.shift = sc, sh
+
+        hid = self.embedding_h.weight.shape[1]
+        E = torch.zeros(self.embedding_h.weight.shape[0], up(hid), dtype=torch.float32, device=dev)
+        E[:, :hid] = self.embedding_h.weight.detach().float()
+        P = {"emb_h": E, "emb_p": padw(self.embedding_p.weight, self.embedding_p.bias, up(hid), self.embedding_p.weight.shape[1])}
+        layers, keep = [], []
+        for conv in self.layers:
+            m = conv.apply_func
+            chain = []
+            for i, lin in enumerate(m.lins):
+                site = None
+                if m.use_bn and i < len(m.lins) - 1:
+                    s0 = self._bn(m.bns[i], False)
+                    site = _Site(padv(s0.scale, up(lin.weight.shape[0])), padv(s0.shift, up(lin.weight.shape[0])))
+                chain.append((padw(lin.weight, lin.bias, up(lin.weight.shape[0]), up(lin.weight.shape[1])), site))
+            # the whole MLP as one sn_mlp_chain_f32 launch: Linear -> ReLU -> [BatchNorm folded into the next Linear] ... -> Linear
+            fused = None
+            widths = [up(m.lins[0].weight.shape[1])] + [up(l.weight.shape[0]) for l in m.lins]
+            rp = max(48, 16 * ((max(widths) + 15) // 16))
+            if rp <= 128 and len(m.lins) <= 16:
+                from .dgl_deepsigns import _fold_bn_before, _pad_mat
+                import ctypes as C_
+                ws = []
+                for i, lin in enumerate(m.lins):
+                    site = self._bn(m.bns[i - 1], False) if (m.use_bn and i > 0) else None
+                    Wf, bf = _fold_bn_before(lin, site)
+                    ws.append(ops.pack_split(_pad_mat(Wf, rp), ops.pad_vec(bf, rp), None, None))
+                keep.extend(ws)
+                fused = ((C_.c_void_p * len(ws))(*[w.data_ptr() for w in ws]), len(ws), rp, up(m.lins[-1].weight.shape[0]))
+            layers.append((conv.eps, chain, fused))
+        P["layers"] = layers
+        P["keep"] = keep
+        fc0 = self.MLP_layer.FC_layers[0]
+        P["fc0"] = padw(fc0.weight, fc0.bias, fc0.weight.shape[0], up(fc0.weight.shape[1]))
+        c["gin_padded"] = P
+        return P
+
     def forward(self, g, h, p, e, snorm_n=None):
         _await_side(g)          # a sign_inv_net in overlap mode hands p over with an event kept on the graph
         ops.require_cuda(h)
@@ -144,6 +206,29 @@ class GINNet(_PackCache, nn.Module):
             y = self._forward_grad(plan, batch, ei, B, hidx, p)
         else:
             with torch.no_grad():
+                if not train and self.embedding_h.weight.shape[1] % 4:
+                    # eval, hidden width not a multiple of 4 (GIN_ZINC_LapPE_signinv_GIN.json: 95): every row would be misaligned and every
+                    # Linear on the scalar kernel; run on zero-padded channels instead (`_gin_padded`: 95 -> 96, all rows 16-byte aligned)
+                    P = self._gin_padded()
+                    x = ops.embedding_sum(hidx, [P["emb_h"]])
+                    x = ops.masked_linear(p, P["emb_p"], residual=x)
+                    for eps, chain, fused in P["layers"]:
+                        a = ops.gin_aggregate(x, plan, eps)
+                        if fused is None:
+                            x = _run_mlp(chain, a)
+                            continue
+                        ws, n_l, rp, d_out = fused                     # the layer's MLP in one launch (sn_mlp_chain_f32)
+                        x = torch.empty(a.shape[0], d_out, dtype=torch.float32, device=a.device)
+                        with ops._span("sn_mlp_chain_f32"):
+                            check(lib().sn_mlp_chain_f32(ptr(a), a.shape[1], a.shape[0], a.shape[1], None, 0, ws, n_l, rp, ptr(x), d_out, d_out,
+                                                         stream()), "sn_mlp_chain_f32")
+                    hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
+                    fcs = self.MLP_layer.FC_layers
+                    hg = ops.masked_linear(hg, P["fc0"], relu=len(fcs) > 1)
+                    for i, fc in enumerate(fcs[1:], 1):
+                        hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
+                    self.g = g
+                    return hg, g
                 x = ops.embedding_sum(hidx, [self.embedding_h.weight])
                 x = ops.masked_linear(p, self._pk(self.embedding_p), residual=x)                                              # h + embedding_p(p)   (:87-92)
                 for conv in self.layers:
