@@ -153,10 +153,14 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
   }
   const float* xr = a.x + row * a.ldx;
   float* yr = a.y + row * a.ldy;
+  // few rows: the output tiles are dealt to gridDim.y workgroups per row block (a [2 950, 236] x [236, 236] Linear was 47 workgroups
+  // walking 15 output tiles each: 82 us on a fifth of the chip)
+  const int otc = (a.nto + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int ot_lo = (int)blockIdx.y * otc, ot_hi = ot_lo + otc < a.nto ? ot_lo + otc : a.nto;
   if (__ballot(valid) == 0ull) {  // nothing valid in this tile: zeros
     if (inr) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      for (int ot = 0; ot < a.nto; ++ot) store4<YV>(yr, 16 * ot + 4 * g, a.d_out, z);
+      for (int ot = ot_lo; ot < ot_hi; ++ot) store4<YV>(yr, 16 * ot + 4 * g, a.d_out, z);
     }
     return;
   }
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
       if (kk < a.nti && valid) in[kk] = load4<XV>(xr, 16 * kk + 4 * g, a.d_in);
     }
   }
-  for (int ot = 0; ot < a.nto; ++ot) {
+  for (int ot = ot_lo; ot < ot_hi; ++ot) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const float4* wo = a.wp + (int64_t)ot * a.nti * 64;
     for (int kc = 0; kc < a.nti; kc += 8) {
@@ -1214,6 +1218,11 @@ static int masked_linear_impl(const float* x, int ldx, int64_t R, int d_in, cons
   const bool yv = (d_out % 4 == 0) && (ldy % 4 == 0) && al16(y) && (!bias || al16(bias)) && (!scale || al16(scale)) &&
                   (!shift || al16(shift)) && (!residual || (al16(residual) && ldr % 4 == 0)) && (!bbias || (al16(bbias) && ldbb % 4 == 0));
   dim3 grid((unsigned)cdiv(R, 64)), block(256);
+  {
+    const int64_t gx = cdiv(R, 64), nto = cdiv(d_out, 16);
+    int64_t ny = gx >= 512 ? 1 : cdiv(512, gx);
+    grid.y = (unsigned)(ny < nto ? ny : nto);
+  }
   hipStream_t st = (hipStream_t)stream;
   if (xv && yv && R >= LIN_LDS_MIN_ROWS) {
     const int rc = launch_linear_lds(a, nullptr, st);
