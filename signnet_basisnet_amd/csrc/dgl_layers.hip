@@ -339,6 +339,54 @@ __global__ __launch_bounds__(256) void k_pna_aggregate_bwd(const float* __restri
   }
 }
 
+// The same with a WAVE per (node, head): lane c owns channel c (C <= 64), the attention logits el = feat_j . attn_l, er = feat_i . attn_r
+// are wave reductions, the two passes over the in-edges (maximum, then weights and the weighted sum) read coalesced rows.  One THREAD
+// per (node, head) walking 59 channels serially was 176 us per layer on the shipped GAT (11 800 threads on a 256-CU part): 62 % of
+// the net's forward.
+__global__ __launch_bounds__(256) void k_gat_aggregate_wave(const float* __restrict__ feat, const float* __restrict__ attn_l,
+                                                            const float* __restrict__ attn_r, const float* __restrict__ bias, int64_t N,
+                                                            int H, int C, float slope, int relu, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col, float* __restrict__ out,
+                                                            float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i - n * H);
+  const int d = H * C;
+  const bool on = lane < C;
+  const float al = on ? attn_l[h * C + lane] : 0.f, ar = on ? attn_r[h * C + lane] : 0.f;
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  const float er = wsum(on ? feat[n * d + h * C + lane] * ar : 0.f);
+  const int lo = rowptr[n], hi = rowptr[n + 1];
+  float m = -INFINITY;
+  for (int e = lo; e < hi; ++e) {
+    const float fj = on ? feat[(int64_t)col[e] * d + h * C + lane] : 0.f;
+    float sc = wsum(fj * al) + er;
+    sc = sc > 0.f ? sc : sc * slope;
+    m = fmaxf(m, sc);
+  }
+  float acc = 0.f, z = 0.f;
+  for (int e = lo; e < hi; ++e) {
+    const float fj = on ? feat[(int64_t)col[e] * d + h * C + lane] : 0.f;
+    float sc = wsum(fj * al) + er;
+    sc = sc > 0.f ? sc : sc * slope;
+    const float w = expf(sc - m);
+    z += w;
+    acc += w * fj;
+  }
+  if (on) {
+    float v = (hi > lo ? acc / z : 0.f) + (bias ? bias[h * C + lane] : 0.f);
+    if (relu) v = fmaxf(v, 0.f);
+    out[n * d + h * C + lane] = v;
+  }
+  if (lse && lane == 0) lse[i] = hi > lo ? m + logf(z) : 0.f;
+}
+
 // adjoint of k_gat_aggregate, destination side — one thread per (node, head): with go = dout * [out > 0] and a_e = exp(s_e - lse),
 //   d s_e = a_e (go . f_src(e) - go . (out - bias)),   d pre_e = d s_e * leaky'(pre_e),   d er_n = sum_e d pre_e.
 // Writes go [N, H*C] (the bias gradient's rows, and what the source side needs), a_e and d pre_e per (edge id, head), d er [N, H].
@@ -651,7 +699,7 @@ extern "C" int sn_gat_aggregate_f32(const float* feat, const float* attn_l, cons
   SN_REQUIRE(feat && attn_l && attn_r && rowptr && out && N >= 0 && heads > 0, "sn_gat_aggregate_f32: bad arguments");
   SN_REQUIRE(C >= 1 && C <= 64, "sn_gat_aggregate_f32: head width %d not in [1, 64]", C);
   if (N == 0) return SN_OK;
-  hipLaunchKernelGGL(k_gat_aggregate, dim3((unsigned)cdiv(N * heads, 256)), dim3(256), 0, (hipStream_t)stream, feat, attn_l, attn_r, bias, N,
+  hipLaunchKernelGGL(k_gat_aggregate_wave, dim3((unsigned)cdiv(N * heads, 4)), dim3(256), 0, (hipStream_t)stream, feat, attn_l, attn_r, bias, N,
                      heads, C, negative_slope, relu, rowptr, col, out, lse);
   SN_CHECK_LAUNCH("sn_gat_aggregate_f32");
   return SN_OK;
