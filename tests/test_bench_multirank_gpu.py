@@ -31,6 +31,10 @@ def test_forward_bench_two_ranks():
     assert d["value"] > 0 and abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
     assert d["distributed"]["world_size"] == 2 and d["distributed"]["data_path_collectives"] == 0
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    # `value` is the loop with the module's overlap mode; the sequential pass (rounds 1-2's definition) rides along and carries the
+    # roofline's HIP events
+    assert "overlap_front=True" in d["config"]["module_mode"] and d["sequential"]["value"] > 0
+    assert d["roofline"]["timed_pass"] == "sequential"
 
 
 def test_train_bench_two_ranks_allreduces_the_flat_gradient():
@@ -38,6 +42,8 @@ def test_train_bench_two_ranks_allreduces_the_flat_gradient():
     assert d["n_gpus"] == 2 and d["value"] > 0
     g = d["distributed"]
     assert g["world_size"] == 2
+    # the captured step with a process group: replay per rank, then the flat gradient's all-reduce + Adam
+    assert d["graphed"]["value"] > 0 and "all-reduce" in d["graphed"]["note"] and d["eager"]["value"] > 0
 
 
 def test_plain_python_launch_reexecs_under_torchrun():
