@@ -785,6 +785,22 @@ typedef struct sn_ign_mlp_params {
 int sn_ign_mlp_supported(int n, int H, int O);
 int sn_ign_mlp_f32(const float* o, int64_t b, int n, int H, int O, const sn_ign_mlp_params* P, float* y, void* stream);
 
+/* EqDeepSetsEncoder (LearningFilters/models.py:58-113) behind its first layer's Linear, for ONE set (n * widest layer but the last <= 16384), in one launch:
+ * z [n, width[0]] = lin1_0(x) + lin2_0(mean x) (pre-activation; or its two halves, see split0); then for i = 1 .. n_layers-1:  h = relu(h); [BatchNorm over the n rows
+ * with gamma[i-1], beta[i-1] — track_running_stats = False: batch statistics in eval too];  h = w1[i] h + b1[i] + w2[i] mean_n(h) + b2[i].
+ * No ReLU / BatchNorm after the last layer.  w1 / w2 [width[i], width[i-1]] row-major; widths <= 32.  y [n, width[n_layers-1]]. */
+#define SN_DEEPSETS_MAX_LAYERS 8
+typedef struct sn_deepsets_tail_params {
+  int n_layers, use_bn;
+  float eps;
+  int split0;      /* 1: z is [n, 2 width[0]] = x [W1_0 ; W2_0]^T + [b1_0 ; b2_0] and the kernel forms z[:, :w] + mean_rows(z[:, w:]) */
+  int width[SN_DEEPSETS_MAX_LAYERS];
+  const float* w1[SN_DEEPSETS_MAX_LAYERS]; const float* b1[SN_DEEPSETS_MAX_LAYERS];
+  const float* w2[SN_DEEPSETS_MAX_LAYERS]; const float* b2[SN_DEEPSETS_MAX_LAYERS];
+  const float* gamma[SN_DEEPSETS_MAX_LAYERS]; const float* beta[SN_DEEPSETS_MAX_LAYERS];
+} sn_deepsets_tail_params;
+int sn_deepsets_tail_f32(const float* z, int n, const sn_deepsets_tail_params* P, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

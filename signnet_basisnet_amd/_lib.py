@@ -32,6 +32,7 @@ SIGNATURES = {
     "sn_gine_aggregate_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p, _p],
     "sn_masked_linear_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     "sn_ign_mlp_f32": [_p, _l, _i, _i, _i, _p, _p, _p],
+    "sn_deepsets_tail_f32": [_p, _i, _p, _p, _p],
     "sn_masked_linear_blockbias_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _l, _i, _i, _p, _p, _p, _i, _p],
     "sn_bn_fold_f32": [_p, _p, _p, _p, _f, _i, _i, _p, _p, _p],
     "sn_bn_running_update_f32": [_p, _p, _p, _f, _i, _p, _p, _p],

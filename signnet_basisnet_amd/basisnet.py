@@ -54,6 +54,14 @@ class _IgnMlpParams(C.Structure):
                                           "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
+_DS_MAX = 8
+
+
+class _DeepSetsTailParams(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("use_bn", C.c_int), ("eps", C.c_float), ("split0", C.c_int), ("width", C.c_int * _DS_MAX)] + \
+               [(n, C.c_void_p * _DS_MAX) for n in ("w1", "b1", "w2", "b2", "gamma", "beta")]
+
+
 def _lin(W, b):
     W = W.detach().contiguous()
     return ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], None if b is None else b.detach().reshape(-1).contiguous())
@@ -270,6 +278,37 @@ class EqDeepSetsEncoder(nn.Module):
                 self.bns.append(nn.BatchNorm1d(dims[i + 1], track_running_stats=False))
         self.use_bn = use_bn
 
+    fused_tail = True        # eval, one set of <= 1024 rows, widths <= 32 behind the first layer: sn_deepsets_tail_f32
+
+    def _tail_params(self):
+        """Eval cache: the parameter block of sn_deepsets_tail_f32 (None when a layer behind the first is wider than 32)."""
+        if getattr(self, "_tail_cache", None) is None:
+            L = len(self.lins1)
+            widths = [self.lins1[0].weight.shape[0]] + [self.lins1[i].weight.shape[0] for i in range(1, L)]
+            if L > _DS_MAX or max(widths) > 32:
+                self._tail_cache = (None,)
+            else:
+                f = lambda t: t.detach().float().contiguous()
+                P, keep = _DeepSetsTailParams(), []
+                P.n_layers, P.use_bn = L, int(self.use_bn)
+                P.eps = float(self.bns[0].eps) if self.use_bn else 1e-5
+                for i, w in enumerate(widths):
+                    P.width[i] = int(w)
+                for i in range(1, L):
+                    ts = [f(self.lins1[i].weight), f(self.lins1[i].bias), f(self.lins2[i].weight), f(self.lins2[i].bias)]
+                    keep += ts
+                    P.w1[i], P.b1[i], P.w2[i], P.b2[i] = (t.data_ptr() for t in ts)
+                    if self.use_bn:
+                        bn = self.bns[i - 1]
+                        gb = [f(bn.weight), f(bn.bias)]
+                        keep += gb
+                        P.gamma[i - 1], P.beta[i - 1] = gb[0].data_ptr(), gb[1].data_ptr()
+                P.split0 = 1
+                W01 = torch.cat([f(self.lins1[0].weight), f(self.lins2[0].weight)], 0).contiguous()
+                b01 = torch.cat([f(self.lins1[0].bias), f(self.lins2[0].bias)], 0).contiguous()
+                self._tail_cache = (P, keep, ops.PackedLinear(ops.pack_weight(W01), W01.shape[0], W01.shape[1], b01))
+        return None if self._tail_cache[0] is None else self._tail_cache
+
     def _packed(self):
         """Eval cache: (lin1, lin2) of every layer as packed Linears (dropped by train(), .to(), load_state_dict())."""
         if getattr(self, "_pk_cache", None) is None:
@@ -277,19 +316,19 @@ class EqDeepSetsEncoder(nn.Module):
         return self._pk_cache
 
     def train(self, mode=True):
-        self._pk_cache = None
+        self._pk_cache = self._tail_cache = None
         return super().train(mode)
 
     def _apply(self, fn, *a, **k):
-        self._pk_cache = None
+        self._pk_cache = self._tail_cache = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._pk_cache = None
+        self._pk_cache = self._tail_cache = None
         return super().load_state_dict(*a, **k)
 
     def _load_from_state_dict(self, *a, **k):
-        self._pk_cache = None
+        self._pk_cache = self._tail_cache = None
         return super()._load_from_state_dict(*a, **k)
 
     def forward(self, x, *args):
@@ -316,6 +355,17 @@ class EqDeepSetsEncoder(nn.Module):
             # eval: lin1(x) + lin2(mean) as ONE Linear with a bias per block of n rows (the mean term), packed weights cached —
             # no [b*n, 2 F] concatenation, no per-forward packing
             P = self._packed()
+            tail = self._tail_params() if (b == 1 and L >= 2 and self.fused_tail) else None
+            if tail is not None and n * max(tail[0].width[i] for i in range(L - 1)) > 16384:
+                tail = None
+            if tail is not None:
+                # one set: x [W1 ; W2]^T as ONE GEMM (the set mean commutes with lin2: mean(x) W2^T = mean(x W2^T)), then everything else in
+                # ONE launch (sn_deepsets_tail_f32)
+                z = ops.masked_linear(h, tail[2])
+                y = torch.empty(n, self.lins1[-1].weight.shape[0], dtype=torch.float32, device=z.device)
+                with ops._span("sn_deepsets_tail_f32"):
+                    check(lib().sn_deepsets_tail_f32(ptr(z), n, C.byref(tail[0]), ptr(y), stream()), "sn_deepsets_tail_f32")
+                return y.view(*shp[:-1], -1)
             for i in range(L):
                 last = i == L - 1
                 m = ops.segment_pool(h, seg, "mean")                                          # x.mean(dim=-2)

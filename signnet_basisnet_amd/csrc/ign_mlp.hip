@@ -216,3 +216,130 @@ extern "C" int sn_ign_mlp_f32(const float* o, int64_t b, int n, int H, int O, co
   SN_CHECK_LAUNCH("sn_ign_mlp_f32");
   return SN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// EqDeepSetsEncoder (LearningFilters/models.py:58-113) behind its first Linear, ONE set (b = 1), eval / no-grad value, in one launch:
+//   h = z (the first layer's lin1(x) + lin2(mean x), pre-activation);   for every further layer i:
+//   h = relu(h);  [h = BatchNorm(h) with the statistics of the n rows (track_running_stats = False: always batch statistics)];
+//   h = W1_i h + b1_i + W2_i mean_n(h) + b2_i          (no ReLU / BatchNorm after the last layer)
+// One workgroup of 1024 threads; the [n, width] activations stay in LDS (n * width <= 16384); column means / variances are block
+// reductions (two passes: mean, then sum (x - mean)^2, as sn_masked_colstats_f32 does).  The layer-at-a-time
+// path spent ~10 launches of 5-20 us per layer on a [1024, 10] matrix.
+namespace sn {
+namespace {
+constexpr int DS_T = 1024, DS_W = 32, DS_BUF = 16384;      // threads; widest layer; floats per activation buffer (n * width)
+
+__global__ __launch_bounds__(DS_T) void k_deepsets_tail(const float* __restrict__ z, int n, sn_deepsets_tail_params P, float* __restrict__ y) {
+  // the activations [n][width] live in LDS (two buffers); every step is a flat loop over its elements — (row, channel) pairs — so the
+  // small widths (10 in the LearningFilters model) cost what they are, not a padded 32 x 32 tile per row
+  extern __shared__ __align__(16) float ds_lds[];
+  float* A = ds_lds;
+  float* Bf = ds_lds + DS_BUF;
+  __shared__ float WA[DS_W * DS_W], WB[DS_W * DS_W], V[6][DS_W], RED[32][DS_W + 1];
+  const int tid = threadIdx.x;
+  int din = P.width[0];
+  const float inv_n = 1.0f / (float)n;
+  if (P.split0) {
+    // z = x [W1 ; W2]^T + [b1 ; b2]  ([n, 2 width0], ONE GEMM of the caller): the first layer is z[:, :w] + mean_rows(z[:, w:]) — the mean of
+    // the set commutes with lin2, so the [n, F] column mean of the (wide) input is never formed
+    const int c = tid & 31, rl = tid >> 5;
+    float sm = 0.f;
+    if (c < din)
+      for (int r = rl; r < n; r += 32) sm += z[(int64_t)r * 2 * din + din + c];
+    RED[rl][c] = sm;
+    __syncthreads();
+    if (tid < DS_W) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) t += RED[q][tid];
+      V[0][tid] = t * inv_n;
+    }
+    __syncthreads();
+    for (int i = tid; i < n * din; i += DS_T) { const int r = i / din, cc = i - r * din; A[i] = z[(int64_t)r * 2 * din + cc] + V[0][cc]; }
+  } else {
+    for (int i = tid; i < n * din; i += DS_T) A[i] = z[i];
+  }
+  // V[slot][c] = sum over the rows of f(A[r][c])   (32 row lanes per column, then a fixed-order fold)
+  auto colsum = [&](int slot, int width, auto f) {
+    __syncthreads();
+    const int c = tid & 31, rl = tid >> 5;
+    float s = 0.f;
+    if (c < width)
+      for (int r = rl; r < n; r += 32) s += f(A[r * width + c], c);
+    RED[rl][c] = s;
+    __syncthreads();
+    if (tid < DS_W) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) t += RED[q][tid];
+      V[slot][tid] = t;
+    }
+    __syncthreads();
+  };
+  for (int i = 1; i < P.n_layers; ++i) {
+    const int dout = P.width[i];
+    __syncthreads();
+    for (int k = tid; k < dout * din; k += DS_T) { WA[k] = P.w1[i][k]; WB[k] = P.w2[i][k]; }
+    if (tid < DS_W) {
+      V[3][tid] = tid < dout ? P.b1[i][tid] + P.b2[i][tid] : 0.f;
+      V[4][tid] = (P.use_bn && tid < din) ? P.gamma[i - 1][tid] : 1.f;
+      V[5][tid] = (P.use_bn && tid < din) ? P.beta[i - 1][tid] : 0.f;
+    }
+    for (int k = tid; k < n * din; k += DS_T) A[k] = fmaxf(A[k], 0.f);
+    colsum(0, din, [](float v, int) { return v; });                                     // V[0] = sum h
+    if (P.use_bn) {
+      colsum(1, din, [&](float v, int c) { const float d = v - V[0][c] * inv_n; return d * d; });      // V[1] = sum (h - mean)^2
+      if (tid < DS_W && tid < din) {            // fold to scale | shift (in V[4] | V[5]); the normalised mean is then the shift + ...
+        const float mean = V[0][tid] * inv_n, var = V[1][tid] * inv_n;
+        const float sc = V[4][tid] / sqrtf(var + P.eps);
+        V[5][tid] = V[5][tid] - mean * sc;
+        V[4][tid] = sc;
+      }
+      __syncthreads();
+      for (int k = tid; k < n * din; k += DS_T) { const int c = k % din; A[k] = A[k] * V[4][c] + V[5][c]; }
+      colsum(0, din, [](float v, int) { return v; });                                   // V[0] = sum of the normalised rows
+    }
+    if (tid < DS_W) {                                                                   // V[2] = W2 mean + b1 + b2
+      float s = V[3][tid];
+      if (tid < dout)
+        for (int d = 0; d < din; ++d) s += WB[tid * din + d] * (V[0][d] * inv_n);
+      V[2][tid] = s;
+    }
+    __syncthreads();
+    float* dst = (i == P.n_layers - 1) ? y : Bf;          // the last layer goes straight to global memory (it may be the widest)
+    for (int k = tid; k < n * dout; k += DS_T) {
+      const int r = k / dout, o = k - r * dout;
+      float a = V[2][o];
+      const float* hr = A + r * din;
+      const float* wr = WA + o * din;
+      for (int d = 0; d < din; ++d) a += wr[d] * hr[d];
+      dst[k] = a;
+    }
+    __syncthreads();
+    float* t = A; A = Bf; Bf = t;
+    din = dout;
+  }
+}
+}  // namespace
+}  // namespace sn
+
+extern "C" int sn_deepsets_tail_f32(const float* z, int n, const sn_deepsets_tail_params* P, float* y, void* stream) {
+  SN_REQUIRE(z && P && y && n >= 1, "sn_deepsets_tail_f32: bad arguments");
+  SN_REQUIRE(P->n_layers >= 2 && P->n_layers <= SN_DEEPSETS_MAX_LAYERS, "sn_deepsets_tail_f32: 2 .. %d layers", SN_DEEPSETS_MAX_LAYERS);
+  for (int i = 0; i < P->n_layers; ++i) SN_REQUIRE(P->width[i] >= 1 && P->width[i] <= sn::DS_W, "sn_deepsets_tail_f32: layer widths up to 32");
+  for (int i = 1; i < P->n_layers; ++i)
+    SN_REQUIRE(P->w1[i] && P->w2[i] && P->b1[i] && P->b2[i] && (!P->use_bn || (P->gamma[i - 1] && P->beta[i - 1])), "sn_deepsets_tail_f32: missing parameter");
+  int wmax = 0;
+  for (int i = 0; i + 1 < P->n_layers; ++i) wmax = P->width[i] > wmax ? P->width[i] : wmax;
+  SN_REQUIRE((int64_t)n * wmax <= sn::DS_BUF, "sn_deepsets_tail_f32: n * widest layer but the last must be <= 16384");
+  const size_t lds = (size_t)2 * sn::DS_BUF * sizeof(float);
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sn::k_deepsets_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return sn::fail(SN_ERR_LAUNCH, "sn_deepsets_tail_f32: cannot raise the dynamic LDS limit");
+    raised = true;
+  }
+  hipLaunchKernelGGL(sn::k_deepsets_tail, dim3(1), dim3(sn::DS_T), lds, (hipStream_t)stream, z, n, *P, y);
+  SN_CHECK_LAUNCH("sn_deepsets_tail_f32");
+  return SN_OK;
+}

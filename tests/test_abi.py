@@ -76,6 +76,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_ign_contract_eigvecs_f32": (None, 4, 4, None, None, 1, 1, None, None),
         "sn_pna_aggregate_f32": (None, 4, None, 4, 4, 2, None, None, 1.0, None, 52, None),
         "sn_ign_mlp_f32": (None, 1, 8, 32, 1, None, None, None),
+        "sn_deepsets_tail_f32": (None, 8, None, None, None),
         "sn_masked_linear_blockbias_f32": (None, 4, 4, 4, None, 4, None, None, 2, 4, 0, None, None, None, 4, None),
         "sn_pna_aggregate_gather_f32": (None, 4, None, 4, None, 4, None, 4, 4, 2, None, None, None, 1.0, None, 52, 0, None),
         "sn_grouped_linear_f32": (None, 8, 4, 2, 4, 4, None, None, None, None, None, None, 8, None),
@@ -113,6 +114,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(sn_gatedgcn_layer), sizeof(sn_gatedgcn_params), offsetof(sn_gatedgcn_params, layers),
          offsetof(sn_gatedgcn_params, ro_w0));
   printf("%zu %zu\n", sizeof(sn_ign_mlp_params), offsetof(sn_ign_mlp_params, fc2_b));
+  printf("%zu %zu %zu\n", sizeof(sn_deepsets_tail_params), offsetof(sn_deepsets_tail_params, width), offsetof(sn_deepsets_tail_params, gamma));
   printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sn_train_linear_args), offsetof(sn_train_linear_args, in_scale),
          offsetof(sn_train_linear_args, stat_part), sizeof(sn_train_linear_bwd_args), offsetof(sn_train_linear_bwd_args, x_mean),
          offsetof(sn_train_linear_bwd_args, dot_part), sizeof(sn_train_scalar_mlp_args), offsetof(sn_train_scalar_mlp_args, w2),
@@ -132,6 +134,7 @@ int main(void) {
             fused._PhiParams.layers.offset, fused._RhoParams.layers.offset, fused._RhoParams.pe_w1.offset,
             S(dgl_nets._GatedLayerC), S(dgl_nets._GatedParamsC), dgl_nets._GatedParamsC.layers.offset, dgl_nets._GatedParamsC.ro_w0.offset,
             S(basisnet._IgnMlpParams), basisnet._IgnMlpParams.fc2_b.offset,
+            S(basisnet._DeepSetsTailParams), basisnet._DeepSetsTailParams.width.offset, basisnet._DeepSetsTailParams.gamma.offset,
             S(train_stage._LinArgs), train_stage._LinArgs.in_scale.offset, train_stage._LinArgs.stat_part.offset,
             S(train_stage._BwdArgs), train_stage._BwdArgs.x_mean.offset, train_stage._BwdArgs.dot_part.offset,
             S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset]

@@ -1027,3 +1027,30 @@ def test_round3_entry_points_against_float64():
             y0 = enc.forward_contractions(o)
         assert y1.shape == y0.shape == (bsz, mult, n)
         close(y1.cpu(), y0.cpu(), f"IGN head n={n} H={H}", 5e-6)
+
+
+def test_deepsets_tail_kernel_equals_the_layer_path():
+    """sn_deepsets_tail_f32 (one set, everything behind the first layer's Linear in one launch) == the layer-at-a-time eval path and the
+    float64 restatement of EqDeepSetsEncoder.forward, with and without the batch-statistics BatchNorm."""
+    from signnet_basisnet_amd import basisnet as BNm
+    for (n, fin, hid, out, L, use_bn) in ((1024, 2048, 10, 32, 3, True), (300, 37, 32, 7, 4, False), (77, 12, 16, 16, 2, True)):
+        torch.manual_seed(n)
+        enc = BNm.EqDeepSetsEncoder(fin, hidden_channels=hid, num_layers=L, out_channels=out, use_bn=use_bn).cuda().eval()
+        x = torch.randn(n, fin, device="cuda")
+        with torch.no_grad():
+            y1 = enc(x)
+            enc.fused_tail = False
+            y0 = enc(x)
+            # float64 restatement (models.py:58-113)
+            h = x.double().cpu()
+            for i in range(L):
+                l1, l2 = enc.lins1[i], enc.lins2[i]
+                h = h @ l1.weight.double().cpu().t() + l1.bias.double().cpu() + (h.mean(0, keepdim=True) @ l2.weight.double().cpu().t() + l2.bias.double().cpu())
+                if i < L - 1:
+                    h = torch.relu(h)
+                    if use_bn:
+                        bn = enc.bns[i]
+                        h = (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + bn.eps) * bn.weight.double().cpu() + bn.bias.double().cpu()
+        assert y1.shape == y0.shape == (n, out)
+        close(y1.cpu(), h, f"deepsets tail vs float64 n={n}", 2e-5)
+        close(y1.cpu(), y0.cpu(), f"deepsets tail vs layer path n={n}", 2e-5)
