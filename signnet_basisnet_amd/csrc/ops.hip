@@ -222,6 +222,73 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
   }
 }
 
+// Deep and narrow (d_in >= 512, d_out <= 64) on few rows — e.g. the first layer of LearningFilters' DeepSets rho, [1024, 2048] x [2048, 20]:
+// k_linear gives every wave a 16-row tile and the whole K loop (128 dependent 16-wide steps, 32 workgroups on the chip: 71 us).  Here
+// the four waves of a workgroup share ONE 16-row tile and split the K tiles round-robin; the partial accumulators meet in LDS and wave 0
+// adds them in wave order (deterministic) and runs k_linear's epilogue.  grid = row tiles.
+template <bool XV, bool YV>
+__global__ __launch_bounds__(256) void k_linear_ksplit(LinArgs a) {
+  __shared__ float4 part[4][4][64];                  // [wave][output tile][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (lane & 15);
+  const bool inr = row < a.R;
+  bool valid = inr;
+  if (inr && a.nvalid) {
+    const int64_t node = row / a.K;
+    valid = (int)(row - node * a.K) < a.nvalid[node];
+  }
+  const float* xr = a.x + row * a.ldx;
+  f32x4 acc[4];
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kk = wave; kk < a.nti; kk += 4) {
+    f32x4 in = {0.f, 0.f, 0.f, 0.f};
+    if (valid) in = load4<XV>(xr, 16 * kk + 4 * g, a.d_in);
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+      if (ot < a.nto) {
+        const float4 w = a.wp[((int64_t)ot * a.nti + kk) * 64 + lane];
+        acc[ot] = mfma16(w.x, in[0], acc[ot]);
+        acc[ot] = mfma16(w.y, in[1], acc[ot]);
+        acc[ot] = mfma16(w.z, in[2], acc[ot]);
+        acc[ot] = mfma16(w.w, in[3], acc[ot]);
+      }
+    }
+  }
+#pragma unroll
+  for (int ot = 0; ot < 4; ++ot) part[wave][ot][lane] = make_float4(acc[ot][0], acc[ot][1], acc[ot][2], acc[ot][3]);
+  __syncthreads();
+  if (wave != 0) return;
+  float* yr = a.y + row * a.ldy;
+  for (int ot = 0; ot < a.nto; ++ot) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const float4 t = part[w][ot][lane]; v += f32x4{t.x, t.y, t.z, t.w}; }
+    const int o0 = 16 * ot + 4 * g;
+    if (!valid) {
+      v = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      if (a.flags & SN_EPI_BIAS) v += load4<YV>(a.bias, o0, a.d_out);
+      if (a.flags & SN_EPI_BLOCK_BIAS) v += load4<YV>(a.bbias + (row / a.bb_rows) * a.ldbb, o0, a.d_out);
+      if (a.flags & SN_EPI_RELU_PRE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.flags & SN_EPI_AFFINE) {
+        const f32x4 sc = load4<YV>(a.scale, o0, a.d_out), sh = load4<YV>(a.shift, o0, a.d_out);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      }
+      if (a.flags & SN_EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.flags & SN_EPI_RESIDUAL) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
+    }
+    if (inr) store4<YV>(yr, o0, a.d_out, v);
+  }
+}
+
 // Large row counts: the packed weight is staged ONCE per workgroup in LDS (k_linear fetches it from L2 per wave and per output
 // tile: at 47 k rows x 128 x 128 the fp32 matrix pipe was a third busy) and every wave walks a grid-stride sequence of 16-row tiles
 // with the whole tile's operand in registers; two output tiles are accumulated at a time (two independent MFMA chains).  The
@@ -1227,6 +1294,15 @@ static int masked_linear_impl(const float* x, int ldx, int64_t R, int d_in, cons
   if (xv && yv && R >= LIN_LDS_MIN_ROWS) {
     const int rc = launch_linear_lds(a, nullptr, st);
     if (rc != 1) { if (rc != SN_OK) return rc; SN_CHECK_LAUNCH("sn_masked_linear_f32"); return SN_OK; }
+  }
+  if (a.nti >= 32 && a.nto <= 4 && R <= 8192) {        // deep, narrow, few rows: split K over the waves of a workgroup
+    const dim3 gk((unsigned)cdiv(R, 16));
+    if (xv && yv) hipLaunchKernelGGL((k_linear_ksplit<true, true>), gk, block, 0, st, a);
+    else if (xv) hipLaunchKernelGGL((k_linear_ksplit<true, false>), gk, block, 0, st, a);
+    else if (yv) hipLaunchKernelGGL((k_linear_ksplit<false, true>), gk, block, 0, st, a);
+    else hipLaunchKernelGGL((k_linear_ksplit<false, false>), gk, block, 0, st, a);
+    SN_CHECK_LAUNCH("sn_masked_linear_f32");
+    return SN_OK;
   }
   if (xv && yv) hipLaunchKernelGGL((k_linear<true, true>), grid, block, 0, st, a);
   else if (xv) hipLaunchKernelGGL((k_linear<true, false>), grid, block, 0, st, a);

@@ -185,7 +185,7 @@ def test_gine_aggregate(batch, dev, C):
     assert torch.equal(out.cpu(), O.gine_aggregate(x, data.edge_index, e, eps))
 
 
-@pytest.mark.parametrize("d_in,d_out", [(1, 1), (1, 128), (128, 128), (108, 108), (6, 44), (256, 128), (95, 4), (300, 70)])
+@pytest.mark.parametrize("d_in,d_out", [(1, 1), (1, 128), (128, 128), (108, 108), (6, 44), (256, 128), (95, 4), (300, 70), (2048, 20), (600, 33)])
 def test_masked_linear(batch, dev, d_in, d_out):
     from signnet_basisnet_amd import ops
     data, d, plan = batch
