@@ -1612,10 +1612,9 @@ __host__ __device__ constexpr int ign_strip(int n) { return n >= 512 ? 128 : IGN
 
 __global__ __launch_bounds__(256) void k_ign_rowcol(const float* __restrict__ X, int n, int nstrips,
                                                     float* __restrict__ rowsum /* [b,n] */, float* __restrict__ diag /* [b,n] */,
-                                                    float* __restrict__ colpart /* [b,nstrips,n] */) {
+                                                    float* __restrict__ colpart /* [b,nstrips,n] */, int strip) {
   __shared__ float red[4];
   const int b = blockIdx.x / nstrips, st = blockIdx.x - b * nstrips;
-  const int strip = ign_strip(n);
   const int r0 = st * strip, r1 = (r0 + strip < n) ? r0 + strip : n;
   const float* Xb = X + (int64_t)b * n * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1655,10 +1654,9 @@ __global__ __launch_bounds__(256) void k_ign_rowcol(const float* __restrict__ X,
 // the loads of several rows are in flight per wave (the scalar kernel above synchronises the block twice per row).
 __global__ __launch_bounds__(256) void k_ign_rowcol_v4(const float* __restrict__ X, int n, int nstrips,
                                                        float* __restrict__ rowsum, float* __restrict__ diag,
-                                                       float* __restrict__ colpart) {
+                                                       float* __restrict__ colpart, int strip) {
   __shared__ float4 fold[4][256];
   const int b = blockIdx.x / nstrips, st = blockIdx.x - b * nstrips;
-  const int strip = ign_strip(n);
   const int r0 = st * strip, r1 = (r0 + strip < n) ? r0 + strip : n;
   const float* Xb = X + (int64_t)b * n * n;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1769,16 +1767,20 @@ extern "C" int64_t sn_ign_contract_scratch_floats(int64_t b, int n) {
 extern "C" int sn_ign_contract_2to1_f32(const float* X, int64_t b, int n, float* ops_out, float* scratch, void* stream) {
   SN_REQUIRE(X && ops_out && scratch && b >= 0 && n > 0, "sn_ign_contract_2to1_f32: bad arguments");
   if (b == 0) return SN_OK;
-  const int nstrips = (int)sn::cdiv(n, sn::ign_strip(n));
+  // 128-row strips from n = 512 on — unless that leaves most of the chip without a workgroup (one 1024 x 1024 projector: 8 strips):
+  // then the 64-row strips the scratch is sized for
+  int strip = sn::ign_strip(n);
+  if (b * sn::cdiv(n, strip) < 256) strip = sn::IGN_STRIP_MIN;
+  const int nstrips = (int)sn::cdiv(n, strip);
   SN_REQUIRE(b * nstrips < (1ll << 31), "sn_ign_contract_2to1_f32: too many workgroups");
   float* rowsum = scratch;
   float* diag = scratch + b * n;
   float* colpart = scratch + 2 * b * n;
   hipStream_t st = (hipStream_t)stream;
   if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(scratch) & 15) == 0)
-    hipLaunchKernelGGL(sn::k_ign_rowcol_v4, dim3((unsigned)(b * nstrips)), dim3(256), 0, st, X, n, nstrips, rowsum, diag, colpart);
+    hipLaunchKernelGGL(sn::k_ign_rowcol_v4, dim3((unsigned)(b * nstrips)), dim3(256), 0, st, X, n, nstrips, rowsum, diag, colpart, strip);
   else
-    hipLaunchKernelGGL(sn::k_ign_rowcol, dim3((unsigned)(b * nstrips)), dim3(256), 0, st, X, n, nstrips, rowsum, diag, colpart);
+    hipLaunchKernelGGL(sn::k_ign_rowcol, dim3((unsigned)(b * nstrips)), dim3(256), 0, st, X, n, nstrips, rowsum, diag, colpart, strip);
   hipLaunchKernelGGL(sn::k_ign_finish, dim3((unsigned)b), dim3(256), 0, st, rowsum, diag, colpart, n, nstrips, ops_out);
   SN_CHECK_LAUNCH("sn_ign_contract_2to1_f32");
   return SN_OK;
