@@ -880,25 +880,35 @@ __global__ __launch_bounds__(256) void k_tbn_bwd_finish(const float* __restrict_
 }
 
 // out[i] (+)= sum_b part[b*stride + i]   (partials added in block order)
-__global__ __launch_bounds__(256) void k_tsum_parts(const float* __restrict__ part, int nparts, int64_t stride, int64_t n,
-                                                    float* __restrict__ out, int accumulate) {
-  // 64 outputs per block, 4 lanes per output: lane q adds the partials b = q, q+4, ... in order (independent loads), then q = 0..3 in order
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void k_tsum_parts(const float* __restrict__ part, int nparts, int64_t stride, int64_t n,
+                                                     float* __restrict__ out, int accumulate) {
+  // 64 outputs per block, 16 lanes per output: lane q adds the partials b = q, q + 16, ... in order, eight loads in flight (with 4 lanes
+  // and 4 loads in flight the 256 partials of a large link were 16 dependent round trips: 6.6 us x 26 launches a step), then the 16
+  // lanes in order
+  __shared__ float red[16][64];
   const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + c;
   float acc = 0.f;
   if (i < n) {
+    const float* src = part + i;
     int b = q;
-    for (; b + 12 < nparts; b += 16) {
-      const float v0 = part[(int64_t)b * stride + i], v1 = part[(int64_t)(b + 4) * stride + i], v2 = part[(int64_t)(b + 8) * stride + i],
-                  v3 = part[(int64_t)(b + 12) * stride + i];
-      acc = (((acc + v0) + v1) + v2) + v3;
+    for (; b + 7 * 16 < nparts; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 16 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; b < nparts; b += 4) acc += part[(int64_t)b * stride + i];
+    for (; b < nparts; b += 16) acc += src[(int64_t)b * stride];
   }
   red[q][c] = acc;
   __syncthreads();
-  if (q == 0 && i < n) out[i] = (accumulate ? out[i] : 0.f) + (((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+  if (q == 0 && i < n) {
+    float t = red[0][c];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += red[w][c];
+    out[i] = (accumulate ? out[i] : 0.f) + t;
+  }
 }
 
 // y = [relu](z * scale[g] + shift[g]) [+ res] on valid rows, 0 elsewhere (the last BatchNorm of a stack, whose output is materialised:
@@ -1480,7 +1490,7 @@ extern "C" int sn_train_dot_finish_f64(const double* part, int n, float* out, in
 extern "C" int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int64_t n, float* out, int accumulate, void* stream) {
   SN_REQUIRE(part && out && nparts >= 1 && n >= 0 && stride >= n, "sn_train_reduce_parts_f32: bad arguments");
   if (n == 0) return SN_OK;
-  hipLaunchKernelGGL(k_tsum_parts, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, nparts, stride, n, out, accumulate);
+  hipLaunchKernelGGL(k_tsum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, (hipStream_t)stream, part, nparts, stride, n, out, accumulate);
   SN_CHECK_LAUNCH("sn_train_reduce_parts_f32");
   return SN_OK;
 }
