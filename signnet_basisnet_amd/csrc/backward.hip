@@ -427,11 +427,22 @@ __global__ __launch_bounds__(256) void k_gine_bwd(const float* __restrict__ h, c
   const int c = (int)(idx - j * C);
   const float hv = h[idx];
   float acc = (1.0f + (eps ? *eps : 0.f)) * g[idx];
-  for (int s = rrow[j]; s < rrow[j + 1]; ++s) {
-    const int64_t e = rperm[s];
-    const float gi = (hv + ee[e * C + c] > 0.f) ? g[(int64_t)rcol[s] * C + c] : 0.f;
-    acc += gi;
-    dee[e * C + c] = gi;
+  const int lo = rrow[j], hi = rrow[j + 1];
+  for (int s0 = lo; s0 < hi; s0 += 4) {        // four out-edges in flight: ids, then their ee / g rows (one at a time the pass was a
+    int64_t e[4], d[4];                        // chain of dependent L2 round trips: 11.6 us for 3 MB)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { e[u] = 0; d[u] = 0; if (s0 + u < hi) { e[u] = rperm[s0 + u]; d[u] = rcol[s0 + u]; } }
+    float ev[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ev[u] = 0.f; gv[u] = 0.f; if (s0 + u < hi) { ev[u] = ee[e[u] * C + c]; gv[u] = g[d[u] * C + c]; } }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + u < hi) {
+        const float gi = (hv + ev[u] > 0.f) ? gv[u] : 0.f;
+        acc += gi;
+        dee[e[u] * C + c] = gi;
+      }
+    }
   }
   dh[idx] = plus ? acc + plus[idx] : acc;      // plus: the gradient of the residual branch of h, added in the same pass
 }

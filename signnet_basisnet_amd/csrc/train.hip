@@ -47,6 +47,10 @@ __device__ __forceinline__ void st4a(float* __restrict__ p, int c0, int C, f32x4
 __device__ __forceinline__ bool row_ok(int64_t r, int64_t R, const int32_t* __restrict__ nvalid, int K) {
   if (r >= R) return false;
   if (!nvalid) return true;
+  if (R <= 0x7fffffffll) {         // (a 64-bit division is ~100 instructions: per row and thread it was most of the pointwise kernels)
+    const uint32_t ru = (uint32_t)r, node = ru / (uint32_t)K;
+    return (int)(ru - node * (uint32_t)K) < nvalid[node];
+  }
   const int64_t node = r / K;
   return (int)(r - node * K) < nvalid[node];
 }
@@ -1078,9 +1082,17 @@ __global__ __launch_bounds__(256) void k_smlp_apply(SMlp p, float* __restrict__ 
   const int C4 = p.d >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)p.G * p.M * C4) return;
-  const int64_t row = idx / C4;
+  int64_t row;
+  int grp;
+  if ((int64_t)p.G * p.M * C4 <= 0x7fffffffll) {          // 32-bit index arithmetic when it fits
+    const uint32_t rw = (uint32_t)idx / (uint32_t)C4;
+    row = rw;
+    grp = (int)(rw / (uint32_t)p.M);
+  } else {
+    row = idx / C4;
+    grp = (int)(row / p.M);
+  }
   const int c0 = 4 * (int)(idx - row * C4);
-  const int grp = (int)(row / p.M);
   const int64_t r = row - (int64_t)grp * p.M;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (row_ok(r, p.M, p.nvalid, p.K)) {
@@ -1107,6 +1119,7 @@ __global__ __launch_bounds__(256) void k_smlp_bwd_pass(SMlp p, const float* __re
   __shared__ float rsum[256];
   const float s3 = (float)p.sst[grp * 8 + 3], s4 = (float)p.sst[grp * 8 + 4], s5 = (float)p.sst[grp * 8 + 5];
   const float sg = (grp == 1 && p.negate1) ? -1.f : 1.f, w1 = p.w1[0];
+  const bool pow2 = (C4 & (C4 - 1)) == 0 && C4 <= 64;
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
   f32x4 pc = {0.f, 0.f, 0.f, 0.f}, be = pc;
   if (rg < nrg) {
@@ -1126,6 +1139,11 @@ __global__ __launch_bounds__(256) void k_smlp_bwd_pass(SMlp p, const float* __re
         a2[t] += gv * hc;
         tsum += pc[t] * gv;
       }
+    }
+    if (pow2) {         // a row's C4 lanes are consecutive lanes of one wave: the row sum is a butterfly, no barrier in the loop
+      for (int off = C4 >> 1; off >= 1; off >>= 1) tsum += __shfl_xor(tsum, off, 64);
+      if (cg == 0 && rg < nrg && r < r_hi) trow[(int64_t)grp * p.M + r] = tsum;
+      continue;
     }
     rsum[threadIdx.x] = tsum;
     __syncthreads();
