@@ -713,6 +713,16 @@ typedef struct {
   double* dot_part;                /*   caller it is the eps gradient of the GIN / GINE aggregation that produced the operand (float64: a cancelling sum) */
 } sn_train_linear_bwd_args;
 
+/* What follows a backward link, in ONE launch (a block does one job): the reduction of the link's per-workgroup dW (and db) partials
+ * ADDED to the parameters' gradients (mandatory), the BatchNorm-backward finish of the producer link (optional: sums_part != NULL;
+ * arguments of sn_train_bn_bwd_finish_f32) and the eps-gradient finish (optional: dot_part != NULL; added to dot_out[0]). */
+typedef struct sn_train_post_args {
+  const float* dw_part; int nparts; int64_t stride; int64_t n_w; float* dw_out; int64_t n_b; float* db_out;
+  const float* sums_part; int nblk; int G; int C; const float* state; const float* count; const float* gamma; float* coef;
+  float* dgamma; float* dbeta; int accumulate_bn;
+  const double* dot_part; int dot_n; float* dot_out;
+} sn_train_post_args;
+int sn_train_post_link_f32(const sn_train_post_args* args, void* stream);
 int sn_train_linear_blocks(int64_t R, int G);
 int sn_train_linear_bwd_blocks(int64_t R, int G);
 int sn_train_bn_bwd_blocks(int64_t R, int G);

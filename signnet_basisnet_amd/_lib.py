@@ -85,6 +85,7 @@ SIGNATURES = {
     "sn_gated_aggregate_f32": [_p, _p, _p, _p, _i, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_gated_aggregate_bwd_f32": [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_adam_step_f32": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _f, _p],
+    "sn_train_post_link_f32": [_p, _p],
     "sn_train_linear_blocks": [_l, _i],                  # (returns a count, not a status)
     "sn_train_linear_bwd_blocks": [_l, _i],
     "sn_train_bn_bwd_blocks": [_l, _i],

@@ -829,13 +829,13 @@ __global__ __launch_bounds__(256) void k_tbn_bwd_sums(const float* __restrict__ 
 //   dz = A*g - B - C*z,   A = gamma*rstd,  B = A*(m1 - m2*rstd*mu),  C = A*m2*rstd,   m1 = sum g / n,  m2 = rstd * sum g (z-mu) / n
 // (coef[0..2][grp][C]) and the affine gradients d beta += sum g, d gamma += rstd * sum g (z - mu) summed over the groups (the
 // reference applies ONE module to both sign passes).  One thread per column; partials added in block order (deterministic).
-__global__ __launch_bounds__(256) void k_tbn_bwd_finish(const float* __restrict__ sums, int nblk, int G, int C, const float* __restrict__ st,
+__device__ __forceinline__ void tbn_bwd_finish_block(int bid, int tid, const float* __restrict__ sums, int nblk, int G, int C, const float* __restrict__ st,
                                                         const float* __restrict__ cnt, const float* __restrict__ gamma, float* __restrict__ coef,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   // 16 columns x 16 lanes per block: a lane adds its slice of the block partials in order, then a fixed pairwise tree
   __shared__ float l1[16][17], l2[16][17];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int cl = tid & 15, rl = tid >> 4;
+  const int c = bid * 16 + cl;
   const int per = (nblk + 15) / 16, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   const int64_t GC = (int64_t)G * C;
   float dg = 0.f, db = 0.f;
@@ -884,14 +884,19 @@ __global__ __launch_bounds__(256) void k_tbn_bwd_finish(const float* __restrict_
 }
 
 // out[i] (+)= sum_b part[b*stride + i]   (partials added in block order)
-__global__ __launch_bounds__(1024) void k_tsum_parts(const float* __restrict__ part, int nparts, int64_t stride, int64_t n,
+__global__ __launch_bounds__(256) void k_tbn_bwd_finish(const float* __restrict__ sums, int nblk, int G, int C, const float* __restrict__ st,
+                                                        const float* __restrict__ cnt, const float* __restrict__ gamma, float* __restrict__ coef,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  tbn_bwd_finish_block(blockIdx.x, threadIdx.x, sums, nblk, G, C, st, cnt, gamma, coef, dgamma, dbeta, accumulate);
+}
+__device__ __forceinline__ void tsum_parts_block(int bid, int tid, const float* __restrict__ part, int nparts, int64_t stride, int64_t n,
                                                      float* __restrict__ out, int accumulate) {
   // 64 outputs per block, 16 lanes per output: lane q adds the partials b = q, q + 16, ... in order, eight loads in flight (with 4 lanes
   // and 4 loads in flight the 256 partials of a large link were 16 dependent round trips: 6.6 us x 26 launches a step), then the 16
   // lanes in order
   __shared__ float red[16][64];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + c;
+  const int c = tid & 63, q = tid >> 6;
+  const int64_t i = (int64_t)bid * 64 + c;
   float acc = 0.f;
   if (i < n) {
     const float* src = part + i;
@@ -913,6 +918,10 @@ __global__ __launch_bounds__(1024) void k_tsum_parts(const float* __restrict__ p
     for (int w = 1; w < 16; ++w) t += red[w][c];
     out[i] = (accumulate ? out[i] : 0.f) + t;
   }
+}
+__global__ __launch_bounds__(1024) void k_tsum_parts(const float* __restrict__ part, int nparts, int64_t stride, int64_t n,
+                                                     float* __restrict__ out, int accumulate) {
+  tsum_parts_block(blockIdx.x, threadIdx.x, part, nparts, stride, n, out, accumulate);
 }
 
 // y = [relu](z * scale[g] + shift[g]) [+ res] on valid rows, 0 elsewhere (the last BatchNorm of a stack, whose output is materialised:
@@ -1488,15 +1497,40 @@ extern "C" int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, 
 }
 
 // out[0] (+)= (float) sum of n float64 partials — the eps gradient of an aggregation (sn_train_linear_bwd_f32's dot_part), one launch
-__global__ __launch_bounds__(256) void k_tdot_finish(const double* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
+__device__ __forceinline__ void tdot_finish_block(int tid, const double* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
   __shared__ double red[4];
   double t = 0.0;
-  for (int i = threadIdx.x; i < n; i += 256) t += part[i];
+  for (int i = tid; i < n; i += 256) t += part[i];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  if ((tid & 63) == 0) red[tid >> 6] = t;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)((red[0] + red[1]) + (red[2] + red[3]));
+  if (tid == 0) out[0] = (accumulate ? out[0] : 0.f) + (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void k_tdot_finish(const double* __restrict__ part, int n, float* __restrict__ out, int accumulate) {
+  tdot_finish_block(threadIdx.x, part, n, out, accumulate);
+}
+
+// What follows a backward link, in ONE launch: the dW (and db) reduction of the link's per-workgroup partials INTO the parameters'
+// gradients, the BatchNorm-backward finish of the producer link (its column sums came out of the same kernel) and the eps-gradient
+// finish — three tiny kernels that each sat at the ~5 us dependent-launch floor, ~21 launches a step.  A block does one job.
+struct TPost {
+  const float* part; int nparts; int64_t stride; int64_t n_w; float* out_w; int64_t n_b; float* out_b;
+  const float* sums; int nblk; int G; int C; const float* st; const float* cnt; const float* gamma; float* coef; float* dgamma; float* dbeta;
+  int acc_f;
+  const double* dpart; int dn; float* dout;
+  int nbw, nbb, nbf;
+};
+__global__ __launch_bounds__(1024) void k_tpost(TPost p) {
+  int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (b < p.nbw) { tsum_parts_block(b, tid, p.part, p.nparts, p.stride, p.n_w, p.out_w, 1); return; }
+  b -= p.nbw;
+  if (b < p.nbb) { tsum_parts_block(b, tid, p.part + p.n_w, p.nparts, p.stride, p.n_b, p.out_b, 1); return; }
+  b -= p.nbb;
+  if (tid >= 256) return;                 // (the two finishes are 256-thread jobs: the other waves leave before any barrier)
+  if (b < p.nbf) { tbn_bwd_finish_block(b, tid, p.sums, p.nblk, p.G, p.C, p.st, p.cnt, p.gamma, p.coef, p.dgamma, p.dbeta, p.acc_f); return; }
+  tdot_finish_block(tid, p.dpart, p.dn, p.dout, 1);
 }
 extern "C" int sn_train_dot_finish_f64(const double* part, int n, float* out, int accumulate, void* stream) {
   SN_REQUIRE(part && out && n >= 1, "sn_train_dot_finish_f64: bad arguments");
@@ -1510,6 +1544,24 @@ extern "C" int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t 
   if (n == 0) return SN_OK;
   hipLaunchKernelGGL(k_tsum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, (hipStream_t)stream, part, nparts, stride, n, out, accumulate);
   SN_CHECK_LAUNCH("sn_train_reduce_parts_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_train_post_link_f32(const sn_train_post_args* args, void* stream) {
+  SN_REQUIRE(args, "sn_train_post_link_f32: null arguments");
+  const sn_train_post_args& q = *args;
+  SN_REQUIRE(q.dw_part && q.nparts >= 1 && q.n_w > 0 && q.dw_out && q.stride >= q.n_w + q.n_b && (q.n_b == 0 || q.db_out),
+             "sn_train_post_link_f32: the dW reduction is mandatory (accumulating into dw_out / db_out)");
+  SN_REQUIRE(!q.sums_part || (q.state && q.count && q.coef && q.nblk >= 1 && q.G >= 1 && q.C > 0), "sn_train_post_link_f32: bad BatchNorm finish arguments");
+  SN_REQUIRE(!q.dot_part || (q.dot_out && q.dot_n >= 1), "sn_train_post_link_f32: bad dot finish arguments");
+  TPost p{q.dw_part, q.nparts, q.stride, q.n_w, q.dw_out, q.n_b, q.db_out, q.sums_part, q.nblk, q.G, q.C, q.state, q.count, q.gamma, q.coef,
+          q.dgamma, q.dbeta, q.accumulate_bn, q.dot_part, q.dot_n, q.dot_out, 0, 0, 0};
+  p.nbw = (int)cdiv(q.n_w, 64);
+  p.nbb = q.n_b > 0 ? (int)cdiv(q.n_b, 64) : 0;
+  p.nbf = q.sums_part ? (int)cdiv(q.C, 16) : 0;
+  const int nbd = q.dot_part ? 1 : 0;
+  hipLaunchKernelGGL(k_tpost, dim3((unsigned)(p.nbw + p.nbb + p.nbf + nbd)), dim3(1024), 0, (hipStream_t)stream, p);
+  SN_CHECK_LAUNCH("sn_train_post_link_f32");
   return SN_OK;
 }
 

@@ -60,6 +60,14 @@ def _w(W):
     return W if W.stride(-1) == 1 else W.contiguous()
 
 
+class _PostArgs(C.Structure):
+    _fields_ = [("dw_part", C.c_void_p), ("nparts", C.c_int), ("stride", C.c_int64), ("n_w", C.c_int64), ("dw_out", C.c_void_p),
+                ("n_b", C.c_int64), ("db_out", C.c_void_p),
+                ("sums_part", C.c_void_p), ("nblk", C.c_int), ("G", C.c_int), ("C", C.c_int), ("state", C.c_void_p), ("count", C.c_void_p),
+                ("gamma", C.c_void_p), ("coef", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate_bn", C.c_int),
+                ("dot_part", C.c_void_p), ("dot_n", C.c_int), ("dot_out", C.c_void_p)]
+
+
 def direct_grad(p):
     """The buffer a parameter's gradient may be accumulated into IN the adjoint kernels (`optim.FlatAdam` marks its parameters: their
     .grad are views of one zeroed flat buffer, so `+=` in the kernel is exactly autograd's AccumulateGrad without the ~100 tiny add
@@ -115,11 +123,15 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
 
 
 def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state=None, x_relu=False, want_sums=False,
-               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None, gx_into=None):
+               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None, gx_into=None, finish_bn=None, dot_acc=None):
     """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h.
     dW_acc / db_acc: accumulate the weight / bias gradient into these buffers (returned dW / db are then None).
     dot_x: also sum gx . dot_x over all rows (per-workgroup partials, left on `linear_bwd.dot_part` for the caller to add up).
-    gx_into: ADD the input gradient to this buffer instead of allocating one (several Linears reading one operand)."""
+    gx_into: ADD the input gradient to this buffer instead of allocating one (several Linears reading one operand).
+    With dW_acc (and db_acc when there is a bias) the reductions behind the kernel are ONE launch (sn_train_post_link_f32), which can also
+    take: finish_bn — the producer's BatchNorm (x_state) whose backward finish these column sums feed, its d gamma / d beta accumulated in
+    place (parameters of a FlatAdam): the (a, b, c) coefficients are left on `linear_bwd.coef`; dot_acc — the buffer the eps gradient
+    (dot_x) is added to (`linear_bwd.dot_part` is then None: nothing left for eps_grad to do)."""
     W = _w(W)
     d_out, d_in = W.shape
     dev = dy.device
@@ -142,7 +154,30 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
     with ops._span("sn_train_linear_bwd_f32"):
         check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
     nw = d_out * d_in
+    linear_bwd.coef = None
     if dW_acc is not None and (not want_db or db_acc is not None):
+        fuse_bn = None
+        if finish_bn is not None and want_sums and x_state is not None:
+            dg, dbt = direct_grad(finish_bn.weight), direct_grad(finish_bn.bias)
+            if dg is not None and dbt is not None:
+                fuse_bn = (dg, dbt)
+        fuse_dot = dot_acc is not None and dot_x is not None
+        if fuse_bn is not None or fuse_dot or want_db:
+            q = _PostArgs(ptr(dwp), G * nblk, stride, nw, ptr(dW_acc), d_out if want_db else 0, ptr(db_acc) if want_db else None,
+                          None, 0, 0, 0, None, None, None, None, None, None, 1, None, 0, None)
+            if fuse_bn is not None:
+                cf = torch.empty(3, x_state.G, x_state.C, dtype=torch.float32, device=dev)
+                q.sums_part, q.nblk, q.G, q.C = ptr(sums), nblk, x_state.G, x_state.C
+                q.state, q.count, q.gamma = ptr(x_state.state), ptr(x_state.count), ptr(finish_bn.weight.detach())
+                q.coef, q.dgamma, q.dbeta = ptr(cf), ptr(fuse_bn[0]), ptr(fuse_bn[1])
+                linear_bwd.coef = cf
+            if fuse_dot:
+                q.dot_part, q.dot_n, q.dot_out = ptr(linear_bwd.dot_part), G * nblk, ptr(dot_acc)
+            with ops._span("sn_train_post_link_f32"):
+                check(lib().sn_train_post_link_f32(C.byref(q), stream()), "sn_train_post_link_f32")
+            if fuse_dot:
+                linear_bwd._dot_keep, linear_bwd.dot_part = linear_bwd.dot_part, None      # (kept alive until the next call)
+            return gx, sums, nblk, None, None
         with ops._span("sn_train_reduce_parts_f32"):
             check(lib().sn_train_reduce_parts_f32(ptr(dwp), G * nblk, stride, nw, ptr(dW_acc), 1, stream()), "sn_train_reduce_parts_f32")
             if want_db:
@@ -161,6 +196,8 @@ def eps_grad(eps):
     """The eps gradient of an aggregation from `linear_bwd.dot_part` (float64 partials): one launch, added straight into eps.grad
     when the optimiser owns it (returns None then), else a [1] tensor for autograd."""
     part = linear_bwd.dot_part
+    if part is None:                  # the link's post launch has already added it to eps.grad
+        return None
     acc = direct_grad(eps)
     out = acc if acc is not None else torch.empty(1, dtype=torch.float32, device=part.device)
     with ops._span("sn_train_dot_finish_f64"):
@@ -212,7 +249,7 @@ def _mlp2_forward(x, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, res):
     return y, z1, z2, st1, st2
 
 
-def _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, want_dx, dot_x=None):
+def _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, want_dx, dot_x=None, dot_acc=None):
     """-> (dx, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2); parameter gradients already accumulated in-kernel come back as None."""
     dg2 = dbe2 = coef2 = mask2 = None
     if st2 is not None:
@@ -221,10 +258,14 @@ def _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, 
         mask2 = (st2.scale, st2.shift) if relu_out else None
     gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, lin2.weight, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
                                            x_state=st1, x_relu=True, want_sums=True, want_db=lin2.bias is not None,
-                                           dW_acc=direct_grad(lin2.weight), db_acc=direct_grad(lin2.bias))
-    coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, bn1.weight, direct_grad(bn1.weight), direct_grad(bn1.bias))
+                                           dW_acc=direct_grad(lin2.weight), db_acc=direct_grad(lin2.bias),
+                                           finish_bn=bn1 if bn1.weight is not None else None)
+    if linear_bwd.coef is not None:           # the finish ran inside the link's post launch (d gamma / d beta accumulated in place)
+        coef1, dg1, dbe1 = linear_bwd.coef, None, None
+    else:
+        coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, bn1.weight, direct_grad(bn1.weight), direct_grad(bn1.bias))
     dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, lin1.weight, nvalid, K, x, zo=z1, coef=coef1, want_dx=want_dx, want_db=lin1.bias is not None,
-                                    dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias), dot_x=dot_x)
+                                    dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias), dot_x=dot_x, dot_acc=dot_acc)
     if bn1.weight is None:
         dg1 = dbe1 = None
     if bn2 is None or bn2.weight is None:
@@ -308,7 +349,8 @@ class _GinLayer(Function):
         dy = _c(dy)
         d = x.shape[1]
         want_eps = ctx.needs_input_grad[1]
-        grads = _mlp2_backward(dy, a, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, True, dot_x=x if want_eps else None)
+        grads = _mlp2_backward(dy, a, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, True, True, dot_x=x if want_eps else None,
+                               dot_acc=direct_grad(ctx.eps_param) if want_eps else None)
         da = grads[0]
         deps = eps_grad(ctx.eps_param) if want_eps else None
         dx = torch.empty_like(x)
@@ -369,7 +411,8 @@ class _GineLayer(Function):
         dy = _c(dy)
         N, d = h.shape
         want_eps = ctx.needs_input_grad[2]
-        grads = _mlp2_backward(dy, u, z1, z2, st1, st2, N, 1, lin1, bn1, lin2, bn2, None, 0, True, True, dot_x=h if want_eps else None)
+        grads = _mlp2_backward(dy, u, z1, z2, st1, st2, N, 1, lin1, bn1, lin2, bn2, None, 0, True, True, dot_x=h if want_eps else None,
+                               dot_acc=direct_grad(ctx.eps_param) if want_eps else None)
         du = grads[0]
         deps = eps_grad(ctx.eps_param) if want_eps else None
         dh = torch.empty_like(h)

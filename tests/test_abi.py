@@ -119,6 +119,7 @@ int main(void) {
          offsetof(sn_train_linear_args, stat_part), sizeof(sn_train_linear_bwd_args), offsetof(sn_train_linear_bwd_args, x_mean),
          offsetof(sn_train_linear_bwd_args, dot_part), sizeof(sn_train_scalar_mlp_args), offsetof(sn_train_scalar_mlp_args, w2),
          offsetof(sn_train_scalar_mlp_args, column_state));
+  printf("%zu %zu %zu\n", sizeof(sn_train_post_args), offsetof(sn_train_post_args, sums_part), offsetof(sn_train_post_args, dot_part));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -137,7 +138,8 @@ int main(void) {
             S(basisnet._DeepSetsTailParams), basisnet._DeepSetsTailParams.width.offset, basisnet._DeepSetsTailParams.gamma.offset,
             S(train_stage._LinArgs), train_stage._LinArgs.in_scale.offset, train_stage._LinArgs.stat_part.offset,
             S(train_stage._BwdArgs), train_stage._BwdArgs.x_mean.offset, train_stage._BwdArgs.dot_part.offset,
-            S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset]
+            S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset,
+            S(train_stage._PostArgs), train_stage._PostArgs.sums_part.offset, train_stage._PostArgs.dot_part.offset]
     assert got == want
 
 

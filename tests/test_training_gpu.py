@@ -293,11 +293,14 @@ def test_flat_adam_over_rccl_world_size_one(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, SN_ROOT=root, SN_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    for attempt in range(2):            # (the rendezvous port is picked free, then released: one retry on a fresh port if it was taken)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, SN_ROOT=root, SN_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        if r.returncode == 0 or "address already in use" not in (r.stderr + r.stdout).lower():
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert out["backend"] == "nccl" and out["world"] == 1
