@@ -324,6 +324,9 @@ int sn_gine_aggregate_bwd_f32(const float* h, const float* ee, const float* g, i
 int sn_slot_broadcast_f32(const float* g, int64_t N, int K, int C, const int32_t* nvalid, float* dx, void* stream);
 int sn_segment_broadcast_f32(const float* g, int64_t B, int C, const int32_t* graph_ptr, int mode, float* dx, void* stream);
 int64_t sn_embedding_bwd_scratch_floats(int64_t R, int nf, const int64_t* table_rows, int C);
+/* forward of the same: out[l][r][:] = sum_f tables[l * nf + f][idx[r, f]] for L <= 16 layers (nf <= 4) that share the index columns */
+int sn_embedding_sum_layers_f32(const int64_t* idx, int ldi, int nf, int64_t R, int L, const float* const* tables,
+                                const int64_t* table_rows, int C, float* out, int32_t* status, void* stream);
 int64_t sn_embedding_bwd_layers_scratch_floats(int64_t R, int L, int C);
 int sn_embedding_sum_bwd_layers_f32(const int64_t* idx, int ldi, int nf, int64_t R, int L, float* const* dtables,
                                     const int64_t* table_rows, int C, const float* g, int32_t* status, float* scratch, void* stream);

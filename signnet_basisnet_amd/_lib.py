@@ -61,6 +61,7 @@ SIGNATURES = {
     "sn_slot_broadcast_f32": [_p, _l, _i, _i, _p, _p, _p],
     "sn_segment_broadcast_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_embedding_sum_bwd_f32": [_p, _i, _i, _l, _p, C.POINTER(C.c_int64), _i, _p, _p, _p, _p],
+    "sn_embedding_sum_layers_f32": [_p, _i, _i, _l, _i, _p, C.POINTER(C.c_int64), _i, _p, _p, _p],
     "sn_embedding_sum_bwd_layers_f32": [_p, _i, _i, _l, _i, _p, C.POINTER(C.c_int64), _i, _p, _p, _p, _p],
     "sn_dot_f32": [_p, _p, _l, _p, _p, _p],
     "sn_pna_aggregate_f32": [_p, _i, _p, _i, _i, _l, _p, _p, _f, _p, _i, _p],

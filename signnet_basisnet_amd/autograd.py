@@ -371,14 +371,20 @@ class _EmbeddingSumLayers(Function):
         Cc = tables[0].shape[1]
         out = torch.empty(L, R, Cc, dtype=torch.float32, device=idx.device)
         rows = (C.c_int64 * nf)(*[tables[f].shape[0] for f in range(nf)])
-        for l in range(L):
-            tabs = [ops._f32c(tables[l * nt + f].detach(), "embedding table") for f in range(nf)]
-            if any(t.shape != tables[f].shape for f, t in enumerate(tabs)):
-                raise ValueError("embedding_sum_layers: the layers' tables must have one shape per feature column")
-            arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs])
-            with ops._span("sn_embedding_sum_f32"):
-                check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, rows, Cc, out[l].data_ptr(), ptr(status), stream()),
-                      "sn_embedding_sum_f32")
+        tabs = [[ops._f32c(tables[l * nt + f].detach(), "embedding table") for f in range(nf)] for l in range(L)]
+        if any(t.shape != tables[f].shape for ts in tabs for f, t in enumerate(ts)):
+            raise ValueError("embedding_sum_layers: the layers' tables must have one shape per feature column")
+        if nf <= 4 and L <= 16:          # all planes in one launch
+            arr = (C.c_void_p * (L * nf))(*[t.data_ptr() for ts in tabs for t in ts])
+            with ops._span("sn_embedding_sum_layers_f32"):
+                check(lib().sn_embedding_sum_layers_f32(ptr(idx), nf, nf, R, L, arr, rows, Cc, ptr(out), ptr(status), stream()),
+                      "sn_embedding_sum_layers_f32")
+        else:
+            for l in range(L):
+                arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs[l]])
+                with ops._span("sn_embedding_sum_f32"):
+                    check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, rows, Cc, out[l].data_ptr(), ptr(status), stream()),
+                          "sn_embedding_sum_f32")
         ctx.idx, ctx.L, ctx.nt, ctx.tables = idx, L, nt, tables
         return out
 

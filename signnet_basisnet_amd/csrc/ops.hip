@@ -1091,6 +1091,26 @@ __global__ __launch_bounds__(256) void k_embedding_sum(const int64_t* __restrict
   if (bad && c == 0 && status != nullptr) atomicOr(status, 1);
 }
 
+// L encoders over ONE index block (the per-layer edge encoders of a GINE stack): out[l][r][:] = sum_f tables[l][f][idx[r, f]], one launch.
+struct LayerTablePtrs { const float* t[16][4]; int64_t rows[4]; };
+__global__ __launch_bounds__(256) void k_embedding_sum_layers(const int64_t* __restrict__ idx, int ldi, int nf, int64_t R,
+                                                              LayerTablePtrs tp, int C, float* __restrict__ out, int32_t* __restrict__ status) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * C) return;
+  const int l = blockIdx.y;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  float s = 0.f;
+  bool bad = false;
+  for (int f = 0; f < nf; ++f) {
+    const int64_t id = idx[r * ldi + f];
+    if ((uint64_t)id < (uint64_t)tp.rows[f]) s += tp.t[l][f][id * C + c];
+    else bad = true;
+  }
+  out[(int64_t)l * R * C + i] = s;
+  if (bad && c == 0 && l == 0 && status != nullptr) atomicOr(status, 1);
+}
+
 // One workgroup per segment; 256 threads = RL row lanes x CW column lanes (CW = the power of two >= min(C, 256)), folded in LDS.
 __global__ __launch_bounds__(256) void k_segment_pool(const float* __restrict__ x, int C,
                                                       const int32_t* __restrict__ graph_ptr, int mode,
@@ -1585,6 +1605,23 @@ extern "C" int sn_embedding_sum_f32(const int64_t* idx, int ldi, int nf, int64_t
   hipLaunchKernelGGL(k_embedding_sum, dim3((unsigned)cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, ldi, nf,
                      R, tp, C, out, status);
   SN_CHECK_LAUNCH("sn_embedding_sum_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_embedding_sum_layers_f32(const int64_t* idx, int ldi, int nf, int64_t R, int L, const float* const* tables,
+                                           const int64_t* table_rows, int C, float* out, int32_t* status, void* stream) {
+  SN_REQUIRE(idx && tables && table_rows && out && nf > 0 && nf <= 4 && ldi >= nf && C > 0 && R >= 0 && L >= 1 && L <= 16,
+             "sn_embedding_sum_layers_f32: bad arguments (nf <= 4, L <= 16)");
+  if (R == 0) return SN_OK;
+  LayerTablePtrs tp;
+  for (int f = 0; f < 4; ++f) tp.rows[f] = f < nf ? table_rows[f] : 0;
+  for (int l = 0; l < 16; ++l)
+    for (int f = 0; f < 4; ++f) tp.t[l][f] = (l < L && f < nf) ? tables[l * nf + f] : nullptr;
+  for (int l = 0; l < L; ++l)
+    for (int f = 0; f < nf; ++f) SN_REQUIRE(tp.t[l][f] && tp.rows[f] > 0, "sn_embedding_sum_layers_f32: table %d of layer %d missing or empty", f, l);
+  hipLaunchKernelGGL(k_embedding_sum_layers, dim3((unsigned)cdiv(R * C, 256), (unsigned)L), dim3(256), 0, (hipStream_t)stream, idx, ldi, nf, R, tp,
+                     C, out, status);
+  SN_CHECK_LAUNCH("sn_embedding_sum_layers_f32");
   return SN_OK;
 }
 

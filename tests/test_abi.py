@@ -87,6 +87,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_act_bwd_f32": (None, None, 2, 4, None, 1, 0.01, None, None),
         "sn_pointwise_f32": (None, 4, 2, 4, None, None, None, 0, 0.0, None, 4, None, 4, None),
         "sn_embedding_sum_bwd_f32": (None, 1, 1, 4, None, i64, 8, None, None, None, None),
+        "sn_embedding_sum_layers_f32": (None, 1, 1, 4, 2, None, i64, 8, None, None, None),
         "sn_embedding_sum_bwd_layers_f32": (None, 1, 1, 4, 2, None, i64, 8, None, None, None, None),
     }
     for name, args in cases.items():
