@@ -166,9 +166,22 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
 
 
+_EMPTY_BUF = {}
+
+
 def ptr(t):
-    """Device pointer of a tensor (None -> NULL)."""
-    return None if t is None else t.data_ptr()
+    """Device pointer of a tensor (None -> NULL).  An EMPTY device tensor (zero rows: a batch without edges, an empty shard) has a NULL
+    data pointer too; the entry points take NULL for "argument absent" and reject it for mandatory ones, so an empty tensor is passed
+    as a valid pointer to a small per-device buffer — with zero rows nothing is read or written through it."""
+    if t is None:
+        return None
+    p = t.data_ptr()
+    if p == 0 and t.is_cuda:
+        buf = _EMPTY_BUF.get(t.device)
+        if buf is None:
+            buf = _EMPTY_BUF[t.device] = torch.zeros(64, dtype=torch.int64, device=t.device)
+        return buf.data_ptr()
+    return p
 
 
 _stream_handle = None      # set by stream_scope: one torch.cuda.current_stream() lookup (~8 us) per forward instead of per launch

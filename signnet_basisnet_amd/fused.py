@@ -293,10 +293,12 @@ class GnnPlan:
         if self.edge_discrete:
             if edge_attr.dtype != torch.int64:
                 raise ValueError("discrete edge features must be int64")
-            edge_attr = edge_attr.reshape(plan.E, -1).contiguous()
+            edge_attr = (edge_attr.reshape(plan.E, -1) if plan.E else edge_attr.reshape(0, 1)).contiguous()   # (no edges: E = 0)
             P.edge_nf = edge_attr.shape[1] if plan.E else 1
         else:
-            edge_attr = edge_attr.reshape(plan.E, -1).contiguous()
+            edge_attr = (edge_attr.reshape(plan.E, -1) if plan.E else edge_attr.reshape(0, max(1, int(P.edge_nf)))).contiguous()
+        if plan.E == 0:      # a batch without edges (single-node graphs): nothing is read, but the entry point wants a pointer
+            edge_attr = torch.zeros(1, max(1, int(P.edge_nf)), dtype=edge_attr.dtype, device=rho_sum.device)
         if P.node_nf > (10 if self.node_discrete else 16) or P.edge_nf > (10 if self.edge_discrete else 16):
             raise ValueError("too many feature columns for the fused gnn kernel")
         y = torch.empty(plan.B, self.n_out, dtype=torch.float32, device=rho_sum.device)

@@ -372,6 +372,8 @@ def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=No
         residual = _f32c(residual, "residual")
     if out is None:
         out = torch.empty(*x.shape[:-1], pl.d_out, dtype=torch.float32, device=x.device)
+    if R == 0:
+        return out
     with _span("sn_masked_linear_f32"):
         check(lib().sn_masked_linear_f32(ptr(x), pl.d_in, R, pl.d_in, ptr(pl.wp), pl.d_out, ptr(bias), ptr(nvalid),
                                          int(K), flags, ptr(scale), ptr(shift), ptr(residual), pl.d_out, ptr(out),
@@ -585,6 +587,8 @@ def embedding_sum(idx, tables, status=None):
     arr = (C.c_void_p * nf)(*[t.data_ptr() for t in tabs])
     rows = (C.c_int64 * nf)(*[t.shape[0] for t in tabs])
     out = torch.empty(R, Cc, dtype=torch.float32, device=idx.device)
+    if R == 0:                      # (a batch without edges / an empty shard)
+        return out
     own = status is None
     if own:
         status = torch.zeros(1, dtype=torch.int32, device=idx.device)

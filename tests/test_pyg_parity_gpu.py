@@ -470,3 +470,39 @@ def test_overlap_front_mode_is_bit_identical_and_stream_ordered():
         torch.cuda.synchronize()
     for i, y in outs:
         assert torch.equal(y, ref[i])
+
+
+@pytest.mark.parametrize("variant,feats,ctor", [("gine", "zinc", (None, None, 32, 1, 2, 2)), ("alchemy", "alchemy", (6, 4, 20, 3, 2, 2))])
+@pytest.mark.parametrize("sizes", [[1, 1, 1, 1], [1, 1]], ids=["four single nodes", "two single nodes"])
+def test_batch_without_edges(variant, feats, ctor, sizes):
+    """A batch of single-node graphs has NO edges (E = 0: empty edge_index / edge_attr, NULL data pointers).  The reference evaluates
+    it (PyG's convolutions over an empty edge_index, nn.Embedding of an empty index tensor); so do the fused stages, the layer path
+    and the differentiable train-mode forward (found by fuzzing the forward against the oracle, scratch work of round 3)."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(7)
+    model = SignNetGNN(*ctor, variant=variant, max_k=4)
+    model.attn_dropout = 0.0
+    host = synth.make_batch(len(sizes), seed=5, features=feats, sizes=sizes)
+    assert host.edge_index.shape[1] == 0
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = O.signnet_gnn(sd, O.make_cfg(variant, *ctor), host, training=False, max_k=4)
+    m = model.cuda().eval()
+    data = synth.batch_to(host, "cuda:0")
+    with torch.no_grad():
+        y = m(data)
+        y_layer, _ = m(data, return_stages=True)
+    assert m._used_fused
+    close(y, ref, "fused forward, batch without edges")
+    close(y_layer, ref, "layer path, batch without edges")
+    # mixed: single-node graphs between ordinary ones
+    host2 = synth.make_batch(4, seed=6, features=feats, sizes=[1, 7, 1, 12])
+    ref2 = O.signnet_gnn(sd, O.make_cfg(variant, *ctor), host2, training=False, max_k=4)
+    with torch.no_grad():
+        close(m(synth.batch_to(host2, "cuda:0")), ref2, "fused forward, single-node graphs in the batch")
+    # the differentiable path runs (values: train-mode statistics over identical rows are degenerate, only finiteness is asserted)
+    m.train()
+    yt = m(data)
+    yt.sum().backward()
+    assert torch.isfinite(yt).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())

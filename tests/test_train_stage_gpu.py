@@ -67,6 +67,10 @@ CASES = [
     (64, 64, 64, 2, 90, 8, True, True, True, True),            # configs[0] widths, Alchemy-style bias
     (32, 128, 64, 1, 77, 4, True, False, True, True),          # unequal widths
     (108, 108, 108, 2, 120, 6, True, True, True, True),        # Alchemy's hidden width (not a multiple of 16)
+    (8, 8, 8, 2, 40, 8, True, True, True, False),              # half a channel tile, a few hundred rows (found by scratch fuzzing)
+    (8, 8, 8, 2, 211, 5, True, True, True, True),
+    (20, 20, 20, 2, 64, 5, True, True, True, True),
+    (64, 64, 64, 2, 739, 5, True, True, True, True),
 ]
 
 
