@@ -1,0 +1,173 @@
+"""-m gpu: graph TOPOLOGIES outside the molecule generator of `synth.make_batch` — everything else in tests/ runs on symmetric,
+degree <= 4, sorted edge lists.  The reference accepts any `edge_index` (PyG's scatter-add over whatever the collate produced:
+GINESignNetPyG/core/model_utils/pyg_gnn_wrapper.py:19-28, Alchemy/sign_net/masked_layers.py:118-131), and the kernels have paths
+only such inputs reach: more than PHI_NBR = 8 in-neighbours of a row (CSR read from global memory), more than four in-edges per
+node in the GINE stage, self loops, duplicate edges, directed (asymmetric) edges, isolated nodes, an edge list in random order
+(the aggregation sums in edge-id order), graphs at the 64-node / 192-edge limits of the stage kernels and just beyond them (layer
+path).  Forward in eval mode (fused stages and layer path) and the train-mode forward + parameter gradients against the CPU oracle
+(fp32, attributed to float64 as everywhere else)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import parity_util as PU
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sym(e):
+    e = np.asarray(e, dtype=np.int64).reshape(-1, 2)
+    return np.concatenate([e, e[:, ::-1]], 0)
+
+
+def _topologies(rng):
+    """(name, n, directed edge list [E, 2] as (src, dst))"""
+    out = []
+    n = 40
+    out.append(("star40", n, _sym([(0, i) for i in range(1, n)])))                     # hub: 39 in-edges
+    n = 12
+    out.append(("complete12", n, np.array([(i, j) for i in range(n) for j in range(n) if i != j], dtype=np.int64)))
+    n = 17
+    out.append(("directed_cycle17", n, np.array([(i, (i + 1) % n) for i in range(n)], dtype=np.int64)))
+    n = 9
+    e = rng.integers(0, n, size=(30, 2))
+    e = np.concatenate([e, e[:7], np.array([(i, i) for i in range(n)])], 0)            # duplicates + self loops
+    out.append(("multigraph9", n, e[rng.permutation(len(e))]))
+    n = 23
+    e = _sym(rng.integers(0, 10, size=(25, 2)))                                        # nodes 10..22 isolated
+    out.append(("isolated23", n, e[rng.permutation(len(e))]))
+    n = 64
+    out.append(("path64", n, _sym([(i, i + 1) for i in range(n - 1)])))                # the stage kernels' row limit
+    n = 33
+    e = _sym(rng.integers(0, n, size=(96, 2)))                                         # exactly 192 edges: the GINE stage's limit
+    out.append(("edges192", n, e[rng.permutation(len(e))]))
+    n = 5
+    out.append(("wheel5_in_only", n, np.array([(i, 0) for i in range(1, n)] + [(0, 0)], dtype=np.int64)))   # in-edges of one node only
+    return out
+
+
+def _batch(topos, features, seed):
+    g = torch.Generator().manual_seed(seed)
+    eis, evecs, evals, batch, sizes = [], [], [], [], []
+    off = 0
+    for b, (_, n, e) in enumerate(topos):
+        eis.append(torch.from_numpy(np.ascontiguousarray(e.T)) + off)
+        q, _ = torch.linalg.qr(torch.randn(n, n, generator=g))                         # any orthonormal basis: the nets only read it
+        evecs.append(q.reshape(-1).float())
+        evals.append(torch.rand(n, generator=g))
+        batch.append(torch.full((n,), b, dtype=torch.long))
+        sizes.append(n)
+        off += n
+    edge_index = torch.cat(eis, 1).contiguous()
+    N, E = off, edge_index.shape[1]
+    if features == "zinc":
+        x = torch.randint(0, 28, (N, 1), generator=g, dtype=torch.long)
+        edge_attr = torch.randint(1, 4, (E,), generator=g, dtype=torch.long)
+    else:
+        x = torch.rand(N, 6, generator=g)
+        edge_attr = torch.rand(E, 4, generator=g)
+    d = types.SimpleNamespace(x=x, edge_index=edge_index, edge_attr=edge_attr, batch=torch.cat(batch), eigen_values=torch.cat(evals),
+                              eigen_vectors=torch.cat(evecs), num_graphs=len(sizes), num_nodes=N)
+    d.sizes = sizes
+    return d
+
+
+def _model(variant, ctor, max_k, seed=0):
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(seed)
+    model = SignNetGNN(*ctor, variant=variant, max_k=max_k)
+    model.attn_dropout = 0.0
+    PU.bn_randomize(model, 2)
+    return model
+
+
+CASES = [("gine", "zinc", (None, None, 64, 1, 3, 3), 8), ("gine", "zinc", (None, None, 128, 1, 4, 6), 16),
+         ("alchemy", "alchemy", (6, 4, 44, 5, 3, 3), None)]
+
+
+@pytest.mark.parametrize("variant,feats,ctor,max_k", CASES, ids=["gine_d64_k8", "gine_d128_k16", "alchemy_d44_allk"])
+def test_forward_on_arbitrary_topologies(variant, feats, ctor, max_k):
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    rng = np.random.default_rng(11)
+    topos = _topologies(rng)
+    model = _model(variant, ctor, max_k)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    cfg = O.make_cfg(variant, *ctor)
+    m = model.to(DEV).eval()
+    # every topology alone (a one-graph batch reaches the per-graph limits on its own), then all of them in one batch
+    for group in [[t] for t in topos] + [topos, topos[::-1]]:
+        host = _batch(group, feats, seed=3)
+        names = "+".join(t[0] for t in group)
+        ref = O.signnet_gnn(sd, cfg, host, training=False, max_k=max_k)
+        ref64 = O.signnet_gnn(PU.to_f64(sd), cfg, PU.data_f64(host), training=False, max_k=max_k)
+        dd = synth.batch_to(host, DEV)
+        with torch.no_grad():
+            y = m(dd)
+            y_layer, _ = m(dd, return_stages=True)
+        assert torch.isfinite(y).all(), names
+        # (a one-graph batch has a single output row: its own cancellation sets the scale, so the case's measured conditioning — the
+        #  fp32 oracle's distance from float64 — sets the bar, as for the small training fixtures)
+        chk = PU.close_conditioned if len(group) == 1 else (lambda a, r32, r64, what: PU.close(a, r32, what, ref64=r64))
+        chk(y, ref, ref64, f"{names}: forward (module default)")
+        chk(y_layer, ref, ref64, f"{names}: layer path")
+
+
+def test_forward_beyond_the_stage_kernels_limits_is_served_by_the_layer_path():
+    """65 nodes / 193+ in-edges in one graph: the stage kernels flag the batch, strict mode (the default) re-runs it layer by layer."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    rng = np.random.default_rng(5)
+    big = [("path65", 65, _sym([(i, i + 1) for i in range(64)])),
+           ("dense30", 30, np.array([(i, j) for i in range(30) for j in range(30) if i != j][:400], dtype=np.int64)),
+           ("star40", 40, _sym([(0, i) for i in range(1, 40)]))]
+    variant, feats, ctor, max_k = CASES[0]
+    model = _model(variant, ctor, max_k)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    m = model.to(DEV).eval()
+    for group in ([big[0]], [big[1]], big):
+        host = _batch(group, feats, seed=4)
+        ref = O.signnet_gnn(sd, O.make_cfg(variant, *ctor), host, training=False, max_k=max_k)
+        ref64 = O.signnet_gnn(PU.to_f64(sd), O.make_cfg(variant, *ctor), PU.data_f64(host), training=False, max_k=max_k)
+        with torch.no_grad():
+            y = m(synth.batch_to(host, DEV))
+        PU.close_conditioned(y, ref, ref64, "+".join(t[0] for t in group) + ": forward beyond the stage limits")
+
+
+@pytest.mark.parametrize("width", [8, 44, 128])
+def test_aggregation_adjoints_on_arbitrary_topologies(width):
+    """The GIN / GINE aggregations and their adjoints (out-edge CSR of the flipped edge list, edge permutation for the per-edge
+    embeddings) on the batch of all topologies against dense float64 autograd.  (Whole-network gradients on such a small batch say
+    nothing: one ReLU decision that falls on the other side of zero in either fp32 evaluation moves every upstream gradient by
+    1e-4 ... 1e-3 — measured on ordinary molecule batches of this size as often as on these — so the adjoint kernels, which are
+    linear in the cotangent, are checked directly; the gradients of the whole nets are checked at the BASELINE sizes in
+    test_training_gpu.py.)"""
+    from signnet_basisnet_amd import autograd as AG
+    from signnet_basisnet_amd import ops
+    from test_backward_gpu import run_pair
+    rng = np.random.default_rng(11)
+    topos = _topologies(rng)
+    host = _batch(topos, "zinc", seed=3)
+    ei, N, E, B = host.edge_index, host.num_nodes, host.edge_index.shape[1], host.num_graphs
+    plan = ops.build_plan(host.batch.to(DEV), ei.to(DEV), B, 0)
+    rplan = ops.build_plan(host.batch.to(DEV), ei.flip(0).contiguous().to(DEV), B, 0)
+    g = torch.Generator().manual_seed(width)
+    A = torch.zeros(N, N, dtype=torch.float64)
+    A.index_put_((ei[1], ei[0]), torch.ones(E, dtype=torch.float64), accumulate=True)      # duplicate edges count twice
+    x = torch.randn(N, 3 * width, generator=g)
+    eps = torch.tensor([0.3])
+    for neg in (False, True):
+        run_pair(lambda x, eps: AG.gin_aggregate(x, eps, plan, rplan, negate=neg),
+                 lambda x, eps: ((1 + eps) * x + A @ x) * (-1 if neg else 1), [x, eps], f"gin negate={neg} width={3 * width}")
+    h, ee = torch.randn(N, width, generator=g), torch.randn(E, width, generator=g)
+    # keep every ReLU argument away from zero: the comparison is of the adjoint, not of a decision at 1e-8
+    s_ = h[ei[0]] + ee
+    ee = ee + torch.where(s_.abs() < 1e-3, torch.sign(s_) * 1e-2 + (s_ == 0) * 1e-2, torch.zeros_like(s_))
+
+    def ref(h, ee, eps):
+        m = torch.relu(h[ei[0]] + ee)
+        return (1 + eps) * h + torch.zeros_like(h).index_add_(0, ei[1], m)
+    run_pair(lambda h, ee, eps: AG.gine_aggregate(h, ee, eps, plan, rplan), ref, [h, ee, eps], f"gine width={width}")
