@@ -21,9 +21,10 @@ from . import ops
 class Graph:
     """Minimal batched graph: edge list + per-graph node counts (what the reference reads from a DGLGraph)."""
 
-    def __init__(self, src, dst, batch_num_nodes):
+    def __init__(self, src, dst, batch_num_nodes, batch_num_edges=None):
         self.src, self.dst = src, dst
         self._bnn = torch.as_tensor(batch_num_nodes)
+        self._bne = None if batch_num_edges is None else torch.as_tensor(batch_num_edges)    # per-graph edge counts, as DGL keeps them
 
     def edges(self):
         return self.src, self.dst
@@ -31,8 +32,11 @@ class Graph:
     def batch_num_nodes(self):
         return self._bnn
 
+    def batch_num_edges(self):
+        return self._bne
+
     def to(self, device):
-        return Graph(self.src.to(device), self.dst.to(device), self._bnn.to(device))
+        return Graph(self.src.to(device), self.dst.to(device), self._bnn.to(device), None if self._bne is None else self._bne.to(device))
 
 
 class MLP(nn.Module):
@@ -266,6 +270,25 @@ def _node_counts(g):
 def _max_nodes(g):
     """Largest graph of the batch (the stage kernels keep a whole graph in one 64-row bin column)."""
     return _node_counts(g)[0]
+
+
+def _max_in_edges(g):
+    """Most edges of one graph of the batch (the one-launch GatedGCN kernel stages a graph's in-edges in LDS), or None when the graph
+    object does not say: DGL's batch_num_edges() — per-graph counts DGL keeps with the batch, like batch_num_nodes() — read ONCE per
+    graph object and cached on it.  Never derived from the edge list: that is a device reduction and a host wait per new graph object,
+    which the one-launch path exists to avoid (the device-side guard covers graphs whose counts are not known)."""
+    me = getattr(g, "_sn_max_edges", None)
+    if me is None:
+        bne = getattr(g, "batch_num_edges", None)
+        t = bne() if callable(bne) else None
+        if t is None:
+            return None
+        me = int(t.max()) if t.numel() else 0
+        try:
+            g._sn_max_edges = me
+        except Exception:
+            pass
+    return me
 
 
 def _await_side(g, plan=None):

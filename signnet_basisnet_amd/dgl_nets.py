@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import check, lib, ptr, stream
-from .dgl_deepsigns import MLP, cached_plan, _await_side, _max_nodes, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
+from .dgl_deepsigns import MLP, cached_plan, _await_side, _max_nodes, _max_in_edges, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
 
 
 class MLPReadout(nn.Module):
@@ -460,9 +460,12 @@ class GatedGCNNet(_PackCache, nn.Module):
         fz = c["fused_gated"]
         if not fz.ok:
             return None
-        # (a graph with more in-edges than the kernel's LDS image holds — sn_gatedgcn_max_edges(d), 176 at hidden 68 — is flagged on
-        #  the device and gets a NaN score: check_last())
-        return fz if 0 < _max_nodes(g) <= 64 else None
+        # (a graph with more than 64 nodes, or more in-edges than the kernel's LDS image holds — sn_gatedgcn_max_edges(d), 176 at hidden
+        #  68 —, takes the layer path, as the reference evaluates any graph: both counts come with a DGL batch (batch_num_nodes(),
+        #  batch_num_edges()) and are read once per graph object.  A duck-typed graph without edge counts reaches the kernel, which
+        #  flags such a graph on the device — NaN score, check_last())
+        me = _max_in_edges(g)
+        return fz if 0 < _max_nodes(g) <= 64 and (me is None or me <= fz.max_edges) else None
 
     def check_last(self):
         """Raise what the last one-launch eval forward flagged on the device (its scores are NaN in that case): a node / edge type

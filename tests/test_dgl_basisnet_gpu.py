@@ -912,9 +912,11 @@ def test_dgl_stage_kernels_oversize_graph_falls_back_to_the_layer_path():
     assert torch.isfinite(y).all()
 
 
-def test_gatedgcn_one_launch_flags_a_graph_with_too_many_edges():
-    """A dense 40-node graph (more in-edges than the kernel's LDS image holds): NaN score for that graph only, the rest unaffected,
-    check_last() raises."""
+def test_gatedgcn_graph_with_too_many_edges_for_the_one_launch_kernel():
+    """A dense 40-node graph (more in-edges than the kernel's LDS image holds).  The module reads the batch's largest per-graph edge
+    count once per graph object and evaluates such a batch layer by layer, as the reference evaluates any graph.  The device-side
+    guard stays: a batch that reaches the kernel anyway (here: the cached count overwritten) gets a NaN score for that graph only,
+    the rest unaffected, and check_last() raises."""
     from signnet_basisnet_amd import dgl_deepsigns as DS
     from signnet_basisnet_amd import synth
     k = 6
@@ -926,10 +928,18 @@ def test_gatedgcn_one_launch_flags_a_graph_with_too_many_edges():
     dense = torch.stack([ii[keep], jj[keep]]) + n0                       # 1560 directed edges inside graph 1
     ei = torch.cat([data.edge_index, dense], dim=1)
     e = torch.cat([data.edge_attr.reshape(-1), torch.ones(dense.shape[1], dtype=torch.long)])
-    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), torch.tensor(data.sizes))
+    bnn = torch.tensor(data.sizes)
+    bne = torch.bincount(torch.bucketize(ei[1], torch.cumsum(bnn, 0), right=True), minlength=3)       # what DGL's batch carries
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), bnn, bne)
     pe = synth.dgl_pos_enc(data, k).to(DEV)
     net.sign_inv_net.fused_stages = False
     pp = net.sign_inv_net(g, pe.unsqueeze(-1)).squeeze(-1)
+    y_auto = net(g, data.x.reshape(-1).to(DEV), pp, e.to(DEV))[0]
+    net.check_last()
+    assert DS._max_in_edges(g) >= dense.shape[1] and net._fused_gated(g) is None      # (the molecule's own edges + the dense block)
+    assert torch.isfinite(y_auto).all()
+    g = DS.Graph(ei[0].to(DEV), ei[1].to(DEV), bnn)                      # no edge counts: the batch reaches the kernel
+    assert DS._max_in_edges(g) is None
     y = net(g, data.x.reshape(-1).to(DEV), pp, e.to(DEV))[0]
     assert torch.isnan(y[1]).all() and torch.isfinite(y[0]).all() and torch.isfinite(y[2]).all()
     with pytest.raises(RuntimeError):
@@ -937,6 +947,7 @@ def test_gatedgcn_one_launch_flags_a_graph_with_too_many_edges():
     net.fused_stages = False
     y_l = net(g, data.x.reshape(-1).to(DEV), pp, e.to(DEV))[0]
     assert torch.isfinite(y_l).all()
+    assert torch.equal(y_auto, y_l)
     close(y[[0, 2]], y_l[[0, 2]], "graphs beside the flagged one")
 
 

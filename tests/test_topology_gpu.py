@@ -171,3 +171,46 @@ def test_aggregation_adjoints_on_arbitrary_topologies(width):
         m = torch.relu(h[ei[0]] + ee)
         return (1 + eps) * h + torch.zeros_like(h).index_add_(0, ei[1], m)
     run_pair(lambda h, ee, eps: AG.gine_aggregate(h, ee, eps, plan, rplan), ref, [h, ee, eps], f"gine width={width}")
+
+
+@pytest.mark.parametrize("name", ["gin", "gatedgcn", "gat", "pna", "transformer", "gatedgcn_mask", "pna_mask", "transformer_mask"])
+def test_dgl_base_nets_on_arbitrary_topologies(name):
+    """The GraphPrediction tree (sign-invariant net + each base net at its shipped width, eval mode) on the same graphs: nodes
+    WITHOUT in-edges (DGL's reducers leave zeros there: layers/pna_layer.py:38-56 mean / max / min / std over an empty mailbox,
+    gat_layer.py's edge softmax, graph_transformer_edge_layer.py's z = 0), 39 in-edges on one node (PNA's degree scalers, the
+    wave-per-(node, head) GAT / Transformer aggregations), duplicate edges and self loops, among ordinary molecules."""
+    from signnet_basisnet_amd import synth
+    from test_full_size_parity_gpu import run_shipped_dgl_config
+    rng = np.random.default_rng(11)
+    topos = [t for t in _topologies(rng) if t[1] <= 37]          # k = 37 = the largest ZINC graph in the masked configs
+    topos.append(("star37", 37, _sym([(0, i) for i in range(1, 37)])))
+    mols = [(f"mol{i}", n, synth._random_molecule(rng, n).T) for i, n in enumerate(rng.integers(9, 31, size=10).tolist())]
+    mixed = [t for pair in zip(mols, topos) for t in pair] + mols[len(topos):]
+    if name == "gat":
+        # DGL's GATConv refuses a graph with 0-in-degree nodes (DGLError; nets/ZINC_graph_regression/gat_net.py:62-66 leaves
+        # allow_zero_in_degree at False): so does the HIP net — and evaluates the batch without those two graphs
+        with pytest.raises(ValueError, match="0-in-degree"):
+            run_shipped_dgl_config(name, _batch(mixed, "zinc", seed=8), elementwise=False)
+        mixed = [t for t in mixed if t[0] not in ("isolated23", "wheel5_in_only")]
+    run_shipped_dgl_config(name, _batch(mixed, "zinc", seed=8), elementwise=False)
+
+
+def test_gatedgcn_graph_beyond_the_one_launch_kernel_takes_the_layer_path():
+    """A graph with more in-edges than the one-launch GatedGCN kernel stages in LDS (sn_gatedgcn_max_edges: 176 at hidden 68) is
+    evaluated by the layer path, decided on the host from the per-graph edge counts a DGL batch carries (batch_num_edges(), cached on
+    the graph object) — the reference evaluates any graph.  Without them the device-side guard applies (NaN score, check_last())."""
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import dgl_nets
+    from test_full_size_parity_gpu import SHIPPED, _COMMON
+    params = dict(_COMMON, device=DEV)
+    params.update({k: v for k, v in SHIPPED["gatedgcn"].items() if k != "cls"})
+    net = dgl_nets.GatedGCNNet(params).to(DEV).eval()
+    rng = np.random.default_rng(3)
+    small = _batch([("path20", 20, _sym([(i, i + 1) for i in range(19)]))], "zinc", seed=1)
+    dense = _batch([("k15", 15, np.array([(i, j) for i in range(15) for j in range(15) if i != j], dtype=np.int64))], "zinc", seed=1)   # 210 in-edges
+    for host, fused in ((small, True), (dense, False)):
+        g = DS.Graph(host.edge_index[0].to(DEV), host.edge_index[1].to(DEV), host.sizes, [host.edge_index.shape[1]])
+        assert (net._fused_gated(g) is not None) == fused
+        assert DS._max_in_edges(g) == host.edge_index.shape[1]
+    g = DS.Graph(dense.edge_index[0].to(DEV), dense.edge_index[1].to(DEV), dense.sizes)        # no batch_num_edges(): not known on the host
+    assert DS._max_in_edges(g) is None and net._fused_gated(g) is not None
