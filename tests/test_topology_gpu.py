@@ -214,3 +214,28 @@ def test_gatedgcn_graph_beyond_the_one_launch_kernel_takes_the_layer_path():
         assert DS._max_in_edges(g) == host.edge_index.shape[1]
     g = DS.Graph(dense.edge_index[0].to(DEV), dense.edge_index[1].to(DEV), dense.sizes)        # no batch_num_edges(): not known on the host
     assert DS._max_in_edges(g) is None and net._fused_gated(g) is not None
+
+
+@pytest.mark.parametrize("norm", [None, "sym"])
+def test_evd_on_degenerate_spectra(norm):
+    """The on-device eigendecomposition (row f2) on graphs whose Laplacians have heavily repeated eigenvalues — a star (eigenvalue 1
+    with multiplicity n - 2), K12 (n - 1 times the same eigenvalue), cycles (pairs), 13 isolated nodes (a 14-fold zero), a 64-node
+    path, one- and two-node graphs — where the molecule batches of test_evd_gpu.py have almost simple spectra: eigenvalues,
+    residual, orthogonality and the projectors onto separated clusters against the CPU oracle (LAPACK), same tolerance."""
+    from signnet_basisnet_amd import transform as TR
+    from test_evd_gpu import _check_batch, _gptr
+    rng = np.random.default_rng(11)
+    topos = _topologies(rng)
+    topos += [("cycle16", 16, _sym([(i, (i + 1) % 16) for i in range(16)])), ("single", 1, np.zeros((0, 2), dtype=np.int64)),
+              ("pair", 2, _sym([(0, 1)])), ("empty5", 5, np.zeros((0, 2), dtype=np.int64)),
+              ("grid8x8", 64, _sym([(8 * i + j, 8 * i + j + 1) for i in range(8) for j in range(7)] + [(8 * i + j, 8 * i + j + 8) for i in range(7) for j in range(8)]))]
+    host = _batch(topos, "zinc", seed=2)
+    # the Laplacian of the transform is that of the undirected simple graph: symmetrised, without self loops and duplicates, as the
+    # oracle builds it (GINESignNetPyG/core/transform.py:29-52 reads to_dense_adj of an undirected edge_index)
+    ei = host.edge_index
+    ei = torch.cat([ei, ei.flip(0)], 1)
+    ei = ei[:, ei[0] != ei[1]]
+    ei = torch.unique(ei, dim=1)
+    D, V = TR.evd_laplacian_batch(ei.to(DEV), ptr=_gptr(host.sizes), norm=norm)[:2]
+    worst = _check_batch(ei.numpy(), list(host.sizes), norm, D.cpu().numpy(), V.cpu().numpy())
+    print(f"\nEVD on degenerate spectra, norm = {norm}: worst {worst}")
