@@ -239,3 +239,31 @@ def test_evd_on_degenerate_spectra(norm):
     D, V = TR.evd_laplacian_batch(ei.to(DEV), ptr=_gptr(host.sizes), norm=norm)[:2]
     worst = _check_batch(ei.numpy(), list(host.sizes), norm, D.cpu().numpy(), V.cpu().numpy())
     print(f"\nEVD on degenerate spectra, norm = {norm}: worst {worst}")
+
+
+@pytest.mark.parametrize("variant,feats,ctor,max_k", CASES, ids=["gine_d64_k8", "gine_d128_k16", "alchemy_d44_allk"])
+def test_train_mode_forward_on_arbitrary_topologies(variant, feats, ctor, max_k):
+    """The differentiable train-mode forward (batch-statistics BatchNorm, the one-pass stage kernels of csrc/train.hip and the
+    layer-at-a-time kernels) on the topologies among ordinary molecules: value against the fp32 / float64 oracle, both train paths."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    rng = np.random.default_rng(11)
+    topos = _topologies(rng)
+    mols = [(f"mol{i}", n, synth._random_molecule(rng, n).T) for i, n in enumerate(rng.integers(9, 31, size=24).tolist())]
+    host = _batch([t for pair in zip(mols[:8], topos) for t in pair] + mols[8:], feats, seed=3)
+    model = _model(variant, ctor, max_k)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    cfg = O.make_cfg(variant, *ctor)
+    with torch.no_grad():
+        ref = O.signnet_gnn({k: v.clone() for k, v in sd.items()}, cfg, host, training=True, max_k=max_k)
+        ref64 = O.signnet_gnn(PU.to_f64(sd), cfg, PU.data_f64(host), training=True, max_k=max_k)
+    m = model.to(DEV).train()
+    dd = synth.batch_to(host, DEV)
+    for stages in (True, False):
+        m.load_state_dict(sd)                      # (the train-mode forward updates the running statistics)
+        m.train_stages = stages
+        y = m(dd)
+        assert y.requires_grad
+        # (train-mode BatchNorm over the 32 rows of the readout: the case's measured conditioning sets the bar, as for the fixtures)
+        e = PU.close_conditioned(y.detach(), ref, ref64, f"train-mode forward, stage kernels {stages}")
+        print(f"\n{variant} d={ctor[2]} stage kernels {stages}: |hip - ref| {e:.2e}, |cpu32 - f64| {PU.relerr(ref, ref64):.2e}")
