@@ -267,3 +267,30 @@ def test_train_mode_forward_on_arbitrary_topologies(variant, feats, ctor, max_k)
         # (train-mode BatchNorm over the 32 rows of the readout: the case's measured conditioning sets the bar, as for the fixtures)
         e = PU.close_conditioned(y.detach(), ref, ref64, f"train-mode forward, stage kernels {stages}")
         print(f"\n{variant} d={ctor[2]} stage kernels {stages}: |hip - ref| {e:.2e}, |cpu32 - f64| {PU.relerr(ref, ref64):.2e}")
+
+
+def test_overlap_mode_on_odd_batches_is_bit_identical():
+    """SignNetGNN.overlap_front (three-stage stream pipeline inside the module) over a sequence of very different resident batches —
+    the topology batch, a batch without edges, a single one-node graph, an ordinary batch — equals the sequential forwards bit for
+    bit, in order (a stage of one forward runs beside other stages of its neighbours: batches of 1 ... 1300 rows)."""
+    from signnet_basisnet_amd import synth
+    rng = np.random.default_rng(11)
+    topos = _topologies(rng)
+    hosts = [_batch(topos, "zinc", seed=3), synth.make_batch(4, seed=5, sizes=[1, 1, 1, 1]), synth.make_batch(1, seed=6, sizes=[1]),
+             synth.make_batch(48, seed=7), _batch(topos[::-1], "zinc", seed=4), synth.make_batch(2, seed=8, sizes=[1, 30])]
+    m = _model("gine", (None, None, 128, 1, 4, 6), 16).to(DEV).eval()
+    with torch.no_grad():
+        ref = [m(synth.batch_to(h, DEV)).clone() for h in hosts]
+        assert all(torch.isfinite(r).all() for r in ref)
+        m.strict, m.overlap_front = False, True
+        outs = []
+        for rep in range(4):
+            for i, h in enumerate(hosts):
+                b = synth.batch_to(h, DEV)
+                torch.cuda.synchronize()                 # resident batch: the mode's precondition
+                outs.append((i, m(b) * 1.0))
+                del b
+        m.check_last()
+        torch.cuda.synchronize()
+    for i, y in outs:
+        assert torch.equal(y, ref[i]), i
