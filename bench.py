@@ -716,6 +716,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="forward bench: `value` from the sequential pass (module overlap mode off)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
     ap.add_argument("--no-scatter", action="store_true", help="skip the scatter_roofline block (standalone GIN / GINE aggregation on > 256 MiB)")
+    ap.add_argument("--clock-ramp-ms", type=float, default=60.0,
+                    help="forward bench: after the W warm-up steps keep issuing untimed forwards until this much wall time has passed since "
+                         "the first one (the GPU reaches its sustained clock; 0 = off).  Reported as `clock_ramp` in the JSON line")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="inside the timed region, bracket every n-th launch of the dominant kernel with HIP events (1 = all; 0 = "
                          "automatic: max(4, steps // 12), i.e. about a dozen brackets over the timed steps and never more than one launch in four — a bracket is two marker packets that idle the stream "
@@ -778,9 +781,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    ramp_steps = 0
     with torch.no_grad():
+        t_ramp = time.perf_counter()
         for _ in range(args.warmup):
             model(data)
+        # clock ramp (untimed, reported in the line as `clock_ramp`): an idle MI355X needs tens of milliseconds of continuous work to reach
+        # its sustained clock, and W = 5 forwards are 1.4 ms of it — measured on one box, same command: phi 137-141 us and 0.290 ms per
+        # sequential step behind --warmup 5, 120-126 us and 0.266 ms behind --warmup 200 (= a loop that has been running for 50 ms,
+        # which is what a training / evaluation epoch is).  So the W warm-up steps are followed by more untimed forwards until
+        # --clock-ramp-ms of wall time have passed since the first one; the timed regions are unchanged (exactly K steps each).
+        if args.clock_ramp_ms > 0:
+            torch.cuda.synchronize()
+            while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
+                for _ in range(8):
+                    model(data)
+                ramp_steps += 8
+                torch.cuda.synchronize()
         # timed region: HIP events only around the dominant kernel, on the launch stream, every --event-stride-th step
         # (a bracket = two marker packets, each idling the stream for ~5 us: measured 0.277-0.284 / 0.270 / 0.266-0.267 ms per step at
         #  stride 1 / 4 / no events on the same box.  Default: about a dozen brackets over the timed steps, at least one in eight)
@@ -896,6 +913,10 @@ def main():
                                    "the roofline block's HIP events are taken in this pass"},
             "strict_mode": {"value": total_graphs / dt_strict, "unit": "graphs/s", "ms_per_step": 1e3 * dt_strict / args.steps,
                             "note": "the module's default: flags waited for after every forward (one host round trip per step); extra pass, not `value`"},
+            "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps,
+                           "note": "untimed forwards issued after the W warm-up steps until `ms` of wall time had passed since the first one, so "
+                                   "that the timed K steps run at the sustained clock (an idle GPU needs tens of ms of work to reach it; "
+                                   "--clock-ramp-ms 0 switches this off)"},
             "roofline": roof,
             "kernels": {k: {"launches_per_step": v[0] / nall, "mean_us": 1e3 * v[1], **all_roofs.get(k, {})}
                         for k, v in ktimes.items()},
