@@ -719,6 +719,9 @@ def main():
     ap.add_argument("--clock-ramp-ms", type=float, default=60.0,
                     help="forward bench: after the W warm-up steps keep issuing untimed forwards until this much wall time has passed since "
                          "the first one (the GPU reaches its sustained clock; 0 = off).  Reported as `clock_ramp` in the JSON line")
+    ap.add_argument("--overlap-warmup", type=int, default=32,
+                    help="forward bench: untimed forwards in the module's overlap mode before its K timed steps (the caching allocator needs a "
+                         "pipeline depth of forwards before it stops asking the driver for memory); reported in `clock_ramp`")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="inside the timed region, bracket every n-th launch of the dominant kernel with HIP events (1 = all; 0 = "
                          "automatic: max(4, steps // 12), i.e. about a dozen brackets over the timed steps and never more than one launch in four — a bracket is two marker packets that idle the stream "
@@ -825,7 +828,7 @@ def main():
         dt = dt_seq
         if overlap:
             model.overlap_front = True
-            for _ in range(max(4, args.warmup // 4)):
+            for _ in range(args.overlap_warmup):        # untimed: the mode's side streams, events and per-forward buffers reach their steady state
                 model(data)
             sync_all()
             t0 = time.perf_counter()
@@ -913,7 +916,7 @@ def main():
                                    "the roofline block's HIP events are taken in this pass"},
             "strict_mode": {"value": total_graphs / dt_strict, "unit": "graphs/s", "ms_per_step": 1e3 * dt_strict / args.steps,
                             "note": "the module's default: flags waited for after every forward (one host round trip per step); extra pass, not `value`"},
-            "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps,
+            "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps, "overlap_warmup_steps": args.overlap_warmup if overlap else 0,
                            "note": "untimed forwards issued after the W warm-up steps until `ms` of wall time had passed since the first one, so "
                                    "that the timed K steps run at the sustained clock (an idle GPU needs tens of ms of work to reach it; "
                                    "--clock-ramp-ms 0 switches this off)"},
