@@ -787,13 +787,16 @@ def main():
     ramp_steps = 0
     with torch.no_grad():
         t_ramp = time.perf_counter()
-        for _ in range(args.warmup):
+        for i in range(args.warmup):
             model(data)
+            if i == 0:                       # (the first forward packs the weights and loads the code objects: not GPU work)
+                torch.cuda.synchronize()
+                t_ramp = time.perf_counter()
         # clock ramp (untimed, reported in the line as `clock_ramp`): an idle MI355X needs tens of milliseconds of continuous work to reach
         # its sustained clock, and W = 5 forwards are 1.4 ms of it — measured on one box, same command: phi 137-141 us and 0.290 ms per
         # sequential step behind --warmup 5, 120-126 us and 0.266 ms behind --warmup 200 (= a loop that has been running for 50 ms,
         # which is what a training / evaluation epoch is).  So the W warm-up steps are followed by more untimed forwards until
-        # --clock-ramp-ms of wall time have passed since the first one; the timed regions are unchanged (exactly K steps each).
+        # --clock-ramp-ms of wall time have passed since the end of the first one; the timed regions are unchanged (exactly K steps each).
         if args.clock_ramp_ms > 0:
             torch.cuda.synchronize()
             while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
