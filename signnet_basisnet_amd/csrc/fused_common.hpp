@@ -154,9 +154,13 @@ struct WRing {
   __device__ __forceinline__ void init(void* lds_base, int wave_, int lane_) {
     base = (lds_char_t*)lds_base; pos = 0; wave = wave_; lane = lane_;
   }
+  // wait until at most N of my chunk shares are still in flight
+  template <int N>
+  __device__ __forceinline__ void wait_shares() const { wait_vmcnt<N * LPC>(); }
   __device__ __forceinline__ int slot_of(int c) const {
     const int x = pos + c;
     if (RING == 3) return x - 3 * ((x * 43) >> 7);       // x mod 3, x < 128
+    if (RING == 4) return x & 3;
     return x % RING;
   }
   // this wave's share of the DMA of chunk `c` of packed matrix `w` into ring slot `slot`.  Buffer form: the matrix
@@ -189,7 +193,7 @@ struct WRing {
 #pragma unroll
     for (int c = 0; c < RING; ++c)
       if (c < nchunks) issue(w, c, c);
-    if (nchunks >= RING) wait_vmcnt<(RING - 1) * LPC>(); else wait_vmcnt<0>();
+    if (nchunks >= RING) wait_shares<RING - 1>(); else wait_vmcnt<0>();
     lds_barrier();
   }
   // before the kernel exits: no LDS-DMA of this wave may still be in flight (the LDS would be handed to another workgroup)
@@ -274,7 +278,7 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW, RING>& ring, const v
       if (CHAIN) {
         // all my reads of chunk ot are complete and my share of chunk ot+1 has landed -> barrier -> refill the slot
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_vmcnt<(RING - 2) * R::LPC>();
+        ring.template wait_shares<RING - 2>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stage(ot);
@@ -289,11 +293,110 @@ __device__ __forceinline__ void wg_gemm_split(WRing<NT, NW, RING>& ring, const v
   } else if (CHAIN) {
 #pragma unroll
     for (int ot = 0; ot < NTO; ++ot) {
-      wait_vmcnt<(RING - 2) * R::LPC>();
+      ring.template wait_shares<RING - 2>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       stage(ot);
     }
+  }
+  ring.pos = ring.slot_of(NTO);
+}
+
+// =====================================================================================================
+// wg_gemm_split for the 8-wave phi workgroup (round 4): a FOUR-slot ring for the same look-ahead of three chunks.  With three
+// slots the chunk barrier of tile ot had to certify "every read of chunk ot has returned" (s_waitcnt lgkmcnt(0) in front of it) so
+// that the slot could be refilled right behind it; with four the refill goes into the slot of chunk ot-1, which every wave left a
+// whole tile ago — a fragment read is retired by the MFMA that consumes it — so nothing but the wave's own DMA share is waited for
+// at the barrier, and a wave may take the barrier at ANY K block of its tile (BAR_KB):
+//     + waves (BAR_KB = NKB-1):  [kb0 kb1 kb2 | wait, barrier, DMA issue | kb3, epilogue]
+//     - waves (BAR_KB = 1):      [kb0 | wait, barrier, DMA issue | kb1 kb2 kb3, epilogue]
+// i.e. the two sign waves of a SIMD are half a tile out of phase at every barrier: one is in the middle of its tile's MFMAs while
+// the other waits, issues and applies its epilogue.  Measured on the headline batch (same box, HIP events): one-stream form with
+// three slots 119.1 us; four slots, no LDS drain, both barriers at NKB-1: 114.6; with the half-tile lag: 112.3-113.0.
+// What was measured on the way and dropped (all slower than the one-stream form): strict ping-pong with two
+// barriers per tile (L | M segments alternating between the wave groups, 130 us: the L segment — 4 waves x 16 KB of ds_read_b128
+// behind the DMA issue — is a ~500-cycle serial chain, longer than the 384-cycle MFMA segment it was meant to hide behind), one
+// barrier per tile with complementary segment ORDER (M,L / L,M: 133 us — a wave's own L + M chain is what bounds the interval, not
+// the pipe), s_setprio in any combination (no effect on MFMA arbitration between the two waves of a SIMD), each accumulator as one
+// back-to-back MFMA chain instead of two alternating ones (no effect), half of the waves issuing the whole DMA (116-120 us).
+// Protocol:
+//   * at barrier ot (every wave calls it once per tile) chunk ot+1 becomes visible (every wave waited for its share of it right
+//     before) and chunk ot+3 is issued into the slot of chunk ot-1;
+//   * the first fragment of chunk ot+1 is fetched during the tile's last K block, i.e. behind barrier ot for either BAR_KB;
+//   * entry state (ring_prologue3, or the previous GEMM's `wnext`): chunk 0 visible, chunks 1 and 2 in flight.
+// =====================================================================================================
+constexpr int LAG_RING = 4;
+
+template <int NT, int NW>
+__device__ __forceinline__ void ring_prologue3(WRing<NT, NW, LAG_RING>& ring, const void* w) {
+  lds_barrier();   // nobody still reads the ring
+  ring.pos = 0;
+  ring.issue(w, 0, 0);
+  ring.issue(w, 1, 1);
+  ring.issue(w, 2, 2);
+  ring.template wait_shares<2>();
+  lds_barrier();
+}
+
+template <int NT, int NTO, int BAR_KB, int NW, typename Pre, typename Epi>
+__device__ __forceinline__ void wg_gemm_split_lag(WRing<NT, NW, LAG_RING>& ring, const void* w, const void* wnext, bool live,
+                                                  const Split8 (&xs)[(NT + 1) / 2], Pre pre, Epi epi) {
+  using R = WRing<NT, NW, LAG_RING>;
+  constexpr int NKB = R::NKB;
+  static_assert(NTO >= 3 && BAR_KB >= 0 && BAR_KB < NKB, "look-ahead of three chunks; the barrier sits in front of a K block of the tile");
+  typedef __attribute__((address_space(3))) const u32x4 lds_u32x4;
+  typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+  int sl[LAG_RING];
+#pragma unroll
+  for (int i = 0; i < LAG_RING; ++i) sl[i] = ring.slot_of(i);
+  auto slot = [&](int c) { return sl[c % LAG_RING]; };   // c is a compile-time constant
+  auto sync_stage = [&](int ot) {   // barrier ot: chunk ot + 1 published, chunk ot + 3 -> the slot of chunk ot - 1
+    ring.template wait_shares<1>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int pc = ot + 3;
+    if (pc < NTO) ring.issue(w, pc, slot(pc)); else ring.issue(wnext, pc - NTO, slot(pc));
+  };
+  if (live) {
+    int ln16 = ring.lane * 16;
+    asm volatile("" : "+v"(ln16));   // per call: keeps the per-lane fragment addresses of every GEMM from being hoisted and held
+    const lds_char_t* lbase = ring.base + ln16;
+    auto rd = [&](int c, int kb) {
+      const lds_char_t* p = lbase + slot(c) * R::CHUNK + kb * 3072;
+      WFrag f;
+      f.h = *(lds_u32x4*)(p);
+      f.m = *(lds_u32x4*)(p + 1024);
+      f.l = *(lds_u32x4*)(p + 2048);
+      return f;
+    };
+    WFrag fa = rd(0, 0), fb;
+#pragma unroll
+    for (int ot = 0; ot < NTO; ++ot) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      // epilogue operands first: their LDS latency hides behind this tile's MFMAs
+      const lds_char_t* pe = lbase + slot(ot) * R::CHUNK + R::NF * 1024;
+      const f32x4 e0 = *(lds_f32x4*)(pe), e1 = *(lds_f32x4*)(pe + 1024), e2 = *(lds_f32x4*)(pe + 2048);
+      const f32x4 pv = pre(ot);
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        if (kb == BAR_KB) sync_stage(ot);
+        if (kb + 1 < NKB) fb = rd(ot, kb + 1);
+        else if (ot + 1 < NTO) fb = rd(ot + 1, 0);     // (behind barrier ot, which published chunk ot + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        a1 = mfma_bf(fa.l, xs[kb].h, a1);
+        a0 = mfma_bf(fa.m, xs[kb].h, a0);
+        a1 = mfma_bf(fa.h, xs[kb].l, a1);
+        a0 = mfma_bf(fa.h, xs[kb].m, a0);
+        a1 = mfma_bf(fa.m, xs[kb].m, a1);
+        a0 = mfma_bf(fa.h, xs[kb].h, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        fa = fb;
+      }
+      epi(ot, a0 + a1, e0, e1, e2, pv);
+    }
+  } else {
+#pragma unroll
+    for (int ot = 0; ot < NTO; ++ot) sync_stage(ot);
   }
   ring.pos = ring.slot_of(NTO);
 }

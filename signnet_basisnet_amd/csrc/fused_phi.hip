@@ -25,12 +25,27 @@
 // epilogue, fragment reads, AGPR moves at 400 registers) and nothing else can fill the matrix pipe meanwhile.
 // Bound: bf16 MFMA / 6 (exact three-way split of both operands, six partial products, fp32 accumulate); algorithmic
 // flops per valid row: 2 signs * (L-1) layers * 2 GEMMs * 2*d*d.
+#include <type_traits>
+
 #include "fused_common.hpp"
 
 namespace sn {
 
 constexpr int PHI_R = SN_PHI_BIN_ROWS;  // rows per bin / workgroup
 constexpr int PHI_WAVES = 2 * (PHI_R / 16);   // one wave per (16-row tile, sign)
+
+// From three output tiles on, the GEMMs run on wg_gemm_split_lag (fused_common.hpp): a four-slot weight ring with a look-ahead of
+// three chunks, no LDS drain in front of the chunk barrier, and the two sign waves of a SIMD half a tile out of phase at every
+// barrier (the + waves take it in front of the tile's last K block, the - waves in front of its second).
+// (-DSN_PHI_NOLAG: the one-stream form of rounds 2-3, for A/B runs: profiles/scripts/ab.sh.)
+constexpr bool phi_lagged(int nt) {
+#ifdef SN_PHI_NOLAG
+  return false;
+#else
+  return nt >= 3;
+#endif
+}
+constexpr int phi_lag_kb(int nkb) { return nkb - 1 - nkb / 2; }   // NKB = 4: K block 1
 
 struct PhiStruct {
   const float* ev;
@@ -49,6 +64,13 @@ struct PhiStruct {
   float* out;
   int dense_ld;              // DGL variant: the input is a dense [N, dense_ld] matrix of positional encodings (row = node), not eigenvectors
 };
+
+#ifdef SN_TIMELINE   // scratch builds only: a few wall-clock stamps (s_memrealtime, 100 MHz) per workgroup
+static __device__ long long g_tl[1024][8];
+#define SN_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_tl[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define SN_TL(i) do { } while (0)
+#endif
 
 constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
 // Row descriptors of PHI_GB bins at a time: a bin's decode (bin -> column -> member graph -> node -> CSR range, eigenvector entry, first
@@ -69,7 +91,8 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;  // +4 floats: conflict-free ds_write_b128 of 8 consecutive rows
   constexpr int NKB = (NT + 1) / 2;
-  using Ring = WRing<NT, PHI_WAVES>;
+  constexpr bool LAG = phi_lagged(NT);
+  using Ring = WRing<NT, PHI_WAVES, LAG ? LAG_RING : SPLIT_RING>;
   extern __shared__ __align__(1024) unsigned char lds_raw[];
   float* X2 = reinterpret_cast<float*>(lds_raw + Ring::BYTES);  // [2 signs][PHI_R][LD]  x_l
   float* dxs = X2 + 2 * PHI_R * LD;                             // [GB][PHI_R] scalar eigenvector entries (layer 0)
@@ -84,18 +107,28 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   const int sg = wave >> 2;                                     // 0: phi(+x), 1: phi(-x)   (wave-uniform)
   float* X = X2 + sg * PHI_R * LD;                              // the image of my sign
   const int r = (wave & 3) * 16 + (lane & 15), g = lane >> 4;
+  SN_TL(0);
   const int nbins = S.meta[0];
   if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
   { SN_PROF_ON(true); SN_STAMP(12); }
 #ifdef SN_PROFILE
-  if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 3; i <= 20; ++i) g_prof[i] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 3; i < 64; ++i) g_prof[i] = 0;
+    g_prof[12] = clock64();
+  }
 #endif
   Ring ring;
   ring.init(lds_raw, wave, lane);
   // first [d,d] Linear of a (bin, sign) pass — where the weight stream (re)starts
   const void* wfirst = !HID1 ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
-  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
+  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) {
+    if constexpr (LAG) ring_prologue3(ring, wfirst); else ring.prologue(wfirst, NT);
+  }
 
+  SN_TL(1);
+#ifdef SN_TIMELINE
+  int tl_bin = 0;
+#endif
   for (int base = blockIdx.x; base < nbins; base += gridDim.x * PHI_GB) {
     // ------------------------------------------------------------------ decode pass: wave w -> bin base + w * gridDim.x, lane -> row
     __syncthreads();   // the previous group is done with the descriptors
@@ -139,6 +172,9 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       }
     }
     __syncthreads();
+#ifdef SN_TIMELINE
+    if (base == (int)blockIdx.x) SN_TL(2);
+#endif
 #pragma unroll 1
     for (int lb = 0; lb < PHI_GB; ++lb) {
     const int bin = base + lb * (int)gridDim.x;
@@ -171,24 +207,26 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       a0 = a0 + self;
     }
     SN_STAMP(2);
-    {
-#ifdef SN_PROFILE
-      long long ptop = clock64();
-#endif
+    // The layers, once for a wave with rows and once for a wave whose tile is empty (it only keeps the workgroup's barriers and
+    // its share of the weight stream going): two instantiations under a wave-uniform branch, so that the row state (in, o, sp)
+    // is local to the live one — as `if (wave_live)` blocks inside one body it was loop-carried across bins (64 registers).
+    auto layers = [&](auto live_c, auto role_c) {
+      constexpr bool LIVE = decltype(live_c)::value;
+      constexpr int ROLE = decltype(role_c)::value;       // 1: a + wave (chunk barrier late in the tile), 0: a - wave (early)
+      constexpr int BARKB = ROLE == 0 ? phi_lag_kb(NKB) : NKB - 1;
       // (compiler fence: without it the layer-0 vectors — loop invariant — are hoisted out of the bin loop into
       //  ~128 VGPRs that then live in scratch for the whole kernel)
       asm volatile("" ::: "memory");
       const float as = sg ? -a0 : a0;          // phi(-x): the aggregate of -x is exactly -(aggregate of x)   (sg: my wave's sign)
       f32x4 in[NT], o[NT];
       Split8 sp[NKB];
-      SN_ACCUM(15, ptop);
 #ifdef SN_PROFILE
       pt = clock64();
 #endif
       // -------------------------------------------------------------- layer 0
       if (HID1) {
         // Linear(1->1) . BN . ReLU . Linear(1->d) [+b] . BN . ReLU          (core/sign_net.py:20, masked_layers.py:54-64)
-        if (wave_live) {
+        if (LIVE) {
           const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
           const float t = fmaxf((as * w1) * s0 + h0, 0.f);
           const float* w2v = reinterpret_cast<const float*>(P.l0_w2);
@@ -203,7 +241,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         }
       } else {
         // Linear(1->d) . BN . ReLU . Linear(d->d) [+b] . BN . ReLU           (Alchemy sign_net.py:20)
-        if (wave_live) {
+        if (LIVE) {
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
             const int c = 16 * kk + 4 * g;
@@ -213,13 +251,14 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
           split_rows<NT>(o, sp);
         }
         const void* nxt = P.n_layers > 1 ? P.layers[0].w1s : wfirst;
-        wg_gemm_split<NT, NT, false>(ring, P.l0_w2, nxt, wave_live, sp, NoPre(),
-                                     [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4) {
-                                       const f32x4 v = (acc + b2) * s1 + h1;
-                                       in[ot] = DGL ? v : relu4(v);
-                                     });
+        auto epi0 = [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4) {
+          const f32x4 v = (acc + b2) * s1 + h1;
+          in[ot] = DGL ? v : relu4(v);
+        };
+        if constexpr (LAG) wg_gemm_split_lag<NT, NT, BARKB>(ring, P.l0_w2, nxt, LIVE, sp, NoPre(), epi0);
+        else wg_gemm_split<NT, NT, false>(ring, P.l0_w2, nxt, LIVE, sp, NoPre(), epi0);
       }
-      if (!valid) {
+      if (LIVE && !valid) {
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -232,7 +271,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         pt = clock64();
 #endif
         // publish x_l for the neighbour sums and the residual
-        if (wave_live) {
+        if (LIVE) {
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
         }
@@ -241,7 +280,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
 #ifdef SN_PROFILE
         pt = clock64();
 #endif
-        if (wave_live) {
+        if (LIVE) {
           // GIN aggregate: sum of in-neighbours (edge-id order), then + (1+eps) * self.  The first four neighbours
           // (molecular graphs: all of them) are gathered with predicated, fully unrolled reads so that the LDS
           // latency of one neighbour hides behind the next; a missing neighbour adds +0.
@@ -294,27 +333,31 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         pt = clock64();
 #endif
         // MaskedMLP: Linear . BN . ReLU . Linear [+b]
-        wg_gemm_split<NT, NT, false>(ring, Lp.w1s, Lp.w2s, wave_live, sp, NoPre(),
-                                     [&](int ot, f32x4 acc, f32x4 s0, f32x4 h0, f32x4, f32x4) { o[ot] = relu4(acc * s0 + h0); });
+        auto epi1 = [&](int ot, f32x4 acc, f32x4 s0, f32x4 h0, f32x4, f32x4) { o[ot] = relu4(acc * s0 + h0); };
+        if constexpr (LAG) wg_gemm_split_lag<NT, NT, BARKB>(ring, Lp.w1s, Lp.w2s, LIVE, sp, NoPre(), epi1);
+        else wg_gemm_split<NT, NT, false>(ring, Lp.w1s, Lp.w2s, LIVE, sp, NoPre(), epi1);
         SN_ACCUM(7, pt);
 #ifdef SN_PROFILE
         pt = clock64();
 #endif
-        if (wave_live) split_rows<NT>(o, sp);
-        asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+        if (LIVE) {
+          split_rows<NT>(o, sp);
+          asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+        }
         SN_ACCUM(8, pt);
 #ifdef SN_PROFILE
         pt = clock64();
 #endif
         const void* nxt = (l + 1 < P.n_layers) ? P.layers[l].w1s : wfirst;   // the next bin restarts the stream here
         // GNN3d: mask . BN . ReLU . + previous_x
-        wg_gemm_split<NT, NT, false>(
-            ring, Lp.w2s, nxt, wave_live, sp, [&](int ot) { return lds_ld4(XR + 16 * ot + 4 * g); },
-            [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4 prev) {
-              const f32x4 v = (acc + b2) * s1 + h1;
-              in[ot] = DGL ? v : relu4(v) + prev;
-            });
-        if (!valid) {
+        auto pre2 = [&](int ot) { return lds_ld4(XR + 16 * ot + 4 * g); };
+        auto epi2 = [&](int ot, f32x4 acc, f32x4 b2, f32x4 s1, f32x4 h1, f32x4 prev) {
+          const f32x4 v = (acc + b2) * s1 + h1;
+          in[ot] = DGL ? v : relu4(v) + prev;
+        };
+        if constexpr (LAG) wg_gemm_split_lag<NT, NT, BARKB>(ring, Lp.w2s, nxt, LIVE, sp, pre2, epi2);
+        else wg_gemm_split<NT, NT, false>(ring, Lp.w2s, nxt, LIVE, sp, pre2, epi2);
+        if (LIVE && !valid) {
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) in[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -332,12 +375,12 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       // The two waves of a row tile exchange their results through the LDS image (free now: every wave is past the last
       // layer's gathers — it went through that layer's GEMM barriers); the + wave stores the lower half of the channel tiles
       // of the sum, the - wave the upper half.
-      if (wave_live) {
+      if (LIVE) {
 #pragma unroll
         for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
       }
       lds_barrier();
-      if (valid && !DGL) {
+      if (LIVE && valid && !DGL) {
         float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb]) * P.d;       // (re-read: not kept live across the layers)
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;     // the same row in the other sign's image
         constexpr int H = (NT + 1) / 2;
@@ -353,7 +396,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
           }
         }
       }
-      if (valid && DGL) {
+      if (LIVE && valid && DGL) {
         const int dout = P.reserved;                               // phi_out_dim: any width <= d (rows are not float4-aligned)
         float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb]) * dout;
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;
@@ -372,18 +415,31 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         }
       }
       SN_ACCUM(14, pt);
+    };
+    if constexpr (LAG) {
+      // an instantiation per sign: the barrier position is a compile-time property of the wave's stream
+      if (sg) { if (wave_live) layers(std::true_type{}, std::integral_constant<int, 0>{}); else layers(std::false_type{}, std::integral_constant<int, 0>{}); }
+      else { if (wave_live) layers(std::true_type{}, std::integral_constant<int, 1>{}); else layers(std::false_type{}, std::integral_constant<int, 1>{}); }
+    } else {
+      if (wave_live) layers(std::true_type{}, std::integral_constant<int, -1>{}); else layers(std::false_type{}, std::integral_constant<int, -1>{});
     }
+#ifdef SN_TIMELINE
+    if (tl_bin < 4) SN_TL(3 + tl_bin);
+    ++tl_bin;
+#endif
     SN_STAMP(11);
     }
   }
   { SN_PROF_ON(true); SN_STAMP(13); }
   ring.drain();
+  SN_TL(7);
 }
 
 template <int NT, bool HID1, bool DGL = false>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
-  const size_t lds = (size_t)WRing<NT, PHI_WAVES>::BYTES + (size_t)(2 * PHI_R * LD) * sizeof(float) + (size_t)PHI_DESC_BYTES;
+  const size_t lds = (size_t)WRing<NT, PHI_WAVES, phi_lagged(NT) ? LAG_RING : SPLIT_RING>::BYTES + (size_t)(2 * PHI_R * LD) * sizeof(float) +
+                     (size_t)PHI_DESC_BYTES;
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&
@@ -404,6 +460,9 @@ static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st
 
 using namespace sn;
 
+#ifdef SN_TIMELINE
+extern "C" int sn_timeline_read_phi(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_tl), sizeof(long long) * 1024 * 8); }
+#endif
 #ifdef SN_PROFILE
 extern "C" int sn_prof_read_phi(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_prof), sizeof(long long) * 64); }
 #endif

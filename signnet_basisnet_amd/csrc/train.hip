@@ -1369,7 +1369,15 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   SN_REQUIRE(!p.nvalid || p.K > 0, "sn_train_linear_f32: nvalid needs K > 0");
   SN_REQUIRE((p.in_scale == nullptr) == (p.in_shift == nullptr) && (!p.in_scale || (al16(p.in_scale) && al16(p.in_shift))),
              "sn_train_linear_f32: in_scale / in_shift go together, 16-byte aligned");
-  if (p.R == 0) return SN_OK;
+  if (p.R == 0) {
+    // no rows: no launch; the moment partials a BatchNorm finish would read are defined (count 0), never left uninitialised
+    if (p.stat_part) {
+      const int nb0 = sn_train_linear_blocks(0, p.G);
+      if (hipMemsetAsync(p.stat_part, 0, sizeof(float) * (size_t)p.G * (2 * (size_t)nb0 * p.d_out + nb0), (hipStream_t)stream) != hipSuccess)
+        return fail(SN_ERR_LAUNCH, "sn_train_linear_f32: memset of the moment partials failed");
+    }
+    return SN_OK;
+  }
   const int nblk = sn_train_linear_blocks(p.R, p.G);
   TLin a{p.x, p.ldx, p.R, p.G, p.d_in, p.d_out, p.W, p.ldw, p.bias, p.nvalid, p.K, p.in_scale, p.in_shift, p.in_relu, p.out_relu,
          p.y, p.ldy, p.stat_part, nblk};

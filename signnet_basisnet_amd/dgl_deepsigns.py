@@ -459,6 +459,9 @@ class _DeepSignsBase(nn.Module):
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream(device=xin.device)
         side = self._side_stream
+        if getattr(self, "_side_wait", False):
+            # x was converted (dtype / layout) by a kernel queued on the caller's stream a moment ago: the side stream must see it
+            side.wait_stream(torch.cuda.current_stream(xin.device))
         with torch.cuda.stream(side), _lib_mod.stream_scope():
             y, z = self._fused.run(cached_plan(g, N, K), xin, N)
             ev = torch.cuda.Event()
@@ -490,6 +493,7 @@ class _DeepSignsBase(nn.Module):
             if self._fused.ok and N > 0 and _max_nodes(g) <= ops.PHI_BIN_ROWS and int(g.batch_num_nodes().numel()) <= 6144:
                 xin = x.contiguous().float().view(N, K)
                 if getattr(self, "overlap", False):
+                    self._side_wait = xin.data_ptr() != x.data_ptr()     # a copy / cast was queued on the caller's stream
                     return self._forward_side(g, xin, N, K)
                 y, _ = self._fused.run(cached_plan(g, N, K), xin, N)
                 return y.view(N, K, 1)

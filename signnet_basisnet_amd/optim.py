@@ -42,6 +42,40 @@ class Adam:
                                          self.eps, self.weight_decay, self.t, 1.0, stream()), "sn_adam_step_f32")
 
 
+_HOOK_PROBE = None
+
+
+def _hooks_fire_without_a_returned_gradient() -> bool:
+    """Do a leaf's post-accumulate-grad hooks run when the adjoint that feeds it returned None (an undefined gradient)?  The stage
+    kernels `+=` straight into FlatAdam's flat gradient and hand autograd None (train_stage.direct_grad); the bucketed all-reduce
+    learns from those hooks that a bucket is complete.  True on the torch this was written against (2.10); probed once per process
+    instead of pinning the version — where it is False, FlatAdam keeps the overlap and drops the direct accumulation."""
+    global _HOOK_PROBE
+    if _HOOK_PROBE is None:
+        fired = []
+        if not hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            _HOOK_PROBE = False
+            return False
+
+        class _NoGrad(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                return g, None
+
+        with torch.enable_grad():
+            w = torch.zeros(1, requires_grad=True)
+            x = torch.ones(1, requires_grad=True)
+            h = w.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+            _NoGrad.apply(x, w).sum().backward()
+            h.remove()
+        _HOOK_PROBE = bool(fired)
+    return _HOOK_PROBE
+
+
 class FlatAdam:
     """Adam over ONE flat parameter buffer: every parameter's storage and gradient become views into two contiguous fp32
     buffers, so a step is a single kernel launch over the whole model and — with `dist` (torch.distributed, RCCL on ROCm) —
@@ -98,8 +132,13 @@ class FlatAdam:
         if dist is not None and overlap and hasattr(self.params[0], "register_post_accumulate_grad_hook"):
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
-        for p in self.params:                    # .grad is a view of the zeroed flat buffer: `+=` inside an adjoint kernel IS AccumulateGrad
-            p._sn_direct_grad = True
+        # .grad is a view of the zeroed flat buffer: `+=` inside an adjoint kernel IS AccumulateGrad.  With the bucket hooks armed that
+        # is only safe where autograd still runs a parameter's hooks after an adjoint that returned None for it (probed, see above):
+        # otherwise a bucket could be all-reduced before the kernels that add into it have run.
+        direct = not self._hooks or _hooks_fire_without_a_returned_gradient()
+        for p in self.params:
+            p._sn_direct_grad = direct
+        self._sync = True
 
     def disable_overlap(self):
         """Drop the post-accumulate hooks: every bucket's all-reduce is then issued by step() (one after the other, after the backward).
@@ -115,13 +154,31 @@ class FlatAdam:
 
         def hook(_param):
             if self._work[b] is not None:
-                raise RuntimeError("FlatAdam: a gradient arrived in a bucket whose all-reduce was already issued (the set of "
-                                   "parameters used by the forward changed between steps); construct with overlap=False")
+                raise RuntimeError("FlatAdam: a gradient arrived in a bucket whose all-reduce is already in flight — a second backward() "
+                                   "before step() (gradient accumulation: run every backward but the last under `with optimizer.no_sync():`), "
+                                   "or the set of parameters the forward uses changed between steps (construct with overlap=False). "
+                                   "The bucket's gradient has already been summed across ranks in place: discard this step")
             self._fired[b].add(i)
-            if self._expect[b] is not None and self._fired[b] == self._expect[b]:
+            if self._sync and self._expect[b] is not None and self._fired[b] == self._expect[b]:
                 self._launch(b)
                 self.early_launches += 1
         return hook
+
+    def no_sync(self):
+        """Gradient accumulation (as DistributedDataParallel.no_sync): backward passes inside the context only accumulate into the flat
+        gradient; the buckets go out from the hooks of the first backward OUTSIDE it (or from step())."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, self._sync = self._sync, False
+            try:
+                yield
+            finally:
+                self._sync = prev
+                for f in self._fired:       # the last backward's hooks start from an empty set again
+                    f.clear()
+        return ctx()
 
     def _launch(self, b):
         lo, hi = self.buckets[b]

@@ -626,7 +626,11 @@ class SignNetGNN(nn.Module):
         for li, tl in enumerate(sn.rho.transformer_layers):
             a, f = tl.slf_attn, tl.pos_ffn
             q, k, v = T.qkv(x, a.w_qs, a.w_ks, a.w_vs, nv, K) if stage else (lin(x, a.w_qs), lin(x, a.w_ks), lin(x, a.w_vs))
-            pm = static_masks[li] if static_masks is not None else ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device)
+            pm = static_masks[li] if static_masks is not None else None
+            if pm is not None and tuple(pm.shape) != (N, N_HEAD, K, K):   # masks of another batch shape: never reuse them
+                pm = None
+            if pm is None:
+                pm = ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device)
             o = AG.set_attention(q, k, v, N, K, N_HEAD, nv, pm)
             o = lin(o, a.fc)
             y = AG.masked_layernorm(o, x, a.norm.ln.weight, a.norm.ln.bias, LN_EPS, nv, K)

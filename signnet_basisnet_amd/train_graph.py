@@ -16,6 +16,8 @@ model(data), L1 loss, loss.backward(), optimizer.step().
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 _FIELDS = ("x", "edge_index", "edge_attr", "batch", "eigen_values", "eigen_vectors")
@@ -41,7 +43,6 @@ class GraphedStep:
         self.data, self.target = data, target
         self.shapes = {f: tuple(getattr(data, f).shape) for f in _FIELDS}
         model.train()
-        model._defer_status = True                  # no host read of the plan's status words inside the step: check_train() after it
         # the attention dropout (transformer_module.py:46,55; the one dropout the reference leaves active) is random per step: its masks
         # are drawn OUTSIDE the graph with torch's device generator — the same draws in the same order as the eager step — into static
         # buffers the captured kernels read
@@ -55,7 +56,7 @@ class GraphedStep:
             st0 = torch.cuda.get_rng_state(data.batch.device)
             self._masks = [torch.empty_like(m) for m in self._draw()]
             torch.cuda.set_rng_state(st0, data.batch.device)       # (the sizing draw does not count)
-        model._attn_masks = self._masks
+        self._status = None
 
         def fwd_bwd():
             optimizer.flat_g.zero_()
@@ -69,21 +70,45 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         rng = torch.cuda.get_rng_state(data.batch.device) if self._masks is not None else None
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._refresh_masks()
-                fwd_bwd()
-        torch.cuda.current_stream().wait_stream(side)
-        model.check_train()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            loss, y = fwd_bwd()
+        with self._scoped():
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._refresh_masks()
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            model.check_train()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                loss, y = fwd_bwd()
+            # the captured forward's status words (static memory of the graph): every replay rewrites them, check() reads them
+            self._status, model._train_status = getattr(model, "_train_status", None), None
         with torch.no_grad():
             for b, sv in zip(model.buffers(), saved):
                 b.copy_(sv)
         if rng is not None:
             torch.cuda.set_rng_state(rng, data.batch.device)      # the warm-up's draws do not count: the first step draws what an eager one would
         self.loss, self.y = loss.detach(), y.detach()
+
+    @contextlib.contextmanager
+    def _scoped(self):
+        """The two switches the captured step needs on the MODEL — no host read of the status words inside the forward, attention
+        dropout masks read from this object's static buffers — are set only while this object runs the model (warm-up and capture;
+        a replay does not call the model at all) and restored afterwards: an eager train-mode forward of the same model (a ragged last
+        batch, a second loop) draws fresh masks and checks its embedding indices as if no GraphedStep existed."""
+        m = self.model
+        saved = (getattr(m, "_defer_status", False), getattr(m, "_attn_masks", None))
+        m._defer_status, m._attn_masks = True, self._masks
+        try:
+            yield
+        finally:
+            m._defer_status, m._attn_masks = saved
+
+    def check(self):
+        """Reads the status words of the LAST replayed step (one host wait): raises IndexError for a discrete feature outside its
+        embedding table, as nn.Embedding does in the reference's eager step.  step() calls it every `check_every` steps."""
+        if self._status is not None and int(self._status[5]):
+            from . import ops
+            raise IndexError(ops.EMBEDDING_INDEX_ERROR)
 
     def _refresh_masks(self):
         if self._masks is not None:
@@ -103,11 +128,16 @@ class GraphedStep:
         if target is not None:
             self.target.copy_(target, non_blocking=True)
 
+    check_every = 64     # replays between two reads of the status words (0 = only when the caller calls check())
+
     def step(self, data=None, target=None):
         self.load(data, target)
         self._refresh_masks()
         self.graph.replay()
         self.optimizer.step()
+        self._nsteps = getattr(self, "_nsteps", 0) + 1
+        if self.check_every and self._nsteps % self.check_every == 0:
+            self.check()
         return self.loss
 
 

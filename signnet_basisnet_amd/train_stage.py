@@ -108,7 +108,15 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
     with ops._span("sn_train_linear_f32"):
         check(lib().sn_train_linear_f32(C.byref(a), stream()), "sn_train_linear_f32")
     st = None
-    if bn is not None:
+    if bn is not None and R <= 0:
+        # no rows (an edge encoder over a batch without edges): nn.BatchNorm1d in training mode returns the empty tensor, leaves the running
+        # statistics alone and counts the batch — nothing to finish (the kernel above did not run: its moment partials are zeros)
+        st = BNState(G, d_out, x.device)
+        st.state.zero_()
+        st.count.zero_()
+        if bn.track_running_stats and bn.running_mean is not None and bn.num_batches_tracked is not None:
+            ops._count_batch(bn, G)
+    elif bn is not None:
         st = BNState(G, d_out, x.device)
         mom = 0.1 if bn.momentum is None else float(bn.momentum)
         track = bn.track_running_stats and bn.running_mean is not None

@@ -7,10 +7,18 @@ from oracle import basisnet as OB
 from oracle import dgl_deepsigns as OD
 from oracle import pyg_signnet as O
 
-TOL = dict(rtol=2e-5, atol=2e-6)
-# batch-stat BN sums in a different order than the reference's transpose(2,1) layout -> fp32 noise
-TOL_BS = dict(rtol=5e-4, atol=5e-5)   # train-mode BN over ~40 rows is ill-conditioned: both sides sit
-# 0.7-2.6e-5 from the fp64 value of the same formula (checked when the fixture was made)
+# The pin of the oracle (<= 1e-6 abs).  Measured distances to the reference's fixture outputs in the build
+# container (round 4): every PyG case, eval and train mode, every stage: 0.0 (bit-identical); DGL DeepSigns eval 6e-8 / 2e-7 abs.
+TOL = dict(rtol=1e-6, atol=1e-6)
+TOL_DGL_EVAL = dict(rtol=2e-6, atol=2e-6)
+# TRAIN mode of the DGL modules only: their batch-statistics BatchNorm sums in a different order than the reference's
+# transpose(2,1) layout, over ~40 rows (ill-conditioned): measured 5.6e-6 / 3.0e-5 abs on outputs of magnitude 2.2-2.4; both sides
+# sit 0.7-2.6e-5 from the fp64 value of the same formula (checked when the fixture was made)
+TOL_BS = dict(rtol=5e-4, atol=5e-5)
+
+
+def _tol(mode):
+    return TOL_BS if mode == "train" else TOL_DGL_EVAL
 
 
 @pytest.mark.parametrize("name", G.PYG_CASES)
@@ -33,7 +41,7 @@ def test_dgl_gin_deepsigns(mode):
     hidden, c, layers, k = (int(v) for v in fx.meta["params"])
     ei = fx.inp["edge_index"]
     y = OD.gin_deepsigns(fx.sd, ei[0], ei[1], fx.inp["pos_enc"].unsqueeze(-1), layers, k, training=(mode == "train"))
-    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **(TOL_BS if mode == "train" else TOL_DGL_EVAL))
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -43,7 +51,7 @@ def test_dgl_masked_gin_deepsigns(mode):
     ei = fx.inp["edge_index"]
     y = OD.masked_gin_deepsigns(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["pos_enc"].unsqueeze(-1), layers, k,
                                 training=(mode == "train"))
-    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **(TOL_BS if mode == "train" else TOL_DGL_EVAL))
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -236,12 +244,12 @@ def test_dgl_pna_base_net(mode):
     hidden, L, k, towers, edge_dim = (int(v) for v in fx.meta["params"])
     ei = fx.inp["edge_index"]
     p = _sign_inv_p(fx, "gin", 3, k, mode)
-    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **TOL_BS)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **_tol(mode))
     out = {}
     y = ON.pna_net(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out[f"{mode}/p"], fx.inp["edge_attr"],
                    fx.inp["snorm_n"], L, towers, float(fx.meta["avg_d"][2]), "sum", training=(mode == "train"), out=out)
-    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **TOL_BS)
-    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **_tol(mode))
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **_tol(mode))
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -252,11 +260,11 @@ def test_dgl_gat_base_net(mode):
     hidden, L, k, heads = (int(v) for v in fx.meta["params"])
     ei = fx.inp["edge_index"]
     p = _sign_inv_p(fx, "gin", 3, k, mode)
-    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **TOL_BS)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **_tol(mode))
     out = {}
     y = ON.gat_net(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out[f"{mode}/p"], L, heads, "mean", out=out)
-    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **TOL_BS)
-    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **_tol(mode))
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **_tol(mode))
 
 
 @pytest.mark.parametrize("name", ["dgl_transformer_concat_k6", "dgl_transformer_add_k8"])
@@ -268,9 +276,9 @@ def test_dgl_transformer_base_net(name, mode):
     hidden, L, k, heads = (int(v) for v in fx.meta["params"])
     ei = fx.inp["edge_index"]
     p = _sign_inv_p(fx, "gin", 3, k, mode)
-    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **TOL_BS)
+    torch.testing.assert_close(p, fx.out[f"{mode}/p"], **_tol(mode))
     out = {}
     y = ON.transformer_net(fx.sd, ei[0], ei[1], fx.inp["sizes"], fx.inp["x"].squeeze(-1), fx.out[f"{mode}/p"], fx.inp["edge_attr"],
                            L, heads, str(fx.meta["pe_aggregate"]), "sum", training=(mode == "train"), out=out)
-    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **TOL_BS)
-    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **TOL_BS)
+    torch.testing.assert_close(out["h_last"], fx.out[f"{mode}/h_last"], **_tol(mode))
+    torch.testing.assert_close(y, fx.out[f"{mode}/y"], **_tol(mode))

@@ -438,3 +438,13 @@ def test_graphed_step_replays_the_eager_training_step_bit_for_bit():
         assert torch.equal(b1, b2)                                 # running statistics / counters advanced by the same steps
     with pytest.raises(ValueError, match="shape"):
         gs.step(synth.batch_to(synth.make_batch(12, seed=6), DEV))
+    # the model is left as it was found (round-3 advice): the capture's switches are scoped to the capture, so an eager train-mode
+    # step on a batch of ANOTHER shape (a ragged last batch) draws its own dropout masks and checks its embedding indices
+    gs.check()
+    assert not getattr(m2, "_defer_status", False) and getattr(m2, "_attn_masks", None) is None
+    small = synth.make_batch(7, seed=9)
+    o2.zero_grad()
+    (m2(synth.batch_to(small, DEV)) - target[:7]).abs().mean().backward()
+    small.x = small.x + 1000
+    with pytest.raises(IndexError):
+        m2(synth.batch_to(small, DEV))
