@@ -713,15 +713,15 @@ def main():
                     help="forward = the headline metric (default); evd = the eigendecomposition pre-transform, train = a full training step (secondary)")
     ap.add_argument("--streams", type=int, default=3, help="streams of the extra pipelined pass (1 = skip it)")
     ap.add_argument("--no-graph", action="store_true", help="--workload train: skip the captured-HIP-graph replay of the step")
-    ap.add_argument("--no-overlap", action="store_true", help="forward bench: `value` from the sequential pass (module overlap mode off)")
+    ap.add_argument("--no-overlap", action="store_true", help="forward bench: skip the extra pass in the module's overlap mode (`overlap_mode` block)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
     ap.add_argument("--no-scatter", action="store_true", help="skip the scatter_roofline block (standalone GIN / GINE aggregation on > 256 MiB)")
     ap.add_argument("--clock-ramp-ms", type=float, default=60.0,
                     help="forward bench: after the W warm-up steps keep issuing untimed forwards until this much wall time has passed since "
                          "the first one (the GPU reaches its sustained clock; 0 = off).  Reported as `clock_ramp` in the JSON line")
     ap.add_argument("--overlap-warmup", type=int, default=32,
-                    help="forward bench: untimed forwards in the module's overlap mode before its K timed steps (the caching allocator needs a "
-                         "pipeline depth of forwards before it stops asking the driver for memory); reported in `clock_ramp`")
+                    help="forward bench: untimed forwards in the module's overlap mode before the K timed steps of the `overlap_mode` extra pass "
+                         "(the caching allocator needs a pipeline depth of forwards before it stops asking the driver for memory)")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="inside the timed region, bracket every n-th launch of the dominant kernel with HIP events (1 = all; 0 = "
                          "automatic: max(4, steps // 12), i.e. about a dozen brackets over the timed steps and never more than one launch in four — a bracket is two marker packets that idle the stream "
@@ -767,9 +767,22 @@ def main():
             dist.destroy_process_group()
         return
 
-    # each rank owns its shard of the global batch: graphs [rank*B, (rank+1)*B)
-    host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2 + 1000 * rank, n_lo=WORKLOAD["n_lo"], n_hi=WORKLOAD["n_hi"],
-                            features=WORKLOAD["features"])
+    # ONE global batch of B x world graphs (BASELINE configs[3]: 1024 graphs over 8 GPUs), the same on every rank (same seed), cut into
+    # contiguous graph ranges by signnet_basisnet_amd.dist.shard_batch: by graph count when the slot count is fixed (every graph costs
+    # about the same), by (node, slot) rows in the all-eigenvector mode (max_k=None: a graph's work grows with n^2).  No data-path
+    # collective: a rank never sees another rank's graphs.
+    if world > 1:
+        glob = synth.make_batch(WORKLOAD["B"] * world, seed=1234 + 2, n_lo=WORKLOAD["n_lo"], n_hi=WORKLOAD["n_hi"], features=WORKLOAD["features"])
+        host = D.shard_batch(glob, rank, world, balance="count" if WORKLOAD["k"] else "rows", max_k=WORKLOAD["k"])
+    else:
+        host = synth.make_batch(WORKLOAD["B"], seed=1234 + 2, n_lo=WORKLOAD["n_lo"], n_hi=WORKLOAD["n_hi"], features=WORKLOAD["features"])
+    # which device every rank runs on (an N-rank line is then self-evidently N ranks on N devices)
+    dev_names = None
+    if dist is not None:
+        props = torch.cuda.get_device_properties(dev)
+        mine = f"rank {rank}: cuda:{local} {props.name} [{getattr(props, 'uuid', '')}]"
+        dev_names = [None] * world
+        dist.all_gather_object(dev_names, mine)
     data = synth.batch_to(host, dev)
     model = build_model(dev)
     # the throughput / serving mode of the module: no host wait per forward.  The device flags of EVERY forward are still posted
@@ -792,11 +805,20 @@ def main():
             if i == 0:                       # (the first forward packs the weights and loads the code objects: not GPU work)
                 torch.cuda.synchronize()
                 t_ramp = time.perf_counter()
-        # clock ramp (untimed, reported in the line as `clock_ramp`): an idle MI355X needs tens of milliseconds of continuous work to reach
-        # its sustained clock, and W = 5 forwards are 1.4 ms of it — measured on one box, same command: phi 137-141 us and 0.290 ms per
+        # (0) COLD pass (reported as `cold`, not `value`): exactly the K steps a `--warmup W --steps K` command line describes, right
+        #     behind the W warm-up forwards and nothing else — the number a reader gets who takes the two flags at their word.  An idle
+        #     MI355X needs tens of milliseconds of continuous work to reach its sustained clock and W = 5 forwards are 1.4 ms of it.
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            model(data)
+        model.check_last()
+        sync_all()
+        dt_cold = time.perf_counter() - t0
+        # clock ramp (untimed, reported in the line as `clock_ramp`): measured on one box, same command: phi 137-141 us and 0.290 ms per
         # sequential step behind --warmup 5, 120-126 us and 0.266 ms behind --warmup 200 (= a loop that has been running for 50 ms,
-        # which is what a training / evaluation epoch is).  So the W warm-up steps are followed by more untimed forwards until
-        # --clock-ramp-ms of wall time have passed since the end of the first one; the timed regions are unchanged (exactly K steps each).
+        # which is what a training / evaluation epoch is).  So more untimed forwards follow until --clock-ramp-ms of wall time have passed
+        # since the end of the first forward (the cold pass counts); the timed regions are exactly K steps each.
         if args.clock_ramp_ms > 0:
             torch.cuda.synchronize()
             while (time.perf_counter() - t_ramp) * 1e3 < args.clock_ramp_ms:
@@ -810,8 +832,9 @@ def main():
         if args.event_stride <= 0:
             args.event_stride = max(4, args.steps // 12)        # never every launch by default: a 20-step driver run is not taxed
         rec = ops.KernelTimer(only=["__none__"] if args.no_kernel_events else [DOMINANT], stride=args.event_stride)
-        # (1) SEQUENTIAL pass: every kernel of a forward on the caller's stream, one after the other.  The dominant kernel's HIP events
-        #     are taken here — alone on the chip its duration is attributable (the roofline block).
+        # (1) `value`: a plain `for: model(data)` loop at one call site, every kernel of a forward on the caller's stream, one after
+        #     the other — the definition of rounds 1-2 (round 3 reported the module's opt-in overlap mode here; it is the `overlap_mode`
+        #     block now).  The dominant kernel's HIP events are taken here: alone on the chip its duration is attributable.
         sync_all()
         t0 = time.perf_counter()
         with rec:
@@ -819,16 +842,15 @@ def main():
                 model(data)
             model.check_last()               # every forward's status flags read and clean before the clock stops
         sync_all()
-        dt_seq = time.perf_counter() - t0
-        # (2) `value`: the same loop, same call site, with the module's overlap mode (pyg.SignNetGNN.overlap_front): a forward is a
-        #     three-stage pipeline — batch plan + phi on side stream A, rho on side stream B, the GINE stage on the caller's stream,
-        #     chained by events — so the stages of consecutive steps share the GPU.  Outputs are bit-identical and ordered on the
-        #     caller's stream; the batch is resident (the mode's precondition).  No kernel events in this pass (concurrent kernels
-        #     stretch each other).
+        dt = time.perf_counter() - t0
+        # (2) extra pass (`overlap_mode`, not `value`): the same loop with the module's opt-in overlap mode (pyg.SignNetGNN.overlap_front):
+        #     a forward is a three-stage pipeline — batch plan + phi on side stream A, rho on side stream B, the GINE stage on the caller's
+        #     stream, chained by events — so the stages of consecutive steps share the GPU.  Outputs are bit-identical and ordered on the
+        #     caller's stream; the batch is resident (the mode's precondition).
         # (small batches — configs[0], 32 graphs — are bound by the host's ~0.1 ms of stream / event calls per overlapped forward: the
-        #  mode is used from 64 graphs per GPU on)
+        #  mode is measured from 64 graphs per GPU on)
         overlap = not args.no_overlap and WORKLOAD["B"] >= 64
-        dt = dt_seq
+        dt_ovl = None
         if overlap:
             model.overlap_front = True
             for _ in range(args.overlap_warmup):        # untimed: the mode's side streams, events and per-forward buffers reach their steady state
@@ -839,7 +861,7 @@ def main():
                 model(data)
             model.check_last()
             sync_all()
-            dt = time.perf_counter() - t0
+            dt_ovl = time.perf_counter() - t0
             model.overlap_front = False
         # extra pass (not `value`): the module's DEFAULT mode, strict = True (the flags are waited for after every forward)
         model.strict = True
@@ -874,14 +896,18 @@ def main():
             for _ in range(min(args.steps, 20)):
                 model(data)
         torch.cuda.synchronize()
+    dt_ranks = D.all_ranks(dt, dist, dev)          # every rank's own clock over the K timed steps (the line's time is their maximum)
+    graphs_ranks = [int(v) for v in D.all_ranks(float(host.num_graphs), dist, dev)]
     dt = D.max_over_ranks(dt, dist, dev)
-    dt_seq = D.max_over_ranks(dt_seq, dist, dev)
+    dt_cold = D.max_over_ranks(dt_cold, dist, dev)
+    if dt_ovl is not None:
+        dt_ovl = D.max_over_ranks(dt_ovl, dist, dev)
     dt_strict = D.max_over_ranks(dt_strict, dist, dev)
     if dt_pipe is not None:
         dt_pipe = D.max_over_ranks(dt_pipe, dist, dev)
 
     if rank == 0:
-        total_graphs = WORKLOAD["B"] * world * args.steps
+        total_graphs = sum(graphs_ranks) * args.steps
         dom_times = rec.summary()                    # {kernel: (launches, mean_ms)} — measured inside the timed region
         roof = None
         if DOMINANT in dom_times:
@@ -910,19 +936,27 @@ def main():
             "config": {"workload": WORKLOAD["name"], "graphs_per_gpu": WORKLOAD["B"], "global_batch": WORKLOAD["B"] * world,
                        "nodes": int(fl["N"]), "valid_rows": int(fl["M"]), "parallelism": f"graph-sharded dp{world}, no collective",
                        "gflop_per_step": fl["total"] / 1e9,
-                       "module_mode": "strict=False (no host wait per forward; every forward's device flags checked inside the timed region)"
-                                      + ("; overlap_front=True (a forward = plan + phi on side stream A -> rho on side stream B -> GINE on the caller's "
-                                         "stream, chained by events: consecutive forwards of the one call site overlap; bit-identical outputs)"
-                                         if overlap else "")},
-            "sequential": {"value": total_graphs / dt_seq, "unit": "graphs/s", "ms_per_step": 1e3 * dt_seq / args.steps,
-                           "note": "overlap_front=False: a forward's kernels one after the other on one stream (rounds 1-2's `value`); "
-                                   "the roofline block's HIP events are taken in this pass"},
+                       "module_mode": "strict=False (no host wait per forward; every forward's device flags checked inside the timed region); "
+                                      "overlap_front=False: a forward's kernels one after the other on the caller's stream"},
+            "value_definition": "K forwards of a plain `for: model(data)` loop at one call site, one stream, between barrier + synchronize "
+                                "(rounds 1-2's definition; round 3's `value` was the opt-in overlap mode, now the `overlap_mode` block)",
+            "warmup_effective": args.warmup + args.steps + ramp_steps,
+            "cold": {"value": total_graphs / dt_cold, "unit": "graphs/s", "ms_per_step": 1e3 * dt_cold / args.steps, "untimed_forwards_before": args.warmup,
+                     "note": "the same K-step loop timed right behind the W warm-up forwards and nothing else (no clock ramp): what `--warmup W "
+                             "--steps K` says literally; `value` is measured after this pass and the clock ramp (`warmup_effective` untimed forwards)"},
+            "sequential": {"value": total_graphs / dt, "unit": "graphs/s", "ms_per_step": 1e3 * dt / args.steps,
+                           "note": "identical to `value` since round 4 (kept so that the block rounds 1-3 printed stays comparable)"},
+            "overlap_mode": None if dt_ovl is None else {
+                "value": total_graphs / dt_ovl, "unit": "graphs/s", "ms_per_step": 1e3 * dt_ovl / args.steps, "untimed_forwards_before": args.overlap_warmup,
+                "note": "extra pass, not `value`: model.overlap_front = True (opt-in): a forward = plan + phi on side stream A -> rho on side "
+                        "stream B -> GINE on the caller's stream, chained by events; consecutive forwards of the one call site overlap; "
+                        "bit-identical outputs (round 3's `value`)"},
             "strict_mode": {"value": total_graphs / dt_strict, "unit": "graphs/s", "ms_per_step": 1e3 * dt_strict / args.steps,
                             "note": "the module's default: flags waited for after every forward (one host round trip per step); extra pass, not `value`"},
-            "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps, "overlap_warmup_steps": args.overlap_warmup if overlap else 0,
-                           "note": "untimed forwards issued after the W warm-up steps until `ms` of wall time had passed since the first one, so "
-                                   "that the timed K steps run at the sustained clock (an idle GPU needs tens of ms of work to reach it; "
-                                   "--clock-ramp-ms 0 switches this off)"},
+            "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps,
+                           "note": "untimed forwards issued after the cold pass until `ms` of wall time had passed since the first forward, so "
+                                   "that the timed K steps of `value` run at the sustained clock (an idle GPU needs tens of ms of work to reach "
+                                   "it; --clock-ramp-ms 0 switches this off: `value` then differs from `cold` only by the K steps of the cold pass)"},
             "roofline": roof,
             "kernels": {k: {"launches_per_step": v[0] / nall, "mean_us": 1e3 * v[1], **all_roofs.get(k, {})}
                         for k, v in ktimes.items()},
@@ -941,7 +975,12 @@ def main():
         rccl = rccl_allreduce_probe(dist, dev, sum(p.numel() for p in model.parameters()))
     if rank == 0:
         out["distributed"] = {"world_size": world, "backend": (f"{backend} (RCCL)" if backend == "nccl" else backend) if dist is not None else None,
-                              "data_path_collectives": 0, "gradient_allreduce": rccl}
+                              "ranks_seen_by_backend": dist.get_world_size() if dist is not None else 1,
+                              "devices": sorted(set(dev_names)) if dev_names else None,
+                              "per_rank_ms_per_step": [1e3 * t / args.steps for t in dt_ranks],
+                              "graphs_per_rank": graphs_ranks,
+                              "data_path_collectives": 0, "gradient_allreduce": rccl,
+                              "allreduce_us": None if rccl is None else rccl["allreduce_us"]}
         if args.config == 1 and not args.no_scatter:
             out["scatter_roofline"] = scatter_roofline(dev)
         print(json.dumps(out))

@@ -338,6 +338,16 @@ __device__ __forceinline__ void ring_prologue3(WRing<NT, NW, LAG_RING>& ring, co
   lds_barrier();
 }
 
+// the same without the wait: for a caller whose next workgroup-wide __syncthreads() (which drains the DMA) comes before the first GEMM
+template <int NT, int NW>
+__device__ __forceinline__ void ring_prologue3_issue(WRing<NT, NW, LAG_RING>& ring, const void* w) {
+  lds_barrier();
+  ring.pos = 0;
+  ring.issue(w, 0, 0);
+  ring.issue(w, 1, 1);
+  ring.issue(w, 2, 2);
+}
+
 template <int NT, int NTO, int BAR_KB, int NW, typename Pre, typename Epi>
 __device__ __forceinline__ void wg_gemm_split_lag(WRing<NT, NW, LAG_RING>& ring, const void* w, const void* wnext, bool live,
                                                   const Split8 (&xs)[(NT + 1) / 2], Pre pre, Epi epi) {

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   int* dslot = dgs + PHI_GB * PHI_R;                            // [GB] eigenvector slot of the bin
   unsigned char* drow0 = reinterpret_cast<unsigned char*>(dslot + PHI_GB);   // [GB][PHI_R] bin row of the graph's first node
   unsigned char* dnbr = drow0 + PHI_GB * PHI_R;                 // [GB][PHI_R][PHI_NBR] bin rows of the first in-neighbours
+  float* l0v = reinterpret_cast<float*>(lds_raw + Ring::BYTES + 2 * PHI_R * LD * sizeof(float) + PHI_DESC_BYTES);   // [4][D] layer-0 vectors
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sg = wave >> 2;                                     // 0: phi(+x), 1: phi(-x)   (wave-uniform)
   float* X = X2 + sg * PHI_R * LD;                              // the image of my sign
@@ -121,9 +122,27 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   ring.init(lds_raw, wave, lane);
   // first [d,d] Linear of a (bin, sign) pass — where the weight stream (re)starts
   const void* wfirst = !HID1 ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
-  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) {
-    if constexpr (LAG) ring_prologue3(ring, wfirst); else ring.prologue(wfirst, NT);
+  // The per-channel vectors of layer 0 (every bin starts with them: four L2 round trips per lane and bin, 3.6 k cycles of a 78 k-cycle
+  // bin) are copied into LDS once per workgroup: [w | b | scale | shift][D].  Requested BEFORE the weight stream starts (the memory
+  // counter is in order: a wait for them must not include the first three weight chunks), stored behind its issue.
+  f32x4 l0r = {0.f, 0.f, 0.f, 0.f};
+  static_assert(4 * (16 * NT / 4) <= PHI_WAVES * 64, "one float4 per thread covers the four vectors");
+  {
+    const float* src[4];
+    if (HID1) { src[0] = reinterpret_cast<const float*>(P.l0_w2); src[1] = P.l0_bias2; src[2] = P.l0_bn_scale; src[3] = P.l0_bn_shift; }
+    else { src[0] = P.l0_w1; src[1] = nullptr; src[2] = P.l0_bn0_scale; src[3] = P.l0_bn0_shift; }
+    const int i = threadIdx.x;
+    if (i < 4 * (D / 4)) {
+      const int v = i / (D / 4), c = 4 * (i - v * (D / 4));
+      if (src[v] != nullptr) l0r = ld4(src[v] + c);
+    }
   }
+  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) {
+    // (LAG: issue only — the first chunks land under the decode pass below, whose closing __syncthreads() waits for them and
+    //  publishes them)
+    if constexpr (LAG) ring_prologue3_issue(ring, wfirst); else ring.prologue(wfirst, NT);
+  }
+  if ((int)threadIdx.x < 4 * (D / 4)) lds_st4(l0v + 4 * threadIdx.x, l0r);
 
   SN_TL(1);
 #ifdef SN_TIMELINE
@@ -131,7 +150,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
 #endif
   for (int base = blockIdx.x; base < nbins; base += gridDim.x * PHI_GB) {
     // ------------------------------------------------------------------ decode pass: wave w -> bin base + w * gridDim.x, lane -> row
-    __syncthreads();   // the previous group is done with the descriptors
+    if (base != (int)blockIdx.x) __syncthreads();   // the previous group is done with the descriptors
     {
       const int dbin = base + wave * (int)gridDim.x;
       if (dbin < nbins) {
@@ -229,14 +248,11 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         if (LIVE) {
           const float w1 = P.l0_w1[0], s0 = P.l0_bn0_scale[0], h0 = P.l0_bn0_shift[0];
           const float t = fmaxf((as * w1) * s0 + h0, 0.f);
-          const float* w2v = reinterpret_cast<const float*>(P.l0_w2);
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
             const int c = 16 * kk + 4 * g;
-            const f32x4 w2 = ld4(w2v + c), s1 = ld4(P.l0_bn_scale + c), h1 = ld4(P.l0_bn_shift + c);
-            f32x4 b2 = {0.f, 0.f, 0.f, 0.f};
-            if (P.l0_bias2) b2 = ld4(P.l0_bias2 + c);
-            in[kk] = relu4((t * w2 + b2) * s1 + h1);
+            const f32x4 w2 = lds_ld4(l0v + c), b2 = lds_ld4(l0v + D + c), s1 = lds_ld4(l0v + 2 * D + c), h1 = lds_ld4(l0v + 3 * D + c);
+            in[kk] = relu4((t * w2 + b2) * s1 + h1);     // (b2: zeros when the Linear has no bias — x + 0 is exact)
           }
         }
       } else {
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
 #pragma unroll
           for (int kk = 0; kk < NT; ++kk) {
             const int c = 16 * kk + 4 * g;
-            const f32x4 w1 = ld4(P.l0_w1 + c), s0 = ld4(P.l0_bn0_scale + c), h0 = ld4(P.l0_bn0_shift + c);
+            const f32x4 w1 = lds_ld4(l0v + c), s0 = lds_ld4(l0v + 2 * D + c), h0 = lds_ld4(l0v + 3 * D + c);
             o[kk] = relu4((as * w1) * s0 + h0);
           }
           split_rows<NT>(o, sp);
@@ -439,7 +455,7 @@ template <int NT, bool HID1, bool DGL = false>
 static int launch_phi(const PhiStruct& S, const sn_phi_params& P, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   const size_t lds = (size_t)WRing<NT, PHI_WAVES, phi_lagged(NT) ? LAG_RING : SPLIT_RING>::BYTES + (size_t)(2 * PHI_R * LD) * sizeof(float) +
-                     (size_t)PHI_DESC_BYTES;
+                     (size_t)PHI_DESC_BYTES + (size_t)(4 * 16 * NT) * sizeof(float);
   static int cus = 0;  // idempotent one-time setup (same values whichever thread wins)
   if (cus == 0) {
     if (lds > 64 * 1024 &&

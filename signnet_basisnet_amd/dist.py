@@ -93,6 +93,16 @@ def max_over_ranks(value: float, dist, device) -> float:
     return float(t.item())
 
 
+def all_ranks(value: float, dist, device):
+    """Every rank's value, in rank order (a one-element list without a process group)."""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist is None:
+        return [float(value)]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def gather_outputs(y: torch.Tensor, dist):
     """All ranks' [B_r, n_out] outputs concatenated in rank order (graph order)."""
     if dist is None:

@@ -31,10 +31,17 @@ def test_forward_bench_two_ranks():
     assert d["value"] > 0 and abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
     assert d["distributed"]["world_size"] == 2 and d["distributed"]["data_path_collectives"] == 0
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
-    # `value` is the loop with the module's overlap mode; the sequential pass (rounds 1-2's definition) rides along and carries the
-    # roofline's HIP events
-    assert "overlap_front=True" in d["config"]["module_mode"] and d["sequential"]["value"] > 0
+    # (round 4: `value` is the plain one-stream loop again — where the roofline's HIP events are taken; the module's opt-in overlap
+    #  mode and the literal `--warmup W --steps K` reading are labelled extra blocks; `warmup` is the driver's W, `warmup_effective`
+    #  the untimed forwards actually issued in front of the timed region)
+    assert "overlap_front=False" in d["config"]["module_mode"] and d["sequential"]["value"] == d["value"]
+    assert d["overlap_mode"]["value"] > 0 and d["cold"]["value"] > 0 and d["cold"]["untimed_forwards_before"] == 2
+    assert d["warmup_effective"] >= d["warmup"] + d["steps"]
     assert d["roofline"]["timed_pass"] == "sequential"
+    # an N-rank line is self-evidently N ranks: what the backend reports, every rank's own clock and shard, the all-reduce probe
+    g = d["distributed"]
+    assert g["ranks_seen_by_backend"] == 2 and len(g["per_rank_ms_per_step"]) == 2 and g["graphs_per_rank"] == [128, 128]
+    assert max(g["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-9) and len(g["devices"]) == 2 and g["allreduce_us"] > 0
 
 
 def test_train_bench_two_ranks_allreduces_the_flat_gradient():

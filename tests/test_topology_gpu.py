@@ -294,3 +294,42 @@ def test_overlap_mode_on_odd_batches_is_bit_identical():
         torch.cuda.synchronize()
     for i, y in outs:
         assert torch.equal(y, ref[i]), i
+
+
+def test_whole_network_gradients_on_the_topology_batch():
+    """d loss / d theta of ONE training step on the eight-topology batch (hub with 39 in-edges, K12, directed cycle, multigraph with
+    self loops, isolated nodes, the 64-node / 192-edge limits, in-edges only), fixed seed, every parameter tensor, against
+    torch.autograd over the fp32 AND the float64 oracle — the population rule of tests/test_training_gpu.py (a wrong adjoint is O(1);
+    two fp32 evaluations of a network with batch-statistics BatchNorms differ by their ReLU / BatchNorm decisions).  Until round 4 the
+    gradients on these topologies were only checked op by op (the aggregation adjoints above)."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from test_training_gpu import _assert_gradient_population
+    variant, feats, ctor, max_k = CASES[0]
+    topos = _topologies(np.random.default_rng(11))
+    host = _batch(topos, feats, seed=3)
+    model = _model(variant, ctor, max_k, seed=4)
+    cfg = O.make_cfg(variant, *ctor)
+    cot = torch.randn(host.num_graphs, ctor[3], generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+
+    def oracle(dt):
+        sd = {}
+        for k, v in model.state_dict().items():
+            if v.is_floating_point():
+                t = v.detach().clone().to(dt)
+                sd[k] = t.requires_grad_(True) if "running" not in k else t
+            else:
+                sd[k] = v.detach().clone()
+        dd = PU.data_f64(host) if dt == torch.float64 else host
+        y = O.signnet_gnn(sd, cfg, dd, training=True, max_k=max_k)
+        (y * cot.to(dt)).sum().backward()
+        return y.detach(), sd
+
+    y64, sd64 = oracle(torch.float64)
+    y32, sd32 = oracle(torch.float32)
+    m = model.to(DEV).train()
+    y = m(synth.batch_to(host, DEV))
+    assert y.requires_grad
+    (y * cot.float().to(DEV)).sum().backward()
+    PU.close(y, y32, "train-mode forward on the topology batch", ref64=y64)
+    _assert_gradient_population(m.named_parameters(), sd32, sd64, "topology batch", 30)
