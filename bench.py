@@ -551,6 +551,51 @@ def dgl_bench(args, dev):
                         "mean_launch_us": 1e3 * gms, "nodes": Nn, "edges": E,
                         "note": "algorithmic bytes 4*d*(3E + 4N): Ce in, e out, Bh and Dh gathered per edge; Ah, Eh in, h out (+den)"},
            "kernels": {kk: {"launches_per_step": v[0] / 3, "mean_us": 1e3 * v[1]} for kk, v in kt.items()}}
+    # The other four shipped base networks run their eval forward layer by layer (50-130 launches: host-bound); for a fixed batch shape
+    # the whole step is one HIP-graph launch (serving.GraphedDGLForward).  Extra blocks, not `value`: ms per 128-graph forward, eager
+    # (a fresh graph object per step) and replayed.
+    from signnet_basisnet_amd import dgl_configs
+    from signnet_basisnet_amd.serving import GraphedDGLForward
+    out["nets"] = {}
+    sn = torch.cat([torch.full((n, 1), 1.0 / n) for n in host.sizes]).sqrt().to(dev)
+    bne = torch.bincount(torch.bucketize(ei[1], torch.cumsum(torch.tensor(host.sizes), 0), right=True), minlength=len(host.sizes))
+    for name in ("gin", "gat", "pna", "transformer", "gatedgcn"):
+        cls, prm = dgl_configs.net_params(name, dev)
+        torch.manual_seed(0)
+        nt = getattr(dgl_nets, cls)(prm).to(dev).eval()
+        kk_ = prm["pos_enc_dim"]
+        pe_n = synth.dgl_pos_enc(host, kk_).unsqueeze(-1).to(dev)
+        snn = sn if name == "pna" else None
+
+        def step_n():
+            gg = DS.Graph(src_d, dst_d, bnn, bne)
+            pp = nt.sign_inv_net(gg, pe_n).squeeze(-1)
+            return nt(gg, hx, pp, ex, snn)[0]
+        with torch.no_grad():
+            for _ in range(max(3, args.warmup)):
+                step_n()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_n()
+            torch.cuda.synchronize()
+            t_eager = (time.perf_counter() - t0) / args.steps
+            rec_n = ops.KernelTimer()
+            with rec_n:
+                step_n()
+            launches = sum(v[0] for v in rec_n.summary().values())
+            gf = GraphedDGLForward(nt, DS.Graph(src_d, dst_d, bnn, bne), hx, pe_n, ex, snn)
+            for _ in range(3):
+                gf()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                gf()
+            torch.cuda.synchronize()
+            t_graph = (time.perf_counter() - t0) / args.steps
+        out["nets"][name] = {"config": f"{cls} hidden {prm['hidden_dim']}, L = {prm['L']}, k = {kk_}, sign_inv_net gin (8 layers)",
+                             "eager_ms": 1e3 * t_eager, "graphed_ms": 1e3 * t_graph, "c_abi_launches": int(launches),
+                             "graphs_per_s_graphed": 128 / t_graph}
     if not args.no_cpu_baseline:
         ssd = {kk[len("sign_inv_net."):]: v for kk, v in sd_cpu.items() if kk.startswith("sign_inv_net.")}
         ts = []

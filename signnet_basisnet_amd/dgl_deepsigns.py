@@ -377,9 +377,11 @@ class _DeepSignsBase(nn.Module):
         src, dst = g.edges()
         bnn = g.batch_num_nodes().to(src.device)
         B = int(bnn.numel())
-        batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn)      # index plumbing only
-        if batch.numel() != N:
+        # (the node total comes from the graph object's cached host counts: repeat_interleave without output_size would read the sum
+        #  back from the device — a host wait per batch, and not recordable in a HIP graph)
+        if _node_counts(g)[1] != N:
             raise ValueError("batch_num_nodes does not sum to the number of feature rows")
+        batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn, output_size=N)      # index plumbing only
         if fused:     # kmax = -k: work bins over all k slots of every graph (zero-padded columns are evaluated like any other)
             return ops.build_plan(batch.long(), torch.stack([src.long(), dst.long()]), B, -self.k, bins=True)
         return ops.build_plan(batch.long(), torch.stack([src.long(), dst.long()]), B, self.k)

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import ops
 from ._lib import check, lib, ptr, stream
-from .dgl_deepsigns import MLP, cached_plan, _await_side, _max_nodes, _max_in_edges, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
+from .dgl_deepsigns import MLP, cached_plan, _await_side, _max_nodes, _max_in_edges, _node_counts, _BNSite, _GINConv, _pack, _prep_mlp, _run_mlp, get_sign_inv_net
 
 
 class MLPReadout(nn.Module):
@@ -124,9 +124,11 @@ class GINNet(_PackCache, nn.Module):
         src, dst = g.edges()
         bnn = g.batch_num_nodes().to(src.device)
         B = int(bnn.numel())
-        batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn)      # index plumbing only
-        if batch.numel() != N:
+        # (the node total comes from the graph object's cached host counts: repeat_interleave without output_size would read the sum
+        #  back from the device — a host wait per batch, and not recordable in a HIP graph)
+        if _node_counts(g)[1] != N:
             raise ValueError("batch_num_nodes does not sum to the number of feature rows")
+        batch = torch.repeat_interleave(torch.arange(B, device=src.device), bnn, output_size=N)      # index plumbing only
         return batch.long(), torch.stack([src.long(), dst.long()]), B
 
     def _gin_padded(self):
@@ -1067,10 +1069,15 @@ class GATNet(_PackCache, nn.Module):
             fcs = self.MLP_layer.FC_layers
             for i, fc in enumerate(fcs):
                 hg = ops.masked_linear(hg, self._pk(fc), relu=i < len(fcs) - 1)
-        plan.check()                     # malformed batch
-        if bool(zero_deg):
-            raise ValueError("There are 0-in-degree nodes in the graph: GATConv's edge softmax is undefined for them (DGL raises "
-                             "DGLError here unless allow_zero_in_degree is set, which gat_net.py:62-66 leaves at False)")
+        zero_msg = ("There are 0-in-degree nodes in the graph: GATConv's edge softmax is undefined for them (DGL raises "
+                    "DGLError here unless allow_zero_in_degree is set, which gat_net.py:62-66 leaves at False)")
+        if ops.deferring():              # a recorded step (serving.GraphedDGLForward) must not wait for the host: its check() reads these
+            ops.defer("plan", plan)
+            ops.defer("flag", zero_deg, zero_msg)
+        else:
+            plan.check()                 # malformed batch
+            if bool(zero_deg):
+                raise ValueError(zero_msg)
         self.g = g
         self._h_last = x
         return hg, g

@@ -568,6 +568,48 @@ EMBEDDING_INDEX_ERROR = ("index out of range in embedding: a discrete node / edg
                          "(DiscreteEncoder's max_num_values) — nn.Embedding raises IndexError here too")
 
 
+_DEFERRED_STATUS = None      # a list while a caller collects the ops' own status words instead of having each op read its own
+
+
+class defer_status:
+    """`with ops.defer_status() as words:` — ops that would read their own status word back (one host wait each: embedding_sum with
+    status=None) append it to `words` instead; the caller checks them later (`ops.raise_deferred(words)`).  For steps that must not
+    synchronise: a HIP-graph capture (serving.GraphedDGLForward), a loop that checks once per epoch."""
+
+    def __enter__(self):
+        global _DEFERRED_STATUS
+        self._prev, _DEFERRED_STATUS = _DEFERRED_STATUS, []
+        self.words = _DEFERRED_STATUS
+        return self.words
+
+    def __exit__(self, *exc):
+        global _DEFERRED_STATUS
+        _DEFERRED_STATUS = self._prev
+        return False
+
+
+def deferring() -> bool:
+    return _DEFERRED_STATUS is not None
+
+
+def defer(kind, tensor, message=None):
+    """Hand a device-side check over to the collector of `defer_status`: kind 'embed' (non-zero: an index outside its embedding table),
+    'plan' (a GraphPlan: its check()), 'flag' (non-zero: ValueError(message))."""
+    _DEFERRED_STATUS.append((kind, tensor, message))
+
+
+def raise_deferred(words):
+    """The collected checks, read back now (a host wait): raises what the ops themselves would have raised."""
+    for kind, t, msg in words:
+        if kind == "plan":
+            t.check()
+        elif kind == "embed":
+            if int(t.reshape(-1)[0]):
+                raise IndexError(EMBEDDING_INDEX_ERROR)
+        elif bool(t.reshape(-1)[0]):
+            raise ValueError(msg)
+
+
 def embedding_sum(idx, tables, status=None):
     """sum_f tables[f][idx[:, f]] — DiscreteEncoder; idx int64 [R] or [R, F].  An index outside its table is never
     dereferenced (it contributes 0) and sets bit 0 of `status` (device int32, e.g. a slot of the batch plan's status block
@@ -594,7 +636,9 @@ def embedding_sum(idx, tables, status=None):
         status = torch.zeros(1, dtype=torch.int32, device=idx.device)
     with _span("sn_embedding_sum_f32"):
         check(lib().sn_embedding_sum_f32(ptr(idx), nf, nf, R, arr, rows, Cc, ptr(out), ptr(status), stream()), "sn_embedding_sum_f32")
-    if own and int(status.item()):
+    if own and _DEFERRED_STATUS is not None:
+        defer("embed", status)
+    elif own and int(status.item()):
         raise IndexError(EMBEDDING_INDEX_ERROR)
     return out
 

@@ -10,6 +10,81 @@ from __future__ import annotations
 import torch
 
 
+class GraphedDGLForward:
+    """sign_inv_net + base network of the DGL tree (GraphPrediction/train/train_ZINC_graph_regression.py:20-25,77-80) in eval mode as
+    ONE HIP-graph launch, for batches of a FIXED SHAPE (node, edge and graph counts: a padded or bucketed loader, a serving loop).
+
+    Every net of `dgl_nets` but GatedGCN runs its eval forward layer by layer — 50-130 launches of ~12 us of host time each for a few
+    us of device work: GIN 0.8, GAT 0.6, PNA 1.0-1.3, Transformer 1.6 ms per 128 graphs, all host-bound.  The launches depend on the
+    batch's SHAPE only (graph sizes, CSR offsets, validity are read from device memory by the kernels; the batch plan — sn_batch_plan —
+    is part of the recorded launches), so for a fixed shape they are recorded once (`torch.cuda.graph` over the same ctypes launches)
+    and replayed: HIP graphs instead of a tracing compiler.  `__call__` copies a new batch of the same shape into the static input
+    buffers, replays, and returns the (static) output tensor — consume or clone it before the next call.
+
+    Host-side decisions are frozen at capture time: the largest graph (<= 64 nodes for the stage kernels) and, for GatedGCN, the
+    largest in-edge count are those of the example batch; a later batch beyond the kernels' limits is flagged on the device (NaN rows,
+    `net.check_last()` raises) instead of being re-routed to the layer path."""
+
+    def __init__(self, net, g, h, pos_enc, e=None, snorm_n=None, warmup=2):
+        from .dgl_deepsigns import Graph
+        from .train_graph import GraphedForward
+        if net.training:
+            raise ValueError("GraphedDGLForward records the eval forward: call net.eval() first")
+        dev = h.device
+        src, dst = g.edges()
+        bnn = torch.as_tensor(g.batch_num_nodes())
+        bne = g.batch_num_edges() if callable(getattr(g, "batch_num_edges", None)) else None
+        self.net = net
+        self.src, self.dst = src.to(dev).clone(), dst.to(dev).clone()
+        self.bnn = bnn.to(dev).clone()                     # on the device: the recorded repeat_interleave reads it at every replay
+        self.g = Graph(self.src, self.dst, self.bnn, bne)
+        # the two host-side facts the modules read from a graph object, taken from the example batch once (no device read later)
+        self.g._sn_node_counts = (int(bnn.max()) if bnn.numel() else 0, int(bnn.sum()))
+        self.h, self.pe = h.clone(), pos_enc.clone()
+        self.e = None if e is None else e.clone()
+        self.snorm = None if snorm_n is None else snorm_n.clone()
+        self.shapes = {"src": tuple(self.src.shape), "h": tuple(self.h.shape), "pos_enc": tuple(self.pe.shape), "graphs": int(self.bnn.numel()),
+                       "e": None if e is None else tuple(e.shape)}
+
+        def fwd():
+            self.g._sn_plans = {}                          # the batch plan is rebuilt inside the recorded step
+            p = net.sign_inv_net(self.g, self.pe).squeeze(-1)
+            return net(self.g, self.h, p, self.e, self.snorm)[0]
+
+        from . import ops
+        # (ops that would read their own status word back — the embeddings' index check — hand it over instead: check() reads them)
+        with ops.defer_status() as words:
+            self._graphed = GraphedForward(fwd, warmup=warmup)
+        self._status_words = list(words)[-max(1, len(words) // (warmup + 1)):] if words else []      # those of the recorded run
+        self.out = self._graphed.out
+
+    def check(self):
+        """One host wait: raises what the LAST replay flagged on the device (an atom / bond type outside its embedding table:
+        IndexError as nn.Embedding; a batch the stage kernels could not hold: the net's own check_last())."""
+        from . import ops
+        ops.raise_deferred(self._status_words)
+        if hasattr(self.net, "check_last"):
+            self.net.check_last()
+
+    def __call__(self, g=None, h=None, pos_enc=None, e=None, snorm_n=None):
+        def put(dst, src, what):
+            if src is None:
+                return
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"GraphedDGLForward: {what} has shape {tuple(src.shape)}, the recorded batch {tuple(dst.shape)}")
+            dst.copy_(src, non_blocking=True)
+        if g is not None:
+            s, d = g.edges()
+            put(self.src, s, "src"); put(self.dst, d, "dst")
+            put(self.bnn, torch.as_tensor(g.batch_num_nodes()), "batch_num_nodes")
+        put(self.h, h, "h"); put(self.pe, pos_enc, "pos_enc")
+        if self.e is not None:
+            put(self.e, e, "e")
+        if self.snorm is not None:
+            put(self.snorm, snorm_n, "snorm_n")
+        return self._graphed.replay()
+
+
 class StreamPipeline:
     def __init__(self, model, streams: int = 3, device=None):
         if streams < 1:

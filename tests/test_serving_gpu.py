@@ -1,0 +1,92 @@
+"""-m gpu: serving.GraphedDGLForward — the DGL tree's eval forward (sign_inv_net + base network) recorded once as a HIP graph for a
+fixed batch SHAPE and replayed: bit-identical to the eager forward, also for another batch of the same shape taken through the
+static input buffers; a batch of another shape is refused."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _inputs(data, k):
+    from signnet_basisnet_amd import dgl_deepsigns as DS
+    from signnet_basisnet_amd import synth
+    pe = synth.dgl_pos_enc(data, k).unsqueeze(-1).to(DEV)
+    src, dst = data.edge_index
+    sizes = torch.tensor(data.sizes)
+    bne = torch.bincount(torch.bucketize(dst, torch.cumsum(sizes, 0), right=True), minlength=len(data.sizes))
+    g = DS.Graph(src.to(DEV), dst.to(DEV), sizes, bne)
+    sn = torch.cat([torch.full((n, 1), 1.0 / n) for n in data.sizes]).sqrt().to(DEV)
+    return g, data.x.squeeze(-1).to(DEV), pe, data.edge_attr.to(DEV), sn
+
+
+def _permuted(data, perm):
+    """The same graphs in another order: same node / edge / graph counts, different batch."""
+    import types
+    sizes = list(data.sizes)
+    starts = [0]
+    for n in sizes:
+        starts.append(starts[-1] + n)
+    vst = [0]
+    for n in sizes:
+        vst.append(vst[-1] + n * n)
+    xs, evs, evl, eis, eas, new_sizes = [], [], [], [], [], []
+    off = 0
+    src, dst = data.edge_index
+    for b in perm:
+        lo, hi = starts[b], starts[b + 1]
+        m = (src >= lo) & (src < hi)
+        eis.append(data.edge_index[:, m] - lo + off)
+        eas.append(data.edge_attr[m])
+        xs.append(data.x[lo:hi]); evl.append(data.eigen_values[lo:hi]); evs.append(data.eigen_vectors[vst[b]:vst[b + 1]])
+        new_sizes.append(sizes[b])
+        off += sizes[b]
+    d = types.SimpleNamespace(x=torch.cat(xs), edge_index=torch.cat(eis, 1), edge_attr=torch.cat(eas),
+                              batch=torch.repeat_interleave(torch.arange(len(perm)), torch.tensor(new_sizes)),
+                              eigen_values=torch.cat(evl), eigen_vectors=torch.cat(evs), num_graphs=len(perm), num_nodes=off)
+    d.sizes = new_sizes
+    return d
+
+
+@pytest.mark.parametrize("name", ["gin", "gat", "pna", "transformer", "gatedgcn"])
+def test_graphed_dgl_forward_replays_the_eager_forward(name):
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, synth
+    from signnet_basisnet_amd.serving import GraphedDGLForward
+    import parity_util as PU
+    cls, params = dgl_configs.net_params(name, DEV)
+    params.update(L=3)                                       # the shipped widths / heads / towers, three layers
+    torch.manual_seed(2)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, 3)
+    net = net.to(DEV).eval()
+    k = params["pos_enc_dim"]
+    a = synth.make_batch(24, seed=11)
+    b = _permuted(a, list(reversed(range(24))))
+    ga, ha, pa, ea, sa = _inputs(a, k)
+    gb, hb, pb, eb, sb = _inputs(b, k)
+    snorm = name == "pna"
+
+    def eager(g, h, p, e, s):
+        with torch.no_grad():
+            q = net.sign_inv_net(g, p).squeeze(-1)
+            return net(g, h, q, e, s if snorm else None)[0].clone()
+
+    ya, yb = eager(ga, ha, pa, ea, sa), eager(gb, hb, pb, eb, sb)
+    assert not torch.equal(ya, yb[: ya.shape[0]])            # a different batch indeed
+    gf = GraphedDGLForward(net, ga, ha, pa, ea, sa if snorm else None)
+    assert torch.equal(gf().clone(), ya)
+    assert torch.equal(gf(gb, hb, pb, eb, sb if snorm else None).clone(), yb)
+    assert torch.equal(gf(ga, ha, pa, ea, sa if snorm else None).clone(), ya)
+    gf.check()
+    if name != "gatedgcn":                                   # (its one-launch kernel reports through check_last(); covered elsewhere)
+        bad = hb.clone()
+        bad[3] = 1000                                        # an atom type outside the table: flagged on the device, raised by check()
+        gf(gb, bad, pb, eb, sb if snorm else None)
+        with pytest.raises(IndexError):
+            gf.check()
+        gf(gb, hb, pb, eb, sb if snorm else None)
+        gf.check()
+    c = synth.make_batch(24, seed=12)
+    gc, hc, pc, ec, sc = _inputs(c, k)
+    with pytest.raises(ValueError, match="shape"):
+        gf(gc, hc, pc, ec, sc if snorm else None)
