@@ -1,6 +1,6 @@
 """Per-workgroup wall-clock stamps of a -DSN_TIMELINE build of fused_phi.hip (s_memrealtime, 10 ns ticks)."""
 import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, numpy as np
 import bench
 from signnet_basisnet_amd import synth, _lib
