@@ -84,8 +84,11 @@ def eq_deepsets(sd, x, num_layers, use_bn, pfx=""):
     return x1 + x2
 
 
-def sign_plus_deepsets(sd, v, num_layers, use_bn, pfx="model."):
-    """SignPlus.forward — signbasisnet.py:16-18 with an EqDeepSetsEncoder inside."""
+def sign_plus_deepsets(sd, v, num_layers, use_bn, pfx="model.", x=None):
+    """SignPlus.forward — signbasisnet.py:16-20 with an EqDeepSetsEncoder inside (x: side features, concatenated un-negated)."""
+    if x is not None:
+        return (eq_deepsets(sd, torch.cat((v, x), dim=-1), num_layers, use_bn, pfx) +
+                eq_deepsets(sd, torch.cat((-v, x), dim=-1), num_layers, use_bn, pfx))
     return eq_deepsets(sd, v, num_layers, use_bn, pfx) + eq_deepsets(sd, -v, num_layers, use_bn, pfx)
 
 

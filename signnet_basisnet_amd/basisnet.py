@@ -394,19 +394,20 @@ class EqDeepSetsEncoder(nn.Module):
 
 
 class SignPlus(nn.Module):
-    """model(v) + model(-v)   (signbasisnet.py:11-20; the `x=` side-feature form is not used by the reference's
-    entry script — it raises NotImplementedError there, training.py:111)."""
+    """model(v) + model(-v); with side features x (negate v, do not negate x): model(cat(v, x)) + model(cat(-v, x))
+    (signbasisnet.py:11-20).  The concatenation is index plumbing (torch.cat); the negation and the sum are device ops."""
 
     def __init__(self, model):
         super().__init__()
         self.model = model
 
     def forward(self, v, *args, x=None):
-        if x is not None:
-            raise NotImplementedError("SignPlus with side features is not reachable in the reference (training.py:111)")
         v = v.contiguous().float()
         neg = ops.masked_affine(v.view(-1, v.shape[-1]), scale=torch.full((v.shape[-1],), -1.0, device=v.device),
                                 shift=torch.zeros(v.shape[-1], device=v.device)).view(v.shape)
+        if x is not None:
+            x = x.float()
+            v, neg = torch.cat((v, x), dim=-1), torch.cat((neg, x), dim=-1)
         a, b = self.model(v), self.model(neg)
         if a.requires_grad or b.requires_grad:
             from . import autograd as AG

@@ -10,7 +10,7 @@
 //             deterministic reduction of the per-workgroup dW partials.
 // Rows come in G groups (the phi(+x) / phi(-x) passes share every weight but keep separate batch statistics: two calls of GNN3d,
 // sign_net.py:113).  fp32-input MFMA throughout (exact products, fp32 accumulate); no atomics: gradients are bitwise reproducible.
-#include "common.hpp"
+#include "fused_common.hpp"
 
 namespace sn {
 
@@ -104,6 +104,35 @@ __device__ __forceinline__ void stage_weight(float4* wl, const float* __restrict
   }
 }
 
+// The same image for the split-bf16 matrix path of fused_common.hpp (fp32 products from six bf16 partial products, exact three-way
+// operand split): per (output tile, K block of 32) three 1 KB fragments [plane h, m, l][lane][8 bf16], lane (o = 16 ot + (lane&15),
+// g = lane>>4) holding the k-slots 32 kb + 16 (s>>2) + 4 g + (s&3).  Built from the RAW row-major parameter (16-byte aligned rows).
+template <int NTO, int NKB>
+__device__ __forceinline__ void stage_weight_split(u32x4* wl, const float* __restrict__ W, int ldw) {
+  constexpr int total = NTO * NKB * 64;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * 64 * TW) {
+    float4 lo[4], hi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 * TW;
+      const int ln = i & 63, blk = i >> 6, kb = blk % NKB, ot = blk / NKB;
+      const float* wr = W + (int64_t)(16 * ot + (ln & 15)) * ldw + 32 * kb + 4 * (ln >> 4);
+      lo[u] = make_float4(0.f, 0.f, 0.f, 0.f); hi[u] = lo[u];
+      if (i < total) { lo[u] = *reinterpret_cast<const float4*>(wr); hi[u] = *reinterpret_cast<const float4*>(wr + 16); }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 64 * TW;
+      if (i < total) {
+        const Split8 sp = split8(f32x4{lo[u].x, lo[u].y, lo[u].z, lo[u].w}, f32x4{hi[u].x, hi[u].y, hi[u].z, hi[u].w});
+        const int ln = i & 63, blk = i >> 6;
+        u32x4* dst = wl + (blk * 3) * 64 + ln;
+        dst[0] = sp.h; dst[64] = sp.m; dst[128] = sp.l;
+      }
+    }
+  }
+}
+
 // ============================================================================ forward link
 struct TLin {
   const float* x; int ldx; int64_t R; int G; int d_in, d_out;
@@ -118,11 +147,18 @@ struct TLin {
 // FULL: d_in = 16 NTI and d_out = 16 NTO exactly (the 128-wide links) — the tile counts are compile-time constants, the per-tile guards
 // fold away and the MFMA loops are straight-line code the compiler can pipeline the LDS reads of (with the guards every 16-column
 // step was its own basic block: read, wait the LDS latency, 8 MFMAs — twice the MFMA time on a one-tile launch).
-template <int NTI, int NTO, bool STATS, bool FULL>
+// SPLIT (round 4; FULL links with 16-byte aligned parameter rows): the products run on the bf16 matrix pipe from the exact three-way
+// split of both operands (fused_common.hpp: 6 x v_mfma_f32_16x16x32_bf16 of 16 cycles per 32-deep K block and output tile against
+// 8 x v_mfma_f32_16x16x4_f32 of 32) — the weight image holds the three bf16 planes (96 KB instead of 64), the operand tile is split in
+// registers after the producer's BatchNorm + ReLU has been applied to it (176 VALU operations per tile for 5 k cycles of matrix pipe saved).
+template <int NTI, int NTO, bool STATS, bool FULL, bool SPLIT = false>
 __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
+  static_assert(!SPLIT || (FULL && NTI % 2 == 0), "the split path serves the full-width links");
   extern __shared__ __align__(16) unsigned char t_lds[];
   float4* wl = reinterpret_cast<float4*>(t_lds);
-  float* icol = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;     // [2][16*NTI] in_scale | in_shift of my group
+  constexpr int NKB = NTI / 2;
+  constexpr size_t WIMG = SPLIT ? (size_t)NTO * NKB * 3 * 1024 : (size_t)NTI * NTO * 1024;     // bytes of the weight image
+  float* icol = reinterpret_cast<float*>(t_lds + WIMG);     // [2][16*NTI] in_scale | in_shift of my group
   float* piv = icol + 2 * 16 * NTI;                                             // [TW][16*NTO] per-wave pivots of the moment sums
   constexpr int CI = 16 * NTI;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
@@ -139,11 +175,13 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   // pivot keeps the final M2 = S2 - S1^2/n free of cancellation.  Reduced over the rows once, at the end.
   float rn = 0.f;
   bool have_piv = false;
-  f32x4 s1[STATS ? NTO : 1], s2[STATS ? NTO : 1];
-  if (STATS) {
+  // (SPLIT: the sums are reduced over a tile's 16 rows at once (DPP) and kept by ONE lane of the row group per output tile — lane
+  //  (lane & 15) == ot — i.e. in 8 registers instead of 64: with the operand's three bf16 planes and a prefetched tile the per-lane
+  //  form does not fit 256 registers)
+  constexpr int NS = (STATS && !SPLIT) ? NTO : 1;
+  f32x4 s1[NS], s2[NS];
 #pragma unroll
-    for (int ot = 0; ot < NTO; ++ot) { s1[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  }
+  for (int ot = 0; ot < NS; ++ot) { s1[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float* mypiv = piv + wave * 16 * NTO;
   auto fetch = [&](int64_t tile, bool v, f32x4 (&buf)[NTI]) {
     const float* xr = xg + (tile * 16 + (lane & 15)) * a.ldx;
@@ -164,7 +202,8 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   static_assert(CI <= 64 * TW, "one column constant per thread");
   float c_sc = 1.f, c_sh = 0.f;
   if (isc && (int)threadIdx.x < a.d_in) { c_sc = isc[threadIdx.x]; c_sh = ish[threadIdx.x]; }
-  stage_weight<false>(wl, a.W, a.ldw, a.d_out, a.d_in, nto, nti);
+  if constexpr (SPLIT) stage_weight_split<NTO, NKB>(reinterpret_cast<u32x4*>(t_lds), a.W, a.ldw);
+  else stage_weight<false>(wl, a.W, a.ldw, a.d_out, a.d_in, nto, nti);
   if (threadIdx.x < CI) { icol[threadIdx.x] = c_sc; icol[CI + threadIdx.x] = c_sh; }
   __syncthreads();
   for (; tile < t_hi; tile += TW) {
@@ -173,7 +212,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
     const bool more = tile + TW < t_hi;
     if (more) {        // the next tile's rows are requested before this tile goes into the matrix pipe
       nvalid_next = row_ok((tile + TW) * 16 + (lane & 15), a.R, a.nvalid, a.K);
-      fetch(tile + TW, nvalid_next, nx);
+      if (!SPLIT) fetch(tile + TW, nvalid_next, nx);     // (SPLIT: into `in` itself, once it has been split — 32 registers less)
     }
     float* yr = yg + row * a.ldy;
     const unsigned long long vb = __ballot(valid);
@@ -218,13 +257,26 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
           for (int r = 0; r < 4; ++r) pv[r] = t16_sum(v[r]) * inv;      // invalid rows hold 0
           if ((lane & 15) == 0) *reinterpret_cast<float4*>(mypiv + o0) = make_float4(pv[0], pv[1], pv[2], pv[3]);
         } else {
-          pv = lds4(mypiv + o0);
+          int po = o0;
+          if (SPLIT) asm volatile("" : "+v"(po));       // (SPLIT: read here, not hoisted above the tile's MFMAs: 32 registers)
+          pv = lds4(mypiv + po);
         }
+        if constexpr (SPLIT) {
+          const bool mine = (lane & 15) == ot;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = valid ? v[r] - pv[r] : 0.f;
-          s1[ot][r] += d;
-          s2[ot][r] += d * d;
+          for (int r = 0; r < 4; ++r) {
+            const float d = valid ? v[r] - pv[r] : 0.f;
+            const float t1 = t16_sum(d), t2 = t16_sum(d * d);
+            s1[0][r] += mine ? t1 : 0.f;
+            s2[0][r] += mine ? t2 : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = valid ? v[r] - pv[r] : 0.f;
+            s1[ot][r] += d;
+            s2[ot][r] += d * d;
+          }
         }
       }
     };
@@ -233,6 +285,41 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         for (int ot = 0; ot < nto; ++ot) st4a(yr, 16 * ot + 4 * g, a.d_out, z);
       }
+    } else if constexpr (SPLIT) {
+      Split8 sp[NKB];
+      split_rows<NTI>(in, sp);
+      asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+      if (more) fetch(tile + TW, nvalid_next, in);
+      const u32x4* wb = reinterpret_cast<const u32x4*>(t_lds) + lane;
+      auto rdw = [&](int ot, int kb, u32x4 (&f)[3]) {
+        const u32x4* q = wb + ((ot * NKB + kb) * 3) * 64;
+        f[0] = q[0]; f[1] = q[64]; f[2] = q[128];
+      };
+      u32x4 fa[3], fb[3];
+      rdw(0, 0, fa);
+      // (a rolled loop over the output tiles: unrolled, the eight epilogues' addresses, pivots and bias vectors were hoisted above the
+      //  tile's MFMAs and the kernel spilled 200 bytes per lane)
+#pragma unroll 1
+      for (int ot = 0; ot < NTO; ++ot) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+          if (kb + 1 < NKB) rdw(ot, kb + 1, fb);          // the next fragments are read while this K block's six MFMAs run
+          else if (ot + 1 < NTO) rdw(ot + 1, 0, fb);
+          __builtin_amdgcn_sched_barrier(0);
+          a1 = mfma_bf(fa[2], sp[kb].h, a1);
+          a0 = mfma_bf(fa[1], sp[kb].h, a0);
+          a1 = mfma_bf(fa[0], sp[kb].l, a1);
+          a0 = mfma_bf(fa[0], sp[kb].m, a0);
+          a1 = mfma_bf(fa[1], sp[kb].m, a1);
+          a0 = mfma_bf(fa[0], sp[kb].h, a0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) fa[q] = fb[q];
+        }
+        epilogue(ot, a0 + a1);
+      }
+      if (STATS) { rn += nt; have_piv = true; }
     } else {
 #pragma unroll
       for (int ot = 0; ot < NTO; ot += 2) {
@@ -278,8 +365,10 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       if (STATS) { rn += nt; have_piv = true; }
     }
     if (more) {
+      if (!SPLIT) {
 #pragma unroll
-      for (int kk = 0; kk < NTI; ++kk) in[kk] = nx[kk];
+        for (int kk = 0; kk < NTI; ++kk) in[kk] = nx[kk];
+      }
       valid = nvalid_next;
     }
   }
@@ -294,7 +383,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       if (have_piv) pv = lds4(mypiv + 16 * ot + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float t1 = t16_sum(s1[ot][r]), t2 = t16_sum(s2[ot][r]);
+        // (SPLIT: lane (lane & 15) == ot of every row group already holds the tile's row-reduced sums: broadcast them to the group)
+        const float t1 = SPLIT ? __shfl(s1[0][r], (lane & 48) | ot, 64) : t16_sum(s1[ot][r]);
+        const float t2 = SPLIT ? __shfl(s2[0][r], (lane & 48) | ot, 64) : t16_sum(s2[ot][r]);
         if ((lane & 15) == 0) {
           const float inv = rn > 0.f ? 1.0f / rn : 0.f;
           sm[(wave * 2 + 0) * 16 * NTO + 16 * ot + 4 * g + r] = pv[r] + t1 * inv;
@@ -1338,6 +1429,12 @@ using namespace sn;
 // workgroups per group of the forward link (= moment partials per group) / of the backward link (= dW, column-sum partials per group)
 // Few rows: one workgroup per 16-row tile (k_tlin_fwd_tile); otherwise the persistent kernel, a workgroup per CU, >= 4 tiles each.
 constexpr int64_t TILE_MODE_MAX = 512;          // row tiles, all groups together
+// (A/B switch of the profile scripts: SN_TRAIN_SPLIT=0 in the environment keeps the links on the fp32-input MFMA)
+static bool train_split_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SN_TRAIN_SPLIT"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
 static bool tile_mode(int64_t R, int G) { return cdiv(R > 0 ? R : 1, 16) * (G < 1 ? 1 : G) <= TILE_MODE_MAX; }
 extern "C" int sn_train_linear_blocks(int64_t R, int G) {
   if (G < 1) G = 1;
@@ -1382,7 +1479,10 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   TLin a{p.x, p.ldx, p.R, p.G, p.d_in, p.d_out, p.W, p.ldw, p.bias, p.nvalid, p.K, p.in_scale, p.in_shift, p.in_relu, p.out_relu,
          p.y, p.ldy, p.stat_part, nblk};
   const int nti = (p.d_in + 15) / 16, nto = (p.d_out + 15) / 16;
-  const size_t lds = (size_t)8 * 8 * 1024 + (size_t)(2 * 16 * 8 + TW * 16 * 8) * sizeof(float);    // weight image + in_scale | in_shift + pivots
+  // (the full-width links with aligned parameter rows: split-bf16 matrix path, three bf16 planes in the image)
+  const bool split = p.d_in == 128 && p.d_out == 128 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0 && (p.ldw & 3) == 0 &&
+                     !tile_mode(p.R, p.G) && train_split_enabled();
+  const size_t lds = (size_t)(split ? 8 * 4 * 3 : 8 * 8) * 1024 + (size_t)(2 * 16 * 8 + TW * 16 * 8) * sizeof(float);    // weight image + in_scale | in_shift + pivots
   hipStream_t st = (hipStream_t)stream;
   int rc;
   const bool full = p.d_in == 128 && p.d_out == 128;
@@ -1394,6 +1494,14 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   if (tile_mode(p.R, p.G)) {
     if (p.stat_part) hipLaunchKernelGGL((k_tlin_fwd_tile<8, true>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), 0, st, a);
     else hipLaunchKernelGGL((k_tlin_fwd_tile<8, false>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), 0, st, a);
+  } else if (split) {
+    if (p.stat_part) {
+      if ((rc = raise_lds(k_tlin_fwd<8, 8, true, true, true>, lds, "sn_train_linear_f32")) != SN_OK) return rc;
+      hipLaunchKernelGGL((k_tlin_fwd<8, 8, true, true, true>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, st, a);
+    } else {
+      if ((rc = raise_lds(k_tlin_fwd<8, 8, false, true, true>, lds, "sn_train_linear_f32")) != SN_OK) return rc;
+      hipLaunchKernelGGL((k_tlin_fwd<8, 8, false, true, true>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds, st, a);
+    }
   } else if (p.stat_part) { if (full) SN_TLIN_FWD(true, true); else SN_TLIN_FWD(true, false); }
   else { if (full) SN_TLIN_FWD(false, true); else SN_TLIN_FWD(false, false); }
 #undef SN_TLIN_FWD
