@@ -133,6 +133,34 @@ __device__ __forceinline__ void stage_weight_split(u32x4* wl, const float* __res
   }
 }
 
+// ... and of the TRANSPOSE (the dX product of the backward link: M = W^T, M[o][k] = W[k][o]): the eight values of an entry sit in
+// eight rows of W — scalar loads, two entries = 16 loads in flight per thread.
+template <int NTO, int NKB>
+__device__ __forceinline__ void stage_weight_split_t(u32x4* wl, const float* __restrict__ W, int ldw) {
+  constexpr int total = NTO * NKB * 64;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 2 * 64 * TW) {
+    float v[2][8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * 64 * TW;
+      const int ln = i & 63, blk = i >> 6, kb = blk % NKB, ot = blk / NKB;
+      const float* wc = W + (16 * ot + (ln & 15)) + (int64_t)(32 * kb + 4 * (ln >> 4)) * ldw;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) v[u][t] = (i < total) ? wc[(int64_t)((t >> 2) * 16 + (t & 3)) * ldw] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = i0 + u * 64 * TW;
+      if (i < total) {
+        const Split8 sp = split8(f32x4{v[u][0], v[u][1], v[u][2], v[u][3]}, f32x4{v[u][4], v[u][5], v[u][6], v[u][7]});
+        const int ln = i & 63, blk = i >> 6;
+        u32x4* dst = wl + (blk * 3) * 64 + ln;
+        dst[0] = sp.h; dst[64] = sp.m; dst[128] = sp.l;
+      }
+    }
+  }
+}
+
 // ============================================================================ forward link
 struct TLin {
   const float* x; int ldx; int64_t R; int G; int d_in, d_out;
@@ -590,14 +618,22 @@ __host__ __device__ constexpr int stage_ld(int ntiles) { return ((16 * ntiles + 
 // FEW rows (a batch of small graphs) — there a workgroup per CU gets one 64-row round, 64 MFMAs deep per phase and wave on a fifth of
 // the chip; with 16-row rounds the same rows are 4x the workgroups, each 4x shallower (the weight image is re-staged per workgroup
 // from L2 either way, and the dW partials — one 64 KB image per workgroup — grow 4x: 12 MB at 2 950 rows, read once by the reduce).
-template <int NTI, int NTO, bool FULL, int RT>
+// SPLIT (round 4, the full-width links on 32-row rounds): the dX product on the bf16 matrix pipe from the exact three-way split of dz
+// and W^T (fused_common.hpp) — a wave's 16 dz rows are split once per round (176 VALU operations) and serve its output tiles at
+// 4 x 6 MFMAs of 16 cycles per tile instead of 32 of 32.  The W^T image holds three bf16 planes (96 KB), which is why the rounds are
+// 32 rows: 64-row staging images no longer fit beside it.  The dW product (K = rows: its operands would have to be split per
+// MFMA step, more VALU work than the matrix pipe saves) stays on the fp32-input MFMA.
+template <int NTI, int NTO, bool FULL, int RT, bool SPLIT = false>
 __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
+  static_assert(!SPLIT || (FULL && NTO % 2 == 0), "the split path serves the full-width links");
   constexpr int LDO = stage_ld(NTO), LDI = stage_ld(NTI);
   constexpr int TR = 16 * RT, NP = TW / RT;
+  constexpr int NKBO = NTO / 2;
+  constexpr size_t WIMG = SPLIT ? (size_t)NTI * NKBO * 3 * 1024 : (size_t)NTI * NTO * 1024;     // bytes of the W^T image
   extern __shared__ __align__(16) unsigned char t_lds[];
   const int nti = FULL ? NTI : (a.d_in + 15) >> 4, nto = FULL ? NTO : (a.d_out + 15) >> 4;
   float4* wl = reinterpret_cast<float4*>(t_lds);                          // W^T image: [ot2 < nti][kk < nto][64] float4
-  float* dzs = reinterpret_cast<float*>(t_lds) + (size_t)NTI * NTO * 256;  // [TR][LDO]
+  float* dzs = reinterpret_cast<float*>(t_lds + WIMG);                    // [TR][LDO]
   float* xsg = dzs + TR * LDO;                                          // [TR][LDI]  raw x (x_hat is re-formed at each use)
   float* red = xsg + TR * LDI;                                          // [3 sums][4 row tiles][16*NTI] running column sums of gx
   float* xcol = red + 3 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
@@ -667,7 +703,10 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     if (cA && i < a.d_out) { c_o[0] = cA[i]; c_o[1] = cB[i]; c_o[2] = cC[i]; }
     if (ms && i < a.d_out) { c_o[3] = ms[i]; c_o[4] = mt[i]; }
   }
-  if (want_dx) stage_weight<true>(wl, a.W, a.ldw, a.d_in, a.d_out, nti, nto);
+  if (want_dx) {
+    if constexpr (SPLIT) stage_weight_split_t<NTI, NKBO>(reinterpret_cast<u32x4*>(t_lds), a.W, a.ldw);
+    else stage_weight<true>(wl, a.W, a.ldw, a.d_in, a.d_out, nti, nto);
+  }
   if (threadIdx.x < CI) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) xcol[j * CI + threadIdx.x] = c_x[j];
@@ -729,11 +768,36 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       }
       float* gr = a.gx + (goff + row) * a.ldgx;
       const float* xrow = xsg + (16 * rt + lr) * LDI;
+      Split8 dsp[SPLIT ? NKBO : 1];
+      if constexpr (SPLIT) {
+        split_rows<NTO>(fr, dsp);
+        asm volatile("" :: "v"(dsp[0].h), "v"(dsp[NKBO - 1].l));
+      }
 #pragma unroll
       for (int j = 0; j < HI; ++j) {
         const int ot = NP * j + part;
         if (ot < nti) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (SPLIT) {
+            const u32x4* wb = reinterpret_cast<const u32x4*>(t_lds) + lane + (ot * NKBO * 3) * 64;
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+            u32x4 fa[3] = {wb[0], wb[64], wb[128]}, fb[3];
+#pragma unroll
+            for (int kb = 0; kb < NKBO; ++kb) {
+              if (kb + 1 < NKBO) { const u32x4* q = wb + ((kb + 1) * 3) * 64; fb[0] = q[0]; fb[1] = q[64]; fb[2] = q[128]; }
+              __builtin_amdgcn_sched_barrier(0);
+              a1 = mfma_bf(fa[2], dsp[kb].h, a1);
+              acc = mfma_bf(fa[1], dsp[kb].h, acc);
+              a1 = mfma_bf(fa[0], dsp[kb].l, a1);
+              acc = mfma_bf(fa[0], dsp[kb].m, acc);
+              a1 = mfma_bf(fa[1], dsp[kb].m, a1);
+              acc = mfma_bf(fa[0], dsp[kb].h, acc);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q = 0; q < 3; ++q) fa[q] = fb[q];
+            }
+            acc = acc + a1;
+          } else {
           const float4* w0 = wl + (ot * nto) * 64 + lane;
           float4 pn = w0[0];
 #pragma unroll
@@ -747,6 +811,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
               acc = mfma16(p.z, fr[kk][2], acc);
               acc = mfma16(p.w, fr[kk][3], acc);
             }
+          }
           }
           const int c0 = 16 * ot + 4 * g;
           const float4 xq = *reinterpret_cast<const float4*>(xrow + c0);
@@ -1548,13 +1613,19 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
          p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk};
-  auto lds_of = [](int rt) {
-    return (size_t)8 * 8 * 1024 + (size_t)16 * rt * (stage_ld(8) + stage_ld(8)) * sizeof(float) +
+  auto lds_of = [](int rt, bool split = false) {
+    return (size_t)(split ? 8 * 4 * 3 : 8 * 8) * 1024 + (size_t)16 * rt * (stage_ld(8) + stage_ld(8)) * sizeof(float) +
            (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
   };
   const bool full = p.d_in == 128 && p.d_out == 128;
   const int rt = tile_mode(p.R, p.G) ? bwd_small_rt() : 4;
   int rc;
+  if (full && rt == 4 && p.gx && train_split_enabled()) {       // the large full-width links: dX on the split-bf16 path, 32-row rounds
+    if ((rc = raise_lds(k_tlin_bwd<8, 8, true, 2, true>, lds_of(2, true), "sn_train_linear_bwd_f32")) != SN_OK) return rc;
+    hipLaunchKernelGGL((k_tlin_bwd<8, 8, true, 2, true>), dim3((unsigned)(nblk * p.G)), dim3(64 * TW), lds_of(2, true), (hipStream_t)stream, a);
+    SN_CHECK_LAUNCH("sn_train_linear_bwd_f32");
+    return SN_OK;
+  }
 #define SN_TLIN_BWD(FULL, RT)                                                                                                    \
   do {                                                                                                                            \
     if ((rc = raise_lds(k_tlin_bwd<8, 8, FULL, RT>, lds_of(RT), "sn_train_linear_bwd_f32")) != SN_OK) return rc;                  \
