@@ -149,6 +149,8 @@ int sn_gine_aggregate_f32(const float* x, const float* ea, float* out, int64_t N
 #define SN_EPI_RELU 8       /* activation after the affine (PyG-tree order) */
 #define SN_EPI_RESIDUAL 16
 #define SN_EPI_BLOCK_BIAS 32 /* + block_bias[row / rows_per_block][:] together with the bias (sn_masked_linear_blockbias_f32 sets it) */
+#define SN_EPI_RESIDUAL_PRE 64 /* the residual is added right behind the bias, BEFORE relu_pre / the affine / relu: BatchNorm(x + Linear(h)) of the
+                                * DGL Transformer layer (layers/transformer.py:283-290) as ONE launch; excludes SN_EPI_RESIDUAL */
 int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
                          const float* bias, const int32_t* nvalid, int K, int flags,
                          const float* scale, const float* shift, const float* residual, int ldr,
@@ -366,6 +368,11 @@ int sn_grouped_linear_f32(const float* x, int ldx, int64_t R, int G, int din, in
                           const float* rowscale, const float* scale, const float* shift, float* y, int ldy, void* stream);
 int sn_edge_attention_f32(const float* Q, const float* K, const float* V, const float* Ee, int64_t N, int heads, int dk,
                           const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream);
+/* The same with row strides (in floats): Q / K / V rows ldq apart — the three column blocks of ONE [N, 3*heads*dk] projection
+ * (MultiHeadAttentionLayer's Q, K, V Linears, layers/transformer.py:122-126, evaluated as one [3d, d] GEMM) — and Ee rows lde apart
+ * (every layer's E projection of the same edge embedding in one [E, L*heads*dk] matrix). */
+int sn_edge_attention_strided_f32(const float* Q, const float* K, const float* V, int ldq, const float* Ee, int lde, int64_t N, int heads,
+                                  int dk, const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out, void* stream);
 int sn_pointwise_f32(const float* x, int ldx, int64_t R, int C, const float* rowscale, const float* scale, const float* shift, int act,
                      float slope, const float* residual, int ldr, float* y, int ldy, void* stream);
 

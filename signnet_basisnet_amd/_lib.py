@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsignnet_hip.so")
 
 EPI_BIAS, EPI_RELU_PRE, EPI_AFFINE, EPI_RELU, EPI_RESIDUAL = 1, 2, 4, 8, 16
+EPI_RESIDUAL_PRE = 64
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "sn_pna_aggregate_gather_f32": [_p, _i, _p, _i, _p, _i, _p, _i, _i, _l, _p, _p, _p, _f, _p, _i, _i, _p],
     "sn_grouped_linear_f32": [_p, _i, _l, _i, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     "sn_edge_attention_f32": [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p, _p],
+    "sn_edge_attention_strided_f32": [_p, _p, _p, _i, _p, _i, _l, _i, _i, _p, _p, _p, _p, _p],
     "sn_pointwise_f32": [_p, _i, _l, _i, _p, _p, _p, _i, _f, _p, _i, _p, _i, _p],
     "sn_deepsigns_phi_f32": [_p, _p, _i, _p, _p, _p, _p, _i, _p, _p],
     "sn_mlp_chain_f32": [_p, _i, _l, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p],

@@ -164,8 +164,10 @@ __global__ __launch_bounds__(256) void k_grouped_linear(const float* __restrict_
 // MultiHeadAttentionLayer.propagate_attention (transformer.py:150-195, full_graph False, edge features): per in-edge (j -> i, id e)
 // and head h:  score = sum_c K[j,h,c] * Q[i,h,c] / sqrt(dk) * E[e,h,c];  s = exp(clamp(score, -5, 5));
 // out[i,h,:] = sum_e s * V[j,h,:] / (sum_e s + 1e-6).  One thread per (node, head); dk <= 32.
+// (ldq / lde: row strides of Q, K, V and of Ee in floats — heads*dk for separate matrices, 3*heads*dk / L*heads*dk for the column
+//  blocks of a fused projection: sn_edge_attention_strided_f32)
 __global__ __launch_bounds__(256) void k_edge_attention(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                        const float* __restrict__ Ee, int64_t N, int H, int dk,
+                                                        int ldq, const float* __restrict__ Ee, int lde, int64_t N, int H, int dk,
                                                         const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                         const int32_t* __restrict__ eperm, float* __restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -176,13 +178,13 @@ __global__ __launch_bounds__(256) void k_edge_attention(const float* __restrict_
   const float root = sqrtf((float)dk);
   float q[32], acc[32];
 #pragma unroll
-  for (int c = 0; c < 32; ++c) { q[c] = c < dk ? Q[n * d + h * dk + c] : 0.f; acc[c] = 0.f; }
+  for (int c = 0; c < 32; ++c) { q[c] = c < dk ? Q[n * ldq + h * dk + c] : 0.f; acc[c] = 0.f; }
   float z = 0.f;
   for (int e = rowptr[n]; e < rowptr[n + 1]; ++e) {
     const int64_t j = col[e], eid = eperm[e];
-    const float* kr = K + j * d + h * dk;
-    const float* er = Ee + eid * d + h * dk;
-    const float* vr = V + j * d + h * dk;
+    const float* kr = K + j * ldq + h * dk;
+    const float* er = Ee + eid * lde + h * dk;
+    const float* vr = V + j * ldq + h * dk;
     float sc = 0.f;
 #pragma unroll
     for (int c = 0; c < 32; ++c)
@@ -626,9 +628,22 @@ extern "C" int sn_edge_attention_f32(const float* Q, const float* K, const float
   SN_REQUIRE(Q && K && V && Ee && rowptr && col && eperm && out && N >= 0 && heads > 0, "sn_edge_attention_f32: bad arguments");
   SN_REQUIRE(dk >= 1 && dk <= 32, "sn_edge_attention_f32: head width %d not in [1, 32]", dk);
   if (N == 0) return SN_OK;
-  hipLaunchKernelGGL(k_edge_attention, dim3((unsigned)cdiv(N * heads, 256)), dim3(256), 0, (hipStream_t)stream, Q, K, V, Ee, N, heads, dk,
-                     rowptr, col, eperm, out);
+  hipLaunchKernelGGL(k_edge_attention, dim3((unsigned)cdiv(N * heads, 256)), dim3(256), 0, (hipStream_t)stream, Q, K, V, heads * dk, Ee,
+                     heads * dk, N, heads, dk, rowptr, col, eperm, out);
   SN_CHECK_LAUNCH("sn_edge_attention_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_edge_attention_strided_f32(const float* Q, const float* K, const float* V, int ldq, const float* Ee, int lde, int64_t N,
+                                             int heads, int dk, const int32_t* rowptr, const int32_t* col, const int32_t* eperm, float* out,
+                                             void* stream) {
+  SN_REQUIRE(Q && K && V && Ee && rowptr && col && eperm && out && N >= 0 && heads > 0, "sn_edge_attention_strided_f32: bad arguments");
+  SN_REQUIRE(dk >= 1 && dk <= 32, "sn_edge_attention_strided_f32: head width %d not in [1, 32]", dk);
+  SN_REQUIRE(ldq >= heads * dk && lde >= heads * dk, "sn_edge_attention_strided_f32: row strides shorter than heads * dk");
+  if (N == 0) return SN_OK;
+  hipLaunchKernelGGL(k_edge_attention, dim3((unsigned)cdiv(N * heads, 256)), dim3(256), 0, (hipStream_t)stream, Q, K, V, ldq, Ee, lde, N, heads,
+                     dk, rowptr, col, eperm, out);
+  SN_CHECK_LAUNCH("sn_edge_attention_strided_f32");
   return SN_OK;
 }
 

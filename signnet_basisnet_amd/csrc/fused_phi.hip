@@ -392,8 +392,12 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       // layer's gathers — it went through that layer's GEMM barriers); the + wave stores the lower half of the channel tiles
       // of the sum, the - wave the upper half.
       if (LIVE) {
+        // (only the channel tiles the partner wave adds and stores: the - wave takes the upper half from the + wave and the other way
+        //  round — ds_write_b128 moves 79 B/clk per CU, a full 128 KB image is 1.6 k cycles of every bin)
+        constexpr int H = (NT + 1) / 2;
 #pragma unroll
-        for (int kk = 0; kk < NT; ++kk) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
+        for (int kk = 0; kk < NT; ++kk)
+          if (sg ? (kk < H) : (kk >= H)) lds_st4(XR + 16 * kk + 4 * g, in[kk]);
       }
       lds_barrier();
       if (LIVE && valid && !DGL) {

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
     } else {
       if (a.flags & SN_EPI_BIAS) v += load4<YV>(a.bias, o0, a.d_out);
       if (a.flags & SN_EPI_BLOCK_BIAS) v += load4<YV>(a.bbias + (row / a.bb_rows) * a.ldbb, o0, a.d_out);
+      if (a.flags & SN_EPI_RESIDUAL_PRE) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
       if (a.flags & SN_EPI_RELU_PRE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void k_linear_ksplit(LinArgs a) {
     } else {
       if (a.flags & SN_EPI_BIAS) v += load4<YV>(a.bias, o0, a.d_out);
       if (a.flags & SN_EPI_BLOCK_BIAS) v += load4<YV>(a.bbias + (row / a.bb_rows) * a.ldbb, o0, a.d_out);
+      if (a.flags & SN_EPI_RESIDUAL_PRE) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
       if (a.flags & SN_EPI_RELU_PRE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t
       } else {
         if (a.flags & SN_EPI_BIAS) v += load4<true>(a.bias, o0, a.d_out);
         if (a.flags & SN_EPI_BLOCK_BIAS) v += load4<true>(a.bbias + (row / a.bb_rows) * a.ldbb, o0, a.d_out);
+        if (a.flags & SN_EPI_RESIDUAL_PRE) v += load4<true>(a.res + row * a.ldr, o0, a.d_out);
         if (a.flags & SN_EPI_RELU_PRE) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
         if (a.flags & SN_EPI_AFFINE) {
           const f32x4 sc = load4<true>(a.scale, o0, a.d_out), sh = load4<true>(a.shift, o0, a.d_out);
@@ -1295,7 +1298,9 @@ static int masked_linear_impl(const float* x, int ldx, int64_t R, int d_in, cons
   SN_REQUIRE(ldx >= d_in && ldy >= d_out, "sn_masked_linear_f32: leading dimension too small");
   SN_REQUIRE(!(flags & SN_EPI_BIAS) || bias, "sn_masked_linear_f32: BIAS without bias");
   SN_REQUIRE(!(flags & SN_EPI_AFFINE) || (scale && shift), "sn_masked_linear_f32: AFFINE without scale/shift");
-  SN_REQUIRE(!(flags & SN_EPI_RESIDUAL) || (residual && ldr >= d_out), "sn_masked_linear_f32: RESIDUAL without residual");
+  SN_REQUIRE(!(flags & (SN_EPI_RESIDUAL | SN_EPI_RESIDUAL_PRE)) || (residual && ldr >= d_out), "sn_masked_linear_f32: RESIDUAL without residual");
+  SN_REQUIRE((flags & (SN_EPI_RESIDUAL | SN_EPI_RESIDUAL_PRE)) != (SN_EPI_RESIDUAL | SN_EPI_RESIDUAL_PRE),
+             "sn_masked_linear_f32: the residual goes in front of the affine or behind it, not both");
   SN_REQUIRE(!nvalid || K > 0, "sn_masked_linear_f32: nvalid needs K > 0");
   SN_REQUIRE(al16(Wp), "sn_masked_linear_f32: Wp must be 16-byte aligned");
   if (R == 0) return SN_OK;

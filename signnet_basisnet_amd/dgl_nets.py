@@ -903,6 +903,24 @@ class TransformerNet(_PackCache, nn.Module):
 
     _plan = GINNet._plan
 
+    fused_layers = True      # eval: fused projections / epilogues (False: one launch per op, as the train-mode value path)
+
+    def _fusable(self):
+        """Every layer maps hidden -> hidden (the shipped configs: out_dim == hidden_dim), so that the layers' E projections stack."""
+        d = self.layers[0].out_channels
+        return self.fused_layers and all(L.in_channels == d and L.out_channels == d for L in self.layers)
+
+    def _fused_eval(self):
+        """Eval cache: cat[W_Q; W_K; W_V] per layer and cat over the layers of W_E, packed (no biases: use_bias False)."""
+        c = self.__dict__.setdefault("_cache", {})
+        if "fused" not in c:
+            def pack(ws):
+                W = torch.cat([w.detach().float() for w in ws], 0).contiguous()
+                return ops.PackedLinear(ops.pack_weight(W), W.shape[0], W.shape[1], None)
+            c["fused"] = {"qkv": [pack([L.attention_h.Q.weight, L.attention_h.K.weight, L.attention_h.V.weight]) for L in self.layers],
+                          "E": pack([L.attention_h.E.weight for L in self.layers])}
+        return c["fused"]
+
     def _bn_res(self, y, res, bn, train):
         """BatchNorm1d(res + y): eval folded into one pointwise pass; train: batch statistics of the sum."""
         site = self._bn(bn, train)
@@ -935,7 +953,22 @@ class TransformerNet(_PackCache, nn.Module):
             else:
                 x = ops.masked_linear(pp, self._pk(self.embedding_p), residual=x)                                     # (:101-102)
             ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
-            for L in self.layers:
+            if not train and self._fusable():
+                # eval (round 4): 5 launches per layer instead of 12.  Q | K | V are ONE [3d, d] Linear whose column blocks the attention
+                # reads in place; every layer's E projection of the (layer-independent) edge embedding is one [L*d, d] Linear up front;
+                # `BatchNorm(x + Linear(h))` is the Linear's epilogue (residual in front of the folded affine: the same operations in the
+                # same order as the add + affine passes they replace — bit-identical).
+                fz = self._fused_eval()
+                Ee_all = ops.masked_linear(ef, fz["E"])
+                for li, L in enumerate(self.layers):
+                    qkv = ops.masked_linear(x, fz["qkv"][li])
+                    a = ops.edge_attention_fused(qkv, Ee_all, li, plan, L.num_heads)                                  # (:150-228)
+                    s1, s2 = self._bn(L.batch_norm1_h, False), self._bn(L.batch_norm2_h, False)
+                    x1 = ops.masked_linear(a, self._pk(L.O_h), residual=x, residual_pre=True, scale=s1.scale, shift=s1.shift)       # (:283-290)
+                    f = ops.masked_linear(x1, self._pk(L.FFN_h_layer1), relu=True)
+                    x = ops.masked_linear(f, self._pk(L.FFN_h_layer2), residual=x1, residual_pre=True, scale=s2.scale, shift=s2.shift)  # (:300-308)
+            else:
+              for L in self.layers:
                 A = L.attention_h
                 Q, K, V = (ops.masked_linear(x, self._pk(getattr(A, n))) for n in "QKV")
                 Ee = ops.masked_linear(ef, self._pk(A.E))

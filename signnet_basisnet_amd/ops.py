@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, check, lib, ptr,
+from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, EPI_RESIDUAL_PRE, check, lib, ptr,
                    require_cuda, stream)
 
 __all__ = ["KernelTimer", "KERNEL_ROOFLINE", "GraphPlan", "PlanBins", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
@@ -350,8 +350,9 @@ def gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan: GraphPlan, want_den=False, epilogu
 
 
 def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False,
-                  residual=None, use_bias=True, out=None):
-    """y = epilogue(x @ W^T); x is a row matrix [..., d_in] (leading dims flattened to rows)."""
+                  residual=None, use_bias=True, out=None, residual_pre=False):
+    """y = epilogue(x @ W^T); x is a row matrix [..., d_in] (leading dims flattened to rows).
+    residual_pre: the residual is added right behind the bias, in front of relu_pre / the affine / relu (BatchNorm(x + Linear(h)))."""
     require_cuda(x)
     x = _f32c(x, "x")
     if x.shape[-1] != pl.d_in:
@@ -368,7 +369,7 @@ def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=No
     if relu:
         flags |= EPI_RELU
     if residual is not None:
-        flags |= EPI_RESIDUAL
+        flags |= EPI_RESIDUAL_PRE if residual_pre else EPI_RESIDUAL
         residual = _f32c(residual, "residual")
     if out is None:
         out = torch.empty(*x.shape[:-1], pl.d_out, dtype=torch.float32, device=x.device)
@@ -725,6 +726,24 @@ def edge_attention(Q, K, V, Ee, plan: GraphPlan, heads: int):
     with _span("sn_edge_attention_f32"):
         check(lib().sn_edge_attention_f32(ptr(Q), ptr(K), ptr(V), ptr(Ee), plan.N, int(heads), d // heads, ptr(plan.rowptr), ptr(plan.col),
                                           ptr(plan.eperm), ptr(out), stream()), "sn_edge_attention_f32")
+    return out
+
+
+def edge_attention_fused(qkv, Ee_all, layer: int, plan: GraphPlan, heads: int):
+    """The same attention on the column blocks of fused projections: qkv [N, 3*d] = [Q | K | V] of one Linear over cat[W_Q; W_K; W_V],
+    Ee_all [E, L*d] = every layer's E projection of the edge embedding side by side (layer `layer` is read) — no copies."""
+    require_cuda(qkv)
+    if qkv.dtype != torch.float32 or not qkv.is_contiguous() or Ee_all.dtype != torch.float32 or not Ee_all.is_contiguous():
+        raise ValueError("edge_attention_fused: contiguous float32 matrices expected")
+    d = qkv.shape[1] // 3
+    if qkv.shape[1] != 3 * d or d % heads or d // heads > 32 or Ee_all.shape[1] % d or not 0 <= layer < Ee_all.shape[1] // d:
+        raise ValueError("edge_attention_fused: qkv must be [N, 3*d], Ee_all [E, L*d], head width <= 32")
+    out = torch.empty(plan.N, d, dtype=torch.float32, device=qkv.device)
+    base, eb = qkv.data_ptr(), Ee_all.data_ptr() + 4 * d * layer
+    with _span("sn_edge_attention_f32"):
+        check(lib().sn_edge_attention_strided_f32(C.c_void_p(base), C.c_void_p(base + 4 * d), C.c_void_p(base + 8 * d), 3 * d, C.c_void_p(eb),
+                                                  Ee_all.shape[1], plan.N, int(heads), d // heads, ptr(plan.rowptr), ptr(plan.col),
+                                                  ptr(plan.eperm), ptr(out), stream()), "sn_edge_attention_strided_f32")
     return out
 
 

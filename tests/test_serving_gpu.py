@@ -90,3 +90,31 @@ def test_graphed_dgl_forward_replays_the_eager_forward(name):
     gc, hc, pc, ec, sc = _inputs(c, k)
     with pytest.raises(ValueError, match="shape"):
         gf(gc, hc, pc, ec, sc if snorm else None)
+
+
+def test_transformer_net_fused_eval_layers_equal_the_op_by_op_path():
+    """TransformerNet eval (round 4): Q | K | V as one [3d, d] Linear read in place by the attention, every layer's E projection in one
+    Linear up front, BatchNorm(x + Linear(h)) as the Linear's epilogue — 5 launches per layer instead of 12, bit-identical."""
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, ops, synth
+    import parity_util as PU
+    cls, params = dgl_configs.net_params("transformer", DEV)
+    params.update(L=4)
+    torch.manual_seed(2)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, 3)
+    net = net.to(DEV).eval()
+    a = synth.make_batch(24, seed=11)
+    g, h, pe, e, _ = _inputs(a, params["pos_enc_dim"])
+    with torch.no_grad():
+        p = net.sign_inv_net(g, pe).squeeze(-1)
+        rec = ops.KernelTimer()
+        with rec:
+            y_fused = net(g, h, p, e, None)[0].clone()
+        n_fused = sum(v[0] for v in rec.summary().values())
+        net.fused_layers = False
+        rec = ops.KernelTimer()
+        with rec:
+            y_ops = net(g, h, p, e, None)[0].clone()
+        n_ops = sum(v[0] for v in rec.summary().values())
+    assert torch.equal(y_fused, y_ops)
+    assert n_fused <= n_ops - 6 * params["L"], (n_fused, n_ops)
