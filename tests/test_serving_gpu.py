@@ -117,4 +117,5 @@ def test_transformer_net_fused_eval_layers_equal_the_op_by_op_path():
             y_ops = net(g, h, p, e, None)[0].clone()
         n_ops = sum(v[0] for v in rec.summary().values())
     assert torch.equal(y_fused, y_ops)
-    assert n_fused <= n_ops - 6 * params["L"], (n_fused, n_ops)
+    assert n_fused <= n_ops - 2 * params["L"], (n_fused, n_ops)      # (the timer sees the launches that go through ops._span: not the
+                                                                      #  four pointwise passes per layer the fused epilogues also replace)
