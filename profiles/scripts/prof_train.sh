@@ -1,7 +1,7 @@
-set -x
-cd ${GRAFT_REPO_ROOT:-.}
-export TMPDIR=/tmp
-O=gpurun_out/${SN_PROF_TAG:-r03train}
-rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python bench.py --workload train --steps 20 --warmup 5 --no-cpu-baseline > $O/train_profiled.json 2> $O/trace.err
-find $O -name "*kernel_stats.csv" | head
+#!/bin/bash
+# cycles per phase of the training link kernels: gpurun -- bash profiles/scripts/prof_train.sh   (rebuilds the default library afterwards)
+cd "${GRAFT_REPO_ROOT:-.}"
+C=signnet_basisnet_amd/csrc
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSN_PROFILE -c $C/train.hip -o $C/train.o && hipcc --offload-arch=gfx950 -shared -fPIC -o signnet_basisnet_amd/libsignnet_hip.so $C/*.o
+python profiles/scripts/prof_train.py 2>&1 | grep -v amdgpu.ids | tail -5
+python -m signnet_basisnet_amd.build --force > /dev/null 2>&1

@@ -162,6 +162,19 @@ __device__ __forceinline__ void stage_weight_split_t(u32x4* wl, const float* __r
 }
 
 // ============================================================================ forward link
+// -DSN_PROFILE (scratch builds only: profiles/scripts/prof_train.sh): cycles per phase of workgroup 0 / wave 0 of the full-width split
+// links, read back with sn_prof_read_train().  Slots: [0..9] backward link, [10..19] backward link with a dot_x operand, [20..29]
+// forward link with statistics, [30..39] forward link without (each: 8 phase sums, the workgroup's rounds / tiles, R), [40..47] the
+// cycle at which each wave of workgroup 0 left the forward tile loop.
+#ifdef SN_PROFILE
+static __device__ long long g_tprof[64];
+#define TP_ON (SPLIT && blockIdx.x == 0 && threadIdx.x == 0)
+#define TP_T0() long long tp0 = clock64()
+#define TP_ACC(i) do { const long long tpn = clock64(); if (TP_ON) tpv[i] += tpn - tp0; tp0 = tpn; } while (0)
+#else
+#define TP_T0() do { } while (0)
+#define TP_ACC(i) do { } while (0)
+#endif
 struct TLin {
   const float* x; int ldx; int64_t R; int G; int d_in, d_out;
   const float* W; int ldw; const float* bias;
@@ -211,6 +224,10 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
 #pragma unroll
   for (int ot = 0; ot < NS; ++ot) { s1[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[ot] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   float* mypiv = piv + wave * 16 * NTO;
+#ifdef SN_PROFILE
+  long long tpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  TP_T0();
   auto fetch = [&](int64_t tile, bool v, f32x4 (&buf)[NTI]) {
     const float* xr = xg + (tile * 16 + (lane & 15)) * a.ldx;
 #pragma unroll
@@ -234,7 +251,14 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   else stage_weight<false>(wl, a.W, a.ldw, a.d_out, a.d_in, nto, nti);
   if (threadIdx.x < CI) { icol[threadIdx.x] = c_sc; icol[CI + threadIdx.x] = c_sh; }
   __syncthreads();
+  TP_ACC(0);
+#ifdef SN_PROFILE
+  const long long tp_loop0 = clock64();
+#endif
   for (; tile < t_hi; tile += TW) {
+#ifdef SN_PROFILE
+    if (TP_ON) tpv[7] += 1;
+#endif
     const int64_t row = tile * 16 + (lane & 15);
     const bool inr = row < a.R;
     const bool more = tile + TW < t_hi;
@@ -265,6 +289,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
           for (int r = 0; r < 4; ++r) in[kk][r] = fmaxf(in[kk][r], 0.f);
       }
     }
+    TP_ACC(1);
     const float nt = (float)__popcll(vb & 0xffffull);
     const bool first = STATS && vb != 0ull && !have_piv;      // wave-uniform
     auto epilogue = [&](int ot, f32x4 acc) {
@@ -317,6 +342,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       Split8 sp[NKB];
       split_rows<NTI>(in, sp);
       asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
+      TP_ACC(2);
       if (more) fetch(tile + TW, nvalid_next, in);
       const u32x4* wb = reinterpret_cast<const u32x4*>(t_lds) + lane;
       auto rdw = [&](int ot, int kb, u32x4 (&f)[3]) {
@@ -330,6 +356,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
 #pragma unroll 1
       for (int ot = 0; ot < NTO; ++ot) {
         f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        TP_ACC(3);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
           if (kb + 1 < NKB) rdw(ot, kb + 1, fb);          // the next fragments are read while this K block's six MFMAs run
@@ -345,6 +372,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
 #pragma unroll
           for (int q = 0; q < 3; ++q) fa[q] = fb[q];
         }
+        TP_ACC(5);
         epilogue(ot, a0 + a1);
       }
       if (STATS) { rn += nt; have_piv = true; }
@@ -392,6 +420,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       }
       if (STATS) { rn += nt; have_piv = true; }
     }
+    TP_ACC(3);
     if (more) {
       if (!SPLIT) {
 #pragma unroll
@@ -402,7 +431,11 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
   }
   if (STATS) {
     // per-wave (n, mean, M2) from the pivoted sums, then one partial per WORKGROUP: the waves meet in LDS, merged in wave order (Chan)
-    __syncthreads();
+#ifdef SN_PROFILE
+    if (SPLIT && blockIdx.x == 0 && lane == 0) g_tprof[40 + wave] = clock64() - tp_loop0;      // when each wave left the tile loop
+#endif
+    lds_barrier();          // (not __syncthreads(): the tile stores of y need not have landed for the waves to meet in LDS)
+    TP_ACC(4);
     float* sm = reinterpret_cast<float*>(t_lds);          // [TW][mean 16*NTO | M2 16*NTO], counts behind  (the weight image is dead)
     float* sc = sm + TW * 2 * 16 * NTO;
 #pragma unroll
@@ -422,7 +455,8 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       }
     }
     if (lane == 0) sc[wave] = rn;
-    __syncthreads();
+    TP_ACC(4);
+    lds_barrier();
     float* stg = a.stat + (int64_t)grp * (2 * (int64_t)a.nblk * a.d_out + a.nblk);
     for (int c = threadIdx.x; c < a.d_out; c += 64 * TW) {
       float n = 0.f, m = 0.f, q = 0.f;
@@ -447,6 +481,15 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
       stg[2 * (int64_t)a.nblk * a.d_out + blk] = n;
     }
   }
+  TP_ACC(4);
+#ifdef SN_PROFILE
+  if (TP_ON) {
+    const int o = STATS ? 20 : 30;
+    for (int i = 0; i < 8; ++i) g_tprof[o + i] = tpv[i];
+    g_tprof[o + 8] = t_hi - t_lo;
+    g_tprof[o + 9] = a.R;
+  }
+#endif
 }
 
 // The same link for FEW rows (a batch of small graphs: 2 950 nodes = 185 row tiles).  The persistent kernel above gives such a launch one
@@ -638,7 +681,6 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   float* red = xsg + TR * LDI;                                          // [3 sums][4 row tiles][16*NTI] running column sums of gx
   float* xcol = red + 3 * 4 * 16 * NTI;                                    // [3][16*NTI] x_scale | x_shift | x_mean of my group
   float* ocol = xcol + 3 * 16 * NTI;                                       // [5][16*NTO] coef a | b | c | mask scale | mask shift
-  double* redd = reinterpret_cast<double*>(ocol + 5 * 16 * NTO);           // [4 row tiles][16*NTI] float64 sums of gx . dot_x
   constexpr int CI = 16 * NTI, CO = 16 * NTO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
   const int rt = wave % RT, part = wave / RT;
@@ -655,11 +697,16 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   const float* xt = a.xs ? a.xt + (int64_t)grp * a.d_in : nullptr;
   const float* xmu = a.xmu ? a.xmu + (int64_t)grp * a.d_in : nullptr;
   const bool want_dx = a.gx != nullptr;
+#ifdef SN_PROFILE
+  long long tpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  TP_T0();
   // dW accumulators of this wave: output tile `wave` (16 dz columns) x every operand tile
   f32x4 dw[NTI];
 #pragma unroll
   for (int it = 0; it < NTI; ++it) dw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
   float dbacc = 0.f;
+  double dots = 0.0;
   // column sums of gx over my rows (a wave's 16 rows x its column tiles), all rounds
   f32x4 cs1[(NTI + TW / RT - 1) / (TW / RT)], cs2[(NTI + TW / RT - 1) / (TW / RT)];
 #pragma unroll
@@ -668,6 +715,10 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   // under the round's 256 MFMAs per wave; a wave loads the column tiles kk = part, part + NP, ... of its 16 rows.
   constexpr int HO = (NTO + NP - 1) / NP, HI = (NTI + NP - 1) / NP;
   f32x4 pdy[HO], pz[HO], px[HI];
+  // the rows of dot_x / of the gradient being accumulated into, fetched with the round's other rows (consumed in phase 2: copied in
+  // front of the next request).  Only where a wave has two column tiles: with four the copies spill, and those read them in place.
+  constexpr bool PREQ = HI <= 2;
+  f32x4 pq[PREQ ? HI : 1], pg[PREQ ? HI : 1];
   bool pvalid = false;
   auto request = [&](int64_t round) {
     const int64_t row = round * TR + 16 * rt + lr;
@@ -689,6 +740,22 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     for (int j = 0; j < HI; ++j) {
       px[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (pvalid && NP * j + part < nti) px[j] = ld4a(xr, 16 * (NP * j + part) + 4 * g, a.d_in);
+    }
+    if constexpr (PREQ) {
+      if (a.dotx) {
+#pragma unroll
+        for (int j = 0; j < HI; ++j) {
+          pq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (pvalid && NP * j + part < nti) pq[j] = ld4a(a.dotx + (goff + row) * a.lddot, 16 * (NP * j + part) + 4 * g, a.d_in);
+        }
+      }
+      if (a.gx_acc && a.gx) {
+#pragma unroll
+        for (int j = 0; j < HI; ++j) {
+          pg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (row < a.R && NP * j + part < nti) pg[j] = ld4a(a.gx + (goff + row) * a.ldgx, 16 * (NP * j + part) + 4 * g, a.d_in);
+        }
+      }
     }
   };
   // Prologue: every global read is in flight before the first wait — the first round's rows, the column constants (one per thread,
@@ -718,8 +785,8 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
   // with them the kernel spilled)
   for (int i = threadIdx.x; i < 3 * 4 * 16 * NTI; i += 64 * TW) red[i] = 0.f;
-  for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) redd[i] = 0.0;
   __syncthreads();          // the column constants (and the weight image) are published before phase 1 reads them
+  TP_ACC(0);
   for (int64_t round = r_lo; round < r_hi; ++round) {
     const int64_t row = round * TR + 16 * rt + lr;     // my row within the group (phases 1, 2)
     const bool valid = pvalid;
@@ -755,7 +822,14 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
         if (kk < nti) *reinterpret_cast<float4*>(dsx + 16 * kk + 4 * g) = make_float4(px[j][0], px[j][1], px[j][2], px[j][3]);
       }
     }
+    TP_ACC(1);
     __syncthreads();
+    TP_ACC(2);
+    f32x4 cq[PREQ ? HI : 1], cg[PREQ ? HI : 1];
+    if constexpr (PREQ) {
+#pragma unroll
+      for (int j = 0; j < HI; ++j) { cq[j] = pq[j]; cg[j] = pg[j]; }
+    }
     if (round + 1 < r_hi) request(round + 1);
     // ---------------------------------------------------------------- phase 2: gx = (dz W) * mask, column sums
     if (want_dx) {
@@ -828,16 +902,16 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
               for (int r = 0; r < 4; ++r) v[r] = xv[r] > 0.f ? v[r] : 0.f;
             }
           }
-          if (a.gx_acc && row < a.R) v += ld4a(gr, c0, a.d_in);
+          if (a.gx_acc && row < a.R) {
+            if constexpr (PREQ) v += cg[PREQ ? j : 0]; else v += ld4a(gr, c0, a.d_in);
+          }
           if (row < a.R) st4a(gr, c0, a.d_in, v);
-          if (a.dotx) {
+          if (a.dotx) {      // a cancelling scalar sum over all rows and columns: float64, one accumulator per lane over all rounds
             f32x4 q = {0.f, 0.f, 0.f, 0.f};
-            if (valid) q = ld4a(a.dotx + (goff + row) * a.lddot, c0, a.d_in);
+            if constexpr (PREQ) q = cq[PREQ ? j : 0];
+            else { if (valid) q = ld4a(a.dotx + (goff + row) * a.lddot, c0, a.d_in); }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float a3 = t16_sum(v[r] * q[r]);
-              if (lr == 0) redd[rt * 16 * NTI + c0 + r] += (double)a3;      // a cancelling scalar sum over all rows and columns: float64
-            }
+            for (int r = 0; r < 4; ++r) dots += (double)(v[r] * q[r]);
           }
           if (xmu) {        // my rows' share of the column sums, in registers over all rounds; across the 16 rows once, after the loop
             const f32x4 mu = lds4(xcol + 2 * CI + c0);
@@ -850,6 +924,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
         }
       }
     }
+    TP_ACC(3);
     // ---------------------------------------------------------------- phase 3: dW[tile `wave`] += dz^T x_hat over the round's rows
     if (wave < nto && a.dwp) {
       float xsc[NTI], xsh[NTI];       // x_hat's column constants of my dW lanes, out of the step loop (16 LDS reads per step otherwise)
@@ -877,7 +952,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
         }
       }
     }
+    TP_ACC(4);
     __syncthreads();
+    TP_ACC(5);
   }
   if (want_dx && xmu) {       // the waves' column sums meet in LDS: slot (row tile, column) has ONE owner
 #pragma unroll
@@ -918,9 +995,8 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       if (g == 0 && o < a.d_out) P[(int64_t)a.d_out * a.d_in + o] = s;
     }
   }
-  if (want_dx && a.dotx) {        // (the last round's barrier has published the sums)
-    double t = 0.0;
-    for (int i = threadIdx.x; i < 4 * 16 * NTI; i += 64 * TW) t += redd[i];
+  if (want_dx && a.dotx) {
+    double t = dots;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
     __shared__ double wsum[TW];
@@ -942,7 +1018,17 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       S[i] = (p[0] + p[16 * NTI]) + (p[2 * 16 * NTI] + p[3 * 16 * NTI]);
     }
   }
+  TP_ACC(6);
+#ifdef SN_PROFILE
+  if (TP_ON) {
+    const int o = a.dotx ? 10 : 0;
+    for (int i = 0; i < 8; ++i) g_tprof[o + i] = tpv[i];
+    g_tprof[o + 8] = r_hi - r_lo;
+    g_tprof[o + 9] = a.R;
+  }
+#endif
 }
+
 
 // Column sums for a BatchNorm backward whose upstream gradient comes from somewhere else than k_tlin_bwd (the last BatchNorm of a
 // stack: its output feeds an aggregation / a residual): sums[grp][blk][0][c] = sum g, [1][c] = sum g * (z - mu), g = dy * [ms*z + mt > 0].
@@ -1488,6 +1574,9 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 }  // namespace sn
+#ifdef SN_PROFILE
+extern "C" int sn_prof_read_train(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sn::g_tprof), sizeof(long long) * 64); }
+#endif
 
 using namespace sn;
 
@@ -1615,7 +1704,7 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
          p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk};
   auto lds_of = [](int rt, bool split = false) {
     return (size_t)(split ? 8 * 4 * 3 : 8 * 8) * 1024 + (size_t)16 * rt * (stage_ld(8) + stage_ld(8)) * sizeof(float) +
-           (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float) + (size_t)4 * 16 * 8 * sizeof(double);
+           (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float);
   };
   const bool full = p.d_in == 128 && p.d_out == 128;
   const int rt = tile_mode(p.R, p.G) ? bwd_small_rt() : 4;
