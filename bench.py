@@ -764,6 +764,9 @@ def main():
     ap.add_argument("--clock-ramp-ms", type=float, default=60.0,
                     help="forward bench: after the W warm-up steps keep issuing untimed forwards until this much wall time has passed since "
                          "the first one (the GPU reaches its sustained clock; 0 = off).  Reported as `clock_ramp` in the JSON line")
+    ap.add_argument("--sustained-ms", type=float, default=None,
+                    help="forward bench, one GPU: extra pass — the `value` loop kept running for this much wall time (`sustained` block; 0 = off; "
+                         "default 1500, or 0 with --no-cpu-baseline: the profiling / A-B command lines stay short)")
     ap.add_argument("--overlap-warmup", type=int, default=32,
                     help="forward bench: untimed forwards in the module's overlap mode before the K timed steps of the `overlap_mode` extra pass "
                          "(the caching allocator needs a pipeline depth of forwards before it stops asking the driver for memory)")
@@ -919,6 +922,27 @@ def main():
         sync_all()
         dt_strict = time.perf_counter() - t0
         model.strict = False
+        # extra pass (not `value`): the one-stream loop kept running for --sustained-ms of wall clock, in chunks of 200 forwards with one
+        # host wait each — the rate the part settles at (clocks, temperature) rather than that of a 25 ms window, and seconds of GPU
+        # activity for an outside utilisation sampler to see
+        sustained = None
+        if args.sustained_ms is None:
+            args.sustained_ms = 0.0 if args.no_cpu_baseline else 1500.0
+        if args.sustained_ms > 0 and world == 1:
+            chunk, rates, n_fw = 200, [], 0
+            sync_all()
+            t_s = time.perf_counter()
+            while (time.perf_counter() - t_s) * 1e3 < args.sustained_ms:
+                t_c = time.perf_counter()
+                for _ in range(chunk):
+                    model(data)
+                torch.cuda.synchronize()
+                rates.append(chunk * host.num_graphs / (time.perf_counter() - t_c))
+                n_fw += chunk
+            dt_s = time.perf_counter() - t_s
+            sustained = {"value": n_fw * host.num_graphs / dt_s, "unit": "graphs/s", "ms_per_step": 1e3 * dt_s / n_fw, "forwards": n_fw,
+                         "wall_ms": 1e3 * dt_s, "chunk_forwards": chunk, "chunk_min": min(rates), "chunk_max": max(rates),
+                         "note": "the `value` loop kept running for --sustained-ms (one host wait per 200 forwards); not `value`"}
         # extra pass (not `value`): the same K steps issued round-robin on S HIP streams, so that independent batches
         # overlap on the device the way a serving loop would run them (fills the tails of one step's kernels with the
         # next step's work).  Same barrier + synchronize bracket, max over ranks.
@@ -996,6 +1020,7 @@ def main():
                 "note": "extra pass, not `value`: model.overlap_front = True (opt-in): a forward = plan + phi on side stream A -> rho on side "
                         "stream B -> GINE on the caller's stream, chained by events; consecutive forwards of the one call site overlap; "
                         "bit-identical outputs (round 3's `value`)"},
+            "sustained": sustained,
             "strict_mode": {"value": total_graphs / dt_strict, "unit": "graphs/s", "ms_per_step": 1e3 * dt_strict / args.steps,
                             "note": "the module's default: flags waited for after every forward (one host round trip per step); extra pass, not `value`"},
             "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps,
