@@ -651,11 +651,27 @@ int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int ldx, const 
                      float* y /* [B, n_out] */,
                      const int32_t* flags_src, int n_flags, int32_t* flags_host /* optional report, see below */,
                      void* stream);
+
 /* Flag report without a separate copy: when flags_host (device-accessible pinned host memory) is not NULL, the last
  * workgroup to finish copies flags_src[0 .. n_flags) (device; typically sn_batch_plan's status words followed by
  * sn_plan_bins.meta) to it, after every workgroup's own flag updates, and then — behind a system-scope fence — stores 1 to
  * flags_host[n_flags] (so flags_host holds n_flags + 1 ints).  A caller that zeroed that word before the launch can poll
  * it from the host: once it reads 1 the flags are there; no event / marker packet on the stream is needed. */
+
+/* The DGL tree's GIN base net, eval mode, one launch on the same per-graph stage kernel (GraphPrediction/nets/ZINC_graph_regression/
+ * gin_net.py:83-126 with layers/gin_layer.py and layers/mlp.py:37-56, layers/mlp_readout_layer.py):
+ *   h = embedding_h[atom] + embedding_p(p);  L x  h = MLP((1 + eps) h_i + sum_{j -> i} h_j);  readout sum / mean;  MLPReadout.
+ * params (all widths zero-padded to d = 64, 96 or 128 by the caller; the same struct as sn_gnn_fused_f32):
+ *   node_discrete = 1, node_nf = 1, ntab[0] = embedding_h.weight [node_vocab, d]; edge_nf = 0; rho_out_w = NULL;
+ *   lin_a = split-packed identity, lin_b = split-packed embedding_p.weight ([d, d], columns >= kp zero) with e0 = its bias;
+ *   layers[l]: w1s = MLP.lins.0 with (e0, e1) = (1, bias), w2s = MLP.lins.1 with the MLP's eval BatchNorm (which follows the ReLU) folded
+ *              in and (e0, e1) = (1, bias'); eps = the layer's eps scalar; nothing follows the second Linear;
+ *   head_w1, head_mid: MLPReadout.FC_layers.0 / .1 with (e0, e1) = (1, bias); head_w2 = FC_layers.2 with e0 = bias; n_out = 1.
+ * atom: int64 [N]; p: [N, ldp] positional encoding, kp columns used; pool_mean: readout 'mean' (else 'sum').  Graphs of more than 64 nodes
+ * or 192 in-edges, or an atom type outside the table: NaN row + status[3] bits, as sn_gnn_fused_f32. */
+int sn_gin_net_fused_f32(const sn_gnn_params* params, const void* head_mid, int pool_mean, const int64_t* atom, const float* p, int ldp,
+                         int kp, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
+                         int32_t* status, float* y, const int32_t* flags_src, int n_flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training-step stage kernels (BASELINE configs[3]).  They replace, for one "Linear -> BatchNorm1d(train) -> ReLU"

@@ -58,6 +58,9 @@ struct GnnStruct {
   const int32_t* flags_src;   // the batch's flag block [status(8) | bins meta(8)]: read for upstream failures, optionally reported
   int n_flags;
   int32_t* flags_host;
+  int rho_ld, rho_w;      // row stride / width of rho_sum (the GINE net: both d; the DGL GIN net: the positional encoding [N, k])
+  const void* head_mid;   // DGL GIN net: the middle Linear of MLPReadout (split-packed, (e0, e1) = (1, bias))
+  int pool_mean;          // DGL GIN net: readout 'mean' instead of 'sum'
 };
 
 // the four channels 16*ot + 4g + t of `row` -> the three planes of a split image (exact 3-way split, fused_common.hpp)
@@ -240,7 +243,12 @@ __device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned 
   if (nn_wsp != nullptr && !nn_tr.empty()) wload<NKB>(cur, nn_wsp, nn_tr.first_ot(), lane);
 }
 
-template <int NT>
+// DGL = true: the GraphPrediction tree's GIN net on the same mapping (nets/ZINC_graph_regression/gin_net.py:83-126 in eval mode):
+//   h = embedding_h[atom] + embedding_p(p)          -> the input stage with lin_a = I, lin_b = embedding_p (bias in e0), "slot sum" = p
+//   L x  h = MLP((1 + eps) h_i + sum_{j -> i} h_j)  -> no edge term and no ReLU in the message; Linear . ReLU . [BN folded] . Linear,
+//                                                      nothing behind the second Linear (no BatchNorm, ReLU or residual)
+//   readout sum / mean, MLPReadout (three Linears)  -> one more head stage (S.head_mid)
+template <int NT, bool DGL = false>
 __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_params& P) {
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
@@ -305,7 +313,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   // per-edge embeddings are staged (use_ee), or gathered directly.
   bool use_tab = false;   // decided after the classes are known
   int ncls = 0;
-  bool use_ee = P.n_layers > 0 && ne <= S.ee_rows;
+  bool use_ee = !DGL && P.n_layers > 0 && ne <= S.ee_rows;
   // embedding of edge k, channels [c, c+4) for layer Lq: DiscreteEncoder sum (elements.py:31-37) or MLP(F_e, d, 1)
   auto edge_embed = [&](const sn_gnn_layer& Lq, int k, int c) -> f32x4 {
     const int EF = P.edge_nf;
@@ -373,7 +381,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   const int rp_v = tid <= n ? S.rowptr[gs + tid] : 0;
   const int src_v = tid < ne ? S.col[e_base + tid] : 0;
   const int eid_v = tid < ne ? S.eperm[e_base + tid] : 0;
-  const bool rs_vec = (d & 3) == 0;
+  const int rho_ld = S.rho_ld, rho_w = S.rho_w;
+  const bool rs_vec = ((rho_ld | rho_w) & 3) == 0;
   f32x4 rs_v[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -381,7 +390,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     const int i = tid + j * GNN_WAVES * 64;
     if (rs_vec && i < n * (D / 4)) {
       const int rr = i / (D / 4), c4 = i % (D / 4);
-      if (4 * c4 < d) rs_v[j] = ld4(S.rho_sum + (int64_t)(gs + rr) * d + 4 * c4);
+      if (4 * c4 < rho_w) rs_v[j] = ld4(S.rho_sum + (int64_t)(gs + rr) * rho_ld + 4 * c4);
     }
   }
   if (!tr.empty()) {
@@ -400,7 +409,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       const int k = tid;
       esrc[k] = src_v - gs;
       const int eid = eid_v;
-      if (P.n_layers > 0) {
+      if (!DGL && P.n_layers > 0) {
         if (P.edge_discrete) {
           const int64_t* ei = reinterpret_cast<const int64_t*>(S.edge_attr) + (int64_t)eid * S.lde;
           for (int f = 0; f < EF; ++f) {
@@ -419,7 +428,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   int graph_bad = __syncthreads_or(id_bad);          // images cleared, efeat complete (+ did anyone see a bad edge feature id)
   id_bad = false;
   // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
-  if (P.n_layers > 0) {
+  if (!DGL && P.n_layers > 0) {
     const int EF = P.edge_nf;
     // lead = first edge with my feature tuple.  Every thread walks ALL the edges with block-uniform (broadcast) LDS reads and no
     // early exit: the reads pipeline, where a scan that stops at the first match serialises one LDS round trip per candidate and
@@ -487,7 +496,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       const int rr = i / (D / 4), c4 = i % (D / 4);
       f32x4 v = zero4;
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) if (4 * c4 + qq < d) v[qq] = S.rho_sum[(int64_t)(gs + rr) * d + 4 * c4 + qq];
+      for (int qq = 0; qq < 4; ++qq) if (4 * c4 + qq < rho_w) v[qq] = S.rho_sum[(int64_t)(gs + rr) * rho_ld + 4 * c4 + qq];
       sp_store4(SA, rr, c4 >> 2, c4 & 3, v);
     }
   }
@@ -569,7 +578,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     a_sr[i] = 0u;
     a_er[i] = 0u;
     const int t = tr.t_lo + i;
-    if (t < tr.t_hi && (use_tab || use_ee)) {
+    if (t < tr.t_hi && (DGL || use_tab || use_ee)) {
       int ot, rt;
       tr.decode(t, ot, rt);
       const int row = rt * 16 + li;
@@ -580,7 +589,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         for (int k = 0; k < 4; ++k) {
           const int ei = k < dg ? e_lo + k : 0;
           a_sr[i] |= (unsigned)(k < dg ? esrc[ei] : row) << (8 * k);
-          a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 0) << (8 * k);
+          if (!DGL) a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 0) << (8 * k);
         }
       }
     }
@@ -594,7 +603,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     ee_fetch(l + 1);   // next layer's edge embeddings: in flight during this aggregation
     {
       const float sc = 1.f + *Lp.eps;
-      if (use_tab || use_ee) {
+      if (DGL || use_tab || use_ee) {
         // my (up to four) pairs, one after the other; the in-edge indices of their rows were read once before the layer loop (a_*)
         const int eoff = use_tab ? l * ncls : 0;
 #pragma unroll
@@ -611,14 +620,15 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
             for (int k = 0; k < 4; ++k) {
               const int sr = (int)((a_sr[i] >> (8 * k)) & 255u), er = (int)((a_er[i] >> (8 * k)) & 255u);
               hv[k] = lds_ld4(X1 + sr * LD + c);
-              ev[k] = lds_ld4(EE + (er + (k < dg ? eoff : 0)) * LD + c);
+              if (!DGL) ev[k] = lds_ld4(EE + (er + (k < dg ? eoff : 0)) * LD + c);
             }
             f32x4 u = zero4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) u += k < dg ? relu4(hv[k] + ev[k]) : zero4;
+            for (int k = 0; k < 4; ++k) u += k < dg ? (DGL ? hv[k] : relu4(hv[k] + ev[k])) : zero4;
             if (dg > 4) {
               const int e_lo = erow[row], e_hi = e_lo + dg;
               for (int e = e_lo + 4; e < e_hi; ++e) {
+                if (DGL) { u += lds_ld4(X1 + esrc[e] * LD + c); continue; }
                 const f32x4 ef = use_tab ? lds_ld4(EE + (l * ncls + ecls[e]) * LD + c) : lds_ld4(EE + e * LD + c);
                 u += relu4(lds_ld4(X1 + esrc[e] * LD + c) + ef);
               }
@@ -670,9 +680,11 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     // Linear ; BN . ReLU ; + previous_x : SB -> X1 (my tiles only: nobody else reads them at this point)
     auto epi_2 = [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) {
       float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
-      lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
+      if (DGL) lds_st4(o, acc * sc + sh);           // the MLP's last Linear: nothing behind it
+      else lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
     };
-    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, tr, lane, epi_2, lastl ? P.head_w2 : P.layers[lastl ? l : l + 1].w2s, lastl ? h2 : tr);
+    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, tr, lane, epi_2, lastl ? (DGL ? S.head_mid : P.head_w2) : P.layers[lastl ? l : l + 1].w2s,
+                                            lastl ? (DGL ? hr : h2) : tr);
     else coop_gemm<NKB>(pre, alt, Lp.w2s, SB, tr, lane, epi_2, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
     lds_barrier();
     SN_ACCUM(12, pt);
@@ -683,8 +695,10 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   for (int i = threadIdx.x; i < 16 * (D / 4); i += GNN_WAVES * 64) {
     const int rr = i / (D / 4), c4 = i % (D / 4);
     f32x4 s = zero4;
-    if (rr == 0)
+    if (rr == 0) {
       for (int j = 0; j < n; ++j) s += lds_ld4(X1 + j * LD + 4 * c4);
+      if (DGL && S.pool_mean) s = s / (float)n;
+    }
     sp_store4(SA, rr, c4 >> 2, c4 & 3, s);
   }
   lds_barrier();
@@ -700,11 +714,24 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   };
+  if constexpr (DGL) {
+    // MLPReadout (layers/mlp_readout_layer.py): Linear . ReLU . Linear . ReLU . Linear — SA -> SB -> SA -> y
+    auto epi_hm = [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) { sp_store4(SA, li, ot, g, relu4(acc * sc + sh)); };
+    if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, hr, lane, epi_h1, wave == 0 ? P.head_w2 : nullptr, h2);
+    else coop_gemm<NKB>(pre, alt, P.head_w1, SA, hr, lane, epi_h1, S.head_mid, hr);
+    lds_barrier();
+    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, hr, lane, epi_hm, nullptr, h2);
+    else coop_gemm<NKB>(pre, alt, S.head_mid, SB, hr, lane, epi_hm, wave == 0 ? P.head_w2 : nullptr, h2);
+    lds_barrier();
+    if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, h2, lane, epi_h2, nullptr, h2);
+    else coop_gemm<NKB>(pre, alt, P.head_w2, SA, h2, lane, epi_h2, nullptr, h2);
+  } else {
   if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, hr, lane, epi_h1, nullptr, h2);
   else coop_gemm<NKB>(pre, alt, P.head_w1, SA, hr, lane, epi_h1, wave == 0 ? P.head_w2 : nullptr, h2);
   lds_barrier();
   if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, h2, lane, epi_h2, nullptr, h2);
   else coop_gemm<NKB>(pre, alt, P.head_w2, SB, h2, lane, epi_h2, nullptr, h2);
+  }
   SN_STAMP(5);
 #ifdef SN_PROFILE
   if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) { g_prof[6] = n; g_prof[7] = ne; }
@@ -712,9 +739,9 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
 }
 
 // One workgroup per graph; the last workgroup to finish reports the batch's flags to the host (no separate copy).
-template <int NT>
+template <int NT, bool DGL = false>
 __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_gnn_params P) {
-  gnn_graph<NT>(S, P);
+  gnn_graph<NT, DGL>(S, P);
   if (S.flags_host != nullptr) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -731,7 +758,7 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   }
 }
 
-template <int NT>
+template <int NT, bool DGL = false>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   const size_t base = (size_t)2 * SP_IMAGE + (size_t)(GNN_ROWS * LD) * sizeof(float) +
@@ -741,18 +768,18 @@ static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hip
   int ee_rows = (int)(room / ((size_t)LD * sizeof(float)));
   if (ee_rows > GNN_EEMAX) ee_rows = GNN_EEMAX;
   GnnStruct S2 = S;
-  S2.ee_rows = P.n_layers > 0 ? ee_rows : 0;
+  S2.ee_rows = (!DGL && P.n_layers > 0) ? ee_rows : 0;
   const size_t lds = base + (size_t)S2.ee_rows * LD * sizeof(float);
   static bool init = false;
   if (!init) {
     const size_t lds_max = lds_cap;
     if (lds_max > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gnn_coop<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gnn_coop<NT, DGL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_max) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_gnn_fused_f32: cannot raise the dynamic LDS limit to %zu", lds_max);
     init = true;
   }
-  hipLaunchKernelGGL((k_gnn_coop<NT>), dim3((unsigned)B), dim3(GNN_WAVES * 64), lds, st, S2, P);
+  hipLaunchKernelGGL((k_gnn_coop<NT, DGL>), dim3((unsigned)B), dim3(GNN_WAVES * 64), lds, st, S2, P);
   return SN_OK;
 }
 
@@ -793,7 +820,8 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
   SN_REQUIRE(!flags_src || n_flags >= 1, "sn_gnn_fused_f32: flags_src needs n_flags >= 1");
   SN_REQUIRE((!P.node_discrete || P.node_vocab > 0) && (P.n_layers == 0 || !P.edge_discrete || P.edge_vocab > 0),
              "sn_gnn_fused_f32: node_vocab / edge_vocab (rows of the embedding tables) missing");
-  GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y, 0, flags_src, n_flags, flags_host};
+  GnnStruct S{x, ldx, edge_attr, lde, rho_sum, graph_ptr, rowptr, col, eperm, status, y, 0, flags_src, n_flags, flags_host,
+              P.d, P.d, nullptr, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   switch ((P.d + 15) / 16) {
@@ -808,5 +836,37 @@ extern "C" int sn_gnn_fused_f32(const sn_gnn_params* params, const void* x, int 
   }
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_gnn_fused_f32");
+  return SN_OK;
+}
+
+// The DGL tree's GIN net (gin_net.py:83-126, eval mode) on the same per-graph stage kernel: see gnn_graph<NT, DGL = true>.
+extern "C" int sn_gin_net_fused_f32(const sn_gnn_params* params, const void* head_mid, int pool_mean, const int64_t* atom, const float* p,
+                                    int ldp, int kp, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr, const int32_t* col,
+                                    const int32_t* eperm, int32_t* status, float* y, const int32_t* flags_src, int n_flags, void* stream) {
+  SN_REQUIRE(params && head_mid && atom && p && graph_ptr && rowptr && col && eperm && status && y && B >= 0, "sn_gin_net_fused_f32: null pointer");
+  const sn_gnn_params& P = *params;
+  SN_REQUIRE(P.d > 0 && P.d <= 128 && (P.d & 3) == 0, "sn_gin_net_fused_f32: padded hidden width %d must be a multiple of 4 in (0, 128]", P.d);
+  SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_GNN_MAX_LAYERS, "sn_gin_net_fused_f32: %d layers unsupported", P.n_layers);
+  SN_REQUIRE(P.n_out >= 1 && P.n_out <= 16, "sn_gin_net_fused_f32: n_out=%d not in [1,16]", P.n_out);
+  SN_REQUIRE(P.node_discrete == 1 && P.node_nf == 1 && P.ntab[0] && P.node_vocab > 0, "sn_gin_net_fused_f32: one atom-type table expected");
+  SN_REQUIRE(P.edge_nf == 0, "sn_gin_net_fused_f32: the GIN net has no edge term (edge_nf must be 0)");
+  SN_REQUIRE(P.lin_a && P.lin_b && P.head_w1 && P.head_w2 && P.rho_out_w == nullptr, "sn_gin_net_fused_f32: parameters missing");
+  SN_REQUIRE(kp >= 1 && kp <= P.d && ldp >= kp, "sn_gin_net_fused_f32: positional encoding width %d unsupported", kp);
+  for (int l = 0; l < P.n_layers; ++l) {
+    const sn_gnn_layer& L = P.layers[l];
+    SN_REQUIRE(L.w1s && L.w2s && L.eps, "sn_gin_net_fused_f32: layer %d parameters missing", l);
+  }
+  SN_REQUIRE(!flags_src || n_flags >= 1, "sn_gin_net_fused_f32: flags_src needs n_flags >= 1");
+  if (B == 0) return SN_OK;
+  GnnStruct S{atom, 1, nullptr, 0, p, graph_ptr, rowptr, col, eperm, status, y, 0, flags_src, n_flags, nullptr, ldp, kp, head_mid, pool_mean};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = SN_OK;
+  switch ((P.d + 15) / 16) {          // (the widths the shipped nets pad to; others round up to the next one at pack time)
+    case 1: case 2: case 3: case 4: rc = launch_gnn<4, true>(S, P, B, st); break;
+    case 5: case 6: rc = launch_gnn<6, true>(S, P, B, st); break;
+    default: rc = launch_gnn<8, true>(S, P, B, st); break;
+  }
+  if (rc != SN_OK) return rc;
+  SN_CHECK_LAUNCH("sn_gin_net_fused_f32");
   return SN_OK;
 }

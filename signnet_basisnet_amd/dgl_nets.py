@@ -91,7 +91,104 @@ class _PackCache:
         return c[id(mlp)]
 
 
+class _FusedGin:
+    """Packed eval-mode parameters of a GINNet for sn_gin_net_fused_f32: embedding_h + embedding_p, every GIN layer, the readout and
+    MLPReadout in ONE launch — one workgroup per graph on the stage kernel of the PyG tree's GINE net (csrc/fused_gnn.hip, DGL mode).
+    `ok` False: shapes the kernel does not take (width > 128, more than 16 layers, MLPs that are not the reference's
+    Linear-ReLU-BN-Linear, a readout other than the 3-Linear MLPReadout to one score) — the layer path serves those."""
+
+    def __init__(self, net):
+        from .fused import _GnnParams, GNN_MAX_LAYERS
+        from .dgl_deepsigns import _fold_bn_before, _pad_mat
+        self.ok = False
+        convs, fcs = list(net.layers), list(net.MLP_layer.FC_layers)
+        hid, kp = net.embedding_h.weight.shape[1], net.embedding_p.weight.shape[1]
+        widths = [hid] + [w for c in convs for w in (c.apply_func.lins[0].weight.shape[0], c.apply_func.lins[-1].weight.shape[0])] + \
+                 [fc.weight.shape[0] for fc in fcs[:-1]]
+        dmax = max(widths + [kp])
+        if dmax > 128 or len(convs) > GNN_MAX_LAYERS or len(convs) < 1 or len(fcs) != 3 or fcs[2].weight.shape[0] != 1:
+            return
+        if any(len(c.apply_func.lins) != 2 for c in convs):
+            return
+        dp = 64 if dmax <= 64 else (96 if dmax <= 96 else 128)
+        dev = net.embedding_h.weight.device
+        keep = self._keep = []
+
+        def hold(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        ones = torch.ones(dp, dtype=torch.float32, device=dev)
+        P = _GnnParams()
+        P.d, P.n_layers, P.n_out = dp, len(convs), 1
+        P.node_discrete, P.node_nf, P.edge_discrete, P.edge_nf = 1, 1, 0, 0
+        P.node_vocab, P.edge_vocab = net.embedding_h.weight.shape[0], 0
+        E = torch.zeros(net.embedding_h.weight.shape[0], dp, dtype=torch.float32, device=dev)
+        E[:, :hid].copy_(net.embedding_h.weight.detach())
+        P.ntab[0] = hold(E)
+        P.rho_out_w = None
+        P.lin_a = hold(ops.pack_split(torch.eye(dp, dtype=torch.float32, device=dev)))
+        P.lin_b = hold(ops.pack_split(_pad_mat(net.embedding_p.weight, dp), ops.pad_vec(net.embedding_p.bias, dp)))
+        for l, conv in enumerate(convs):
+            m = conv.apply_func
+            site = net._bn(m.bns[0], False) if m.use_bn else None        # the BatchNorm between the ReLU and the second Linear: folded
+            W2, b2 = _fold_bn_before(m.lins[1], site)
+            Lp = P.layers[l]
+            Lp.w1s = hold(ops.pack_split(_pad_mat(m.lins[0].weight, dp), ones, ops.pad_vec(m.lins[0].bias, dp)))
+            Lp.w2s = hold(ops.pack_split(_pad_mat(W2, dp), ones, ops.pad_vec(b2, dp)))
+            Lp.eps = hold(conv.eps.detach().float().reshape(1).contiguous())
+        P.head_w1 = hold(ops.pack_split(_pad_mat(fcs[0].weight, dp), ones, ops.pad_vec(fcs[0].bias, dp)))
+        self.head_mid = hold(ops.pack_split(_pad_mat(fcs[1].weight, dp), ones, ops.pad_vec(fcs[1].bias, dp)))
+        P.head_w2 = hold(ops.pack_split(_pad_mat(fcs[2].weight, dp), ops.pad_vec(fcs[2].bias, dp)))
+        self.params, self.kp, self.pool_mean = P, kp, 0 if net.readout == "sum" else 1
+        self.ok = True
+
+    def run(self, plan, hidx, p):
+        """atom types [N] int64, positional encoding [N, k] -> scores [B, 1]"""
+        y = torch.empty(plan.B, 1, dtype=torch.float32, device=p.device)
+        with ops._span("sn_gin_net_fused_f32"):
+            check(lib().sn_gin_net_fused_f32(C.byref(self.params), self.head_mid, self.pool_mean, ptr(hidx), ptr(p), p.shape[1], self.kp,
+                                             ptr(plan.graph_ptr), plan.B, ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm),
+                                             ptr(plan.status), ptr(y), ptr(plan.status), 8, stream()), "sn_gin_net_fused_f32")
+        return y
+
+
 class GINNet(_PackCache, nn.Module):
+    fused_stages = True      # eval: embeddings, every layer and the readout in ONE launch (sn_gin_net_fused_f32); False: the layer path
+
+    def _fused_gin(self, g):
+        """The packed stage-kernel parameters if this batch can take the one-launch path, else None (as GatedGCNNet._fused_gated: graph
+        sizes come with the batch object; a batch beyond the kernel's limits that still reaches it gets NaN scores + check_last())."""
+        if self.training or not self.fused_stages or self.pe_init != "lap_pe":
+            return None
+        c = self.__dict__.setdefault("_cache", {})
+        if "fused_gin" not in c:
+            c["fused_gin"] = _FusedGin(self)
+        fz = c["fused_gin"]
+        if not fz.ok:
+            return None
+        me = _max_in_edges(g)
+        return fz if 0 < _max_nodes(g) <= 64 and (me is None or me <= 192) else None
+
+    def check_last(self):
+        """Raise what the last one-launch eval forward flagged on the device (its scores are NaN in that case): an atom type outside
+        the embedding table (IndexError, as nn.Embedding), a malformed batch, or a graph the stage kernel could not hold.  One host
+        sync; also run by train().  The layer path (fused_stages = False, train mode) raises immediately instead."""
+        plan, self._last_plan = getattr(self, "_last_plan", None), None
+        if plan is not None:
+            st = plan.status.tolist()
+            if st[0]:
+                raise ValueError(f"GINNet: the last batch is malformed (sn_batch_plan status {st[0]})")
+            if st[3] & 4:
+                raise IndexError(ops.EMBEDDING_INDEX_ERROR)
+            if st[3] & 3:
+                raise RuntimeError("GINNet: a graph of the last batch has more than 64 nodes or 192 in-edges; its score is NaN — set "
+                                   "fused_stages = False for such batches")
+
+    def train(self, mode=True):
+        self.check_last()
+        return super().train(mode)
+
     def __init__(self, net_params):
         super().__init__()
         p = net_params
@@ -208,6 +305,13 @@ class GINNet(_PackCache, nn.Module):
             y = self._forward_grad(plan, batch, ei, B, hidx, p)
         else:
             with torch.no_grad():
+                fz = self._fused_gin(g)
+                if fz is not None:
+                    # no host sync on this path: a bad atom type / an oversize graph is flagged in the plan's status block, the score is
+                    # NaN, check_last() raises
+                    self._last_plan = plan
+                    self.g = g
+                    return fz.run(plan, hidx.contiguous(), p), g
                 if not train and self.embedding_h.weight.shape[1] % 4:
                     # eval, hidden width not a multiple of 4 (GIN_ZINC_LapPE_signinv_GIN.json: 95): every row would be misaligned and every
                     # Linear on the scalar kernel; run on zero-padded channels instead (`_gin_padded`: 95 -> 96, all rows 16-byte aligned)

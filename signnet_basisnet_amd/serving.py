@@ -56,6 +56,9 @@ class GraphedDGLForward:
         with ops.defer_status() as words:
             self._graphed = GraphedForward(fwd, warmup=warmup)
         self._status_words = list(words)[-max(1, len(words) // (warmup + 1)):] if words else []      # those of the recorded run
+        # (a net whose one-launch kernel reports through check_last() remembers the plan of its last forward and forgets it once
+        #  checked: the recorded plan's status block is rewritten by every replay, so check() re-arms it)
+        self._last_plan = getattr(net, "_last_plan", None)
         self.out = self._graphed.out
 
     def check(self):
@@ -64,6 +67,8 @@ class GraphedDGLForward:
         from . import ops
         ops.raise_deferred(self._status_words)
         if hasattr(self.net, "check_last"):
+            if self._last_plan is not None:
+                self.net._last_plan = self._last_plan
             self.net.check_last()
 
     def __call__(self, g=None, h=None, pos_enc=None, e=None, snorm_n=None):

@@ -119,3 +119,39 @@ def test_transformer_net_fused_eval_layers_equal_the_op_by_op_path():
     assert torch.equal(y_fused, y_ops)
     assert n_fused <= n_ops - 2 * params["L"], (n_fused, n_ops)      # (the timer sees the launches that go through ops._span: not the
                                                                       #  four pointwise passes per layer the fused epilogues also replace)
+
+
+@pytest.mark.parametrize("hidden,readout", [(95, "mean"), (64, "sum"), (128, "mean"), (40, "sum")])
+def test_gin_net_one_launch_eval_equals_the_layer_path(hidden, readout):
+    """GINNet eval (round 4): embeddings, the L GIN layers, the readout and MLPReadout in ONE launch (sn_gin_net_fused_f32: a workgroup
+    per graph on the PyG tree's GINE stage kernel) against the layer path (fused_stages = False) — widths that pad to 64 / 96 / 128,
+    both readouts; the same values up to the rounding of different GEMM orders."""
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, ops, synth
+    import parity_util as PU
+    cls, params = dgl_configs.net_params("gin", DEV)
+    params.update(hidden_dim=hidden, out_dim=hidden, readout=readout, L=5)
+    torch.manual_seed(4)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, 5)
+    net = net.to(DEV).eval()
+    a = synth.make_batch(40, seed=21)
+    g, h, pe, e, _ = _inputs(a, params["pos_enc_dim"])
+    with torch.no_grad():
+        p = net.sign_inv_net(g, pe).squeeze(-1)
+        rec = ops.KernelTimer()
+        with rec:
+            y_one = net(g, h, p, e, None)[0].clone()
+        assert "sn_gin_net_fused_f32" in rec.summary(), rec.summary().keys()
+        net.check_last()
+        net.fused_stages = False
+        y_lay = net(g, h, p, e, None)[0].clone()
+        net.fused_stages = True
+        assert torch.isfinite(y_one).all()
+        scale = y_lay.abs().max().clamp_min(1e-6)
+        assert ((y_one - y_lay).abs().max() / scale).item() < 2e-5, ((y_one - y_lay).abs().max() / scale).item()
+        bad = h.clone()
+        bad[3] = 1000                       # an atom type outside the table: NaN score for that graph, IndexError from check_last()
+        y_bad = net(g, bad, p, e, None)[0]
+        with pytest.raises(IndexError):
+            net.check_last()
+        assert torch.isnan(y_bad).any()
