@@ -151,6 +151,7 @@ int sn_gine_aggregate_f32(const float* x, const float* ea, float* out, int64_t N
 #define SN_EPI_BLOCK_BIAS 32 /* + block_bias[row / rows_per_block][:] together with the bias (sn_masked_linear_blockbias_f32 sets it) */
 #define SN_EPI_RESIDUAL_PRE 64 /* the residual is added right behind the bias, BEFORE relu_pre / the affine / relu: BatchNorm(x + Linear(h)) of the
                                 * DGL Transformer layer (layers/transformer.py:283-290) as ONE launch; excludes SN_EPI_RESIDUAL */
+#define SN_EPI_LEAKY 128       /* LeakyReLU(0.01) (nn.LeakyReLU's default slope: PNA's mixing FCLayer, pna_utils.py) after the affine, in RELU's place */
 int sn_masked_linear_f32(const float* x, int ldx, int64_t R, int d_in, const float* Wp, int d_out,
                          const float* bias, const int32_t* nvalid, int K, int flags,
                          const float* scale, const float* shift, const float* residual, int ldr,

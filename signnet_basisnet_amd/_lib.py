@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsignnet_hip.so")
 
 EPI_BIAS, EPI_RELU_PRE, EPI_AFFINE, EPI_RELU, EPI_RESIDUAL = 1, 2, 4, 8, 16
 EPI_RESIDUAL_PRE = 64
+EPI_LEAKY = 128
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

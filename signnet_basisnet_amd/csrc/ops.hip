@@ -217,6 +217,10 @@ __global__ __launch_bounds__(256) void k_linear(LinArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
       }
+      if (a.flags & SN_EPI_LEAKY) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * 0.01f;
+      }
       if (a.flags & SN_EPI_RESIDUAL) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
     }
     if (inr) store4<YV>(yr, o0, a.d_out, v);
@@ -284,6 +288,10 @@ __global__ __launch_bounds__(256) void k_linear_ksplit(LinArgs a) {
       if (a.flags & SN_EPI_RELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (a.flags & SN_EPI_LEAKY) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * 0.01f;
       }
       if (a.flags & SN_EPI_RESIDUAL) v += load4<YV>(a.res + row * a.ldr, o0, a.d_out);
     }
@@ -393,6 +401,10 @@ __global__ __launch_bounds__(64 * LIN_W, 1) void k_linear_lds(LinArgs a, int64_t
           for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
         }
         if (a.flags & SN_EPI_RELU) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+        if (a.flags & SN_EPI_LEAKY) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * 0.01f;
+        }
         if (a.flags & SN_EPI_RESIDUAL) v += load4<true>(a.res + row * a.ldr, o0, a.d_out);
       }
       if (inr) store4<true>(yr, o0, a.d_out, v);
@@ -1296,6 +1308,7 @@ static int masked_linear_impl(const float* x, int ldx, int64_t R, int d_in, cons
   SN_REQUIRE(x && Wp && y && R >= 0 && d_in > 0 && d_out > 0, "sn_masked_linear_f32: bad arguments");
   SN_REQUIRE(!(flags & SN_EPI_BLOCK_BIAS) || (bbias && bb_rows > 0 && ldbb >= d_out), "sn_masked_linear_blockbias_f32: block bias missing");
   SN_REQUIRE(ldx >= d_in && ldy >= d_out, "sn_masked_linear_f32: leading dimension too small");
+  SN_REQUIRE((flags & (SN_EPI_RELU | SN_EPI_LEAKY)) != (SN_EPI_RELU | SN_EPI_LEAKY), "sn_masked_linear_f32: RELU and LEAKY are exclusive");
   SN_REQUIRE(!(flags & SN_EPI_BIAS) || bias, "sn_masked_linear_f32: BIAS without bias");
   SN_REQUIRE(!(flags & SN_EPI_AFFINE) || (scale && shift), "sn_masked_linear_f32: AFFINE without scale/shift");
   SN_REQUIRE(!(flags & (SN_EPI_RESIDUAL | SN_EPI_RESIDUAL_PRE)) || (residual && ldr >= d_out), "sn_masked_linear_f32: RESIDUAL without residual");

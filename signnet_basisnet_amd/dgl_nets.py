@@ -719,6 +719,9 @@ class PNANet(_PackCache, nn.Module):
     gather is folded into the aggregation, on activations padded to 16-byte rows (sn_pna_aggregate_gather_f32, `_forward_eval_padded`).  Eval, train-mode value (batch-statistic BatchNorm, running statistics
     updated) and — with gradients enabled — the differentiable path (`_forward_grad`)."""
 
+    fused_layers = True      # eval, padded layout: one edge-term Linear for all layers, LeakyReLU + residual as the mixing Linear's epilogue
+
+
     def __init__(self, net_params):
         super().__init__()
         p = net_params
@@ -868,11 +871,16 @@ class PNANet(_PackCache, nn.Module):
             Wm, bm = z(Cout_p, Cout_p), z(Cout_p)
             Wm[pout[:, None], pout[None, :]] = ml.weight.detach().float()
             bm[pout] = ml.bias.detach().float()
-            layers.append({"sd": mk(Wsd, None), "e": mk(We, be), "post_w": Wpo.contiguous(), "post_b": bpo, "nt": nt, "it_p": it_p,
+            layers.append({"sd": mk(Wsd, None), "e": mk(We, be), "e_raw": (We, be), "post_w": Wpo.contiguous(), "post_b": bpo, "nt": nt, "it_p": it_p,
                            "grouped": ot_p <= 16 and 13 * it_p <= 256, "scale": sc, "shift": sh, "mix": mk(Wm, bm),
                            "residual": L.residual, "pos_out": pout, "C_out": Cout_p})
         P["layers"] = layers
         P["ok"] = all(F["grouped"] for F in layers)       # (wider towers: the per-tower layer path below serves the net)
+        # the edge features do not change from layer to layer (pna_layer.py updates h only): every layer's edge term W_e e + b as ONE
+        # [E, L*C] Linear in front of the layer loop, read in place by the aggregation (column block l, row stride L*C)
+        P["e_all"] = None
+        if len({tuple(F["e_raw"][0].shape) for F in layers}) == 1:
+            P["e_all"] = mk(torch.cat([F["e_raw"][0] for F in layers], 0), torch.cat([F["e_raw"][1] for F in layers], 0))
         fc0 = self.MLP_layer.FC_layers[0]
         W0 = z(fc0.weight.shape[0], layers[-1]["C_out"])
         W0[:, layers[-1]["pos_out"]] = fc0.weight.detach().float()
@@ -888,14 +896,22 @@ class PNANet(_PackCache, nn.Module):
         x = ops.embedding_sum(h.long().reshape(N), [P["emb_h"]])
         x = ops.masked_linear(p.contiguous().float(), P["emb_p"], residual=x)                                    # h + embedding_p(p)  (:124-126)
         ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight])
-        for F in P["layers"]:
+        fuse = self.fused_layers
+        qe_all = ops.masked_linear(ef, P["e_all"]) if (fuse and P["e_all"] is not None) else None                # [E, L*C]
+        for li, F in enumerate(P["layers"]):
             psd = ops.masked_linear(x, F["sd"])                                                                  # [N, 2C] = [W_s h | W_d h]
-            qe = ops.masked_linear(ef, F["e"])                                                                   # [E, C]  = W_e e + b
-            a = ops.pna_aggregate_gather(psd, qe, x, plan, avg_log, tower_width=F["it_p"])                       # (:50-56, :69), tower-major
+            if qe_all is not None:
+                a = ops.pna_aggregate_gather(psd, qe_all, x, plan, avg_log, tower_width=F["it_p"], qe_layer=li)
+            else:
+                qe = ops.masked_linear(ef, F["e"])                                                               # [E, C]  = W_e e + b
+                a = ops.pna_aggregate_gather(psd, qe, x, plan, avg_log, tower_width=F["it_p"])                   # (:50-56, :69), tower-major
             hc = ops.grouped_linear(a, F["post_w"], F["post_b"], F["nt"], rowscale=sn, scale=F["scale"], shift=F["shift"])   # posttrans,
             #                                                                                            * snorm_n, BatchNorm (:69-79)
-            mix = ops.masked_linear(hc, F["mix"])
-            x = ops.pointwise(mix, act="leaky", slope=0.01, residual=x if F["residual"] else None)               # FCLayer LeakyReLU + residual
+            if fuse:      # FCLayer's LeakyReLU and the residual as the mixing Linear's epilogue
+                x = ops.masked_linear(hc, F["mix"], leaky=True, residual=x if F["residual"] else None)
+            else:
+                mix = ops.masked_linear(hc, F["mix"])
+                x = ops.pointwise(mix, act="leaky", slope=0.01, residual=x if F["residual"] else None)           # FCLayer LeakyReLU + residual
         self._h_last = x.index_select(1, P["layers"][-1]["pos_out"])
         hg = ops.segment_pool(x, plan, "mean" if self.readout != "sum" else "add")
         fcs = self.MLP_layer.FC_layers

@@ -11,7 +11,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, EPI_RESIDUAL_PRE, check, lib, ptr,
+from ._lib import (EPI_AFFINE, EPI_BIAS, EPI_LEAKY, EPI_RELU, EPI_RELU_PRE, EPI_RESIDUAL, EPI_RESIDUAL_PRE, check, lib, ptr,
                    require_cuda, stream)
 
 __all__ = ["KernelTimer", "KERNEL_ROOFLINE", "GraphPlan", "PlanBins", "build_plan", "pack_eig", "pack_weight", "gin_aggregate", "gine_aggregate",
@@ -350,7 +350,7 @@ def gated_aggregate(Ah, Bh, Dh, Eh, Ce, plan: GraphPlan, want_den=False, epilogu
 
 
 def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=None, relu_pre=False, relu=False,
-                  residual=None, use_bias=True, out=None, residual_pre=False):
+                  residual=None, use_bias=True, out=None, residual_pre=False, leaky=False):
     """y = epilogue(x @ W^T); x is a row matrix [..., d_in] (leading dims flattened to rows).
     residual_pre: the residual is added right behind the bias, in front of relu_pre / the affine / relu (BatchNorm(x + Linear(h)))."""
     require_cuda(x)
@@ -368,6 +368,8 @@ def masked_linear(x, pl: PackedLinear, nvalid=None, K=0, *, scale=None, shift=No
         flags |= EPI_AFFINE
     if relu:
         flags |= EPI_RELU
+    if leaky:                   # LeakyReLU(0.01) in RELU's place (then + residual)
+        flags |= EPI_LEAKY
     if residual is not None:
         flags |= EPI_RESIDUAL_PRE if residual_pre else EPI_RESIDUAL
         residual = _f32c(residual, "residual")
@@ -698,18 +700,23 @@ def grouped_linear(x, W, bias, G, *, rowscale=None, scale=None, shift=None):
     return y
 
 
-def pna_aggregate_gather(psd, qe, hself, plan: GraphPlan, avg_log: float, tower_width: int = 0):
+def pna_aggregate_gather(psd, qe, hself, plan: GraphPlan, avg_log: float, tower_width: int = 0, qe_layer=None):
     """PNA aggregation with the pretrans message formed in the kernel: psd [N, 2C] = [W_s h | W_d h] per node, qe [E, C] = W_e e + b,
     message (j -> n, e) = psd[j, :C] + psd[n, C:] + qe[e]; -> [N, 13*C] = cat[hself, scalers(aggregators(.))] (all towers side by side;
     tower_width = it > 0: tower-major columns [tower][13 blocks][it], the input layout of grouped_linear)."""
     require_cuda(psd)
     psd, qe, hself = _f32c(psd, "psd"), _f32c(qe, "qe"), _f32c(hself, "hself")
-    Cc = qe.shape[1]
+    Cc, ldq, qoff = qe.shape[1], qe.shape[1], 0
+    if qe_layer is not None:    # qe is [E, L*C], every layer's edge term side by side: this layer's column block is read in place
+        Cc = hself.shape[1]
+        if qe.shape[1] % Cc or not 0 <= qe_layer < qe.shape[1] // Cc:
+            raise ValueError("pna_aggregate_gather: qe must be [E, L*C] with 0 <= qe_layer < L")
+        qoff = 4 * qe_layer * Cc
     if psd.shape[1] != 2 * Cc or hself.shape[1] != Cc:
         raise ValueError("pna_aggregate_gather: psd must be [N, 2C], hself [N, C] for qe [E, C]")
     out = torch.empty(plan.N, 13 * Cc, dtype=torch.float32, device=psd.device)
     with _span("sn_pna_aggregate_gather_f32"):
-        check(lib().sn_pna_aggregate_gather_f32(psd.data_ptr(), 2 * Cc, psd.data_ptr() + 4 * Cc, 2 * Cc, ptr(qe), Cc, ptr(hself), Cc, Cc, plan.N,
+        check(lib().sn_pna_aggregate_gather_f32(psd.data_ptr(), 2 * Cc, psd.data_ptr() + 4 * Cc, 2 * Cc, qe.data_ptr() + qoff, ldq, ptr(hself), Cc, Cc, plan.N,
                                                 ptr(plan.rowptr), ptr(plan.col), ptr(plan.eperm), float(avg_log), ptr(out), 13 * Cc, int(tower_width), stream()),
               "sn_pna_aggregate_gather_f32")
     return out

@@ -155,3 +155,32 @@ def test_gin_net_one_launch_eval_equals_the_layer_path(hidden, readout):
         with pytest.raises(IndexError):
             net.check_last()
         assert torch.isnan(y_bad).any()
+
+
+def test_pna_net_fused_eval_layers_equal_the_op_by_op_path():
+    """PNANet eval (round 4): every layer's edge term W_e e + b as ONE [E, L*C] Linear read in place by the aggregation, and the mixing
+    FCLayer's LeakyReLU + residual as its Linear's epilogue (SN_EPI_LEAKY) — 4 launches per layer instead of 6, the same bits."""
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, ops, synth
+    import parity_util as PU
+    cls, params = dgl_configs.net_params("pna", DEV)
+    params.update(L=4)
+    torch.manual_seed(2)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, 3)
+    net = net.to(DEV).eval()
+    a = synth.make_batch(24, seed=11)
+    g, h, pe, e, sn = _inputs(a, params["pos_enc_dim"])
+    with torch.no_grad():
+        p = net.sign_inv_net(g, pe).squeeze(-1)
+        rec = ops.KernelTimer()
+        with rec:
+            y_fused = net(g, h, p, e, sn)[0].clone()
+        n_fused = sum(v[0] for v in rec.summary().values())
+        net.fused_layers = False
+        rec = ops.KernelTimer()
+        with rec:
+            y_ops = net(g, h, p, e, sn)[0].clone()
+        n_ops = sum(v[0] for v in rec.summary().values())
+    assert torch.equal(y_fused, y_ops)
+    assert n_fused <= n_ops - (params["L"] - 1), (n_fused, n_ops)    # (the timer sees the L - 1 edge-term Linears that went away; the pointwise
+                                                                      #  pass per layer that the epilogue also replaces is not one of its spans)
