@@ -674,6 +674,22 @@ int sn_gin_net_fused_f32(const sn_gnn_params* params, const void* head_mid, int 
                          int kp, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr, const int32_t* col, const int32_t* eperm,
                          int32_t* status, float* y, const int32_t* flags_src, int n_flags, void* stream);
 
+/* The DGL tree's sparse graph Transformer base net, eval mode, one launch on the same per-graph stage kernel (GraphPrediction/nets/
+ * ZINC_graph_regression/transformer_net.py:88-140 with layers/transformer.py:150-312; the shipped shape: hidden 64, 8 heads, residual,
+ * BatchNorm):
+ *   h = embedding_h[atom] + embedding_p(p)  (or pe_proj(cat[.,.]): lin_a = pe_proj.weight[:, :64], lin_b = the two maps behind p folded);  L x [ Q, K, V -> edge attention with E_ij -> x1 = BatchNorm(h + O_h(a)) ->
+ *   h = BatchNorm(x1 + FFN2(relu(FFN1(x1)))) ];  readout sum / mean;  MLPReadout.
+ * params: as sn_gin_net_fused_f32 with d = 64 (input stage, head, node table); layers[l].etab[0..7] = the layer's eight [64, 64] stage
+ * matrices, split-packed: Q, K, V (no epilogue vectors), O_h with (e0, e1, e2) = (bias, BatchNorm1 scale, shift), FFN_h_layer1 rows
+ * [0, 64) and [64, 128) with e0 = their bias halves, FFN_h_layer2 columns [0, 64) (no vectors) and [64, 128) with (e0, e1, e2) = (bias,
+ * BatchNorm2 scale, shift); layers[l].w1s / w2s repeat etab[0] / etab[1].  e_proj: [E, lde] fp32 in edge-id order, columns
+ * [l * 64, (l + 1) * 64) = layer l's E projection of the edge embedding (one Linear over all layers, computed by the caller).
+ * Limits and error reporting as sn_gin_net_fused_f32. */
+int sn_transformer_net_fused_f32(const sn_gnn_params* params, const void* head_mid, int pool_mean, const int64_t* atom, const float* p,
+                                 int ldp, int kp, const float* e_proj, int lde, const int32_t* graph_ptr, int64_t B, const int32_t* rowptr,
+                                 const int32_t* col, const int32_t* eperm, int32_t* status, float* y, const int32_t* flags_src, int n_flags,
+                                 void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training-step stage kernels (BASELINE configs[3]).  They replace, for one "Linear -> BatchNorm1d(train) -> ReLU"
  * link of a MaskedMLP / MLP (Alchemy/sign_net/model_utils/masked_layers.py:34-64, GINESignNetPyG/core/model_utils/elements.py:40-69),

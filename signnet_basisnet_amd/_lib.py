@@ -43,6 +43,7 @@ SIGNATURES = {
     "sn_rho_fused_f32": [_p, _p, _p, _p, _l, _l, _p, _i, _i, _p, _p],
     "sn_gnn_fused_f32": [_p, _p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p, _i, _p, _p],
     "sn_gin_net_fused_f32": [_p, _p, _i, _p, _p, _i, _i, _p, _l, _p, _p, _p, _p, _p, _p, _i, _p],
+    "sn_transformer_net_fused_f32": [_p, _p, _i, _p, _p, _i, _i, _p, _i, _p, _l, _p, _p, _p, _p, _p, _p, _i, _p],
     "sn_masked_colstats_f32": [_p, _i, _l, _i, _p, _i, _p, _p, _p, _p, _p],
     "sn_masked_affine_f32": [_p, _i, _l, _i, _p, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     "sn_masked_layernorm_f32": [_p, _p, _l, _i, _p, _p, _f, _p, _i, _p, _p],

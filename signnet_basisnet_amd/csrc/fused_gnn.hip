@@ -248,8 +248,18 @@ __device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned 
 //   L x  h = MLP((1 + eps) h_i + sum_{j -> i} h_j)  -> no edge term and no ReLU in the message; Linear . ReLU . [BN folded] . Linear,
 //                                                      nothing behind the second Linear (no BatchNorm, ReLU or residual)
 //   readout sum / mean, MLPReadout (three Linears)  -> one more head stage (S.head_mid)
-template <int NT, bool DGL = false>
+// MODE 2: the DGL tree's sparse graph Transformer on the same mapping (transformer_net.py:88-140 with layers/transformer.py:150-312,
+// eval mode, d = 64, 8 heads; all stages are [64, 64] Linears — NT = 4):
+//   per layer  Q, K, V (fp32 rows parked in the OTHER split image's space) -> one lane per (node, head): the edge attention of
+//   sn_edge_attention_f32 over the node's in-edges, E_ij read from the [E, L*d] projection in global memory -> O_h + x, BatchNorm ->
+//   FFN 1 (two 64-column halves of the 128 hidden channels) -> FFN 2 (two 64-deep halves, the first one's sums parked in fp32) + x1,
+//   BatchNorm.  The two split images swap roles every layer (operand in one, Q | K | V / the next operand in the other).
+// The eight stage matrices of layer l are layers[l].etab[0..7] = Q, K, V, O_h, FFN1[:64], FFN1[64:], FFN2[:, :64], FFN2[:, 64:]
+// (w1s / w2s repeat etab[0] / etab[1]: what the input stage prefetches).
+template <int NT, int MODE = 0>
 __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_params& P) {
+  constexpr bool DGL = MODE != 0, TF = MODE == 2;
+  static_assert(!TF || NT == 4, "the Transformer mode is written for d = 64");
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
   constexpr int NKB = (NT + 1) / 2;
@@ -264,6 +274,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   int* elead = ecls + GNN_EMAX;                                     // [GNN_EMAX] first edge with the same features (scratch)
   int* cedge = elead + GNN_EMAX;                                    // [GNN_CLS]  representative edge of every class
   float* EE = reinterpret_cast<float*>(cedge + GNN_CLS);           // [ee_rows][LD] edge embeddings (per class x layer, or per edge)
+  float* PART = EE;                                                  // Transformer mode (no edge tables): [64][LD] fp32 sums of FFN 2's first half
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
   const int gi = blockIdx.x;
   SN_STAMP(0);
@@ -409,6 +420,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       const int k = tid;
       esrc[k] = src_v - gs;
       const int eid = eid_v;
+      if (TF) ecls[k] = eid;                              // the attention reads E[eid] from global memory
       if (!DGL && P.n_layers > 0) {
         if (P.edge_discrete) {
           const int64_t* ei = reinterpret_cast<const int64_t*>(S.edge_attr) + (int64_t)eid * S.lde;
@@ -566,6 +578,102 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   ee_store();
   lds_barrier();
   SN_STAMP(2);
+  if constexpr (TF) {
+    // ---------------------------------------------------------------- graph Transformer layers: h in X1 (fp32) and split in image A
+    static_assert(ROLL, "one output tile per wave and Linear");
+    for (int t = tr.t_lo; t < tr.t_hi; ++t) {
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      const int row = rt * 16 + li, c = 16 * ot + 4 * g;
+      sp_store4(SA, row, ot, g, lds_ld4(X1 + row * LD + c));
+    }
+    lds_barrier();
+    unsigned char* A = SA;
+    unsigned char* B = SB;
+    const float* Eg = reinterpret_cast<const float*>(S.edge_attr);
+    const int an = (int)threadIdx.x >> 3, ah = (int)threadIdx.x & 7;          // the attention's (node, head) of this lane
+    const float root = sqrtf(8.f);
+    for (int l = 0; l < P.n_layers; ++l) {
+      const sn_gnn_layer& Lp = P.layers[l];
+      const bool lastl = l + 1 == P.n_layers;
+      // the stage matrices in launch order, running on into the next layer / the readout (what every stage prefetches two ahead)
+      auto seq = [&](int j) -> const void* {
+        if (j < 8) return Lp.etab[j];
+        if (!lastl) return P.layers[l + 1].etab[j - 8];
+        return j == 8 ? P.head_w1 : S.head_mid;
+      };
+      auto seq_tr = [&](int j) { return (j < 8 || !lastl) ? tr : hr; };
+      float* Qi = reinterpret_cast<float*>(B);            // Q | K | V rows, fp32, in the other image's space (3 * 64 * LD floats = one image)
+      float* Ki = Qi + GNN_ROWS * LD;
+      float* Vi = Ki + GNN_ROWS * LD;
+      static_assert((size_t)3 * GNN_ROWS * LD * sizeof(float) <= (size_t)SP_IMAGE, "Q | K | V fit one split image");
+      auto epi_q = [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Qi + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc); };
+      auto epi_k = [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Ki + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc); };
+      auto epi_v = [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(Vi + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc); };
+      coop_gemm_roll<NKB>(pre, A, tr, lane, epi_q, seq(2), seq_tr(2));
+      coop_gemm_roll<NKB>(alt, A, tr, lane, epi_k, seq(3), seq_tr(3));
+      coop_gemm_roll<NKB>(pre, A, tr, lane, epi_v, seq(4), seq_tr(4));
+      lds_barrier();
+      // the edge attention (layers/transformer.py:150-228; arithmetic of k_edge_attention, csrc/dgl_layers.hip): one lane per (node, head)
+      if (an < n) {
+        const f32x4 q0 = lds_ld4(Qi + an * LD + 8 * ah), q1 = lds_ld4(Qi + an * LD + 8 * ah + 4);
+        f32x4 a0 = zero4, a1 = zero4;
+        float z = 0.f;
+        const int e_lo = erow[an], e_hi = erow[an + 1];
+        for (int e = e_lo; e < e_hi; ++e) {
+          const int sr = esrc[e];
+          const float* er = Eg + (int64_t)ecls[e] * S.lde + l * D + 8 * ah;
+          const f32x4 e0 = ld4(er), e1 = ld4(er + 4);
+          const f32x4 k0 = lds_ld4(Ki + sr * LD + 8 * ah), k1 = lds_ld4(Ki + sr * LD + 8 * ah + 4);
+          const f32x4 v0 = lds_ld4(Vi + sr * LD + 8 * ah), v1 = lds_ld4(Vi + sr * LD + 8 * ah + 4);
+          float sc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sc += ((k0[c] * q0[c]) / root) * e0[c];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sc += ((k1[c] * q1[c]) / root) * e1[c];
+          const float sw = expf(fminf(fmaxf(sc, -5.f), 5.f));
+          z += sw;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { a0[c] += v0[c] * sw; a1[c] += v1[c] * sw; }
+        }
+        const float rz = 1.0f / (z + 1e-6f);
+        sp_store4(A, an, ah >> 1, 2 * (ah & 1), a0 * rz);
+        sp_store4(A, an, ah >> 1, 2 * (ah & 1) + 1, a1 * rz);
+      }
+      lds_barrier();
+      // x1 = BatchNorm(x + O_h(a)) -> X1 and, split, the other image (Q | K | V are dead)
+      auto epi_o = [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4 sc, f32x4 sh) {
+        float* o = X1 + (rt * 16 + li) * LD + 16 * ot + 4 * g;
+        f32x4 v = acc + bias;
+        v = v + lds_ld4(o);
+        v = v * sc + sh;
+        lds_st4(o, v);
+        sp_store4(B, rt * 16 + li, ot, g, v);
+      };
+      coop_gemm_roll<NKB>(alt, A, tr, lane, epi_o, seq(5), seq_tr(5));
+      lds_barrier();
+      // FFN layer 1 in two halves of 64 hidden channels: relu(W x1 + b) -> image A, channels [0, 64) and [64, 128)
+      auto epi_f1a = [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) { sp_store4(A, rt * 16 + li, ot, g, relu4(acc + bias)); };
+      auto epi_f1b = [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4, f32x4) { sp_store4(A, rt * 16 + li, ot + NT, g, relu4(acc + bias)); };
+      coop_gemm_roll<NKB>(pre, B, tr, lane, epi_f1a, seq(6), seq_tr(6));
+      coop_gemm_roll<NKB>(alt, B, tr, lane, epi_f1b, seq(7), seq_tr(7));
+      lds_barrier();
+      // FFN layer 2 in two halves of its 128-deep sum: the first half's sums parked in fp32, then x = BatchNorm(x1 + W f + b)
+      auto epi_f2a = [&](int rt, int ot, f32x4 acc, f32x4, f32x4, f32x4) { lds_st4(PART + (rt * 16 + li) * LD + 16 * ot + 4 * g, acc); };
+      auto epi_f2b = [&](int rt, int ot, f32x4 acc, f32x4 bias, f32x4 sc, f32x4 sh) {
+        const int off = (rt * 16 + li) * LD + 16 * ot + 4 * g;
+        f32x4 v = (lds_ld4(PART + off) + acc) + bias;
+        v = v + lds_ld4(X1 + off);
+        v = v * sc + sh;
+        lds_st4(X1 + off, v);
+        sp_store4(B, rt * 16 + li, ot, g, v);
+      };
+      coop_gemm_roll<NKB>(pre, A, tr, lane, epi_f2a, seq(8), seq_tr(8));
+      coop_gemm_roll<NKB>(alt, A + 2 * 64, tr, lane, epi_f2b, seq(9), seq_tr(9));      // K blocks 2, 3 of the hidden rows
+      lds_barrier();
+      unsigned char* tsw = A; A = B; B = tsw;
+    }
+  } else {
   // ---------------------------------------------------------------- GINE layers: h lives in X1           (model.py:47-55)
   // The in-edges of my pairs' rows do not change from layer to layer: degree, the first four source rows and their edge classes
   // (or edge ids) are read ONCE — the aggregation of every layer then starts with its row reads instead of two dependent index
@@ -690,6 +798,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     SN_ACCUM(12, pt);
     SN_STAMP(24 + l);
   }
+  }
   SN_STAMP(3);
   // ---------------------------------------------------------------- add pooling -> row 0 of SA (rows 1..15: zero)   (model.py:57-61)
   for (int i = threadIdx.x; i < 16 * (D / 4); i += GNN_WAVES * 64) {
@@ -739,9 +848,9 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
 }
 
 // One workgroup per graph; the last workgroup to finish reports the batch's flags to the host (no separate copy).
-template <int NT, bool DGL = false>
+template <int NT, int MODE = 0>
 __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_gnn_params P) {
-  gnn_graph<NT, DGL>(S, P);
+  gnn_graph<NT, MODE>(S, P);
   if (S.flags_host != nullptr) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -758,8 +867,9 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
   }
 }
 
-template <int NT, bool DGL = false>
+template <int NT, int MODE = 0>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
+  constexpr bool DGL = MODE != 0;
   constexpr int LD = 16 * NT + 4;
   const size_t base = (size_t)2 * SP_IMAGE + (size_t)(GNN_ROWS * LD) * sizeof(float) +
                       (size_t)(GNN_ROWS + 4 + GNN_EMAX * (3 + (P.n_layers > 0 ? P.edge_nf : 0)) + GNN_CLS) * sizeof(int);
@@ -768,18 +878,18 @@ static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hip
   int ee_rows = (int)(room / ((size_t)LD * sizeof(float)));
   if (ee_rows > GNN_EEMAX) ee_rows = GNN_EEMAX;
   GnnStruct S2 = S;
-  S2.ee_rows = (!DGL && P.n_layers > 0) ? ee_rows : 0;
+  S2.ee_rows = MODE == 2 ? GNN_ROWS : ((!DGL && P.n_layers > 0) ? ee_rows : 0);        // (Transformer mode: the fp32 partial-sum image)
   const size_t lds = base + (size_t)S2.ee_rows * LD * sizeof(float);
   static bool init = false;
   if (!init) {
     const size_t lds_max = lds_cap;
     if (lds_max > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gnn_coop<NT, DGL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_gnn_coop<NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_max) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_gnn_fused_f32: cannot raise the dynamic LDS limit to %zu", lds_max);
     init = true;
   }
-  hipLaunchKernelGGL((k_gnn_coop<NT, DGL>), dim3((unsigned)B), dim3(GNN_WAVES * 64), lds, st, S2, P);
+  hipLaunchKernelGGL((k_gnn_coop<NT, MODE>), dim3((unsigned)B), dim3(GNN_WAVES * 64), lds, st, S2, P);
   return SN_OK;
 }
 
@@ -862,11 +972,42 @@ extern "C" int sn_gin_net_fused_f32(const sn_gnn_params* params, const void* hea
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   switch ((P.d + 15) / 16) {          // (the widths the shipped nets pad to; others round up to the next one at pack time)
-    case 1: case 2: case 3: case 4: rc = launch_gnn<4, true>(S, P, B, st); break;
-    case 5: case 6: rc = launch_gnn<6, true>(S, P, B, st); break;
-    default: rc = launch_gnn<8, true>(S, P, B, st); break;
+    case 1: case 2: case 3: case 4: rc = launch_gnn<4, 1>(S, P, B, st); break;
+    case 5: case 6: rc = launch_gnn<6, 1>(S, P, B, st); break;
+    default: rc = launch_gnn<8, 1>(S, P, B, st); break;
   }
   if (rc != SN_OK) return rc;
   SN_CHECK_LAUNCH("sn_gin_net_fused_f32");
+  return SN_OK;
+}
+
+// The DGL tree's sparse graph Transformer (transformer_net.py:88-140, eval mode, hidden 64, 8 heads) on the per-graph stage kernel:
+// see gnn_graph<4, MODE = 2>.
+extern "C" int sn_transformer_net_fused_f32(const sn_gnn_params* params, const void* head_mid, int pool_mean, const int64_t* atom,
+                                            const float* p, int ldp, int kp, const float* e_proj, int lde, const int32_t* graph_ptr, int64_t B,
+                                            const int32_t* rowptr, const int32_t* col, const int32_t* eperm, int32_t* status, float* y,
+                                            const int32_t* flags_src, int n_flags, void* stream) {
+  SN_REQUIRE(params && head_mid && atom && p && e_proj && graph_ptr && rowptr && col && eperm && status && y && B >= 0,
+             "sn_transformer_net_fused_f32: null pointer");
+  const sn_gnn_params& P = *params;
+  SN_REQUIRE(P.d == 64, "sn_transformer_net_fused_f32: hidden width %d (the stage kernel is written for 64 = 8 heads of 8)", P.d);
+  SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_GNN_MAX_LAYERS, "sn_transformer_net_fused_f32: %d layers unsupported", P.n_layers);
+  SN_REQUIRE(P.n_out >= 1 && P.n_out <= 16, "sn_transformer_net_fused_f32: n_out=%d not in [1,16]", P.n_out);
+  SN_REQUIRE(P.node_discrete == 1 && P.node_nf == 1 && P.ntab[0] && P.node_vocab > 0, "sn_transformer_net_fused_f32: one atom-type table expected");
+  SN_REQUIRE(P.edge_nf == 0, "sn_transformer_net_fused_f32: edge_nf must be 0 (the edge term is e_proj)");
+  SN_REQUIRE(P.lin_a && P.lin_b && P.head_w1 && P.head_w2 && P.rho_out_w == nullptr, "sn_transformer_net_fused_f32: parameters missing");
+  SN_REQUIRE(kp >= 1 && kp <= P.d && ldp >= kp && lde >= P.n_layers * P.d && (lde & 3) == 0 && (reinterpret_cast<uintptr_t>(e_proj) & 15) == 0,
+             "sn_transformer_net_fused_f32: positional encoding / edge projection shapes");
+  for (int l = 0; l < P.n_layers; ++l) {
+    const sn_gnn_layer& L = P.layers[l];
+    for (int j = 0; j < 8; ++j) SN_REQUIRE(L.etab[j], "sn_transformer_net_fused_f32: layer %d stage matrix %d missing", l, j);
+    SN_REQUIRE(L.w1s == (const void*)L.etab[0] && L.w2s == (const void*)L.etab[1], "sn_transformer_net_fused_f32: w1s / w2s must repeat etab[0] / etab[1]");
+  }
+  SN_REQUIRE(!flags_src || n_flags >= 1, "sn_transformer_net_fused_f32: flags_src needs n_flags >= 1");
+  if (B == 0) return SN_OK;
+  GnnStruct S{atom, 1, e_proj, lde, p, graph_ptr, rowptr, col, eperm, status, y, 0, flags_src, n_flags, nullptr, ldp, kp, head_mid, pool_mean};
+  const int rc = launch_gnn<4, 2>(S, P, B, (hipStream_t)stream);
+  if (rc != SN_OK) return rc;
+  SN_CHECK_LAUNCH("sn_transformer_net_fused_f32");
   return SN_OK;
 }

@@ -178,12 +178,12 @@ class GINNet(_PackCache, nn.Module):
         if plan is not None:
             st = plan.status.tolist()
             if st[0]:
-                raise ValueError(f"GINNet: the last batch is malformed (sn_batch_plan status {st[0]})")
-            if st[3] & 4:
+                raise ValueError(f"{type(self).__name__}: the last batch is malformed (sn_batch_plan status {st[0]})")
+            if (st[3] & 4) or st[5]:
                 raise IndexError(ops.EMBEDDING_INDEX_ERROR)
             if st[3] & 3:
-                raise RuntimeError("GINNet: a graph of the last batch has more than 64 nodes or 192 in-edges; its score is NaN — set "
-                                   "fused_stages = False for such batches")
+                raise RuntimeError(f"{type(self).__name__}: a graph of the last batch has more than 64 nodes or 192 in-edges; its score is "
+                                   "NaN — set fused_stages = False for such batches")
 
     def train(self, mode=True):
         self.check_last()
@@ -985,6 +985,79 @@ class BatchedTransformerLayer(nn.Module):
         self.batch_norm2_h = nn.BatchNorm1d(out_dim)
 
 
+class _FusedTransformer:
+    """Packed eval-mode parameters of a TransformerNet for sn_transformer_net_fused_f32: embeddings, every layer (projections, edge
+    attention, O_h, both BatchNorms, the FFN), readout and MLPReadout in ONE launch — a workgroup per graph on the stage kernel of
+    csrc/fused_gnn.hip (Transformer mode).  The layers' E projections of the edge embedding stay one Linear in front of it.  `ok`
+    False: anything but the shipped shape (hidden = out = 64, 8 heads, BatchNorm, residual, 3-Linear readout; pe_aggregate 'add' or 'concat')."""
+
+    def __init__(self, net):
+        from .fused import _GnnParams, GNN_MAX_LAYERS
+        from .dgl_deepsigns import _pad_mat
+        self.ok = False
+        Ls, fcs = list(net.layers), list(net.MLP_layer.FC_layers)
+        d, kp = net.embedding_h.weight.shape[1], net.embedding_p.weight.shape[1]
+        if not (d == 64 and net.batch_norm and net.residual and kp <= 64):        # (the net's layer_norm flag is not handed to the layers)
+            return
+        if len(Ls) > GNN_MAX_LAYERS or len(fcs) != 3 or fcs[2].weight.shape[0] != 1:
+            return
+        if any(L.in_channels != 64 or L.out_channels != 64 or L.num_heads != 8 for L in Ls):
+            return
+        dev = net.embedding_h.weight.device
+        keep = self._keep = []
+
+        def hold(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        ones = torch.ones(64, dtype=torch.float32, device=dev)
+        w = lambda t: t.detach().float().contiguous()
+        P = _GnnParams()
+        P.d, P.n_layers, P.n_out = 64, len(Ls), 1
+        P.node_discrete, P.node_nf, P.edge_discrete, P.edge_nf = 1, 1, 0, 0
+        P.node_vocab, P.edge_vocab = net.embedding_h.weight.shape[0], 0
+        P.ntab[0] = hold(w(net.embedding_h.weight))
+        P.rho_out_w = None
+        if net.pe_aggregate == "concat":
+            # h = pe_proj(cat[embedding_h, embedding_p(p)]) (transformer_net.py:96-99) = W[:, :d] emb_h + (W[:, d:] W_p) p + (W[:, d:] b_p + b):
+            # the two affine maps behind p folded once, in float64 (as the GINE net folds rho.out into its input Linear)
+            Wc, bc = net.pe_proj.weight.detach().double(), net.pe_proj.bias.detach().double()
+            Wp_, bp_ = net.embedding_p.weight.detach().double(), net.embedding_p.bias.detach().double()
+            P.lin_a = hold(ops.pack_split(Wc[:, :64].float().contiguous()))
+            P.lin_b = hold(ops.pack_split(_pad_mat((Wc[:, 64:] @ Wp_).float(), 64), (Wc[:, 64:] @ bp_ + bc).float().contiguous()))
+        else:
+            P.lin_a = hold(ops.pack_split(torch.eye(64, dtype=torch.float32, device=dev)))
+            P.lin_b = hold(ops.pack_split(_pad_mat(net.embedding_p.weight, 64), ops.pad_vec(net.embedding_p.bias, 64)))
+        for l, L in enumerate(Ls):
+            A = L.attention_h
+            s1, s2 = net._bn(L.batch_norm1_h, False), net._bn(L.batch_norm2_h, False)
+            W1, b1, W2 = w(L.FFN_h_layer1.weight), w(L.FFN_h_layer1.bias), w(L.FFN_h_layer2.weight)
+            mats = [ops.pack_split(w(A.Q.weight)), ops.pack_split(w(A.K.weight)), ops.pack_split(w(A.V.weight)),
+                    ops.pack_split(w(L.O_h.weight), w(L.O_h.bias), s1.scale, s1.shift),
+                    ops.pack_split(W1[:64].contiguous(), b1[:64].contiguous()), ops.pack_split(W1[64:].contiguous(), b1[64:].contiguous()),
+                    ops.pack_split(W2[:, :64].contiguous()),
+                    ops.pack_split(W2[:, 64:].contiguous(), w(L.FFN_h_layer2.bias), s2.scale, s2.shift)]
+            Lp = P.layers[l]
+            for j, m in enumerate(mats):
+                Lp.etab[j] = hold(m)
+            Lp.w1s, Lp.w2s = Lp.etab[0], Lp.etab[1]
+        P.head_w1 = hold(ops.pack_split(_pad_mat(fcs[0].weight, 64), ones, ops.pad_vec(fcs[0].bias, 64)))
+        self.head_mid = hold(ops.pack_split(_pad_mat(fcs[1].weight, 64), ones, ops.pad_vec(fcs[1].bias, 64)))
+        P.head_w2 = hold(ops.pack_split(_pad_mat(fcs[2].weight, 64), ops.pad_vec(fcs[2].bias, 64)))
+        self.params, self.kp, self.pool_mean = P, kp, 0 if net.readout == "sum" else 1
+        self.ok = True
+
+    def run(self, plan, hidx, p, e_proj):
+        """atom types [N] int64, positional encoding [N, k], the layers' E projections [E, L*64] -> scores [B, 1]"""
+        y = torch.empty(plan.B, 1, dtype=torch.float32, device=p.device)
+        with ops._span("sn_transformer_net_fused_f32"):
+            check(lib().sn_transformer_net_fused_f32(C.byref(self.params), self.head_mid, self.pool_mean, ptr(hidx), ptr(p), p.shape[1], self.kp,
+                                                     ptr(e_proj), e_proj.shape[1], ptr(plan.graph_ptr), plan.B, ptr(plan.rowptr), ptr(plan.col),
+                                                     ptr(plan.eperm), ptr(plan.status), ptr(y), ptr(plan.status), 8, stream()),
+                  "sn_transformer_net_fused_f32")
+        return y
+
+
 class TransformerNet(_PackCache, nn.Module):
     """nets/ZINC_graph_regression/transformer_net.py:21-150 for pe_init 'lap_pe', lap_lspe False, edge_feat True, full_graph False
     (Transformer_ZINC_LapPE_signinv_GIN[_masked].json): embedding_h / embedding_p with `add` or `concat` + pe_proj, edge
@@ -1024,6 +1097,26 @@ class TransformerNet(_PackCache, nn.Module):
     _plan = GINNet._plan
 
     fused_layers = True      # eval: fused projections / epilogues (False: one launch per op, as the train-mode value path)
+    fused_stages = True      # eval, the shipped shape: everything behind the E projection in ONE launch (sn_transformer_net_fused_f32)
+
+    def _fused_tf(self, g):
+        """The packed stage-kernel parameters if this batch can take the one-launch path, else None (see GINNet._fused_gin)."""
+        if self.training or not self.fused_stages or not self._fusable():
+            return None
+        c = self.__dict__.setdefault("_cache", {})
+        if "fused_tf" not in c:
+            c["fused_tf"] = _FusedTransformer(self)
+        fz = c["fused_tf"]
+        if not fz.ok:
+            return None
+        me = _max_in_edges(g)
+        return fz if 0 < _max_nodes(g) <= 64 and (me is None or me <= 192) else None
+
+    check_last = GINNet.check_last
+
+    def train(self, mode=True):
+        self.check_last()
+        return super().train(mode)
 
     def _fusable(self):
         """Every layer maps hidden -> hidden (the shipped configs: out_dim == hidden_dim), so that the layers' E projections stack."""
@@ -1065,6 +1158,15 @@ class TransformerNet(_PackCache, nn.Module):
             self.g = g
             return hg, g
         with torch.no_grad():
+            fzs = self._fused_tf(g)
+            if fzs is not None:
+                # no host sync on this path: a bad atom type / an oversize graph -> NaN score + check_last(); a bond type outside its table
+                # is flagged in the plan's status block by the embedding (status[5]) and raised by check_last() as well
+                ef = ops.embedding_sum(e.long().reshape(-1), [self.embedding_e.weight], status=plan.status[5:6])
+                Ee_all = ops.masked_linear(ef, self._fused_eval()["E"])
+                self._last_plan = plan
+                self.g = g
+                return fzs.run(plan, h.long().reshape(N).contiguous(), p.contiguous().float(), Ee_all), g
             x = ops.embedding_sum(h.long().reshape(N), [self.embedding_h.weight])
             pp = p.contiguous().float()
             if self.pe_aggregate == "concat":

@@ -71,6 +71,7 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_deepsigns_phi_f32": (None, None, 8, None, None, None, None, 8, None, None),
         "sn_mlp_chain_f32": (None, 8, 4, 8, None, 0, None, 2, 64, None, 8, 8, None),
         "sn_gin_net_fused_f32": (None, None, 0, None, None, 8, 8, None, 4, None, None, None, None, None, None, 0, None),
+        "sn_transformer_net_fused_f32": (None, None, 0, None, None, 8, 8, None, 64, None, 4, None, None, None, None, None, None, 0, None),
         "sn_gatedgcn_fused_f32": (None,) * 4 + (1,) + (None,) * 6,
         "sn_eigenspace_group": (None, 4, 5) + (None,) * 8,
         "sn_eigenspace_projectors_f32": (None, 4, 4, None, None, 1, None, None),

@@ -103,6 +103,7 @@ def test_transformer_net_fused_eval_layers_equal_the_op_by_op_path():
     net = getattr(dgl_nets, cls)(params)
     PU.bn_randomize(net, 3)
     net = net.to(DEV).eval()
+    net.fused_stages = False          # (the layer path's own fusions are compared here; the one-launch stage kernel has its own test)
     a = synth.make_batch(24, seed=11)
     g, h, pe, e, _ = _inputs(a, params["pos_enc_dim"])
     with torch.no_grad():
@@ -184,3 +185,39 @@ def test_pna_net_fused_eval_layers_equal_the_op_by_op_path():
     assert torch.equal(y_fused, y_ops)
     assert n_fused <= n_ops - (params["L"] - 1), (n_fused, n_ops)    # (the timer sees the L - 1 edge-term Linears that went away; the pointwise
                                                                       #  pass per layer that the epilogue also replaces is not one of its spans)
+
+
+@pytest.mark.parametrize("readout,L", [("mean", 3), ("sum", 10)])
+def test_transformer_net_one_launch_eval_equals_the_layer_path(readout, L):
+    """TransformerNet eval (round 4): embeddings, the L layers (Q | K | V, edge attention, O_h, FFN, both BatchNorms), readout and
+    MLPReadout in ONE launch (sn_transformer_net_fused_f32: a workgroup per graph, Transformer mode of the GINE stage kernel) against the
+    layer path (fused_stages = False); the same values up to the rounding of different GEMM orders."""
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, ops, synth
+    import parity_util as PU
+    cls, params = dgl_configs.net_params("transformer", DEV)
+    params.update(readout=readout, L=L)
+    torch.manual_seed(4)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, 5)
+    net = net.to(DEV).eval()
+    a = synth.make_batch(40, seed=21)
+    g, h, pe, e, _ = _inputs(a, params["pos_enc_dim"])
+    with torch.no_grad():
+        p = net.sign_inv_net(g, pe).squeeze(-1)
+        rec = ops.KernelTimer()
+        with rec:
+            y_one = net(g, h, p, e, None)[0].clone()
+        assert "sn_transformer_net_fused_f32" in rec.summary(), rec.summary().keys()
+        net.check_last()
+        net.fused_stages = False
+        y_lay = net(g, h, p, e, None)[0].clone()
+        net.fused_stages = True
+        assert torch.isfinite(y_one).all()
+        scale = y_lay.abs().max().clamp_min(1e-6)
+        assert ((y_one - y_lay).abs().max() / scale).item() < 5e-5, ((y_one - y_lay).abs().max() / scale).item()
+        bad = h.clone()
+        bad[3] = 1000
+        y_bad = net(g, bad, p, e, None)[0]
+        with pytest.raises(IndexError):
+            net.check_last()
+        assert torch.isnan(y_bad).any()
