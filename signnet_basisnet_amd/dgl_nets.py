@@ -296,14 +296,15 @@ class GINNet(_PackCache, nn.Module):
         if p is None or self.pe_init != "lap_pe":
             raise NotImplementedError("HIP GINNet needs the positional encoding p (pe_init='lap_pe')")
         N = h.shape[0]
-        batch, ei, B = self._plan(g, N)
-        plan = ops.build_plan(batch, ei, B, 0)
         hidx = h.long().reshape(N)
         p = p.contiguous().float()
         train = self.training
         if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            batch, ei, B = self._plan(g, N)
+            plan = ops.build_plan(batch, ei, B, 0)
             y = self._forward_grad(plan, batch, ei, B, hidx, p)
         else:
+            plan = cached_plan(g, N)       # the sign-invariant net's plan of this graph object, if there is one: ONE sn_batch_plan per batch
             with torch.no_grad():
                 fz = self._fused_gin(g)
                 if fz is not None:
@@ -765,13 +766,18 @@ class PNANet(_PackCache, nn.Module):
         if p is None or snorm_n is None:
             raise NotImplementedError("HIP PNANet needs the positional encoding p and snorm_n (graph_norm)")
         N = h.shape[0]
-        batch, ei, B = self._plan(g, N)
-        plan = ops.build_plan(batch, ei, B, 0)
-        src, dst = ei[0], ei[1]
         train = self.training
         avg_log = float(self.avg_d["log"])
         sn = snorm_n.reshape(N).contiguous().float()
-        if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+        grad = train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters())
+        if grad:
+            batch, ei, B = self._plan(g, N)
+            plan = ops.build_plan(batch, ei, B, 0)
+            src, dst = ei[0], ei[1]
+        else:
+            plan = cached_plan(g, N)       # shared with the sign-invariant net: ONE sn_batch_plan per batch
+            src, dst = (t.long() for t in g.edges())
+        if grad:
             hg = self._forward_grad(plan, batch, ei, B, h.long().reshape(N), p.contiguous().float(), e.long().reshape(-1), sn, avg_log)
             self.g = g
             return hg, g
@@ -1150,13 +1156,14 @@ class TransformerNet(_PackCache, nn.Module):
         if p is None:
             raise NotImplementedError("HIP TransformerNet needs the positional encoding p")
         N = h.shape[0]
-        batch, ei, B = self._plan(g, N)
-        plan = ops.build_plan(batch, ei, B, 0)
         train = self.training
         if train and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            batch, ei, B = self._plan(g, N)
+            plan = ops.build_plan(batch, ei, B, 0)
             hg = self._forward_grad(plan, batch, ei, B, h.long().reshape(N), p.contiguous().float(), e.long().reshape(-1))
             self.g = g
             return hg, g
+        plan = cached_plan(g, N)           # shared with the sign-invariant net: ONE sn_batch_plan per batch
         with torch.no_grad():
             fzs = self._fused_tf(g)
             if fzs is not None:
