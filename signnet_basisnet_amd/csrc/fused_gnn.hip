@@ -408,9 +408,11 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);                      // in flight while the inputs are staged
     if constexpr (ROLL) wload<NKB>(alt, P.lin_b, tr.first_ot(), lane);
   }
+  SN_STAMP(30);
   // ---------------------------------------------------------------- clear the split images (K padding must read as 0)
   for (int i = threadIdx.x; i < 2 * SP_IMAGE / 16; i += GNN_WAVES * 64)
     reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+  SN_STAMP(31);
   // ---------------------------------------------------------------- per-graph CSR + edge data -> LDS (once)
   bool id_bad = false;        // a discrete feature value of this graph lies outside its embedding table
   {
@@ -439,6 +441,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   }
   int graph_bad = __syncthreads_or(id_bad);          // images cleared, efeat complete (+ did anyone see a bad edge feature id)
   id_bad = false;
+  SN_STAMP(32);
   // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
   if (!DGL && P.n_layers > 0) {
     const int EF = P.edge_nf;
@@ -493,6 +496,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   }
+  SN_STAMP(33);
   // ---------------------------------------------------------------- stage the slot sum (rho output), split, in SA
   if (rs_vec) {
 #pragma unroll
@@ -512,6 +516,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       sp_store4(SA, rr, c4 >> 2, c4 & 3, v);
     }
   }
+  SN_STAMP(34);
   // ---------------------------------------------------------------- input encoder -> SB (model.py:37)
   if (P.node_discrete) {
     for (int t = tr.t_lo; t < tr.t_hi; ++t) {
@@ -552,6 +557,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   }
+  SN_STAMP(35);
   graph_bad |= __syncthreads_or(id_bad);   // inputs staged (+ did anyone see a bad node feature id); later barriers are LDS-only:
   SN_STAMP(1);                             // a __syncthreads() would also drain the weight prefetch in flight (vmcnt(0))
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
