@@ -225,6 +225,10 @@ int sn_masked_layernorm_f32(const float* x, const float* residual /* may be NULL
 int sn_set_attention_f32(const float* q, const float* k, const float* v, int64_t N, int K, int heads,
                          int dk, const int32_t* nvalid, const float* prob_mask, float* out, void* stream);
 
+/* The CSR of two disjoint copies of a batch: rowptr2 [2N + 1] = [rowptr | rowptr[1:] + E], col2 [2E] = [col | col + N] — the graph the
+ * training step's stacked phi(+x) / phi(-x) aggregation walks in one launch (sign_net.py:113: both sign passes over the same edges). */
+int sn_plan_double_i32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int32_t* rowptr2, int32_t* col2, void* stream);
+
 /* out[n, :] = sum_k x[n, k, :]  (torch.sum(x, dim=1), sign_net.py:70). */
 int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* out, void* stream);
 

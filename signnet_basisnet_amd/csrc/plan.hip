@@ -788,3 +788,31 @@ extern "C" int sn_pack_eig_f32(const float* eigen_vectors, const float* eigen_va
   SN_CHECK_LAUNCH("sn_pack_eig_f32");
   return SN_OK;
 }
+
+// The CSR of two disjoint copies of a batch (nodes N .. 2N-1 = the second copy): what the training step's stacked phi(+x) / phi(-x)
+// aggregation walks (train_stage.py).  Index plumbing — it replaced eight torch launches (add, cat) per step.
+namespace sn {
+__global__ __launch_bounds__(256) void k_plan_double(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int64_t E,
+                                                     int32_t* __restrict__ rowptr2, int32_t* __restrict__ col2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i <= N) {
+    const int32_t r = rowptr[i];
+    rowptr2[i] = r;
+    if (i > 0) rowptr2[N + i] = r + (int32_t)E;
+  }
+  if (i < E) {
+    const int32_t c = col[i];
+    col2[i] = c;
+    col2[E + i] = c + (int32_t)N;
+  }
+}
+}  // namespace sn
+
+extern "C" int sn_plan_double_i32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int32_t* rowptr2, int32_t* col2, void* stream) {
+  SN_REQUIRE(rowptr && rowptr2 && N >= 0 && E >= 0 && (E == 0 || (col && col2)), "sn_plan_double_i32: bad arguments");
+  SN_REQUIRE(2 * N < (1ll << 31) && 2 * E < (1ll << 31), "sn_plan_double_i32: the doubled graph does not fit 32-bit indices");
+  const int64_t work = (N + 1 > E ? N + 1 : E);
+  hipLaunchKernelGGL(sn::k_plan_double, dim3((unsigned)sn::cdiv(work, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, N, E, rowptr2, col2);
+  SN_CHECK_LAUNCH("sn_plan_double_i32");
+  return SN_OK;
+}

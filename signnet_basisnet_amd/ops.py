@@ -302,13 +302,15 @@ def gin_aggregate(x, plan: GraphPlan, eps=None, negate=False, slab=False):
 
 def doubled_plan(plan: GraphPlan):
     """The CSR of two disjoint copies of the batch (nodes N..2N-1 = the second copy): the phi(+x) / phi(-x) passes stacked group-major
-    aggregate in ONE launch over [2N, K*d].  Index plumbing only (two concatenations), kept on the plan."""
+    aggregate in ONE launch over [2N, K*d].  Index plumbing only (one launch: sn_plan_double_i32), kept on the plan."""
     d = getattr(plan, "_doubled", None)
     if d is None:
         import types
         E = plan.col.numel()
-        d = types.SimpleNamespace(N=2 * plan.N, B=2 * plan.B, E=2 * E, rowptr=torch.cat([plan.rowptr, plan.rowptr[1:] + E]),
-                                  col=torch.cat([plan.col, plan.col + plan.N]))
+        rowptr2 = torch.empty(2 * plan.N + 1, dtype=torch.int32, device=plan.rowptr.device)
+        col2 = torch.empty(2 * E, dtype=torch.int32, device=plan.rowptr.device)
+        check(lib().sn_plan_double_i32(ptr(plan.rowptr), ptr(plan.col), plan.N, E, ptr(rowptr2), ptr(col2), stream()), "sn_plan_double_i32")
+        d = types.SimpleNamespace(N=2 * plan.N, B=2 * plan.B, E=2 * E, rowptr=rowptr2, col=col2)
         plan._doubled = d
     return d
 

@@ -51,6 +51,19 @@ def test_plan(batch):
         assert col[seg].tolist() == src[ids].tolist()
 
 
+def test_doubled_plan_is_two_disjoint_copies(batch):
+    """ops.doubled_plan (sn_plan_double_i32, round 4: one launch instead of eight torch ones): the CSR of two disjoint copies of the
+    batch, nodes N .. 2N-1 the second copy."""
+    from signnet_basisnet_amd import ops
+    data, d, plan = batch
+    d2 = ops.doubled_plan(plan)
+    E = plan.col.numel()
+    assert d2.N == 2 * plan.N and d2.E == 2 * E and d2.rowptr.dtype == torch.int32 and d2.col.dtype == torch.int32
+    assert torch.equal(d2.rowptr, torch.cat([plan.rowptr, plan.rowptr[1:] + E]))
+    assert torch.equal(d2.col, torch.cat([plan.col, plan.col + plan.N]))
+    assert ops.doubled_plan(plan) is d2             # kept on the plan
+
+
 def test_plan_large_batch_multikernel_path(dev):
     """N > 4096 takes the five-launch path; same contract."""
     from signnet_basisnet_amd import ops
