@@ -229,6 +229,10 @@ int sn_set_attention_f32(const float* q, const float* k, const float* v, int64_t
  * training step's stacked phi(+x) / phi(-x) aggregation walks in one launch (sign_net.py:113: both sign passes over the same edges). */
 int sn_plan_double_i32(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t E, int32_t* rowptr2, int32_t* col2, void* stream);
 
+/* Uniform draws -> a scaled keep-mask, in place: u[i] = u[i] >= p ? scale : 0 — the attention dropout mask of transformer_module.py:49,55
+ * (the caller draws u with its own generator; scale = 1 / (1 - p)); u 16-byte aligned. */
+int sn_keep_mask_f32(float* u, int64_t n, float p, float scale, void* stream);
+
 /* out[n, :] = sum_k x[n, k, :]  (torch.sum(x, dim=1), sign_net.py:70). */
 int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* out, void* stream);
 

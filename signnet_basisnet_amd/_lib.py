@@ -50,6 +50,7 @@ SIGNATURES = {
     "sn_set_attention_f32": [_p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p],
     "sn_slot_sum_f32": [_p, _l, _i, _i, _p, _p],
     "sn_plan_double_i32": [_p, _p, _l, _l, _p, _p, _p],
+    "sn_keep_mask_f32": [_p, _l, _f, _f, _p],
     "sn_embedding_sum_f32": [_p, _i, _i, _l, C.POINTER(_p), C.POINTER(C.c_int64), _i, _p, _p, _p],
     "sn_segment_pool_f32": [_p, _l, _i, _p, _i, _p, _p],
     "sn_ign_contract_2to1_f32": [_p, _l, _i, _p, _p, _p],

@@ -1604,6 +1604,27 @@ extern "C" int sn_set_attention_f32(const float* q, const float* k, const float*
   return SN_OK;
 }
 
+namespace sn {
+__global__ __launch_bounds__(256) void k_keep_mask(float* __restrict__ u, int64_t n, float p, float scale) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 v = *reinterpret_cast<float4*>(u + i);
+    v.x = v.x >= p ? scale : 0.f; v.y = v.y >= p ? scale : 0.f; v.z = v.z >= p ? scale : 0.f; v.w = v.w >= p ? scale : 0.f;
+    *reinterpret_cast<float4*>(u + i) = v;
+  } else {
+    for (int64_t j = i; j < n; ++j) u[j] = u[j] >= p ? scale : 0.f;
+  }
+}
+}  // namespace sn
+
+extern "C" int sn_keep_mask_f32(float* u, int64_t n, float p, float scale, void* stream) {
+  SN_REQUIRE(u && n >= 0 && (reinterpret_cast<uintptr_t>(u) & 15) == 0, "sn_keep_mask_f32: bad arguments");
+  if (n == 0) return SN_OK;
+  hipLaunchKernelGGL(sn::k_keep_mask, dim3((unsigned)sn::cdiv(sn::cdiv(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, u, n, p, scale);
+  SN_CHECK_LAUNCH("sn_keep_mask_f32");
+  return SN_OK;
+}
+
 extern "C" int sn_slot_sum_f32(const float* x, int64_t N, int K, int C, float* out, void* stream) {
   SN_REQUIRE(x && out && N >= 0 && K > 0 && C > 0, "sn_slot_sum_f32: bad arguments");
   if (N == 0) return SN_OK;
