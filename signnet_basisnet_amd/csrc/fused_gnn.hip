@@ -17,6 +17,12 @@
 //     of a Linear is the matrix once per CU; one barrier per Linear;
 //   * edges of a graph repeat a handful of feature tuples (ZINC: 3 bond types): their embeddings for every layer are
 //     built once into an LDS table indexed by edge class.
+//
+// Round 4: the same mapping serves two base nets of the DGL tree (GraphPrediction/nets/ZINC_graph_regression), each as ONE launch —
+// gnn_graph<NT, MODE>: MODE 1 = gin_net.py (sn_gin_net_fused_f32: no edge term, plain messages, nothing behind the MLP's second Linear,
+// a three-Linear readout), MODE 2 = transformer_net.py (sn_transformer_net_fused_f32: hidden 64, every stage a [64, 64] Linear, the edge
+// attention one lane per (node, head), the two split images swapping roles per layer).  The mode is a template parameter: the GINE
+// instantiations carry none of it.
 #include "fused_common.hpp"
 
 namespace sn {
