@@ -287,3 +287,41 @@ def test_one_launch_dgl_nets_on_random_shapes_and_odd_graphs(seed):
     assert torch.isfinite(y_one).all()
     err = ((y_one - y_lay).abs().max() / y_lay.abs().max().clamp_min(1e-6)).item()
     assert err < 2e-5, (name, params["hidden_dim"], params["L"], err)
+
+
+@pytest.mark.parametrize("name", ["gin", "transformer"])
+def test_one_launch_dgl_nets_route_or_flag_graphs_beyond_the_kernel_limits(name):
+    """A graph with more in-edges than the stage kernel stages (192) or more than 64 nodes: with the batch object's counts the net takes
+    the layer path (finite scores, no stage launch); a duck-typed graph WITHOUT edge counts reaches the kernel, which hands back NaN for
+    that graph only and flags it — check_last() raises."""
+    import numpy as np
+    from signnet_basisnet_amd import dgl_configs, dgl_nets, ops, dgl_deepsigns as DS
+    import parity_util as PU
+    cls, params = dgl_configs.net_params(name, DEV)
+    params.update(L=2)
+    torch.manual_seed(0)
+    net = getattr(dgl_nets, cls)(params)
+    PU.bn_randomize(net, 1)
+    net = net.to(DEV).eval()
+    rng = np.random.default_rng(5)
+    # graph 0: 20 nodes, 300 random edges (> 192); graph 1: a 10-node path
+    e0 = np.stack([rng.integers(0, 20, 300), rng.integers(0, 20, 300)])
+    a = np.arange(9)
+    e1 = np.concatenate([np.stack([a, a + 1]), np.stack([a + 1, a])], 1) + 20
+    ei = torch.from_numpy(np.concatenate([e0, e1], 1)).long()
+    szt = torch.tensor([20, 10])
+    bne = torch.tensor([300, 18])
+    gt = torch.Generator().manual_seed(1)
+    h = torch.randint(0, 28, (30,), generator=gt).to(DEV)
+    e = torch.randint(1, 4, (ei.shape[1],), generator=gt).to(DEV)
+    p = torch.randn(30, params["pos_enc_dim"], generator=gt).to(DEV)
+    with torch.no_grad():
+        rec = ops.KernelTimer()
+        with rec:
+            y_lay = net(DS.Graph(ei[0].to(DEV), ei[1].to(DEV), szt, bne), h, p, e, None)[0].clone()
+        assert not any("net_fused" in k for k in rec.summary()) and torch.isfinite(y_lay).all()
+        y = net(DS.Graph(ei[0].to(DEV), ei[1].to(DEV), szt, None), h, p, e, None)[0].clone()      # no edge counts: the kernel decides
+        assert torch.isnan(y[0]).all() and torch.isfinite(y[1]).all()
+        assert ((y[1] - y_lay[1]).abs() / y_lay.abs().max().clamp_min(1e-6)).max().item() < 2e-5
+        with pytest.raises(RuntimeError, match="192 in-edges"):
+            net.check_last()
