@@ -605,7 +605,28 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     const float* Eg = reinterpret_cast<const float*>(S.edge_attr);
     const int an = (int)threadIdx.x >> 3, ah = (int)threadIdx.x & 7;          // the attention's (node, head) of this lane
     const float root = sqrtf(8.f);
+    // my node's in-edges do not change from layer to layer: degree and the first four (source row, edge id) pairs are read ONCE, and a
+    // layer's E rows of those edges are requested at the layer's entry — three Linear stages before the attention needs them
+    int at_lo = 0, at_dg = 0, at_sr[4] = {0, 0, 0, 0};
+    const float* at_er[4] = {Eg, Eg, Eg, Eg};
+    if (an < n) {
+      at_lo = erow[an];
+      at_dg = erow[an + 1] - at_lo;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < at_dg) {
+          at_sr[k] = esrc[at_lo + k];
+          at_er[k] = Eg + (int64_t)ecls[at_lo + k] * S.lde + 8 * ah;
+        }
+      }
+    }
     for (int l = 0; l < P.n_layers; ++l) {
+      f32x4 pe0[4], pe1[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        pe0[k] = zero4; pe1[k] = zero4;
+        if (k < at_dg) { pe0[k] = ld4(at_er[k] + l * D); pe1[k] = ld4(at_er[k] + l * D + 4); }
+      }
       const sn_gnn_layer& Lp = P.layers[l];
       const bool lastl = l + 1 == P.n_layers;
       // the stage matrices in launch order, running on into the next layer / the readout (what every stage prefetches two ahead)
@@ -631,11 +652,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         const f32x4 q0 = lds_ld4(Qi + an * LD + 8 * ah), q1 = lds_ld4(Qi + an * LD + 8 * ah + 4);
         f32x4 a0 = zero4, a1 = zero4;
         float z = 0.f;
-        const int e_lo = erow[an], e_hi = erow[an + 1];
-        for (int e = e_lo; e < e_hi; ++e) {
-          const int sr = esrc[e];
-          const float* er = Eg + (int64_t)ecls[e] * S.lde + l * D + 8 * ah;
-          const f32x4 e0 = ld4(er), e1 = ld4(er + 4);
+        auto edge = [&](int sr, f32x4 e0, f32x4 e1) {
           const f32x4 k0 = lds_ld4(Ki + sr * LD + 8 * ah), k1 = lds_ld4(Ki + sr * LD + 8 * ah + 4);
           const f32x4 v0 = lds_ld4(Vi + sr * LD + 8 * ah), v1 = lds_ld4(Vi + sr * LD + 8 * ah + 4);
           float sc = 0.f;
@@ -647,6 +664,13 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
           z += sw;
 #pragma unroll
           for (int c = 0; c < 4; ++c) { a0[c] += v0[c] * sw; a1[c] += v1[c] * sw; }
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < at_dg) edge(at_sr[k], pe0[k], pe1[k]);              // edge-id order: the first four from the prefetched rows
+        for (int e = at_lo + 4; e < at_lo + at_dg; ++e) {              // a node with more in-edges: the rest straight from memory
+          const float* er = Eg + (int64_t)ecls[e] * S.lde + l * D + 8 * ah;
+          edge(esrc[e], ld4(er), ld4(er + 4));
         }
         const float rz = 1.0f / (z + 1e-6f);
         sp_store4(A, an, ah >> 1, 2 * (ah & 1), a0 * rz);
