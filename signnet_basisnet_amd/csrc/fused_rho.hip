@@ -35,6 +35,12 @@ struct RhoStruct {
   float* out_sum;        // [N, d]
   const int32_t* node_graph;  // [N] graph of every node (register-attention variants: node-major bins)
   int N;
+  // phi's columns (sn_plan_bins): with all eigenvectors (kmax == 0) a node's slot rows are as many as its graph has nodes, so bin i
+  // of a column = node i of every member graph is a rho bin of the same shape as phi's slab bin (k_rho_wide, COLS)
+  const int32_t* bin_col;
+  const int32_t* col_bin0;
+  const int32_t* col_mem;
+  const int32_t* col_off;
 };
 
 // HP (head-padded layout, see sn_rho_params.head_pad): the tile count exceeds ceil(d/16), so every tile from the one holding
@@ -276,104 +282,12 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         float qh[DKMAX];
         const int hc = g * dk;
         constexpr int DKF = D / 4;      // head width when d fills the padded width (d = 128: 32; d = 64: 16)
-        constexpr bool MM_OK = (DKF % 16) == 0;                       // matrix-pipe attention: whole 16-channel tiles per head
-        const bool mm_attn = MM_OK && dk == DKF;                      // (uniform)
-        constexpr int QC = MM_OK ? DKF / 4 : 1;                       // channels of a head a lane group supplies to S = Q K^T
-        float qv[4][QC];                                              // q[my row][head h][QC g + s] / sqrt(dk)
-        if (mm_attn) {
 #pragma unroll
-          for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int c = 0; c < QC; c += 4) {
-              const f32x4 t = wave_live ? lds_ld4(Ar + h * DKF + QC * g + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-              qv[h][c] = t[0] * rtemp; qv[h][c + 1] = t[1] * rtemp; qv[h][c + 2] = t[2] * rtemp; qv[h][c + 3] = t[3] * rtemp;
-            }
-        } else {
-#pragma unroll
-          for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
-        }
+        for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
         // (q rows are written and read by the same wave only: no barrier before A is reused for v)
         wg_gemm_split<NT, NT, false, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
         lds_barrier();
-        if (mm_attn) {
-          // ======== K > 16 on the fp32 matrix pipe (round 3).  A node's rows are `pad` = 16 * nkt consecutive bin rows (its slots, tile
-          // aligned), my wave holds one 16-query tile of it; k lives in Bm, v in A.  Operand roles as in attention16.hip:
-          //   S^T tile = K_tile Q^T : A[i = key li][k] = k[key][c], B[k][j = query li] = q[query][c], c = QC g + s  (both operands of a lane
-          //     are values of its OWN row li: no transposes) -> lane (li, g) holds S[query li][key 16 kt + 4g + r]
-          //   O = P V               : A[i = query li][k = key 4g + s] = P (its own register s), B[k][j = c] = v[key][16 t + li]
-          // The scalar loop this replaces read every key and value row once PER LANE (16 ds_read_b128 per key and wave, ~1.5 k cycles per
-          // key); here a key tile costs QC + 4 * DKF/16 MFMAs per head with one or two LDS reads each.
-          const int nkt = (kv + 15) >> 4;                               // key tiles of my node (<= 4)
-          f32x4 sc[4][4];
-#pragma unroll
-          for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-              if (kt < nkt) {
-                const float* kr = Bm + (u0 + 16 * kt + li) * LD + h * DKF + QC * g;
-#pragma unroll
-                for (int c = 0; c < QC; c += 4) {
-                  const f32x4 kq = lds_ld4(kr + c);
-                  acc = mfma16(kq[0], qv[h][c], acc);
-                  acc = mfma16(kq[1], qv[h][c + 1], acc);
-                  acc = mfma16(kq[2], qv[h][c + 2], acc);
-                  acc = mfma16(kq[3], qv[h][c + 3], acc);
-                }
-              }
-              sc[h][kt] = acc;
-            }
-          // masked softmax over the keys of my query (registers r, lane groups g, key tiles kt)
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            float m = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-              for (int t = 0; t < 4; ++t)
-                if (16 * kt + 4 * g + t < kv) m = fmaxf(m, sc[h][kt][t]);
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float z = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const float e = (16 * kt + 4 * g + t < kv) ? expf(sc[h][kt][t] - m) : 0.f;
-                sc[h][kt][t] = e;
-                z += e;
-              }
-            z += __shfl_xor(z, 16, 64);
-            z += __shfl_xor(z, 32, 64);
-            const float zi = (kv > 0 && z > 0.f) ? 1.0f / z : 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-              for (int t = 0; t < 4; ++t) sc[h][kt][t] *= zi;
-          }
-          lds_barrier();   // all reads of k (Bm) are done: Bm receives the attention output
-          float* Bt = Bm + (wave * 16) * LD;                            // my tile's rows
-#pragma unroll
-          for (int h = 0; h < 4; ++h)
-#pragma unroll
-            for (int t = 0; t < DKF / 16; ++t) {
-              f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-              for (int kt = 0; kt < 4; ++kt)
-                if (kt < nkt) {
-                  const float* vr = A + (u0 + 16 * kt + 4 * g) * LD + h * DKF + 16 * t + li;
-                  acc = mfma16(sc[h][kt][0], vr[0], acc);
-                  acc = mfma16(sc[h][kt][1], vr[LD], acc);
-                  acc = mfma16(sc[h][kt][2], vr[2 * LD], acc);
-                  acc = mfma16(sc[h][kt][3], vr[3 * LD], acc);
-                }
-#pragma unroll
-              for (int t2 = 0; t2 < 4; ++t2) Bt[(4 * g + t2) * LD + h * DKF + 16 * t + li] = acc[t2];      // O[query 4g + t2][channel]
-            }
-          // (the attention output rows are written and read back by the same wave: no barrier, LDS operations of a wave are ordered)
-#pragma unroll
-          for (int kk = 0; kk < NT; ++kk) o[kk] = lds_ld4(Br + 16 * kk + 4 * g);
-        } else {
+        {
         float m = -INFINITY;
         float oh[DKMAX];
 #pragma unroll
@@ -532,6 +446,288 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
   ring.drain();
 }
 
+// =====================================================================================================
+// k_rho_wide (round 5): nodes of MORE than 16 slots, d in {64, 128} (whole 16-channel tiles per head).  What differs from
+// k_rho_fused<REGATTN = false>:
+//   * ONE LDS image instead of two.  q stays in registers (its accumulator layout IS the MFMA operand layout of S^T = K Q^T), k goes
+//     through the image, the scores and the softmax live in registers, v then goes through the SAME image and O^T = V^T P^T comes out
+//     in the operand layout of the output projection (no attention-output image).  45 KB ring + 33 KB image + 2 KB per layer of
+//     LayerNorm vectors = exactly 80 KB for a one-layer net: TWO workgroups per CU (the two-image form ran one, i.e. one wave per SIMD).
+//   * Nodes need not start on a 16-row tile.  A wave computes its 16 queries against every key tile of the bin that one of its
+//     queries' nodes touches (wave-uniform range) and masks each score by "key row inside my query's node" — so a bin is any set of whole
+//     nodes with <= 64 rows in total.
+//   * COLS (all eigenvectors, kmax == 0): a node of graph g has n_g slot rows, i.e. rho's units have exactly the shapes of phi's
+//     (graph, slot) slabs, and phi's columns (sn_batch_plan: graphs packed to <= 64 rows) are reused: bin i of a column = node i of every
+//     member graph with n_g > i.  On the bench batch (n uniform in 9..37): 1 302 bins at 92 % fill instead of 1 750 at 68 % — a
+//     33-37-slot node no longer owns a 64-row bin alone.  !COLS (16 < kmax < n): the closed-form per-graph bins (rho_bin0), nodes padded
+//     to whole tiles, same kernel body.
+//   * the slot sum is a [members x rows] . [rows x channels] product on the fp32 MFMA from the image (exact products by 0 / 1).
+// Reference semantics: model_utils/transformer_module.py:27-127 (post-LN encoder layer, softmax over the node's valid slots).
+// =====================================================================================================
+template <int NT, bool ONE, bool COLS>
+__global__ __launch_bounds__(RHO_R * 4, ONE ? 2 : 1) void k_rho_wide(RhoStruct S, sn_rho_params P) {
+  static_assert(NT == 4 || NT == 8, "head width 16 or 32");
+  constexpr int D = 16 * NT;
+  constexpr int LD = D + 4;
+  constexpr int NKB = (NT + 1) / 2;
+  constexpr int CPH = NT / 4;                                        // 16-channel tiles per head
+  using Ring = WRing<NT>;
+  extern __shared__ __align__(1024) unsigned char lds_raw[];
+  float* IMG = reinterpret_cast<float*>(lds_raw + Ring::BYTES);      // [RHO_R][LD]  k, then v, then the rows to be summed
+  float* lnv = IMG + RHO_R * LD;                                     // [n_layers][4][D]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
+  const int nbins = COLS ? S.meta[0] : S.meta[4];
+  if (S.meta[5] != 0 || (COLS && S.meta[1] != 0)) return;
+  const int d = P.d;
+  const float rtemp = 1.0f / sqrtf((float)(d / P.heads));
+  for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
+    const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
+    const sn_rho_layer& Lq = P.layers[l];
+    const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
+    lnv[i] = src[c];
+  }
+  __syncthreads();
+  Ring ring;
+  ring.init(lds_raw, wave, lane);
+  const void* wfirst = P.n_layers > 0 ? P.layers[0].wq : nullptr;
+  if (wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
+  float* IMGr = IMG + r * LD;
+
+  for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
+    // ---------------------------------------------------------------- bin -> member nodes (wave-uniform: scalar registers)
+    int m_off[8], m_len[8], m_node[8], m_gs[8];
+    if constexpr (COLS) {
+      const int colid = S.bin_col[bin];
+      const int i = bin - S.col_bin0[colid];                         // node index inside every member graph
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int gi_raw = S.col_mem[colid * 8 + k];
+        const int gi = gi_raw < 0 ? 0 : gi_raw;
+        const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
+        m_off[k] = S.col_off[colid * 8 + k];
+        m_len[k] = (gi_raw >= 0 && i < n) ? n : 0;                   // kmax == 0: K_g = n
+        m_node[k] = g0 + i;
+        m_gs[k] = g0;
+      }
+    } else {
+      int lo = 0, hi = S.B;                                          // the graph of the bin: largest g with rho_bin0[g] <= bin
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (S.rho_bin0[mid] <= bin) lo = mid; else hi = mid;
+      }
+      const int gs = S.graph_ptr[lo], n = S.graph_ptr[lo + 1] - gs;
+      const int kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
+      const int pad = ((kg + 15) >> 4) << 4;
+      const int upb = RHO_R / pad;
+      const int ub = (bin - S.rho_bin0[lo]) * upb;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        m_off[k] = k * pad;
+        m_len[k] = (k < upb && ub + k < n) ? kg : 0;
+        m_node[k] = gs + ub + k;
+        m_gs[k] = gs;
+      }
+    }
+    // my row; the key rows my wave's queries attend to
+    int u0 = 0, kv = 0, node = 0, gsr = 0;
+    int klo = RHO_R, khi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (r >= m_off[k] && r < m_off[k] + m_len[k]) { u0 = m_off[k]; kv = m_len[k]; node = m_node[k]; gsr = m_gs[k]; }
+      if (m_len[k] > 0 && m_off[k] < wave * 16 + 16 && m_off[k] + m_len[k] > wave * 16) {
+        klo = min(klo, m_off[k]);
+        khi = max(khi, m_off[k] + m_len[k]);
+      }
+    }
+    const int slot = r - u0;
+    const bool valid = kv > 0;
+    const bool wave_live = khi > 0;
+    const int kt_lo = klo >> 4, kt_hi = (khi + 15) >> 4;             // key tiles [kt_lo, kt_hi)
+    // ---------------------------------------------------------------- load x (+ eigenvalue encoding)
+    f32x4 x[NT];
+    auto load_x = [&]() {
+      int slot_ = slot, g_ = g;
+      asm volatile("" : "+v"(slot_), "+v"(g_));
+      const float* xr = S.x + (valid ? ((int64_t)node * S.K + slot_) : (int64_t)0) * D;
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const f32x4 v = ld4(xr + 16 * kk + 4 * g_);
+        x[kk] = valid ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    load_x();
+    if (valid && P.has_pos) {
+      const float ev = S.eigvals[gsr + slot];
+      const float t0 = fmaxf((ev * P.pe_w1[0]) * P.pe_bn0_scale[0] + P.pe_bn0_shift[0], 0.f);
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const int c = 16 * kk + 4 * g;
+        const f32x4 w2 = ld4(P.pe_w2 + c), s1 = ld4(P.pe_bn1_scale + c), h1 = ld4(P.pe_bn1_shift + c);
+        x[kk] += relu4((t0 * w2) * s1 + h1);
+      }
+    }
+    // ---------------------------------------------------------------- encoder layers
+#pragma unroll 1
+    for (int l = 0; l < (ONE ? 1 : P.n_layers); ++l) {
+      const sn_rho_layer& Lp = P.layers[l];
+      const void* wafter = (l + 1 < P.n_layers) ? P.layers[l + 1].wq : wfirst;
+      f32x4 o[NT];
+      Split8 sp[NKB];
+      if (wave_live) split_rows<NT>(x, sp);
+      {
+        f32x4 qf[NT];
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc * rtemp; });
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(IMGr + 16 * ot + 4 * g, acc); });
+        lds_barrier();
+        // S^T tile = K_tile Q^T on the fp32 MFMA: A[i = key li][k] = k[key][c], B[k][j = query li] = q[query][c], c = 16 ot + 4 g + t
+        // (both operands of a lane are values of its own lane row) -> lane (li, g) holds S[query li][key 16 kt + 4 g + t]
+        f32x4 sc[4][4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (wave_live && kt >= kt_lo && kt < kt_hi) {
+              const float* kr = IMG + (16 * kt + li) * LD + 16 * CPH * h + 4 * g;
+#pragma unroll
+              for (int j = 0; j < CPH; ++j) {
+                const f32x4 kq = lds_ld4(kr + 16 * j);
+                acc = mfma16(kq[0], qf[CPH * h + j][0], acc);
+                acc = mfma16(kq[1], qf[CPH * h + j][1], acc);
+                acc = mfma16(kq[2], qf[CPH * h + j][2], acc);
+                acc = mfma16(kq[3], qf[CPH * h + j][3], acc);
+              }
+            }
+            sc[h][kt] = acc;
+          }
+        // softmax over the keys of my query's node: key row 16 kt + 4 g + t is a key iff it lies in [u0, u0 + kv)
+        if (wave_live) {
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                if ((unsigned)(16 * kt + 4 * g + t - u0) < (unsigned)kv) m = fmaxf(m, sc[h][kt][t]);
+            m = group_allmax(m);
+            float z = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const float e = ((unsigned)(16 * kt + 4 * g + t - u0) < (unsigned)kv) ? expf(sc[h][kt][t] - m) : 0.f;
+                sc[h][kt][t] = e;
+                z += e;
+              }
+            z = row_allsum(z);
+            const float zi = (kv > 0 && z > 0.f) ? 1.0f / z : 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+              for (int t = 0; t < 4; ++t) sc[h][kt][t] *= zi;
+          }
+        }
+        lds_barrier();   // every wave has read its keys: the image receives v
+        wg_gemm_split<NT, NT, false, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(IMGr + 16 * ot + 4 * g, acc); });
+        lds_barrier();
+        // O^T tile = V^T P^T: A[i = channel li][k = key 4 g + s] = v[key][16 ot + li], B[k][j = query li] = P[query][key] (my own
+        // register s) -> lane (li, g) holds O[query li][16 ot + 4 g + r]: the operand layout of the output projection
+#pragma unroll
+        for (int ot = 0; ot < NT; ++ot) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            if (wave_live && kt >= kt_lo && kt < kt_hi) {
+              const float* vr = IMG + (16 * kt + 4 * g) * LD + 16 * ot + li;
+              acc = mfma16(vr[0], sc[ot / CPH][kt][0], acc);
+              acc = mfma16(vr[LD], sc[ot / CPH][kt][1], acc);
+              acc = mfma16(vr[2 * LD], sc[ot / CPH][kt][2], acc);
+              acc = mfma16(vr[3 * LD], sc[ot / CPH][kt][3], acc);
+            }
+          o[ot] = acc;
+        }
+      }
+      // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
+      if (wave_live) split_rows<NT>(o, sp);
+      if (ONE) load_x();   // the residual operand, straight from the input buffer
+      wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });
+      if (wave_live) {
+        int gl = g;
+        asm volatile("" : "+v"(gl));
+        masked_layernorm<NT>(x, lnv + (l * 4 + 0) * D, lnv + (l * 4 + 1) * D, P.ln_eps, d, gl, valid);
+        split_rows<NT>(x, sp);
+      }
+      // FFN: w2(relu(w1 y + b1)) + b2 + y -> LayerNorm               (transformer_module.py:113-127)
+      wg_gemm_split<NT, NT, false>(ring, Lp.w1, Lp.w2, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
+      if (wave_live) split_rows<NT>(o, sp);
+      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + x[ot]; });
+      if (wave_live) {
+        int gl = g;
+        asm volatile("" : "+v"(gl));
+        masked_layernorm<NT>(x, lnv + (l * 4 + 2) * D, lnv + (l * 4 + 3) * D, P.ln_eps, d, gl, valid);
+      }
+    }
+    // ---------------------------------------------------------------- sum over every node's slots -> out_sum[node, :]
+    // out[member][c] = sum_rows M[member][row] X[row][c], M = 0 / 1 membership: A[i = member li][k = row 4 s + g], B[k][j = channel li].
+    // Every wave publishes its rows (zeros for rows without a slot: 0 * stale would be NaN) and owns CPH channel tiles of the sums.
+#pragma unroll
+    for (int kk = 0; kk < NT; ++kk) lds_st4(IMGr + 16 * kk + 4 * g, valid ? x[kk] : f32x4{0.f, 0.f, 0.f, 0.f});
+    lds_barrier();
+    {
+      int mo = 0, ml = 0;                                            // member li (< 8) of this lane: first row, row count
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (li == k) { mo = m_off[k]; ml = m_len[k]; }
+      int nd[4];                                                     // node of member 4 g + t (stores: lane groups 0 and 1 only)
+      bool st[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        nd[t] = g == 0 ? m_node[t] : m_node[4 + t];
+        st[t] = g < 2 && (g == 0 ? m_len[t] : m_len[4 + t]) > 0;
+      }
+#pragma unroll
+      for (int j = 0; j < CPH; ++j) {
+        const int ct = wave * CPH + j;
+        const float* xc = IMG + g * LD + 16 * ct + li;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < RHO_R / 4; ++s) {
+          const float a = ((unsigned)(4 * s + g - mo) < (unsigned)ml) ? 1.f : 0.f;
+          acc = mfma16(a, xc[4 * s * LD], acc);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (st[t]) S.out_sum[(int64_t)nd[t] * D + 16 * ct + li] = acc[t];
+      }
+    }
+  }
+  ring.drain();
+}
+
+template <int NT, bool ONE, bool COLS>
+static int launch_rho_wide(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
+  constexpr int LD = 16 * NT + 4;
+  const size_t lds_fixed = (size_t)WRing<NT>::BYTES + (size_t)(RHO_R * LD) * sizeof(float);
+  const size_t lds_max = lds_fixed + (size_t)SN_RHO_MAX_LAYERS * 4 * 16 * NT * sizeof(float);
+  const size_t lds = lds_fixed + (size_t)(P.n_layers > 0 ? P.n_layers : 1) * 4 * 16 * NT * sizeof(float);
+  static int cus = 0;
+  if (cus == 0) {
+    if (lds_max > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_wide<NT, ONE, COLS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_max) != hipSuccess)
+      return fail(SN_ERR_LAUNCH, "sn_rho_fused_f32: cannot raise the dynamic LDS limit to %zu", lds_max);
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = n > 0 ? n : 256;
+  }
+  int64_t grid = bins_bound < (int64_t)2 * cus ? bins_bound : (int64_t)2 * cus;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((k_rho_wide<NT, ONE, COLS>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
+  return SN_OK;
+}
+
 template <int NT, bool REGATTN, bool ONE, bool HP = false>
 static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
@@ -600,7 +796,8 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   SN_REQUIRE(K > 0 && B >= 0 && N >= 0 && B < (1ll << 31), "sn_rho_fused_f32: bad sizes");
   if (B == 0 || N == 0) return SN_OK;
   SN_REQUIRE(N < (1ll << 31), "sn_rho_fused_f32: too many nodes");
-  RhoStruct S{x, eigen_values, graph_ptr, bins->rho_bin0, bins->meta, (int)B, kmax, K, out_sum, bins->node_graph, (int)N};
+  RhoStruct S{x, eigen_values, graph_ptr, bins->rho_bin0, bins->meta, (int)B, kmax, K, out_sum, bins->node_graph, (int)N,
+              bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem, bins->phi_col_off};
   hipStream_t st = (hipStream_t)stream;
   const int64_t bound = N + B;   // every bin holds at least one node
   // attention in registers when every node has <= 16 slots and the head width is a multiple of 16
@@ -621,6 +818,18 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
                "natural-layout parameters for this batch", kcap);
     const bool regattn = kcap <= 16 && ((P.d / P.heads) & 15) == 0;
     const int nt = (P.d + 15) / 16;
+    if (!regattn && (P.d == 64 || P.d == 128)) {
+      // more than 16 slots per node, whole 16-channel tiles per head: one-image kernel, unaligned nodes; with all eigenvectors
+      // (kmax == 0) on phi's columns (k_rho_wide)
+      const bool cols = kmax == 0 && bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off;
+      if (P.d == 128) {
+        if (cols) rc = one ? launch_rho_wide<8, true, true>(S, P, bound, st) : launch_rho_wide<8, false, true>(S, P, bound, st);
+        else rc = one ? launch_rho_wide<8, true, false>(S, P, bound, st) : launch_rho_wide<8, false, false>(S, P, bound, st);
+      } else {
+        if (cols) rc = one ? launch_rho_wide<4, true, true>(S, P, bound, st) : launch_rho_wide<4, false, true>(S, P, bound, st);
+        else rc = one ? launch_rho_wide<4, true, false>(S, P, bound, st) : launch_rho_wide<4, false, false>(S, P, bound, st);
+      }
+    } else
     rc = regattn ? (one ? dispatch_rho<true, true>(nt, S, P, bound, st) : dispatch_rho<true, false>(nt, S, P, bound, st))
                  : (one ? dispatch_rho<false, true>(nt, S, P, bound, st) : dispatch_rho<false, false>(nt, S, P, bound, st));
   }

@@ -102,6 +102,44 @@ def test_full_eigenvector_mode_uses_the_lds_attention_path():
     close(model.cuda().eval()(synth.batch_to(data, "cuda:0")), yref, "all-eigenvector forward")
 
 
+@pytest.mark.parametrize("variant,ctor,max_k,sizes", [
+    # k_rho_wide<8, ONE, COLS>: the reference's ZINC default (all eigenvectors), nodes unaligned inside phi's columns
+    ("gine", (None, None, 128, 1, 2, 2), None, [37, 27, 33, 31, 17, 21, 26, 9, 12, 64, 1, 2, 5, 40, 24, 16, 18, 46]),
+    # k_rho_wide<8, ONE, !COLS>: 16 < max_k < n — per-graph bins, nodes padded to whole tiles
+    ("gine", (None, None, 128, 1, 2, 2), 20, [37, 27, 33, 31, 17, 21, 26, 9, 12, 64, 1, 2, 5, 40, 24, 16, 18, 46]),
+    ("gine", (None, None, 64, 1, 2, 2), 33, [37, 27, 33, 31, 17, 21, 26, 9, 12, 64, 1, 2, 5, 40, 24, 16, 18, 46]),
+    # several encoder layers + the eigenvalue encoder (Alchemy tree at a width the wide kernel takes): !ONE instantiations
+    ("alchemy", (6, 4, 64, 12, 2, 2), None, [37, 27, 33, 31, 17, 21, 26, 9, 12, 64, 1, 2, 5, 40]),
+    ("alchemy", (6, 4, 128, 12, 2, 2), 24, [37, 27, 33, 9, 12, 64, 1, 2, 5, 40]),
+])
+def test_rho_with_more_than_16_slots_per_node(variant, ctor, max_k, sizes):
+    """The one-image rho kernel (k_rho_wide, round 5): its slot sum against the layer-at-a-time kernels and the fp32 / float64 oracle,
+    and the model output, in every instantiation family (columns of phi / per-graph bins, one layer / several + eigenvalue encoder)."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(3)
+    model = SignNetGNN(*ctor, variant=variant, max_k=max_k)
+    PU.bn_randomize(model, 2)
+    data = synth.make_batch(len(sizes), seed=11, sizes=sizes, features="alchemy" if variant == "alchemy" else "zinc")
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = O.make_cfg(variant, *ctor)
+    o32, o64 = {}, {}
+    with torch.no_grad():
+        y32 = O.signnet_gnn(sd, cfg, data, training=False, max_k=max_k, out=o32)
+        y64 = O.signnet_gnn(PU.to_f64(sd), cfg, PU.data_f64(data), training=False, max_k=max_k, out=o64)
+    model = model.cuda().eval()
+    dd = synth.batch_to(data, "cuda:0")
+    with torch.no_grad():
+        y = model(dd)
+        model.check_last()
+        _, st = model(dd, return_stages=True)
+    assert not torch.isnan(st["rho_sum_fused"]).any()
+    close(st["rho_sum_fused"], o32["rho_sum"], "fused rho slot sum vs oracle", ref64=o64["rho_sum"])
+    close(st["rho_sum_fused"], st["rho_sum"], "fused rho slot sum vs layer kernels", ref64=o64["rho_sum"])
+    close(y, y32, "model output", ref64=y64)
+
+
 @pytest.mark.parametrize("variant,ctor,feat,max_k", [
     ("gine", (None, None, 128, 1, 4, 6), "zinc", 16),
     ("gine", (None, None, 64, 1, 4, 6), "zinc", 8),
