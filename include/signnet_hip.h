@@ -69,16 +69,46 @@ typedef struct {
   int32_t* phi_col_off;   /* [B][8]          row offset of each member inside a bin                       */
   /* rho (sn_rho_fused_f32): a node's K_g slot rows padded to 16*ceil(K_g/16); 64/pad nodes per bin, per graph */
   int32_t* rho_bin0;      /* [B+1]           first bin of each graph                                      */
-  int32_t* meta;          /* [8]  phi: nbins, error, real rows, columns ; rho: nbins, error, real rows, 0 */
+  int32_t* meta;          /* [8]  phi: nbins, error, real rows, columns ; rho: nbins, error, real rows ; [7] record bins (phi_bin_mem) */
   const int32_t* node_graph; /* [N] sn_batch_plan's node_graph output (set by the caller): with <= 16 slots per node rho uses
                                 node-major bins — four consecutive nodes of the batch per bin, ceil(N/4) bins — instead of rho_bin0 */
+  /* Member records of every bin, what the stage kernels walk (may be NULL: sn_phi_fused_f32 / the wide rho kernel then need it):
+   * [phi_max_bins][8] word pairs, 16-byte aligned; word 0 = graph | index << 13 | row offset << 19 | (rows - 1) << 25 (-1: no
+   * member), word 1 = first node of the graph.  A member is one SLAB of a graph of n nodes: phi reads it as the n node rows of
+   * eigenvector slot `index`; with all eigenvectors (kmax = 0) rho reads it as the n slot rows of node `index` (same shapes, same
+   * bins).  meta[7] = number of record bins.  kmax != 0: the bins of the columns above.  kmax = 0 (one-launch plan): slabs of
+   * ANY graphs packed best-fit-decreasing per bin (98-99 % fill where the columns reach 92 %: a column's bins above its shorter
+   * members hold only the taller ones), so meta[7] <= meta[0]. */
+  int32_t* phi_bin_mem;
 } sn_plan_bins;
+
+/* Early report of a batch's flags (sn_batch_plan_ex): the workgroups of the one-launch plan write them to PINNED host memory as they
+ * finish — the host learns "can the fused stages serve this batch" ~20 us into a forward instead of after its last kernel.
+ * host: int32[16], zeroed by the caller before the launch:
+ *   [0] status[0] (malformed batch)   [1] largest graph (nodes)   [2] largest in-degree   [3] 1: a graph has > max_graph_edges in-edges
+ *   [4] meta[1] (phi bins: 1 = a graph of > 64 nodes)   [5] meta[5] (rho bins)   [6] 1: a feature id outside its embedding tables
+ *   [8..11] set to 1 by the CSR / phi-bin / rho-bin / feature-id workgroup AFTER its words above (poll all four).
+ * node_ids / edge_ids (may be NULL): the int64 feature ids of the DiscreteEncoders that consume this batch (every column of data.x /
+ * data.edge_attr, model_utils/elements.py:21-37) and the row count of their tables: nn.Embedding's IndexError, decided here. */
+typedef struct {
+  const int64_t* node_ids; int64_t n_node_ids; int64_t node_vocab;
+  const int64_t* edge_ids; int64_t n_edge_ids; int64_t edge_vocab;
+  int max_graph_edges;     /* > 0: the in-edge capacity of the fused GINE stage (192) */
+  int reserved;
+  int32_t* host;
+} sn_plan_early;
 
 int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index, int64_t E,
                   int kmax, int32_t* graph_ptr, int32_t* node_graph, int32_t* nvalid, int64_t* evoff,
                   int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* status,
                   const sn_plan_bins* bins /* host struct of device pointers, or NULL */,
                   int32_t* scratch, void* stream);
+/* the same with the early report (one-launch plan only: sn_batch_plan_early_supported(N, E, B) != 0); early = NULL: sn_batch_plan */
+int sn_batch_plan_ex(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index, int64_t E,
+                     int kmax, int32_t* graph_ptr, int32_t* node_graph, int32_t* nvalid, int64_t* evoff,
+                     int32_t* rowptr, int32_t* col, int32_t* eperm, int32_t* status,
+                     const sn_plan_bins* bins, int32_t* scratch, const sn_plan_early* early, void* stream);
+int sn_batch_plan_early_supported(int64_t N, int64_t E, int64_t B);
 int64_t sn_phi_bins_bound(int64_t B, int kmax);
 
 /* Eigen-data packing.  Replaces to_dense_list_EVD (transform.py:52-61): x0[node, j] = V_b[local, j]

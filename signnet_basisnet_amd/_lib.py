@@ -25,6 +25,8 @@ SIGNATURES = {
     "sn_version": [],
     "sn_device_info": [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "sn_batch_plan_ex": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    "sn_batch_plan_early_supported": [_l, _l, _l],                # (returns 0 / 1, not a status)
     "sn_pack_eig_f32": [_p, _p, _p, _p, _p, _p, _l, _i, _p, _p, _p],
     "sn_pack_weight_f32": [_p, _i, _i, _i, _p, _p],
     "sn_pack_weight_t_f32": [_p, _i, _i, _i, _p, _p],

@@ -53,11 +53,9 @@ struct PhiStruct {
   const int64_t* evoff;
   const int32_t* rowptr;
   const int32_t* col;
-  const int32_t* bin_col;    // [nbins]   column of every bin
-  const int32_t* col_bin0;   // [ncol+1]  first bin of every column
-  const int32_t* col_mem;    // [ncol][8] member graphs (-1 = none)
-  const int32_t* col_off;    // [ncol][8] row offset of each member inside a bin
-  const int32_t* meta;       // [0] nbins, [1] error
+  const int32_t* bin_mem;    // [nbins][8][2] member records of every bin (sn_plan_bins.phi_bin_mem): graph | slot << 13 | row offset << 19 |
+                             //               (rows - 1) << 25 (-1 = none), first node of the graph
+  const int32_t* meta;       // [7] nbins, [1] error
   int64_t max_bins;
   int kmax;
   int K;
@@ -73,11 +71,12 @@ static __device__ long long g_tl[1024][8];
 #endif
 
 constexpr int PHI_NBR = 8;   // in-neighbours of a row kept in LDS (more: read from the CSR in global memory)
-// Row descriptors of PHI_GB bins at a time: a bin's decode (bin -> column -> member graph -> node -> CSR range, eigenvector entry, first
-// in-neighbours) is a chain of five dependent global loads, ~7 k cycles when done per bin (7.5 % of a bin); the eight waves of the
-// workgroup decode the next eight bins of the workgroup in one pass instead — one wave per bin — and park the result in LDS.
+// Row descriptors of PHI_GB bins at a time: a bin's decode (bin -> member records -> node -> CSR range, eigenvector entry, first
+// in-neighbours) is a chain of dependent global loads (five levels through the planner's columns until round 4: ~7 k cycles per
+// bin; three since the planner writes per-bin member records); the eight waves of the workgroup decode the next eight bins of the
+// workgroup in one pass — one wave per bin — and park the result in LDS.
 constexpr int PHI_GB = PHI_WAVES;
-constexpr int PHI_DESC_BYTES = 5 * PHI_GB * PHI_R * 4 + PHI_GB * 4 + PHI_GB * PHI_R + PHI_GB * PHI_R * PHI_NBR;
+constexpr int PHI_DESC_BYTES = 5 * PHI_GB * PHI_R * 4 + PHI_GB * PHI_R + PHI_GB * PHI_R + PHI_GB * PHI_R * PHI_NBR;
 
 // HID1: layer 0 is Linear(1->1).BN.ReLU.Linear(1->d) (GINESignNetPyG) — no [d,d] GEMM in layer 0; else Linear(1->d)...Linear(d->d)
 // (Alchemy).  A template parameter so that the variant without the layer-0 GEMM does not carry its registers.
@@ -100,8 +99,8 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   int* delo = dnode + PHI_GB * PHI_R;                           // [GB][PHI_R] first in-edge (CSR position)
   int* ddeg = delo + PHI_GB * PHI_R;                            // [GB][PHI_R] in-degree
   int* dgs = ddeg + PHI_GB * PHI_R;                             // [GB][PHI_R] first node of the row's graph
-  int* dslot = dgs + PHI_GB * PHI_R;                            // [GB] eigenvector slot of the bin
-  unsigned char* drow0 = reinterpret_cast<unsigned char*>(dslot + PHI_GB);   // [GB][PHI_R] bin row of the graph's first node
+  unsigned char* dslot = reinterpret_cast<unsigned char*>(dgs + PHI_GB * PHI_R);   // [GB][PHI_R] eigenvector slot of the row's slab
+  unsigned char* drow0 = dslot + PHI_GB * PHI_R;                // [GB][PHI_R] bin row of the graph's first node
   unsigned char* dnbr = drow0 + PHI_GB * PHI_R;                 // [GB][PHI_R][PHI_NBR] bin rows of the first in-neighbours
   float* l0v = reinterpret_cast<float*>(lds_raw + Ring::BYTES + 2 * PHI_R * LD * sizeof(float) + PHI_DESC_BYTES);   // [4][D] layer-0 vectors
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   float* X = X2 + sg * PHI_R * LD;                              // the image of my sign
   const int r = (wave & 3) * 16 + (lane & 15), g = lane >> 4;
   SN_TL(0);
-  const int nbins = S.meta[0];
+  const int nbins = S.meta[7];
   if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
   { SN_PROF_ON(true); SN_STAMP(12); }
 #ifdef SN_PROFILE
@@ -155,24 +154,20 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       const int dbin = base + wave * (int)gridDim.x;
       if (dbin < nbins) {
         const int rr = lane;
-        const int colid = S.bin_col[dbin];
-        const int slot = dbin - S.col_bin0[colid];       // every member contributes its slab of eigenvector `slot`
-        // (all eight member slots are decoded at once — wave-uniform scalar loads with no serial dependence between
-        //  members; an empty slot (-1) reads graph 0 and is masked out)
-        int node = -1, gs = 0, row0 = 0, gsel = 0, nsel = 0;
+        // (the eight member records are decoded at once — wave-uniform scalar loads with no serial dependence between members)
+        const int32_t* rec = S.bin_mem + (int64_t)dbin * 16;
+        int node = -1, gs = 0, row0 = 0, gsel = 0, nsel = 0, slot = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int gi_raw = S.col_mem[colid * 8 + k];
-          const int gi = gi_raw < 0 ? 0 : gi_raw;
-          const int off = S.col_off[colid * 8 + k];
-          const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
-          const int kg = DGL ? S.kmax : ((S.kmax > 0 && n > S.kmax) ? S.kmax : n);
-          if (gi_raw >= 0 && rr >= off && rr < off + n && slot < kg) {
+          const int w0 = rec[2 * k], g0 = rec[2 * k + 1];
+          const int off = (w0 >> 19) & 63, n = ((w0 >> 25) & 63) + 1, sl = (w0 >> 13) & 63;
+          if (w0 >= 0 && rr >= off && rr < off + n && sl < S.K) {      // (sl < K: a caller's K smaller than the batch's slot count must not write outside `out`)
             node = g0 + (rr - off);
             gs = g0;
             row0 = off;
-            gsel = gi;
+            gsel = w0 & 8191;
             nsel = n;
+            slot = sl;
           }
         }
         int e_lo = 0, e_hi = 0;
@@ -186,8 +181,8 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
         int o = wave * PHI_R + rr;
         asm volatile("" : "+v"(o));      // (else the six descriptor addresses are hoisted out of the bin loop and one of them spills)
         dxs[o] = xval; dnode[o] = node; delo[o] = e_lo; ddeg[o] = deg; dgs[o] = gs; drow0[o] = (unsigned char)row0;
+        dslot[o] = (unsigned char)slot;
         for (int e = 0; e < deg && e < PHI_NBR; ++e) dnbr[o * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
-        if (lane == 0) dslot[wave] = slot;
       }
     }
     __syncthreads();
@@ -401,7 +396,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       }
       lds_barrier();
       if (LIVE && valid && !DGL) {
-        float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb]) * P.d;       // (re-read: not kept live across the layers)
+        float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb * PHI_R + r]) * P.d;       // (re-read: not kept live across the layers)
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;     // the same row in the other sign's image
         constexpr int H = (NT + 1) / 2;
         // (d % 4 == 0 is an entry-point requirement: whole float4 per lane; only the last 16-channel tile can be partial)
@@ -418,7 +413,7 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
       }
       if (LIVE && valid && DGL) {
         const int dout = P.reserved;                               // phi_out_dim: any width <= d (rows are not float4-aligned)
-        float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb]) * dout;
+        float* orow = S.out + ((int64_t)dnode[lb * PHI_R + r] * S.K + dslot[lb * PHI_R + r]) * dout;
         const float* XO = X2 + (1 - sg) * PHI_R * LD + r * LD;
         constexpr int H = (NT + 1) / 2;
 #pragma unroll
@@ -491,8 +486,7 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
                                 const int64_t* evoff, const int32_t* rowptr, const int32_t* col,
                                 const sn_plan_bins* bins, int kmax, int K, float* out, void* stream) {
   SN_REQUIRE(params && eigen_vectors && graph_ptr && evoff && rowptr && bins && out, "sn_phi_fused_f32: null pointer");
-  SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->meta,
-             "sn_phi_fused_f32: incomplete sn_plan_bins");
+  SN_REQUIRE(bins->phi_bin_mem && bins->meta, "sn_phi_fused_f32: incomplete sn_plan_bins (phi_bin_mem, meta)");
   const sn_phi_params& P = *params;
   SN_REQUIRE(P.d > 0 && P.d <= 128 && (P.d & 3) == 0, "sn_phi_fused_f32: hidden width %d must be a multiple of 4 in (0, 128]", P.d);
   SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS, "sn_phi_fused_f32: %d layers unsupported", P.n_layers);
@@ -506,8 +500,7 @@ extern "C" int sn_phi_fused_f32(const sn_phi_params* params, const float* eigen_
   }
   SN_REQUIRE(K > 0 && bins->phi_max_bins >= 0, "sn_phi_fused_f32: bad K / max_bins");
   if (bins->phi_max_bins == 0) return SN_OK;
-  PhiStruct S{eigen_vectors, graph_ptr, evoff, rowptr, col, bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem,
-              bins->phi_col_off, bins->meta, bins->phi_max_bins, kmax, K, out, 0};
+  PhiStruct S{eigen_vectors, graph_ptr, evoff, rowptr, col, bins->phi_bin_mem, bins->meta, bins->phi_max_bins, kmax, K, out, 0};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   const int nt = (P.d + 15) / 16;
@@ -544,8 +537,7 @@ extern "C" int sn_deepsigns_phi_f32(const sn_phi_params* params, const float* x,
                                     const int32_t* rowptr, const int32_t* col, const sn_plan_bins* bins, int K, float* out,
                                     void* stream) {
   SN_REQUIRE(params && x && graph_ptr && rowptr && bins && out, "sn_deepsigns_phi_f32: null pointer");
-  SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->meta,
-             "sn_deepsigns_phi_f32: incomplete sn_plan_bins");
+  SN_REQUIRE(bins->phi_bin_mem && bins->meta, "sn_deepsigns_phi_f32: incomplete sn_plan_bins (phi_bin_mem, meta)");
   const sn_phi_params& P = *params;
   SN_REQUIRE(P.d >= 48 && P.d <= 112 && (P.d & 15) == 0, "sn_deepsigns_phi_f32: padded hidden width %d must be a multiple of 16 in [48, 112]", P.d);
   SN_REQUIRE(P.n_layers >= 1 && P.n_layers <= SN_PHI_MAX_LAYERS && P.hid0 == P.d, "sn_deepsigns_phi_f32: bad layer count / hid0");
@@ -557,8 +549,7 @@ extern "C" int sn_deepsigns_phi_f32(const sn_phi_params* params, const float* x,
   }
   SN_REQUIRE(K > 0 && K <= 64 && ldx >= K && bins->phi_max_bins >= 0, "sn_deepsigns_phi_f32: bad K / ldx / max_bins");
   if (bins->phi_max_bins == 0) return SN_OK;
-  PhiStruct S{x, graph_ptr, nullptr, rowptr, col, bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem,
-              bins->phi_col_off, bins->meta, bins->phi_max_bins, K, K, out, ldx};
+  PhiStruct S{x, graph_ptr, nullptr, rowptr, col, bins->phi_bin_mem, bins->meta, bins->phi_max_bins, K, K, out, ldx};
   hipStream_t st = (hipStream_t)stream;
   int rc = SN_OK;
   switch (P.d / 16) {

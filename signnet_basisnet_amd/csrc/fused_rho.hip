@@ -35,12 +35,10 @@ struct RhoStruct {
   float* out_sum;        // [N, d]
   const int32_t* node_graph;  // [N] graph of every node (register-attention variants: node-major bins)
   int N;
-  // phi's columns (sn_plan_bins): with all eigenvectors (kmax == 0) a node's slot rows are as many as its graph has nodes, so bin i
-  // of a column = node i of every member graph is a rho bin of the same shape as phi's slab bin (k_rho_wide, COLS)
-  const int32_t* bin_col;
-  const int32_t* col_bin0;
-  const int32_t* col_mem;
-  const int32_t* col_off;
+  // the planner's bin member records (sn_plan_bins.phi_bin_mem): with all eigenvectors (kmax == 0) a node's slot rows are as many as
+  // its graph has nodes, so phi's slab bins are rho bins too — record (graph, index, offset) = the n slot rows of node `index` of the
+  // graph at bin row `offset` (k_rho_wide, COLS)
+  const int32_t* bin_mem;
 };
 
 // HP (head-padded layout, see sn_rho_params.head_pad): the tile count exceeds ceil(d/16), so every tile from the one holding
@@ -457,9 +455,10 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
 //     queries' nodes touches (wave-uniform range) and masks each score by "key row inside my query's node" — so a bin is any set of whole
 //     nodes with <= 64 rows in total.
 //   * COLS (all eigenvectors, kmax == 0): a node of graph g has n_g slot rows, i.e. rho's units have exactly the shapes of phi's
-//     (graph, slot) slabs, and phi's columns (sn_batch_plan: graphs packed to <= 64 rows) are reused: bin i of a column = node i of every
-//     member graph with n_g > i.  On the bench batch (n uniform in 9..37): 1 302 bins at 92 % fill instead of 1 750 at 68 % — a
-//     33-37-slot node no longer owns a 64-row bin alone.  !COLS (16 < kmax < n): the closed-form per-graph bins (rho_bin0), nodes padded
+//     (graph, slot) slabs, and the planner's bin member records (sn_plan_bins.phi_bin_mem: slabs of any graphs packed to <= 64 rows) are
+//     reused: record (graph, index) = node `index` of the graph.  On the bench batch (n uniform in 9..37): 1 208 bins at 99 % fill
+//     (1 302 at 92 % on phi's columns until the planner packed slabs; 1 750 at 68 % with tile-aligned nodes) — a 33-37-slot node no
+//     longer owns a 64-row bin alone.  !COLS (16 < kmax < n): the closed-form per-graph bins (rho_bin0), nodes padded
 //     to whole tiles, same kernel body.
 //   * the slot sum is a [members x rows] . [rows x channels] product on the fp32 MFMA from the image (exact products by 0 / 1).
 // Reference semantics: model_utils/transformer_module.py:27-127 (post-LN encoder layer, softmax over the node's valid slots).
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(RHO_R * 4, ONE ? 2 : 1) void k_rho_wide(RhoStruct S
   float* lnv = IMG + RHO_R * LD;                                     // [n_layers][4][D]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
-  const int nbins = COLS ? S.meta[0] : S.meta[4];
+  const int nbins = COLS ? S.meta[7] : S.meta[4];
   if (S.meta[5] != 0 || (COLS && S.meta[1] != 0)) return;
   const int d = P.d;
   const float rtemp = 1.0f / sqrtf((float)(d / P.heads));
@@ -498,16 +497,14 @@ __global__ __launch_bounds__(RHO_R * 4, ONE ? 2 : 1) void k_rho_wide(RhoStruct S
     // ---------------------------------------------------------------- bin -> member nodes (wave-uniform: scalar registers)
     int m_off[8], m_len[8], m_node[8], m_gs[8];
     if constexpr (COLS) {
-      const int colid = S.bin_col[bin];
-      const int i = bin - S.col_bin0[colid];                         // node index inside every member graph
+      const int32_t* rec = S.bin_mem + (int64_t)bin * 16;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int gi_raw = S.col_mem[colid * 8 + k];
-        const int gi = gi_raw < 0 ? 0 : gi_raw;
-        const int g0 = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - g0;
-        m_off[k] = S.col_off[colid * 8 + k];
-        m_len[k] = (gi_raw >= 0 && i < n) ? n : 0;                   // kmax == 0: K_g = n
-        m_node[k] = g0 + i;
+        const int w0 = rec[2 * k], g0 = rec[2 * k + 1];
+        const int n = ((w0 >> 25) & 63) + 1;                         // kmax == 0: K_g = n
+        m_off[k] = (w0 >> 19) & 63;
+        m_len[k] = (w0 >= 0 && n <= S.K) ? n : 0;                    // (n <= K: a caller's K smaller than the graph must not read outside x)
+        m_node[k] = g0 + ((w0 >> 13) & 63);
         m_gs[k] = g0;
       }
     } else {
@@ -797,7 +794,7 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
   if (B == 0 || N == 0) return SN_OK;
   SN_REQUIRE(N < (1ll << 31), "sn_rho_fused_f32: too many nodes");
   RhoStruct S{x, eigen_values, graph_ptr, bins->rho_bin0, bins->meta, (int)B, kmax, K, out_sum, bins->node_graph, (int)N,
-              bins->phi_bin_col, bins->phi_col_bin0, bins->phi_col_mem, bins->phi_col_off};
+              bins->phi_bin_mem};
   hipStream_t st = (hipStream_t)stream;
   const int64_t bound = N + B;   // every bin holds at least one node
   // attention in registers when every node has <= 16 slots and the head width is a multiple of 16
@@ -821,7 +818,7 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
     if (!regattn && (P.d == 64 || P.d == 128)) {
       // more than 16 slots per node, whole 16-channel tiles per head: one-image kernel, unaligned nodes; with all eigenvectors
       // (kmax == 0) on phi's columns (k_rho_wide)
-      const bool cols = kmax == 0 && bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off;
+      const bool cols = kmax == 0 && bins->phi_bin_mem != nullptr;
       if (P.d == 128) {
         if (cols) rc = one ? launch_rho_wide<8, true, true>(S, P, bound, st) : launch_rho_wide<8, false, true>(S, P, bound, st);
         else rc = one ? launch_rho_wide<8, true, false>(S, P, bound, st) : launch_rho_wide<8, false, false>(S, P, bound, st);

@@ -22,7 +22,29 @@ struct BinsDev {  // device view of sn_plan_bins
   int32_t* phi_col_off;
   int32_t* rho_bin0;
   int32_t* meta;
+  int32_t* phi_bin_mem;   // [phi_max_bins][16] member records of every bin (see sn_plan_bins), or null
 };
+
+// Early report of the batch's flags to pinned host memory (sn_plan_early): every workgroup of the one-launch plan writes the words it
+// owns and then its own "done" word — no counter to zero, no extra launch.
+struct EarlyDev {
+  const int64_t* node_ids;
+  long long n_node_ids, node_vocab;
+  const int64_t* edge_ids;
+  long long n_edge_ids, edge_vocab;
+  int max_graph_edges;
+  int32_t* host;          // null: no report
+};
+enum { EH_ERR = 0, EH_NMAX = 1, EH_DEGMAX = 2, EH_EDGES = 3, EH_PHI = 4, EH_RHO = 5, EH_IDS = 6, EH_DONE = 8 };
+__device__ __forceinline__ void early_put(int32_t* host, int i, int v) {
+  __hip_atomic_store(&host[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// (thread 0 of a block, after its early_put()s)
+__device__ __forceinline__ void early_done(int32_t* host, int block) {
+  __threadfence_system();
+  __hip_atomic_store(&host[EH_DONE + block], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+}
 
 // exclusive scan of one int per thread over a PLAN_T-thread workgroup; wsum: LDS int[32]; returns the exclusive
 // prefix, *total gets the grand total (valid for every thread).
@@ -96,14 +118,16 @@ __device__ __forceinline__ int phi_slots_of(int n, int kmax) { return kmax < 0 ?
 //      tile; 64/p units per bin, bins never mix graphs -> closed form, no sequential pass.
 // gp: graph_ptr in LDS ([B+1]); lds: int scratch [5*B + 3*66 + 32 + 4].
 #ifdef SN_PROFILE
-static __device__ long long g_pprof[32];
+static __device__ long long g_pprof[64];
 #define PL_STAMP(i) do { if (threadIdx.x == 0) g_pprof[(i) + 16 * blockIdx.x] = clock64(); } while (0)
+#define PL_STAMP_T(i, thr) do { if (threadIdx.x == (thr)) g_pprof[(i) + 16 * blockIdx.x] = clock64(); } while (0)
 #else
 #define PL_STAMP(i) do { } while (0)
+#define PL_STAMP_T(i, thr) do { } while (0)
 #endif
 
 // rho bins (closed form per graph + a prefix): independent of the phi columns — its own workgroup in the single-launch plan
-__device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
+__device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* lds, int32_t* early_host = nullptr) {
   const int t = threadIdx.x;
   int* nbv = lds;               // [B]   rho bins per graph
   int* wsum = lds + B;          // [32]
@@ -145,7 +169,7 @@ __device__ void plan_rho_block(const int* gp, int B, int kmax, BinsDev bd, int* 
     bd.meta[4] = total;
     bd.meta[5] = (s_rerr & 2);
     bd.meta[6] = rtot;
-    bd.meta[7] = 0;
+    if (early_host != nullptr) early_put(early_host, EH_RHO, s_rerr & 2);
   }
 }
 
@@ -156,8 +180,26 @@ __device__ __forceinline__ int writelane(int vec, int val, int lane) {
   return vec;
 }
 
-__device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds) {
+// Slab-level packing of the all-eigenvector mode (kmax == 0; `pat` != null).  There a graph of n nodes is n slabs of n rows (phi: one
+// per eigenvector; rho: one per node, n slot rows each), and column packing leaves the bins above a column's shorter members part
+// empty (bench batch, n uniform in 9..37: 1 302 bins at 92 % fill, six rounds of 256 workgroups).  Packing the SLABS — any slabs
+// of any graphs, best-fit-decreasing on the size classes, <= 8 per bin — reaches 98-99 % (1 208 bins, five rounds).  The chain
+// walks bin PATTERNS, not slabs: with c_s = s * (graphs of size s) slabs per class the greedy choice repeats until a class of the
+// pattern runs out, so one link covers r = min_s floor(left_s / copies_s) identical bins and every link retires a class (or leaves
+// it fewer slabs than the pattern took): a few dozen links on a ZINC batch, at most PAT_MAX (from PAT_MAX - 64 links on the
+// remaining classes are emitted one slab per bin, which needs at most 64 more).  A pattern is expanded into its bins' member
+// records in parallel afterwards: slab q of class s is (graph = q / s-th of the class in id order, index = q % s).
+constexpr int PAT_MAX = 160;
+constexpr int PAT_INTS = (PAT_MAX + 1) + PAT_MAX + 2 * 8 * PAT_MAX;   // first bin [PAT_MAX+1] | members [PAT_MAX] | member words | slab bases
+
+__device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds, int* pat, int32_t* early_host = nullptr) {
   const int t = threadIdx.x;
+  const bool slab = pat != nullptr && kmax == 0 && bd.phi_bin_mem != nullptr;
+  int* pat_first = pat;                          // [PAT_MAX + 1]
+  int* pat_nm = pat + (PAT_MAX + 1);             // [PAT_MAX]
+  int* pat_mem = pat_nm + PAT_MAX;               // [PAT_MAX][8]  class | row offset << 7 | copy index << 13
+  int* pat_base = pat_mem + 8 * PAT_MAX;         // [PAT_MAX][8]  first slab of the member's class this pattern takes (+ copy index)
+  __shared__ int s_npat, s_slab_bins;
   int* bucket = lds;            // [B]   graph ids grouped by size, ascending id inside a group
   int* nbv = lds + B;           // [B]   (record scratch of the column packing)
   int* hist = lds + 2 * B;      // [66]
@@ -199,11 +241,68 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* col_start = rec_pre + B;                // [B] record index of every column's first member
   int* col_bin = col_start + B;                // [B + 1] first bin of every column
   PL_STAMP(4);
-  if (t >= 64) {
-    // ---- meanwhile, on the other 15 waves: the graphs of every size class in ascending id order (`bucket`; the packer only needs the
+  const int rank_t0 = slab ? 128 : 64;             // first thread of the id-ranking waves
+  if (slab && t >= 64 && t < 128) {
+    // ---- wave 1, all-eigenvector mode: the slab-level pattern chain (see above).  State in registers: lane s-1 holds class s's
+    //      unplaced / placed slab counts; the members of the pattern being built sit in lanes 0..7 of two registers and go to LDS
+    //      with one store per pattern; the run length is a float-reciprocal quotient (corrected to the exact floor) reduced over
+    //      the pattern's classes by a ballot walk (<= 8 set bits) — no LDS round trip inside a link.
+    const int lane = t - 64;
+    int cnt = hist[lane + 1] * (lane + 1);          // slabs of class s = lane + 1 not yet placed
+    int used = 0;                                   // ... and placed
+    unsigned long long avail = __ballot(cnt > 0);
+    int np = 0, nb = 0;
+    while (avail) {
+      int mult = 0;                                 // copies of my class in this pattern
+      int pm = -1, pb = 0;                          // lanes 0..7: the pattern's member words / first slabs
+      int cap = 64, nm = 0;
+      int cls = 64 - __clzll(avail);
+      const bool single = np >= PAT_MAX - 64;
+      while (true) {
+        const int copies = __builtin_amdgcn_readlane(mult, cls - 1);
+        const int left = __builtin_amdgcn_readlane(cnt, cls - 1) - copies;
+        if (left > 0 && cls <= cap && nm < 8) {
+          pm = writelane(pm, cls | ((64 - cap) << 7) | (copies << 13), nm);
+          pb = writelane(pb, __builtin_amdgcn_readlane(used, cls - 1) + copies, nm);
+          mult = writelane(mult, copies + 1, cls - 1);
+          cap -= cls;
+          ++nm;
+          if (single) break;
+          continue;                                 // another slab of the same class, if it fits
+        }
+        const int limit = cap < cls - 1 ? cap : cls - 1;      // next: the largest class below this one that still fits
+        if (limit <= 0 || nm >= 8) break;
+        const unsigned long long m = avail & ((1ull << limit) - 1ull);    // 0 < limit < 64
+        if (!m) break;
+        cls = 64 - __clzll(m);
+      }
+      // run length r = min over the pattern's classes of floor(cnt / mult)   (cnt < 2^24: the float quotient is within one of it)
+      int q = 0;
+      if (mult > 0) {
+        q = (int)((float)cnt * __frcp_rn((float)mult));
+        q += ((q + 1) * mult <= cnt) ? 1 : 0;
+        q -= (q * mult > cnt) ? 1 : 0;
+      }
+      int r = 0x7fffffff;
+      for (unsigned long long pmask = __ballot(mult > 0); pmask; pmask &= pmask - 1) {
+        const int qc = __builtin_amdgcn_readlane(q, __builtin_ctzll(pmask));
+        r = qc < r ? qc : r;
+      }                                            // r >= 1: every class of the pattern had its copies left
+      cnt -= r * mult;
+      used += r * mult;
+      if (lane < 8) { pat_mem[np * 8 + lane] = pm; pat_base[np * 8 + lane] = pb; }
+      if (lane == 0) { pat_first[np] = nb; pat_nm[np] = nm; }
+      nb += r;
+      ++np;
+      avail = __ballot(cnt > 0);
+    }
+    if (lane == 0) { pat_first[np] = nb; s_npat = np; s_slab_bins = nb; }
+    PL_STAMP_T(8, 64);
+  } else if (t >= rank_t0) {
+    // ---- meanwhile, on the other waves: the graphs of every size class in ascending id order (`bucket`; the packer only needs the
     //      class counts, the ids are resolved after it).  Rank inside the class = number of earlier graphs of the same size (LDS
     //      broadcast reads): deterministic without a sort, and off the critical path whatever it costs.
-    for (int g = t - 64; g < B; g += PLAN_T - 64) {
+    for (int g = t - rank_t0; g < B; g += PLAN_T - rank_t0) {
       const int n = gp[g + 1] - gp[g];
       if (n > 0 && n <= 64) {
         int rank = 0, prev = gp[0];
@@ -241,6 +340,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     }
     if (lane < (nrec & 63)) rec[(nrec & ~63) + lane] = recv;     // the partial group
     if (lane == 0) s_nrec = nrec;
+    PL_STAMP(9);
   }
   __syncthreads();
   PL_STAMP(5);
@@ -271,12 +371,78 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     if (t == 0) col_bin[ncol] = nbins;
     __syncthreads();
     // ---- write-out (no barrier from here on)
-    const bool over = nbins > bd.phi_max_bins;
+    const int rbins = slab ? s_slab_bins : nbins;        // bins of the member records (what the stage kernels walk)
+    const bool over = nbins > bd.phi_max_bins || rbins > bd.phi_max_bins;
     if (t == 0) {
       bd.meta[0] = nbins;
       bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
       bd.meta[3] = ncol;
+      bd.meta[7] = bd.phi_bin_mem != nullptr ? rbins : 0;
+      if (early_host != nullptr) { early_put(early_host, EH_PHI, (s_err & 1) | (over ? 4 : 0)); early_done(early_host, 1); }
     }
+    PL_STAMP(6);
+    // ---- member records of every bin: word pair (graph | index << 13 | row offset << 19 | (rows - 1) << 25, first node of the graph),
+    //      -1 = no member.  index = the eigenvector slot (phi) / the node (rho, all-eigenvector mode) of the slab.
+    if (bd.phi_bin_mem != nullptr && !over) {
+      if (slab) {
+        const int npat = s_npat;
+        for (int b = t; b < rbins; b += PLAN_T) {
+          int lo = 0, hi = npat;                           // largest p with pat_first[p] <= b
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pat_first[mid] <= b) lo = mid; else hi = mid;
+          }
+          const int rep = b - pat_first[lo], nm = pat_nm[lo];
+          int w[16];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            w[2 * k] = -1; w[2 * k + 1] = 0;
+            if (k < nm) {
+              const int pw = pat_mem[lo * 8 + k];
+              const int cls = pw & 127, off = (pw >> 7) & 63;
+              int step = 0;
+              for (int k2 = 0; k2 < nm; ++k2) step += ((pat_mem[lo * 8 + k2] & 127) == cls) ? 1 : 0;
+              const int q = pat_base[lo * 8 + k] + rep * step;
+              const int rank = q / cls, idx = q - rank * cls;
+              const int g = bucket[bstart[cls] + rank];
+              w[2 * k] = g | (idx << 13) | (off << 19) | ((cls - 1) << 25);
+              w[2 * k + 1] = gp[g];
+            }
+          }
+          int4* dst = reinterpret_cast<int4*>(bd.phi_bin_mem + (size_t)b * 16);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[k] = make_int4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        }
+      } else {
+        for (int b = t; b < nbins; b += PLAN_T) {
+          int lo = 0, hi = ncol;                           // largest c with col_bin[c] <= b
+          while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (col_bin[mid] <= b) lo = mid; else hi = mid;
+          }
+          const int slot = b - col_bin[lo];
+          const int cs = col_start[lo], ce = (lo + 1 < ncol) ? col_start[lo + 1] : nrec;
+          int w[16];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            w[2 * k] = -1; w[2 * k + 1] = 0;
+            if (cs + k < ce) {
+              const int rw = rec[cs + k];
+              const int cls = rw & 127, left = rw >> 8;
+              if (slot < phi_slots_of(cls, kmax)) {
+                const int g = bucket[bstart[cls] + hist[cls] - 1 - left];
+                w[2 * k] = g | (slot << 13) | ((rec_pre[cs + k] - rec_pre[cs]) << 19) | ((cls - 1) << 25);
+                w[2 * k + 1] = gp[g];
+              }
+            }
+          }
+          int4* dst = reinterpret_cast<int4*>(bd.phi_bin_mem + (size_t)b * 16);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) dst[k] = make_int4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        }
+      }
+    }
+    PL_STAMP(7);
     for (int c = t; c <= ncol; c += PLAN_T) bd.phi_col_bin0[c] = col_bin[c];
     // member records: the column of record r is the number of column starts <= r, found by bisection over col_start; the last member
     // of a column also closes its unused slots
@@ -331,6 +497,7 @@ __device__ void lds_graph_ptr(const int64_t* __restrict__ batch, int N, int B, i
 // Block 0: nodes, CSR (LDS atomics + per-segment sort), scans, write-out.  Block 1: the work bins.
 // Limits: N <= 4096, E <= 12288, B <= 1024 (the reference's batches: 128-256 molecules).
 constexpr int PS_NMAX = 4096, PS_EMAX = 12288, PS_BMAX = 1024;
+constexpr int PS_BINS_INTS = 5 * PS_BMAX + 3 * 66 + 32 + 8;     // plan_bins_block's scratch; the pattern table follows it
 
 
 
@@ -340,7 +507,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
                                                        int32_t* __restrict__ nvalid, int64_t* __restrict__ evoff,
                                                        int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
                                                        int32_t* __restrict__ eperm, int32_t* __restrict__ status, BinsDev bd,
-                                                       int do_bins) {
+                                                       int do_bins, EarlyDev early) {
   extern __shared__ int sm[];
   const int t = threadIdx.x;
   PL_STAMP(0);
@@ -349,14 +516,25 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     int* gp = sm;                      // [B+1]
     lds_graph_ptr(batch, N, B, gp, nullptr);
     PL_STAMP(1);
-    plan_bins_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
+    plan_bins_block(gp, B, kmax, bd, sm + (PS_BMAX + 4), sm + (PS_BMAX + 4) + PS_BINS_INTS, early.host);
     PL_STAMP(2);
+    return;
+  }
+  if (blockIdx.x == 3) {
+    // fourth workgroup (sn_plan_early with feature ids): every discrete feature id against the rows of its embedding tables — what
+    // nn.Embedding would raise IndexError for (model_utils/elements.py:21-37); the fused GINE stage never dereferences such an id,
+    // this is the same verdict a forward earlier
+    int bad = 0;
+    for (long long i = t; i < early.n_node_ids; i += PLAN_T) bad |= ((unsigned long long)early.node_ids[i] >= (unsigned long long)early.node_vocab) ? 1 : 0;
+    for (long long i = t; i < early.n_edge_ids; i += PLAN_T) bad |= ((unsigned long long)early.edge_ids[i] >= (unsigned long long)early.edge_vocab) ? 1 : 0;
+    bad = __syncthreads_or(bad);
+    if (t == 0) { early_put(early.host, EH_IDS, bad ? 1 : 0); early_done(early.host, 3); }
     return;
   }
   if (blockIdx.x == 2) {               // rho bins: third workgroup (off the critical path of the column packing)
     int* gp = sm;
     lds_graph_ptr(batch, N, B, gp, nullptr);
-    plan_rho_block(gp, B, kmax, bd, sm + (PS_BMAX + 4));
+    plan_rho_block(gp, B, kmax, bd, sm + (PS_BMAX + 4), early.host);
     // evoff = exclusive scan of n^2 and the largest graph: nothing of the CSR block depends on them, so they are taken here
     {
       int* wsum2 = sm + (PS_BMAX + 4) + B;     // plan_rho_block's scan scratch
@@ -372,44 +550,84 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
       int qtot;
       int qrun = block_exscan(q, wsum2, t, &qtot);
       for (int g = blo; g < bhi; ++g) { const int n = gp[g + 1] - gp[g]; evoff[g] = qrun; qrun += n * n; }
-      if (t == 0) { evoff[B] = qtot; status[ST_NMAX] = s_nmax2; }
+      if (t == 0) {
+        evoff[B] = qtot; status[ST_NMAX] = s_nmax2;
+        if (early.host != nullptr) { early_put(early.host, EH_NMAX, s_nmax2); early_done(early.host, 2); }
+      }
     }
     return;
   }
   int* gp = sm;                        // [B+1]
-  int* deg = gp + (PS_BMAX + 4);       // [N]  in-degree, then fill cursor
+  int* deg = gp + (PS_BMAX + 4);       // [N]  in-degree
   int* rp = deg + PS_NMAX;             // [N+1]
-  int* lperm = rp + (PS_NMAX + 4) + PS_EMAX;   // [E]  one packed key per in-edge: edge id << 12 | source  ([E] ints before it are spare)
+  int* lfill = rp + (PS_NMAX + 4);     // [E]  one packed key per in-edge in arrival order: edge id << 12 | source
+  int* lperm = lfill + PS_EMAX;        // [E]  ... sorted by edge id inside every node's segment
   int* wsum = lperm + PS_EMAX;         // [32]
   int* ng = wsum + 32;                 // [N]  graph id of every node (edge validation without global gathers)
-  __shared__ int s_err, s_nmax, s_dmax;
-  if (t == 0) { s_err = 0; s_nmax = 0; s_dmax = 0; }
-  for (int i = t; i < N; i += PLAN_T) deg[i] = 0;
-  __syncthreads();
-  lds_graph_ptr(batch, N, B, gp, &s_err, ng);
-  PL_STAMP(1);
-  // ---- in-degrees (LDS atomics) + edge validation
-  // (four edges per thread and iteration with independent loads; the same-graph check reads the LDS copy of `batch`)
-  for (int e0 = 4 * t; e0 < E; e0 += 4 * PLAN_T) {
-    long long sv[4], dv[4];
+  __shared__ int s_err, s_nmax, s_dmax, s_big;
+  if (t == 0) { s_err = 0; s_nmax = 0; s_dmax = 0; s_big = 0; }
+  // Round 5: every global read of this workgroup is requested up front (the batch vector and both rows of edge_index: <= 4 nodes and
+  // <= 12 edges per thread, coalesced) — until round 4 the edge list was read twice (degree pass, fill pass) behind the batch vector,
+  // three exposed memory round trips of ~3 k cycles each — and every in-edge keeps its arrival position from the degree pass's LDS
+  // atomic, so the fill is a plain store and the per-segment sort a rank count (reads of a segment pipeline; the per-node sorting
+  // networks walked three nodes per thread with dependent LDS round trips: 12 k cycles).
+  constexpr int NPT = PS_NMAX / PLAN_T, EPT = PS_EMAX / PLAN_T;
+  long long bcur[NPT], bprev[NPT];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u;
-      sv[u] = e < E ? ei[e] : 0;
-      dv[u] = e < E ? ei[(long long)E + e] : 0;
+  for (int k = 0; k < NPT; ++k) {
+    const int i = t + k * PLAN_T;
+    bcur[k] = i < N ? batch[i] : 0;
+    bprev[k] = (i < N && i > 0) ? batch[i - 1] : -1;
+  }
+  int es[EPT], ed[EPT];                // source / target of my edges (-1: out of range)
+  {
+    long long sv[EPT], dv[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = t + k * PLAN_T;
+      sv[k] = e < E ? ei[e] : 0;
+      dv[k] = e < E ? ei[(long long)E + e] : 0;
     }
+    for (int i = t; i < N; i += PLAN_T) deg[i] = 0;
+    for (int i = t; i <= B; i += PLAN_T) gp[i] = N;
+    __syncthreads();
+    // graph_ptr (first node of every graph, empty graphs included) and the nodes' graph ids
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u;
-      if (e < E) {
-        const long long s = sv[u], d = dv[u];
-        const bool bad = s < 0 || s >= N || d < 0 || d >= N;
-        if (bad) atomicOr(&s_err, ERR_EDGE_RANGE);
+    for (int k = 0; k < NPT; ++k) {
+      const int i = t + k * PLAN_T;
+      if (i < N) {
+        const long long g = bcur[k], gprev = bprev[k];
+        const bool ok = g >= 0 && g < B;
+        ng[i] = ok ? (int)g : -1;
+        if (!ok) atomicOr(&s_err, ERR_GRAPH_ID);
         else {
-          if (ng[s] != ng[d]) atomicOr(&s_err, ERR_EDGE_CROSS);
-          atomicAdd(&deg[d], 1);
+          if (gprev > g) atomicOr(&s_err, ERR_UNSORTED);
+          if (gprev < g) {
+            const long long lo = gprev < -1 ? 0 : gprev + 1;
+            for (long long q = lo; q <= g; ++q) gp[q] = i;
+          }
         }
       }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int e = t + k * PLAN_T;
+      const bool bad = e < E && (sv[k] < 0 || sv[k] >= N || dv[k] < 0 || dv[k] >= N);
+      if (bad) atomicOr(&s_err, ERR_EDGE_RANGE);
+      es[k] = (e < E && !bad) ? (int)sv[k] : -1;
+      ed[k] = (e < E && !bad) ? (int)dv[k] : -1;
+    }
+  }
+  __syncthreads();
+  PL_STAMP(1);
+  // ---- in-degrees (LDS atomics: the value returned is the edge's arrival position in its segment) + edge validation
+  int epos[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    epos[k] = 0;
+    if (ed[k] >= 0) {
+      if (ng[es[k]] != ng[ed[k]]) atomicOr(&s_err, ERR_EDGE_CROSS);
+      epos[k] = atomicAdd(&deg[ed[k]], 1);
     }
   }
   __syncthreads();
@@ -424,7 +642,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
     if ((t & 63) == 0) atomicMax(&s_dmax, dmax);
     int total;
     int run = block_exscan(s, wsum, t, &total);
-    for (int i = lo; i < hi; ++i) { const int dg = deg[i]; rp[i] = run; deg[i] = run; run += dg; }
+    for (int i = lo; i < hi; ++i) { rp[i] = run; run += deg[i]; }
     if (t == 0) rp[N] = total;
     if (!do_bins) {     // (with the bin planner the third workgroup takes evoff and the largest graph)
       const int perb = (B + PLAN_T - 1) / PLAN_T;
@@ -441,62 +659,26 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
   }
   __syncthreads();
   PL_STAMP(3);
-  // ---- fill the CSR segments (arbitrary arrival order), then sort each segment by edge id
-  for (int e0 = 4 * t; e0 < E; e0 += 4 * PLAN_T) {
-    long long sv[4], dv[4];
+  // ---- the CSR segments in arrival order (plain stores: every in-edge kept its position) ...
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u;
-      sv[u] = e < E ? ei[e] : 0;
-      dv[u] = e < E ? ei[(long long)E + e] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u;
-      const long long s = sv[u], d = dv[u];
-      if (e < E && !(s < 0 || s >= N || d < 0 || d >= N)) {
-        const int p = atomicAdd(&deg[d], 1);
-        lperm[p] = (e << 12) | (int)s;          // one sort key per in-edge: edge id (< 2^14: E <= 12288) above the source node (< 2^12)
-      }
-    }
+  for (int k = 0; k < EPT; ++k)
+    if (ed[k] >= 0) lfill[rp[ed[k]] + epos[k]] = ((t + k * PLAN_T) << 12) | es[k];   // edge id (< 2^14: E <= 12288) above the source node (< 2^12)
+  if (early.host != nullptr && early.max_graph_edges > 0) {
+    // (early report) a graph with more in-edges than the fused GINE stage stages in LDS: its rows of the CSR are contiguous
+    for (int g = t; g < B; g += PLAN_T)
+      if (rp[gp[g + 1]] - rp[gp[g]] > early.max_graph_edges) atomicOr(&s_big, 1);
   }
   __syncthreads();
   PL_STAMP(4);
-  // every segment sorted by edge id: the keys are distinct, a comparator is one min and one max
-  for (int i = t; i < N; i += PLAN_T) {
-    const int lo = rp[i], hi = rp[i + 1], dg = hi - lo;
-    if (dg <= 1) continue;
-    if (dg <= 4) {
-      // up to four in-edges (molecular graphs: always): 5-comparator network on registers
-      int k[4];
+  // ---- ... then by edge id: an in-edge's place is the number of smaller keys in its segment (the keys are distinct)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) k[u] = u < dg ? lperm[lo + u] : 0x7fffffff;
-      auto cx = [&](int a, int b) { const int x = min(k[a], k[b]), y = max(k[a], k[b]); k[a] = x; k[b] = y; };
-      cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (u < dg) lperm[lo + u] = k[u];
-      continue;
-    }
-    if (dg <= 8) {
-      // five to eight in-edges: the 19-comparator network (the insertion sort below walks LDS with a dependent access per move — a
-      // few nodes of degree 6-7 made this phase the longest of the CSR block)
-      int k[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) k[u] = u < dg ? lperm[lo + u] : 0x7fffffff;
-      auto cx = [&](int a, int b) { const int x = min(k[a], k[b]), y = max(k[a], k[b]); k[a] = x; k[b] = y; };
-      cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7); cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7); cx(1, 2); cx(5, 6); cx(0, 4); cx(3, 7);
-      cx(1, 5); cx(2, 6); cx(1, 4); cx(3, 6); cx(2, 4); cx(3, 5); cx(3, 4);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (u < dg) lperm[lo + u] = k[u];
-      continue;
-    }
-    for (int a = lo + 1; a < hi; ++a) {
-      const int ke = lperm[a];
-      int b = a - 1;
-      while (b >= lo && lperm[b] > ke) { lperm[b + 1] = lperm[b]; --b; }
-      lperm[b + 1] = ke;
+  for (int k = 0; k < EPT; ++k) {
+    if (ed[k] >= 0) {
+      const int key = ((t + k * PLAN_T) << 12) | es[k];
+      const int lo = rp[ed[k]], hi = rp[ed[k] + 1];
+      int rank = 0;
+      for (int q = lo; q < hi; ++q) rank += lfill[q] < key ? 1 : 0;
+      lperm[lo + rank] = key;
     }
   }
   __syncthreads();
@@ -506,14 +688,25 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_small(const int64_t* __restrict
   for (int i = t; i < E; i += PLAN_T) { const int k = lperm[i]; col[i] = k & 4095; eperm[i] = k >> 12; }
   for (int i = t; i <= B; i += PLAN_T) graph_ptr[i] = gp[i];
   for (int i = t; i < N; i += PLAN_T) {
-    const long long g = batch[i];
+    const int g = ng[i];
     int nv = 0, gi = 0;
-    if (g >= 0 && g < B) { gi = (int)g; nv = slots_of(gp[g + 1] - gp[g], kmax); }
+    if (g >= 0) { gi = g; nv = slots_of(gp[g + 1] - gp[g], kmax); }
     node_graph[i] = gi;
     nvalid[i] = nv;
   }
   if (t == 0) { status[ST_ERR] = s_err; if (!do_bins) status[ST_NMAX] = s_nmax; status[ST_DEGMAX] = s_dmax; status[3] = 0; }
   if (t >= 4 && t < 8) status[t] = 0;
+  if (early.host != nullptr) {
+    if (t == 0) {
+      early_put(early.host, EH_ERR, s_err);
+      early_put(early.host, EH_DEGMAX, s_dmax);
+      early_put(early.host, EH_EDGES, s_big);
+      if (!do_bins) { early_put(early.host, EH_NMAX, s_nmax); early_put(early.host, EH_PHI, 0); early_put(early.host, EH_RHO, 0); }
+      early_done(early.host, 0);
+      if (!do_bins) { early_done(early.host, 1); early_done(early.host, 2); }
+      if (early.node_ids == nullptr && early.edge_ids == nullptr) { early_put(early.host, EH_IDS, 0); early_done(early.host, 3); }
+    }
+  }
   PL_STAMP(6);
 }
 
@@ -573,7 +766,7 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_scan(int64_t N, int64_t B, int 
     __syncthreads();
     plan_rho_block(gp, (int)B, kmax, bd, sm + B + 4);
     __syncthreads();
-    plan_bins_block(gp, (int)B, kmax, bd, sm + B + 4);
+    plan_bins_block(gp, (int)B, kmax, bd, sm + B + 4, nullptr);   // (no room for the pattern table beside 6 144 graphs: records from the columns)
     return;
   }
   __shared__ long long part[PLAN_T];
@@ -699,11 +892,15 @@ __global__ void k_pack_eig(const float* __restrict__ ev, const float* __restrict
 
 using namespace sn;
 
-extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index,
-                             int64_t E, int kmax, int32_t* graph_ptr, int32_t* node_graph,
-                             int32_t* nvalid, int64_t* evoff, int32_t* rowptr, int32_t* col,
-                             int32_t* eperm, int32_t* status, const sn_plan_bins* bins, int32_t* scratch,
-                             void* stream) {
+static bool plan_one_launch(int64_t N, int64_t E, int64_t B) { return N > 0 && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX; }
+
+extern "C" int sn_batch_plan_early_supported(int64_t N, int64_t E, int64_t B) { return plan_one_launch(N, E, B) ? 1 : 0; }
+
+extern "C" int sn_batch_plan_ex(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index,
+                                int64_t E, int kmax, int32_t* graph_ptr, int32_t* node_graph,
+                                int32_t* nvalid, int64_t* evoff, int32_t* rowptr, int32_t* col,
+                                int32_t* eperm, int32_t* status, const sn_plan_bins* bins, int32_t* scratch,
+                                const sn_plan_early* early, void* stream) {
   SN_REQUIRE(N >= 0 && B >= 0 && E >= 0, "sn_batch_plan: negative size");
   SN_REQUIRE(N < (1ll << 31) && E < (1ll << 31), "sn_batch_plan: N/E exceed int32");
   SN_REQUIRE(graph_ptr && node_graph && nvalid && evoff && rowptr && status && scratch,
@@ -717,13 +914,25 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
                    bins->meta && bins->phi_max_bins >= 0,
                "sn_batch_plan: incomplete sn_plan_bins");
     SN_REQUIRE(B <= BINS_BMAX, "sn_batch_plan: work bins support at most %d graphs per batch (got %lld)", BINS_BMAX, (long long)B);
+    SN_REQUIRE(!bins->phi_bin_mem || (reinterpret_cast<uintptr_t>(bins->phi_bin_mem) & 15) == 0, "sn_batch_plan: phi_bin_mem must be 16-byte aligned");
     bd = BinsDev{bins->phi_bin_col, bins->phi_max_bins, bins->phi_col_bin0, bins->phi_col_mem, bins->phi_col_off,
-                 bins->rho_bin0, bins->meta};
+                 bins->rho_bin0, bins->meta, bins->phi_bin_mem};
+  }
+  EarlyDev ed{};
+  if (early != nullptr) {
+    SN_REQUIRE(early->host, "sn_batch_plan_ex: sn_plan_early.host (pinned int32[16]) missing");
+    SN_REQUIRE(plan_one_launch(N, E, B), "sn_batch_plan_ex: the early report needs the one-launch plan (N <= %d, E <= %d, B <= %d): ask "
+               "sn_batch_plan_early_supported first", PS_NMAX, PS_EMAX, PS_BMAX);
+    SN_REQUIRE((!early->node_ids && !early->edge_ids) || do_bins, "sn_batch_plan_ex: the feature-id check runs beside the bin planner (bins must be given)");
+    SN_REQUIRE((!early->node_ids || (early->n_node_ids >= 0 && early->node_vocab > 0)) && (!early->edge_ids || (early->n_edge_ids >= 0 && early->edge_vocab > 0)),
+               "sn_batch_plan_ex: feature-id counts / table rows");
+    ed = EarlyDev{early->node_ids, early->node_ids ? early->n_node_ids : 0, early->node_vocab, early->edge_ids,
+                  early->edge_ids ? early->n_edge_ids : 0, early->edge_vocab, early->max_graph_edges, early->host};
   }
   hipStream_t st = (hipStream_t)stream;
-  if (N > 0 && N <= PS_NMAX && E <= PS_EMAX && B <= PS_BMAX) {
+  if (plan_one_launch(N, E, B)) {
     const size_t lds0 = (size_t)((PS_BMAX + 4) + PS_NMAX + (PS_NMAX + 4) + 2 * PS_EMAX + 32 + PS_NMAX) * sizeof(int);
-    const size_t lds1 = (size_t)((PS_BMAX + 4) + 5 * PS_BMAX + 3 * 66 + 32 + 4) * sizeof(int);
+    const size_t lds1 = (size_t)((PS_BMAX + 4) + PS_BINS_INTS + PAT_INTS) * sizeof(int);
     const size_t lds = lds0 > lds1 ? lds0 : lds1;
     static bool init = false;
     if (!init) {
@@ -732,8 +941,9 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
         return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit to %zu", lds);
       init = true;
     }
-    hipLaunchKernelGGL(k_plan_small, dim3(do_bins ? 3 : 1), dim3(PLAN_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E,
-                       kmax, graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bd, do_bins ? 1 : 0);
+    const bool ids = ed.host != nullptr && (ed.node_ids != nullptr || ed.edge_ids != nullptr);
+    hipLaunchKernelGGL(k_plan_small, dim3(do_bins ? (ids ? 4 : 3) : 1), dim3(PLAN_T), lds, st, batch, (int)N, (int)B, edge_index, (int)E,
+                       kmax, graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bd, do_bins ? 1 : 0, ed);
     SN_CHECK_LAUNCH("sn_batch_plan");
     return SN_OK;
   }
@@ -744,12 +954,12 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   const int64_t ne = N > E ? N : E;
   hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(ne > 0 ? ne : 1, T)), dim3(T), 0, st, batch, edge_index, E, N, B, deg,
                      status);
-  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32 + 4) * sizeof(int) : 0;
+  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32 + 8) * sizeof(int) : 0;
   if (lds3 > 48 * 1024) {
     static bool init3 = false;
     if (!init3) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_plan_scan), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)(6 * BINS_BMAX + 4 + 3 * 66 + 32 + 4) * sizeof(int))) != hipSuccess)
+                              (int)((size_t)(6 * BINS_BMAX + 4 + 3 * 66 + 32 + 8) * sizeof(int))) != hipSuccess)
         return fail(SN_ERR_LAUNCH, "sn_batch_plan: cannot raise the dynamic LDS limit");
       init3 = true;
     }
@@ -764,8 +974,17 @@ extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const i
   return SN_OK;
 }
 
+extern "C" int sn_batch_plan(const int64_t* batch, int64_t N, int64_t B, const int64_t* edge_index,
+                             int64_t E, int kmax, int32_t* graph_ptr, int32_t* node_graph,
+                             int32_t* nvalid, int64_t* evoff, int32_t* rowptr, int32_t* col,
+                             int32_t* eperm, int32_t* status, const sn_plan_bins* bins, int32_t* scratch,
+                             void* stream) {
+  return sn_batch_plan_ex(batch, N, B, edge_index, E, kmax, graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, bins,
+                          scratch, nullptr, stream);
+}
+
 #ifdef SN_PROFILE
-extern "C" int sn_prof_read_plan(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pprof), sizeof(long long) * 32); }
+extern "C" int sn_prof_read_plan(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pprof), sizeof(long long) * 64); }
 #endif
 
 extern "C" int64_t sn_phi_bins_bound(int64_t B, int kmax) {

@@ -187,6 +187,7 @@ class RhoPlan:
 
 GNN_MAX_LAYERS = 16
 GNN_MAX_NODES = 64
+GNN_MAX_EDGES = 192      # in-edges of one graph the fused GINE stage stages in LDS (GNN_EMAX, csrc/fused_gnn.hip)
 
 
 class _GnnLayer(C.Structure):

@@ -110,6 +110,7 @@ class PlanBins:
     rho_bin0: torch.Tensor       # int32 [B+1]
     meta: torch.Tensor           # int32 [8]
     cstruct: object              # ctypes mirror (sn_plan_bins) holding the device pointers
+    phi_bin_mem: torch.Tensor = None   # int32 [phi_max_bins * 16] member records of every bin (meta[7] bins)
 
 
 @dataclass
@@ -146,11 +147,78 @@ class GraphPlan:
 class _PlanBinsC(C.Structure):
     _fields_ = [("phi_bin_col", C.c_void_p), ("phi_max_bins", C.c_int64), ("phi_col_bin0", C.c_void_p),
                 ("phi_col_mem", C.c_void_p), ("phi_col_off", C.c_void_p), ("rho_bin0", C.c_void_p), ("meta", C.c_void_p),
-                ("node_graph", C.c_void_p)]
+                ("node_graph", C.c_void_p), ("phi_bin_mem", C.c_void_p)]
 
 
-def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins: bool = False) -> GraphPlan:
-    """bins=True also lays out the work bins of the fused stages (same launch, no host sync)."""
+class _PlanEarlyC(C.Structure):
+    _fields_ = [("node_ids", C.c_void_p), ("n_node_ids", C.c_int64), ("node_vocab", C.c_int64),
+                ("edge_ids", C.c_void_p), ("n_edge_ids", C.c_int64), ("edge_vocab", C.c_int64),
+                ("max_graph_edges", C.c_int), ("reserved", C.c_int), ("host", C.c_void_p)]
+
+
+class EarlyReport:
+    """The batch's flags as sn_batch_plan_ex reports them to pinned host memory while the rest of the forward is still running
+    (include/signnet_hip.h: sn_plan_early).  `wait()` polls the four done words (the plan is the first ~20 us of a forward: they
+    are normally set by the time the host has queued the stage kernels) and returns the flag words as a list."""
+    ERR, NMAX, DEGMAX, EDGES, PHI, RHO, IDS, DONE = 0, 1, 2, 3, 4, 5, 6, 8
+    _pool = []
+
+    def __init__(self):
+        if EarlyReport._pool:
+            self.t, self.v = EarlyReport._pool.pop()
+        else:
+            self.t = torch.zeros(16, dtype=torch.int32, pin_memory=True)
+            self.v = self.t.numpy()
+        self.v[:] = 0
+        self.cstruct = None
+        self._keep = None
+
+    def arm(self, node_ids=None, node_vocab=0, edge_ids=None, edge_vocab=0, max_graph_edges=0):
+        self._keep = (node_ids, edge_ids)
+        self.cstruct = _PlanEarlyC(ptr(node_ids), 0 if node_ids is None else node_ids.numel(), int(node_vocab),
+                                   ptr(edge_ids), 0 if edge_ids is None else edge_ids.numel(), int(edge_vocab),
+                                   int(max_graph_edges), 0, self.t.data_ptr())
+        return self
+
+    def wait(self, timeout_s=5.0):
+        v = self.v
+        if not (v[8] and v[9] and v[10] and v[11]):
+            import time
+            t_end = time.perf_counter() + timeout_s
+            while not (v[8] and v[9] and v[10] and v[11]):
+                if time.perf_counter() > t_end:
+                    torch.cuda.synchronize()
+                    if not (v[8] and v[9] and v[10] and v[11]):
+                        raise RuntimeError("sn_batch_plan_ex did not report its flags")
+        return v[:8].tolist()
+
+    def wait_nmax(self):
+        """Only the largest graph (the rho-bins workgroup's word): what the all-eigenvector mode sizes its tensors from."""
+        v = self.v
+        if not v[10]:
+            import time
+            t_end = time.perf_counter() + 5.0
+            while not v[10]:
+                if time.perf_counter() > t_end:
+                    torch.cuda.synchronize()
+                    if not v[10]:
+                        raise RuntimeError("sn_batch_plan_ex did not report the largest graph")
+        return int(v[1])
+
+    def release(self):
+        """Back to the pool (only once the launch that writes it has completed: after wait())."""
+        self._keep = self.cstruct = None
+        EarlyReport._pool.append((self.t, self.v))
+
+
+def early_supported(N: int, E: int, B: int) -> bool:
+    return bool(lib().sn_batch_plan_early_supported(int(N), int(E), int(B)))
+
+
+def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins: bool = False,
+               early: "EarlyReport | None" = None) -> GraphPlan:
+    """bins=True also lays out the work bins of the fused stages (same launch, no host sync).  early: an armed EarlyReport — the
+    batch's flags are also written to its pinned buffer by the plan kernel itself (one-launch plans only: early_supported())."""
     require_cuda(batch, edge_index)
     if batch.dtype != torch.int64 or edge_index.dtype != torch.int64:
         raise ValueError("build_plan: batch and edge_index must be int64 (the reference's index dtype)")
@@ -163,7 +231,7 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     mb = 0
     if bins:
         mb = int(lib().sn_phi_bins_bound(B, int(kmax)))
-        sizes += [8, mb, B + 1, 8 * B, 8 * B, B + 1]
+        sizes += [8, mb, B + 1, 8 * B, 8 * B, B + 1, 16 * mb]
     offs = [0]
     for s in sizes:
         offs.append(offs[-1] + ((s + 3) // 4) * 4)
@@ -173,14 +241,15 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     evoff = torch.empty(B + 1, dtype=torch.int64, device=dev)
     pb = None
     if bins:
-        meta, bc, cb0, mem, off, rb0 = parts[8:14]
+        meta, bc, cb0, mem, off, rb0, bmem = parts[8:15]
         cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr(),
-                        node_graph.data_ptr())
-        pb = PlanBins(bc, mb, cb0, mem, off, rb0, meta, cs)
+                        node_graph.data_ptr(), bmem.data_ptr())
+        pb = PlanBins(bc, mb, cb0, mem, off, rb0, meta, cs, bmem)
     with _span("sn_batch_plan"):
-        check(lib().sn_batch_plan(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
-                                  ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
-                                  C.byref(pb.cstruct) if pb is not None else None, ptr(scratch), stream()), "sn_batch_plan")
+        check(lib().sn_batch_plan_ex(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),
+                                     ptr(nvalid), ptr(evoff), ptr(rowptr), ptr(col), ptr(eperm), ptr(status),
+                                     C.byref(pb.cstruct) if pb is not None else None, ptr(scratch),
+                                     C.byref(early.cstruct) if early is not None else None, stream()), "sn_batch_plan")
     plan = GraphPlan(N, B, E, int(kmax), graph_ptr, node_graph, nvalid, evoff, rowptr, col, eperm, status, pb)
     plan.flags = arena[offs[7]:offs[7] + 16] if bins else status      # [status(8) | meta(8)] contiguous
     return plan

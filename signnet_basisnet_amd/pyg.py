@@ -280,6 +280,27 @@ def _drop_prepared(module, incompatible_keys=None):
     module._prep = None
 
 
+def host_max_nodes(data):
+    """The largest graph of a batch from HOST-side bookkeeping the batch object already carries, or None: `data.sizes` (a list of
+    node counts: synth.make_batch, dist.shard_batch), PyG's `Batch._slice_dict` (CPU tensors of per-graph offsets that collate builds
+    and `.to(device)` leaves on the host) or a CPU `ptr`.  With it the all-eigenvector mode (max_k=None: K = N_max, core/transform.py:
+    29-38) sizes its tensors without reading a graph size back from the device (the reference does: `int(num_nodes.max())`)."""
+    N, B = int(data.batch.numel()), int(data.num_graphs)
+    s = getattr(data, "sizes", None)
+    if s is not None and not torch.is_tensor(s):
+        # (bookkeeping that does not even add up to the batch is ignored: the device is asked instead)
+        return (int(max(s)) if len(s) else 0) if (len(s) == B and sum(s) == N) else None
+    cands = []
+    sd = getattr(data, "_slice_dict", None)
+    if isinstance(sd, dict):
+        cands += [sd.get(key) for key in ("x", "eigen_values", "batch")]
+    cands.append(getattr(data, "ptr", None))
+    for t in cands:
+        if torch.is_tensor(t) and not t.is_cuda and t.dim() == 1 and t.numel() == B + 1 and B >= 1 and int(t[-1]) - int(t[0]) == N:
+            return int((t[1:] - t[:-1]).max())
+    return None
+
+
 class SignNetGNN(nn.Module):
     """HIP SignNet + GINE.  `variant` selects which reference tree's semantics are reproduced.
 
@@ -303,9 +324,14 @@ class SignNetGNN(nn.Module):
         self.train_stages = True    # training: the one-pass link kernels of train_stage.py; False = one launch per op (autograd.py)
         # Fused stages require graphs of <= 64 nodes (and <= 192 edges for the GINE stage); a batch that violates this, a
         # malformed batch, or a discrete feature value outside its embedding table raises device-side flags.
-        #   strict=True : (default) the flags are read after every forward (the GINE kernel writes them to pinned memory: one
-        #                 host wait, no event); an oversize batch is re-run on the layer path, anything else raises on the
-        #                 spot — every input the reference evaluates is evaluated, errors are the reference's errors.
+        #   strict=True : (default) the flags are read in every forward; an oversize batch is re-run on the layer path, anything
+        #                 else raises on the spot — every input the reference evaluates is evaluated, errors are the reference's
+        #                 errors.  Since round 5 the flags are DECIDED BY THE PLAN KERNEL, the first ~20 us of a forward (graph
+        #                 sizes, in-edge counts, malformed batch, feature ids against their embedding tables), which writes them
+        #                 to pinned memory itself (ops.EarlyReport / sn_batch_plan_ex): the host queues the three stage kernels
+        #                 behind the plan, then polls words that are already there — the GPU never waits for the host (until
+        #                 round 4 the GINE kernel reported them at the END of the forward: one host round trip per step, 9 %).
+        #                 Batches beyond the one-launch plan (> 4096 nodes / 12288 edges / 1024 graphs) keep that older wait.
         #   strict=False: the serving / throughput mode (bench.py): no host wait.  The outputs of every graph that could not
         #                 be evaluated are NaN (never uninitialised memory: the GINE kernel fills them), and the error itself
         #                 is raised at the next forward, at check_last() or at train()/eval(), whichever comes first (a
@@ -520,7 +546,25 @@ class SignNetGNN(nn.Module):
         self.check_last(wait=False)
         with _lib_mod.stream_scope():
             y = self._forward(data, return_stages)
-        if self.use_fused and not return_stages and self._used_fused:
+        early, self._early = getattr(self, "_early", None), None
+        if early is not None:
+            # strict mode, flags from the plan kernel (already in pinned memory: the stage kernels were queued in the meantime)
+            fl = early.wait()
+            early.release()
+            E_ = ops.EarlyReport
+            if fl[E_.ERR]:
+                raise ValueError("malformed graph batch (unsorted batch vector, graph id / edge endpoint out of range or an edge across graphs)")
+            if fl[E_.IDS]:
+                raise IndexError(ops.EMBEDDING_INDEX_ERROR)
+            if not self.max_k and fl[E_.NMAX] > self._last_K:
+                raise ValueError(f"the batch's host-side graph sizes (largest: {self._last_K}) disagree with its batch vector (largest graph: {fl[E_.NMAX]} nodes)")
+            if fl[E_.EDGES] or fl[E_.PHI] or fl[E_.RHO]:      # a graph beyond the fused stages' limits: layer by layer
+                saved, self.use_fused, self._prep = self.use_fused, False, None
+                try:
+                    y = self._forward(data, False)
+                finally:
+                    self.use_fused, self._prep = saved, None
+        elif self.use_fused and not return_stages and self._used_fused:
             ev, host = self._post_status(self._last_plan)
             if self.strict:
                 self._wait_status(ev, host)
@@ -684,6 +728,19 @@ class SignNetGNN(nn.Module):
             raise IndexError(ops.EMBEDDING_INDEX_ERROR)
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _arm_early(gplan, data):
+        """An EarlyReport for this batch: the plan kernel also checks what the fused GINE stage would flag at the END of the forward —
+        a graph with more than 192 in-edges, discrete feature ids outside their embedding tables (nn.Embedding's IndexError)."""
+        xi = ei = None
+        nv = ev = 0
+        if gplan.node_discrete and data.x.dtype == torch.int64 and data.x.is_cuda:
+            xi, nv = data.x.contiguous(), int(gplan.params.node_vocab)
+        if gplan.edge_discrete and int(gplan.params.n_layers) > 0 and data.edge_attr.dtype == torch.int64 and data.edge_attr.is_cuda \
+                and data.edge_attr.numel() > 0:
+            ei, ev = data.edge_attr.contiguous(), int(gplan.params.edge_vocab)
+        return ops.EarlyReport().arm(xi, nv, ei, ev, fused.GNN_MAX_EDGES)
+
     def _forward_overlapped(self, data, P, B):
         """The fused eval forward as a three-stage pipeline over the module's two side streams and the caller's stream:
             side A: batch plan + phi      -> event ->      side B: rho      -> event ->      caller's stream: GINE stage.
@@ -709,7 +766,8 @@ class SignNetGNN(nn.Module):
             plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=True)
             # all-eigenvector mode (max_k None): K = the largest graph, read back as the reference's to_dense_EVD does — the host waits
             # for side A only (the previous forward's rho / GINE keep running)
-            K = int(self.max_k) if self.max_k else plan.check()[1]
+            K_host = None if self.max_k else host_max_nodes(data)
+            K = int(self.max_k) if self.max_k else (int(K_host) if K_host is not None else plan.check()[1])
             x = P["phi_fused"].run(plan, data.eigen_vectors, K, zero_invalid=False).view(plan.N * K, d)
             ev_a = torch.cuda.Event()
             ev_a.record(side_a)
@@ -749,13 +807,31 @@ class SignNetGNN(nn.Module):
         if (self.overlap_front and use_phi_fused and use_rho_fused and use_gnn_fused and not return_stages and not train
                 and not self.strict):
             return self._forward_overlapped(data, P, B)
-        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=use_phi_fused or use_rho_fused)
+        all_fused = use_phi_fused and use_rho_fused and use_gnn_fused and not return_stages and not train
+        early = None
+        N_, E_n = int(data.batch.numel()), (int(data.edge_index.shape[1]) if data.edge_index.numel() else 0)
+        if all_fused and self.strict and ops.early_supported(N_, E_n, B):
+            early = self._arm_early(P["gnn_fused"], data)
+        K_host = None if self.max_k else host_max_nodes(data)
+        if not self.max_k and K_host is None and early is None and not return_stages and ops.early_supported(N_, E_n, B):
+            early = ops.EarlyReport().arm()          # only for the largest graph: a poll of pinned memory instead of a device read-back
+        plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=use_phi_fused or use_rho_fused, early=early)
         self._last_plan, self._used_fused = plan, (use_phi_fused or use_rho_fused or use_gnn_fused)
         if self.max_k:
             K = int(self.max_k)
             plan.check() if return_stages else None
+        elif K_host is not None:
+            K = int(K_host)              # N_max from the batch object's host-side sizes: no device read-back
+            plan.check() if return_stages else None
+        elif early is not None:
+            K = early.wait_nmax()        # N_max as the plan kernel reports it to pinned memory (the reference's to_dense_EVD reads it back too)
         else:
             K = plan.check()[1]          # N_max: one host sync, as the reference's to_dense_EVD does
+        if early is not None and not (all_fused and self.strict):
+            early.wait()
+            early.release()
+            early = None
+        self._early, self._last_K = early, K
         N, d = plan.N, self.cfg["n_hid"]
         nv = plan.nvalid
         want_vals = "eig" in P or "eig2" in P
@@ -811,7 +887,7 @@ class SignNetGNN(nn.Module):
                 x = ops.masked_layernorm(z, y, L["ln2"][0], L["ln2"][1], LN_EPS, nv, K)
             s = ops.slot_sum(x, N, K)
         if use_gnn_fused and not return_stages:
-            self._flags_host = self._host_flags() if (plan.bins is not None and not _NO_KERNEL_FLAGS) else None
+            self._flags_host = self._host_flags() if (plan.bins is not None and not _NO_KERNEL_FLAGS and self._early is None) else None
             if self._flags_host is not None:
                 self._flags_host[1][:] = 0        # host-side; the kernel's last workgroup overwrites it, ready word last
             return P["gnn_fused"].run(plan, data.x, data.edge_attr, s, None if self._flags_host is None else self._flags_host[0])

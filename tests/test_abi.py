@@ -42,6 +42,7 @@ def test_python_binding_covers_the_header(lib):
                                      "sn_bn_act_bwd_scratch_floats", "sn_embedding_bwd_scratch_floats", "sn_embedding_bwd_layers_scratch_floats", "sn_ign_mlp_supported",
                                      "sn_gatedgcn_max_edges",
                                      "sn_train_linear_bwd_part_floats", "sn_train_scalar_mlp_work_doubles"}
+    # (sn_batch_plan_early_supported is in SIGNATURES: it returns 0 / 1)
     assert set(declared_symbols()) == bound
 
 
@@ -123,6 +124,7 @@ int main(void) {
          offsetof(sn_train_linear_bwd_args, dot_part), sizeof(sn_train_scalar_mlp_args), offsetof(sn_train_scalar_mlp_args, w2),
          offsetof(sn_train_scalar_mlp_args, column_state));
   printf("%zu %zu %zu\n", sizeof(sn_train_post_args), offsetof(sn_train_post_args, sums_part), offsetof(sn_train_post_args, dot_part));
+  printf("%zu %zu %zu %zu\n", sizeof(sn_plan_early), offsetof(sn_plan_early, max_graph_edges), offsetof(sn_plan_early, host), offsetof(sn_plan_bins, phi_bin_mem));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as td:
@@ -142,7 +144,8 @@ int main(void) {
             S(train_stage._LinArgs), train_stage._LinArgs.in_scale.offset, train_stage._LinArgs.stat_part.offset,
             S(train_stage._BwdArgs), train_stage._BwdArgs.x_mean.offset, train_stage._BwdArgs.dot_part.offset,
             S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset,
-            S(train_stage._PostArgs), train_stage._PostArgs.sums_part.offset, train_stage._PostArgs.dot_part.offset]
+            S(train_stage._PostArgs), train_stage._PostArgs.sums_part.offset, train_stage._PostArgs.dot_part.offset,
+            S(ops._PlanEarlyC), ops._PlanEarlyC.max_graph_edges.offset, ops._PlanEarlyC.host.offset, ops._PlanBinsC.phi_bin_mem.offset]
     assert got == want
 
 

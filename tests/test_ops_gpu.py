@@ -142,6 +142,156 @@ def test_plan_phi_columns_match_the_host_restatement(dev, B, kmax, seed, lo, hi)
     assert bc == [c for c, (_, h) in enumerate(cols) for _ in range(h)]
 
 
+def _reference_slab_bins(sizes):
+    """The planner's slab-level packing of the all-eigenvector mode restated on the host (csrc/plan.hip, plan_bins_block): a graph of n
+    nodes is n slabs of n rows; best-fit-decreasing over the size classes, <= 8 slabs and <= 64 rows per bin, one chain link per bin
+    PATTERN (repeated while every class of the pattern still has its copies); slab q of a class = (q // n)-th graph of the class in id
+    order, index q % n."""
+    classes = {}
+    for g, n in enumerate(sizes):
+        if 0 < n <= 64:
+            classes.setdefault(n, []).append(g)
+    cnt = {s: s * len(gs) for s, gs in classes.items()}
+    used = {s: 0 for s in classes}
+    bins, npat = [], 0
+    while cnt:
+        single = npat >= 160 - 64
+        mult, members, cap = {}, [], 64
+        cls = max(cnt)
+        while True:
+            copies = mult.get(cls, 0)
+            if cnt[cls] - copies > 0 and cls <= cap and len(members) < 8:
+                members.append((cls, 64 - cap, copies))
+                mult[cls] = copies + 1
+                cap -= cls
+                if single:
+                    break
+                continue
+            limit = min(cap, cls - 1)
+            if limit <= 0 or len(members) >= 8:
+                break
+            cand = [c for c in cnt if c <= limit]
+            if not cand:
+                break
+            cls = max(cand)
+        r = min(cnt[c] // m for c, m in mult.items())
+        assert r >= 1
+        for rep in range(r):
+            b = []
+            for c, off, t in members:
+                rank, idx = divmod(used[c] + t + rep * mult[c], c)
+                b.append((classes[c][rank], idx, off, c))
+            bins.append(b)
+        for c, m in mult.items():
+            cnt[c] -= r * m
+            used[c] += r * m
+            if cnt[c] == 0:
+                del cnt[c]
+        npat += 1
+    return bins
+
+
+def _decode_bin_records(plan):
+    nb = int(plan.bins.meta[7])
+    rec = plan.bins.phi_bin_mem.cpu()[:nb * 16].view(nb, 8, 2).tolist()
+    out = []
+    for b in rec:
+        out.append([(w0 & 8191, (w0 >> 13) & 63, (w0 >> 19) & 63, ((w0 >> 25) & 63) + 1, g0) for w0, g0 in b if w0 >= 0])
+    return out
+
+
+@pytest.mark.parametrize("B,kmax,seed,lo,hi", [(128, 0, 1236, 9, 37), (128, 16, 1236, 9, 37), (256, 0, 3, 6, 14), (40, 0, 9, 1, 64),
+                                                (37, 8, 5, 1, 64), (300, 0, 11, 1, 9), (1500, 4, 7, 1, 5), (2100, -3, 9, 1, 3),
+                                                (1500, 0, 13, 1, 3), (1, 0, 2, 9, 9)])
+def test_plan_bin_member_records(dev, B, kmax, seed, lo, hi):
+    """The per-bin member records the stage kernels walk (sn_plan_bins.phi_bin_mem): every (graph, index) slab exactly once, members
+    of a bin disjoint inside 64 rows, word 1 = the graph's first node; with kmax != 0 (and on the five-launch plan) the bins of the
+    columns, with all eigenvectors on the one-launch plan the slab-level packing — equal to its host restatement, at >= 95 % fill on
+    the ZINC-like batch where the columns reach 92 %."""
+    from signnet_basisnet_amd import ops
+    data = synth.make_batch(B, seed=seed, n_lo=lo, n_hi=hi)
+    d = synth.batch_to(data, dev)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True)
+    assert plan.check()[0] == 0
+    sizes = list(data.sizes)
+    gp = [0]
+    for n in sizes:
+        gp.append(gp[-1] + n)
+    slots = (lambda n: -kmax) if kmax < 0 else (lambda n: min(n, kmax) if kmax > 0 else n)
+    meta = plan.bins.meta.cpu().tolist()
+    got = _decode_bin_records(plan)
+    seen = set()
+    for b in got:
+        spans = sorted((off, off + n) for _, _, off, n, _ in b)
+        assert b and spans[-1][1] <= 64 and all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+        for g, idx, off, n, g0 in b:
+            assert n == sizes[g] and g0 == gp[g] and idx < slots(n) and (g, idx) not in seen
+            seen.add((g, idx))
+    assert seen == {(g, i) for g, n in enumerate(sizes) if 0 < n <= 64 for i in range(slots(n))}
+    one_launch = sum(sizes) <= 4096 and d.edge_index.shape[1] <= 12288 and B <= 1024
+    if kmax == 0 and one_launch:
+        want = _reference_slab_bins(sizes)
+        assert len(got) == len(want) <= meta[0]
+        for b, (gb, wb) in enumerate(zip(got, want)):
+            assert [(g, idx, off, n) for g, idx, off, n, _ in gb] == wb, b
+        if (lo, hi) == (9, 37):
+            assert meta[2] / (64 * len(got)) >= 0.95 > meta[2] / (64 * meta[0])
+    else:
+        assert len(got) == meta[0]             # the columns' bins
+        cols = _reference_columns(sizes, kmax)
+        b = 0
+        for members, h in cols:
+            for j in range(h):
+                assert [(g, idx, off) for g, idx, off, _, _ in got[b]] == [(g, j, off) for g, off in members if j < slots(sizes[g])], (b, j)
+                b += 1
+
+
+def test_plan_early_report(dev):
+    """sn_batch_plan_ex: the plan kernel writes the batch's flags to pinned host memory itself (what the module's strict mode polls
+    instead of waiting for the end of the forward)."""
+    from signnet_basisnet_amd import ops
+    data = synth.make_batch(12, seed=4, sizes=[10, 30, 12, 64, 9, 20, 33, 1, 17, 25, 40, 5])
+    d = synth.batch_to(data, dev)
+    assert ops.early_supported(d.batch.numel(), d.edge_index.shape[1], d.num_graphs) and not ops.early_supported(5000, 10, 10)
+    E = ops.EarlyReport
+    rep = E().arm(d.x, 28, d.edge_attr, 4, 192)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, 0, bins=True, early=rep)
+    fl = rep.wait()
+    st = plan.check()
+    assert fl[E.ERR] == 0 and fl[E.NMAX] == 64 == st[1] and fl[E.DEGMAX] == st[2] and fl[E.EDGES] == 0 and fl[E.PHI] == 0 and fl[E.RHO] == 0 and fl[E.IDS] == 0
+    assert rep.wait_nmax() == 64
+    rep.release()
+    # a node id outside its table / an edge id outside its table / a graph with more in-edges than the limit given / an oversize graph
+    for what in ("node", "edge", "edges", "nodes", "unsorted", "noids"):
+        x, ea, batch, lim, dd = d.x, d.edge_attr, d.batch, 192, d
+        if what == "node":
+            x = d.x.clone(); x[17, 0] = 28
+        if what == "edge":
+            ea = d.edge_attr.clone(); ea[5] = -1
+        if what == "edges":
+            lim = 40
+        if what == "nodes":
+            dd = synth.batch_to(synth.make_batch(3, seed=4, sizes=[10, 70, 12]), dev)
+            x, ea, batch = dd.x, dd.edge_attr, dd.batch
+        if what == "unsorted":
+            batch = d.batch.flip(0).contiguous()
+        rep = E().arm(None if what == "noids" else x, 28, None if what == "noids" else ea, 4, lim)
+        ops.build_plan(batch, dd.edge_index, dd.num_graphs, 16, bins=True, early=rep)
+        fl = rep.wait()
+        rep.release()
+        assert bool(fl[E.ERR]) == (what == "unsorted"), what
+        if what != "unsorted":               # (a malformed batch has no meaningful graph boundaries: only its error word counts)
+            assert bool(fl[E.IDS]) == (what in ("node", "edge")), what
+            assert bool(fl[E.EDGES]) == (what == "edges"), what
+            assert bool(fl[E.PHI]) == (what == "nodes"), what
+    # without the bin planner (one workgroup): every done word still arrives
+    rep = E().arm(None, 0, None, 0, 192)
+    ops.build_plan(d.batch, d.edge_index, d.num_graphs, 16, bins=False, early=rep)
+    fl = rep.wait()
+    rep.release()
+    assert fl[E.NMAX] == 64 and fl[E.ERR] == 0
+
+
 def test_plan_kmax_and_errors(dev):
     from signnet_basisnet_amd import ops
     data = synth.make_batch(4, seed=2, sizes=[3, 20, 7, 12])

@@ -257,6 +257,54 @@ def test_feature_id_outside_the_embedding_table_raises_like_nn_embedding():
     assert int(st) == 1 and torch.equal(out[1], torch.zeros(8, device="cuda:0")) and torch.equal(out[0], tab[0])
 
 
+def test_all_eigenvector_slot_count_from_host_sizes_or_the_plan_report():
+    """max_k=None: K = the largest graph.  With host-side sizes on the batch object (`data.sizes`, PyG's `_slice_dict`, a CPU `ptr`) no
+    graph size is read back; without them the plan kernel's pinned-memory report is polled; all routes give the same bits, in the
+    strict (default) and the serving mode.  Host sizes that understate the batch are caught (strict) and never write out of bounds."""
+    import types
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import pyg, synth
+    torch.manual_seed(5)
+    ctor = (None, None, 64, 1, 3, 2)
+    model = pyg.SignNetGNN(*ctor, variant="gine")
+    host = synth.make_batch(12, seed=21, sizes=[9, 37, 20, 33, 12, 27, 16, 30, 10, 36, 22, 17])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = O.signnet_gnn(sd, O.make_cfg("gine", *ctor), host, training=False, max_k=None)
+    model = model.cuda().eval()
+    with_sizes = synth.batch_to(host, "cuda:0")
+    assert pyg.host_max_nodes(with_sizes) == 37
+    bare = types.SimpleNamespace(**{k: v for k, v in vars(with_sizes).items() if k != "sizes"})
+    assert pyg.host_max_nodes(bare) is None
+    ptr = torch.tensor([0] + list(host.sizes)).cumsum(0)
+    sliced = types.SimpleNamespace(**vars(bare), _slice_dict={"x": ptr})
+    with_ptr = types.SimpleNamespace(**vars(bare), ptr=ptr)
+    assert pyg.host_max_nodes(sliced) == 37 == pyg.host_max_nodes(with_ptr)
+    outs = []
+    with torch.no_grad():
+        for strict in (True, False):
+            model.strict = strict
+            for d in (with_sizes, bare, sliced, with_ptr):
+                outs.append(model(d).clone())
+                model.check_last()
+    close(outs[0], ref, "all eigenvectors vs oracle")
+    for y in outs[1:]:
+        assert torch.equal(y, outs[0])
+    no_sum = types.SimpleNamespace(**vars(bare), sizes=[20] * 12)           # does not even add up to the batch: ignored
+    assert pyg.host_max_nodes(no_sum) is None
+    with torch.no_grad():
+        assert torch.equal(model(no_sum), outs[0])
+    liar = types.SimpleNamespace(**vars(bare), sizes=[22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 22, 22])   # adds up (269), largest 23, not 37
+    assert sum(liar.sizes) == sum(host.sizes) and pyg.host_max_nodes(liar) == 23
+    model.strict = True
+    with pytest.raises(ValueError, match="disagree"), torch.no_grad():
+        model(liar)
+    model.strict = False
+    with torch.no_grad():
+        model(liar)                                                           # (graphs of > 23 nodes are dropped, nothing is touched outside the tensors)
+    torch.cuda.synchronize()
+    model.check_last()
+
+
 def test_malformed_batch_comes_back_as_nan_and_raises():
     from signnet_basisnet_amd import synth
     from signnet_basisnet_amd.pyg import SignNetGNN
