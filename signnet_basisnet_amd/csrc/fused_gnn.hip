@@ -42,11 +42,17 @@ constexpr int GNN_CLS = 16;                  // edge-feature classes per graph w
 constexpr int GNN_EEMAX = 96;                // rows of the edge-embedding area (class x layer table, or per-edge staging)
 constexpr int GNN_EEPF = (GNN_EEMAX * 32 + GNN_WAVES * 64 - 1) / (GNN_WAVES * 64);   // float4 per thread (d_pad = 128)
 
-// split image: three bf16 planes [64 rows][SP_STRIDE bytes]; inside a row the k-slots of K block kb and lane group g
-// are contiguous (kb*64 + g*16 bytes: 8 bf16 = channels 32kb + 16(s>>2) + 4g + (s&3)) -> one ds_read_b128 per plane.
-constexpr int SP_STRIDE = 272;                       // 256 + 16: staggers rows over the LDS banks
+// split image: three bf16 planes [64 rows][256 bytes]; inside a row the k-slots of K block kb and lane group g are one 16-byte chunk
+// (8 bf16 = channels 32kb + 16(s>>2) + 4g + (s&3)) -> one ds_read_b128 per plane.  Chunk c = 4 kb + g of row r lives at chunk
+// c ^ (r & 15) of the row (round 5): a ds_read_b128 is served in groups of 16 lanes — rows {0-3, 12-15} of lane group g with rows
+// 4-11 of lane group g + 1 — and with the rows merely staggered (272-byte stride until round 4) every group had two lanes on one
+// bank quad: 2 LDS cycles per group instead of 1, 43 % of the kernel's LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE,
+// profiles/r04_pmc_sq_detail.txt); the XOR puts the 16 lanes of every group on 16 different quads (stores: unchanged, 2-way).
+constexpr int SP_STRIDE = 256;
 constexpr int SP_PLANE = GNN_ROWS * SP_STRIDE;
-constexpr int SP_IMAGE = 3 * SP_PLANE;               // 52224 bytes
+constexpr int SP_IMAGE = 52224;                      // 3 planes (49152 bytes) + room for the Transformer mode's fp32 Q | K | V rows
+static_assert(SP_IMAGE >= 3 * SP_PLANE && SP_IMAGE % 16 == 0, "three planes fit an image");
+__device__ __forceinline__ int sp_chunk(int row, int c) { return ((c ^ row) & 15) << 4; }   // byte offset of logical chunk c in its row
 
 struct GnnStruct {
   const void* x;          // int64 [N, ldx] (discrete) or float [N, F]
@@ -79,7 +85,7 @@ __device__ __forceinline__ void sp_store4(unsigned char* img, int row, int ot, i
     m[i] = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
     l[i] = r - m[i];
   }
-  unsigned char* p = img + row * SP_STRIDE + (ot >> 1) * 64 + g * 16 + (ot & 1) * 8;
+  unsigned char* p = img + row * SP_STRIDE + sp_chunk(row, (ot >> 1) * 4 + g) + (ot & 1) * 8;
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
   *reinterpret_cast<uint2*>(p + SP_PLANE) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
   *reinterpret_cast<uint2*>(p + 2 * SP_PLANE) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
@@ -150,14 +156,15 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
   int otl, rtl;
   tr.decode(tr.t_hi - 1, otl, rtl);
   const bool two_ots = otl != ot0;
-  const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE + (lane >> 4) * 16;
+  const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE;
   auto load_rows = [&](int rt, Split8 (&x)[NKB]) {
     const unsigned char* p = rowbase + rt * 16 * SP_STRIDE;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      x[kb].h = *reinterpret_cast<const u32x4*>(p + kb * 64);
-      x[kb].m = *reinterpret_cast<const u32x4*>(p + kb * 64 + SP_PLANE);
-      x[kb].l = *reinterpret_cast<const u32x4*>(p + kb * 64 + 2 * SP_PLANE);
+      const unsigned char* pc = p + sp_chunk(lane & 15, kb * 4 + (lane >> 4));
+      x[kb].h = *reinterpret_cast<const u32x4*>(pc);
+      x[kb].m = *reinterpret_cast<const u32x4*>(pc + SP_PLANE);
+      x[kb].l = *reinterpret_cast<const u32x4*>(pc + 2 * SP_PLANE);
     }
   };
 #ifdef SN_PROFILE
@@ -222,12 +229,14 @@ __device__ __forceinline__ void coop_gemm(WSplit<NKB>& pre, WSplit<NKB>& alt, co
 // done.  A tile is then on its way for a whole stage (the barrier, the other register tile's Linear, possibly an aggregation) before
 // it is needed; with the ping-pong of coop_gemm it is needed one short stage (~1 us of work per wave) after its issue, and every one of
 // the 22 stages waited out most of a memory round trip (fetch-size sweep: DESIGN.md §8).
+// kb0: first K block of the operand rows (the Transformer mode's FFN 2 reads the two halves of its 128 hidden channels as K blocks 0-1
+// and 2-3 of one image).
 template <int NKB, typename Epi>
 __device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned char* img, TileRange tr, int lane, Epi epi,
-                                               const void* nn_wsp, TileRange nn_tr) {
+                                               const void* nn_wsp, TileRange nn_tr, int kb0 = 0) {
   if (!tr.empty()) {
     asm volatile("" : "+v"(tr.t_lo), "+v"(tr.t_hi), "+v"(tr.T));     // (see coop_gemm)
-    const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE + (lane >> 4) * 16;
+    const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int t = tr.t_lo + i;
@@ -236,11 +245,14 @@ __device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned 
         tr.decode(t, ot, rt);
         Split8 in[NKB];
         const unsigned char* p = rowbase + rt * 16 * SP_STRIDE;
+        int cx = (lane & 15) ^ (lane >> 4) ^ (kb0 << 2);             // my chunk of K block kb: (4 kb) ^ cx
+        asm volatile("" : "+v"(cx));                                   // (per pair: else the chunk addresses of all four pairs are kept live)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-          in[kb].h = *reinterpret_cast<const u32x4*>(p + kb * 64);
-          in[kb].m = *reinterpret_cast<const u32x4*>(p + kb * 64 + SP_PLANE);
-          in[kb].l = *reinterpret_cast<const u32x4*>(p + kb * 64 + 2 * SP_PLANE);
+          const unsigned char* pc = p + (((4 * kb) ^ cx) << 4);
+          in[kb].h = *reinterpret_cast<const u32x4*>(pc);
+          in[kb].m = *reinterpret_cast<const u32x4*>(pc + SP_PLANE);
+          in[kb].l = *reinterpret_cast<const u32x4*>(pc + 2 * SP_PLANE);
         }
         epi(rt, ot, mfma_split_tile<NKB>(cur, in), cur.e[0], cur.e[1], cur.e[2]);
       }
@@ -705,7 +717,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         sp_store4(B, rt * 16 + li, ot, g, v);
       };
       coop_gemm_roll<NKB>(pre, A, tr, lane, epi_f2a, seq(8), seq_tr(8));
-      coop_gemm_roll<NKB>(alt, A + 2 * 64, tr, lane, epi_f2b, seq(9), seq_tr(9));      // K blocks 2, 3 of the hidden rows
+      coop_gemm_roll<NKB>(alt, A, tr, lane, epi_f2b, seq(9), seq_tr(9), 2);      // K blocks 2, 3 of the hidden rows
       lds_barrier();
       unsigned char* tsw = A; A = B; B = tsw;
     }

@@ -197,8 +197,8 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   const bool slab = pat != nullptr && kmax == 0 && bd.phi_bin_mem != nullptr;
   int* pat_first = pat;                          // [PAT_MAX + 1]
   int* pat_nm = pat + (PAT_MAX + 1);             // [PAT_MAX]
-  int* pat_mem = pat_nm + PAT_MAX;               // [PAT_MAX][8]  class | row offset << 7 | copy index << 13
-  int* pat_base = pat_mem + 8 * PAT_MAX;         // [PAT_MAX][8]  first slab of the member's class this pattern takes (+ copy index)
+  int* pat_mem = pat_nm + PAT_MAX;               // [PAT_MAX][8]  runs: class | row offset << 7 | copies << 13
+  int* pat_base = pat_mem + 8 * PAT_MAX;         // [PAT_MAX][8]  first slab of the run's class this pattern takes
   __shared__ int s_npat, s_slab_bins;
   int* bucket = lds;            // [B]   graph ids grouped by size, ascending id inside a group
   int* nbv = lds + B;           // [B]   (record scratch of the column packing)
@@ -241,8 +241,9 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
   int* col_start = rec_pre + B;                // [B] record index of every column's first member
   int* col_bin = col_start + B;                // [B + 1] first bin of every column
   PL_STAMP(4);
-  const int rank_t0 = slab ? 128 : 64;             // first thread of the id-ranking waves
-  if (slab && t >= 64 && t < 128) {
+  const int rank_t0 = 128;                         // first thread of the id-ranking waves (wave 0: the column chain, wave 1: the slab chain)
+  if (t >= 64 && t < 128) {
+    if (slab) {
     // ---- wave 1, all-eigenvector mode: the slab-level pattern chain (see above).  State in registers: lane s-1 holds class s's
     //      unplaced / placed slab counts; the members of the pattern being built sit in lanes 0..7 of two registers and go to LDS
     //      with one store per pattern; the run length is a float-reciprocal quotient (corrected to the exact floor) reduced over
@@ -254,32 +255,30 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     int np = 0, nb = 0;
     while (avail) {
       int mult = 0;                                 // copies of my class in this pattern
-      int pm = -1, pb = 0;                          // lanes 0..7: the pattern's member words / first slabs
-      int cap = 64, nm = 0;
-      int cls = 64 - __clzll(avail);
+      int pm = -1, pb = 0;                          // lanes 0..7: the pattern's runs (class | row offset << 7 | copies << 13) / their first slabs
+      int cap = 64, nm = 0, nrun = 0;
       const bool single = np >= PAT_MAX - 64;
-      while (true) {
-        const int copies = __builtin_amdgcn_readlane(mult, cls - 1);
-        const int left = __builtin_amdgcn_readlane(cnt, cls - 1) - copies;
-        if (left > 0 && cls <= cap && nm < 8) {
-          pm = writelane(pm, cls | ((64 - cap) << 7) | (copies << 13), nm);
-          pb = writelane(pb, __builtin_amdgcn_readlane(used, cls - 1) + copies, nm);
-          mult = writelane(mult, copies + 1, cls - 1);
-          cap -= cls;
-          ++nm;
-          if (single) break;
-          continue;                                 // another slab of the same class, if it fits
-        }
-        const int limit = cap < cls - 1 ? cap : cls - 1;      // next: the largest class below this one that still fits
-        if (limit <= 0 || nm >= 8) break;
-        const unsigned long long m = avail & ((1ull << limit) - 1ull);    // 0 < limit < 64
-        if (!m) break;
-        cls = 64 - __clzll(m);
-      }
-      // run length r = min over the pattern's classes of floor(cnt / mult)   (cnt < 2^24: the float quotient is within one of it)
+      unsigned long long m = avail;
+      do {
+        const int cls = 64 - __clzll(m);            // the largest class with slabs left that fits the rows left
+        const int left = __builtin_amdgcn_readlane(cnt, cls - 1);
+        int lim = left < 8 - nm ? left : 8 - nm;    // as many copies of it as fit (a run)
+        if (single) lim = 1;
+        int j = 1, capj = cap - cls;
+        while (j < lim && capj >= cls) { ++j; capj -= cls; }
+        pm = writelane(pm, cls | ((64 - cap) << 7) | (j << 13), nrun);
+        pb = writelane(pb, __builtin_amdgcn_readlane(used, cls - 1), nrun);
+        mult = writelane(mult, j, cls - 1);
+        cap = capj;
+        nm += j;
+        ++nrun;
+        const int limit = cap < cls - 1 ? cap : cls - 1;       // next: the largest class below this one that still fits
+        m = (limit > 0 && nm < 8 && !single) ? (avail & ((1ull << limit) - 1ull)) : 0ull;
+      } while (m);
+      // run length r = min over the pattern's classes of floor(cnt / mult)   (cnt < 2^24: the reciprocal quotient is within one of it)
       int q = 0;
       if (mult > 0) {
-        q = (int)((float)cnt * __frcp_rn((float)mult));
+        q = (int)((float)cnt * __builtin_amdgcn_rcpf((float)mult));
         q += ((q + 1) * mult <= cnt) ? 1 : 0;
         q -= (q * mult > cnt) ? 1 : 0;
       }
@@ -291,13 +290,14 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       cnt -= r * mult;
       used += r * mult;
       if (lane < 8) { pat_mem[np * 8 + lane] = pm; pat_base[np * 8 + lane] = pb; }
-      if (lane == 0) { pat_first[np] = nb; pat_nm[np] = nm; }
+      if (lane == 0) { pat_first[np] = nb; pat_nm[np] = nrun; }
       nb += r;
       ++np;
       avail = __ballot(cnt > 0);
     }
     if (lane == 0) { pat_first[np] = nb; s_npat = np; s_slab_bins = nb; }
     PL_STAMP_T(8, 64);
+    }
   } else if (t >= rank_t0) {
     // ---- meanwhile, on the other waves: the graphs of every size class in ascending id order (`bucket`; the packer only needs the
     //      class counts, the ids are resolved after it).  Rank inside the class = number of earlier graphs of the same size (LDS
@@ -314,6 +314,8 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
         bucket[bstart[n] + rank] = g;
       }
     }
+  } else if (slab) {
+    if (t == 0) s_nrec = 0;                         // (slab mode lays out no columns: the stage kernels walk the member records only)
   } else {
     const int lane = t;
     int cnt = hist[lane + 1];                       // class s = lane + 1
@@ -374,7 +376,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     const int rbins = slab ? s_slab_bins : nbins;        // bins of the member records (what the stage kernels walk)
     const bool over = nbins > bd.phi_max_bins || rbins > bd.phi_max_bins;
     if (t == 0) {
-      bd.meta[0] = nbins;
+      bd.meta[0] = rbins;
       bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
       bd.meta[3] = ncol;
       bd.meta[7] = bd.phi_bin_mem != nullptr ? rbins : 0;
@@ -392,21 +394,23 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
             const int mid = (lo + hi) >> 1;
             if (pat_first[mid] <= b) lo = mid; else hi = mid;
           }
-          const int rep = b - pat_first[lo], nm = pat_nm[lo];
+          const int rep = b - pat_first[lo], nrun = pat_nm[lo];
           int w[16];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            w[2 * k] = -1; w[2 * k + 1] = 0;
-            if (k < nm) {
-              const int pw = pat_mem[lo * 8 + k];
-              const int cls = pw & 127, off = (pw >> 7) & 63;
-              int step = 0;
-              for (int k2 = 0; k2 < nm; ++k2) step += ((pat_mem[lo * 8 + k2] & 127) == cls) ? 1 : 0;
-              const int q = pat_base[lo * 8 + k] + rep * step;
+          for (int k = 0; k < 16; ++k) w[k] = (k & 1) ? 0 : -1;
+          int mi = 0;                                      // member of the bin (<= 8 over all runs)
+          for (int k = 0; k < nrun; ++k) {
+            const int pw = pat_mem[lo * 8 + k];
+            const int cls = pw & 127, off = (pw >> 7) & 63, j = (pw >> 13) & 15;
+            const int q0 = pat_base[lo * 8 + k] + rep * j;
+            for (int c = 0; c < j; ++c, ++mi) {
+              const int q = q0 + c;
               const int rank = q / cls, idx = q - rank * cls;
               const int g = bucket[bstart[cls] + rank];
-              w[2 * k] = g | (idx << 13) | (off << 19) | ((cls - 1) << 25);
-              w[2 * k + 1] = gp[g];
+              const int w0 = g | (idx << 13) | ((off + c * cls) << 19) | ((cls - 1) << 25), w1 = gp[g];
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (u == mi) { w[2 * u] = w0; w[2 * u + 1] = w1; }
             }
           }
           int4* dst = reinterpret_cast<int4*>(bd.phi_bin_mem + (size_t)b * 16);

@@ -23,7 +23,14 @@ class GraphedDGLForward:
 
     Host-side decisions are frozen at capture time: the largest graph (<= 64 nodes for the stage kernels) and, for GatedGCN, the
     largest in-edge count are those of the example batch; a later batch beyond the kernels' limits is flagged on the device (NaN rows,
-    `net.check_last()` raises) instead of being re-routed to the layer path."""
+    `net.check_last()` raises) instead of being re-routed to the layer path.
+
+    THE WEIGHTS ARE FROZEN AT CAPTURE TOO.  The recorded launches carry device pointers into the eval-time packed copies of the
+    parameters (the nets' `_cache`, the sign-invariant net's `_prep` / `_fused`), which `train()`, `eval()`, `.to()`,
+    `load_state_dict()` — anything that drops those caches — would free under the recorded graph, while the embedding tables are read
+    in place.  This object therefore keeps the caches of the capture alive and remembers the version counter of every parameter and
+    buffer: a replay after the net was switched to another mode, moved, re-loaded or trained in between raises instead of returning
+    scores of freed or half-updated weights — build a new GraphedDGLForward then."""
 
     def __init__(self, net, g, h, pos_enc, e=None, snorm_n=None, warmup=2):
         from .dgl_deepsigns import Graph
@@ -60,6 +67,30 @@ class GraphedDGLForward:
         #  checked: the recorded plan's status block is rewritten by every replay, so check() re-arms it)
         self._last_plan = getattr(net, "_last_plan", None)
         self.out = self._graphed.out
+        # what the recorded pointers refer to: held here so that the allocator cannot hand the blocks out, and fingerprinted
+        self._held = self._cache_objects()
+        self._stamp = self._fingerprint()
+
+    def _cache_objects(self):
+        held = []
+        for m in self.net.modules():
+            for name in ("_cache", "_prep", "_fused", "_keep", "_pk", "_bn"):
+                v = m.__dict__.get(name)
+                if v is not None:
+                    held.append((m, name, v))
+        return held
+
+    def _fingerprint(self):
+        ver = sum(int(t._version) for t in list(self.net.parameters()) + list(self.net.buffers()))
+        return (ver, bool(self.net.training), tuple(id(v) for _, _, v in self._held))
+
+    def _assert_fresh(self):
+        now = (sum(int(t._version) for t in list(self.net.parameters()) + list(self.net.buffers())), bool(self.net.training),
+               tuple(id(m.__dict__.get(name)) for m, name, _ in self._held))
+        if now != self._stamp:
+            raise RuntimeError("GraphedDGLForward: the network changed since the forward was recorded (train()/eval(), .to(), load_state_dict "
+                               "or an update of its parameters): the recorded launches point into the packed weights of the capture — "
+                               "record a new GraphedDGLForward")
 
     def check(self):
         """One host wait: raises what the LAST replay flagged on the device (an atom / bond type outside its embedding table:
@@ -72,21 +103,34 @@ class GraphedDGLForward:
             self.net.check_last()
 
     def __call__(self, g=None, h=None, pos_enc=None, e=None, snorm_n=None):
+        self._assert_fresh()
+        todo = []
+
         def put(dst, src, what):
             if src is None:
                 return
             if tuple(src.shape) != tuple(dst.shape):
                 raise ValueError(f"GraphedDGLForward: {what} has shape {tuple(src.shape)}, the recorded batch {tuple(dst.shape)}")
-            dst.copy_(src, non_blocking=True)
+            todo.append((dst, src))
+        # every argument is validated BEFORE anything is copied: a rejected call leaves the recorded inputs as they were
         if g is not None:
             s, d = g.edges()
             put(self.src, s, "src"); put(self.dst, d, "dst")
-            put(self.bnn, torch.as_tensor(g.batch_num_nodes()), "batch_num_nodes")
+            bnn = torch.as_tensor(g.batch_num_nodes())
+            put(self.bnn, bnn, "batch_num_nodes")
+            if not bnn.is_cuda:            # (host-side counts, as DGL keeps them: the frozen totals are checked here, not left to check())
+                nmax, ntot = (int(bnn.max()), int(bnn.sum())) if bnn.numel() else (0, 0)
+                if ntot != self.g._sn_node_counts[1]:
+                    raise ValueError(f"GraphedDGLForward: batch_num_nodes sums to {ntot}, the recorded batch has {self.g._sn_node_counts[1]} nodes")
+                if nmax > max(self.g._sn_node_counts[0], 64):
+                    raise ValueError(f"GraphedDGLForward: a graph of {nmax} nodes exceeds the recorded batch's largest graph and the stage kernels' 64")
         put(self.h, h, "h"); put(self.pe, pos_enc, "pos_enc")
         if self.e is not None:
             put(self.e, e, "e")
         if self.snorm is not None:
             put(self.snorm, snorm_n, "snorm_n")
+        for dst, src in todo:
+            dst.copy_(src, non_blocking=True)
         return self._graphed.replay()
 
 

@@ -90,6 +90,22 @@ def test_graphed_dgl_forward_replays_the_eager_forward(name):
     gc, hc, pc, ec, sc = _inputs(c, k)
     with pytest.raises(ValueError, match="shape"):
         gf(gc, hc, pc, ec, sc if snorm else None)
+    # a rejected call copied nothing (every argument is validated first): the recorded inputs are still batch b's
+    with pytest.raises(ValueError, match="shape"):
+        gf(ga, ha, pa[:, :-1] if pa.shape[1] > 1 else pa[:-1], ea, sa if snorm else None)
+    assert torch.equal(gf().clone(), yb)
+    # the weights are frozen at capture: after a mode round trip (which drops the packed copies the recorded launches point into),
+    # an in-place update or a re-load, a replay raises instead of reading freed or half-updated weights
+    net.train()
+    net.eval()
+    with pytest.raises(RuntimeError, match="changed since the forward was recorded"):
+        gf()
+    gf2 = GraphedDGLForward(net, ga, ha, pa, ea, sa if snorm else None)
+    assert torch.equal(gf2().clone(), ya)
+    with torch.no_grad():
+        next(net.parameters()).mul_(1.0)
+    with pytest.raises(RuntimeError, match="changed since the forward was recorded"):
+        gf2()
 
 
 def test_transformer_net_fused_eval_layers_equal_the_op_by_op_path():
