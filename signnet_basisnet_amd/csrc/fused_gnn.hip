@@ -261,6 +261,66 @@ __device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned 
   if (nn_wsp != nullptr && !nn_tr.empty()) wload<NKB>(cur, nn_wsp, nn_tr.first_ot(), lane);
 }
 
+// coop_gemm_roll for a graph whose row-tile count is a COMPILE-TIME constant (PAIRS; NT = 8: wave w owns output tile w and the row
+// tiles 0 .. PAIRS-1): the refill of `cur` is issued INSIDE the last tile product — K block kb's three weight fragments are dead as
+// soon as its six MFMAs are issued, so the next tile's fragments of that K block are requested right there, and the epilogue vectors
+// behind the epilogue.  With coop_gemm_roll all 15 loads of every wave sit between the last epilogue and the stage's barrier: 8
+// waves x 15 KB through the CU's 64 B/clk vector-memory path, ~1.9 k cycles per stage that nothing overlaps
+// (profiles/r04_gnn_stage_stamps.txt: 3.6 k cycles of every stage do not depend on the graph's size).  The refill is unconditional
+// (`nn_wsp` / `nn_ot` always name a valid tile: a wave without work in the stage after the next fetches one it will not use), so the
+// register tile has ONE definition per call — as a branch the woven form made the compiler copy tiles at every join (900 bytes of
+// private segment per lane).
+template <int NKB, int PAIRS, typename Epi>
+__device__ __forceinline__ void coop_gemm_weave(WSplit<NKB>& cur, const unsigned char* img, int ot, int lane, Epi epi,
+                                                const void* nn_wsp, int nn_ot) {
+  constexpr int NFE = 3 * NKB + SPLIT_EPI;
+  const __amdgpu_buffer_rsrc_t rs = weight_rsrc(reinterpret_cast<const float*>(nn_wsp), 0x7fffffff);
+  const int voff = lane * 16;
+  const int base = __builtin_amdgcn_readfirstlane(nn_ot * NFE * 1024);
+  const unsigned char* rowbase = img + (lane & 15) * SP_STRIDE;
+#pragma unroll
+  for (int rt = 0; rt < PAIRS; ++rt) {
+    Split8 in[NKB];
+    const unsigned char* p = rowbase + rt * 16 * SP_STRIDE;
+    int cx = (lane & 15) ^ (lane >> 4);
+    asm volatile("" : "+v"(cx));                                   // (per pair: see coop_gemm_roll)
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const unsigned char* pc = p + (((4 * kb) ^ cx) << 4);
+      in[kb].h = *reinterpret_cast<const u32x4*>(pc);
+      in[kb].m = *reinterpret_cast<const u32x4*>(pc + SP_PLANE);
+      in[kb].l = *reinterpret_cast<const u32x4*>(pc + 2 * SP_PLANE);
+    }
+    if (rt + 1 < PAIRS) {
+      epi(rt, ot, mfma_split_tile<NKB>(cur, in), cur.e[0], cur.e[1], cur.e[2]);
+      __builtin_amdgcn_sched_barrier(0);                           // pairs stay sequential (registers)
+    } else {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const u32x4 wh = cur.f[3 * kb], wm = cur.f[3 * kb + 1], wl = cur.f[3 * kb + 2];
+        a1 = mfma_bf(wl, in[kb].h, a1);
+        a0 = mfma_bf(wm, in[kb].h, a0);
+        a1 = mfma_bf(wh, in[kb].l, a1);
+        a0 = mfma_bf(wh, in[kb].m, a0);
+        a1 = mfma_bf(wm, in[kb].m, a1);
+        a0 = mfma_bf(wh, in[kb].h, a0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cur.f[3 * kb + j] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (3 * kb + j) * 1024, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      epi(rt, ot, a0 + a1, cur.e[0], cur.e[1], cur.e[2]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < SPLIT_EPI; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, base + (3 * NKB + j) * 1024, 0);
+        cur.e[j] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+      }
+    }
+  }
+}
+
 // DGL = true: the GraphPrediction tree's GIN net on the same mapping (nets/ZINC_graph_regression/gin_net.py:83-126 in eval mode):
 //   h = embedding_h[atom] + embedding_p(p)          -> the input stage with lin_a = I, lin_b = embedding_p (bias in e0), "slot sum" = p
 //   L x  h = MLP((1 + eps) h_i + sum_{j -> i} h_j)  -> no edge term and no ReLU in the message; Linear . ReLU . [BN folded] . Linear,
@@ -274,9 +334,12 @@ __device__ __forceinline__ void coop_gemm_roll(WSplit<NKB>& cur, const unsigned 
 //   BatchNorm.  The two split images swap roles every layer (operand in one, Q | K | V / the next operand in the other).
 // The eight stage matrices of layer l are layers[l].etab[0..7] = Q, K, V, O_h, FFN1[:64], FFN1[64:], FFN2[:, :64], FFN2[:, 64:]
 // (w1s / w2s repeat etab[0] / etab[1]: what the input stage prefetches).
-template <int NT, int MODE = 0>
+// TC > 0 (the GINE net at NT = 8 only): the graph's row-tile count as a compile-time constant — the node-row Linears run on
+// coop_gemm_weave (the kernel dispatches on ceil(n / 16)).
+template <int NT, int MODE = 0, int TC = 0>
 __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_params& P) {
   constexpr bool DGL = MODE != 0, TF = MODE == 2;
+  static_assert(TC == 0 || (NT == 8 && MODE == 0), "compile-time row tiles: the GINE net at NT = 8");
   static_assert(!TF || NT == 4, "the Transformer mode is written for d = 64");
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
@@ -311,10 +374,13 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   if (n <= 0) { give_up(0); return; }
   if (n > GNN_ROWS) { give_up(1); return; }
   const int e_base = S.rowptr[gs];
-  const int ne = S.rowptr[gs + n] - e_base;
-  if (ne > GNN_EMAX) { give_up(2); return; }
+  const int ne = S.rowptr[gs + n] - e_base;               // (checked below, behind the loads that need `gs` only)
   const int d = P.d;
-  const int T = (n + 15) >> 4;                               // row tiles (1..4)
+  // block-wide facts of the prologue: [0] a discrete feature id of this graph lies outside its embedding table, [1] an edge feature
+  // value the small class table cannot index, [2] bit v: edge feature value v occurs (one discrete edge feature column)
+  __shared__ unsigned s_pro[3];
+  if (threadIdx.x == 0) { s_pro[0] = 0u; s_pro[1] = 0u; s_pro[2] = 0u; }
+  const int T = TC > 0 ? TC : (n + 15) >> 4;                // row tiles (1..4)
   const int ntile = T * NT;
   TileRange tr;                                               // my share of every node-row Linear (output-tile major)
   tr.T = T;
@@ -382,7 +448,19 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       if (idx < ne * (D / 4)) eepf[i] = edge_embed(Lq, idx / (D / 4), 4 * (idx % (D / 4)));
     }
   };
+  bool tab_pending = false;    // the class table's rows are in registers (eepf), stored by ee_store() behind the input Linears
   auto ee_store = [&]() {
+    if (tab_pending) {
+      tab_pending = false;
+      int t1 = threadIdx.x;
+      asm volatile("" : "+v"(t1));
+#pragma unroll
+      for (int i = 0; i < GNN_EEPF; ++i) {
+        const int idx = t1 + i * GNN_WAVES * 64;
+        if (idx < P.n_layers * ncls * (D / 4)) lds_st4(EE + (idx / (D / 4)) * LD + 4 * (idx % (D / 4)), eepf[i]);
+      }
+      return;
+    }
     if (!use_ee) return;
     int t0 = threadIdx.x;
     asm volatile("" : "+v"(t0));
@@ -407,9 +485,12 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   // to four float4 of the slot sum per thread cover the whole graph (n <= 64, ne <= 192 < blockDim).
   static_assert(GNN_EMAX <= GNN_WAVES * 64 && GNN_ROWS < GNN_WAVES * 64 && GNN_ROWS * (D / 4) <= 4 * GNN_WAVES * 64, "one pass of the block covers the graph");
   const int tid = threadIdx.x;
+  // Round 5: what needs only the graph's first node — CSR row pointers, the slot sum, the node feature ids of my rows — is requested
+  // before the in-edge count is even known; the edge lists follow, then the edge features and the node-table rows (as soon as their
+  // ids are there), and only then the two 15 KB weight tiles: every wait below names loads issued before them.  The prologue used to be
+  // six dependent round trips (graph_ptr, rowptr, edge lists, edge features, class table | node ids, node table): the node side now
+  // runs beside the edge side and the class table's rows land under the two input Linears.
   const int rp_v = tid <= n ? S.rowptr[gs + tid] : 0;
-  const int src_v = tid < ne ? S.col[e_base + tid] : 0;
-  const int eid_v = tid < ne ? S.eperm[e_base + tid] : 0;
   const int rho_ld = S.rho_ld, rho_w = S.rho_w;
   const bool rs_vec = ((rho_ld | rho_w) & 3) == 0;
   f32x4 rs_v[4];
@@ -422,17 +503,30 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       if (4 * c4 < rho_w) rs_v[j] = ld4(S.rho_sum + (int64_t)(gs + rr) * rho_ld + 4 * c4);
     }
   }
-  if (!tr.empty()) {
-    wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);                      // in flight while the inputs are staged
-    if constexpr (ROLL) wload<NKB>(alt, P.lin_b, tr.first_ot(), lane);
+  const bool xid_pref = P.node_discrete && P.node_nf == 1 && (d & 3) == 0;     // one id column: the ids of my (<= 4) rows, up front
+  long long xid[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xid[i] = -1;
+    const int t = tr.t_lo + i;
+    if (xid_pref && t < tr.t_hi) {
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      if (rt * 16 + li < n) xid[i] = reinterpret_cast<const int64_t*>(S.x)[(int64_t)(gs + rt * 16 + li) * S.ldx];
+    }
   }
+  if (ne > GNN_EMAX) { give_up(2); return; }
+  const int src_v = tid < ne ? S.col[e_base + tid] : 0;
+  const int eid_v = tid < ne ? S.eperm[e_base + tid] : 0;
   SN_STAMP(30);
   // ---------------------------------------------------------------- clear the split images (K padding must read as 0)
   for (int i = threadIdx.x; i < 2 * SP_IMAGE / 16; i += GNN_WAVES * 64)
     reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+  lds_barrier();               // (the prologue's flags are initialised)
   SN_STAMP(31);
   // ---------------------------------------------------------------- per-graph CSR + edge data -> LDS (once)
-  bool id_bad = false;        // a discrete feature value of this graph lies outside its embedding table
+  const bool efast = !DGL && P.n_layers > 0 && P.edge_discrete && P.edge_nf == 1 && (d & 3) == 0;   // classes = the feature values
+  int my_ev = 0;
   {
     const int EF = P.edge_nf;
     if (tid <= n) erow[tid] = rp_v - e_base;
@@ -448,7 +542,11 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
             const int64_t v = ei[f];
             const bool ok = (uint64_t)v < (uint64_t)P.edge_vocab;      // nn.Embedding would raise IndexError: never dereferenced
             efeat[k * EF + f] = ok ? (int)v : 0;
-            if (!ok) { atomicOr(&S.status[3], 4); id_bad = true; }
+            if (!ok) { atomicOr(&S.status[3], 4); atomicOr(&s_pro[0], 1u); }
+            if (efast) {
+              my_ev = ok ? (int)v : 0;
+              if (my_ev < 32) atomicOr(&s_pro[2], 1u << my_ev); else atomicOr(&s_pro[1], 1u);
+            }
           }
         } else {
           const float* ea = reinterpret_cast<const float*>(S.edge_attr) + (int64_t)eid * S.lde;
@@ -457,11 +555,55 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       }
     }
   }
-  int graph_bad = __syncthreads_or(id_bad);          // images cleared, efeat complete (+ did anyone see a bad edge feature id)
-  id_bad = false;
+  // the node-table rows of my pairs (their ids were the first loads): in flight during the class work below
+  f32x4 nrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    nrow[i] = zero4;
+    const int t = tr.t_lo + i;
+    if (xid_pref && t < tr.t_hi && xid[i] != -1) {
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      long long xv = xid[i];
+      if ((uint64_t)xv >= (uint64_t)P.node_vocab) { xv = 0; atomicOr(&S.status[3], 4); atomicOr(&s_pro[0], 1u); }
+      const int c = 16 * ot + 4 * g;
+      if (c < d) nrow[i] = ld4(P.ntab[0] + xv * d + c);
+    }
+  }
+  if (!tr.empty()) {
+    wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);                      // in flight while the inputs are staged
+    if constexpr (ROLL) wload<NKB>(alt, P.lin_b, tr.first_ot(), lane);
+  }
+  lds_barrier();               // images cleared, CSR / edge features staged (an LDS-only barrier: the loads above stay in flight)
   SN_STAMP(32);
   // ---------------------------------------------------------------- edge-feature classes (see use_tab above)
-  if (!DGL && P.n_layers > 0) {
+  if (efast && s_pro[1] == 0u) {
+    // one discrete feature column with small values (ZINC: bond types 1..3): the class of an edge IS its value's rank among the
+    // values present — no search over the edges, no further barrier; row (l, c) of the table = layer l's embedding of value c
+    const unsigned present = s_pro[2];
+    ncls = __popc(present);
+    if (tid < ne) ecls[tid] = __popc(present & ((1u << my_ev) - 1u));
+    use_tab = ncls <= GNN_CLS && P.n_layers * ncls <= S.ee_rows;
+    if (use_tab) {
+      use_ee = false;
+      tab_pending = true;
+      int t0 = threadIdx.x;
+      asm volatile("" : "+v"(t0));
+#pragma unroll
+      for (int i = 0; i < GNN_EEPF; ++i) {
+        const int idx = t0 + i * GNN_WAVES * 64;
+        eepf[i] = zero4;
+        if (idx < P.n_layers * ncls * (D / 4)) {
+          const int rowi = idx / (D / 4), ch = 4 * (idx % (D / 4));
+          const int l = rowi / ncls, c = rowi - l * ncls;
+          unsigned m = present;
+          for (int q = 0; q < c; ++q) m &= m - 1u;           // the c-th value present
+          if (ch < d) eepf[i] = ld4(P.layers[l].etab[0] + (int64_t)__builtin_ctz(m) * d + ch);
+        }
+      }
+    }
+  }
+  if (!DGL && P.n_layers > 0 && !tab_pending && !(efast && s_pro[1] == 0u)) {
     const int EF = P.edge_nf;
     // lead = first edge with my feature tuple.  Every thread walks ALL the edges with block-uniform (broadcast) LDS reads and no
     // early exit: the reads pipeline, where a scan that stops at the first match serialises one LDS round trip per candidate and
@@ -536,7 +678,17 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   }
   SN_STAMP(34);
   // ---------------------------------------------------------------- input encoder -> SB (model.py:37)
-  if (P.node_discrete) {
+  if (xid_pref) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = tr.t_lo + i;
+      if (t < tr.t_hi && xid[i] != -1) {
+        int ot, rt;
+        tr.decode(t, ot, rt);
+        sp_store4(SB, rt * 16 + li, ot, g, nrow[i]);
+      }
+    }
+  } else if (P.node_discrete) {
     for (int t = tr.t_lo; t < tr.t_hi; ++t) {
       int ot, rt;
       tr.decode(t, ot, rt);
@@ -546,7 +698,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
         f32x4 s = zero4;
         for (int f = 0; f < P.node_nf; ++f) {
           int64_t xv = xi[f];
-          if ((uint64_t)xv >= (uint64_t)P.node_vocab) { xv = 0; atomicOr(&S.status[3], 4); id_bad = true; }    // see the edge features above
+          if ((uint64_t)xv >= (uint64_t)P.node_vocab) { xv = 0; atomicOr(&S.status[3], 4); atomicOr(&s_pro[0], 1u); }    // see the edge features above
           const float* trow = P.ntab[f] + xv * d;
           if ((d & 3) == 0) { if (c < d) s += ld4(trow + c); }
           else {
@@ -576,7 +728,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     }
   }
   SN_STAMP(35);
-  graph_bad |= __syncthreads_or(id_bad);   // inputs staged (+ did anyone see a bad node feature id); later barriers are LDS-only:
+  lds_barrier();                           // inputs staged; LDS-only like every later barrier:
+  const int graph_bad = (int)s_pro[0];     // (did anyone see a bad feature id)
   SN_STAMP(1);                             // a __syncthreads() would also drain the weight prefetch in flight (vmcnt(0))
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]) (model.py:39-40), pos = BN(W_out . slot_sum)
@@ -593,10 +746,12 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       lds_st4(o, (lds_ld4(o) + acc) + bias);
     };
     const bool hasl = P.n_layers > 0;
-    if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SB, tr, lane, epi_a, first_w, first_tr);
+    if constexpr (TC > 0) coop_gemm_weave<NKB, TC>(pre, SB, wave, lane, epi_a, first_w, first_tr.first_ot());
+    else if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SB, tr, lane, epi_a, first_w, first_tr);
     else coop_gemm<NKB>(pre, alt, P.lin_a, SB, tr, lane, epi_a, P.lin_b, tr);
     SN_STAMP(20);
-    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SA, tr, lane, epi_b, hasl ? P.layers[0].w2s : P.head_w2, hasl ? tr : h2);
+    if constexpr (TC > 0) coop_gemm_weave<NKB, TC>(alt, SA, wave, lane, epi_b, hasl ? P.layers[0].w2s : P.head_w2, hasl ? wave : 0);
+    else if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SA, tr, lane, epi_b, hasl ? P.layers[0].w2s : P.head_w2, hasl ? tr : h2);
     else coop_gemm<NKB>(pre, alt, P.lin_b, SA, tr, lane, epi_b, first_w, first_tr);
   }
   ee_store();
@@ -826,7 +981,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     // nn: Linear . BN . ReLU : SA -> SB
     const bool lastl = l + 1 == P.n_layers;
     auto epi_1 = [&](int rt, int ot, f32x4 acc, f32x4 sc, f32x4 sh, f32x4) { sp_store4(SB, rt * 16 + li, ot, g, relu4(acc * sc + sh)); };
-    if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, tr, lane, epi_1, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
+    if constexpr (TC > 0) coop_gemm_weave<NKB, TC>(pre, SA, wave, lane, epi_1, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, wave);
+    else if constexpr (ROLL) coop_gemm_roll<NKB>(pre, SA, tr, lane, epi_1, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
     else coop_gemm<NKB>(pre, alt, Lp.w1s, SA, tr, lane, epi_1, Lp.w2s, tr);
     lds_barrier();
     SN_ACCUM(11, pt);
@@ -839,7 +995,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       if (DGL) lds_st4(o, acc * sc + sh);           // the MLP's last Linear: nothing behind it
       else lds_st4(o, relu4(acc * sc + sh) + lds_ld4(o));
     };
-    if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, tr, lane, epi_2, lastl ? (DGL ? S.head_mid : P.head_w2) : P.layers[lastl ? l : l + 1].w2s,
+    if constexpr (TC > 0) coop_gemm_weave<NKB, TC>(alt, SB, wave, lane, epi_2, lastl ? P.head_w2 : P.layers[lastl ? l : l + 1].w2s, lastl ? 0 : wave);
+    else if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, tr, lane, epi_2, lastl ? (DGL ? S.head_mid : P.head_w2) : P.layers[lastl ? l : l + 1].w2s,
                                             lastl ? (DGL ? hr : h2) : tr);
     else coop_gemm<NKB>(pre, alt, Lp.w2s, SB, tr, lane, epi_2, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
     lds_barrier();
@@ -898,7 +1055,24 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
 // One workgroup per graph; the last workgroup to finish reports the batch's flags to the host (no separate copy).
 template <int NT, int MODE = 0>
 __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_gnn_params P) {
-  gnn_graph<NT, MODE>(S, P);
+  if constexpr (NT == 8 && MODE == 0) {
+    // one instantiation per row-tile count from two on (a graph's nodes: 17-32, 33-48, 49-64; see coop_gemm_weave) — with a fourth
+    // one for 1-16 nodes in the same kernel the compiler's allocation ended in 2.3 KB of private segment per lane; such a graph runs
+    // the general form (its chain is the shortest of the batch anyway)
+    const int n = S.graph_ptr[blockIdx.x + 1] - S.graph_ptr[blockIdx.x];
+    switch ((n + 15) >> 4) {
+      case 1: gnn_graph<NT, MODE, 1>(S, P); break;
+      case 2: gnn_graph<NT, MODE, 2>(S, P); break;
+      case 3: gnn_graph<NT, MODE, 3>(S, P); break;
+      case 4: gnn_graph<NT, MODE, 4>(S, P); break;
+      default:                                          // an empty / oversize graph: a NaN output row, the oversize flag
+        if (threadIdx.x == 0 && n > GNN_ROWS) atomicOr(&S.status[3], 1);
+        if ((int)threadIdx.x < P.n_out) S.y[(int64_t)blockIdx.x * P.n_out + threadIdx.x] = __uint_as_float(0x7fc00000u);
+        break;
+    }
+  } else {
+    gnn_graph<NT, MODE>(S, P);
+  }
   if (S.flags_host != nullptr) {
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -91,6 +91,7 @@ def test_graphed_dgl_forward_replays_the_eager_forward(name):
     with pytest.raises(ValueError, match="shape"):
         gf(gc, hc, pc, ec, sc if snorm else None)
     # a rejected call copied nothing (every argument is validated first): the recorded inputs are still batch b's
+    assert torch.equal(gf(gb, hb, pb, eb, sb if snorm else None).clone(), yb)
     with pytest.raises(ValueError, match="shape"):
         gf(ga, ha, pa[:, :-1] if pa.shape[1] > 1 else pa[:-1], ea, sa if snorm else None)
     assert torch.equal(gf().clone(), yb)
