@@ -363,6 +363,9 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   if ((int)blockIdx.x == g_prof_block && threadIdx.x == 0) for (int i = 8; i < 20; ++i) g_prof[i] = 0;
   long long pt = 0;
 #endif
+  WSplit<NKB> pre, alt;
+  // (measured and dropped: wave w's tile of the first Linear requested here, before graph_ptr is read — the graph's own loads then
+  //  queue behind 15 KB per wave on the in-order memory counter: prologue 20.3 k -> 23.6 k cycles)
   const int gs = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - gs;
   // a graph that cannot be evaluated gets a NaN output row (never uninitialised memory): see sn_gnn_fused_f32
   auto give_up = [&](int bit) {
@@ -471,7 +474,6 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     }
   };
 
-  WSplit<NKB> pre, alt;
   // one output tile per wave and Linear -> coop_gemm_roll: NT in {1, 2, 4, 8} by the range split above; NT = 7: the wave's share
   // q = ceil(7 T / 8) of the (tile, row tile) pairs equals T for every T <= 4
   constexpr bool ROLL = NT >= 7 || GNN_WAVES % NT == 0;
@@ -999,21 +1001,39 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
     else if constexpr (ROLL) coop_gemm_roll<NKB>(alt, SB, tr, lane, epi_2, lastl ? (DGL ? S.head_mid : P.head_w2) : P.layers[lastl ? l : l + 1].w2s,
                                             lastl ? (DGL ? hr : h2) : tr);
     else coop_gemm<NKB>(pre, alt, Lp.w2s, SB, tr, lane, epi_2, lastl ? P.head_w1 : P.layers[lastl ? l : l + 1].w1s, lastl ? hr : tr);
-    lds_barrier();
+    // TC > 0 (NT = 8): wave w owns channel tile w of EVERY row, in this Linear and in the next layer's aggregation alike — the rows the
+    // aggregation gathers were written by this very wave (LDS operations of a wave execute in order): no workgroup barrier between
+    // the two, only in front of the pooling, which reads all channels
+    if (TC > 0 && !lastl) asm volatile("" ::: "memory");
+    else lds_barrier();
     SN_ACCUM(12, pt);
     SN_STAMP(24 + l);
   }
   }
   SN_STAMP(3);
   // ---------------------------------------------------------------- add pooling -> row 0 of SA (rows 1..15: zero)   (model.py:57-61)
-  for (int i = threadIdx.x; i < 16 * (D / 4); i += GNN_WAVES * 64) {
-    const int rr = i / (D / 4), c4 = i % (D / 4);
-    f32x4 s = zero4;
-    if (rr == 0) {
-      for (int j = 0; j < n; ++j) s += lds_ld4(X1 + j * LD + 4 * c4);
-      if (DGL && S.pool_mean) s = s / (float)n;
+  // (sixteen interleaved partial sums per channel quad, then their sum in order: 4 + 16 dependent adds instead of n)
+  static_assert(16 * (D / 4) <= GNN_WAVES * 64 && (size_t)16 * D * sizeof(float) <= (size_t)(SP_PLANE - 16 * SP_STRIDE), "one pass; the partial sums fit");
+  // [16][D], parked in rows 16.. of image A's first plane: the head reads row tile 0 only, and unlike image B's — whose K padding of
+  // rows 0-15 the head's second Linear reads and must find zero — nothing there is looked at again
+  float* PS = reinterpret_cast<float*>(SA + 16 * SP_STRIDE);
+  {
+    const int pj = threadIdx.x / (D / 4), pc4 = threadIdx.x % (D / 4);
+    if (pj < 16) {
+      f32x4 s = zero4;
+      for (int r = pj; r < n; r += 16) s += lds_ld4(X1 + r * LD + 4 * pc4);
+      lds_st4(PS + pj * D + 4 * pc4, s);
     }
-    sp_store4(SA, rr, c4 >> 2, c4 & 3, s);
+    lds_barrier();
+    if (pj < 16) {
+      f32x4 s = zero4;
+      if (pj == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += lds_ld4(PS + j * D + 4 * pc4);
+        if (DGL && S.pool_mean) s = s / (float)n;
+      }
+      sp_store4(SA, pj, pc4 >> 2, pc4 & 3, s);
+    }
   }
   lds_barrier();
   SN_STAMP(4);

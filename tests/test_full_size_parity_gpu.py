@@ -206,3 +206,45 @@ def run_shipped_dgl_config(name, data=None, elementwise=True):
         if elementwise:
             PU.elementwise(hip, r32, f"{name}: {what} element-wise", ref64=r64)
         print(f"\n{name}: {what}: max|hip - cpu32| / max|cpu32| = {e:.2e}, |hip - f64| {PU.relerr(hip, r64):.2e}, |cpu32 - f64| {PU.relerr(r32, r64):.2e}")
+
+
+@pytest.mark.parametrize("balance,k", [("count", 16), ("rows", None)])
+def test_config4_global_batch_sharded_eight_ways_vs_the_oracle_of_the_whole_batch(balance, k):
+    """BASELINE configs[3] on one GPU: the 1 024-graph ZINC batch cut into the eight shards `bench.py --gpus 8` gives its ranks
+    (`dist.shard_batch`: by graph count with k = 16, by (node, slot) rows with all eigenvectors), the HIP forward of every shard, the
+    concatenation against the CPU oracle of the WHOLE batch at north_star's 1e-5 — SURVEY.md section 8(e): no data-path collective,
+    a rank never sees another rank's graphs; the module's default (strict) mode and the serving mode give the same bits."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import dist as D
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    ctor = (None, None, 128, 1, 4, 6)
+    torch.manual_seed(0)
+    m = SignNetGNN(*ctor, variant="gine", max_k=k)
+    PU.bn_randomize(m, 1)
+    world = 8
+    data = synth.make_batch(128 * world if k else 256, seed=1234 + 2, n_lo=9, n_hi=37)    # (all eigenvectors: 256 graphs keep the CPU oracle short)
+    cfg = O.make_cfg("gine", *ctor)
+    sd = {kk: v.detach().clone() for kk, v in m.state_dict().items()}
+    with torch.no_grad():
+        y_ref = O.signnet_gnn(sd, cfg, data, training=False, max_k=k)
+    m = m.cuda().eval()
+    shards = [D.shard_batch(data, r, world, balance=balance, max_k=k) for r in range(world)]
+    assert sum(s.num_graphs for s in shards) == data.num_graphs and all(s.num_graphs >= 1 for s in shards)
+    if balance == "count":
+        assert {s.num_graphs for s in shards} == {128}
+    else:
+        rows = [sum(n * n for n in s.sizes) for s in shards]
+        assert max(rows) <= 1.25 * (sum(rows) / world), rows                # rows-balanced: no rank much above the mean
+    outs = {}
+    for strict in (True, False):
+        m.strict = strict
+        ys = []
+        with torch.no_grad():
+            for s in shards:
+                ys.append(m(synth.batch_to(s, "cuda:0")))
+            m.check_last()
+        outs[strict] = torch.cat(ys, 0)
+    assert torch.equal(outs[True], outs[False])
+    PU.close(outs[True], y_ref, f"config 4 ({balance}): concatenated shard outputs vs the oracle of the whole batch")
+    PU.elementwise(outs[True], y_ref, f"config 4 ({balance}): y element-wise")

@@ -59,6 +59,58 @@ def test_two_rank_sharded_forward_equals_single_rank():
     assert tmax == 2.0          # max over ranks of (1 + rank)
 
 
+def _worker8(rank, world, port, q, balance):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import golden_util as G
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import dist as D
+    from signnet_basisnet_amd import synth
+    dist = D.init_process_group("gloo")
+    fx = G.load("gine_d16")
+    cfg = G.pyg_cfg(fx)
+    # 11 graphs over 8 ranks: uneven shards, ranks with a single graph; one graph (24 nodes) heavier than several ranks' whole share
+    data = synth.make_batch(11, seed=23, sizes=[5, 9, 4, 24, 6, 7, 10, 3, 8, 12, 5])
+    shard = D.shard_batch(data, rank, world, balance=balance, max_k=None)
+    y = O.signnet_gnn(fx.sd, cfg, shard, training=False) if shard.num_graphs else torch.zeros(0, fx.sd[[k for k in fx.sd][-1]].shape[0])
+    ally = D.gather_outputs(y, dist)
+    counts = D.all_ranks(float(shard.num_graphs), dist, "cpu")
+    tmax = D.max_over_ranks(1.0 + rank, dist, "cpu")
+    dist.barrier()
+    if rank == 0:
+        full = O.signnet_gnn(fx.sd, cfg, data, training=False)
+        q.put((tuple(ally.shape) == tuple(full.shape) and torch.allclose(ally, full, rtol=1e-6, atol=1e-6),
+               float((ally - full).abs().max()) if tuple(ally.shape) == tuple(full.shape) else -1.0, tmax, [int(c) for c in counts]))
+    dist.destroy_process_group()
+
+
+def _run8(balance):
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, balance)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out
+
+
+def test_eight_rank_sharded_forward_equals_single_rank():
+    """BASELINE configs[3]'s world size on CPU / gloo: 11 graphs over 8 ranks — uneven shards, ranks holding one graph — by graph count
+    and by (node, slot) rows; the concatenation of the ranks' outputs is the unsharded forward, the time is the maximum over the ranks."""
+    for balance in ("count", "rows"):
+        ok, err, tmax, counts = _run8(balance)
+        assert ok, f"balance={balance}: sharded forward differs from the unsharded one by {err} (graphs per rank {counts})"
+        assert tmax == 8.0 and sum(counts) == 11 and min(counts) >= 1 and len(counts) == 8, counts
+        assert 1 in counts and max(counts) >= 2, counts
+
+
 def test_shard_batch_is_a_partition():
     sys.path.insert(0, ROOT)
     from signnet_basisnet_amd import dist as D
