@@ -61,7 +61,8 @@ int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz);
  * five launches otherwise; never a host synchronisation.
  */
 typedef struct {
-  /* phi (sn_phi_fused_f32): graphs packed into columns of <= 64 rows; bin j of a column = slot j of its graphs */
+  /* phi: graphs packed into columns of <= 64 rows; bin j of a column = slot j of its graphs.  The four column arrays are OPTIONAL
+   * (all NULL: only the member records below are written — what the stage kernels walk; the planner's write-out is shorter) */
   int32_t* phi_bin_col;   /* [phi_max_bins]  column of each bin                                        */
   int64_t phi_max_bins;   /* capacity of phi_bin_col: sn_phi_bins_bound(B, kmax)                          */
   int32_t* phi_col_bin0;  /* [B+1]           first bin of each column (columns <= graphs)                 */
@@ -86,7 +87,7 @@ typedef struct {
  * finish — the host learns "can the fused stages serve this batch" ~20 us into a forward instead of after its last kernel.
  * host: int32[16], zeroed by the caller before the launch:
  *   [0] status[0] (malformed batch)   [1] largest graph (nodes)   [2] largest in-degree   [3] 1: a graph has > max_graph_edges in-edges
- *   [4] meta[1] (phi bins: 1 = a graph of > 64 nodes)   [5] meta[5] (rho bins)   [6] 1: a feature id outside its embedding tables
+ *   [4] meta[1] (phi bins: 1 = a graph of > 64 nodes) | 8 = a graph without nodes   [5] meta[5] (rho bins)   [6] 1: a feature id outside its embedding tables
  *   [8..11] set to 1 by the CSR / phi-bin / rho-bin / feature-id workgroup AFTER its words above (poll all four).
  * node_ids / edge_ids (may be NULL): the int64 feature ids of the DiscreteEncoders that consume this batch (every column of data.x /
  * data.edge_attr, model_utils/elements.py:21-37) and the row count of their tables: nn.Embedding's IndexError, decided here. */

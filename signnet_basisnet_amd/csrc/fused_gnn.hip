@@ -374,7 +374,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   };
   // earlier stages of this batch failed (malformed batch: status[0]; phi / rho bins not laid out: meta[1], meta[5])
   if (S.flags_src != nullptr && (S.flags_src[0] != 0 || (S.n_flags >= 16 && (S.flags_src[9] != 0 || S.flags_src[13] != 0)))) { give_up(0); return; }
-  if (n <= 0) { give_up(0); return; }
+  if (n <= 0) { give_up(8); return; }          // (a graph without nodes: flagged — the layer path evaluates it as the reference does)
   if (n > GNN_ROWS) { give_up(1); return; }
   const int e_base = S.rowptr[gs];
   const int ne = S.rowptr[gs + n] - e_base;               // (checked below, behind the loads that need `gs` only)
@@ -1085,8 +1085,8 @@ __global__ __launch_bounds__(GNN_WAVES * 64, 2) void k_gnn_coop(GnnStruct S, sn_
       case 2: gnn_graph<NT, MODE, 2>(S, P); break;
       case 3: gnn_graph<NT, MODE, 3>(S, P); break;
       case 4: gnn_graph<NT, MODE, 4>(S, P); break;
-      default:                                          // an empty / oversize graph: a NaN output row, the oversize flag
-        if (threadIdx.x == 0 && n > GNN_ROWS) atomicOr(&S.status[3], 1);
+      default:                                          // an empty / oversize graph: a NaN output row and its flag
+        if (threadIdx.x == 0) atomicOr(&S.status[3], n > GNN_ROWS ? 1 : 8);
         if ((int)threadIdx.x < P.n_out) S.y[(int64_t)blockIdx.x * P.n_out + threadIdx.x] = __uint_as_float(0x7fc00000u);
         break;
     }

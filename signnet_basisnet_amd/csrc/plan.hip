@@ -216,6 +216,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     const int n = gp[g + 1] - gp[g];
     if (n > 64) atomicOr(&s_err, 1);
     else if (n > 0) atomicAdd(&hist[n], 1);
+    else atomicOr(&s_err, 8);                      // (a graph without nodes: no bins; told to the early report only)
   }
   __syncthreads();
   if (t < 64) {   // bstart = exclusive prefix of hist[0..65] (wave scan; hist[0] = 0: empty graphs are not binned)
@@ -257,6 +258,8 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       int mult = 0;                                 // copies of my class in this pattern
       int pm = -1, pb = 0;                          // lanes 0..7: the pattern's runs (class | row offset << 7 | copies << 13) / their first slabs
       int cap = 64, nm = 0, nrun = 0;
+      int r = 0x7fffffff;                           // run length so far: min over the runs with ONE copy of their class (no division)
+      bool multi = false;                           // a run with several copies of its class: its quotient is taken below
       const bool single = np >= PAT_MAX - 64;
       unsigned long long m = avail;
       do {
@@ -269,23 +272,25 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
         pm = writelane(pm, cls | ((64 - cap) << 7) | (j << 13), nrun);
         pb = writelane(pb, __builtin_amdgcn_readlane(used, cls - 1), nrun);
         mult = writelane(mult, j, cls - 1);
+        if (j == 1) r = left < r ? left : r; else multi = true;
         cap = capj;
         nm += j;
         ++nrun;
         const int limit = cap < cls - 1 ? cap : cls - 1;       // next: the largest class below this one that still fits
         m = (limit > 0 && nm < 8 && !single) ? (avail & ((1ull << limit) - 1ull)) : 0ull;
       } while (m);
-      // run length r = min over the pattern's classes of floor(cnt / mult)   (cnt < 2^24: the reciprocal quotient is within one of it)
-      int q = 0;
-      if (mult > 0) {
-        q = (int)((float)cnt * __builtin_amdgcn_rcpf((float)mult));
-        q += ((q + 1) * mult <= cnt) ? 1 : 0;
-        q -= (q * mult > cnt) ? 1 : 0;
-      }
-      int r = 0x7fffffff;
-      for (unsigned long long pmask = __ballot(mult > 0); pmask; pmask &= pmask - 1) {
-        const int qc = __builtin_amdgcn_readlane(q, __builtin_ctzll(pmask));
-        r = qc < r ? qc : r;
+      if (multi) {
+        // floor(cnt / mult) of the classes taken several times   (cnt < 2^24: the reciprocal quotient is within one of it)
+        int q = 0x7fffffff;
+        if (mult > 1) {
+          q = (int)((float)cnt * __builtin_amdgcn_rcpf((float)mult));
+          q += ((q + 1) * mult <= cnt) ? 1 : 0;
+          q -= (q * mult > cnt) ? 1 : 0;
+        }
+        for (unsigned long long pmask = __ballot(mult > 1); pmask; pmask &= pmask - 1) {
+          const int qc = __builtin_amdgcn_readlane(q, __builtin_ctzll(pmask));
+          r = qc < r ? qc : r;
+        }
       }                                            // r >= 1: every class of the pattern had its copies left
       cnt -= r * mult;
       used += r * mult;
@@ -380,7 +385,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       bd.meta[1] = (s_err & 1) | (over ? 4 : 0);
       bd.meta[3] = ncol;
       bd.meta[7] = bd.phi_bin_mem != nullptr ? rbins : 0;
-      if (early_host != nullptr) { early_put(early_host, EH_PHI, (s_err & 1) | (over ? 4 : 0)); early_done(early_host, 1); }
+      if (early_host != nullptr) { early_put(early_host, EH_PHI, (s_err & 9) | (over ? 4 : 0)); early_done(early_host, 1); }
     }
     PL_STAMP(6);
     // ---- member records of every bin: word pair (graph | index << 13 | row offset << 19 | (rows - 1) << 25, first node of the graph),
@@ -447,6 +452,7 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
       }
     }
     PL_STAMP(7);
+    if (bd.phi_bin_col == nullptr) return;            // the caller wants the member records only (what the stage kernels walk)
     for (int c = t; c <= ncol; c += PLAN_T) bd.phi_col_bin0[c] = col_bin[c];
     // member records: the column of record r is the number of column starts <= r, found by bisection over col_start; the last member
     // of a column also closes its unused slots
@@ -914,9 +920,9 @@ extern "C" int sn_batch_plan_ex(const int64_t* batch, int64_t N, int64_t B, cons
   BinsDev bd{};
   const bool do_bins = bins != nullptr;
   if (do_bins) {
-    SN_REQUIRE(bins->phi_bin_col && bins->phi_col_bin0 && bins->phi_col_mem && bins->phi_col_off && bins->rho_bin0 &&
-                   bins->meta && bins->phi_max_bins >= 0,
-               "sn_batch_plan: incomplete sn_plan_bins");
+    SN_REQUIRE(bins->rho_bin0 && bins->meta && bins->phi_max_bins >= 0, "sn_batch_plan: incomplete sn_plan_bins");
+    const int ncolp = (bins->phi_bin_col != nullptr) + (bins->phi_col_bin0 != nullptr) + (bins->phi_col_mem != nullptr) + (bins->phi_col_off != nullptr);
+    SN_REQUIRE(ncolp == 4 || (ncolp == 0 && bins->phi_bin_mem), "sn_batch_plan: give all four column arrays of sn_plan_bins, or none of them and phi_bin_mem");
     SN_REQUIRE(B <= BINS_BMAX, "sn_batch_plan: work bins support at most %d graphs per batch (got %lld)", BINS_BMAX, (long long)B);
     SN_REQUIRE(!bins->phi_bin_mem || (reinterpret_cast<uintptr_t>(bins->phi_bin_mem) & 15) == 0, "sn_batch_plan: phi_bin_mem must be 16-byte aligned");
     bd = BinsDev{bins->phi_bin_col, bins->phi_max_bins, bins->phi_col_bin0, bins->phi_col_mem, bins->phi_col_off,

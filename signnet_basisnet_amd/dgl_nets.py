@@ -177,10 +177,15 @@ class GINNet(_PackCache, nn.Module):
         plan, self._last_plan = getattr(self, "_last_plan", None), None
         if plan is not None:
             st = plan.status.tolist()
+            if st[3] or st[5]:
+                plan.status[3:6].zero_()         # (the plan is cached on the graph object: a later forward of the same graph starts clean)
             if st[0]:
                 raise ValueError(f"{type(self).__name__}: the last batch is malformed (sn_batch_plan status {st[0]})")
             if (st[3] & 4) or st[5]:
                 raise IndexError(ops.EMBEDDING_INDEX_ERROR)
+            if st[3] & 8:
+                raise RuntimeError(f"{type(self).__name__}: a graph of the last batch has no nodes; its score is NaN — set fused_stages = False "
+                                   "for such batches")
             if st[3] & 3:
                 raise RuntimeError(f"{type(self).__name__}: a graph of the last batch has more than 64 nodes or 192 in-edges; its score is "
                                    "NaN — set fused_stages = False for such batches")
@@ -581,6 +586,8 @@ class GatedGCNNet(_PackCache, nn.Module):
         plan, self._last_plan = getattr(self, "_last_plan", None), None
         if plan is not None:
             st = plan.status.tolist()
+            if st[3] or st[5]:
+                plan.status[3:6].zero_()         # (the plan is cached on the graph object: a later forward of the same graph starts clean)
             if st[0]:
                 raise ValueError("GatedGCNNet: the last batch is malformed (batch_num_nodes / edges do not describe a batched graph; "
                                  f"sn_batch_plan status {st[0]})")

@@ -216,9 +216,11 @@ def early_supported(N: int, E: int, B: int) -> bool:
 
 
 def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, kmax: int = 0, bins: bool = False,
-               early: "EarlyReport | None" = None) -> GraphPlan:
+               early: "EarlyReport | None" = None, columns: bool = False) -> GraphPlan:
     """bins=True also lays out the work bins of the fused stages (same launch, no host sync).  early: an armed EarlyReport — the
-    batch's flags are also written to its pinned buffer by the plan kernel itself (one-launch plans only: early_supported())."""
+    batch's flags are also written to its pinned buffer by the plan kernel itself (one-launch plans only: early_supported()).
+    columns=True: the planner's column arrays (phi_bin_col, phi_col_bin0, phi_col_mem, phi_col_off) are written too — the stage kernels
+    walk the per-bin member records (phi_bin_mem) only, so the forward leaves them out."""
     require_cuda(batch, edge_index)
     if batch.dtype != torch.int64 or edge_index.dtype != torch.int64:
         raise ValueError("build_plan: batch and edge_index must be int64 (the reference's index dtype)")
@@ -231,7 +233,7 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     mb = 0
     if bins:
         mb = int(lib().sn_phi_bins_bound(B, int(kmax)))
-        sizes += [8, mb, B + 1, 8 * B, 8 * B, B + 1, 16 * mb]
+        sizes += [8, mb if columns else 0, (B + 1) if columns else 0, (8 * B) if columns else 0, (8 * B) if columns else 0, B + 1, 16 * mb]
     offs = [0]
     for s in sizes:
         offs.append(offs[-1] + ((s + 3) // 4) * 4)
@@ -242,8 +244,12 @@ def build_plan(batch: torch.Tensor, edge_index: torch.Tensor, num_graphs: int, k
     pb = None
     if bins:
         meta, bc, cb0, mem, off, rb0, bmem = parts[8:15]
-        cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr(),
-                        node_graph.data_ptr(), bmem.data_ptr())
+        if columns:
+            cs = _PlanBinsC(bc.data_ptr(), mb, cb0.data_ptr(), mem.data_ptr(), off.data_ptr(), rb0.data_ptr(), meta.data_ptr(),
+                            node_graph.data_ptr(), bmem.data_ptr())
+        else:
+            bc = cb0 = mem = off = None
+            cs = _PlanBinsC(None, mb, None, None, None, rb0.data_ptr(), meta.data_ptr(), node_graph.data_ptr(), bmem.data_ptr())
         pb = PlanBins(bc, mb, cb0, mem, off, rb0, meta, cs, bmem)
     with _span("sn_batch_plan"):
         check(lib().sn_batch_plan_ex(ptr(batch), N, B, ptr(edge_index), E, int(kmax), ptr(graph_ptr), ptr(node_graph),

@@ -464,6 +464,9 @@ class SignNetGNN(nn.Module):
         if host[0]:
             return ValueError("an earlier batch was malformed (unsorted batch vector, graph id / edge endpoint out of range or an edge "
                               "across graphs): its outputs are NaN")
+        if host[3] & 8:
+            return RuntimeError("an earlier batch had a graph without nodes: the fused GINE stage returns NaN for it; set model.strict = True "
+                                "(re-runs such batches layer by layer) or model.use_fused = False")
         return RuntimeError("an earlier batch had a graph too large for the fused SignNet kernels (> 64 nodes or > 192 edges): "
                             "the outputs of that batch are NaN; set model.strict = True (re-runs such batches layer by layer) or "
                             "model.use_fused = False")

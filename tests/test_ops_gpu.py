@@ -122,7 +122,7 @@ def test_plan_phi_columns_match_the_host_restatement(dev, B, kmax, seed, lo, hi)
     from signnet_basisnet_amd import ops
     data = synth.make_batch(B, seed=seed, n_lo=lo, n_hi=hi)
     d = synth.batch_to(data, dev)
-    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True, columns=True)
     assert plan.check()[0] == 0
     cols = _reference_columns(list(data.sizes), kmax)
     nb, err, rows, ncol = plan.bins.meta.cpu().tolist()[:4]
@@ -215,7 +215,7 @@ def test_plan_bin_member_records(dev, B, kmax, seed, lo, hi):
     from signnet_basisnet_amd import ops
     data = synth.make_batch(B, seed=seed, n_lo=lo, n_hi=hi)
     d = synth.batch_to(data, dev)
-    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True)
+    plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True, columns=True)
     assert plan.check()[0] == 0
     sizes = list(data.sizes)
     gp = [0]

@@ -57,7 +57,7 @@ def test_plan_bins():
     n = torch.tensor(data.sizes)
     for kmax in (0, 16, 5):
         kg = n.clamp(max=kmax) if kmax else n
-        plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True)
+        plan = ops.build_plan(d.batch, d.edge_index, d.num_graphs, kmax, bins=True, columns=True)
         assert plan.check()[0] == 0
         b = plan.bins
         meta = b.meta.cpu().tolist()

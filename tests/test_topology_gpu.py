@@ -333,3 +333,31 @@ def test_whole_network_gradients_on_the_topology_batch():
     (y * cot.float().to(DEV)).sum().backward()
     PU.close(y, y32, "train-mode forward on the topology batch", ref64=y64)
     _assert_gradient_population(m.named_parameters(), sd32, sd64, "topology batch", 30)
+
+
+def test_a_graph_without_nodes_is_evaluated_like_the_reference_or_flagged():
+    """A batch whose graph 1 has no nodes (PyG's add-pooling gives such a graph a zero row, the output encoder a finite score): the
+    module's default mode evaluates it (the plan kernel's early report routes the batch to the layer path), the serving mode returns
+    NaN for that graph only and raises at the next check."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    ctor = (None, None, 32, 1, 2, 2)
+    model = SignNetGNN(*ctor, variant="gine", max_k=8)
+    data = synth.make_batch(4, seed=3, sizes=[5, 0, 7, 3])
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = O.signnet_gnn(sd, O.make_cfg("gine", *ctor), data, training=False, max_k=8)
+    model = model.cuda().eval()
+    dd = synth.batch_to(data, "cuda:0")
+    with torch.no_grad():
+        y = model(dd)
+    err = (y.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-5, err
+    model.strict = False
+    with torch.no_grad():
+        y2 = model(dd)
+    torch.cuda.synchronize()
+    assert torch.isnan(y2[1]).all() and torch.allclose(y2[[0, 2, 3]].cpu(), ref[[0, 2, 3]], rtol=1e-4, atol=1e-5)
+    with pytest.raises(RuntimeError, match="without nodes"):
+        model.check_last()
