@@ -880,6 +880,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="--workload train: skip the captured-HIP-graph replay of the step")
     ap.add_argument("--no-overlap", action="store_true", help="forward bench: skip the extra pass in the module's overlap mode (`overlap_mode` block)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP events (no roofline block)")
+    ap.add_argument("--all-eigenvectors", action="store_true",
+                    help="forward bench, extra measurement (not the headline): the main loop itself with max_k=None — every eigenvector, K = the "
+                         "batch's largest graph (what the `all_eigenvectors` block of the default line times; this flag is for profiler passes)")
     ap.add_argument("--no-extras", action="store_true", help="forward bench: skip the `all_eigenvectors` and `protocol_8d` extra passes")
     ap.add_argument("--no-scatter", action="store_true", help="skip the scatter_roofline block (standalone GIN / GINE aggregation on > 256 MiB)")
     ap.add_argument("--clock-ramp-ms", type=float, default=60.0,
@@ -904,6 +907,9 @@ def main():
             basisnet_bench(args, torch.device("cuda", 0))
         return
     WORKLOAD = WORKLOADS[args.config]
+    if args.all_eigenvectors:
+        WORKLOAD = dict(WORKLOAD, k=None, name=WORKLOAD["name"] + " with max_k=None (all eigenvectors; extra measurement)")
+        args.no_extras = True
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1117,7 +1123,8 @@ def main():
                 r = f(fl, WORKLOAD, host, mean_ms, launches / nall)
                 all_roofs[name] = {"achieved_tflops": r["achieved"], "frac": r["frac"]}
         out = {
-            "metric": "graphs/sec SignNet+GINE forward, ZINC batch=128 k=16" if args.config == 1 else
+            "metric": "graphs/sec SignNet+GINE forward, ZINC batch=128 k=16" if (args.config == 1 and not args.all_eigenvectors) else
+                      "graphs/sec SignNet+GINE forward, ZINC batch=128, all eigenvectors (extra measurement, not the headline)" if args.all_eigenvectors else
                       f"graphs/sec SignNet+GINE forward, BASELINE configs[{args.config}] (extra measurement, not the headline)",
             "value": total_graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,

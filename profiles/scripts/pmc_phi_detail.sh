@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 O=gpurun_out/pmc_detail
 rm -rf $O; mkdir -p $O
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > $O/sq_counters.txt
-B="python bench.py --steps 20 --warmup 5 --streams 1 --no-overlap --no-scatter --no-cpu-baseline"
+B="python bench.py --steps 20 --warmup 5 --streams 1 --no-overlap --no-scatter --no-cpu-baseline --no-extras"
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAVE_CYCLES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAVE_CYCLES" \
