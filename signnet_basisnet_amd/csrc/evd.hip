@@ -190,13 +190,6 @@ __device__ __forceinline__ void evd_jacobi(const EvdArgs& a, const int32_t* cls_
 
   bool pending = false;
   int sweep = 0;
-  // Round 5: the rotation of V lags ONE step behind that of G.  A step's angle comes from G alone, so the V columns can be rotated
-  // while the next step's G columns are being exchanged: the two halves of a step (exchange + dot products + rotate G | exchange +
-  // rotate V) were one dependent chain on a wave that has its SIMD to itself (nothing else hides a ds_bpermute round trip or a VALU
-  // dependency), now they interleave — the same rotations in the same order.  Dot products in four chains, not two (a different rounding of the angles).
-  bool vpend = false;               // (wave-uniform) a V rotation is outstanding
-  float sp = 0.f, taup = 0.f;
-  int plp = lane;
   for (; sweep < EVD_MAX_SWEEPS; ++sweep) {
     bool rotated = false;
     pending = false;
@@ -209,18 +202,11 @@ __device__ __forceinline__ void evd_jacobi(const EvdArgs& a, const int32_t* cls_
       if (j == mm1) p = (step & 1) ? (step + mm1) >> 1 : step >> 1;
       if (!active) p = j;
       const int pl = base + p;
-      if (vpend) {
-        EVD_ROWS(T[r] = bperm(pl, G[r]); { const float vt = bperm(plp, V[r]); V[r] = fmaf(sp, fmaf(-taup, V[r], vt), V[r]); })
-        vpend = false;
-      } else {
-        EVD_ROWS(T[r] = bperm(pl, G[r]);)
-      }
-      float al0 = 0.f, al1 = 0.f, al2 = 0.f, al3 = 0.f, ga0 = 0.f, ga1 = 0.f, ga2 = 0.f, ga3 = 0.f;
-      EVD_ROWS(if ((q & 3) == 0) { al0 = fmaf(G[r], G[r], al0); ga0 = fmaf(G[r], T[r], ga0); }
-               else if ((q & 3) == 1) { al1 = fmaf(G[r], G[r], al1); ga1 = fmaf(G[r], T[r], ga1); }
-               else if ((q & 3) == 2) { al2 = fmaf(G[r], G[r], al2); ga2 = fmaf(G[r], T[r], ga2); }
-               else { al3 = fmaf(G[r], G[r], al3); ga3 = fmaf(G[r], T[r], ga3); })
-      const float alpha = (al0 + al2) + (al1 + al3), gamma = (ga0 + ga2) + (ga1 + ga3);
+      EVD_ROWS(T[r] = bperm(pl, G[r]);)
+      float al0 = 0.f, al1 = 0.f, ga0 = 0.f, ga1 = 0.f;
+      EVD_ROWS(if (q & 1) { al1 = fmaf(G[r], G[r], al1); ga1 = fmaf(G[r], T[r], ga1); }
+               else { al0 = fmaf(G[r], G[r], al0); ga0 = fmaf(G[r], T[r], ga0); })
+      const float alpha = al0 + al1, gamma = ga0 + ga1;
       const float beta = bperm(pl, alpha);
       const bool first = j < p;
       const float lo = first ? alpha : beta, hi = first ? beta : alpha;     // norm^2 of the lower / the higher column
@@ -240,12 +226,10 @@ __device__ __forceinline__ void evd_jacobi(const EvdArgs& a, const int32_t* cls_
       }
       // lower column: x - s (y + tau x);  higher column: x + s (y - tau x)   (signs folded into s, tau above)
       EVD_ROWS(G[r] = fmaf(s, fmaf(-tau, G[r], T[r]), G[r]);)
-      sp = s; taup = tau; plp = pl; vpend = true;      // V: with the next step's exchange (a lane that does not rotate: s = tau = 0)
+      EVD_ROWS(T[r] = bperm(pl, V[r]);)
+      EVD_ROWS(V[r] = fmaf(s, fmaf(-tau, V[r], T[r]), V[r]);)
     }
     if (__ballot(rotated) == 0ull) break;
-  }
-  if (vpend) {
-    EVD_ROWS({ const float vt = bperm(plp, V[r]); V[r] = fmaf(sp, fmaf(-taup, V[r], vt), V[r]); })
   }
   if (__ballot(pending) != 0ull && lane == 0) atomicOr(&a.status[0], EVD_ST_NOCONV);
   if (lane == 0) atomicMax(&a.status[1], sweep + 1);          // most sweeps any wave needed (diagnostic)
