@@ -1049,6 +1049,25 @@ def main():
         sync_all()
         dt_strict = time.perf_counter() - t0
         model.strict = False
+        # extra pass (not `value`): the LAYER-AT-A-TIME path (model.use_fused = False) — what serves a batch beyond the stage kernels'
+        # limits (a graph of > 64 nodes or > 192 in-edges, d > 128, ...: the reference has no such limits, Alchemy/sign_net/sign_net.py:
+        # 96-118), one launch per op on the same batch
+        dt_layer = None
+        if not args.no_extras:
+            model.use_fused, model._prep = False, None
+            for _ in range(3):
+                model(data)
+            sync_all()
+            n_layer = max(3, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(n_layer):
+                model(data)
+            sync_all()
+            dt_layer = (time.perf_counter() - t0) / n_layer
+            model.use_fused, model._prep = True, None
+            for _ in range(3):
+                model(data)
+            sync_all()
         # extra pass (not `value`): the one-stream loop kept running for --sustained-ms of wall clock, in chunks of 200 forwards with one
         # host wait each — the rate the part settles at (clocks, temperature) rather than that of a 25 ms window, and seconds of GPU
         # activity for an outside utilisation sampler to see
@@ -1157,6 +1176,11 @@ def main():
                            "note": "untimed forwards issued after the cold pass until `ms` of wall time had passed since the first forward, so "
                                    "that the timed K steps of `value` run at the sustained clock (an idle GPU needs tens of ms of work to reach "
                                    "it; --clock-ramp-ms 0 switches this off: `value` then differs from `cold` only by the K steps of the cold pass)"},
+            "layer_path": None if dt_layer is None else {
+                "value": sum(graphs_ranks) / dt_layer, "unit": "graphs/s", "ms_per_step": 1e3 * dt_layer,
+                "note": "extra pass, not `value`: model.use_fused = False — every op its own launch (sn_masked_linear_f32, sn_gin_aggregate_f32, "
+                        "sn_set_attention_f32, ...): the path a batch takes that the whole-stage kernels cannot hold (a graph of > 64 nodes or "
+                        "> 192 in-edges, hidden width > 128); the default mode routes such a batch here by itself"},
             "protocol_8d": proto,
             "roofline": roof,
             "kernels": {k: {"launches_per_step": v[0] / nall, "mean_us": 1e3 * v[1], **all_roofs.get(k, {}), **KERNEL_BOUND_NOTES.get(k, {})}
