@@ -347,8 +347,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   extern __shared__ __align__(16) unsigned char lds_raw[];
   unsigned char* SA = lds_raw;                                   // split image: slot sum, then u, then the pooled row
   unsigned char* SB = lds_raw + SP_IMAGE;                        // split image: encoder output, pos, hidden rows
-  float* X1 = reinterpret_cast<float*>(lds_raw + 2 * SP_IMAGE);  // [64][LD] fp32: h
-  int* erow = reinterpret_cast<int*>(X1 + GNN_ROWS * LD);        // [65]  CSR row pointers local to the graph
+  float* X1 = reinterpret_cast<float*>(lds_raw + 2 * SP_IMAGE);  // [64 + 1][LD] fp32: h; row 64 stays zero (what a missing in-edge reads)
+  int* erow = reinterpret_cast<int*>(X1 + (GNN_ROWS + 1) * LD);  // [65]  CSR row pointers local to the graph
   int* esrc = erow + GNN_ROWS + 4;                               // [GNN_EMAX] local source row of every in-edge
   int* efeat = esrc + GNN_EMAX;                                  // [GNN_EMAX][edge_nf] feature words (int idx / float)
   int* ecls = efeat + GNN_EMAX * (P.n_layers > 0 ? P.edge_nf : 0);   // [GNN_EMAX] feature class of every in-edge
@@ -364,8 +364,6 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   long long pt = 0;
 #endif
   WSplit<NKB> pre, alt;
-  // (measured and dropped: wave w's tile of the first Linear requested here, before graph_ptr is read — the graph's own loads then
-  //  queue behind 15 KB per wave on the in-order memory counter: prologue 20.3 k -> 23.6 k cycles)
   const int gs = S.graph_ptr[gi], n = S.graph_ptr[gi + 1] - gs;
   // a graph that cannot be evaluated gets a NaN output row (never uninitialised memory): see sn_gnn_fused_f32
   auto give_up = [&](int bit) {
@@ -524,6 +522,7 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   // ---------------------------------------------------------------- clear the split images (K padding must read as 0)
   for (int i = threadIdx.x; i < 2 * SP_IMAGE / 16; i += GNN_WAVES * 64)
     reinterpret_cast<uint4*>(lds_raw)[i] = make_uint4(0u, 0u, 0u, 0u);
+  if ((int)threadIdx.x < LD) { X1[GNN_ROWS * LD + threadIdx.x] = 0.f; EE[S.ee_rows * LD + threadIdx.x] = 0.f; }   // the two zero rows
   lds_barrier();               // (the prologue's flags are initialised)
   SN_STAMP(31);
   // ---------------------------------------------------------------- per-graph CSR + edge data -> LDS (once)
@@ -572,6 +571,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
       if (c < d) nrow[i] = ld4(P.ntab[0] + xv * d + c);
     }
   }
+  // (both weight tiles behind every load of the graph's own data; measured and dropped: the first tile right behind the edge lists
+  //  — prologue 20.3 k -> 22.5 k cycles — and in front of everything — 23.6 k)
   if (!tr.empty()) {
     wload<NKB>(pre, P.lin_a, tr.first_ot(), lane);                      // in flight while the inputs are staged
     if constexpr (ROLL) wload<NKB>(alt, P.lin_b, tr.first_ot(), lane);
@@ -901,8 +902,8 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int ei = k < dg ? e_lo + k : 0;
-          a_sr[i] |= (unsigned)(k < dg ? esrc[ei] : row) << (8 * k);
-          if (!DGL) a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 0) << (8 * k);
+          a_sr[i] |= (unsigned)(k < dg ? esrc[ei] : GNN_ROWS) << (8 * k);              // (a missing in-edge: the zero row of X1 ...
+          if (!DGL) a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 255) << (8 * k);   //  ... and, marked 255, the zero row of EE)
         }
       }
     }
@@ -926,18 +927,19 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
             int ot, rt;
             tr.decode(t, ot, rt);
             const int row = rt * 16 + li, c = 16 * ot + 4 * g, dg = a_dg[i];
-            // the first four in-edges (molecular graphs: all) with predicated, unrolled reads: the eight row reads, then the adds in
-            // edge order (a missing edge adds +0)
+            // the first four in-edges (molecular graphs: all) with unrolled reads: the eight row reads, then the adds in edge order; a
+            // missing in-edge reads the two zero rows, relu(0 + 0) = +0 is added: no select on the values (round 5: 16 of a pair's ~95
+            // vector instructions were those selects)
             f32x4 hv[4], ev[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const int sr = (int)((a_sr[i] >> (8 * k)) & 255u), er = (int)((a_er[i] >> (8 * k)) & 255u);
               hv[k] = lds_ld4(X1 + sr * LD + c);
-              if (!DGL) ev[k] = lds_ld4(EE + (er + (k < dg ? eoff : 0)) * LD + c);
+              if (!DGL) ev[k] = lds_ld4(EE + (er == 255 ? S.ee_rows : er + eoff) * LD + c);
             }
             f32x4 u = zero4;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) u += k < dg ? (DGL ? hv[k] : relu4(hv[k] + ev[k])) : zero4;
+            for (int k = 0; k < 4; ++k) u += DGL ? hv[k] : relu4(hv[k] + ev[k]);
             if (dg > 4) {
               const int e_lo = erow[row], e_hi = e_lo + dg;
               for (int e = e_lo + 4; e < e_hi; ++e) {
@@ -1113,15 +1115,16 @@ template <int NT, int MODE = 0>
 static int launch_gnn(const GnnStruct& S, const sn_gnn_params& P, int64_t B, hipStream_t st) {
   constexpr bool DGL = MODE != 0;
   constexpr int LD = 16 * NT + 4;
-  const size_t base = (size_t)2 * SP_IMAGE + (size_t)(GNN_ROWS * LD) * sizeof(float) +
+  const size_t base = (size_t)2 * SP_IMAGE + (size_t)((GNN_ROWS + 1) * LD) * sizeof(float) +
                       (size_t)(GNN_ROWS + 4 + GNN_EMAX * (3 + (P.n_layers > 0 ? P.edge_nf : 0)) + GNN_CLS) * sizeof(int);
   const size_t lds_cap = 160 * 1024 - 512;     // the kernel also has a few bytes of static LDS (__syncthreads_count)
   const size_t room = base < lds_cap ? lds_cap - base : 0;
-  int ee_rows = (int)(room / ((size_t)LD * sizeof(float)));
+  int ee_rows = (int)(room / ((size_t)LD * sizeof(float))) - 1;      // (one more row behind them: the zero row a missing in-edge reads)
   if (ee_rows > GNN_EEMAX) ee_rows = GNN_EEMAX;
+  if (ee_rows < 0) ee_rows = 0;
   GnnStruct S2 = S;
   S2.ee_rows = MODE == 2 ? GNN_ROWS : ((!DGL && P.n_layers > 0) ? ee_rows : 0);        // (Transformer mode: the fp32 partial-sum image)
-  const size_t lds = base + (size_t)S2.ee_rows * LD * sizeof(float);
+  const size_t lds = base + (size_t)(S2.ee_rows + 1) * LD * sizeof(float);
   static bool init = false;
   if (!init) {
     const size_t lds_max = lds_cap;

@@ -813,10 +813,12 @@ class SignNetGNN(nn.Module):
         all_fused = use_phi_fused and use_rho_fused and use_gnn_fused and not return_stages and not train
         early = None
         N_, E_n = int(data.batch.numel()), (int(data.edge_index.shape[1]) if data.edge_index.numel() else 0)
-        if all_fused and self.strict and ops.early_supported(N_, E_n, B):
+        # (a forward being captured into a HIP graph must not wait on the host: no early report, the flags stay on the device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if all_fused and self.strict and not capturing and ops.early_supported(N_, E_n, B):
             early = self._arm_early(P["gnn_fused"], data)
         K_host = None if self.max_k else host_max_nodes(data)
-        if not self.max_k and K_host is None and early is None and not return_stages and ops.early_supported(N_, E_n, B):
+        if not self.max_k and K_host is None and early is None and not return_stages and not capturing and ops.early_supported(N_, E_n, B):
             early = ops.EarlyReport().arm()          # only for the largest graph: a poll of pinned memory instead of a device read-back
         plan = ops.build_plan(data.batch, data.edge_index, B, self.max_k or 0, bins=use_phi_fused or use_rho_fused, early=early)
         self._last_plan, self._used_fused = plan, (use_phi_fused or use_rho_fused or use_gnn_fused)
