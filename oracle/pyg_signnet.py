@@ -146,8 +146,10 @@ def gnn3d(sd, pfx, x, edge_index, mask, nlayer, training, trace=None):
 
 
 # --------------------------------------------------------------------------- a7-a8: rho
-def encoder_layer(sd, pfx, x, mask):
-    """TransformerEncoderLayer.forward — transformer_module.py:34-42 (eval: no dropout)."""
+def encoder_layer(sd, pfx, x, mask, keep=None):
+    """TransformerEncoderLayer.forward — transformer_module.py:34-42.  keep: the scaled Bernoulli keep-mask [N, heads, K, K] (0 or
+    1 / (1 - p)) of the attention dropout that the reference leaves active in train mode (:46,55: `self.dropout(F.softmax(attn))`);
+    None = no dropout (eval, or the deterministic train-mode fixtures)."""
     N, K, d = x.shape
     dk = d // N_HEAD
     pair = (mask.unsqueeze(1) * mask.unsqueeze(2)).unsqueeze(1)              # :78,:93  [N,1,K,K]
@@ -157,7 +159,10 @@ def encoder_layer(sd, pfx, x, mask):
     v = _linear(sd, pfx + ".slf_attn.w_vs", x).view(N, K, N_HEAD, dk).transpose(1, 2)
     att = torch.matmul(q / (dk ** 0.5), k.transpose(2, 3))                   # :52
     att = att.masked_fill(pair == 0, -1e10)                                  # :54
-    att = torch.softmax(att, dim=-1) * pair                                  # :55-56
+    att = torch.softmax(att, dim=-1)                                         # :55
+    if keep is not None:
+        att = att * keep.to(att.dtype)                                       # :55  nn.Dropout on the probabilities
+    att = att * pair                                                         # :56
     o = torch.matmul(att, v).transpose(1, 2).contiguous().view(N, K, d)      # :57,:98
     o = _linear(sd, pfx + ".slf_attn.fc", o) + res                           # :99-100
     o = masked_ln(sd, pfx + ".slf_attn.norm", o, mask)
@@ -171,11 +176,11 @@ def encoder_layer(sd, pfx, x, mask):
     return z.masked_fill(~mask.unsqueeze(-1), 0.0)                           # :41
 
 
-def set_transformer(sd, pfx, x, pos, mask, nlayer, training, trace=None):
+def set_transformer(sd, pfx, x, pos, mask, nlayer, training, trace=None, attn_keep=None):
     """SetTransformer.forward — sign_net.py:60-72 [core/sign_net.py:64-77]."""
     x = x + pos
     for l in range(nlayer):
-        x = encoder_layer(sd, f"{pfx}.transformer_layers.{l}", x, mask)
+        x = encoder_layer(sd, f"{pfx}.transformer_layers.{l}", x, mask, None if attn_keep is None else attn_keep[l])
         if trace is not None:
             trace.append(x.clone())
     s = x.sum(dim=1)
@@ -183,7 +188,7 @@ def set_transformer(sd, pfx, x, pos, mask, nlayer, training, trace=None):
 
 
 # --------------------------------------------------------------------------- a2: SignNet
-def sign_net(sd, cfg, data, training=False, max_k=None, out=None):
+def sign_net(sd, cfg, data, training=False, max_k=None, out=None, attn_keep=None):
     """SignNet.forward — sign_net.py:96-118 [core/sign_net.py:99-120]."""
     eig_s, eig_v, mask = to_dense_list_evd(data.eigen_values, data.eigen_vectors, data.batch,
                                            getattr(data, "num_graphs", None), max_k)
@@ -196,7 +201,7 @@ def sign_net(sd, cfg, data, training=False, max_k=None, out=None):
     phi = (gnn3d(sd, "sign_net.phi", x, data.edge_index, mask, cfg["nl_signnet"], training, tr_p)
            + gnn3d(sd, "sign_net.phi", -x, data.edge_index, mask, cfg["nl_signnet"], training, tr_m))
     tr_r = [] if out is not None else None
-    pe, ssum = set_transformer(sd, "sign_net.rho", phi, pos, mask, cfg["nl_rho"], training, tr_r)
+    pe, ssum = set_transformer(sd, "sign_net.rho", phi, pos, mask, cfg["nl_rho"], training, tr_r, attn_keep)
     if out is not None:
         out.update(eigV_dense=eig_v, eigS_dense=eig_s, mask=mask, phi_plus_layers=tr_p,
                    phi_minus_layers=tr_m, phi=phi, rho_layers=tr_r, rho_sum=ssum, pos=pe)
@@ -237,9 +242,10 @@ def gnn(sd, cfg, data, pe, training=False, out=None):
     return y
 
 
-def signnet_gnn(sd, cfg, data, training=False, max_k=None, out=None):
-    """SignNetGNN.forward — sign_net.py:130-132 [core/sign_net.py:132-134]."""
-    pe = sign_net(sd, cfg, data, training, max_k, out)
+def signnet_gnn(sd, cfg, data, training=False, max_k=None, out=None, attn_keep=None):
+    """SignNetGNN.forward — sign_net.py:130-132 [core/sign_net.py:132-134].  attn_keep: per encoder layer, the attention dropout's scaled
+    keep-mask (train mode; see encoder_layer)."""
+    pe = sign_net(sd, cfg, data, training, max_k, out, attn_keep)
     return gnn(sd, cfg, data, pe, training, out)
 
 

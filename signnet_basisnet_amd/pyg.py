@@ -879,11 +879,14 @@ class SignNetGNN(nn.Module):
                 p = _lin_bn(s0.view(N * K, 1), E_["l0"], E_["bn0"], train, nv, K, relu=True)
                 p = _lin_bn(p, E_["l1"], E_["bn1"], train, nv, K, relu=True)
                 x = ops.masked_affine(x, nv, K, residual=p)
-            for L in P["rho"]:
+            given = getattr(self, "_attn_masks", None) if train else None      # explicit masks: the reference's own draws (tests), GraphedStep
+            for li, L in enumerate(P["rho"]):
                 q = ops.masked_linear(x, L["q"], nv, K)
                 k = ops.masked_linear(x, L["k"], nv, K)
                 v = ops.masked_linear(x, L["v"], nv, K)
-                pm = ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device) if train else None
+                pm = None
+                if train:
+                    pm = given[li] if given is not None else ops.attention_dropout_mask(N, K, N_HEAD, self.attn_dropout, x.device)
                 o = ops.set_attention(q, k, v, N, K, N_HEAD, nv, pm)
                 o = ops.masked_linear(o, L["fc"], nv, K)
                 y = ops.masked_layernorm(o, x, L["ln1"][0], L["ln1"][1], LN_EPS, nv, K)

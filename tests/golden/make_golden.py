@@ -123,6 +123,28 @@ def pyg_case(name, variant, ctor_args, sizes, features, seed):
     with torch.no_grad():
         yt = model(data)
     arrays.update({"out/train/y": yt.numpy(), "out/train/pos": cap["pos"].numpy()})
+    # train-mode forward WITH the attention dropout the reference leaves active (ScaledDotProductAttention(attn_dropout=0.1),
+    # transformer_module.py:46,55): torch's own Bernoulli draws, seeded; the keep-masks it drew are read off the Dropout modules'
+    # inputs / outputs (out != 0 wherever the softmax probability is not 0) and stored with the outputs, so that the HIP path can be
+    # run on the very same masks.  (BatchNorm in train mode normalises with batch statistics: the earlier forwards do not matter.)
+    cap.clear()
+    rng = torch.get_rng_state()
+    torch.manual_seed(seed + 1000)
+    masks = {}
+    mhooks = []
+    for li, layer in enumerate(model.sign_net.rho.transformer_layers):
+        layer.slf_attn.attention.dropout.p = 0.1
+        mhooks.append(layer.slf_attn.attention.dropout.register_forward_hook(
+            lambda m, i, o, li=li: masks.__setitem__(li, ((o != 0) | (i[0] == 0)).detach().clone())))
+    with torch.no_grad():
+        yd = model(data)
+    for h in mhooks:
+        h.remove()
+    torch.set_rng_state(rng)
+    arrays.update({"out/train_do/y": yd.numpy(), "out/train_do/pos": cap["pos"].numpy()})
+    for li, m in masks.items():
+        arrays[f"out/train_do/keep{li}"] = np.packbits(m.numpy().astype(np.uint8))           # [N, heads, K, K] bits, row-major
+        arrays[f"out/train_do/keep{li}_shape"] = np.array(m.shape, dtype=np.int64)
     for h in hooks:
         h.remove()
     save(name, **arrays)

@@ -76,3 +76,18 @@ def load_filters(name="learning_filters_grid6"):
     for c in cases.values():
         c["cfg"] = dict(c["args"], mults=[int(m) for m in c["mults"]] if "mults" in c else [])
     return types.SimpleNamespace(inp=inp, cases=cases, side=int(z["meta/side"]))
+
+
+def attn_keep_masks(fx, p=0.1, device="cpu", dtype=torch.float32):
+    """The attention dropout's keep-masks the reference drew for the `train_do` outputs of a PyG fixture (make_golden.py), scaled as
+    nn.Dropout scales them: one [N, heads, K, K] tensor per encoder layer with entries 0 or 1 / (1 - p)."""
+    masks, l = [], 0
+    while f"train_do/keep{l}" in fx.out:
+        shape = [int(v) for v in fx.out[f"train_do/keep{l}_shape"]]
+        n = 1
+        for v in shape:
+            n *= v
+        bits = np.unpackbits(fx.out[f"train_do/keep{l}"].numpy())[:n].reshape(shape)
+        masks.append((torch.from_numpy(bits.astype(np.float32)) * (1.0 / (1.0 - p))).to(dtype).to(device).contiguous())
+        l += 1
+    return masks

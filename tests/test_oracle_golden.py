@@ -35,6 +35,21 @@ def test_pyg_signnet_gnn(name, mode):
         torch.testing.assert_close(out["phi_minus_layers"][-1], fx.out["eval/phi_minus"], **TOL)
 
 
+@pytest.mark.parametrize("name", G.PYG_CASES)
+def test_pyg_signnet_gnn_train_mode_with_the_references_attention_dropout_draws(name):
+    """Train mode with the attention dropout active (transformer_module.py:46,55), on the keep-masks torch drew for the reference when
+    the fixture was made: the oracle's restatement of that line is pinned to the reference's own stochastic forward."""
+    fx = G.load(name)
+    cfg, data = G.pyg_cfg(fx), G.as_data(fx.inp)
+    keep = G.attn_keep_masks(fx)
+    assert len(keep) == cfg["nl_rho"]
+    out = {}
+    y = O.signnet_gnn(fx.sd, cfg, data, training=True, out=out, attn_keep=keep)
+    torch.testing.assert_close(out["pos"], fx.out["train_do/pos"], **TOL)
+    torch.testing.assert_close(y, fx.out["train_do/y"], **TOL)
+    assert (fx.out["train_do/y"] - fx.out["train/y"]).abs().max() > 1e-4      # the draws matter
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_dgl_gin_deepsigns(mode):
     fx = G.load("dgl_gin_k8")

@@ -422,6 +422,33 @@ def test_fused_width_not_multiple_of_32():
 
 
 @pytest.mark.parametrize("name", G.PYG_CASES)
+def test_train_mode_forward_with_the_references_own_attention_dropout_draws(name):
+    """The one dropout the reference leaves active in training (ScaledDotProductAttention(attn_dropout=0.1), transformer_module.py:
+    46,55) against the reference ITSELF: the fixture's `train_do` outputs were produced with torch's own seeded Bernoulli draws, the
+    keep-masks it drew are stored beside them, and the HIP train-mode forward (value path and differentiable path) is run on those
+    very masks."""
+    from signnet_basisnet_amd import synth
+    fx = G.load(name)
+    model = build(fx)
+    model.train()
+    data = synth.batch_to(G.as_data(fx.inp), "cuda:0")
+    masks = G.attn_keep_masks(fx, device="cuda:0")
+    assert len(masks) == len(model.sign_net.rho.transformer_layers) and all(0.05 < float((m == 0).float().mean()) < 0.2 for m in masks)
+    model._attn_masks = masks
+    try:
+        with torch.no_grad():
+            y, st = model(data, return_stages=True)
+        yg = model(data)                                  # gradients enabled: the differentiable path (autograd.Function per op)
+    finally:
+        model._attn_masks = None
+    for what, got, ref in (("y", y, fx.out["train_do/y"]), ("pos", st["pos"], fx.out["train_do/pos"]), ("y (differentiable path)", yg.detach(), fx.out["train_do/y"])):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 5e-4 * max(1.0, ref.abs().max().item()) + 5e-5, f"train-mode {what} with the reference's dropout draws: {err:.3e}"
+    # and the draws matter: without them the output is a different one
+    assert (fx.out["train_do/y"] - fx.out["train/y"]).abs().max().item() > 1e-4
+
+
+@pytest.mark.parametrize("name", G.PYG_CASES)
 def test_train_mode_forward_value_and_running_stats(name):
     """model.train() forward: BatchNorm with batch statistics over the valid rows (reference fixture generated with the
     attention dropout switched off), and the running-statistics side effect of every BatchNorm (momentum 0.1, unbiased
