@@ -734,6 +734,31 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   lds_barrier();                           // inputs staged; LDS-only like every later barrier:
   const int graph_bad = (int)s_pro[0];     // (did anyone see a bad feature id)
   SN_STAMP(1);                             // a __syncthreads() would also drain the weight prefetch in flight (vmcnt(0))
+  // (round 5: read here, under the wait for the first weight tile, not in front of layer 0)
+  int a_dg[4];
+  unsigned a_sr[4], a_er[4];       // four source rows (< 64) / four edge classes or edge ids (< 256), a byte each
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_dg[i] = -1;
+    a_sr[i] = 0u;
+    a_er[i] = 0u;
+    const int t = tr.t_lo + i;
+    if (!TF && t < tr.t_hi && (DGL || use_tab || use_ee)) {
+      int ot, rt;
+      tr.decode(t, ot, rt);
+      const int row = rt * 16 + li;
+      if (row < n) {
+        const int e_lo = erow[row], dg = erow[row + 1] - e_lo;
+        a_dg[i] = dg;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int ei = k < dg ? e_lo + k : 0;
+          a_sr[i] |= (unsigned)(k < dg ? esrc[ei] : GNN_ROWS) << (8 * k);              // (a missing in-edge: the zero row of X1 ...
+          if (!DGL) a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 255) << (8 * k);   //  ... and, marked 255, the zero row of EE)
+        }
+      }
+    }
+  }
   ee_fetch(0);     // needs efeat (staged above); the loads fly during the three Linears below
   // ---------------------------------------------------------------- h = Linear(cat[x, pos]) (model.py:39-40), pos = BN(W_out . slot_sum)
   //   (sign_net.py:71).  Order: x part (SB -> X1), pos (SA -> SB, SB being free after a barrier), pos part (SB -> X1 +=).
@@ -884,30 +909,6 @@ __device__ __forceinline__ void gnn_graph(const GnnStruct& S, const sn_gnn_param
   // The in-edges of my pairs' rows do not change from layer to layer: degree, the first four source rows and their edge classes
   // (or edge ids) are read ONCE — the aggregation of every layer then starts with its row reads instead of two dependent index
   // round trips per pair.
-  int a_dg[4];
-  unsigned a_sr[4], a_er[4];       // four source rows (< 64) / four edge classes or edge ids (< 256), a byte each
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    a_dg[i] = -1;
-    a_sr[i] = 0u;
-    a_er[i] = 0u;
-    const int t = tr.t_lo + i;
-    if (t < tr.t_hi && (DGL || use_tab || use_ee)) {
-      int ot, rt;
-      tr.decode(t, ot, rt);
-      const int row = rt * 16 + li;
-      if (row < n) {
-        const int e_lo = erow[row], dg = erow[row + 1] - e_lo;
-        a_dg[i] = dg;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int ei = k < dg ? e_lo + k : 0;
-          a_sr[i] |= (unsigned)(k < dg ? esrc[ei] : GNN_ROWS) << (8 * k);              // (a missing in-edge: the zero row of X1 ...
-          if (!DGL) a_er[i] |= (unsigned)(k < dg ? (use_tab ? ecls[ei] : ei) : 255) << (8 * k);   //  ... and, marked 255, the zero row of EE)
-        }
-      }
-    }
-  }
   for (int l = 0; l < P.n_layers; ++l) {
     const sn_gnn_layer& Lp = P.layers[l];
     // u = sum_{j->i} relu(h_j + e_ji) + (1+eps) h_i  for my (channel tile, row tile) pairs: X1 -> SA (split)
