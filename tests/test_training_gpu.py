@@ -95,45 +95,32 @@ def test_three_hundred_adam_steps_track_the_float64_oracle_loss_curve():
     """No dataset ships with this image, so accuracy on real data (GraphPrediction/README.md:14-30) cannot be reproduced; what can be
     bounded is drift: 300 optimiser steps (forward, L1 loss, backward, Adam, lr 1e-3) on the device against the same 300 steps of
     torch.optim.Adam on the float64 oracle AND on the float32 oracle (what the reference computes), from the same weights on the same
-    batch and targets.  L1's sign gradients make a trajectory sensitive to rounding (one residual changing sign moves the loss curve
-    by a percent for a few steps), so the bound is relative to what fp32 itself does: the HIP curve stays as close to the float64 one
-    as the fp32 CPU curve does (x 4), its first ten steps within 1e-5, and all three learn."""
-    from oracle import pyg_signnet as O
+    batch and targets (curves stored by tests/golden/make_adam_curve.py).  L1's sign gradients make a trajectory sensitive to rounding
+    (one residual changing sign moves the loss curve by a percent for a few steps), so the bound is relative to what fp32 itself
+    does: the HIP curve stays as close to the float64 one as the fp32 CPU curve does (x 4), its first ten steps within 1e-5, and all
+    three learn."""
+    import os
+    import numpy as np
     from signnet_basisnet_amd import optim, synth
+    z = np.load(os.path.join(G.GOLDEN, "adam_curve_gine_d16.npz"))
+    o64, o32 = z["f64"].tolist(), z["f32"].tolist()
+    steps = int(z["meta"][0])
     fx = G.load("gine_d16")
     model = build(fx).train()
     data = synth.batch_to(G.as_data(fx.inp), DEV)
-    cfg = G.pyg_cfg(fx)
-    n_out = int(fx.meta["ctor"][3])
-    target = None
-    curves = {}
-    for dt in (torch.float64, torch.float32):
-        sd, odata = oracle_setup(fx, dt)
-        if target is None:
-            target = torch.randn(len(odata.sizes), n_out, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
-        oopt = torch.optim.Adam([v for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad], lr=1e-3)
-        ls = []
-        for step in range(300):
-            oopt.zero_grad()
-            oloss = (O.signnet_gnn(sd, cfg, odata, training=True) - target.to(dt)).abs().mean()
-            oloss.backward()
-            oopt.step()
-            ls.append(oloss.item())
-        curves[dt] = ls
-    tdev = target.float().to(DEV)
-    opt = optim.FlatAdam(model.parameters(), lr=1e-3)
+    tdev = torch.from_numpy(z["target"]).float().to(DEV)
+    opt = optim.FlatAdam(model.parameters(), lr=float(z["lr"]))
     losses = []
-    for step in range(300):
+    for step in range(steps):
         opt.zero_grad()
         loss = (model(data) - tdev).abs().mean()
         loss.backward()
         opt.step()
         losses.append(loss.item())
-    o64, o32 = curves[torch.float64], curves[torch.float32]
     dev = [abs(a - b) / max(1.0, abs(b)) for a, b in zip(losses, o64)]
     dev32 = [abs(a - b) / max(1.0, abs(b)) for a, b in zip(o32, o64)]
     mean = lambda v: sum(v) / len(v)
-    print(f"\n300 Adam steps: loss {o64[0]:.4f} -> {o64[-1]:.4f} (float64 oracle), {losses[0]:.4f} -> {losses[-1]:.4f} (HIP fp32), "
+    print(f"\n{steps} Adam steps: loss {o64[0]:.4f} -> {o64[-1]:.4f} (float64 oracle), {losses[0]:.4f} -> {losses[-1]:.4f} (HIP fp32), "
           f"{o32[-1]:.4f} (fp32 oracle); deviation from float64 per step: HIP max {max(dev):.2e} mean {mean(dev):.2e} first ten {max(dev[:10]):.2e}; "
           f"fp32 CPU oracle max {max(dev32):.2e} mean {mean(dev32):.2e}")
     for ls in (o64, o32, losses):
