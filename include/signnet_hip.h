@@ -77,7 +77,7 @@ typedef struct {
    * [phi_max_bins][8] word pairs, 16-byte aligned; word 0 = graph | index << 13 | row offset << 19 | (rows - 1) << 25 (-1: no
    * member), word 1 = first node of the graph.  A member is one SLAB of a graph of n nodes: phi reads it as the n node rows of
    * eigenvector slot `index`; with all eigenvectors (kmax = 0) rho reads it as the n slot rows of node `index` (same shapes, same
-   * bins).  meta[7] = number of record bins.  kmax != 0: the bins of the columns above.  kmax = 0 on the one-launch plan: slabs of
+   * bins).  meta[7] = number of record bins.  kmax != 0: the bins of the columns above.  kmax = 0 (up to 4096 graphs): slabs of
    * ANY graphs packed best-fit-decreasing per bin (98-99 % fill where columns reach 92 %: a column's bins above its shorter
    * members hold only the taller ones); no columns are laid out then (meta[3] = 0, meta[0] = meta[7]). */
   int32_t* phi_bin_mem;

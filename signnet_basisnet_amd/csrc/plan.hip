@@ -190,7 +190,8 @@ __device__ __forceinline__ int writelane(int vec, int val, int lane) {
 // remaining classes are emitted one slab per bin, which needs at most 64 more).  A pattern is expanded into its bins' member
 // records in parallel afterwards: slab q of class s is (graph = q / s-th of the class in id order, index = q % s).
 constexpr int PAT_MAX = 160;
-constexpr int PAT_INTS = (PAT_MAX + 1) + PAT_MAX + 2 * 8 * PAT_MAX;   // first bin [PAT_MAX+1] | members [PAT_MAX] | member words | slab bases
+constexpr int PAT_INTS = (PAT_MAX + 1) + PAT_MAX + 2 * 8 * PAT_MAX;
+constexpr int PLAN_SLAB_BMAX = 4096;   // five-launch plan: slab-level packing up to this many graphs (the pattern table must fit the LDS beside 6 B ints)   // first bin [PAT_MAX+1] | members [PAT_MAX] | member words | slab bases
 
 __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int* lds, int* pat, int32_t* early_host = nullptr) {
   const int t = threadIdx.x;
@@ -776,7 +777,8 @@ __global__ __launch_bounds__(PLAN_T) void k_plan_scan(int64_t N, int64_t B, int 
     __syncthreads();
     plan_rho_block(gp, (int)B, kmax, bd, sm + B + 4);
     __syncthreads();
-    plan_bins_block(gp, (int)B, kmax, bd, sm + B + 4, nullptr);   // (no room for the pattern table beside 6 144 graphs: records from the columns)
+    // (the slab chain's pattern table follows the block's scratch when the launch made room for it: up to PLAN_SLAB_BMAX graphs)
+    plan_bins_block(gp, (int)B, kmax, bd, sm + B + 4, (kmax == 0 && B <= PLAN_SLAB_BMAX) ? sm + B + 4 + 5 * (int)B + 3 * 66 + 32 + 8 : nullptr);
     return;
   }
   __shared__ long long part[PLAN_T];
@@ -964,7 +966,7 @@ extern "C" int sn_batch_plan_ex(const int64_t* batch, int64_t N, int64_t B, cons
   const int64_t ne = N > E ? N : E;
   hipLaunchKernelGGL(k_plan_degree, dim3((unsigned)cdiv(ne > 0 ? ne : 1, T)), dim3(T), 0, st, batch, edge_index, E, N, B, deg,
                      status);
-  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32 + 8) * sizeof(int) : 0;
+  const size_t lds3 = do_bins ? (size_t)((B + 4) + 5 * B + 3 * 66 + 32 + 8 + ((kmax == 0 && B <= PLAN_SLAB_BMAX) ? PAT_INTS : 0)) * sizeof(int) : 0;
   if (lds3 > 48 * 1024) {
     static bool init3 = false;
     if (!init3) {

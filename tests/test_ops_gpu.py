@@ -126,8 +126,8 @@ def test_plan_phi_columns_match_the_host_restatement(dev, B, kmax, seed, lo, hi)
     assert plan.check()[0] == 0
     cols = _reference_columns(list(data.sizes), kmax)
     nb, err, rows, ncol = plan.bins.meta.cpu().tolist()[:4]
-    if kmax == 0 and sum(data.sizes) <= 4096 and B <= 1024:
-        # all eigenvectors on the one-launch plan: slab-level bins, no columns (test_plan_bin_member_records)
+    if kmax == 0 and B <= 4096:
+        # all eigenvectors: slab-level bins, no columns (test_plan_bin_member_records)
         assert err == 0 and ncol == 0 and nb == len(_reference_slab_bins(list(data.sizes)))
         return
     assert err == 0 and ncol == len(cols)
@@ -206,7 +206,7 @@ def _decode_bin_records(plan):
 
 @pytest.mark.parametrize("B,kmax,seed,lo,hi", [(128, 0, 1236, 9, 37), (128, 16, 1236, 9, 37), (256, 0, 3, 6, 14), (40, 0, 9, 1, 64),
                                                 (37, 8, 5, 1, 64), (300, 0, 11, 1, 9), (1500, 4, 7, 1, 5), (2100, -3, 9, 1, 3),
-                                                (1500, 0, 13, 1, 3), (1, 0, 2, 9, 9)])
+                                                (1500, 0, 13, 1, 3), (1, 0, 2, 9, 9), (300, 0, 17, 9, 37), (4200, 0, 19, 1, 2)])
 def test_plan_bin_member_records(dev, B, kmax, seed, lo, hi):
     """The per-bin member records the stage kernels walk (sn_plan_bins.phi_bin_mem): every (graph, index) slab exactly once, members
     of a bin disjoint inside 64 rows, word 1 = the graph's first node; with kmax != 0 (and on the five-launch plan) the bins of the
@@ -232,8 +232,7 @@ def test_plan_bin_member_records(dev, B, kmax, seed, lo, hi):
             assert n == sizes[g] and g0 == gp[g] and idx < slots(n) and (g, idx) not in seen
             seen.add((g, idx))
     assert seen == {(g, i) for g, n in enumerate(sizes) if 0 < n <= 64 for i in range(slots(n))}
-    one_launch = sum(sizes) <= 4096 and d.edge_index.shape[1] <= 12288 and B <= 1024
-    if kmax == 0 and one_launch:
+    if kmax == 0 and B <= 4096:              # slab-level packing (the five-launch plan too, up to 4096 graphs)
         want = _reference_slab_bins(sizes)
         assert len(got) == len(want) == meta[0] and meta[3] == 0
         for b, (gb, wb) in enumerate(zip(got, want)):

@@ -309,6 +309,36 @@ def test_all_eigenvector_slot_count_from_host_sizes_or_the_plan_report():
     model.check_last()
 
 
+def test_all_eigenvectors_beyond_the_one_launch_plan():
+    """max_k=None on a batch of 300 graphs (~6 900 nodes: the five-launch plan, which packs slabs up to 4096 graphs): fused forward vs
+    the CPU oracle, strict and serving mode identical."""
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(4)
+    ctor = (None, None, 64, 1, 2, 2)
+    model = SignNetGNN(*ctor, variant="gine")
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+    data = synth.make_batch(300, seed=31)
+    assert data.batch.numel() > 4096
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ref = O.signnet_gnn(sd, O.make_cfg("gine", *ctor), data, training=False, max_k=None)
+    model = model.cuda().eval()
+    dd = synth.batch_to(data, "cuda:0")
+    with torch.no_grad():
+        y = model(dd)
+        model.strict = False
+        y2 = model(dd)
+        model.check_last()
+    close(y, ref, "all eigenvectors, 300 graphs (five-launch plan)")
+    assert torch.equal(y, y2)
+
+
 def test_malformed_batch_comes_back_as_nan_and_raises():
     from signnet_basisnet_amd import synth
     from signnet_basisnet_amd.pyg import SignNetGNN
