@@ -12,7 +12,7 @@ for flags in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $fl -c $C/$f.hip -o $C/$f.o || { echo "build failed: $flags"; continue; }
   hipcc --offload-arch=gfx950 -shared -fPIC -o signnet_basisnet_amd/libsignnet_hip.so $C/*.o
   for rep in $(seq 1 ${REPS:-2}); do
-    python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-scatter --streams 1 > $out/b_${i}_$rep.json 2> $out/b_${i}_$rep.err
+    python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-scatter --no-extras --no-overlap --streams 1 > $out/b_${i}_$rep.json 2> $out/b_${i}_$rep.err
     python - "$flags" $out/b_${i}_$rep.json <<'P'
 import json,sys
 try:
