@@ -36,7 +36,7 @@ constexpr int PHI_WAVES = 2 * (PHI_R / 16);   // one wave per (16-row tile, sign
 
 // From three output tiles on, the GEMMs run on wg_gemm_split_lag (fused_common.hpp): a four-slot weight ring with a look-ahead of
 // three chunks, no LDS drain in front of the chunk barrier, and the two sign waves of a SIMD half a tile out of phase at every
-// barrier (the + waves take it in front of the tile's last K block, the - waves in front of its second).
+// barrier (the + waves take it in front of the tile's last K block, the - waves in front of its first: phi_lag_kb).
 // (-DSN_PHI_NOLAG: the one-stream form of rounds 2-3, for A/B runs: profiles/scripts/ab.sh.)
 constexpr bool phi_lagged(int nt) {
 #ifdef SN_PHI_NOLAG
@@ -45,7 +45,14 @@ constexpr bool phi_lagged(int nt) {
   return nt >= 3;
 #endif
 }
-constexpr int phi_lag_kb(int nkb) { return nkb - 1 - nkb / 2; }   // NKB = 4: K block 1
+// (round 5, A/B on two boxes with -DSN_PHI_LAGKB=0 / 1 / 2, the - waves' barrier in front of K block 0 / 1 / 2 of their tile: 0 is 1-2 %
+//  faster than round 4's 1 (121.1 against 123.1 us, 110.3 against 111.4), 2 is 2-3 % slower — the two waves of a SIMD a whole tile
+//  apart at every barrier instead of half a tile)
+#ifdef SN_PHI_LAGKB
+constexpr int phi_lag_kb(int nkb) { return SN_PHI_LAGKB < nkb ? SN_PHI_LAGKB : nkb - 1; }
+#else
+constexpr int phi_lag_kb(int) { return 0; }
+#endif
 
 struct PhiStruct {
   const float* ev;
