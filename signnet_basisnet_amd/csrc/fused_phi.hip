@@ -115,8 +115,42 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
   float* X = X2 + sg * PHI_R * LD;                              // the image of my sign
   const int r = (wave & 3) * 16 + (lane & 15), g = lane >> 4;
   SN_TL(0);
-  const int nbins = S.meta[7];
-  if (S.meta[1] != 0) return;  // a graph has more than 64 nodes: the host falls back to the layer path
+  // Round 5 (end): the member records of the first group of bins are requested BEFORE the plan's flag words are known (bin ids are
+  // arithmetic; the record array has phi_max_bins rows, a row past the bin count is read and ignored) and as FOUR wide loads: written
+  // as `rec[2 k]`, `rec[2 k + 1]` inside the member loop they compiled to sixteen single-dword loads, each behind the previous one's
+  // round trip and a branch — 2 of the 2.9 us the first decode pass took (profiles/r05_phi_timeline.txt).
+  auto load_rec = [&](int dbin_, int4 (&rq_)[4]) {
+    int z = 0;
+    asm volatile("" : "+v"(z));      // (vector loads on both paths: as scalar loads the sixteen words cost sixteen of the kernel's last scalar registers)
+    const int4* rp = reinterpret_cast<const int4*>(S.bin_mem + (int64_t)((int64_t)dbin_ < S.max_bins ? dbin_ : 0) * 16) + z;
+    rq_[0] = rp[0]; rq_[1] = rp[1]; rq_[2] = rp[2]; rq_[3] = rp[3];
+  };
+  int4 rq[4];
+  load_rec((int)blockIdx.x + wave * (int)gridDim.x, rq);
+  const int nb_raw = S.meta[7];
+  const int merr = S.meta[1];   // a graph has more than 64 nodes: no bins here (folded into the bin count: an early `return` in front
+                                // of the barriers did not compile — "illegal VGPR to SGPR copy"), the host falls back to the layer path
+  // The per-channel vectors of layer 0 (every bin starts with them: four L2 round trips per lane and bin, 3.6 k cycles of a 78 k-cycle
+  // bin) are copied into LDS once per workgroup: [w | b | scale | shift][D].  Requested with the records and the flag words — one
+  // round trip for all three — and stored BEFORE the weight stream starts (behind it the compiler would wait for every LDS-DMA in
+  // flight in front of an LDS store: it cannot tell the ring from these rows).  Straight-line: threads past the vectors repeat
+  // thread 0's float4, a missing vector (no bias) reads the first one and stores zeros.
+  static_assert(4 * (16 * NT / 4) <= PHI_WAVES * 64, "one float4 per thread covers the four vectors");
+  f32x4 l0r;
+  bool l0has;
+  const int l0i = (int)threadIdx.x < 4 * (D / 4) ? (int)threadIdx.x : 0;
+  {
+    const float* src[4];
+    if (HID1) { src[0] = reinterpret_cast<const float*>(P.l0_w2); src[1] = P.l0_bias2; src[2] = P.l0_bn_scale; src[3] = P.l0_bn_shift; }
+    else { src[0] = P.l0_w1; src[1] = nullptr; src[2] = P.l0_bn0_scale; src[3] = P.l0_bn0_shift; }
+    const int v = l0i / (D / 4), c = 4 * (l0i - v * (D / 4));
+    typedef __attribute__((address_space(1))) const float gfloat_t;      // (a pointer picked by lane is generic: a flat load otherwise)
+    const float* sp_ = v == 0 ? src[0] : (v == 1 ? src[1] : (v == 2 ? src[2] : src[3]));
+    l0has = sp_ != nullptr;
+    gfloat_t* gp_ = (gfloat_t*)(l0has ? sp_ : src[0]);
+    l0r = f32x4{gp_[c], gp_[c + 1], gp_[c + 2], gp_[c + 3]};
+  }
+  const int nbins = merr != 0 ? 0 : nb_raw;
   { SN_PROF_ON(true); SN_STAMP(12); }
 #ifdef SN_PROFILE
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -124,31 +158,16 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
     g_prof[12] = clock64();
   }
 #endif
+  lds_st4(l0v + 4 * l0i, l0has ? l0r : f32x4{0.f, 0.f, 0.f, 0.f});
   Ring ring;
   ring.init(lds_raw, wave, lane);
   // first [d,d] Linear of a (bin, sign) pass — where the weight stream (re)starts
   const void* wfirst = !HID1 ? P.l0_w2 : (P.n_layers > 1 ? P.layers[0].w1s : nullptr);
-  // The per-channel vectors of layer 0 (every bin starts with them: four L2 round trips per lane and bin, 3.6 k cycles of a 78 k-cycle
-  // bin) are copied into LDS once per workgroup: [w | b | scale | shift][D].  Requested BEFORE the weight stream starts (the memory
-  // counter is in order: a wait for them must not include the first three weight chunks), stored behind its issue.
-  f32x4 l0r = {0.f, 0.f, 0.f, 0.f};
-  static_assert(4 * (16 * NT / 4) <= PHI_WAVES * 64, "one float4 per thread covers the four vectors");
-  {
-    const float* src[4];
-    if (HID1) { src[0] = reinterpret_cast<const float*>(P.l0_w2); src[1] = P.l0_bias2; src[2] = P.l0_bn_scale; src[3] = P.l0_bn_shift; }
-    else { src[0] = P.l0_w1; src[1] = nullptr; src[2] = P.l0_bn0_scale; src[3] = P.l0_bn0_shift; }
-    const int i = threadIdx.x;
-    if (i < 4 * (D / 4)) {
-      const int v = i / (D / 4), c = 4 * (i - v * (D / 4));
-      if (src[v] != nullptr) l0r = ld4(src[v] + c);
-    }
-  }
   if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) {
     // (LAG: issue only — the first chunks land under the decode pass below, whose closing __syncthreads() waits for them and
     //  publishes them)
     if constexpr (LAG) ring_prologue3_issue(ring, wfirst); else ring.prologue(wfirst, NT);
   }
-  if ((int)threadIdx.x < 4 * (D / 4)) lds_st4(l0v + 4 * threadIdx.x, l0r);
 
   SN_TL(1);
 #ifdef SN_TIMELINE
@@ -159,14 +178,16 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
     if (base != (int)blockIdx.x) __syncthreads();   // the previous group is done with the descriptors
     {
       const int dbin = base + wave * (int)gridDim.x;
+      if (base != (int)blockIdx.x) load_rec(dbin, rq);     // (the first group's: requested at the kernel's start)
       if (dbin < nbins) {
         const int rr = lane;
-        // (the eight member records are decoded at once — wave-uniform scalar loads with no serial dependence between members)
-        const int32_t* rec = S.bin_mem + (int64_t)dbin * 16;
+        // (the eight member records: sixteen words already in registers — no load, no branch between the members)
+        const int rw[16] = {rq[0].x, rq[0].y, rq[0].z, rq[0].w, rq[1].x, rq[1].y, rq[1].z, rq[1].w,
+                            rq[2].x, rq[2].y, rq[2].z, rq[2].w, rq[3].x, rq[3].y, rq[3].z, rq[3].w};
         int node = -1, gs = 0, row0 = 0, gsel = 0, nsel = 0, slot = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int w0 = rec[2 * k], g0 = rec[2 * k + 1];
+          const int w0 = rw[2 * k], g0 = rw[2 * k + 1];
           const int off = (w0 >> 19) & 63, n = ((w0 >> 25) & 63) + 1, sl = (w0 >> 13) & 63;
           if (w0 >= 0 && rr >= off && rr < off + n && sl < S.K) {      // (sl < K: a caller's K smaller than the batch's slot count must not write outside `out`)
             node = g0 + (rr - off);
@@ -177,19 +198,43 @@ __global__ __launch_bounds__(PHI_WAVES * 64, 2) void k_phi_fused(PhiStruct S, sn
             slot = sl;
           }
         }
+        // level 2: the row's CSR range and its graph's eigenvector block; level 3: the eigenvector entry and the first PHI_NBR
+        // in-neighbours — all of a level requested before any of it is used.  (As a loop over the row's degree the neighbour reads
+        // compiled to one load, one wait and one byte store per in-edge: three or four more round trips of every first decode pass.)
         int e_lo = 0, e_hi = 0;
-        float xval = 0.f;
+        long long eo = 0;
         if (node >= 0) {
           e_lo = S.rowptr[node];
           e_hi = S.rowptr[node + 1];
-          xval = DGL ? S.ev[(int64_t)node * S.dense_ld + slot] : S.ev[S.evoff[gsel] + (int64_t)(node - gs) * nsel + slot];
+          if (!DGL) eo = S.evoff[gsel];
         }
         const int deg = e_hi - e_lo;
+        // (an unconditional load from a clamped address, the row's validity applied at the store: as `valid ? load : 0` the select —
+        //  and with it the wait for the entry — was placed in front of the neighbour reads)
+        const float xraw = S.ev[node >= 0 ? (DGL ? (int64_t)node * S.dense_ld + slot : eo + (int64_t)(node - gs) * nsel + slot) : (int64_t)0];
+        // (one predicated region, eight loads from addresses clamped to the row's own segment: with one predicate per load the compiler
+        //  put a partial wait between them)
+        int cv[PHI_NBR];
+#pragma unroll
+        for (int e = 0; e < PHI_NBR; ++e) cv[e] = gs;
+        if (deg > 0) {
+          const int32_t* cp = S.col + e_lo;
+#pragma unroll
+          for (int e = 0; e < PHI_NBR; ++e) cv[e] = cp[e < deg ? e : deg - 1];
+        }
+        const float xval = node >= 0 ? xraw : 0.f;
+        unsigned nlo = 0u, nhi = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          nlo |= (unsigned)((row0 + cv[e] - gs) & 255) << (8 * e);
+          nhi |= (unsigned)((row0 + cv[e + 4] - gs) & 255) << (8 * e);
+        }
+        static_assert(PHI_NBR == 8, "the neighbour bytes of a row are one 8-byte store");
         int o = wave * PHI_R + rr;
         asm volatile("" : "+v"(o));      // (else the six descriptor addresses are hoisted out of the bin loop and one of them spills)
         dxs[o] = xval; dnode[o] = node; delo[o] = e_lo; ddeg[o] = deg; dgs[o] = gs; drow0[o] = (unsigned char)row0;
         dslot[o] = (unsigned char)slot;
-        for (int e = 0; e < deg && e < PHI_NBR; ++e) dnbr[o * PHI_NBR + e] = (unsigned char)(row0 + S.col[e_lo + e] - gs);
+        *reinterpret_cast<uint2*>(dnbr + o * PHI_NBR) = make_uint2(nlo, nhi);
       }
     }
     __syncthreads();

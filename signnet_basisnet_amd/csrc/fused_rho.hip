@@ -119,25 +119,122 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
   const int nbins = REGATTN ? (S.N + 3) >> 2 : S.meta[4];
-  if (S.meta[5] != 0) return;
   const int d = P.d, H = P.heads, dk = d / H;
+  // Round 5: the start of a workgroup used to be six dependent memory round trips (error word -> LayerNorm vectors -> first weight
+  // chunk -> node's graph -> its node range -> the rows), ~1 us each, in front of the first MFMA of a kernel of two bins per
+  // workgroup.  With node-major bins (REGATTN) nothing but the node range depends on an earlier load: the error word, the first
+  // bin's graph id, its rows (node and slot are arithmetic; the rows of slots past the graph's count are read — they exist, x is
+  // dense [N, K, d] — and zeroed once the count is known), the LayerNorm vectors and the weight stream are all requested up front.
+  f32x4 x[NT];
+  int pf_gs = 0, pf_n = 0;                      // node range of the NEXT bin's graph (this wave's node), fetched a bin ahead
+  // (pure loads, no selects on the values: a select would make the compiler wait for the rows right here; the masks — slot count,
+  //  channel padding — are applied at the top of the bin)
+  auto fetch_rows = [&](int node_) {
+    int slot_ = lane & 15, g_ = g;
+    asm volatile("" : "+v"(slot_), "+v"(g_));
+    const bool ok = node_ < S.N && slot_ < S.K;
+    const float* xr = S.x + (ok ? ((int64_t)node_ * S.K + slot_) : (int64_t)0) * d;
+#pragma unroll
+    for (int kk = 0; kk < NT; ++kk) {
+      const int c = 16 * kk + 4 * g_;
+      const bool inb = HP ? c < d : (kk + 1 < NT || c < d);
+      x[kk] = ld4(xr + (inb ? c : 0));
+    }
+  };
+  // graph id -> node range of a wave's node: two dependent SCALAR loads written as such.  (Left to the compiler they are scalar only
+  // in front of the first LDS-DMA — behind anything that may write memory a uniform load is no longer provably invariant and becomes a
+  // vector load, whose wait (the memory counter is in order) then includes every weight chunk in flight.)  The scalar counter is
+  // waited for by hand: graph_id() ... graph_range() ... graph_take(), each behind the previous one's round trip.
+  int pf_gi = 0;
+  long long pf_rng = 0;
+  auto graph_id = [&](int node_) {
+    const int32_t* p = S.node_graph + (node_ < S.N ? node_ : 0);
+    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pf_gi) : "s"(p));
+  };
+  auto graph_range = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf_gi));
+    const int32_t* p = S.graph_ptr + pf_gi;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(pf_rng) : "s"(p));
+  };
+  auto graph_take = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf_rng));
+    pf_gs = (int)(pf_rng & 0xffffffffll);
+    pf_n = (int)(pf_rng >> 32) - pf_gs;
+  };
+  // (not for the multi-layer variants at d = 128: their row array is live through the whole layer and the kernel sits at 256
+  //  registers — with the rows requested a bin ahead 12-20 bytes per lane went to a private segment)
+#ifdef SN_RHO_OLDSTART            // (A/B builds: the start as it was until round 5 — six dependent round trips)
+  constexpr bool EARLY = false;
+#else
+  constexpr bool EARLY = REGATTN && (ONE || NT < 8);
+#endif
+  const int err = S.meta[5];
   const float temp = sqrtf((float)dk);
   const float rtemp = 1.0f / temp;
   { SN_PROF_ON(true); SN_STAMP(13); }
   // LayerNorm gamma / beta of every layer, staged once: read between GEMMs they would otherwise wait (vmcnt 0) behind
   // the weight stream's in-flight LDS-DMA plus their own L2 latency, twice per layer
   float* lnv = reinterpret_cast<float*>(lds_raw + Ring::BYTES) + (REGATTN ? 0 : 2 * RHO_R * LD);   // [n_layers][4][D]
-  for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
-    const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
-    const sn_rho_layer& Lq = P.layers[l];
-    const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
-    lnv[i] = src[c];
-  }
-  __syncthreads();
   Ring ring;
   ring.init(lds_raw, wave, lane);
   const void* wfirst = P.n_layers > 0 ? P.layers[0].wq : nullptr;
-  if (NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
+  const bool stream = NT >= SPLIT_RING && wfirst != nullptr && nbins > (int)blockIdx.x;
+  if constexpr (EARLY && ONE && NT >= SPLIT_RING) {
+    // everything the first bin needs, in ONE round trip: rows, the layer's four LayerNorm vectors (one float4 per thread; the
+    // pointers are kernel arguments), the first RING weight chunks (nobody has touched the ring yet: no barrier in front of the
+    // issue), graph id -> node range (the only dependent load).  Straight-line code: behind a branch the compiler can no longer count
+    // the loads in flight and waits for all of them (vmcnt(0): the whole ring) before the first use of any.
+    if (nbins <= (int)blockIdx.x) return;      // (a workgroup without a bin: nothing requested yet)
+    const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+    graph_id(node0);
+    fetch_rows(node0);
+    static_assert(4 * (D / 4) <= RHO_R * 4, "one float4 per thread covers the four vectors");
+    const int li4 = (int)threadIdx.x < 4 * (D / 4) ? (int)threadIdx.x : 0;
+    const sn_rho_layer& L0 = P.layers[0];
+    const float *p0 = L0.ln1_g, *p1 = L0.ln1_b, *p2 = L0.ln2_g, *p3 = L0.ln2_b;
+    asm volatile("" : "+s"(p0), "+s"(p1), "+s"(p2), "+s"(p3));      // (four scalar pointers: as a lane-indexed read of the argument block
+                                                                      //  the choice below is a dependent load in front of the vector's)
+    const int lv = li4 / (D / 4), lc = 4 * (li4 - lv * (D / 4));
+    typedef __attribute__((address_space(1))) const float gfloat_t;      // (laundered pointers are generic: a flat load otherwise)
+    gfloat_t* src = (gfloat_t*)(lv == 0 ? p0 : (lv == 1 ? p1 : (lv == 2 ? p2 : p3)));
+    const f32x4 lnr = f32x4{src[lc], src[lc + 1], src[lc + 2], src[lc + 3]};
+    ring.pos = 0;
+#pragma unroll
+    for (int c = 0; c < Ring::DEPTH; ++c) ring.issue(wfirst, c, c);
+    graph_range();
+    {
+      // (the store as an instruction: for an LDS store the compiler can see it waits for every LDS-DMA in flight — it cannot tell the
+      //  ring from the vectors' rows — i.e. for all RING chunks instead of for the one float4 in front of them)
+      typedef __attribute__((address_space(3))) float lds_float_t;
+      const unsigned la = (unsigned)(size_t)(lds_float_t*)(lnv + 4 * li4);
+      asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(lnr) : "memory");     // (threads past the vectors repeat thread 0's float4)
+    }
+    ring.template wait_shares<Ring::DEPTH - 1>();
+    lds_barrier();
+    if (err != 0) { ring.drain(); return; }
+  } else {
+    if constexpr (EARLY) {
+      if (nbins > (int)blockIdx.x) {
+        const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+        graph_id(node0);
+        fetch_rows(node0);
+        graph_range();
+      }
+    } else {
+      if (err != 0) return;
+    }
+    for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
+      const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
+      const sn_rho_layer& Lq = P.layers[l];
+      const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
+      lnv[i] = src[c];
+    }
+    __syncthreads();
+    if (stream) ring.prologue(wfirst, NT);
+    if constexpr (EARLY) {
+      if (err != 0) { ring.drain(); return; }
+    }
+  }
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
     // ---------------------------------------------------------------- bin -> graph (bins never mix graphs)
@@ -152,12 +249,19 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       slot = lane & 15;
       node = __builtin_amdgcn_readfirstlane(bin * 4 + wave);
       unit_ok = node < S.N;
-      const int gi = unit_ok ? S.node_graph[node] : 0;
-      gs = S.graph_ptr[gi];
-      n = S.graph_ptr[gi + 1] - gs;
+      if constexpr (EARLY) {
+        graph_take();                                                // (requested a bin ago / at the kernel's start)
+        gs = pf_gs;
+        n = pf_n;
+      } else {
+        const int gi = unit_ok ? S.node_graph[node] : 0;
+        gs = S.graph_ptr[gi];
+        n = S.graph_ptr[gi + 1] - gs;
+      }
       kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
       kv = unit_ok ? kg : 0;
       u0 = q * 16;
+      if (EARLY && bin + (int)gridDim.x < nbins) graph_id(__builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * 4 + wave));   // the next bin's
     } else {
       __syncthreads();
       for (int gq = threadIdx.x; gq < S.B; gq += RHO_R * 4)
@@ -185,7 +289,6 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
     SN_STAMP(1);
     // ---------------------------------------------------------------- load x (+ eigenvalue encoding)
     // branch-free (clamped addresses + selects): per-element branches here would turn x[] into a web of phi copies
-    f32x4 x[NT];
     auto load_x = [&]() {
       // (slot and g are laundered: otherwise the compiler keeps the 64-bit row / column offsets of every tile — loop-invariant lane
       //  constants — alive across the whole bin loop, and in the 256-register multi-layer variants they were what spilled)
@@ -200,7 +303,16 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         x[kk] = (valid && inb) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     };
-    load_x();
+    if constexpr (EARLY) {
+      // (the rows were requested before the node's slot count was known: slots past it read as zero)
+#pragma unroll
+      for (int kk = 0; kk < NT; ++kk) {
+        const bool inb = HP ? (16 * kk + 4 * g < d) : (kk + 1 < NT || 16 * kk + 4 * g < d);
+        x[kk] = (valid && inb) ? x[kk] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      load_x();
+    }
     if (valid) {
       if (P.has_pos) {
         // eigen_encoder = MaskedMLP(1 -> 1 -> d): Linear . BN . ReLU . Linear . BN . ReLU   (sign_net.py:86,108)
@@ -382,6 +494,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
+      if (EARLY && l + 1 >= (ONE ? 1 : P.n_layers) && bin + (int)gridDim.x < nbins) graph_range();   // (next bin: id -> node range)
       if (ONE) load_x();   // the residual operand, straight from the input buffer (see ONE above)
       wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
@@ -424,6 +537,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
           if (li == 0 && unit_ok && (HP ? c < d : (kk + 1 < NT || c < d))) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
         }
       }
+      if (EARLY && bin + (int)gridDim.x < nbins) fetch_rows(__builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * 4 + wave));   // the next bin's rows
     } else {
 #pragma unroll
       for (int kk = 0; kk < NT; ++kk) lds_st4(Br + 16 * kk + 4 * g, valid ? x[kk] : f32x4{0.f, 0.f, 0.f, 0.f});
