@@ -590,31 +590,66 @@ __global__ __launch_bounds__(RHO_R * 4, ONE ? 2 : 1) void k_rho_wide(RhoStruct S
   float* lnv = IMG + RHO_R * LD;                                     // [n_layers][4][D]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
-  const int nbins = COLS ? S.meta[7] : S.meta[4];
-  if (S.meta[5] != 0 || (COLS && S.meta[1] != 0)) return;
+  // (the three plan words at once — as `a != 0 || (COLS && b != 0)` plus the bin count they were three scalar round trips in a row)
+  const int nb_raw = COLS ? S.meta[7] : S.meta[4];
+  const int m_err = S.meta[5] | (COLS ? S.meta[1] : 0);
+  const int nbins = m_err != 0 ? 0 : nb_raw;
   const int d = P.d;
   const float rtemp = 1.0f / sqrtf((float)(d / P.heads));
-  for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
-    const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
-    const sn_rho_layer& Lq = P.layers[l];
-    const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
-    lnv[i] = src[c];
-  }
-  __syncthreads();
   Ring ring;
   ring.init(lds_raw, wave, lane);
   const void* wfirst = P.n_layers > 0 ? P.layers[0].wq : nullptr;
-  if (wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
+  if constexpr (ONE) {
+    // one layer: its four LayerNorm vectors (one float4 per thread, scalar pointers) and the first RING weight chunks in ONE round
+    // trip, straight-line (see k_rho_fused: behind a branch, or in front of an LDS store the compiler can see, every wait is for
+    // all the LDS-DMA in flight)
+    static_assert(4 * (D / 4) <= RHO_R * 4, "one float4 per thread covers the four vectors");
+    const int li4 = (int)threadIdx.x < 4 * (D / 4) ? (int)threadIdx.x : 0;
+    const sn_rho_layer& L0 = P.layers[0];
+    const float *p0 = L0.ln1_g, *p1 = L0.ln1_b, *p2 = L0.ln2_g, *p3 = L0.ln2_b;
+    asm volatile("" : "+s"(p0), "+s"(p1), "+s"(p2), "+s"(p3));
+    const int lv = li4 / (D / 4), lc = 4 * (li4 - lv * (D / 4));
+    typedef __attribute__((address_space(1))) const float gfloat_t;
+    gfloat_t* src = (gfloat_t*)(lv == 0 ? p0 : (lv == 1 ? p1 : (lv == 2 ? p2 : p3)));
+    const f32x4 lnr = f32x4{src[lc], src[lc + 1], src[lc + 2], src[lc + 3]};
+    if (nbins <= (int)blockIdx.x) return;      // (a workgroup without a bin, or a plan that failed: the LDS is untouched)
+    ring.pos = 0;
+#pragma unroll
+    for (int c = 0; c < Ring::DEPTH; ++c) ring.issue(wfirst, c, c);
+    {
+      typedef __attribute__((address_space(3))) float lds_float_t;
+      const unsigned la = (unsigned)(size_t)(lds_float_t*)(lnv + 4 * li4);
+      asm volatile("ds_write_b128 %0, %1" :: "v"(la), "v"(lnr) : "memory");
+    }
+    ring.template wait_shares<Ring::DEPTH - 1>();
+    lds_barrier();
+  } else {
+    for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
+      const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
+      const sn_rho_layer& Lq = P.layers[l];
+      const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
+      lnv[i] = src[c];
+    }
+    __syncthreads();
+    if (wfirst != nullptr && nbins > (int)blockIdx.x) ring.prologue(wfirst, NT);
+  }
   float* IMGr = IMG + r * LD;
 
   for (int bin = blockIdx.x; bin < nbins; bin += gridDim.x) {
     // ---------------------------------------------------------------- bin -> member nodes (wave-uniform: scalar registers)
     int m_off[8], m_len[8], m_node[8], m_gs[8];
     if constexpr (COLS) {
-      const int32_t* rec = S.bin_mem + (int64_t)bin * 16;
+      // (the bin's eight member records as ONE scalar load: left to the compiler — vector loads behind the ring's LDS-DMA, made
+      //  uniform word by word — they were four loads each behind the previous one's round trip, in every bin)
+      typedef int i32x16 __attribute__((ext_vector_type(16)));
+      i32x16 rw;
+      {
+        const int32_t* rec = S.bin_mem + (int64_t)bin * 16;
+        asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rw) : "s"(rec) : "memory");
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int w0 = rec[2 * k], g0 = rec[2 * k + 1];
+        const int w0 = rw[2 * k], g0 = rw[2 * k + 1];
         const int n = ((w0 >> 25) & 63) + 1;                         // kmax == 0: K_g = n
         m_off[k] = (w0 >> 19) & 63;
         m_len[k] = (w0 >= 0 && n <= S.K) ? n : 0;                    // (n <= K: a caller's K smaller than the graph must not read outside x)
