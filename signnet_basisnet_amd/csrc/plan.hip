@@ -326,17 +326,22 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
     const int lane = t;
     int cnt = hist[lane + 1];                       // class s = lane + 1
     unsigned long long avail = __ballot(cnt > 0);
-    int nrec = 0, recv = 0;
+    // (round 5, end: a link's record goes straight to LDS — a store the chain never waits for — instead of into a lane of a register
+    //  that is flushed every 64 links (mask, M0, writelane, compare, branch: 7 instructions of the ~30 per link); the availability
+    //  update is a branch that is taken once per class, not a select chain on every link)
+    int nrec = 0;
     while (avail) {
       int cls = 64 - __clzll(avail);
       int cap = 64, members = 0, first = 1 << 7;
       while (true) {
         const int left = __builtin_amdgcn_readlane(cnt, cls - 1) - 1;
         cnt = writelane(cnt, left, cls - 1);
-        if (left == 0) avail &= ~(1ull << (cls - 1));
-        recv = writelane(recv, cls | first | (left << 8), nrec & 63);
+        if (__builtin_expect(left == 0, 0)) {
+          asm volatile("" : "+s"(avail));                                   // (keeps this a branch)
+          avail &= ~(1ull << (cls - 1));
+        }
+        rec[nrec] = cls | first | (left << 8);
         ++nrec;
-        if ((nrec & 63) == 0) rec[nrec - 64 + lane] = recv;      // flush 64 records
         first = 0;
         ++members;
         cap -= cls;
@@ -346,7 +351,6 @@ __device__ void plan_bins_block(const int* gp, int B, int kmax, BinsDev bd, int*
         cls = 64 - __clzll(m);
       }
     }
-    if (lane < (nrec & 63)) rec[(nrec & ~63) + lane] = recv;     // the partial group
     if (lane == 0) s_nrec = nrec;
     PL_STAMP(9);
   }
