@@ -79,7 +79,9 @@ typedef struct {
    * eigenvector slot `index`; with all eigenvectors (kmax = 0) rho reads it as the n slot rows of node `index` (same shapes, same
    * bins).  meta[7] = number of record bins.  kmax != 0: the bins of the columns above.  kmax = 0 (up to 4096 graphs): slabs of
    * ANY graphs packed best-fit-decreasing per bin (98-99 % fill where columns reach 92 %: a column's bins above its shorter
-   * members hold only the taller ones); no columns are laid out then (meta[3] = 0, meta[0] = meta[7]). */
+   * members hold only the taller ones); no columns are laid out then (meta[3] = 0, meta[0] = meta[7]).
+   * All phi_max_bins rows must be readable: a stage kernel requests the rows of its first bins before the plan's bin count has
+   * arrived (rows past meta[7] are read and ignored). */
   int32_t* phi_bin_mem;
 } sn_plan_bins;
 
