@@ -143,23 +143,18 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
   };
   // graph id -> node range of a wave's node: two dependent SCALAR loads written as such.  (Left to the compiler they are scalar only
   // in front of the first LDS-DMA — behind anything that may write memory a uniform load is no longer provably invariant and becomes a
-  // vector load, whose wait (the memory counter is in order) then includes every weight chunk in flight.)  The scalar counter is
-  // waited for by hand: graph_id() ... graph_range() ... graph_take(), each behind the previous one's round trip.
-  int pf_gi = 0;
-  long long pf_rng = 0;
-  auto graph_id = [&](int node_) {
+  // vector load, whose wait (the memory counter is in order) then includes every weight chunk in flight.)  Each load and its wait are
+  // ONE asm statement: the compiler does not know an asm's output may still be in flight, it could copy or spill the register before
+  // the value has arrived.  Called behind the request for the node's rows, whose latency covers the two scalar round trips.
+  auto fetch_graph = [&](int node_) {
     const int32_t* p = S.node_graph + (node_ < S.N ? node_ : 0);
-    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pf_gi) : "s"(p));
-  };
-  auto graph_range = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf_gi));
-    const int32_t* p = S.graph_ptr + pf_gi;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(pf_rng) : "s"(p));
-  };
-  auto graph_take = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pf_rng));
-    pf_gs = (int)(pf_rng & 0xffffffffll);
-    pf_n = (int)(pf_rng >> 32) - pf_gs;
+    int gi;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gi) : "s"(p) : "memory");
+    const int32_t* q = S.graph_ptr + gi;
+    long long rng;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rng) : "s"(q) : "memory");
+    pf_gs = (int)(rng & 0xffffffffll);
+    pf_n = (int)(rng >> 32) - pf_gs;
   };
   // (not for the multi-layer variants at d = 128: their row array is live through the whole layer and the kernel sits at 256
   //  registers — with the rows requested a bin ahead 12-20 bytes per lane went to a private segment)
@@ -186,7 +181,6 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
     // the loads in flight and waits for all of them (vmcnt(0): the whole ring) before the first use of any.
     if (nbins <= (int)blockIdx.x) return;      // (a workgroup without a bin: nothing requested yet)
     const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
-    graph_id(node0);
     fetch_rows(node0);
     static_assert(4 * (D / 4) <= RHO_R * 4, "one float4 per thread covers the four vectors");
     const int li4 = (int)threadIdx.x < 4 * (D / 4) ? (int)threadIdx.x : 0;
@@ -201,7 +195,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
     ring.pos = 0;
 #pragma unroll
     for (int c = 0; c < Ring::DEPTH; ++c) ring.issue(wfirst, c, c);
-    graph_range();
+    fetch_graph(node0);
     {
       // (the store as an instruction: for an LDS store the compiler can see it waits for every LDS-DMA in flight — it cannot tell the
       //  ring from the vectors' rows — i.e. for all RING chunks instead of for the one float4 in front of them)
@@ -216,9 +210,8 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
     if constexpr (EARLY) {
       if (nbins > (int)blockIdx.x) {
         const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
-        graph_id(node0);
         fetch_rows(node0);
-        graph_range();
+        fetch_graph(node0);
       }
     } else {
       if (err != 0) return;
@@ -250,8 +243,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       node = __builtin_amdgcn_readfirstlane(bin * 4 + wave);
       unit_ok = node < S.N;
       if constexpr (EARLY) {
-        graph_take();                                                // (requested a bin ago / at the kernel's start)
-        gs = pf_gs;
+        gs = pf_gs;                                                  // (read at the end of the previous bin / at the kernel's start)
         n = pf_n;
       } else {
         const int gi = unit_ok ? S.node_graph[node] : 0;
@@ -261,7 +253,6 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       kg = (S.kmax > 0 && n > S.kmax) ? S.kmax : n;
       kv = unit_ok ? kg : 0;
       u0 = q * 16;
-      if (EARLY && bin + (int)gridDim.x < nbins) graph_id(__builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * 4 + wave));   // the next bin's
     } else {
       __syncthreads();
       for (int gq = threadIdx.x; gq < S.B; gq += RHO_R * 4)
@@ -494,7 +485,6 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       SN_STAMP(5);
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
-      if (EARLY && l + 1 >= (ONE ? 1 : P.n_layers) && bin + (int)gridDim.x < nbins) graph_range();   // (next bin: id -> node range)
       if (ONE) load_x();   // the residual operand, straight from the input buffer (see ONE above)
       wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
@@ -537,7 +527,11 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
           if (li == 0 && unit_ok && (HP ? c < d : (kk + 1 < NT || c < d))) *reinterpret_cast<float4*>(orow + c) = make_float4(s[0], s[1], s[2], s[3]);
         }
       }
-      if (EARLY && bin + (int)gridDim.x < nbins) fetch_rows(__builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * 4 + wave));   // the next bin's rows
+      if (EARLY && bin + (int)gridDim.x < nbins) {                       // the next bin's rows and node range
+        const int nnode = __builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * 4 + wave);
+        fetch_rows(nnode);
+        fetch_graph(nnode);
+      }
     } else {
 #pragma unroll
       for (int kk = 0; kk < NT; ++kk) lds_st4(Br + 16 * kk + 4 * g, valid ? x[kk] : f32x4{0.f, 0.f, 0.f, 0.f});
