@@ -26,3 +26,15 @@ d1 = rel[:, 3] - rel[:, 2]; d2 = rel[:, 4] - rel[:, 3]
 print("bin1 duration med %.2f  bin2 duration med %.2f us" % (np.median(d1), np.median(d2[t[:, 4] > 0])))
 three = t[:, 5] > 0
 print("workgroups with 3 bins:", int(three.sum()), " bin3 duration med %.2f" % np.median((rel[:, 5] - rel[:, 4])[three]))
+# per column (16 consecutive bins = the 16 eigenvector slots of one column of graphs): median bin duration
+if os.environ.get("SN_TL_COLUMNS"):
+    starts = rel[:, 2:6]
+    for rnd in range(3):
+        dur = rel[:, 3 + rnd] - rel[:, 2 + rnd]
+        ok = t[:, 3 + rnd] > 0
+        cols = {}
+        for b in range(256):
+            if ok[b]: cols.setdefault((rnd * 256 + b) // 16, []).append(dur[b])
+        print("round", rnd, " ".join(f"{c}:{np.median(v):.1f}" for c, v in sorted(cols.items())))
+    tot = rel[:, 5].copy(); tot[~(t[:, 5] > 0)] = rel[:, 4][~(t[:, 5] > 0)]
+    print("per-WG end (us) by WG index /16 :", " ".join(f"{np.median(tot[16*i:16*i+16]):.1f}" for i in range(16)))
