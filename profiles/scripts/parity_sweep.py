@@ -10,14 +10,15 @@ W = bench.WORKLOAD
 dev = torch.device("cuda:0")
 worst = 0.0
 cases = 0
-for k in (16, None, 8, 37):
-    WK = dict(W, k=k)
+configs = [dict(W, k=k) for k in (16, None, 8, 37)] + [dict(bench.WORKLOADS[0]), dict(bench.WORKLOADS[2]), dict(bench.WORKLOADS[2], k=6)]
+for WK in configs:
+    k = (WK["name"][:24], WK["k"])
     bench.WORKLOAD = WK
     model = bench.build_model(dev)
     model.strict = False
     for B, lo, hi in ((1, 1, 64), (2, 1, 3), (7, 9, 37), (33, 1, 64), (128, 9, 37), (300, 2, 20), (64, 40, 64)):
         for seed in range(3):
-            host = synth.make_batch(B, seed=100 * B + seed, n_lo=lo, n_hi=hi, features=W["features"])
+            host = synth.make_batch(B, seed=100 * B + seed, n_lo=lo, n_hi=hi, features=WK["features"])
             data = synth.batch_to(host, dev)
             with torch.no_grad():
                 model.use_fused, model._prep = True, None
