@@ -32,7 +32,7 @@ extern "C" {
 #define SN_ERR_LAUNCH (-2)   /* HIP launch / runtime error */
 #define SN_ERR_UNSUPPORTED (-3)
 
-#define SN_ABI_VERSION 1
+#define SN_ABI_VERSION 2   /* 2: sn_plan_bins.phi_bin_mem, the fused finishes of the training links (trailing struct fields) */
 
 int sn_version(void);
 const char* sn_last_error(void);
@@ -773,6 +773,14 @@ typedef struct {
   int in_relu, out_relu;
   float* y; int ldy;
   float* stat_part;                               /* NULL: no statistics */
+  /* ABI 2 — the BatchNorm finish inside the same launch (fin_state != NULL; needs stat_part, d_out <= 128): the LAST workgroup to
+   * arrive (an agent-scope ticket behind write-through stores of the partials) merges the moments in block order — the result does
+   * not depend on who is last; the slicing and order of sn_train_bn_finish_f32 (equal up to the compiler's FMA contraction: last-bit
+   * differences) — and writes fin_state / fin_count / the running statistics.  Measured SLOWER than the separate launch in a
+   * replayed HIP graph; the Python side uses it only under SN_TRAIN_FUSE_FINISH=1. */
+  const float* fin_gamma; const float* fin_beta; float fin_eps, fin_momentum;
+  float* fin_running_mean; float* fin_running_var;
+  float* fin_state; float* fin_count;
 } sn_train_linear_args;
 
 typedef struct {
@@ -795,6 +803,13 @@ typedef struct {
   int gx_accumulate;               /* gx += instead of gx =: several Linears share one operand (q, k, v of the attention); excludes x_mean / dot_x */
   const float* dot_x; int lddot;   /* optional [G*R, d_in]: dot_part[g*nblk + blk] = sum over the block's rows of gx . dot_x — summed by the */
   double* dot_part;                /*   caller it is the eps gradient of the GIN / GINE aggregation that produced the operand (float64: a cancelling sum) */
+  /* ABI 2 — what sn_train_post_link_f32 did behind the link, inside the link's own launch by its last-arriving workgroup (same
+   * slicing and order; equal up to FMA contraction): fin_coef != NULL: the BatchNorm-backward finish of the PRODUCER link from sums_part (arguments of
+   * sn_train_bn_bwd_finish_f32; C = d_in <= 128; d gamma / d beta written, or added when fin_accumulate);  fin_dot_out != NULL:
+   * fin_dot_out[0] += the eps gradient (the sum of dot_part). */
+  const float* fin_state; const float* fin_count; const float* fin_gamma;
+  float* fin_coef; float* fin_dgamma; float* fin_dbeta; int fin_accumulate;
+  float* fin_dot_out;
 } sn_train_linear_bwd_args;
 
 /* What follows a backward link, in ONE launch (a block does one job): the reduction of the link's per-workgroup dW (and db) partials
@@ -822,6 +837,16 @@ int sn_train_bn_bwd_finish_f32(const float* sums_part, int nblk, int G, int C, c
 int sn_train_bn_apply_f32(const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K, const float* state,
                           int relu, const float* residual, int ldr, float* y, int ldy, void* stream);
 int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int64_t n, float* out, int accumulate, void* stream);
+/* The same reduction for up to SN_TRAIN_MAX_REDUCE_JOBS (part, nparts, stride, n, out) tuples in ONE launch: the dW / db partials of
+ * every backward link of a step, reduced once at the end of loss.backward() (GINESignNetPyG/core/train.py:62) instead of one launch
+ * per link; out[i] (+)= sum_b part[b * stride + i] in block order, job by job independent.  Same arithmetic as the single form. */
+#define SN_TRAIN_MAX_REDUCE_JOBS 64
+typedef struct { const float* part; int nparts; int64_t stride; int64_t n; float* out; int accumulate; } sn_train_reduce_job;
+int sn_train_reduce_jobs_f32(const sn_train_reduce_job* jobs, int njobs, void* stream);
+/* sn_train_bn_bwd_sums_f32 + sn_train_bn_bwd_finish_f32 in one launch (C <= 128): the last workgroup to arrive finishes. */
+int sn_train_bn_bwd_f32(const float* dy, int lddy, const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K,
+                        const float* state, const float* count, int relu, const float* gamma, float* sums_part, float* coef,
+                        float* dgamma, float* dbeta, int accumulate, void* stream);
 /* out[0] (+)= (float) sum of n float64 partials (dot_part of sn_train_linear_bwd_f32: the eps gradient), one launch */
 int sn_train_dot_finish_f64(const double* part, int n, float* out, int accumulate, void* stream);
 

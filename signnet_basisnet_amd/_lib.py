@@ -18,6 +18,7 @@ EPI_RESIDUAL_PRE = 64
 EPI_LEAKY = 128
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+ABI_VERSION = 2          # = SN_ABI_VERSION of include/signnet_hip.h (struct layouts of the parameter blocks included)
 
 # name -> argtypes (restype int unless noted).  Must mirror include/signnet_hip.h exactly;
 # tests/test_abi.py cross-checks the symbol list against the header.
@@ -107,6 +108,8 @@ SIGNATURES = {
     "sn_train_bn_apply_f32": [_p, _i, _l, _i, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "sn_train_reduce_parts_f32": [_p, _i, _l, _l, _p, _i, _p],
     "sn_train_dot_finish_f64": [_p, _i, _p, _i, _p],
+    "sn_train_reduce_jobs_f32": [_p, _i, _p],
+    "sn_train_bn_bwd_f32": [_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p],
     "sn_masked_layernorm_bwd_acc_f32": [_p, _p, _p, _l, _i, _p, _f, _p, _i, _p, _p, _p, _p, _p],
     "sn_gin_aggregate_add_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p],
     "sn_gine_aggregate_bwd_add_f32": [_p, _p, _p, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p],
@@ -163,8 +166,9 @@ def lib():
         L.sn_train_linear_bwd_part_floats.restype = C.c_int64
         L.sn_train_scalar_mlp_work_doubles.argtypes = [_l, _i, _i]
         L.sn_train_scalar_mlp_work_doubles.restype = C.c_int64
-        if L.sn_version() != 1:
-            raise RuntimeError("libsignnet_hip.so ABI version mismatch")
+        if L.sn_version() != ABI_VERSION:
+            raise RuntimeError(f"libsignnet_hip.so ABI version {L.sn_version()} != {ABI_VERSION} (include/signnet_hip.h: SN_ABI_VERSION): "
+                               "rebuild with `python -m signnet_basisnet_amd.build --force`")
         _lib = L
     return _lib
 

@@ -11,6 +11,7 @@
 // Rows come in G groups (the phi(+x) / phi(-x) passes share every weight but keep separate batch statistics: two calls of GNN3d,
 // sign_net.py:113).  fp32-input MFMA throughout (exact products, fp32 accumulate); no atomics: gradients are bitwise reproducible.
 #include "fused_common.hpp"
+#include <atomic>
 
 namespace sn {
 
@@ -44,6 +45,40 @@ __device__ __forceinline__ f32x4 lds4(const float* p) {
 __device__ __forceinline__ void st4a(float* __restrict__ p, int c0, int C, f32x4 v) {
   if (c0 < C) *reinterpret_cast<float4*>(p + c0) = make_float4(v[0], v[1], v[2], v[3]);
 }
+// ---- hand-off of per-workgroup partials to the LAST workgroup of the same launch (the "finish" of a link without a second launch) ----
+// Producers publish with write-through (sc1, agent-scope) stores, drain them (vmcnt(0)), meet at the workgroup barrier and take an
+// agent-scope ticket; the workgroup that draws the last ticket reads every partial with sc1 loads (served past this CU's L1) and reduces
+// them in BLOCK order — the result does not depend on who was last.  No release fence: nothing but the partials has to be visible, and
+// a buffer_wbl2 behind a pass that has just dirtied megabytes of L2 is what made the fenced form slower than a second launch.
+constexpr int N_TICKETS = 4096;
+__device__ unsigned g_tickets[N_TICKETS];        // zero at load; the last arriver of a launch resets its word
+
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (write-through only when a last arriver will read the partial in this launch: an sc1 store drops the line from the XCD's L2, and the
+//  finish KERNEL of the unfused path would fetch it from memory instead — k_tbn_finish 6.9 -> 10.6 us when every partial was sc1)
+__device__ __forceinline__ void st_pub(float* p, float v, bool wt) { if (wt) st_sc1(p, v); else *p = v; }
+__device__ __forceinline__ void st_pub(double* p, double v, bool wt) { if (wt) st_sc1(p, v); else *p = v; }
+// 16 bytes with the sc1 policy (aux bit 4): through a buffer descriptor over the whole partial array (offsets < 2 GB)
+__device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t rs, int64_t float_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(float_off * 4), 0, 16);
+  return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+// true in every thread of exactly one workgroup of the launch: the one that arrives last.  `flag`: one LDS word.
+__device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my write-through stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = (t == gridDim.x - 1) ? 1u : 0u;
+    if (t == gridDim.x - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the launch that takes this word next
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
 __device__ __forceinline__ bool row_ok(int64_t r, int64_t R, const int32_t* __restrict__ nvalid, int K) {
   if (r >= R) return false;
   if (!nvalid) return true;
@@ -175,6 +210,113 @@ static __device__ long long g_tprof[64];
 #define TP_T0() do { } while (0)
 #define TP_ACC(i) do { } while (0)
 #endif
+__device__ __forceinline__ void chan(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+  if (nb <= 0.f) return;
+  const float n = na + nb, d = mb - ma;
+  ma += d * (nb / n);
+  qa += qb + d * d * (na * nb / n);
+  na = n;
+}
+// (four columns that share the block counts: column by column the arithmetic of chan())
+__device__ __forceinline__ void chan4(float& na, f32x4& ma, f32x4& qa, float nb, f32x4 mb, f32x4 qb) {
+  float n = na;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    n = na;
+    float m = ma[r], q = qa[r];
+    chan(n, m, q, nb, mb[r], qb[r]);
+    ma[r] = m; qa[r] = q;
+  }
+  na = n;
+}
+
+// The finish of a forward link's BatchNorm (what k_tbn_finish does in a launch of its own), run by the last-arriving workgroup of the
+// link: NT threads = 32 column quads x NT/32 lanes; a column's <= nblk partials are merged (Chan) by 16 slices in block order and a
+// fixed pairwise tree over the slices — the slicing, the order and every expression of k_tbn_finish (the two are compiled separately:
+// where the compiler contracts an FMA in one and not the other the last bit differs; with `#pragma clang fp contract(off)` in both,
+// all four launch structures of profiles/scripts/train_ab.sh gave identical gradients, parameters and running statistics).
+// C <= 128, C % 4 == 0.  lds: (16*32 + 2*16*128) floats.
+struct TFin {
+  const float* gamma; const float* beta; float eps, momentum; float* rmean; float* rvar; float* st; float* cnt; unsigned* ticket;
+};
+constexpr int FIN_LDS_FLOATS = 16 * 32 + 2 * 16 * 128;
+template <int NT>
+__device__ __forceinline__ void tbn_finish_tail(const float* stat, int nblk, int G, int C, const TFin& f, float* lds) {
+  static_assert(NT == 256 || NT == 512, "8 or 16 slice lanes");
+  constexpr int SL = 512 / NT;               // slices per thread
+  float* ln = lds;                            // [16][32]
+  float* lm = lds + 16 * 32;                  // [16][128]
+  float* lq = lm + 16 * 128;                  // [16][128]
+  const int c4 = threadIdx.x & 31, rl0 = threadIdx.x >> 5;
+  const bool col = 4 * c4 < C;
+  const int per = (nblk + 15) / 16;
+  const int64_t GC = (int64_t)G * C;
+  for (int grp = 0; grp < G; ++grp) {
+    const float* sg = stat + (int64_t)grp * (2 * (int64_t)nblk * C + nblk);
+    const __amdgpu_buffer_rsrc_t rs = weight_rsrc(sg, 0x7fffffff);
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int rl = rl0 + sl * (NT / 32);
+      const int b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+      float n = 0.f;
+      f32x4 m = {0.f, 0.f, 0.f, 0.f}, q = m;
+      if (col) {
+        for (int b = b0; b < b1; b += 8) {        // eight partials in flight
+          float nb[8];
+          f32x4 mb[8], qb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            nb[u] = 0.f; mb[u] = f32x4{0.f, 0.f, 0.f, 0.f}; qb[u] = mb[u];
+            if (b + u < b1) {
+              nb[u] = ld_sc1(sg + 2 * (int64_t)nblk * C + b + u);
+              mb[u] = ld4_sc1(rs, (int64_t)(b + u) * C + 4 * c4);
+              qb[u] = ld4_sc1(rs, ((int64_t)nblk + b + u) * C + 4 * c4);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) chan4(n, m, q, nb[u], mb[u], qb[u]);
+        }
+      }
+      ln[rl * 32 + c4] = n;
+      *reinterpret_cast<float4*>(lm + rl * 128 + 4 * c4) = make_float4(m[0], m[1], m[2], m[3]);
+      *reinterpret_cast<float4*>(lq + rl * 128 + 4 * c4) = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    __syncthreads();
+    for (int step = 8; step >= 1; step >>= 1) {
+      if (rl0 < step) {
+        float n = ln[rl0 * 32 + c4];
+        f32x4 m = lds4(lm + rl0 * 128 + 4 * c4), q = lds4(lq + rl0 * 128 + 4 * c4);
+        chan4(n, m, q, ln[(rl0 + step) * 32 + c4], lds4(lm + (rl0 + step) * 128 + 4 * c4), lds4(lq + (rl0 + step) * 128 + 4 * c4));
+        ln[rl0 * 32 + c4] = n;
+        *reinterpret_cast<float4*>(lm + rl0 * 128 + 4 * c4) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4*>(lq + rl0 * 128 + 4 * c4) = make_float4(q[0], q[1], q[2], q[3]);
+      }
+      __syncthreads();
+    }
+    if (rl0 == 0 && col) {
+      const float n = ln[c4];
+      const f32x4 m4 = lds4(lm + 4 * c4), q4 = lds4(lq + 4 * c4);
+      float* s = f.st + (int64_t)grp * C;               // st[component][grp][C]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * c4 + r;
+        const float m = m4[r], q = q4[r];
+        const float v = n > 0.f ? q / n : 0.f;
+        const float rsd = 1.0f / sqrtf(v + f.eps);
+        const float sc = (f.gamma ? f.gamma[c] : 1.f) * rsd;
+        s[c] = m; s[GC + c] = v; s[2 * GC + c] = rsd; s[3 * GC + c] = sc; s[4 * GC + c] = (f.beta ? f.beta[c] : 0.f) - m * sc;
+        if (c == 0) f.cnt[grp] = n;
+        if (f.rmean) {
+          const float unb = n > 1.f ? v * (n / (n - 1.f)) : v;
+          f.rmean[c] = (1.f - f.momentum) * f.rmean[c] + f.momentum * m;
+          f.rvar[c] = (1.f - f.momentum) * f.rvar[c] + f.momentum * unb;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 struct TLin {
   const float* x; int ldx; int64_t R; int G; int d_in, d_out;
   const float* W; int ldw; const float* bias;
@@ -183,6 +325,7 @@ struct TLin {
   float* y; int ldy;
   float* stat;          // per group: [mean nblk*d_out | M2 nblk*d_out | count nblk]
   int nblk;             // workgroups per group
+  TFin fin;             // fin.st != NULL: the statistics are finished by the launch's last workgroup
 };
 
 // FULL: d_in = 16 NTI and d_out = 16 NTO exactly (the 128-wide links) — the tile counts are compile-time constants, the per-tile guards
@@ -471,14 +614,19 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_fwd(TLin a) {
           n = nn;
         }
       }
-      stg[(int64_t)blk * a.d_out + c] = m;
-      stg[((int64_t)a.nblk + blk) * a.d_out + c] = q;
+      st_pub(stg + (int64_t)blk * a.d_out + c, m, a.fin.st != nullptr);
+      st_pub(stg + ((int64_t)a.nblk + blk) * a.d_out + c, q, a.fin.st != nullptr);
     }
     if (threadIdx.x == 0) {
       float n = 0.f;
 #pragma unroll
       for (int w = 0; w < TW; ++w) n += sc[w];
-      stg[2 * (int64_t)a.nblk * a.d_out + blk] = n;
+      st_pub(stg + 2 * (int64_t)a.nblk * a.d_out + blk, n, a.fin.st != nullptr);
+    }
+    if (a.fin.st) {        // (wave-uniform: a launch argument)
+      unsigned* flag = reinterpret_cast<unsigned*>(t_lds + 16 * 1024);          // behind sm / sc (8 KB + 32 B)
+      if (last_arriver(a.fin.ticket, flag))
+        tbn_finish_tail<64 * TW>(a.stat, a.nblk, a.G, a.d_out, a.fin, reinterpret_cast<float*>(t_lds + 20 * 1024));
     }
   }
   TP_ACC(4);
@@ -502,10 +650,12 @@ template <int NTI, bool STATS>
 __global__ __launch_bounds__(64 * TW) void k_tlin_fwd_tile(TLin a) {
   const int lane = threadIdx.x & 63, ot = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
   const int nti = (a.d_in + 15) >> 4, nto = (a.d_out + 15) >> 4;
-  if (ot >= nto) return;
+  const bool fin = STATS && a.fin.st != nullptr;
+  if (ot >= nto && !fin) return;          // (with the finish in this launch every wave stays: the last workgroup needs all of its lanes)
+  const bool act = ot < nto;
   const int grp = blockIdx.x / a.nblk, blk = blockIdx.x - grp * a.nblk;
   const int64_t row = (int64_t)blk * 16 + lr;
-  const bool inr = row < a.R, valid = row_ok(row, a.R, a.nvalid, a.K);
+  const bool inr = row < a.R && act, valid = act && row_ok(row, a.R, a.nvalid, a.K);
   const float* xr = a.x + ((int64_t)grp * a.R + row) * a.ldx;
   const int o = 16 * ot + lr;
   const float* wr = a.W + (int64_t)o * a.ldw;
@@ -567,12 +717,17 @@ __global__ __launch_bounds__(64 * TW) void k_tlin_fwd_tile(TLin a) {
       const float m = t16_sum(v[r]) * inv;                 // invalid rows hold 0
       const float d = valid ? v[r] - m : 0.f;
       const float q = t16_sum(d * d);
-      if (lr == 0 && o0 + r < a.d_out) {
-        stg[(int64_t)blk * a.d_out + o0 + r] = m;
-        stg[((int64_t)a.nblk + blk) * a.d_out + o0 + r] = q;
+      if (lr == 0 && act && o0 + r < a.d_out) {
+        st_pub(stg + (int64_t)blk * a.d_out + o0 + r, m, fin);
+        st_pub(stg + ((int64_t)a.nblk + blk) * a.d_out + o0 + r, q, fin);
       }
     }
-    if (threadIdx.x == 0) stg[2 * (int64_t)a.nblk * a.d_out + blk] = nt;
+    if (threadIdx.x == 0) st_pub(stg + 2 * (int64_t)a.nblk * a.d_out + blk, nt, fin);
+    if (fin) {
+      __shared__ __align__(16) float fin_lds[FIN_LDS_FLOATS + 4];
+      if (last_arriver(a.fin.ticket, reinterpret_cast<unsigned*>(fin_lds + FIN_LDS_FLOATS)))
+        tbn_finish_tail<64 * TW>(a.stat, a.nblk, a.G, a.d_out, a.fin, fin_lds);
+    }
   }
 }
 
@@ -580,13 +735,6 @@ __global__ __launch_bounds__(64 * TW) void k_tlin_fwd_tile(TLin a) {
 // state the consumers and the backward read — st[0..4][grp][C] = mean, var (biased), rstd, scale = gamma*rstd, shift = beta - mean*scale;
 // cnt[grp] — and applies the running-statistics updates in group order (two sequential calls of the module in the reference).
 // grid cdiv(C,16), 256 threads = 16 columns x 16 lanes.
-__device__ __forceinline__ void chan(float& na, float& ma, float& qa, float nb, float mb, float qb) {
-  if (nb <= 0.f) return;
-  const float n = na + nb, d = mb - ma;
-  ma += d * (nb / n);
-  qa += qb + d * d * (na * nb / n);
-  na = n;
-}
 __global__ __launch_bounds__(256) void k_tbn_finish(const float* __restrict__ stat, int nblk, int G, int C, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
                                                     float* __restrict__ rvar, float* __restrict__ st, float* __restrict__ cnt) {
@@ -643,6 +791,103 @@ __global__ __launch_bounds__(256) void k_tbn_finish(const float* __restrict__ st
 // Outputs: gx = (dz W) * [x_hat > 0 if xrelu] — the gradient at the producer's BatchNorm output, masked by its ReLU;
 //          sums[grp][blk][0][c] = sum_rows gx, sums[..][1][c] = sum_rows gx * (x - xmu)  (xmu != NULL: for the producer's BatchNorm backward);
 //          dwp[blk] = sum_rows dz^T x_hat  (+ db behind it): per-workgroup partials, all groups together (shared weights).
+// The finish of a BatchNorm backward (k_tbn_bwd_finish / tbn_bwd_finish_block in a launch of their own) by the last-arriving workgroup
+// of the kernel that produced the column-sum partials: 16 slices per column in block order, the fixed pairwise tree, the same expressions.
+// NT threads = 32 column quads x NT/32 lanes, C <= 128, C % 4 == 0.  lds: 2*16*128 floats.
+struct TBFin {
+  const float* st; const float* cnt; const float* gamma; float* coef; float* dgamma; float* dbeta; int acc;    // coef != NULL: BatchNorm finish
+  float* dot_out;                                                                                              // != NULL: eps finish
+  unsigned* ticket;
+};
+constexpr int BFIN_LDS_FLOATS = 2 * 16 * 128;
+template <int NT>
+__device__ __forceinline__ void tbn_bwd_finish_tail(const float* sums, int nblk, int G, int C, const TBFin& f, float* lds) {
+  static_assert(NT == 256 || NT == 512, "8 or 16 slice lanes");
+  constexpr int SL = 512 / NT;
+  float* l1 = lds;                  // [16][128]
+  float* l2 = lds + 16 * 128;
+  const int c4 = threadIdx.x & 31, rl0 = threadIdx.x >> 5;
+  const bool col = 4 * c4 < C;
+  const int per = (nblk + 15) / 16;
+  const int64_t GC = (int64_t)G * C;
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
+  for (int grp = 0; grp < G; ++grp) {
+    const float* S = sums + (int64_t)grp * nblk * 2 * C;
+    const __amdgpu_buffer_rsrc_t rs = weight_rsrc(S, 0x7fffffff);
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      const int rl = rl0 + sl * (NT / 32);
+      const int b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+      f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+      if (col) {
+        for (int b = b0; b < b1; b += 8) {        // eight partials in flight
+          f32x4 v1[8], v2[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; v2[u] = v1[u];
+            if (b + u < b1) { v1[u] = ld4_sc1(rs, (int64_t)(b + u) * 2 * C + 4 * c4); v2[u] = ld4_sc1(rs, (int64_t)(b + u) * 2 * C + C + 4 * c4); }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
+        }
+      }
+      *reinterpret_cast<float4*>(l1 + rl * 128 + 4 * c4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(l2 + rl * 128 + 4 * c4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+    __syncthreads();
+    for (int step = 8; step >= 1; step >>= 1) {
+      if (rl0 < step) {
+        const f32x4 s1 = lds4(l1 + rl0 * 128 + 4 * c4) + lds4(l1 + (rl0 + step) * 128 + 4 * c4);
+        const f32x4 s2 = lds4(l2 + rl0 * 128 + 4 * c4) + lds4(l2 + (rl0 + step) * 128 + 4 * c4);
+        *reinterpret_cast<float4*>(l1 + rl0 * 128 + 4 * c4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *reinterpret_cast<float4*>(l2 + rl0 * 128 + 4 * c4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+      }
+      __syncthreads();
+    }
+    if (rl0 == 0 && col) {
+      const f32x4 t1 = lds4(l1 + 4 * c4), t2 = lds4(l2 + 4 * c4);
+      const float* s = f.st + (int64_t)grp * C;
+      const float n = f.cnt[grp];
+      float* o = f.coef + (int64_t)grp * C;              // coef[0..2][grp][C]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * c4 + r;
+        const float s1 = t1[r], s2 = t2[r];
+        const float mu = s[c], rsd = s[2 * GC + c];
+        const float A = (f.gamma ? f.gamma[c] : 1.f) * rsd;
+        const float m1 = n > 0.f ? s1 / n : 0.f, m2 = n > 0.f ? rsd * s2 / n : 0.f;
+        o[c] = A;
+        o[GC + c] = A * (m1 - m2 * rsd * mu);
+        o[2 * GC + c] = A * m2 * rsd;
+        db[r] += s1;
+        dg[r] += rsd * s2;
+      }
+    }
+    __syncthreads();
+  }
+  if (rl0 == 0 && col) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * c4 + r;
+      if (f.dgamma) f.dgamma[c] = (f.acc ? f.dgamma[c] : 0.f) + dg[r];
+      if (f.dbeta) f.dbeta[c] = (f.acc ? f.dbeta[c] : 0.f) + db[r];
+    }
+  }
+}
+// ... and of the eps gradient (tdot_finish_block): threads 0..255 add the n float64 partials, out[0] += the sum.  red: 4 doubles in LDS.
+__device__ __forceinline__ void tdot_finish_tail(const double* part, int n, float* out, double* red) {
+  const int tid = threadIdx.x;
+  double t = 0.0;
+  if (tid < 256) {
+    for (int i = tid; i < n; i += 256) t += ld_sc1(part + i);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = t;
+  }
+  __syncthreads();
+  if (tid == 0) out[0] = out[0] + (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 struct TBwd {
   int64_t R; int G; const int32_t* nvalid; int K; int d_in, d_out;
   const float* dy; int lddy; const float* zo; int ldzo;
@@ -653,6 +898,7 @@ struct TBwd {
   int gx_acc;                                     // gx += (several Linears share one operand: q, k, v of the attention)
   const float* dotx; int lddot; double* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
   int nblk;             // workgroups per group
+  TBFin fin;            // fin.ticket != NULL: the producer's BatchNorm-backward finish / the eps finish by the launch's last workgroup
 };
 
 __host__ __device__ constexpr int stage_ld(int ntiles) { return ((16 * ntiles + 63) / 64) * 64 + 16; }   // row stride = 16 mod 64 banks
@@ -1006,7 +1252,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
       double tt = 0.0;
 #pragma unroll
       for (int w = 0; w < TW; ++w) tt += wsum[w];
-      a.dotp[blockIdx.x] = tt;
+      st_pub(a.dotp + blockIdx.x, tt, a.fin.ticket != nullptr);
     }
   }
   if (want_dx && xmu) {
@@ -1015,7 +1261,14 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     for (int i = threadIdx.x; i < 2 * a.d_in; i += 64 * TW) {
       const int w = i / a.d_in, c = i - w * a.d_in;
       const float* p = red + (w * 4) * 16 * NTI + c;
-      S[i] = (p[0] + p[16 * NTI]) + (p[2 * 16 * NTI] + p[3 * 16 * NTI]);
+      st_pub(S + i, (p[0] + p[16 * NTI]) + (p[2 * 16 * NTI] + p[3 * 16 * NTI]), a.fin.ticket != nullptr);
+    }
+  }
+  if (a.fin.ticket) {          // (a launch argument: wave-uniform)
+    __shared__ unsigned s_last;
+    if (last_arriver(a.fin.ticket, &s_last)) {      // (its barriers also retire every read of `red` and of the weight image)
+      if (a.fin.coef) tbn_bwd_finish_tail<64 * TW>(a.sums, a.nblk, a.G, a.d_in, a.fin, reinterpret_cast<float*>(t_lds));
+      if (a.fin.dot_out) tdot_finish_tail(a.dotp, a.nblk * a.G, a.fin.dot_out, reinterpret_cast<double*>(t_lds));
     }
   }
   TP_ACC(6);
@@ -1034,13 +1287,14 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
 // stack: its output feeds an aggregation / a residual): sums[grp][blk][0][c] = sum g, [1][c] = sum g * (z - mu), g = dy * [ms*z + mt > 0].
 __global__ __launch_bounds__(256) void k_tbn_bwd_sums(const float* __restrict__ dy, int lddy, const float* __restrict__ z, int ldz, int64_t R,
                                                       int G, int C, const int32_t* __restrict__ nvalid, int K, const float* __restrict__ st,
-                                                      int relu, int nblk, float* __restrict__ sums) {
+                                                      int relu, int nblk, float* sums, TBFin fin) {
   const int grp = blockIdx.x / nblk, blk = blockIdx.x - grp * nblk;
   const int C4 = C >> 2, cg = threadIdx.x % C4, rg = threadIdx.x / C4, nrg = 256 / C4;      // C % 4 == 0, C <= 1024
   const int64_t r_lo = R * blk / nblk, r_hi = R * (blk + 1) / nblk;
   const float* s = st + (int64_t)grp * C;
   const int64_t GC = (int64_t)G * C;
-  __shared__ float red[2][256][4];
+  __shared__ __align__(16) float sh[BFIN_LDS_FLOATS + 4];       // the row groups' sums; then the finish of the last workgroup + its flag
+  float (*red)[256][4] = reinterpret_cast<float (*)[256][4]>(sh);
   f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
   if (rg < nrg) {
     const f32x4 mu = ld4a(s, 4 * cg, C), sc = ld4a(s + 3 * GC, 4 * cg, C), sh = ld4a(s + 4 * GC, 4 * cg, C);
@@ -1063,7 +1317,10 @@ __global__ __launch_bounds__(256) void k_tbn_bwd_sums(const float* __restrict__ 
     const int w = i / C, c = i - w * C;
     float acc = 0.f;
     for (int q = 0; q < nrg; ++q) acc += red[w][q * C4 + (c >> 2)][c & 3];
-    S[i] = acc;
+    if (fin.ticket) st_sc1(S + i, acc); else S[i] = acc;
+  }
+  if (fin.ticket) {
+    if (last_arriver(fin.ticket, reinterpret_cast<unsigned*>(sh + BFIN_LDS_FLOATS))) tbn_bwd_finish_tail<256>(sums, nblk, G, C, fin, sh);
   }
 }
 
@@ -1164,6 +1421,19 @@ __device__ __forceinline__ void tsum_parts_block(int bid, int tid, const float* 
 __global__ __launch_bounds__(1024) void k_tsum_parts(const float* __restrict__ part, int nparts, int64_t stride, int64_t n,
                                                      float* __restrict__ out, int accumulate) {
   tsum_parts_block(blockIdx.x, threadIdx.x, part, nparts, stride, n, out, accumulate);
+}
+
+// ... for a table of jobs in one launch (the dW / db partials of every backward link of a step): block -> job by the prefix of block counts
+struct TJobs {
+  const float* part[SN_TRAIN_MAX_REDUCE_JOBS]; float* out[SN_TRAIN_MAX_REDUCE_JOBS]; int64_t stride[SN_TRAIN_MAX_REDUCE_JOBS];
+  int64_t n[SN_TRAIN_MAX_REDUCE_JOBS]; int nparts[SN_TRAIN_MAX_REDUCE_JOBS]; int first[SN_TRAIN_MAX_REDUCE_JOBS + 1]; int acc_mask_lo, acc_mask_hi;
+  int njobs;
+};
+__global__ __launch_bounds__(1024) void k_treduce_jobs(TJobs J) {
+  int j = 0;
+  while (j + 1 < J.njobs && (int)blockIdx.x >= J.first[j + 1]) ++j;          // (uniform: <= 64 scalar compares)
+  const int acc = j < 32 ? (J.acc_mask_lo >> j) & 1 : (J.acc_mask_hi >> (j - 32)) & 1;
+  tsum_parts_block((int)blockIdx.x - J.first[j], threadIdx.x, J.part[j], J.nparts[j], J.stride[j], J.n[j], J.out[j], acc);
 }
 
 // y = [relu](z * scale[g] + shift[g]) [+ res] on valid rows, 0 elsewhere (the last BatchNorm of a stack, whose output is materialised:
@@ -1572,6 +1842,20 @@ int raise_lds(KFn fn, size_t lds, const char* who) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// one arrival word per launch, round-robin over N_TICKETS (the last arriver resets its word: a word is reused N_TICKETS launches later)
+unsigned* take_ticket() {
+  static unsigned* base[32] = {};
+  static std::atomic<unsigned> next{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tickets)) != hipSuccess) return nullptr;
+    base[dev] = static_cast<unsigned*>(p);
+  }
+  return base[dev] + (next.fetch_add(1u) % (unsigned)N_TICKETS);
+}
+
 }  // namespace
 }  // namespace sn
 #ifdef SN_PROFILE
@@ -1620,6 +1904,8 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   SN_REQUIRE(!p.nvalid || p.K > 0, "sn_train_linear_f32: nvalid needs K > 0");
   SN_REQUIRE((p.in_scale == nullptr) == (p.in_shift == nullptr) && (!p.in_scale || (al16(p.in_scale) && al16(p.in_shift))),
              "sn_train_linear_f32: in_scale / in_shift go together, 16-byte aligned");
+  SN_REQUIRE(!p.fin_state || (p.stat_part && p.fin_count && al16(p.stat_part) && (p.fin_running_mean != nullptr) == (p.fin_running_var != nullptr)),
+             "sn_train_linear_f32: the fused finish needs stat_part (16-byte aligned), fin_count and running_mean / running_var together");
   if (p.R == 0) {
     // no rows: no launch; the moment partials a BatchNorm finish would read are defined (count 0), never left uninitialised
     if (p.stat_part) {
@@ -1631,7 +1917,12 @@ extern "C" int sn_train_linear_f32(const sn_train_linear_args* args, void* strea
   }
   const int nblk = sn_train_linear_blocks(p.R, p.G);
   TLin a{p.x, p.ldx, p.R, p.G, p.d_in, p.d_out, p.W, p.ldw, p.bias, p.nvalid, p.K, p.in_scale, p.in_shift, p.in_relu, p.out_relu,
-         p.y, p.ldy, p.stat_part, nblk};
+         p.y, p.ldy, p.stat_part, nblk, TFin{}};
+  if (p.fin_state) {
+    a.fin = TFin{p.fin_gamma, p.fin_beta, p.fin_eps, p.fin_momentum, p.fin_running_mean, p.fin_running_var, p.fin_state, p.fin_count,
+                 take_ticket()};
+    SN_REQUIRE(a.fin.ticket, "sn_train_linear_f32: no arrival ticket");
+  }
   const int nti = (p.d_in + 15) / 16, nto = (p.d_out + 15) / 16;
   // (the full-width links with aligned parameter rows: split-bf16 matrix path, three bf16 planes in the image)
   const bool split = p.d_in == 128 && p.d_out == 128 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0 && (p.ldw & 3) == 0 &&
@@ -1701,7 +1992,14 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   const int nblk = sn_train_linear_bwd_blocks(p.R, p.G);
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
-         p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk};
+         p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk, TBFin{}};
+  if (p.fin_coef || p.fin_dot_out) {
+    SN_REQUIRE(!p.fin_coef || (p.x_mean && p.sums_part && al16(p.sums_part) && p.fin_state && p.fin_count),
+               "sn_train_linear_bwd_f32: the fused BatchNorm finish needs x_mean, sums_part (16-byte aligned), fin_state and fin_count");
+    SN_REQUIRE(!p.fin_dot_out || (p.dot_x && p.dot_part), "sn_train_linear_bwd_f32: the fused eps finish needs dot_x / dot_part");
+    a.fin = TBFin{p.fin_state, p.fin_count, p.fin_gamma, p.fin_coef, p.fin_dgamma, p.fin_dbeta, p.fin_accumulate, p.fin_dot_out, take_ticket()};
+    SN_REQUIRE(a.fin.ticket, "sn_train_linear_bwd_f32: no arrival ticket");
+  }
   auto lds_of = [](int rt, bool split = false) {
     return (size_t)(split ? 8 * 4 * 3 : 8 * 8) * 1024 + (size_t)16 * rt * (stage_ld(8) + stage_ld(8)) * sizeof(float) +
            (size_t)(3 * 4 + 3 + 5) * 16 * 8 * sizeof(float);
@@ -1743,8 +2041,25 @@ extern "C" int sn_train_bn_bwd_sums_f32(const float* dy, int lddy, const float* 
   SN_REQUIRE(!nvalid || K > 0, "sn_train_bn_bwd_sums_f32: nvalid needs K > 0");
   const int nblk = sn_train_bn_bwd_blocks(R, G);
   hipLaunchKernelGGL(k_tbn_bwd_sums, dim3((unsigned)(nblk * G)), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz, R, G, C, nvalid, K, state,
-                     relu, nblk, sums_part);
+                     relu, nblk, sums_part, TBFin{});
   SN_CHECK_LAUNCH("sn_train_bn_bwd_sums_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_train_bn_bwd_f32(const float* dy, int lddy, const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K,
+                                   const float* state, const float* count, int relu, const float* gamma, float* sums_part, float* coef,
+                                   float* dgamma, float* dbeta, int accumulate, void* stream) {
+  SN_REQUIRE(dy && z && state && count && sums_part && coef && R >= 0 && G >= 1 && C > 0 && C % 4 == 0 && C <= 128,
+             "sn_train_bn_bwd_f32: bad arguments (C: a multiple of 4 up to 128)");
+  SN_REQUIRE(lddy >= C && ldz >= C && lddy % 4 == 0 && ldz % 4 == 0 && al16(dy) && al16(z) && al16(state) && al16(sums_part),
+             "sn_train_bn_bwd_f32: rows must be 16-byte aligned");
+  SN_REQUIRE(!nvalid || K > 0, "sn_train_bn_bwd_f32: nvalid needs K > 0");
+  const int nblk = sn_train_bn_bwd_blocks(R, G);
+  const TBFin fin{state, count, gamma, coef, dgamma, dbeta, accumulate, nullptr, take_ticket()};
+  SN_REQUIRE(fin.ticket, "sn_train_bn_bwd_f32: no arrival ticket");
+  hipLaunchKernelGGL(k_tbn_bwd_sums, dim3((unsigned)(nblk * G)), dim3(256), 0, (hipStream_t)stream, dy, lddy, z, ldz, R, G, C, nvalid, K, state,
+                     relu, nblk, sums_part, fin);
+  SN_CHECK_LAUNCH("sn_train_bn_bwd_f32");
   return SN_OK;
 }
 
@@ -1820,6 +2135,27 @@ extern "C" int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t 
   if (n == 0) return SN_OK;
   hipLaunchKernelGGL(k_tsum_parts, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, (hipStream_t)stream, part, nparts, stride, n, out, accumulate);
   SN_CHECK_LAUNCH("sn_train_reduce_parts_f32");
+  return SN_OK;
+}
+
+extern "C" int sn_train_reduce_jobs_f32(const sn_train_reduce_job* jobs, int njobs, void* stream) {
+  SN_REQUIRE(jobs && njobs >= 1 && njobs <= SN_TRAIN_MAX_REDUCE_JOBS, "sn_train_reduce_jobs_f32: 1..%d jobs", SN_TRAIN_MAX_REDUCE_JOBS);
+  TJobs J{};
+  int nb = 0, k = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const sn_train_reduce_job& q = jobs[j];
+    SN_REQUIRE(q.part && q.out && q.nparts >= 1 && q.n >= 0 && q.stride >= q.n, "sn_train_reduce_jobs_f32: bad job %d", j);
+    if (q.n == 0) continue;
+    J.part[k] = q.part; J.out[k] = q.out; J.stride[k] = q.stride; J.n[k] = q.n; J.nparts[k] = q.nparts; J.first[k] = nb;
+    if (q.accumulate) { if (k < 32) J.acc_mask_lo |= 1 << k; else J.acc_mask_hi |= 1 << (k - 32); }
+    nb += (int)cdiv(q.n, 64);
+    ++k;
+  }
+  if (k == 0) return SN_OK;
+  J.first[k] = nb;
+  J.njobs = k;
+  hipLaunchKernelGGL(k_treduce_jobs, dim3((unsigned)nb), dim3(1024), 0, (hipStream_t)stream, J);
+  SN_CHECK_LAUNCH("sn_train_reduce_jobs_f32");
   return SN_OK;
 }
 

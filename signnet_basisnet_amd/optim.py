@@ -181,10 +181,14 @@ class FlatAdam:
         return ctx()
 
     def _launch(self, b):
+        from . import train_stage
+        train_stage.flush_deferred()          # weight gradients still waiting as per-workgroup partials are added first
         lo, hi = self.buckets[b]
         self._work[b] = self.dist.all_reduce(self.flat_g[lo:hi], async_op=True)
 
     def zero_grad(self, set_to_none=False):
+        from . import train_stage
+        train_stage.flush_deferred()
         self._finish()
         self.flat_g.zero_()
 
@@ -198,6 +202,8 @@ class FlatAdam:
         """SUM over the data-parallel ranks (buckets not yet issued by the backward hooks are issued here, then all are waited
         for); returns the scale that turns the sum into the mean.  With a process group the collective always runs, also at
         world size 1 (RCCL init and ncclAllReduce are then exercised on a one-GPU box)."""
+        from . import train_stage
+        train_stage.flush_deferred()          # (a no-op after a complete loss.backward(): its end-of-backward callback has run)
         if self.dist is None:
             return 1.0
         early = sum(w is not None for w in self._work)

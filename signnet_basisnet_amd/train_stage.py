@@ -26,7 +26,9 @@ class _LinArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("R", C.c_int64), ("G", C.c_int), ("d_in", C.c_int), ("d_out", C.c_int),
                 ("W", C.c_void_p), ("ldw", C.c_int), ("bias", C.c_void_p), ("nvalid", C.c_void_p), ("K", C.c_int),
                 ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_relu", C.c_int), ("out_relu", C.c_int),
-                ("y", C.c_void_p), ("ldy", C.c_int), ("stat_part", C.c_void_p)]
+                ("y", C.c_void_p), ("ldy", C.c_int), ("stat_part", C.c_void_p),
+                ("fin_gamma", C.c_void_p), ("fin_beta", C.c_void_p), ("fin_eps", C.c_float), ("fin_momentum", C.c_float),
+                ("fin_running_mean", C.c_void_p), ("fin_running_var", C.c_void_p), ("fin_state", C.c_void_p), ("fin_count", C.c_void_p)]
 
 
 class _BwdArgs(C.Structure):
@@ -37,7 +39,9 @@ class _BwdArgs(C.Structure):
                 ("x", C.c_void_p), ("ldx", C.c_int), ("x_scale", C.c_void_p), ("x_shift", C.c_void_p), ("x_relu", C.c_int),
                 ("x_mean", C.c_void_p), ("W", C.c_void_p), ("ldw", C.c_int), ("gx", C.c_void_p), ("ldgx", C.c_int),
                 ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int), ("gx_accumulate", C.c_int),
-                ("dot_x", C.c_void_p), ("lddot", C.c_int), ("dot_part", C.c_void_p)]
+                ("dot_x", C.c_void_p), ("lddot", C.c_int), ("dot_part", C.c_void_p),
+                ("fin_state", C.c_void_p), ("fin_count", C.c_void_p), ("fin_gamma", C.c_void_p), ("fin_coef", C.c_void_p),
+                ("fin_dgamma", C.c_void_p), ("fin_dbeta", C.c_void_p), ("fin_accumulate", C.c_int), ("fin_dot_out", C.c_void_p)]
 
 
 class _SMlpArgs(C.Structure):
@@ -45,6 +49,20 @@ class _SMlpArgs(C.Structure):
                 ("d", C.c_int), ("w1", C.c_void_p), ("gamma_a", C.c_void_p), ("beta_a", C.c_void_p), ("eps_a", C.c_float),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("gamma_b", C.c_void_p), ("beta_b", C.c_void_p), ("eps_b", C.c_float),
                 ("relu_b", C.c_int), ("scalar_state", C.c_void_p), ("column_state", C.c_void_p)]
+
+
+# Launch structure of a link's reductions (environment, read once; profiles/scripts/train_ab.sh measures all four combinations):
+#   SN_TRAIN_FUSE_FINISH=1  the finishes of a link's batch statistics / BatchNorm backward / eps gradient run INSIDE the link's launch, by
+#                           its last-arriving workgroup (agent-scope ticket behind write-through partials): 175 -> 119 launches per step,
+#                           the same reduction order (last-bit differences from FMA contraction) — and 0.10-0.29 ms SLOWER per replayed
+#                           step (3.10 -> 3.31 ms, 3.22 -> 3.32, 3.08 -> 3.37 on three boxes): one
+#                           workgroup pulling 130-260 KB of partials through one CU's memory path behind an atomic round trip costs more
+#                           than the ~2 us boundary + 8-block finish kernel it replaces.  OFF by default; kept for the A/B and because
+#                           a host-bound EAGER loop gains from it (4.32 -> 3.90 ms).
+#   SN_TRAIN_DEFER_DW=0     the dW / db reduction behind every link instead of one launch at the end of loss.backward().
+import os as _os
+FUSE_FINISH = _os.environ.get("SN_TRAIN_FUSE_FINISH", "0") == "1"
+DEFER_DW = _os.environ.get("SN_TRAIN_DEFER_DW", "1") != "0"
 
 
 def supported(d_in: int, d_out: int) -> bool:
@@ -66,6 +84,50 @@ class _PostArgs(C.Structure):
                 ("sums_part", C.c_void_p), ("nblk", C.c_int), ("G", C.c_int), ("C", C.c_int), ("state", C.c_void_p), ("count", C.c_void_p),
                 ("gamma", C.c_void_p), ("coef", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("accumulate_bn", C.c_int),
                 ("dot_part", C.c_void_p), ("dot_n", C.c_int), ("dot_out", C.c_void_p)]
+
+
+class _ReduceJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("nparts", C.c_int), ("stride", C.c_int64), ("n", C.c_int64), ("out", C.c_void_p),
+                ("accumulate", C.c_int)]
+
+
+MAX_REDUCE_JOBS = 64
+
+
+class _Deferred:
+    """The dW / db partial sums of the backward links of ONE loss.backward(), reduced into the parameters' gradients by a single launch
+    when the backward pass ends (sn_train_reduce_jobs_f32) instead of one small launch behind every link: nothing reads a weight
+    gradient before the optimiser (or a gradient all-reduce: optim.FlatAdam flushes first).  Only gradients that are accumulated in
+    place (`direct_grad`) are deferred; the arithmetic per parameter is that of sn_train_reduce_parts_f32, bit for bit."""
+    jobs = []            # (partials tensor [kept alive], byte offset, nparts, stride, n, out tensor)
+    outs = set()
+    armed = False
+
+
+def _defer_reduce(part, off_floats, nparts, stride, n, out):
+    key = out.data_ptr()
+    if key in _Deferred.outs or len(_Deferred.jobs) >= 4 * MAX_REDUCE_JOBS:       # two adds into one gradient must not share a launch
+        flush_deferred()
+    _Deferred.jobs.append((part, off_floats, nparts, stride, n, out))
+    _Deferred.outs.add(key)
+    if not _Deferred.armed:
+        try:        # at the end of the running backward pass (on the caller's stream, inside a HIP-graph capture too)
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
+            _Deferred.armed = True
+        except RuntimeError:        # not inside a backward pass (a direct call of linear_bwd): reduce now
+            flush_deferred()
+
+
+def flush_deferred():
+    _Deferred.armed = False
+    jobs, _Deferred.jobs, _Deferred.outs = _Deferred.jobs, [], set()
+    for i in range(0, len(jobs), MAX_REDUCE_JOBS):
+        chunk = jobs[i:i + MAX_REDUCE_JOBS]
+        arr = (_ReduceJob * len(chunk))()
+        for j, (part, off, nparts, stride, n, out) in enumerate(chunk):
+            arr[j] = _ReduceJob(part.data_ptr() + 4 * off, nparts, stride, n, out.data_ptr(), 1)
+        with ops._span("sn_train_reduce_jobs_f32"):
+            check(lib().sn_train_reduce_jobs_f32(arr, len(chunk), stream()), "sn_train_reduce_jobs_f32")
 
 
 def direct_grad(p):
@@ -105,9 +167,23 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
     a = _LinArgs(ptr(x), x.stride(0), R, G, d_in, d_out, ptr(W), W.stride(0), ptr(None if b is None else b.detach()), ptr(nvalid), int(K),
                  ptr(None if in_state is None else in_state.scale), ptr(None if in_state is None else in_state.shift),
                  int(in_relu), int(out_relu), ptr(y), d_out, ptr(stat))
+    st = None
+    if bn is not None and R > 0 and FUSE_FINISH:
+        # the BatchNorm finish inside the link's launch (its last-arriving workgroup): no second launch
+        st = BNState(G, d_out, x.device)
+        mom = 0.1 if bn.momentum is None else float(bn.momentum)
+        track = bn.track_running_stats and bn.running_mean is not None
+        a.fin_gamma, a.fin_beta = ptr(None if bn.weight is None else bn.weight.detach()), ptr(None if bn.bias is None else bn.bias.detach())
+        a.fin_eps, a.fin_momentum = float(bn.eps), mom
+        a.fin_running_mean, a.fin_running_var = ptr(bn.running_mean if track else None), ptr(bn.running_var if track else None)
+        a.fin_state, a.fin_count = ptr(st.state), ptr(st.count)
+        with ops._span("sn_train_linear_f32"):
+            check(lib().sn_train_linear_f32(C.byref(a), stream()), "sn_train_linear_f32")
+        if track and bn.num_batches_tracked is not None:
+            ops._count_batch(bn, G)
+        return y, st
     with ops._span("sn_train_linear_f32"):
         check(lib().sn_train_linear_f32(C.byref(a), stream()), "sn_train_linear_f32")
-    st = None
     if bn is not None and R <= 0:
         # no rows (an edge encoder over a batch without edges): nn.BatchNorm1d in training mode returns the empty tensor, leaves the running
         # statistics alone and counts the batch — nothing to finish (the kernel above did not run: its moment partials are zeros)
@@ -145,9 +221,10 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
     dev = dy.device
     nblk = int(lib().sn_train_linear_bwd_blocks(R, G))
     gx = (gx_into if gx_into is not None else torch.empty(G * R, d_in, dtype=torch.float32, device=dev)) if want_dx else None
-    sums = torch.empty(G * nblk * 2 * d_in, dtype=torch.float32, device=dev) if want_sums else None
+    alloc = torch.empty if R > 0 else torch.zeros        # (no rows: no launch — the partials the reductions read are zeros)
+    sums = alloc(G * nblk * 2 * d_in, dtype=torch.float32, device=dev) if want_sums else None
     stride = d_out * d_in + (d_out if want_db else 0)
-    dwp = torch.empty(G * nblk * stride, dtype=torch.float32, device=dev)
+    dwp = alloc(G * nblk * stride, dtype=torch.float32, device=dev)
     a = _BwdArgs(R, G, ptr(nvalid), int(K), d_in, d_out, ptr(dy), dy.stride(0), ptr(zo), 0 if zo is None else zo.stride(0),
                  ptr(None if coef is None else coef[0]), ptr(None if coef is None else coef[1]), ptr(None if coef is None else coef[2]),
                  ptr(None if mask is None else mask[0]), ptr(None if mask is None else mask[1]),
@@ -157,19 +234,41 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
                  0 if dot_x is None else dot_x.stride(0), None)
     linear_bwd.dot_part = None
     if dot_x is not None:
-        linear_bwd.dot_part = torch.empty(G * nblk, dtype=torch.float64, device=dev)
+        linear_bwd.dot_part = alloc(G * nblk, dtype=torch.float64, device=dev)
         a.dot_part = ptr(linear_bwd.dot_part)
-    with ops._span("sn_train_linear_bwd_f32"):
-        check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
     nw = d_out * d_in
     linear_bwd.coef = None
-    if dW_acc is not None and (not want_db or db_acc is not None):
-        fuse_bn = None
-        if finish_bn is not None and want_sums and x_state is not None:
-            dg, dbt = direct_grad(finish_bn.weight), direct_grad(finish_bn.bias)
-            if dg is not None and dbt is not None:
-                fuse_bn = (dg, dbt)
-        fuse_dot = dot_acc is not None and dot_x is not None
+    acc_w = dW_acc is not None and (not want_db or db_acc is not None)
+    fuse_bn = None
+    if acc_w and finish_bn is not None and want_sums and x_state is not None:
+        dg, dbt = direct_grad(finish_bn.weight), direct_grad(finish_bn.bias)
+        if dg is not None and dbt is not None:
+            fuse_bn = (dg, dbt)
+    fuse_dot = acc_w and dot_acc is not None and dot_x is not None
+    in_launch = FUSE_FINISH and R > 0 and (fuse_bn is not None or fuse_dot)
+    if in_launch:            # the finishes behind the link run in the link's own launch (its last-arriving workgroup)
+        if fuse_bn is not None:
+            cf = torch.empty(3, x_state.G, x_state.C, dtype=torch.float32, device=dev)
+            a.fin_state, a.fin_count, a.fin_gamma = ptr(x_state.state), ptr(x_state.count), ptr(finish_bn.weight.detach())
+            a.fin_coef, a.fin_dgamma, a.fin_dbeta, a.fin_accumulate = ptr(cf), ptr(fuse_bn[0]), ptr(fuse_bn[1]), 1
+            linear_bwd.coef = cf
+        if fuse_dot:
+            a.fin_dot_out = ptr(dot_acc)
+    with ops._span("sn_train_linear_bwd_f32"):
+        check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
+    if acc_w and DEFER_DW and (in_launch or not (fuse_bn is not None or fuse_dot)):
+        # the dW / db partials wait for the end of the backward pass (one reduction launch for all links)
+        _defer_reduce(dwp, 0, G * nblk, stride, nw, dW_acc)
+        if want_db:
+            _defer_reduce(dwp, nw, G * nblk, stride, d_out, db_acc)
+        if fuse_dot:
+            linear_bwd._dot_keep, linear_bwd.dot_part = linear_bwd.dot_part, None      # (kept alive until the next call)
+        return gx, sums, nblk, None, None
+    if acc_w:
+        if in_launch:
+            fuse_bn, fuse_dot = None, False        # (already done; only the dW reduction is left)
+            if linear_bwd.dot_part is not None and dot_acc is not None:
+                linear_bwd._dot_keep, linear_bwd.dot_part = linear_bwd.dot_part, None
         if fuse_bn is not None or fuse_dot or want_db:
             q = _PostArgs(ptr(dwp), G * nblk, stride, nw, ptr(dW_acc), d_out if want_db else 0, ptr(db_acc) if want_db else None,
                           None, 0, 0, 0, None, None, None, None, None, None, 1, None, 0, None)
@@ -237,6 +336,25 @@ def bn_bwd_finish(sums, nblk, st, gamma, dg_acc=None, db_acc=None):
     return (coef, None, None) if acc else (coef, dgb[0], dgb[1])
 
 
+def bn_bwd(dy, z, R, G, nvalid, K, st, relu, gamma, dg_acc=None, db_acc=None):
+    """bn_bwd_sums + bn_bwd_finish; ONE launch (the sums kernel's last-arriving workgroup finishes) for widths up to 128."""
+    Cc = z.shape[-1]
+    if not (FUSE_FINISH and R > 0 and Cc <= 128):
+        sums, nblk = bn_bwd_sums(dy, z, R, G, nvalid, K, st, relu)
+        return bn_bwd_finish(sums, nblk, st, gamma, dg_acc, db_acc)
+    nblk = int(lib().sn_train_bn_bwd_blocks(R, G))
+    sums = torch.empty(G * nblk * 2 * Cc, dtype=torch.float32, device=z.device)
+    coef = torch.empty(3, st.G, st.C, dtype=torch.float32, device=z.device)
+    acc = dg_acc is not None and db_acc is not None
+    dgb = None if acc else torch.empty(2, st.C, dtype=torch.float32, device=z.device)
+    with ops._span("sn_train_bn_bwd_f32"):
+        check(lib().sn_train_bn_bwd_f32(ptr(dy), dy.stride(0), ptr(z), z.stride(0), R, G, Cc, ptr(nvalid), int(K), ptr(st.state),
+                                        ptr(st.count), int(relu), ptr(None if gamma is None else gamma.detach()), ptr(sums), ptr(coef),
+                                        ptr(dg_acc if acc else dgb[0]), ptr(db_acc if acc else dgb[1]), int(acc), stream()),
+              "sn_train_bn_bwd_f32")
+    return (coef, None, None) if acc else (coef, dgb[0], dgb[1])
+
+
 def bn_apply(z, R, G, nvalid, K, st, relu, residual):
     """y = [relu](z * scale[g] + shift[g]) [+ residual] on valid rows, 0 elsewhere."""
     y = torch.empty_like(z)
@@ -261,8 +379,7 @@ def _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, 
     """-> (dx, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2); parameter gradients already accumulated in-kernel come back as None."""
     dg2 = dbe2 = coef2 = mask2 = None
     if st2 is not None:
-        sums2, nb2 = bn_bwd_sums(dy, z2, R, G, nvalid, K, st2, relu_out)
-        coef2, dg2, dbe2 = bn_bwd_finish(sums2, nb2, st2, bn2.weight, direct_grad(bn2.weight), direct_grad(bn2.bias))
+        coef2, dg2, dbe2 = bn_bwd(dy, z2, R, G, nvalid, K, st2, relu_out, bn2.weight, direct_grad(bn2.weight), direct_grad(bn2.bias))
         mask2 = (st2.scale, st2.shift) if relu_out else None
     gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, lin2.weight, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
                                            x_state=st1, x_relu=True, want_sums=True, want_db=lin2.bias is not None,
@@ -320,8 +437,7 @@ class _LinBn(Function):
         x, z = ctx.saved_tensors
         R, nvalid, K, relu, st, has_res, lin, bn = ctx.meta
         dy = _c(dy)
-        sums, nb = bn_bwd_sums(dy, z, R, 1, nvalid, K, st, relu)
-        coef, dg, dbe = bn_bwd_finish(sums, nb, st, bn.weight, direct_grad(bn.weight), direct_grad(bn.bias))
+        coef, dg, dbe = bn_bwd(dy, z, R, 1, nvalid, K, st, relu, bn.weight, direct_grad(bn.weight), direct_grad(bn.bias))
         dx, _, _, dW, db = linear_bwd(dy, R, 1, lin.weight, nvalid, K, x, zo=z, coef=coef, mask=(st.scale, st.shift) if relu else None,
                                       want_dx=ctx.needs_input_grad[0], want_db=lin.bias is not None,
                                       dW_acc=direct_grad(lin.weight), db_acc=direct_grad(lin.bias))

@@ -47,7 +47,10 @@ def test_python_binding_covers_the_header(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.sn_version() == 1
+    from signnet_basisnet_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "signnet_hip.h")).read()
+    import re
+    assert lib.sn_version() == L.ABI_VERSION == int(re.search(r"#define SN_ABI_VERSION (\d+)", hdr).group(1)) == 2
     # argument validation happens on the host before any launch: callable without a GPU
     rc = lib.sn_pack_weight_f32(None, 4, 4, 4, None, None)
     assert rc == -1 and b"sn_pack_weight_f32" in lib.sn_last_error()
@@ -124,6 +127,9 @@ int main(void) {
          offsetof(sn_train_linear_bwd_args, dot_part), sizeof(sn_train_scalar_mlp_args), offsetof(sn_train_scalar_mlp_args, w2),
          offsetof(sn_train_scalar_mlp_args, column_state));
   printf("%zu %zu %zu\n", sizeof(sn_train_post_args), offsetof(sn_train_post_args, sums_part), offsetof(sn_train_post_args, dot_part));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(sn_train_linear_args, fin_eps), offsetof(sn_train_linear_args, fin_count),
+         offsetof(sn_train_linear_bwd_args, fin_coef), offsetof(sn_train_linear_bwd_args, fin_dot_out), sizeof(sn_train_reduce_job),
+         offsetof(sn_train_reduce_job, out));
   printf("%zu %zu %zu %zu\n", sizeof(sn_plan_early), offsetof(sn_plan_early, max_graph_edges), offsetof(sn_plan_early, host), offsetof(sn_plan_bins, phi_bin_mem));
   return 0;
 }'''
@@ -145,6 +151,8 @@ int main(void) {
             S(train_stage._BwdArgs), train_stage._BwdArgs.x_mean.offset, train_stage._BwdArgs.dot_part.offset,
             S(train_stage._SMlpArgs), train_stage._SMlpArgs.w2.offset, train_stage._SMlpArgs.column_state.offset,
             S(train_stage._PostArgs), train_stage._PostArgs.sums_part.offset, train_stage._PostArgs.dot_part.offset,
+            train_stage._LinArgs.fin_eps.offset, train_stage._LinArgs.fin_count.offset, train_stage._BwdArgs.fin_coef.offset,
+            train_stage._BwdArgs.fin_dot_out.offset, S(train_stage._ReduceJob), train_stage._ReduceJob.out.offset,
             S(ops._PlanEarlyC), ops._PlanEarlyC.max_graph_edges.offset, ops._PlanEarlyC.host.offset, ops._PlanBinsC.phi_bin_mem.offset]
     assert got == want
 
