@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32 MFMA (f32 in / f32 acc) dense peak
+VALU_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: "Peak FP32 (vector) 157.3 TFLOPS (spec)" (packed v_pk_fma_f32; scalar-width FMAs issue at half of it)
 
 DOMINANT = "sn_phi_fused_f32"     # the kernel the roofline block is quoted on (largest share of the step)
 # what bounds a kernel whose MFMA fraction alone would mislead (kernels.* block of the line)
@@ -169,8 +170,11 @@ def evd_bench(args, dev):
     out = {"metric": "graphs/sec batched Laplacian eigendecomposition ('sym'), ZINC-like graphs", "unit": "graphs/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
            "vs_baseline": None, "roofline": None,
-           "roofline_note": "one-sided Jacobi in registers: bound by the dependent ds_bpermute / FMA chain of one wave per "
-                            "graph group (latency), neither HBM nor MFMA"}
+           "roofline_note": "one-sided Jacobi in registers, four waves per graph (rows dealt round-robin, the partial dot products "
+                            "meet in LDS once per rotation step): bound by the step's DEPENDENT chain — partner rows through "
+                            "ds_bpermute -> dot products -> LDS meeting + barrier -> rotation parameters -> update — of which a sweep "
+                            "has n - 1 and a graph ~9 sweeps; neither HBM nor MFMA.  `roofline` prices the arithmetic of those steps "
+                            "against the fp32 VECTOR peak (the pipe it runs on): the fraction is the VALU-issue share of the chain"}
     for tag, B in (("batch128", WORKLOAD["B"]), ("batch8192", 8192)):
         base = synth.make_batch(min(B, 1024), seed=1236)
         reps = max(1, B // 1024)
@@ -188,7 +192,19 @@ def evd_bench(args, dev):
         dt = (time.perf_counter() - t0) / args.steps
         out[tag] = {"graphs": len(sizes), "nodes": N, "ms_per_step": 1e3 * dt, "value": len(sizes) / dt,
                     "status": st.tolist()}
+        # arithmetic of the Jacobi steps: per sweep m - 1 steps (m = n rounded to even), per step and column n rows x (2 FMA of the two
+        # dot products + 4 FMA of the G and V updates) = 12 flop; sweeps = the measured maximum (status[1] - 1 rotating sweeps + the
+        # confirming one), an upper bound for the smaller graphs
+        sweeps = max(1, int(st[1].item()))
+        flops = sum(sweeps * ((v + 1) // 2 * 2 - 1) * v * v * 12.0 for v in sizes)
+        out[tag]["jacobi_gflop"] = flops / 1e9
         if tag == "batch128":
+            ach = flops / dt / 1e12
+            out["roofline"] = {"bound": "valu (latency chain)", "achieved": ach, "peak": VALU_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ach / VALU_F32_PEAK_TF,
+                               "traffic": None, "sweeps": sweeps,
+                               "note": "achieved = 12 flop x rows x columns x steps of every graph / wall time of the whole call (memset, class "
+                                       "lists, adjacency scatter and the Jacobi launch); peak = the fp32 vector peak of MI355X_MICROARCH.md (157.3 TFLOP/s, packed "
+                                       "FMA)"}
             out["value"], out["ms_per_step"] = len(sizes) / dt, 1e3 * dt
             out["config"] = {"workload": f"EVDTransform('sym') of one collated batch of {len(sizes)} ZINC-like graphs (n 9..37)"}
             t0 = time.perf_counter()

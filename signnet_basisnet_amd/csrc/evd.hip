@@ -6,10 +6,11 @@
 //   lap_positional_encoding        GraphPrediction/data/molecules.py:148-181
 //     (I - D^-1/2 A D^-1/2 -> eig -> sort -> columns 1..k, zero padded)
 //
-// Method: parallel one-sided (Hestenes) Jacobi in registers.  A graph of n <= NR nodes is owned by NR lanes of a
-// wave (NR = 16 / 32 / 64: 4 / 2 / 1 graphs per wave); lane j holds column j of G = L*V and of V (NR registers
-// each).  A step rotates n/2 disjoint column pairs at once (round-robin tournament): a lane pulls its partner's
-// column through ds_bpermute, forms the three dot products in registers, and applies its half of the rotation in
+// Method: parallel one-sided (Hestenes) Jacobi in registers.  A graph of n <= NR nodes is owned by NR lanes of each of
+// the FOUR waves of a workgroup (NR = 16 / 32 / 64: 4 / 2 / 1 graphs per workgroup); lane j holds column j of G = L*V
+// and of V, wave w the rows [w NR/4, (w+1) NR/4) of them.  A step rotates n/2 disjoint column pairs at once (round-robin
+// tournament): a lane pulls its partner's column through ds_bpermute, forms its share of the three dot products (the
+// four waves' shares meet in LDS, one barrier per step), and applies its half of the rotation in
 // the Rutishauser form x' = x -/+ s (y +/- tau x) (keeps V orthogonal to fp32 rounding: the plain c/s form drifts,
 // because c rounds to 1 for small angles while s does not).  Converged when a whole sweep rotates nothing;
 // eigenvalues are the Rayleigh quotients v_j . g_j, ranked in registers, and the columns are stored in ascending
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void k_evd_prep(const int32_t* __restrict__ gr
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid < 3) cnt[tid] = 0;
   if (tid == 0) carry_s = 0;
+  if (tid < 4) status[tid] = 0;          // (this kernel is the call's first: the later ones only OR / max into the words)
   __syncthreads();
   int flags = 0;
   for (int g0 = 0; g0 < B; g0 += 256) {
@@ -123,21 +125,25 @@ struct EvdArgs {
   int norm, k, skip;
 };
 
-// rows in blocks of 8 under a wave-uniform bound: rows >= the largest n of the wave's graphs are zero in G and V
-// (real columns never mix with the padding columns), so they are skipped without dynamic register indexing
-#define EVD_ROWS(...)                                   \
-  _Pragma("unroll") for (int rb = 0; rb < NR / 8; ++rb) \
-    if (rb * 8 < nmax) {                                \
-      _Pragma("unroll") for (int q = 0; q < 8; ++q) {   \
-        const int r = rb * 8 + q;                       \
-        __VA_ARGS__                                     \
-      }                                                 \
-    }
+// Four waves per graph (round 6; one wave per graph before: a 37-node graph walked 40 rows x (2 ds_bpermute + 6 FMA) serially per
+// rotation step on one SIMD of one CU while the CU's other three SIMDs and half the chip's CUs idled).  The rotation is row-parallel:
+// wave w of the workgroup owns rows [w*RW, (w+1)*RW), RW = NR/4, of G and V; lane j still owns column j.  Per step a wave forms its
+// partial dot products over its rows, the four partials meet in LDS (two alternating slots: ONE barrier per step), every wave adds
+// them in wave order — the same bits in all four, so the rotate / skip / converged decisions are workgroup-uniform — and rotates its
+// rows.  The partner's V rows are requested with its G rows at the top of the step (the LDS crossbar is idle otherwise), so the
+// V update does not wait for a second bpermute round trip.
+constexpr int EVD_WV = 4;          // waves per workgroup (measured, 128 ZINC graphs: 2 -> -, 4 -> 0.235 ms, 8 -> 0.273 ms and 1.8x slower at 8 192 graphs)
 
-template <int NR>
-__device__ __forceinline__ void evd_jacobi(const EvdArgs& a, const int32_t* cls_list, int count, int blk) {
+// Rows are dealt to the waves round-robin (row r belongs to wave r % WV): whatever the largest graph of the workgroup, every wave
+// gets ceil(nmax / WV) live rows (37 nodes on 4 waves: 10 rows each; in contiguous quarters of 64 it was 16, 16, 6, 0).
+// RW = live rows per wave: a COMPILE-TIME bound (the dispatcher below rounds ceil(nmax / WV) up to even): the row loops are straight-line
+// code — with a run-time guard per pair of rows every loop was eight basic blocks and the step 1.3x slower than contiguous quarters.
+template <int NR, int WV, int RW>
+__device__ __noinline__ void evd_jacobi_rows(const EvdArgs& a, const int32_t* cls_list, int count, int blk, float* lds) {
   constexpr int GPW = 64 / NR;
-  const int lane = threadIdx.x, j = lane & (NR - 1), base = lane & ~(NR - 1);
+  static_assert(RW >= 1 && RW * WV <= NR + WV, "live rows per wave");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & (NR - 1), base = lane & ~(NR - 1);
   const int slot = blk * GPW + lane / NR;
   const bool live = slot < count;
   int n = 0, n0 = 0;
@@ -155,121 +161,195 @@ __device__ __forceinline__ void evd_jacobi(const EvdArgs& a, const int32_t* cls_
 #pragma unroll
   for (int o = NR; o < 64; o <<= 1) mmax = max(mmax, __shfl_xor(mmax, o));
   mmax = __builtin_amdgcn_readfirstlane(mmax);
-  const int nmax = mmax;                   // rows / columns >= nmax are padding in every graph of this wave
-  float G[NR], V[NR], T[NR];
-  // adjacency column j (= row j), degrees, Laplacian
+  // my rows: r(i) = wave + WV * i, i < RW; rows >= mmax (the largest graph of this workgroup, rounded to even) are padding in G and V
+  // of every real column — zero, and they stay zero: computing on the few padding rows below WV * RW is harmless
+#define EVD_ROWS(...)                                  \
+  _Pragma("unroll") for (int i = 0; i < RW; ++i) {     \
+    const int r = wave + WV * i;                       \
+    (void)r;                                           \
+    __VA_ARGS__                                        \
+  }
+  float G[RW], V[RW], TG[RW], TV[RW];
+  // adjacency column j (= row j: symmetric), degree over the WHOLE column, Laplacian rows of this wave
   float deg = 0.f;
+  for (int r = 0; r < mmax; ++r) deg += (col && r < n) ? a.vec[off + (int64_t)r * n + j] : 0.f;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    G[r] = (col && r < n) ? a.vec[off + (int64_t)r * n + j] : 0.f;
-    deg += G[r];
-    V[r] = (r == j) ? 1.f : 0.f;
-    T[r] = 0.f;
+  for (int i = 0; i < RW; ++i) {
+    const int r = wave + WV * i;
+    G[i] = (col && r < n) ? a.vec[off + (int64_t)r * n + j] : 0.f;
+    V[i] = (r == j) ? 1.f : 0.f;
+    TG[i] = 0.f; TV[i] = 0.f;
   }
   if (a.norm == 1) {       // get_laplacian(normalization='sym'): I - D^-1/2 A D^-1/2, 1/sqrt(0) -> 0, unit diagonal everywhere
     const float dis = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
+    for (int i = 0; i < RW; ++i) {
+      const int r = wave + WV * i;
       const float dr = bperm(base + r, dis);
-      G[r] = -(G[r] * dr) * dis;
-      if (r == j && col) G[r] = 1.f;
+      G[i] = -(G[i] * dr) * dis;
+      if (r == j && col) G[i] = 1.f;
     }
   } else {                 // normalization=None: D - A
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      G[r] = -G[r];
-      if (r == j) G[r] = deg;
+    for (int i = 0; i < RW; ++i) {
+      G[i] = -G[i];
+      if (wave + WV * i == j) G[i] = deg;
     }
   }
-  float amax = 0.f;
+  // the waves' partials of a column: part[slot][wave][lane] = (x, y); two alternating slots, ONE barrier per meeting.  A lane also
+  // reads its PARTNER's partials (its column norm) from the same slot: no second cross-lane round trip for it.
+  float2* part = reinterpret_cast<float2*>(lds);
+  auto meet = [&](int sl, float x, float y, int pl, float& sx, float& sy, float& px) {
+    part[(sl * WV + wave) * 64 + lane] = make_float2(x, y);
+    __syncthreads();
+    sx = 0.f; sy = 0.f; px = 0.f;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) amax = fmaf(G[r], G[r], amax);
+    for (int w = 0; w < WV; ++w) {
+      const float2 t = part[(sl * WV + w) * 64 + lane];
+      const float u = part[(sl * WV + w) * 64 + pl].x;
+      sx += t.x; sy += t.y; px += u;
+    }
+  };
+  float amax = 0.f, d0, d1;
+#pragma unroll
+  for (int i = 0; i < RW; ++i) amax = fmaf(G[i], G[i], amax);
+  meet(0, amax, 0.f, lane, amax, d0, d1);
 #pragma unroll
   for (int o = 1; o < NR; o <<= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
   const float athr = EVD_ZERO * EVD_ZERO * amax;
 
   bool pending = false;
-  int sweep = 0;
+  int sweep = 0, sl = 1;
   for (; sweep < EVD_MAX_SWEEPS; ++sweep) {
     bool rotated = false;
     pending = false;
-    for (int step = 0; step < mmax - 1; ++step) {
-      // round-robin partner inside the graph's m columns (m even): i+j = step (mod m-1), the fixed point meets m-1
-      const bool active = j < m && step < mm1;
+    // round-robin partner inside the graph's m columns (m even): i+j = step (mod m-1), the fixed point meets m-1
+    auto partner = [&](int step, bool& active) {
+      active = j < m && step < mm1;
       int p = step - j;
       if (p < 0) p += mm1;
       if (p == j) p = mm1;
       if (j == mm1) p = (step & 1) ? (step + mm1) >> 1 : step >> 1;
       if (!active) p = j;
+      return p;
+    };
+    bool active_n;
+    int p_n = partner(0, active_n);
+    for (int step = 0; step < mmax - 1; ++step) {
+      const bool active = active_n;
+      const int p = p_n;
       const int pl = base + p;
-      EVD_ROWS(T[r] = bperm(pl, G[r]);)
       float al0 = 0.f, al1 = 0.f, ga0 = 0.f, ga1 = 0.f;
-      EVD_ROWS(if (q & 1) { al1 = fmaf(G[r], G[r], al1); ga1 = fmaf(G[r], T[r], ga1); }
-               else { al0 = fmaf(G[r], G[r], al0); ga0 = fmaf(G[r], T[r], ga0); })
-      const float alpha = al0 + al1, gamma = ga0 + ga1;
-      const float beta = bperm(pl, alpha);
+      EVD_ROWS(TG[i] = bperm(pl, G[i]);)
+      // under the partner rows' flight: my own column norm and the NEXT step's partner (neither needs them)
+      EVD_ROWS(if (i & 1) al1 = fmaf(G[i], G[i], al1); else al0 = fmaf(G[i], G[i], al0);)
+      p_n = partner(step + 1, active_n);
+      __builtin_amdgcn_sched_barrier(0);
+      EVD_ROWS(if (i & 1) ga1 = fmaf(G[i], TG[i], ga1); else ga0 = fmaf(G[i], TG[i], ga0);)
+      float alpha, gamma, beta;
+      meet(sl, al0 + al1, ga0 + ga1, pl, alpha, gamma, beta);
+      sl ^= 1;
       const bool first = j < p;
       const float lo = first ? alpha : beta, hi = first ? beta : alpha;     // norm^2 of the lower / the higher column
       const bool rot = active && gamma * gamma > (EVD_TOL * EVD_TOL) * (lo * hi) && fminf(lo, hi) > athr;
       if (__ballot(rot) == 0ull) continue;
+      EVD_ROWS(TV[i] = bperm(pl, V[i]);)          // (in flight under the rotation's parameters)
       rotated |= rot;
       pending |= rot && gamma * gamma > (EVD_NOCONV_TOL * EVD_NOCONV_TOL) * (lo * hi);
       float s = 0.f, tau = 0.f;
       if (rot) {
-        const float zeta = (hi - lo) * __builtin_amdgcn_rcpf(2.0f * gamma);
-        float t = __builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(fmaf(zeta, zeta, 1.0f)));
-        t = zeta < 0.f ? -t : t;
-        const float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
-        s = c * t;
+        // zeta = d / gamma, d = (hi - lo) / 2;  t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)),  c = 1 / sqrt(1 + t^2),  s = c t.  With
+        // R = sqrt(d^2 + gamma^2) and w = 1 / sqrt(2 R (R + |d|)):  c = (R + |d|) w,  s = sgn(d) gamma w  (1 + t^2 = 2 R / (R + |d|)):
+        // three dependent transcendentals (sqrt, rsq, rcp) instead of five on the step's critical path
+        const float d = 0.5f * (hi - lo);
+        const float R = __builtin_amdgcn_sqrtf(fmaf(d, d, gamma * gamma));
+        const float u = R + fabsf(d);
+        const float w = __builtin_amdgcn_rsqf(2.0f * R * u);
+        const float c = u * w;
+        s = (d < 0.f ? -gamma : gamma) * w;
         tau = s * __builtin_amdgcn_rcpf(1.0f + c);
         if (first) { s = -s; tau = -tau; }
       }
       // lower column: x - s (y + tau x);  higher column: x + s (y - tau x)   (signs folded into s, tau above)
-      EVD_ROWS(G[r] = fmaf(s, fmaf(-tau, G[r], T[r]), G[r]);)
-      EVD_ROWS(T[r] = bperm(pl, V[r]);)
-      EVD_ROWS(V[r] = fmaf(s, fmaf(-tau, V[r], T[r]), V[r]);)
+      EVD_ROWS(G[i] = fmaf(s, fmaf(-tau, G[i], TG[i]), G[i]);)
+      EVD_ROWS(V[i] = fmaf(s, fmaf(-tau, V[i], TV[i]), V[i]);)
     }
     if (__ballot(rotated) == 0ull) break;
   }
-  if (__ballot(pending) != 0ull && lane == 0) atomicOr(&a.status[0], EVD_ST_NOCONV);
-  if (lane == 0) atomicMax(&a.status[1], sweep + 1);          // most sweeps any wave needed (diagnostic)
+  if (wave == 0) {
+    if (__ballot(pending) != 0ull && lane == 0) atomicOr(&a.status[0], EVD_ST_NOCONV);
+    if (lane == 0) atomicMax(&a.status[1], sweep + 1);          // most sweeps any workgroup needed (diagnostic)
+  }
 
   // Rayleigh quotients, ascending rank (ties by column index), stores
   float lam = 0.f;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) lam = fmaf(V[r], G[r], lam);
+  for (int i = 0; i < RW; ++i) lam = fmaf(V[i], G[i], lam);
+  meet(sl, lam, 0.f, lane, lam, d0, d1);
   int rank = 0;
-#pragma unroll
-  for (int i = 0; i < NR; ++i) {
+  for (int i = 0; i < mmax; ++i) {
     const float li = bperm(base + i, lam);
     rank += (i < n && (li < lam || (li == lam && i < j))) ? 1 : 0;
   }
   if (!col) return;
-  a.val[n0 + rank] = lam;
+  if (wave == 0) a.val[n0 + rank] = lam;
 #pragma unroll
-  for (int r = 0; r < NR; ++r)
-    if (r < n) a.vec[off + (int64_t)r * n + rank] = V[r];
+  for (int i = 0; i < RW; ++i) {
+    const int r = wave + WV * i;
+    if (r < n) a.vec[off + (int64_t)r * n + rank] = V[i];
+  }
   if (a.pos_enc != nullptr) {
     const int c = rank - a.skip;
     if (c >= 0 && c < a.k) {
 #pragma unroll
-      for (int r = 0; r < NR; ++r)
-        if (r < n) a.pos_enc[(int64_t)(n0 + r) * a.k + c] = V[r];
+      for (int i = 0; i < RW; ++i) {
+        const int r = wave + WV * i;
+        if (r < n) a.pos_enc[(int64_t)(n0 + r) * a.k + c] = V[i];
+      }
     }
   }
-}
 #undef EVD_ROWS
+}
+
+template <int NR, int WV>
+__device__ __forceinline__ void evd_jacobi(const EvdArgs& a, const int32_t* cls_list, int count, int blk, float* lds) {
+  // the largest graph of this workgroup (workgroup-uniform: every wave reads the same class-list entries)
+  constexpr int GPW = 64 / NR;
+  int nmax = 0;
+  for (int q = 0; q < GPW; ++q) {
+    const int slot = blk * GPW + q;
+    if (slot < count) { const int g = cls_list[slot]; nmax = max(nmax, a.graph_ptr[g + 1] - a.graph_ptr[g]); }
+  }
+  nmax = __builtin_amdgcn_readfirstlane((nmax + 1) & ~1);
+  const int rows = (nmax + WV - 1) / WV;          // live rows per wave
+  constexpr int RMAX = NR / WV;
+  if constexpr (RMAX >= 16) {
+    if (rows > 14) return evd_jacobi_rows<NR, WV, 16>(a, cls_list, count, blk, lds);
+    if (rows > 12) return evd_jacobi_rows<NR, WV, 14>(a, cls_list, count, blk, lds);
+    if (rows > 10) return evd_jacobi_rows<NR, WV, 12>(a, cls_list, count, blk, lds);
+    if (rows > 8) return evd_jacobi_rows<NR, WV, 10>(a, cls_list, count, blk, lds);
+  }
+  if constexpr (RMAX >= 8) {
+    if (rows > 6) return evd_jacobi_rows<NR, WV, 8>(a, cls_list, count, blk, lds);
+    if (rows > 4) return evd_jacobi_rows<NR, WV, 6>(a, cls_list, count, blk, lds);
+  }
+  if constexpr (RMAX >= 4) {
+    if (rows > 2) return evd_jacobi_rows<NR, WV, 4>(a, cls_list, count, blk, lds);
+  }
+  return evd_jacobi_rows<NR, WV, (RMAX < 2 ? RMAX : 2)>(a, cls_list, count, blk, lds);
+}
 
 // one launch for the three size classes, largest first (their chains are the longest): block ranges from the class counts
-__global__ __launch_bounds__(64) void k_evd_jacobi(EvdArgs a, int B) {
+__global__ __launch_bounds__(64 * EVD_WV) void k_evd_jacobi(EvdArgs a, int B) {
+  __shared__ __align__(8) float lds[2 * EVD_WV * 64 * 2];
   const int c16 = a.cls_count[0], c32 = a.cls_count[1], c64 = a.cls_count[2];
   int b = blockIdx.x;
-  if (b < c64) return evd_jacobi<64>(a, a.cls_list + 2 * (int64_t)B, c64, b);
+  if (b < c64) return evd_jacobi<64, EVD_WV>(a, a.cls_list + 2 * (int64_t)B, c64, b, lds);
   b -= c64;
   const int b32 = (c32 + 1) >> 1;
-  if (b < b32) return evd_jacobi<32>(a, a.cls_list + B, c32, b);
+  if (b < b32) return evd_jacobi<32, EVD_WV>(a, a.cls_list + B, c32, b, lds);
   b -= b32;
-  if (b < ((c16 + 3) >> 2)) evd_jacobi<16>(a, a.cls_list, c16, b);
+  if (b < ((c16 + 3) >> 2)) evd_jacobi<16, EVD_WV>(a, a.cls_list, c16, b, lds);
 }
 
 }  // namespace
@@ -287,7 +367,8 @@ extern "C" int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const 
   SN_REQUIRE(norm == 0 || norm == 1, "sn_laplacian_evd_f32: norm must be 0 (None: D - A) or 1 ('sym'), got %d", norm);
   SN_REQUIRE(pos_enc == nullptr || (k > 0 && skip >= 0), "sn_laplacian_evd_f32: pos_enc needs k > 0, skip >= 0");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st);
+  hipError_t e = hipSuccess;
+  if (B == 0) e = hipMemsetAsync(status, 0, 4 * sizeof(int32_t), st);        // (otherwise k_evd_prep clears the status words)
   if (e == hipSuccess && total) e = hipMemsetAsync(eigen_vectors, 0, (size_t)total * sizeof(float), st);
   if (e == hipSuccess && pos_enc && N) e = hipMemsetAsync(pos_enc, 0, (size_t)N * k * sizeof(float), st);
   if (e != hipSuccess) return fail(SN_ERR_LAUNCH, "sn_laplacian_evd_f32: memset: %s", hipGetErrorString(e));
@@ -303,7 +384,7 @@ extern "C" int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const 
   }
   EvdArgs a{graph_ptr, evoff, cls_list, cls_count, eigen_values, eigen_vectors, pos_enc, status, total, norm, k, skip};
   // a + b + c = B graphs in the three classes need at most ceil(a/4) + ceil(b/2) + c <= B + 2 blocks
-  hipLaunchKernelGGL(k_evd_jacobi, dim3((unsigned)(B + 2)), dim3(64), 0, st, a, (int)B);
+  hipLaunchKernelGGL(k_evd_jacobi, dim3((unsigned)(B + 2)), dim3(64 * EVD_WV), 0, st, a, (int)B);
   SN_CHECK_LAUNCH("k_evd_jacobi");
   return SN_OK;
 }
