@@ -215,7 +215,35 @@ def evd_bench(args, dev):
             out["cpu_baseline"] = {"value": n_rep * len(sizes) / (time.perf_counter() - t0), "unit": "graphs/s", "cores": 1,
                                    "kind": "port", "sample": f"{n_rep} passes over the same batch, oracle/evd.py "
                                    "(numpy LAPACK ssyevd per graph, one thread, as a DataLoader worker runs the reference's transform)"}
+    out["device"] = device_block(dev)
     print(json.dumps(out))
+
+
+def device_block(dev):
+    """Which device ran this line and at what clock: name, CU count, the driver's nominal clock and the clock MEASURED under load
+    (sn_clock_probe: a wave counts 40 M shader cycles between two events, right behind ~50 ms of spinning that lets the part ramp) —
+    the boxes of a pool differ by up to 10 % on the same kernels; with this block a box effect is distinguishable from a kernel edit."""
+    import ctypes as C
+    from signnet_basisnet_amd._lib import check, lib, stream
+    cu, lds, khz = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(lib().sn_device_info(C.byref(cu), C.byref(lds), C.byref(khz)), "sn_device_info")
+    out = {"name": torch.cuda.get_device_name(dev), "cu_count": cu.value, "lds_bytes_per_cu": lds.value, "nominal_clock_mhz": khz.value / 1e3}
+    try:
+        buf = torch.zeros(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            check(lib().sn_clock_probe(120_000_000, buf.data_ptr(), stream()), "sn_clock_probe")       # ramp (~50 ms)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib().sn_clock_probe(40_000_000, buf.data_ptr(), stream()), "sn_clock_probe")
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        out["measured_clock_mhz"] = int(buf.item()) / ms / 1e3
+        out["probe"] = {"cycles": int(buf.item()), "ms": ms}
+    except Exception as e:            # (the probe is evidence, not part of the measurement)
+        out["measured_clock_mhz"] = None
+        out["probe_error"] = str(e)[:200]
+    return out
 
 
 def train_roofline(fwd_flops, dt):
@@ -302,7 +330,8 @@ def train_bench(args, dev, dist=None, rank=0, world=1):
         return
     per = {k: {"launches_per_step": v[0] / 3, "mean_us": 1e3 * v[1], "us_per_step": 1e3 * v[1] * v[0] / 3} for k, v in kt.items()}
     fl = algorithmic_flops(host, WORKLOAD["k"], WORKLOAD["hidden"], WORKLOAD["nl_signnet"], WORKLOAD["nl_rho"], WORKLOAD["nl_gnn"])
-    out = {"metric": "graphs/sec SignNet+GINE training step (forward + backward + Adam), ZINC batch=128 k=16", "unit": "graphs/s",
+    out = {"device": device_block(dev) if rank == 0 else None,
+           "metric": "graphs/sec SignNet+GINE training step (forward + backward + Adam), ZINC batch=128 k=16", "unit": "graphs/s",
            "value": WORKLOAD["B"] * world / dt, "ms_per_step": 1e3 * dt, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic", "vs_baseline": None, "final_loss": final_loss,
            "config": {"workload": WORKLOAD["name"] + ", train step", "gflop_per_step": 3 * fl["total"] / 1e9},
@@ -1089,7 +1118,9 @@ def main():
         # activity for an outside utilisation sampler to see
         sustained = None
         if args.sustained_ms is None:
-            args.sustained_ms = 0.0 if args.no_cpu_baseline else 1500.0
+            # >= 6 s: an outside utilisation sampler with 5 s spacing lands in it at least once (`gpu_busy` of the driver's record read 0
+            # for three rounds: the longest busy window of a run was 1.5 s)
+            args.sustained_ms = 0.0 if args.no_cpu_baseline else 6500.0
         if args.sustained_ms > 0 and world == 1:
             chunk, rates, n_fw = 200, [], 0
             sync_all()
@@ -1186,6 +1217,7 @@ def main():
                         "stream B -> GINE on the caller's stream, chained by events; consecutive forwards of the one call site overlap; "
                         "bit-identical outputs (round 3's `value`)"},
             "sustained": sustained,
+            "device": device_block(dev),
             "strict_mode": {"value": total_graphs / dt_strict, "unit": "graphs/s", "ms_per_step": 1e3 * dt_strict / args.steps,
                             "note": "the module's default: flags waited for after every forward (one host round trip per step); extra pass, not `value`"},
             "clock_ramp": {"ms": args.clock_ramp_ms, "extra_untimed_steps": ramp_steps,

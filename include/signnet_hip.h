@@ -38,6 +38,9 @@ int sn_version(void);
 const char* sn_last_error(void);
 /* number of compute units / XCDs of the current device (for grid sizing and roofline maths) */
 int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz);
+/* one wave spins for `cycles` shader cycles and writes the count it reached to out_cycles[0] (device memory): bracketed by events it
+ * measures the clock the device runs at (bench.py puts it in its line: a slower box is then distinguishable from a slower kernel) */
+int sn_clock_probe(int64_t cycles, int64_t* out_cycles, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batch plan.  Replaces: to_dense_EVD bookkeeping (Alchemy/sign_net/transform.py:26-38),

@@ -19,18 +19,49 @@ N_HEAD = 4         # sign_net.py:50 / core/sign_net.py:57  (TransformerEncoderLa
 
 
 # --------------------------------------------------------------------------- helpers
+# TERM_PROBE (tests only; None = off): the gradient of a ONE-ENTRY parameter (GIN / GINE eps, GINESignNetPyG's Linear(1, 1) and
+# BatchNorm1d(1)) is one sum over ~10^5 rows; its fp32 noise scales with the TERMS of that sum, not with the (cancelling) result.
+# With a dict here, every such parameter enters the arithmetic as a per-row copy of itself (same values, same result) whose .grad —
+# retained — is the vector of per-row terms: tests/test_training_gpu.py prices the one-entry gradients with eps32 * sqrt(sum t_r^2).
+TERM_PROBE = None
+
+
+def _rows_of(key, t, lead_shape):
+    """Per-row copy of the one-entry parameter `t` (shape lead_shape + (1,)); its gradient is kept for the probe."""
+    r = t.reshape(()).expand(tuple(lead_shape) + (1,)) * 1.0
+    if r.requires_grad:
+        r.retain_grad()
+        TERM_PROBE[key] = r
+    return r
+
+
+def _eps(sd, key, x):
+    e = sd[key]
+    if TERM_PROBE is not None and e.numel() == 1 and e.requires_grad:
+        return _rows_of(key, e, x.shape[:-1])
+    return e
+
+
 def _has(sd, key):
     return key in sd
 
 
 def _linear(sd, pfx, x):
     """nn.Linear with reference keys `<pfx>.weight` (+ `.bias` when registered)."""
-    return F.linear(x, sd[pfx + ".weight"], sd.get(pfx + ".bias"))
+    W = sd[pfx + ".weight"]
+    if TERM_PROBE is not None and W.numel() == 1 and W.requires_grad:
+        y = x * _rows_of(pfx + ".weight", W, x.shape[:-1])
+        b = sd.get(pfx + ".bias")
+        return y if b is None else y + _rows_of(pfx + ".bias", b, x.shape[:-1])
+    return F.linear(x, W, sd.get(pfx + ".bias"))
 
 
 def _bn_rows(sd, pfx, rows, training):
     """BatchNorm1d on [M, C] rows.  eval: running stats; train: batch stats (biased var),
     running stats NOT updated here (forward value only)."""
+    if training and TERM_PROBE is not None and rows.shape[-1] == 1 and sd[pfx + ".weight"].requires_grad:
+        xh = F.batch_norm(rows, None, None, None, None, True, 0.0, BN_EPS)
+        return xh * _rows_of(pfx + ".weight", sd[pfx + ".weight"], rows.shape[:-1]) + _rows_of(pfx + ".bias", sd[pfx + ".bias"], rows.shape[:-1])
     if training:
         return F.batch_norm(rows, None, None, sd[pfx + ".weight"], sd[pfx + ".bias"], True, 0.0, BN_EPS)
     return F.batch_norm(rows, sd[pfx + ".running_mean"], sd[pfx + ".running_var"],
@@ -133,7 +164,7 @@ def gnn3d(sd, pfx, x, edge_index, mask, nlayer, training, trace=None):
     m = mask.transpose(0, 1)
     prev = 0
     for l in range(nlayer):
-        a = gin_aggregate(x, edge_index, sd[f"{pfx}.convs.{l}.layer.eps"])   # masked_layers.py:75
+        a = gin_aggregate(x, edge_index, _eps(sd, f"{pfx}.convs.{l}.layer.eps", x))   # masked_layers.py:75
         h = masked_mlp(sd, f"{pfx}.convs.{l}.nn", a, m, 2, False, training)     # :83 / :79
         h = h.masked_fill(~m.unsqueeze(-1), 0.0)                               # sign_net.py:39
         h = masked_bn(sd, f"{pfx}.norms.{l}", h, m, training)
@@ -228,7 +259,7 @@ def gnn(sd, cfg, data, pe, training=False, out=None):
             e = discrete_encoder(sd, f"gnn.edge_encoders.{l}", ea)
         else:
             e = plain_mlp(sd, f"gnn.edge_encoders.{l}", ea, 1, True, training)
-        u = gine_aggregate(h, data.edge_index, e, sd[f"gnn.convs.{l}.layer.eps"])
+        u = gine_aggregate(h, data.edge_index, e, _eps(sd, f"gnn.convs.{l}.layer.eps", h))
         u = plain_mlp(sd, f"gnn.convs.{l}.nn", u, 2, False, training)
         u = torch.relu(_bn_rows(sd, f"gnn.norms.{l}", u, training))
         h = u + prev

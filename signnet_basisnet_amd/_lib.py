@@ -25,6 +25,7 @@ ABI_VERSION = 2          # = SN_ABI_VERSION of include/signnet_hip.h (struct lay
 SIGNATURES = {
     "sn_version": [],
     "sn_device_info": [C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "sn_clock_probe": [_l, _p, _p],
     "sn_batch_plan": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_batch_plan_ex": [_p, _l, _l, _p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "sn_batch_plan_early_supported": [_l, _l, _l],                # (returns 0 / 1, not a status)

@@ -1186,6 +1186,24 @@ extern "C" int sn_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_k
   return SN_OK;
 }
 
+// Clock probe: one wave spins for `cycles` shader cycles (s_memtime ticks = shader cycles) and reports what it counted; the caller
+// brackets the launch with events: cycles / elapsed = the clock the part actually runs at under this launch pattern (a bench line
+// that carries it lets a reader tell a slower BOX from a slower kernel).
+namespace sn { namespace {
+__global__ void k_clock_probe(long long cycles, long long* out) {
+  const long long t0 = clock64();
+  long long t = t0;
+  while (t - t0 < cycles) t = clock64();
+  if (threadIdx.x == 0) out[0] = t - t0;
+}
+} }
+extern "C" int sn_clock_probe(int64_t cycles, int64_t* out_cycles, void* stream) {
+  SN_REQUIRE(out_cycles && cycles > 0 && cycles <= (1ll << 34), "sn_clock_probe: bad arguments");
+  hipLaunchKernelGGL(sn::k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)cycles, reinterpret_cast<long long*>(out_cycles));
+  SN_CHECK_LAUNCH("sn_clock_probe");
+  return SN_OK;
+}
+
 extern "C" int64_t sn_packed_weight_floats(int d_out, int d_in) {
   return (int64_t)cdiv(d_out, 16) * cdiv(d_in, 16) * 256;
 }

@@ -454,13 +454,16 @@ class SignNetGNN(nn.Module):
     def _flags_bad(host):
         # layout: [status(8) | meta(8)]: status[0] plan errors, status[3] gnn flags, status[5] embedding index (layer path),
         # meta[1] phi, meta[5] rho bin errors
-        return bool(host[0] or host[3] or host[5] or host[9] or host[13])
+        return bool(host[0] or host[3] or host[5] or host[9] or host[13] or (host[SignNetGNN._KWORD] and host[1] > host[SignNetGNN._KWORD]))
 
     @staticmethod
     def _flags_error(host):
         """The exception an offending batch deserves (same types as the reference raises: IndexError from nn.Embedding)."""
         if (host[3] & 4) or host[5]:
             return IndexError(ops.EMBEDDING_INDEX_ERROR + " — the outputs of the affected graphs are NaN")
+        if host[SignNetGNN._KWORD] and host[1] > host[SignNetGNN._KWORD]:
+            return ValueError(f"the batch's host-side graph sizes (largest: {host[SignNetGNN._KWORD]}) disagree with its batch vector (largest graph: "
+                              f"{host[1]} nodes): eigenvector slots beyond the host-side count were dropped")
         if host[0]:
             return ValueError("an earlier batch was malformed (unsorted batch vector, graph id / edge endpoint out of range or an edge "
                               "across graphs): its outputs are NaN")
@@ -486,6 +489,18 @@ class SignNetGNN(nn.Module):
                 raise self._flags_error(host[1])
 
     _READY = 16          # word of the pinned buffer the GINE kernel sets to 1 after the 16 flags (sn_gnn_fused_f32)
+    _KWORD = 24          # word the HOST writes: the slot count an all-eigenvector forward sized its tensors with (0: max_k given)
+
+    def check_captured(self):
+        """After replaying a HIP graph that captured this module's forward: read the captured plan's status words (one host wait) and
+        raise what the eager forward would have raised for the batch of the LAST replay."""
+        plan = getattr(self, "_captured_plan", None)
+        if plan is None:
+            return
+        flags = plan.flags.cpu().tolist() + [0] * 16
+        flags[self._KWORD] = 0 if self.max_k else int(self._captured_K)
+        if self._flags_bad(flags):
+            raise self._flags_error(flags)
 
     @classmethod
     def _arrived(cls, ev, host):
@@ -546,10 +561,29 @@ class SignNetGNN(nn.Module):
             from . import dist as D
             n = -(-int(data.num_graphs) // MAX_FUSED_GRAPHS)
             return torch.cat([self.forward(D.shard_batch(data, i, n)) for i in range(n)], 0)
-        self.check_last(wait=False)
-        with _lib_mod.stream_scope():
-            y = self._forward(data, return_stages)
-        early, self._early = getattr(self, "_early", None), None
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.check_last(wait=False)
+        self._early = None            # (a report armed by a forward that raised must never be read as this batch's)
+        try:
+            with _lib_mod.stream_scope():
+                y = self._forward(data, return_stages)
+        except BaseException:
+            stale, self._early = self._early, None
+            if stale is not None:     # the plan kernel may still write to the pinned words: hand them back only once it has
+                try:
+                    stale.wait()
+                    stale.release()
+                except Exception:
+                    pass              # (left to the garbage collector: never recycled while a launch may write to it)
+            raise
+        early, self._early = self._early, None
+        if capturing:
+            # A forward being captured into a HIP graph never waits on the host — whatever `strict` says: the flags stay on the device
+            # (status words of the captured plan, rewritten by every replay); `check_captured()` reads them after a replay.
+            self._captured_plan, self._captured_K = self._last_plan, self._last_K
+            self._last_plan = None
+            return y
         if early is not None:
             # strict mode, flags from the plan kernel (already in pinned memory: the stage kernels were queued in the meantime)
             fl = early.wait()
@@ -569,12 +603,15 @@ class SignNetGNN(nn.Module):
                     self.use_fused, self._prep = saved, None
         elif self.use_fused and not return_stages and self._used_fused:
             ev, host = self._post_status(self._last_plan)
+            # all-eigenvector mode: the slot count came from host bookkeeping (data.sizes / ptr): the device's largest graph (status[1])
+            # is compared with it when the flags arrive — here, or in check_last() for a queued report
+            host[1][self._KWORD] = 0 if self.max_k else int(self._last_K)
             if self.strict:
                 self._wait_status(ev, host)
                 flags = host[1].tolist()
                 self._free_hosts.append(host)
                 if self._flags_bad(flags):
-                    if flags[0] or flags[5] or (flags[3] & 4):
+                    if flags[0] or flags[5] or (flags[3] & 4) or (flags[self._KWORD] and flags[1] > flags[self._KWORD]):
                         raise self._flags_error(flags)
                     saved, self.use_fused, self._prep = self.use_fused, False, None
                     try:
@@ -791,7 +828,7 @@ class SignNetGNN(nn.Module):
             t.record_stream(cur)
         x.record_stream(side_b)
         s.record_stream(cur)
-        self._last_plan, self._used_fused = plan, True
+        self._last_plan, self._used_fused, self._last_K = plan, True, K
         with _lib_mod.stream_scope():
             self._flags_host = self._host_flags() if (plan.bins is not None and not _NO_KERNEL_FLAGS) else None
             if self._flags_host is not None:

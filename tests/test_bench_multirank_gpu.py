@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, port):
-    env = dict(os.environ, SN_BENCH_BACKEND="gloo", SN_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"] + extra
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+def _run(extra, port, world=2):
+    env = dict(os.environ, SN_BENCH_BACKEND="gloo", SN_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "2"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE line
@@ -42,6 +42,25 @@ def test_forward_bench_two_ranks():
     g = d["distributed"]
     assert g["ranks_seen_by_backend"] == 2 and len(g["per_rank_ms_per_step"]) == 2 and g["graphs_per_rank"] == [128, 128]
     assert max(g["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-9) and len(g["devices"]) == 2 and g["allreduce_us"] > 0
+
+
+def test_forward_bench_eight_ranks():
+    """The driver's largest scaling point (N = 8, BASELINE configs[3]: 1 024 graphs as 8 x 128), launched exactly as the driver launches
+    it, on the one-GPU box: eight ranks share cuda:0 over gloo.  What an 8-GPU node cannot break silently afterwards: eight ranks seen
+    by the backend, eight clocks, eight shards of 128 graphs, a whole-job value over all of them, ONE line."""
+    d = _run(["--no-cpu-baseline", "--no-scatter", "--streams", "1", "--no-overlap", "--no-extras"], 29741, world=8)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 1024 and d["config"]["graphs_per_gpu"] == 128
+    g = d["distributed"]
+    assert g["world_size"] == 8 and g["ranks_seen_by_backend"] == 8 and g["data_path_collectives"] == 0
+    assert len(g["per_rank_ms_per_step"]) == 8 and g["graphs_per_rank"] == [128] * 8 and len(g["devices"]) == 8
+    assert max(g["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-9)
+    assert abs(d["value"] - 1024 * 4 / (d["ms_per_step"] * 4e-3)) <= 1e-6 * d["value"]
+
+
+def test_train_bench_eight_ranks_allreduces_the_flat_gradient():
+    d = _run(["--workload", "train", "--no-cpu-baseline", "--no-graph"], 29743, world=8)
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["distributed"]["world_size"] == 8
+    assert d["distributed"]["gradient_allreduce"] is not None
 
 
 def test_train_bench_two_ranks_allreduces_the_flat_gradient():

@@ -306,6 +306,64 @@ def test_all_eigenvector_slot_count_from_host_sizes_or_the_plan_report():
     with torch.no_grad():
         model(liar)                                                           # (graphs of > 23 nodes are dropped, nothing is touched outside the tensors)
     torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="disagree"):                         # ... and the serving mode says so when its flags arrive
+        model.check_last()                                                    # (round-5 advice: the late path compared nothing with K)
+    with torch.no_grad():
+        assert torch.equal(model(with_sizes), outs[0])
+    model.check_last()
+
+
+def test_forward_under_hip_graph_capture_never_waits_on_the_host():
+    """Round-5 advice: with strict=True (the default) a forward on a capturing stream spun on a pinned ready word no kernel was going to
+    write and then called torch.cuda.synchronize() — illegal during capture.  Now a capturing forward leaves the flags on the device
+    whatever `strict` says; `check_captured()` reads them after a replay."""
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    model = SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
+    assert model.strict
+    dd = synth.batch_to(synth.make_batch(6, seed=3), "cuda:0")
+    with torch.no_grad():
+        y_eager = model(dd).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            model(dd)                                  # warm-up on the capture's side stream (lazy one-time setup)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y_cap = model(dd)
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(y_cap, y_eager)
+    model.check_captured()
+    # a bad feature id written into the STATIC input buffer shows up in the captured plan's flags after the next replay
+    dd.x.add_(1000)
+    g.replay()
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        model.check_captured()
+    dd.x.sub_(1000)
+
+
+def test_a_forward_that_raises_leaves_no_stale_early_report():
+    """Round-5 advice: `_early` was armed inside _forward and consumed in forward() with no try / finally — a forward that raised
+    behind build_plan left the report of ITS batch on the module for a later forward to read."""
+    import types
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(0)
+    model = SignNetGNN(None, None, 32, 1, 2, 2, variant="gine", max_k=8).cuda().eval()
+    good = synth.batch_to(synth.make_batch(5, seed=8), "cuda:0")
+    with torch.no_grad():
+        y0 = model(good).clone()
+    bad = types.SimpleNamespace(**vars(good))
+    bad.x = good.x.float()                              # the GINE stage refuses float node ids — after the plan was queued and the report armed
+    with pytest.raises((ValueError, TypeError, RuntimeError)), torch.no_grad():
+        model(bad)
+    assert getattr(model, "_early", None) is None
+    with torch.no_grad():
+        assert torch.equal(model(good), y0)
     model.check_last()
 
 

@@ -47,13 +47,19 @@ def test_parameter_gradients_match_oracle_autograd(name):
     cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
     (y * cot.float().to(DEV)).sum().backward()
     sds, ys = {}, {}
+    tp = None
     for dt in (torch.float64, torch.float32):
         sd, odata = oracle_setup(fx, dt)
-        yo = O.signnet_gnn(sd, G.pyg_cfg(fx), odata, training=True)
-        (yo * cot.to(dt)).sum().backward()
+        if dt == torch.float64:
+            with term_probe() as tp:
+                yo = O.signnet_gnn(sd, G.pyg_cfg(fx), odata, training=True)
+                (yo * cot.to(dt)).sum().backward()
+        else:
+            yo = O.signnet_gnn(sd, G.pyg_cfg(fx), odata, training=True)
+            (yo * cot.to(dt)).sum().backward()
         sds[dt], ys[dt] = sd, yo.detach()
     PU.close(y, ys[torch.float32], "train-mode forward", ref64=ys[torch.float64])
-    _assert_gradient_population(model.named_parameters(), sds[torch.float32], sds[torch.float64], name, 40)
+    _assert_gradient_population(model.named_parameters(), sds[torch.float32], sds[torch.float64], name, 40, term_norms=tp.norms)
 
 
 def test_adam_training_steps_follow_the_oracle():
@@ -350,7 +356,26 @@ def test_flat_adam_over_rccl_world_size_one(tmp_path):
     assert out["buckets"] >= 3 and out["early"][0] == 0 and min(out["early"][1:]) >= out["buckets"] // 2, out
 
 
-def _assert_gradient_population(named_params, sd32, sd64, label, min_tensors):
+class term_probe:
+    """`with term_probe() as tp:` around the FLOAT64 oracle's forward + backward: tp.norms[name] = sqrt(sum_r t_r^2) of the per-row terms
+    t_r whose sum is the gradient of the one-entry parameter `name` (oracle.pyg_signnet.TERM_PROBE)."""
+
+    def __enter__(self):
+        from oracle import pyg_signnet as O
+        O.TERM_PROBE = {}
+        self.norms = {}
+        return self
+
+    def __exit__(self, *a):
+        from oracle import pyg_signnet as O
+        probe, O.TERM_PROBE = O.TERM_PROBE, None
+        for k, v in probe.items():
+            if v.grad is not None:
+                self.norms[k] = float(v.grad.double().pow(2).sum().sqrt())
+        return False
+
+
+def _assert_gradient_population(named_params, sd32, sd64, label, min_tensors, term_norms=None):
     """Every parameter gradient against the fp32 and the float64 oracle gradients.
     The fp32 oracle's OWN gradient sits 1e-3 ... 1e-2 (relative) from the float64 one as soon as there are tens of thousands of
     ReLU / BatchNorm decisions: a handful fall on the other side of zero in any fp32 evaluation, each moving a gradient entry by
@@ -375,8 +400,18 @@ def _assert_gradient_population(named_params, sd32, sd64, label, min_tensors):
         if s64 <= 1e-7 * gmax:        # a bias in front of a batch-statistics BatchNorm: exact gradient 0
             assert hip.abs().max().item() <= 1e-6 * gmax + 10 * a32.abs().max().item(), f"{pname}: gradient where the exact one is zero"
             continue
-        rows.append((pname, (hip - a64).abs().max().item() / s64, (a32 - a64).abs().max().item() / s64,
-                     (hip - a32).abs().max().item() / max(a32.abs().max().item(), 1e-300), hip.numel()))
+        # A ONE-ENTRY gradient (GIN / GINE eps, the Linear(1,1) / BatchNorm1d(1) of GINESignNetPyG's first phi layer) is one sum over up to
+        # ~10^5 rows, often a cancelling one: it has no largest entry to normalise by but itself, and |entry| says nothing about the size
+        # of what was summed.  Its scale is the root-sum-square of its per-row terms (sqrt(rows) x rms |term|: what the sum would be without
+        # cancellation), read off the float64 oracle (term_probe) — the absolute scale the round-4 / round-5 advice asked for.
+        tn = None
+        if term_norms is not None and hip.numel() <= 2:
+            for k in (pname, pname.replace(".nn.", ".layer.nn.", 1)):
+                if k in term_norms:
+                    tn = term_norms[k]
+        sc = s64 if tn is None else max(s64, tn)
+        rows.append((pname, (hip - a64).abs().max().item() / sc, (a32 - a64).abs().max().item() / sc,
+                     (hip - a32).abs().max().item() / max(a32.abs().max().item(), 1e-300), hip.numel(), None if tn is None else tn / s64))
     assert len(rows) >= min_tensors, len(rows)
     level = sorted(r[2] for r in rows)[int(0.9 * (len(rows) - 1))]
     ratios = sorted(r[1] / max(r[2], 1e-300) for r in rows if max(r[1], r[2]) > PU.REL)
@@ -384,13 +419,15 @@ def _assert_gradient_population(named_params, sd32, sd64, label, min_tensors):
     worst = max(rows, key=lambda r: r[1] / max(r[2], 1e-300))
     print(f"{label}: {len(rows)} parameter tensors, {len(ratios)} above 1e-5; fp32 oracle's own error level (90th pct) {level:.2e}; "
           f"median |hip-f64|/|cpu32-f64| {med:.2f}; worst ratio {worst[1] / max(worst[2], 1e-300):.1f} ({worst[1]:.2e} vs {worst[2]:.2e}) at {worst[0]}")
-    for pname, eh, ec, e32, numel in rows:
-        # (a tensor of one or two entries — the Linear(1,1) / BatchNorm1d(1) of GINESignNetPyG's first phi layer — has no largest entry to
-        #  normalise by but itself: its relative distance is the noise of ONE cancelling sum over ~10^5 rows, and it moved from 5 x to
-        #  8.1 x the level when the forward links went to the split-bf16 path, whose outputs are CLOSER to float64 than the fp32-MFMA ones
-        #  (rms 1.3e-7 against 2.0e-7, profiles/README.md round 4): 16 x for those, 8 x for every tensor with a population of entries)
-        factor = 16.0 if numel <= 2 else 8.0
-        assert e32 <= PU.REL or eh <= factor * max(ec, level) + PU.ATTR, (
+    for pname, eh, ec, e32, numel, tn in rows:
+        # Every tensor is held to the same factor: 8 x the larger of the reference's own distance on that tensor and its error level.
+        # (Rounds 4-5 allowed tensors of one or two entries 16 x: relative to the ENTRY, the BatchNorm1d(1) bias of the headline model sat
+        #  at 8.1 x the level — its terms are 9.6 x the entry; relative to the terms it sits below the level.  Roundoff alone — 2^-24 x
+        #  sqrt(sum t_r^2) — is 3-5 orders of magnitude below every distance measured here, the float32 oracle's included: what moves
+        #  these gradients are ReLU decisions that fall on the other side of zero in any fp32 evaluation, each worth one term.)
+        if tn is not None:
+            print(f"   one-entry {pname}: rss(terms) / |entry| = {tn:.3g}; against that scale |hip-f64| {eh:.2e}  |cpu32-f64| {ec:.2e}")
+        assert e32 <= PU.REL or eh <= 8.0 * max(ec, level) + PU.ATTR, (
             f"{pname}: |hip - cpu32| {e32:.2e}; |hip - f64| {eh:.2e} vs |cpu32 - f64| {ec:.2e} (oracle error level {level:.2e})")
     assert len(ratios) < 10 or med <= 2.0, med
 
@@ -433,14 +470,15 @@ def test_parameter_gradients_at_baseline_size_vs_oracle_fp32_and_fp64(name):
         (y * cot.to(dt)).sum().backward()
         return y.detach(), sd
 
-    y64, sd64 = oracle(torch.float64)
+    with term_probe() as tp:
+        y64, sd64 = oracle(torch.float64)
     y32, sd32 = oracle(torch.float32)
     m = m.cuda().train()
     y = m(synth.batch_to(data, DEV))
     assert y.requires_grad
     (y * cot.float().to(DEV)).sum().backward()
     PU_.close(y, y32, "train-mode forward at size", ref64=y64)
-    _assert_gradient_population(m.named_parameters(), sd32, sd64, name, 60)
+    _assert_gradient_population(m.named_parameters(), sd32, sd64, name, 60, term_norms=tp.norms)
 
 
 def test_graphed_step_replays_the_eager_training_step_bit_for_bit():
