@@ -561,7 +561,7 @@ class SignNetGNN(nn.Module):
             from . import dist as D
             n = -(-int(data.num_graphs) // MAX_FUSED_GRAPHS)
             return torch.cat([self.forward(D.shard_batch(data, i, n)) for i in range(n)], 0)
-        capturing = torch.cuda.is_current_stream_capturing()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()       # (no GPU: the first op raises 'GPU only')
         if not capturing:
             self.check_last(wait=False)
         self._early = None            # (a report armed by a forward that raised must never be read as this batch's)
