@@ -1,6 +1,7 @@
-"""Round-6 verdict item 7 (mixed batches): what would splitting a batch buy?  The layer-at-a-time path is a chain of ~100 launches whose
-cost hardly depends on the number of graphs; measured here: the layer path on 1 / 8 / 128 graphs, the fused path on 127 / 128 graphs, and
-the default (strict) module on 127 good graphs + one 70-node graph (today: the whole batch on the layer path).
+"""Round-6 verdict item 7 (mixed batches).  The layer-at-a-time path is a chain of ~100 launches: 0.6 ms for ONE graph, 1.2 ms for 128.
+Measured here: the layer path on 1 / 8 / 128 graphs, the fused path on the same batches, and the default (strict) module on 127 molecules +
+one 70-node graph — 3.67 ms until round 6 (the whole batch layer by layer, every weight re-packed on the way), 1.63 ms since (only the
+oversize graph layer by layer, `SignNetGNN._serve_beyond_limits`): bounded below by fused(127) + layer path(1) = 0.86 ms.
     gpurun -- python profiles/scripts/layer_path_vs_batch.py"""
 import json
 import os
@@ -42,6 +43,6 @@ sizes[64] = 70
 mixed = synth.batch_to(synth.make_batch(128, seed=1236, sizes=sizes), dev)
 model.strict, model.use_fused, model._prep = True, True, None
 out["strict_mixed_127_plus_one_70_node_graph_ms"] = timed(lambda: model(mixed), n=20, w=5)
-out["note"] = ("splitting the mixed batch into (good graphs: fused) + (oversize graph: layer path) would cost fused_B128 + layer_path_B1; "
-               "the layer path is launch-bound, so that sum is not below what the whole batch costs on the layer path today")
+out["note"] = ("the mixed batch = the refused whole-batch attempt + two fused runs of the graphs around the oversize one + that graph layer by layer "
+               "+ the host-side slicing (per-graph node / in-edge counts read back, boolean edge masks)")
 print(json.dumps(out))

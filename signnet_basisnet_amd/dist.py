@@ -58,6 +58,14 @@ def shard_batch(data, rank: int, world: int, balance: str = "count", max_k=None)
         lo, hi = shard_range(B, rank, world)
     else:
         raise ValueError("balance must be 'count' or 'rows'")
+    return slice_graphs(data, lo, hi, sizes)
+
+
+def slice_graphs(data, lo: int, hi: int, sizes=None):
+    """The graphs [lo, hi) of a collated batch as a batch of their own (node / edge ids re-based): pure indexing."""
+    B = int(data.num_graphs)
+    if sizes is None:
+        sizes = list(data.sizes) if hasattr(data, "sizes") else torch.bincount(data.batch, minlength=B).tolist()
     nstart = sum(sizes[:lo])
     nend = nstart + sum(sizes[lo:hi])
     vstart = sum(s * s for s in sizes[:lo])

@@ -196,7 +196,19 @@ def test_oversize_graph_is_flagged_and_served_by_the_layer_path():
     model = model.cuda().eval()
     dd = synth.batch_to(data, "cuda:0")
     assert model.strict, "the safe mode is the default: every input the reference evaluates is evaluated"
-    close(model(dd), yref, "strict mode (layer-path fallback)")
+    y_mixed = model(dd)
+    close(y_mixed, yref, "strict mode (layer-path fallback)")
+    # round 6: only the oversize graph goes layer by layer — the rows of the graphs around it are the stage kernels' bits
+    good = synth.batch_to(synth.make_batch(3, seed=4, sizes=[10, 70, 12]), "cuda:0")
+    from signnet_basisnet_amd import dist as D
+    y_first, y_last = model(D.slice_graphs(good, 0, 1)), model(D.slice_graphs(good, 2, 3))
+    assert torch.equal(y_mixed[0:1], y_first) and torch.equal(y_mixed[2:3], y_last)
+    model.use_fused = False
+    model._prep = None
+    y_layer = model(dd)
+    model.use_fused = True
+    model._prep = None
+    assert torch.equal(y_mixed[1:2], y_layer[1:2]) and not torch.equal(y_mixed[0:1], y_layer[0:1])
     model.strict = False                        # the serving mode: no host wait
     y = model(dd)                               # flags raised on the device, reported late ...
     torch.cuda.synchronize()
