@@ -39,6 +39,8 @@ class GraphedStep:
             optimizer.disable_overlap()
         if not getattr(model, "max_k", None):
             raise ValueError("GraphedStep: the number of eigenvector slots must be fixed (max_k): the all-eigenvector mode sizes tensors from the batch")
+        from . import train_stage
+        train_stage.flush_deferred()          # (nothing of an earlier eager backward may be left for the captured one to reduce)
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.data, self.target = data, target
         self.shapes = {f: tuple(getattr(data, f).shape) for f in _FIELDS}

@@ -102,6 +102,7 @@ class _Deferred:
     jobs = []            # (partials tensor [kept alive], byte offset, nparts, stride, n, out tensor)
     outs = set()
     armed = False
+    task = -1            # autograd graph-task id of the backward pass the callback was queued in
 
 
 def _defer_reduce(part, off_floats, nparts, stride, n, out):
@@ -110,12 +111,18 @@ def _defer_reduce(part, off_floats, nparts, stride, n, out):
         flush_deferred()
     _Deferred.jobs.append((part, off_floats, nparts, stride, n, out))
     _Deferred.outs.add(key)
-    if not _Deferred.armed:
-        try:        # at the end of the running backward pass (on the caller's stream, inside a HIP-graph capture too)
+    # one end-of-backward callback per BACKWARD PASS (autograd's graph-task id): a pass that raised before its callback ran must not leave
+    # the next one without (a callback that finds nothing queued does nothing)
+    task = _graph_task_id()
+    if not _Deferred.armed or task != _Deferred.task:
+        try:        # runs on the caller's stream, inside a HIP-graph capture too
             torch.autograd.Variable._execution_engine.queue_callback(flush_deferred)
-            _Deferred.armed = True
+            _Deferred.armed, _Deferred.task = True, task
         except RuntimeError:        # not inside a backward pass (a direct call of linear_bwd): reduce now
             flush_deferred()
+
+
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)
 
 
 def flush_deferred():
