@@ -742,19 +742,40 @@ __global__ __launch_bounds__(256) void k_tbn_finish(const float* __restrict__ st
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   const int per = (nblk + 15) / 16, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  // (round 6: the kernel is nothing but latency — 6.9-7.6 us in the trace, 20 launches a step.  The column's affine parameters and running
+  //  statistics are requested up front instead of behind the merge tree, and a lane's <= 16 partials of a group in ONE round trip from
+  //  clamped addresses — straight-line loads, the count of a slot past the slice reads as 0 — instead of 8 + 4 behind a predicate each.)
+  const bool fin = rl == 0 && c < C;
+  float g_c = 1.f, be_c = 0.f, rm_c = 0.f, rv_c = 0.f;
+  if (fin) {
+    if (gamma) g_c = gamma[c];
+    if (beta) be_c = beta[c];
+    if (rmean) { rm_c = rmean[c]; rv_c = rvar[c]; }
+  }
   for (int grp = 0; grp < G; ++grp) {
     const float* sg = stat + (int64_t)grp * (2 * (int64_t)nblk * C + nblk);
     float n = 0.f, m = 0.f, q = 0.f;
-    if (c < C) {
-      for (int b = b0; b < b1; b += 8) {        // eight partials in flight (one at a time: a chain of L2 round trips per column)
-        float nb[8], mb[8], qb[8];
+    if (c < C && b0 < b1) {
+      if (per <= 16) {
+        float nb[16], mb[16], qb[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
-          if (b + u < b1) { nb[u] = sg[2 * (int64_t)nblk * C + b + u]; mb[u] = sg[(int64_t)(b + u) * C + c]; qb[u] = sg[((int64_t)nblk + b + u) * C + c]; }
+        for (int u = 0; u < 16; ++u) {
+          const int b = b0 + u < b1 ? b0 + u : b1 - 1;
+          nb[u] = sg[2 * (int64_t)nblk * C + b]; mb[u] = sg[(int64_t)b * C + c]; qb[u] = sg[((int64_t)nblk + b) * C + c];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) chan(n, m, q, nb[u], mb[u], qb[u]);
+        for (int u = 0; u < 16; ++u) chan(n, m, q, b0 + u < b1 ? nb[u] : 0.f, mb[u], qb[u]);
+      } else {
+        for (int b = b0; b < b1; b += 8) {        // eight partials in flight (one at a time: a chain of L2 round trips per column)
+          float nb[8], mb[8], qb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            nb[u] = 0.f; mb[u] = 0.f; qb[u] = 0.f;
+            if (b + u < b1) { nb[u] = sg[2 * (int64_t)nblk * C + b + u]; mb[u] = sg[(int64_t)(b + u) * C + c]; qb[u] = sg[((int64_t)nblk + b + u) * C + c]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) chan(n, m, q, nb[u], mb[u], qb[u]);
+        }
       }
     }
     ln[rl][cl] = n; lm[rl][cl] = m; lq[rl][cl] = q;
@@ -766,22 +787,23 @@ __global__ __launch_bounds__(256) void k_tbn_finish(const float* __restrict__ st
       }
       __syncthreads();
     }
-    if (rl == 0 && c < C) {
+    if (fin) {
       const float v = n > 0.f ? q / n : 0.f;
       const float rs = 1.0f / sqrtf(v + eps);
-      const float sc = (gamma ? gamma[c] : 1.f) * rs;
+      const float sc = g_c * rs;
       float* s = st + (int64_t)grp * C;               // st[component][grp][C]: every component is one contiguous [G][C] block
       const int64_t GC = (int64_t)G * C;
-      s[c] = m; s[GC + c] = v; s[2 * GC + c] = rs; s[3 * GC + c] = sc; s[4 * GC + c] = (beta ? beta[c] : 0.f) - m * sc;
+      s[c] = m; s[GC + c] = v; s[2 * GC + c] = rs; s[3 * GC + c] = sc; s[4 * GC + c] = be_c - m * sc;
       if (c == 0) cnt[grp] = n;
-      if (rmean) {
+      if (rmean) {                                    // group order: two sequential calls of the module
         const float unb = n > 1.f ? v * (n / (n - 1.f)) : v;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        rm_c = (1.f - momentum) * rm_c + momentum * m;
+        rv_c = (1.f - momentum) * rv_c + momentum * unb;
       }
     }
     __syncthreads();
   }
+  if (fin && rmean) { rmean[c] = rm_c; rvar[c] = rv_c; }
 }
 
 // ============================================================================ backward link
@@ -1332,25 +1354,42 @@ __device__ __forceinline__ void tbn_bwd_finish_block(int bid, int tid, const flo
                                                         const float* __restrict__ cnt, const float* __restrict__ gamma, float* __restrict__ coef,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
   // 16 columns x 16 lanes per block: a lane adds its slice of the block partials in order, then a fixed pairwise tree
+  // (round 6: the group's statistics / count / gamma requested with the partials instead of behind the tree, and a lane's <= 16
+  //  partials in one round trip from clamped addresses: see k_tbn_finish)
   __shared__ float l1[16][17], l2[16][17];
   const int cl = tid & 15, rl = tid >> 4;
   const int c = bid * 16 + cl;
   const int per = (nblk + 15) / 16, b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   const int64_t GC = (int64_t)G * C;
+  const bool fin = rl == 0 && c < C;
+  const float g_c = (fin && gamma) ? gamma[c] : 1.f;
   float dg = 0.f, db = 0.f;
   for (int grp = 0; grp < G; ++grp) {
     const float* S = sums + (int64_t)grp * nblk * 2 * C;
+    float mu = 0.f, rs = 0.f, n = 0.f;
+    if (fin) { const float* s = st + (int64_t)grp * C; mu = s[c]; rs = s[2 * GC + c]; n = cnt[grp]; }
     float s1 = 0.f, s2 = 0.f;
-    if (c < C) {
-      for (int b = b0; b < b1; b += 8) {        // eight partials in flight
-        float v1[8], v2[8];
+    if (c < C && b0 < b1) {
+      if (per <= 16) {
+        float v1[16], v2[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          v1[u] = 0.f; v2[u] = 0.f;
-          if (b + u < b1) { v1[u] = S[(int64_t)(b + u) * 2 * C + c]; v2[u] = S[(int64_t)(b + u) * 2 * C + C + c]; }
+        for (int u = 0; u < 16; ++u) {
+          const int b = b0 + u < b1 ? b0 + u : b1 - 1;
+          v1[u] = S[(int64_t)b * 2 * C + c]; v2[u] = S[(int64_t)b * 2 * C + C + c];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
+        for (int u = 0; u < 16; ++u) { s1 += b0 + u < b1 ? v1[u] : 0.f; s2 += b0 + u < b1 ? v2[u] : 0.f; }
+      } else {
+        for (int b = b0; b < b1; b += 8) {        // eight partials in flight
+          float v1[8], v2[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v1[u] = 0.f; v2[u] = 0.f;
+            if (b + u < b1) { v1[u] = S[(int64_t)(b + u) * 2 * C + c]; v2[u] = S[(int64_t)(b + u) * 2 * C + C + c]; }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
+        }
       }
     }
     l1[rl][cl] = s1; l2[rl][cl] = s2;
@@ -1362,10 +1401,8 @@ __device__ __forceinline__ void tbn_bwd_finish_block(int bid, int tid, const flo
       }
       __syncthreads();
     }
-    if (rl == 0 && c < C) {
-      const float* s = st + (int64_t)grp * C;
-      const float mu = s[c], rs = s[2 * GC + c], n = cnt[grp];
-      const float A = (gamma ? gamma[c] : 1.f) * rs;
+    if (fin) {
+      const float A = g_c * rs;
       const float m1 = n > 0.f ? s1 / n : 0.f, m2 = n > 0.f ? rs * s2 / n : 0.f;
       float* o = coef + (int64_t)grp * C;              // coef[0..2][grp][C]
       o[c] = A;
@@ -1376,7 +1413,7 @@ __device__ __forceinline__ void tbn_bwd_finish_block(int bid, int tid, const flo
     }
     __syncthreads();
   }
-  if (rl == 0 && c < C) {
+  if (fin) {
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + dg;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + db;
   }
