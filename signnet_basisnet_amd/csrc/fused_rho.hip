@@ -103,22 +103,28 @@ __device__ __forceinline__ float tile_rowsum(float v) {
 // ONE: exactly one encoder layer without eigenvalue encoding (GINESignNetPyG: nl_rho is ignored, 1 layer).  The layer's
 // input rows are then still in the input buffer when the residual needs them, so they are not kept in registers across
 // the q / k / v projections and the attention but re-read right before the output projection.
-template <int NT, bool REGATTN, bool ONE, bool HP = false>
+// NW (round 6; REGATTN only): waves per workgroup = nodes per bin.  The hypothesis: rho is bound by its weight stream — a layer is six
+// split-packed [d, d] matrices = 720 KB of LDS-DMA per bin at d = 128, two 4-wave workgroups per CU = two streams; the register-attention
+// variants keep their rows in registers, so ONE 8-wave workgroup per CU could hold the same 8 nodes behind ONE stream.  Built (NW = 8),
+// bit-identical outputs, and measured SLOWER (61.5 -> 72.9 us on the headline batch): see rho_eight_waves() below.  Default: 4.
+template <int NT, bool REGATTN, bool ONE, bool HP = false, int NW = 4>
 // (the LDS-attention variants hold two 64-row images beside the weight ring: one workgroup per CU fits, so they may use the whole
 //  register file of a SIMD — 512 registers per lane, no private segment)
-__global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStruct S, sn_rho_params P) {
+__global__ __launch_bounds__(64 * NW, REGATTN ? 2 : 1) void k_rho_fused(RhoStruct S, sn_rho_params P) {
+  static_assert(NW == 4 || (NW == 8 && REGATTN), "eight waves: the register-attention variants only (no 64-row LDS images)");
+  constexpr int NTHR = 64 * NW;
   constexpr int D = 16 * NT;
   constexpr int LD = D + 4;
   constexpr int DKMAX = (D + 3) / 4;   // heads = 4: dk <= D/4
   constexpr int NKB = (NT + 1) / 2;
-  using Ring = WRing<NT>;
+  using Ring = WRing<NT, NW>;
   extern __shared__ __align__(1024) unsigned char lds_raw[];
   float* A = reinterpret_cast<float*>(lds_raw + Ring::BYTES);   // [RHO_R][LD]   q, then v          (LDS attention path only)
   float* Bm = A + RHO_R * LD;                                     // [RHO_R][LD]   k, then the attention output / slot-sum image
   __shared__ int s_graph;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = wave * 16 + (lane & 15), g = lane >> 4, li = lane & 15;
-  const int nbins = REGATTN ? (S.N + 3) >> 2 : S.meta[4];
+  const int nbins = REGATTN ? (S.N + NW - 1) / NW : S.meta[4];
   const int d = P.d, H = P.heads, dk = d / H;
   // Round 5: the start of a workgroup used to be six dependent memory round trips (error word -> LayerNorm vectors -> first weight
   // chunk -> node's graph -> its node range -> the rows), ~1 us each, in front of the first MFMA of a kernel of two bins per
@@ -180,9 +186,9 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
     // issue), graph id -> node range (the only dependent load).  Straight-line code: behind a branch the compiler can no longer count
     // the loads in flight and waits for all of them (vmcnt(0): the whole ring) before the first use of any.
     if (nbins <= (int)blockIdx.x) return;      // (a workgroup without a bin: nothing requested yet)
-    const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+    const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NW + wave);
     fetch_rows(node0);
-    static_assert(4 * (D / 4) <= RHO_R * 4, "one float4 per thread covers the four vectors");
+    static_assert(4 * (D / 4) <= NTHR, "one float4 per thread covers the four vectors");
     const int li4 = (int)threadIdx.x < 4 * (D / 4) ? (int)threadIdx.x : 0;
     const sn_rho_layer& L0 = P.layers[0];
     const float *p0 = L0.ln1_g, *p1 = L0.ln1_b, *p2 = L0.ln2_g, *p3 = L0.ln2_b;
@@ -209,14 +215,14 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
   } else {
     if constexpr (EARLY) {
       if (nbins > (int)blockIdx.x) {
-        const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+        const int node0 = __builtin_amdgcn_readfirstlane((int)blockIdx.x * NW + wave);
         fetch_rows(node0);
         fetch_graph(node0);
       }
     } else {
       if (err != 0) return;
     }
-    for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += RHO_R * 4) {
+    for (int i = threadIdx.x; i < P.n_layers * 4 * D; i += NTHR) {
       const int l = i / (4 * D), v = (i / D) & 3, c = i % D;
       const sn_rho_layer& Lq = P.layers[l];
       const float* src = v == 0 ? Lq.ln1_g : (v == 1 ? Lq.ln1_b : (v == 2 ? Lq.ln2_g : Lq.ln2_b));
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       // mixed freely — ceil(N/4) bins instead of sum_g ceil(n_g/4) (6 % fewer on ZINC sizes), no bin -> graph search
       q = wave;
       slot = lane & 15;
-      node = __builtin_amdgcn_readfirstlane(bin * 4 + wave);
+      node = __builtin_amdgcn_readfirstlane(bin * NW + wave);
       unit_ok = node < S.N;
       if constexpr (EARLY) {
         gs = pf_gs;                                                  // (read at the end of the previous bin / at the kernel's start)
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       u0 = q * 16;
     } else {
       __syncthreads();
-      for (int gq = threadIdx.x; gq < S.B; gq += RHO_R * 4)
+      for (int gq = threadIdx.x; gq < S.B; gq += NTHR)
         if (S.rho_bin0[gq] <= bin && bin < S.rho_bin0[gq + 1]) s_graph = gq;
       __syncthreads();
       const int gi = s_graph;
@@ -336,10 +342,10 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         // then v (swapped operands: V[key = 4g+r][c = 16ot + li]) with O^T = V^T.P^T in its epilogue (v is never stored).
         constexpr int CPH = NT / 4 > 0 ? NT / 4 : 1;   // 16-channel chunks per head
         f32x4 qf[NT], sc[4];
-        wg_gemm_split<NT, NT, false, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc * rtemp; });   // q / sqrt(dk)  (:52), as a multiply by the rounded reciprocal (<= 1 ulp)
+        wg_gemm_split<NT, NT, false, false, NW>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { qf[ot] = acc * rtemp; });   // q / sqrt(dk)  (:52), as a multiply by the rounded reciprocal (<= 1 ulp)
 #pragma unroll
         for (int h = 0; h < 4; ++h) sc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
-        wg_gemm_split<NT, NT, false, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 kf, f32x4, f32x4, f32x4, f32x4) {
+        wg_gemm_split<NT, NT, false, false, NW>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 kf, f32x4, f32x4, f32x4, f32x4) {
           // lane (query = li, g) accumulates S[query][key = 4g + r] of head ot / CPH
           const int h = ot / CPH < 4 ? ot / CPH : 3;
           sc[h] = mfma16(kf[0], qf[ot][0], sc[h]);
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
           }
         }
         SN_STAMP(4);
-        wg_gemm_split<NT, NT, true, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 vt, f32x4, f32x4, f32x4, f32x4) {
+        wg_gemm_split<NT, NT, true, false, NW>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 vt, f32x4, f32x4, f32x4, f32x4) {
           // O^T[c][query] = sum_key V[key][c] P[query][key]  -> lane (query, g) holds O[query][16*ot + 4g + r]
           const int h = ot / CPH < 4 ? ot / CPH : 3;
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         });
       } else {
         // ======== attention through LDS (nodes of more than 16 slots span several waves' tiles) ========
-        wg_gemm_split<NT, NT, false, false>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
-        wg_gemm_split<NT, NT, false, false>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false, false, NW>(ring, Lp.wq, Lp.wk, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false, false, NW>(ring, Lp.wk, Lp.wv, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Br + 16 * ot + 4 * g, acc); });
         lds_barrier();
         float qh[DKMAX];
         const int hc = g * dk;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
 #pragma unroll
         for (int c = 0; c < DKMAX; ++c) qh[c] = (c < dk && wave_live) ? Ar[hc + c] / temp : 0.f;
         // (q rows are written and read by the same wave only: no barrier before A is reused for v)
-        wg_gemm_split<NT, NT, false, false>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
+        wg_gemm_split<NT, NT, false, false, NW>(ring, Lp.wv, Lp.wfc, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { lds_st4(Ar + 16 * ot + 4 * g, acc); });
         lds_barrier();
         {
         float m = -INFINITY;
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       // fc(o) + x -> LayerNorm                                      (transformer_module.py:99-101)
       if (wave_live) split_rows<NT>(o, sp);
       if (ONE) load_x();   // the residual operand, straight from the input buffer (see ONE above)
-      wg_gemm_split<NT, NT, false, false>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
+      wg_gemm_split<NT, NT, false, false, NW>(ring, Lp.wfc, Lp.w1, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4, f32x4, f32x4, f32x4) { x[ot] = acc + x[ot]; });   // residual in place: one row array for the whole layer
       SN_STAMP(6);
       if (wave_live) {
         int gl = g;
@@ -496,14 +502,14 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
       }
       SN_STAMP(7);
       // FFN: w2(relu(w1 y + b1)) + b2 + y -> LayerNorm               (transformer_module.py:113-127)
-      wg_gemm_split<NT, NT, false>(ring, Lp.w1, Lp.w2, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
+      wg_gemm_split<NT, NT, false, true, NW>(ring, Lp.w1, Lp.w2, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b1, f32x4, f32x4, f32x4) { o[ot] = relu4(acc + b1); });
       SN_STAMP(8);
       if (wave_live) split_rows<NT>(o, sp);
 #ifdef SN_PROFILE
       asm volatile("" :: "v"(sp[0].h), "v"(sp[NKB - 1].l));
 #endif
       SN_STAMP(14);
-      wg_gemm_split<NT, NT, false>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + x[ot]; });
+      wg_gemm_split<NT, NT, false, true, NW>(ring, Lp.w2, wafter, wave_live, sp, NoPre(), [&](int ot, f32x4 acc, f32x4 b2, f32x4, f32x4, f32x4) { x[ot] = acc + b2 + x[ot]; });
       SN_STAMP(9);
       if (wave_live) {
         int gl = g;
@@ -528,7 +534,7 @@ __global__ __launch_bounds__(RHO_R * 4, REGATTN ? 2 : 1) void k_rho_fused(RhoStr
         }
       }
       if (EARLY && bin + (int)gridDim.x < nbins) {                       // the next bin's rows and node range
-        const int nnode = __builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * 4 + wave);
+        const int nnode = __builtin_amdgcn_readfirstlane((bin + (int)gridDim.x) * NW + wave);
         fetch_rows(nnode);
         fetch_graph(nnode);
       }
@@ -868,36 +874,55 @@ static int launch_rho_wide(const RhoStruct& S, const sn_rho_params& P, int64_t b
   return SN_OK;
 }
 
-template <int NT, bool REGATTN, bool ONE, bool HP = false>
+template <int NT, bool REGATTN, bool ONE, bool HP = false, int NW = 4>
 static int launch_rho(const RhoStruct& S, const sn_rho_params& P, int64_t bins_bound, hipStream_t st) {
   constexpr int LD = 16 * NT + 4;
   // (the LayerNorm vectors of the layers the net HAS, not of SN_RHO_MAX_LAYERS: 47 KB instead of 61 for the register-attention variant
   //  of a one-layer net — LDS the overlap mode's co-resident kernels can use)
-  const size_t lds_fixed = (size_t)WRing<NT>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float));
+  const size_t lds_fixed = (size_t)WRing<NT, NW>::BYTES + (REGATTN ? 0 : (size_t)(2 * RHO_R * LD) * sizeof(float));
   const size_t lds_max = lds_fixed + (size_t)SN_RHO_MAX_LAYERS * 4 * 16 * NT * sizeof(float);
   const size_t lds = lds_fixed + (size_t)(P.n_layers > 0 ? P.n_layers : 1) * 4 * 16 * NT * sizeof(float);
   static int cus = 0;
   if (cus == 0) {
     if (lds_max > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN, ONE, HP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_rho_fused<NT, REGATTN, ONE, HP, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_max) != hipSuccess)
       return fail(SN_ERR_LAUNCH, "sn_rho_fused_f32: cannot raise the dynamic LDS limit to %zu", lds_max);
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     cus = n > 0 ? n : 256;
   }
-  // (two workgroups per CU: with the 47 KB of a one-layer net three or four fit, measured 61.5 against 60.6 us — no gain)
-  int64_t grid = bins_bound < (int64_t)2 * cus ? bins_bound : (int64_t)2 * cus;
+  // eight waves per CU either way: two 4-wave workgroups (two weight streams), or one 8-wave workgroup (one stream)
+  // (4 waves, two workgroups per CU: with the 47 KB of a one-layer net three or four fit, measured 61.5 against 60.6 us — no gain)
+  const int64_t per_cu = NW == 8 ? 1 : 2;
+  int64_t grid = bins_bound < per_cu * cus ? bins_bound : per_cu * cus;
 #ifdef SN_RHO_GRID1
   grid = cus;
 #endif
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN, ONE, HP>), dim3((unsigned)grid), dim3(RHO_R * 4), lds, st, S, P);
+  hipLaunchKernelGGL((k_rho_fused<NT, REGATTN, ONE, HP, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, st, S, P);
   return SN_OK;
+}
+
+// (A/B switch of the profile scripts: SN_RHO_WAVES=8 in the environment puts the register-attention variants of the common widths on
+//  8-wave workgroups.  MEASURED SLOWER and therefore off by default — profiles/scripts/ab_env.sh, one box, alternating: headline rho
+//  61.5 -> 72.9 us, Alchemy 203.7 -> 246.8, hidden 64 16.6 -> 19.8: the stream is not what bounds rho; eight waves meeting at every
+//  chunk barrier cost more than the second stream they save.)
+static bool rho_eight_waves() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SN_RHO_WAVES"); v = (e && e[0] == '8') ? 1 : 0; }
+  return v == 1;
 }
 
 template <bool REGATTN, bool ONE>
 static int dispatch_rho(int nt, const RhoStruct& S, const sn_rho_params& P, int64_t bound, hipStream_t st) {
+  if constexpr (REGATTN) {
+    // the common widths on 8-wave workgroups (one weight stream per CU)
+    if (rho_eight_waves()) {
+      if (nt == 8) return launch_rho<8, true, ONE, false, 8>(S, P, bound, st);
+      if (nt == 4) return launch_rho<4, true, ONE, false, 8>(S, P, bound, st);
+    }
+  }
   switch (nt) {
     case 1: return launch_rho<1, REGATTN, ONE>(S, P, bound, st);
     case 2: return launch_rho<2, REGATTN, ONE>(S, P, bound, st);
@@ -951,7 +976,10 @@ extern "C" int sn_rho_fused_f32(const sn_rho_params* params, const float* x, con
     // attention applies to any d; all weights / vectors are zero-padded to heads*head_pad channels by the caller
     SN_REQUIRE((P.head_pad == 16 || P.head_pad == 32) && P.head_pad >= P.d / P.heads,
                "sn_rho_fused_f32: head_pad must be 16 or 32 and >= d/heads (got %d for d=%d)", P.head_pad, P.d);
-    if (P.head_pad == 16) rc = one ? launch_rho<4, true, true, true>(S, P, bound, st) : launch_rho<4, true, false, true>(S, P, bound, st);
+    if (rho_eight_waves()) {
+      if (P.head_pad == 16) rc = one ? launch_rho<4, true, true, true, 8>(S, P, bound, st) : launch_rho<4, true, false, true, 8>(S, P, bound, st);
+      else rc = one ? launch_rho<8, true, true, true, 8>(S, P, bound, st) : launch_rho<8, true, false, true, 8>(S, P, bound, st);
+    } else if (P.head_pad == 16) rc = one ? launch_rho<4, true, true, true>(S, P, bound, st) : launch_rho<4, true, false, true>(S, P, bound, st);
     else rc = one ? launch_rho<8, true, true, true>(S, P, bound, st) : launch_rho<8, true, false, true>(S, P, bound, st);
   } else {
     SN_REQUIRE(P.head_pad == 0, "sn_rho_fused_f32: head-padded parameters need <= 16 slots per node (got %d); pass the "
