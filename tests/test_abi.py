@@ -96,6 +96,11 @@ def test_round2_entry_points_validate_their_arguments_on_the_host(lib):
         "sn_embedding_sum_layers_f32": (None, 1, 1, 4, 2, None, i64, 8, None, None, None),
         "sn_embedding_sum_bwd_layers_f32": (None, 1, 1, 4, 2, None, i64, 8, None, None, None, None),
     }
+    cases.update({      # round 6
+        "sn_train_reduce_jobs_f32": (None, 0, None),
+        "sn_train_bn_bwd_f32": (None, 4, None, 4, 2, 1, 4, None, 0, None, None, 0, None, None, None, None, None, 0, None),
+        "sn_clock_probe": (0, None, None),
+    })
     for name, args in cases.items():
         rc = getattr(lib, name)(*args)
         assert rc == -1 and name.encode() in lib.sn_last_error(), (name, rc, lib.sn_last_error())

@@ -279,3 +279,76 @@ def test_scalar_mlp_closed_form_vs_float64(d, N, K, G):
             continue
         attributed(v, g32[k], g64[k], "d" + k)
     assert int(bn1.num_batches_tracked) == G and int(bn2.num_batches_tracked) == G
+
+
+# ----------------------------------------------------------------------------- round 6: the launch structures of a link's reductions
+def _train_step_grads(fuse_finish, defer_dw, monkeypatch):
+    """Gradients, loss and running statistics of one training step of a small ragged model under the given launch structure."""
+    from signnet_basisnet_amd import optim, synth, train_stage
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    monkeypatch.setattr(train_stage, "FUSE_FINISH", fuse_finish)
+    monkeypatch.setattr(train_stage, "DEFER_DW", defer_dw)
+    torch.manual_seed(7)
+    m = SignNetGNN(None, None, 128, 1, 3, 2, variant="gine", max_k=8).to(DEV).train()
+    m.attn_dropout = 0.0
+    o = optim.FlatAdam(m.parameters(), lr=1e-3)
+    d = synth.batch_to(synth.make_batch(40, seed=5), DEV)
+    target = torch.randn(40, 1, generator=torch.Generator().manual_seed(2)).to(DEV)
+    o.zero_grad()
+    loss = (m(d) - target).abs().mean()
+    loss.backward()
+    return o.flat_g.clone(), loss.item(), [b.clone() for b in m.buffers()]
+
+
+def test_deferred_dw_reduction_gives_the_same_bits(monkeypatch):
+    """The dW / db partials of every backward link reduced by ONE launch at the end of loss.backward() (sn_train_reduce_jobs_f32, queued
+    by autograd's end-of-backward callback) instead of one launch per link: the same arithmetic per parameter, so the same bits."""
+    g0, l0, b0 = _train_step_grads(False, False, monkeypatch)
+    g1, l1, b1 = _train_step_grads(False, True, monkeypatch)
+    assert l0 == l1 and torch.equal(g0, g1) and all(torch.equal(x, y) for x, y in zip(b0, b1))
+    assert g0.abs().max().item() > 0
+
+
+def test_in_launch_finishes_agree_with_the_separate_launches(monkeypatch):
+    """The opt-in launch structure (SN_TRAIN_FUSE_FINISH=1): batch statistics, BatchNorm-backward coefficients and the eps gradient finished
+    by the LAST-ARRIVING workgroup of the link's own launch (agent-scope ticket behind write-through partials).  Same slicing and order as
+    the finish kernels; the two are compiled separately, so FMA contraction may differ in the last bit: compared at 1e-5 of the largest
+    gradient entry (and the running statistics at 1e-6), far below the 1e-3 two fp32 evaluations of a step differ by."""
+    g0, l0, b0 = _train_step_grads(False, True, monkeypatch)
+    g1, l1, b1 = _train_step_grads(True, True, monkeypatch)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0)
+    assert (g0 - g1).abs().max().item() <= 1e-5 * g0.abs().max().item()
+    for x, y in zip(b0, b1):
+        if x.is_floating_point():
+            assert (x - y).abs().max().item() <= 1e-6 * max(1.0, x.abs().max().item())
+        else:
+            assert torch.equal(x, y)
+    # ... and replayed: tickets are reset by their last arriver, so a second and third step work from the same words
+    g2, _, _ = _train_step_grads(True, True, monkeypatch)
+    assert torch.equal(g1, g2)
+
+
+def test_reduce_jobs_entry_point_vs_torch():
+    import ctypes as C
+    from signnet_basisnet_amd import train_stage as T
+    from signnet_basisnet_amd._lib import check, lib, stream
+    torch.manual_seed(0)
+    parts = [torch.randn(37, 300, device=DEV), torch.randn(5, 64, device=DEV), torch.randn(256, 1000, device=DEV)]
+    ns = [260, 64, 1000]
+    outs = [torch.randn(n, device=DEV) for n in ns]
+    want = [o.double() + p[:, :n].double().sum(0) for o, p, n in zip(outs, parts, ns)]
+    arr = (T._ReduceJob * 3)()
+    for j, (p, n, o) in enumerate(zip(parts, ns, outs)):
+        arr[j] = T._ReduceJob(p.data_ptr(), p.shape[0], p.shape[1], n, o.data_ptr(), 1)
+    check(lib().sn_train_reduce_jobs_f32(arr, 3, stream()), "sn_train_reduce_jobs_f32")
+    for o, w in zip(outs, want):
+        assert (o.double() - w).abs().max().item() <= 1e-5 * w.abs().max().item()
+    assert lib().sn_train_reduce_jobs_f32(arr, 65, stream()) == -1        # more than SN_TRAIN_MAX_REDUCE_JOBS: refused on the host
+
+
+def test_clock_probe_counts_what_it_is_asked():
+    from signnet_basisnet_amd._lib import check, lib, stream
+    buf = torch.zeros(1, dtype=torch.int64, device=DEV)
+    check(lib().sn_clock_probe(2_000_000, buf.data_ptr(), stream()), "sn_clock_probe")
+    torch.cuda.synchronize()
+    assert 2_000_000 <= int(buf.item()) < 2_100_000
