@@ -123,6 +123,7 @@ struct EvdArgs {
   int32_t* status;
   int64_t total;
   int norm, k, skip;
+  float tol2;                  // EVD_TOL^2
 };
 
 // Four waves per graph (round 6; one wave per graph before: a 37-node graph walked 40 rows x (2 ds_bpermute + 6 FMA) serially per
@@ -251,9 +252,13 @@ __device__ __noinline__ void evd_jacobi_rows(const EvdArgs& a, const int32_t* cl
       sl ^= 1;
       const bool first = j < p;
       const float lo = first ? alpha : beta, hi = first ? beta : alpha;     // norm^2 of the lower / the higher column
-      const bool rot = active && gamma * gamma > (EVD_TOL * EVD_TOL) * (lo * hi) && fminf(lo, hi) > athr;
+      const bool rot = active && gamma * gamma > a.tol2 * (lo * hi) && fminf(lo, hi) > athr;
       if (__ballot(rot) == 0ull) continue;
-      EVD_ROWS(TV[i] = bperm(pl, V[i]);)          // (in flight under the rotation's parameters)
+      // (in flight under the rotation's parameters.  Measured and dropped, round 6: the V half deferred to the top of the NEXT step — its
+      //  partner rows requested behind that step's G rows, the update applied under the meeting's round trip — 0.237 against 0.222 ms per
+      //  128 graphs and 1.57 against 1.15 ms per 8 192: V is off the decision path, but the extra uniform branches and the longer live
+      //  ranges cost more than the one LDS round trip they hide)
+      EVD_ROWS(TV[i] = bperm(pl, V[i]);)
       rotated |= rot;
       pending |= rot && gamma * gamma > (EVD_NOCONV_TOL * EVD_NOCONV_TOL) * (lo * hi);
       float s = 0.f, tau = 0.f;
@@ -382,7 +387,9 @@ extern "C" int sn_laplacian_evd_f32(const int64_t* edge_index, int64_t E, const 
                        evoff, total, eigen_vectors, status);
     SN_CHECK_LAUNCH("k_evd_scatter");
   }
-  EvdArgs a{graph_ptr, evoff, cls_list, cls_count, eigen_values, eigen_vectors, pos_enc, status, total, norm, k, skip};
+  // (the rotation threshold is not a lever: 5e-7 ... 4e-6 all need the same 9 sweeps on the bench batch — a sweep's rotations are either
+  //  ~1e-3 or below 1e-7 — profiles/scripts/evd_tol_sweep.py)
+  EvdArgs a{graph_ptr, evoff, cls_list, cls_count, eigen_values, eigen_vectors, pos_enc, status, total, norm, k, skip, EVD_TOL * EVD_TOL};
   // a + b + c = B graphs in the three classes need at most ceil(a/4) + ceil(b/2) + c <= B + 2 blocks
   hipLaunchKernelGGL(k_evd_jacobi, dim3((unsigned)(B + 2)), dim3(64 * EVD_WV), 0, st, a, (int)B);
   SN_CHECK_LAUNCH("k_evd_jacobi");
