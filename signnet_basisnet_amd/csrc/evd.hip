@@ -199,6 +199,12 @@ __device__ __noinline__ void evd_jacobi_rows(const EvdArgs& a, const int32_t* cl
   }
   // the waves' partials of a column: part[slot][wave][lane] = (x, y); two alternating slots, ONE barrier per meeting.  A lane also
   // reads its PARTNER's partials (its column norm) from the same slot: no second cross-lane round trip for it.
+  // (Measured and dropped, round 6: an LDS MIRROR of every wave's rows of G and V — column-major, written by the owning lane with
+  //  ds_write_b128 after each update, read by the partner lane with ds_read_b128: 12 wide LDS instructions per rotating step instead of 20
+  //  ds_bpermutes — 0.229 against 0.222-0.230 ms per 128 graphs and 1.49 against 1.15 ms per 8 192.  Cycle stamps of the largest graph's
+  //  workgroup (s_memtime per phase, which itself costs ~70 cycles a stamp) gave, per step of ~1 500 cycles: partner rows + dot products
+  //  ~40 %, the rotating steps' V rows + parameters + updates ~30 %, the meeting (LDS write, barrier, reads, sums) ~25 % — with either
+  //  exchange.  The step is a chain of short dependent operations on ONE wave per SIMD: nothing hides their latencies.)
   float2* part = reinterpret_cast<float2*>(lds);
   auto meet = [&](int sl, float x, float y, int pl, float& sx, float& sy, float& px) {
     part[(sl * WV + wave) * 64 + lane] = make_float2(x, y);
