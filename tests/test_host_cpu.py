@@ -229,3 +229,91 @@ def test_learning_filters_factories_have_the_reference_state_dict_keys():
         LF.Transformer(4, dropout=0.1)
     with pytest.raises(RuntimeError):            # no CPU path: the forward needs the HIP library and device tensors
         LF.MLP(3)(torch.zeros(5, 3))
+
+
+def test_slice_graphs_is_the_oracle_of_the_sub_batch():
+    """dist.slice_graphs (what the default mode uses to serve the graphs around an oversize one through the stage kernels, and shard_batch to
+    cut a global batch): the graphs [lo, hi) of a collated batch as a batch of their own — the CPU oracle of the slice equals the rows of the
+    oracle of the whole batch (the eval forward never mixes graphs), for a middle range, the first graph and the last."""
+    import torch
+    from oracle import pyg_signnet as O
+    from signnet_basisnet_amd import dist as D
+    from signnet_basisnet_amd import synth
+    from signnet_basisnet_amd.pyg import SignNetGNN
+    torch.manual_seed(3)
+    ctor = (None, None, 16, 1, 2, 2)
+    m = SignNetGNN(*ctor, variant="gine", max_k=8)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    cfg = O.make_cfg("gine", *ctor)
+    data = synth.make_batch(7, seed=11)
+    with torch.no_grad():
+        whole = O.signnet_gnn(sd, cfg, data, training=False, max_k=8)
+        for lo, hi in ((2, 5), (0, 1), (6, 7), (0, 7)):
+            sub = D.slice_graphs(data, lo, hi)
+            assert sub.num_graphs == hi - lo and sub.sizes == data.sizes[lo:hi] and int(sub.batch.max()) == hi - lo - 1
+            assert sub.eigen_vectors.numel() == sum(n * n for n in sub.sizes) and int(sub.edge_index.max()) < sub.num_nodes
+            part = O.signnet_gnn(sd, cfg, sub, training=False, max_k=8)
+            assert (part - whole[lo:hi]).abs().max().item() <= 1e-5 * whole.abs().max().item()
+    # shard_batch is slice_graphs over shard_range
+    s1 = D.shard_batch(data, 1, 3)
+    lo, hi = D.shard_range(7, 1, 3)
+    s2 = D.slice_graphs(data, lo, hi)
+    assert torch.equal(s1.edge_index, s2.edge_index) and torch.equal(s1.x, s2.x) and s1.sizes == s2.sizes
+
+
+def test_deferred_reduction_queue_is_armed_once_per_backward_pass():
+    """train_stage's deferred dW reductions are flushed by ONE end-of-backward callback per backward pass (autograd's graph-task id),
+    re-armed for the next pass even if an earlier pass never ran its callback; outside a backward pass a job is reduced at once.  Host
+    logic only: the flush is replaced by a recorder."""
+    import torch
+    from signnet_basisnet_amd import train_stage as T
+    calls = []
+    real = T.flush_deferred
+
+    def recorder():
+        calls.append(len(T._Deferred.jobs))
+        T._Deferred.armed = False
+        T._Deferred.jobs, T._Deferred.outs = [], set()
+
+    T.flush_deferred = recorder
+    try:
+        outs = [torch.zeros(4) for _ in range(3)]
+
+        class F(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                for o in outs:
+                    T._defer_reduce(torch.zeros(8), 0, 2, 4, 4, o)
+                return g
+
+        x = torch.ones(2, requires_grad=True)
+        F.apply(x).sum().backward()
+        assert calls == [3], calls                      # one flush, at the end of the pass, with the three jobs
+        T._Deferred.armed = True                         # (a pass that raised before its callback ran leaves this behind)
+        F.apply(x).sum().backward()
+        assert calls == [3, 3], calls                    # the next pass still flushes its own jobs at its end
+        T._defer_reduce(torch.zeros(8), 0, 2, 4, 4, outs[0])
+        assert calls == [3, 3, 1], calls                 # no backward pass running: reduced at once
+        # two adds into one gradient never share a launch: the second one flushes the first
+        F2_calls = len(calls)
+
+        class G2(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                T._defer_reduce(torch.zeros(8), 0, 2, 4, 4, outs[0])
+                T._defer_reduce(torch.zeros(8), 0, 2, 4, 4, outs[0])
+                return g
+
+        G2.apply(x).sum().backward()
+        assert calls[F2_calls:] == [1, 1, 0], calls       # (the mid-pass flush re-arms: the pass's second callback finds nothing queued)
+    finally:
+        T.flush_deferred = real
+        T._Deferred.jobs, T._Deferred.outs, T._Deferred.armed = [], set(), False
