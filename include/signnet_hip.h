@@ -813,6 +813,13 @@ typedef struct {
   const float* fin_state; const float* fin_count; const float* fin_gamma;
   float* fin_coef; float* fin_dgamma; float* fin_dbeta; int fin_accumulate;
   float* fin_dot_out;
+  /* ABI 2 — the CONSUMER-side form: merge_sums != NULL: coef a | b | c of THIS link's BatchNorm backward are not given (coef_* NULL) but
+   * merged by the link itself, in its prologue, from the column-sum partials of sn_train_bn_bwd_sums_f32 / of the consumer link's
+   * sums_part (float[G * merge_nblk * 2 * d_out]) with the statistics merge_state ([5][G][d_out]) / merge_count ([G]) of the forward:
+   * no finish launch in front of the link.  Workgroup 0 writes d gamma / d beta (added when merge_accumulate). */
+  const float* merge_sums; int merge_nblk;
+  const float* merge_state; const float* merge_count; const float* merge_gamma;
+  float* merge_dgamma; float* merge_dbeta; int merge_accumulate;
 } sn_train_linear_bwd_args;
 
 /* What follows a backward link, in ONE launch (a block does one job): the reduction of the link's per-workgroup dW (and db) partials
@@ -846,6 +853,10 @@ int sn_train_reduce_parts_f32(const float* part, int nparts, int64_t stride, int
 #define SN_TRAIN_MAX_REDUCE_JOBS 64
 typedef struct { const float* part; int nparts; int64_t stride; int64_t n; float* out; int accumulate; } sn_train_reduce_job;
 int sn_train_reduce_jobs_f32(const sn_train_reduce_job* jobs, int njobs, void* stream);
+/* out[0] += (float) sum of n float64 partials, for up to SN_TRAIN_MAX_REDUCE_JOBS (part, n, out) in ONE launch: the eps gradients of every
+ * aggregation of a step (sn_train_linear_bwd_f32's dot_part), added once at the end of loss.backward(). */
+typedef struct { const double* part; int n; float* out; } sn_train_dot_job;
+int sn_train_dot_jobs_f64(const sn_train_dot_job* jobs, int njobs, void* stream);
 /* sn_train_bn_bwd_sums_f32 + sn_train_bn_bwd_finish_f32 in one launch (C <= 128): the last workgroup to arrive finishes. */
 int sn_train_bn_bwd_f32(const float* dy, int lddy, const float* z, int ldz, int64_t R, int G, int C, const int32_t* nvalid, int K,
                         const float* state, const float* count, int relu, const float* gamma, float* sums_part, float* coef,

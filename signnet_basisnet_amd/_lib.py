@@ -110,6 +110,7 @@ SIGNATURES = {
     "sn_train_reduce_parts_f32": [_p, _i, _l, _l, _p, _i, _p],
     "sn_train_dot_finish_f64": [_p, _i, _p, _i, _p],
     "sn_train_reduce_jobs_f32": [_p, _i, _p],
+    "sn_train_dot_jobs_f64": [_p, _i, _p],
     "sn_train_bn_bwd_f32": [_p, _i, _p, _i, _l, _i, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _p],
     "sn_masked_layernorm_bwd_acc_f32": [_p, _p, _p, _l, _i, _p, _f, _p, _i, _p, _p, _p, _p, _p],
     "sn_gin_aggregate_add_f32": [_p, _p, _p, _l, _i, _p, _p, _p, _p],

@@ -910,6 +910,90 @@ __device__ __forceinline__ void tdot_finish_tail(const double* part, int n, floa
   if (tid == 0) out[0] = out[0] + (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Round 6, the consumer-side form of the same finish: the backward link that READS the coefficients merges the column-sum partials of
+// its own BatchNorm in its prologue — every workgroup for its own group, in parallel, under the weight staging — instead of a finish
+// launch (k_tbn_bwd_finish / the finish blocks of k_tpost) in front of it: the finish step is removed, not moved.  Same slicing, order and
+// expressions as tbn_bwd_finish_block.  coef a | b | c of the workgroup's group go to LDS (`ocol`: [3][CO]); workgroup 0 also walks the
+// other groups and adds d gamma / d beta (summed over the groups in group order).  NT threads, C <= 128, C % 4 == 0; lds: 2*16*128 floats.
+struct TBMerge {
+  const float* sums; int nblk; const float* st; const float* cnt; const float* gamma; float* dgamma; float* dbeta; int acc;
+};
+template <int NT>
+__device__ __forceinline__ void tbn_bwd_merge(const TBMerge& f, int G, int C, int mygrp, bool all_groups, float* lds, float* ocol, int CO) {
+  static_assert(NT == 512, "16 slice lanes");
+  float* l1 = lds;                  // [16][128]
+  float* l2 = lds + 16 * 128;
+  const int c4 = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const bool col = 4 * c4 < C;
+  const int nblk = f.nblk;
+  const int per = (nblk + 15) / 16;
+  const int b0 = rl * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+  const int64_t GC = (int64_t)G * C;
+  f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = dg;
+  for (int grp = all_groups ? 0 : mygrp; grp < (all_groups ? G : mygrp + 1); ++grp) {
+    const float* S = f.sums + (int64_t)grp * nblk * 2 * C;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (col) {
+      for (int b = b0; b < b1; b += 8) {        // eight partials in flight
+        f32x4 v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; v2[u] = v1[u];
+          if (b + u < b1) { v1[u] = ld4a(S + (int64_t)(b + u) * 2 * C, 4 * c4, C); v2[u] = ld4a(S + (int64_t)(b + u) * 2 * C + C, 4 * c4, C); }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += v1[u]; s2 += v2[u]; }
+      }
+    }
+    *reinterpret_cast<float4*>(l1 + rl * 128 + 4 * c4) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(l2 + rl * 128 + 4 * c4) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    __syncthreads();
+    for (int step = 8; step >= 1; step >>= 1) {
+      if (rl < step) {
+        const f32x4 t1 = lds4(l1 + rl * 128 + 4 * c4) + lds4(l1 + (rl + step) * 128 + 4 * c4);
+        const f32x4 t2 = lds4(l2 + rl * 128 + 4 * c4) + lds4(l2 + (rl + step) * 128 + 4 * c4);
+        *reinterpret_cast<float4*>(l1 + rl * 128 + 4 * c4) = make_float4(t1[0], t1[1], t1[2], t1[3]);
+        *reinterpret_cast<float4*>(l2 + rl * 128 + 4 * c4) = make_float4(t2[0], t2[1], t2[2], t2[3]);
+      }
+      __syncthreads();
+    }
+    if (rl == 0 && col) {
+      const f32x4 t1 = lds4(l1 + 4 * c4), t2 = lds4(l2 + 4 * c4);
+      const float* s = f.st + (int64_t)grp * C;
+      const float n = f.cnt[grp];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * c4 + r;
+        const float mu = s[c], rsd = s[2 * GC + c];
+        const float A = (f.gamma ? f.gamma[c] : 1.f) * rsd;
+        const float m1 = n > 0.f ? t1[r] / n : 0.f, m2 = n > 0.f ? rsd * t2[r] / n : 0.f;
+        if (grp == mygrp) {
+          ocol[c] = A;
+          ocol[CO + c] = A * (m1 - m2 * rsd * mu);
+          ocol[2 * CO + c] = A * m2 * rsd;
+        }
+        db[r] += t1[r];
+        dg[r] += rsd * t2[r];
+      }
+    } else if (rl == 0 && grp == mygrp) {        // padding columns of the last tile: the identity (their dz must stay finite: 0 * NaN)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * c4 + r;
+        if (c < CO) { ocol[c] = 1.f; ocol[CO + c] = 0.f; ocol[2 * CO + c] = 0.f; }
+      }
+    }
+    __syncthreads();
+  }
+  if (all_groups && rl == 0 && col) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 4 * c4 + r;
+      if (f.dgamma) f.dgamma[c] = (f.acc ? f.dgamma[c] : 0.f) + dg[r];
+      if (f.dbeta) f.dbeta[c] = (f.acc ? f.dbeta[c] : 0.f) + db[r];
+    }
+  }
+}
+
 struct TBwd {
   int64_t R; int G; const int32_t* nvalid; int K; int d_in, d_out;
   const float* dy; int lddy; const float* zo; int ldzo;
@@ -921,6 +1005,7 @@ struct TBwd {
   const float* dotx; int lddot; double* dotp;      // dotp[blockIdx] = sum over my rows of gx . dotx   (the GIN / GINE eps gradient)
   int nblk;             // workgroups per group
   TBFin fin;            // fin.ticket != NULL: the producer's BatchNorm-backward finish / the eps finish by the launch's last workgroup
+  TBMerge mg;           // mg.sums != NULL: coef a | b | c are merged from these column-sum partials in the prologue (cA / cB / cC unused)
 };
 
 __host__ __device__ constexpr int stage_ld(int ntiles) { return ((16 * ntiles + 63) / 64) * 64 + 16; }   // row stride = 16 mod 64 banks
@@ -1030,6 +1115,9 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
   // held in registers), the weight image — then the LDS writes.  (One after the other these were five L2 round trips, ~6 us a launch.)
   request(r_lo);
   static_assert(CI <= 64 * TW && CO <= 64 * TW, "one column constant per thread");
+  const bool merged = a.mg.sums != nullptr;
+  if (merged)        // (the staging images are idle until the first round: the merge tree uses their LDS; its barriers come before any other LDS write)
+    tbn_bwd_merge<64 * TW>(a.mg, a.G, a.d_out, grp, blockIdx.x == 0, dzs, ocol, CO);
   float c_x[3] = {1.f, 0.f, 0.f}, c_o[5] = {1.f, 0.f, 0.f, 0.f, 1.f};
   {
     const int i = threadIdx.x;
@@ -1047,8 +1135,12 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
     for (int j = 0; j < 3; ++j) xcol[j * CI + threadIdx.x] = c_x[j];
   }
   if (threadIdx.x < CO) {
+    if (!merged) {                                                                          // (merged: a | b | c are in place)
 #pragma unroll
-    for (int j = 0; j < 5; ++j) ocol[j * CO + threadIdx.x] = c_o[j];
+      for (int j = 0; j < 3; ++j) ocol[j * CO + threadIdx.x] = c_o[j];
+    }
+#pragma unroll
+    for (int j = 3; j < 5; ++j) ocol[j * CO + threadIdx.x] = c_o[j];
   }
   // running column sums of gx: one LDS slot per (row tile, column), owned by one lane of one wave (kept out of the register file:
   // with them the kernel spilled)
@@ -1074,7 +1166,7 @@ __global__ __launch_bounds__(64 * TW, 1) void k_tlin_bwd(TBwd a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (z[r] * m0[r] + m1[r] > 0.f) ? v[r] : 0.f;
             }
-            if (cA) {
+            if (cA || merged) {
               const f32x4 A = lds4(ocol + c0), B = lds4(ocol + CO + c0), Cc = lds4(ocol + 2 * CO + c0);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (A[r] * v[r] - B[r]) - Cc[r] * z[r];
@@ -2029,7 +2121,12 @@ extern "C" int sn_train_linear_bwd_f32(const sn_train_linear_bwd_args* args, voi
   const int nblk = sn_train_linear_bwd_blocks(p.R, p.G);
   TBwd a{p.R, p.G, p.nvalid, p.K, p.d_in, p.d_out, p.dy, p.lddy, p.zo, p.ldzo, p.coef_a, p.coef_b, p.coef_c, p.mask_scale, p.mask_shift,
          p.x, p.ldx, p.x_scale, p.x_shift, p.x_relu, p.x_mean, p.W, p.ldw, p.gx, p.ldgx, p.sums_part, p.dw_part, p.want_db,
-         p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk, TBFin{}};
+         p.gx_accumulate, p.dot_x, p.lddot, p.dot_part, nblk, TBFin{}, TBMerge{}};
+  if (p.merge_sums) {
+    SN_REQUIRE(!p.coef_a && p.zo && p.merge_nblk >= 1 && p.merge_state && p.merge_count && al16(p.merge_sums),
+               "sn_train_linear_bwd_f32: merge_sums excludes coef_a/b/c and needs zo, merge_nblk, merge_state, merge_count (sums 16-byte aligned)");
+    a.mg = TBMerge{p.merge_sums, p.merge_nblk, p.merge_state, p.merge_count, p.merge_gamma, p.merge_dgamma, p.merge_dbeta, p.merge_accumulate};
+  }
   if (p.fin_coef || p.fin_dot_out) {
     SN_REQUIRE(!p.fin_coef || (p.x_mean && p.sums_part && al16(p.sums_part) && p.fin_state && p.fin_count),
                "sn_train_linear_bwd_f32: the fused BatchNorm finish needs x_mean, sums_part (16-byte aligned), fin_state and fin_count");
@@ -2160,6 +2257,23 @@ __global__ __launch_bounds__(1024) void k_tpost(TPost p) {
   if (b < p.nbf) { tbn_bwd_finish_block(b, tid, p.sums, p.nblk, p.G, p.C, p.st, p.cnt, p.gamma, p.coef, p.dgamma, p.dbeta, p.acc_f); return; }
   tdot_finish_block(tid, p.dpart, p.dn, p.dout, 1);
 }
+// ... for a table of eps gradients in one launch (a block per job): the dot finishes of every aggregation of a step, at the end of backward
+struct TDotJobs { const double* part[SN_TRAIN_MAX_REDUCE_JOBS]; float* out[SN_TRAIN_MAX_REDUCE_JOBS]; int n[SN_TRAIN_MAX_REDUCE_JOBS]; };
+__global__ __launch_bounds__(256) void k_tdot_jobs(TDotJobs J) {
+  tdot_finish_block(threadIdx.x, J.part[blockIdx.x], J.n[blockIdx.x], J.out[blockIdx.x], 1);
+}
+extern "C" int sn_train_dot_jobs_f64(const sn_train_dot_job* jobs, int njobs, void* stream) {
+  SN_REQUIRE(jobs && njobs >= 1 && njobs <= SN_TRAIN_MAX_REDUCE_JOBS, "sn_train_dot_jobs_f64: 1..%d jobs", SN_TRAIN_MAX_REDUCE_JOBS);
+  TDotJobs J{};
+  for (int j = 0; j < njobs; ++j) {
+    SN_REQUIRE(jobs[j].part && jobs[j].out && jobs[j].n >= 1, "sn_train_dot_jobs_f64: bad job %d", j);
+    J.part[j] = jobs[j].part; J.out[j] = jobs[j].out; J.n[j] = jobs[j].n;
+  }
+  hipLaunchKernelGGL(k_tdot_jobs, dim3((unsigned)njobs), dim3(256), 0, (hipStream_t)stream, J);
+  SN_CHECK_LAUNCH("sn_train_dot_jobs_f64");
+  return SN_OK;
+}
+
 extern "C" int sn_train_dot_finish_f64(const double* part, int n, float* out, int accumulate, void* stream) {
   SN_REQUIRE(part && out && n >= 1, "sn_train_dot_finish_f64: bad arguments");
   hipLaunchKernelGGL(k_tdot_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n, out, accumulate);

@@ -41,7 +41,9 @@ class _BwdArgs(C.Structure):
                 ("sums_part", C.c_void_p), ("dw_part", C.c_void_p), ("want_db", C.c_int), ("gx_accumulate", C.c_int),
                 ("dot_x", C.c_void_p), ("lddot", C.c_int), ("dot_part", C.c_void_p),
                 ("fin_state", C.c_void_p), ("fin_count", C.c_void_p), ("fin_gamma", C.c_void_p), ("fin_coef", C.c_void_p),
-                ("fin_dgamma", C.c_void_p), ("fin_dbeta", C.c_void_p), ("fin_accumulate", C.c_int), ("fin_dot_out", C.c_void_p)]
+                ("fin_dgamma", C.c_void_p), ("fin_dbeta", C.c_void_p), ("fin_accumulate", C.c_int), ("fin_dot_out", C.c_void_p),
+                ("merge_sums", C.c_void_p), ("merge_nblk", C.c_int), ("merge_state", C.c_void_p), ("merge_count", C.c_void_p),
+                ("merge_gamma", C.c_void_p), ("merge_dgamma", C.c_void_p), ("merge_dbeta", C.c_void_p), ("merge_accumulate", C.c_int)]
 
 
 class _SMlpArgs(C.Structure):
@@ -61,7 +63,10 @@ class _SMlpArgs(C.Structure):
 #                           a host-bound EAGER loop gains from it (4.32 -> 3.90 ms).
 #   SN_TRAIN_DEFER_DW=0     the dW / db reduction behind every link instead of one launch at the end of loss.backward().
 import os as _os
+#   SN_TRAIN_MERGE=0        the BatchNorm-backward coefficients from a finish launch in front of the backward link instead of merged by the
+#                           link itself in its prologue (the consumer-side form: removes the finish step instead of moving it).
 FUSE_FINISH = _os.environ.get("SN_TRAIN_FUSE_FINISH", "0") == "1"
+MERGE_COEF = _os.environ.get("SN_TRAIN_MERGE", "1") != "0"
 DEFER_DW = _os.environ.get("SN_TRAIN_DEFER_DW", "1") != "0"
 
 
@@ -91,6 +96,10 @@ class _ReduceJob(C.Structure):
                 ("accumulate", C.c_int)]
 
 
+class _DotJob(C.Structure):
+    _fields_ = [("part", C.c_void_p), ("n", C.c_int), ("out", C.c_void_p)]
+
+
 MAX_REDUCE_JOBS = 64
 
 
@@ -100,6 +109,7 @@ class _Deferred:
     gradient before the optimiser (or a gradient all-reduce: optim.FlatAdam flushes first).  Only gradients that are accumulated in
     place (`direct_grad`) are deferred; the arithmetic per parameter is that of sn_train_reduce_parts_f32, bit for bit."""
     jobs = []            # (partials tensor [kept alive], byte offset, nparts, stride, n, out tensor)
+    dots = []            # (float64 partials [kept alive], out tensor): the eps gradients, one launch for all of them
     outs = set()
     armed = False
     task = -1            # autograd graph-task id of the backward pass the callback was queued in
@@ -111,6 +121,10 @@ def _defer_reduce(part, off_floats, nparts, stride, n, out):
         flush_deferred()
     _Deferred.jobs.append((part, off_floats, nparts, stride, n, out))
     _Deferred.outs.add(key)
+    _arm()
+
+
+def _arm():
     # one end-of-backward callback per BACKWARD PASS (autograd's graph-task id): a pass that raised before its callback ran must not leave
     # the next one without (a callback that finds nothing queued does nothing)
     task = _graph_task_id()
@@ -125,8 +139,24 @@ def _defer_reduce(part, off_floats, nparts, stride, n, out):
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", lambda: -1)
 
 
+def _defer_dot(part, out):
+    key = out.data_ptr()
+    if key in _Deferred.outs or len(_Deferred.dots) >= MAX_REDUCE_JOBS:
+        flush_deferred()
+    _Deferred.dots.append((part, out))
+    _Deferred.outs.add(key)
+    _arm()
+
+
 def flush_deferred():
     _Deferred.armed = False
+    dots, _Deferred.dots = _Deferred.dots, []
+    if dots:
+        arr = (_DotJob * len(dots))()
+        for j, (part, out) in enumerate(dots):
+            arr[j] = _DotJob(part.data_ptr(), part.numel(), out.data_ptr())
+        with ops._span("sn_train_dot_jobs_f64"):
+            check(lib().sn_train_dot_jobs_f64(arr, len(dots), stream()), "sn_train_dot_jobs_f64")
     jobs, _Deferred.jobs, _Deferred.outs = _Deferred.jobs, [], set()
     for i in range(0, len(jobs), MAX_REDUCE_JOBS):
         chunk = jobs[i:i + MAX_REDUCE_JOBS]
@@ -214,7 +244,7 @@ def linear_fwd(x, R, G, W, b, nvalid, K, in_state=None, in_relu=False, out_relu=
 
 
 def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state=None, x_relu=False, want_sums=False,
-               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None, gx_into=None, finish_bn=None, dot_acc=None):
+               want_dx=True, want_db=True, dW_acc=None, db_acc=None, dot_x=None, gx_into=None, finish_bn=None, dot_acc=None, merge=None):
     """One pass: gx (the input gradient, masked by the operand's ReLU), its column-sum partials, dW / db.  See signnet_hip.h.
     dW_acc / db_acc: accumulate the weight / bias gradient into these buffers (returned dW / db are then None).
     dot_x: also sum gx . dot_x over all rows (per-workgroup partials, left on `linear_bwd.dot_part` for the caller to add up).
@@ -239,6 +269,14 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
                  int(x_relu), ptr(x_state.mean if (want_sums and x_state is not None) else None), ptr(W), W.stride(0),
                  ptr(gx), d_in, ptr(sums), ptr(dwp), int(want_db), int(gx_into is not None), ptr(dot_x),
                  0 if dot_x is None else dot_x.stride(0), None)
+    if merge is not None:
+        # merge = (sums_part, nblk, BNState, gamma, dgamma_acc, dbeta_acc): this link's BatchNorm-backward coefficients are merged from
+        # the column-sum partials by the link itself (coef must be None); d gamma / d beta are added in place by its workgroup 0
+        m_sums, m_nblk, m_st, m_gamma, m_dg, m_db = merge
+        a.merge_sums, a.merge_nblk = ptr(m_sums), int(m_nblk)
+        a.merge_state, a.merge_count = ptr(m_st.state), ptr(m_st.count)
+        a.merge_gamma = ptr(None if m_gamma is None else m_gamma.detach())
+        a.merge_dgamma, a.merge_dbeta, a.merge_accumulate = ptr(m_dg), ptr(m_db), 1
     linear_bwd.dot_part = None
     if dot_x is not None:
         linear_bwd.dot_part = alloc(G * nblk, dtype=torch.float64, device=dev)
@@ -263,13 +301,15 @@ def linear_bwd(dy, R, G, W, nvalid, K, x, zo=None, coef=None, mask=None, x_state
             a.fin_dot_out = ptr(dot_acc)
     with ops._span("sn_train_linear_bwd_f32"):
         check(lib().sn_train_linear_bwd_f32(C.byref(a), stream()), "sn_train_linear_bwd_f32")
-    if acc_w and DEFER_DW and (in_launch or not (fuse_bn is not None or fuse_dot)):
-        # the dW / db partials wait for the end of the backward pass (one reduction launch for all links)
+    if acc_w and DEFER_DW and (in_launch or fuse_bn is None):
+        # the dW / db partials — and the eps gradient's — wait for the end of the backward pass (one launch each for all links)
         _defer_reduce(dwp, 0, G * nblk, stride, nw, dW_acc)
         if want_db:
             _defer_reduce(dwp, nw, G * nblk, stride, d_out, db_acc)
         if fuse_dot:
-            linear_bwd._dot_keep, linear_bwd.dot_part = linear_bwd.dot_part, None      # (kept alive until the next call)
+            if not in_launch:
+                _defer_dot(linear_bwd.dot_part, dot_acc)
+            linear_bwd._dot_keep, linear_bwd.dot_part = linear_bwd.dot_part, None      # (eps_grad has nothing left to do)
         return gx, sums, nblk, None, None
     if acc_w:
         if in_launch:
@@ -382,22 +422,36 @@ def _mlp2_forward(x, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, res):
     return y, z1, z2, st1, st2
 
 
+def _can_merge(bn, R, C):
+    """The consumer-side merge needs the BatchNorm's affine gradients accumulated in place (a FlatAdam's parameters) and rows to walk."""
+    return (MERGE_COEF and R > 0 and C <= 128 and bn is not None and bn.weight is not None and
+            direct_grad(bn.weight) is not None and direct_grad(bn.bias) is not None)
+
+
 def _mlp2_backward(dy, x, z1, z2, st1, st2, R, G, lin1, bn1, lin2, bn2, nvalid, K, relu_out, want_dx, dot_x=None, dot_acc=None):
     """-> (dx, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2); parameter gradients already accumulated in-kernel come back as None."""
-    dg2 = dbe2 = coef2 = mask2 = None
+    dg2 = dbe2 = coef2 = mask2 = merge2 = None
     if st2 is not None:
-        coef2, dg2, dbe2 = bn_bwd(dy, z2, R, G, nvalid, K, st2, relu_out, bn2.weight, direct_grad(bn2.weight), direct_grad(bn2.bias))
+        if _can_merge(bn2, R, z2.shape[-1]):
+            sums2, nb2 = bn_bwd_sums(dy, z2, R, G, nvalid, K, st2, relu_out)
+            merge2 = (sums2, nb2, st2, bn2.weight, direct_grad(bn2.weight), direct_grad(bn2.bias))
+        else:
+            coef2, dg2, dbe2 = bn_bwd(dy, z2, R, G, nvalid, K, st2, relu_out, bn2.weight, direct_grad(bn2.weight), direct_grad(bn2.bias))
         mask2 = (st2.scale, st2.shift) if relu_out else None
+    merge1_ok = _can_merge(bn1, R, z1.shape[-1]) and direct_grad(lin2.weight) is not None and (lin2.bias is None or direct_grad(lin2.bias) is not None)
     gz1, sums1, nb1, dW2, db2 = linear_bwd(dy, R, G, lin2.weight, nvalid, K, z1, zo=z2 if st2 is not None else None, coef=coef2, mask=mask2,
                                            x_state=st1, x_relu=True, want_sums=True, want_db=lin2.bias is not None,
                                            dW_acc=direct_grad(lin2.weight), db_acc=direct_grad(lin2.bias),
-                                           finish_bn=bn1 if bn1.weight is not None else None)
-    if linear_bwd.coef is not None:           # the finish ran inside the link's post launch (d gamma / d beta accumulated in place)
-        coef1, dg1, dbe1 = linear_bwd.coef, None, None
+                                           finish_bn=None if merge1_ok else (bn1 if bn1.weight is not None else None), merge=merge2)
+    coef1 = dg1 = dbe1 = merge1 = None
+    if merge1_ok:                             # lin1's own launch merges sums1 (no finish in front of it)
+        merge1 = (sums1, nb1, st1, bn1.weight, direct_grad(bn1.weight), direct_grad(bn1.bias))
+    elif linear_bwd.coef is not None:         # the finish ran inside the link's post launch (d gamma / d beta accumulated in place)
+        coef1 = linear_bwd.coef
     else:
         coef1, dg1, dbe1 = bn_bwd_finish(sums1, nb1, st1, bn1.weight, direct_grad(bn1.weight), direct_grad(bn1.bias))
     dx, _, _, dW1, db1 = linear_bwd(gz1, R, G, lin1.weight, nvalid, K, x, zo=z1, coef=coef1, want_dx=want_dx, want_db=lin1.bias is not None,
-                                    dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias), dot_x=dot_x, dot_acc=dot_acc)
+                                    dW_acc=direct_grad(lin1.weight), db_acc=direct_grad(lin1.bias), dot_x=dot_x, dot_acc=dot_acc, merge=merge1)
     if bn1.weight is None:
         dg1 = dbe1 = None
     if bn2 is None or bn2.weight is None:
@@ -444,10 +498,15 @@ class _LinBn(Function):
         x, z = ctx.saved_tensors
         R, nvalid, K, relu, st, has_res, lin, bn = ctx.meta
         dy = _c(dy)
-        coef, dg, dbe = bn_bwd(dy, z, R, 1, nvalid, K, st, relu, bn.weight, direct_grad(bn.weight), direct_grad(bn.bias))
+        coef = dg = dbe = merge = None
+        if _can_merge(bn, R, z.shape[-1]):
+            sums, nb = bn_bwd_sums(dy, z, R, 1, nvalid, K, st, relu)
+            merge = (sums, nb, st, bn.weight, direct_grad(bn.weight), direct_grad(bn.bias))
+        else:
+            coef, dg, dbe = bn_bwd(dy, z, R, 1, nvalid, K, st, relu, bn.weight, direct_grad(bn.weight), direct_grad(bn.bias))
         dx, _, _, dW, db = linear_bwd(dy, R, 1, lin.weight, nvalid, K, x, zo=z, coef=coef, mask=(st.scale, st.shift) if relu else None,
                                       want_dx=ctx.needs_input_grad[0], want_db=lin.bias is not None,
-                                      dW_acc=direct_grad(lin.weight), db_acc=direct_grad(lin.bias))
+                                      dW_acc=direct_grad(lin.weight), db_acc=direct_grad(lin.bias), merge=merge)
         if bn.weight is None:
             dg = dbe = None
         return dx, dW, db, dg, dbe, (dy if has_res else None), None, None, None, None, None

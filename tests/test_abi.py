@@ -135,6 +135,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(sn_train_linear_args, fin_eps), offsetof(sn_train_linear_args, fin_count),
          offsetof(sn_train_linear_bwd_args, fin_coef), offsetof(sn_train_linear_bwd_args, fin_dot_out), sizeof(sn_train_reduce_job),
          offsetof(sn_train_reduce_job, out));
+  printf("%zu %zu\n", offsetof(sn_train_linear_bwd_args, merge_sums), offsetof(sn_train_linear_bwd_args, merge_accumulate));
   printf("%zu %zu %zu %zu\n", sizeof(sn_plan_early), offsetof(sn_plan_early, max_graph_edges), offsetof(sn_plan_early, host), offsetof(sn_plan_bins, phi_bin_mem));
   return 0;
 }'''
@@ -158,6 +159,7 @@ int main(void) {
             S(train_stage._PostArgs), train_stage._PostArgs.sums_part.offset, train_stage._PostArgs.dot_part.offset,
             train_stage._LinArgs.fin_eps.offset, train_stage._LinArgs.fin_count.offset, train_stage._BwdArgs.fin_coef.offset,
             train_stage._BwdArgs.fin_dot_out.offset, S(train_stage._ReduceJob), train_stage._ReduceJob.out.offset,
+            train_stage._BwdArgs.merge_sums.offset, train_stage._BwdArgs.merge_accumulate.offset,
             S(ops._PlanEarlyC), ops._PlanEarlyC.max_graph_edges.offset, ops._PlanEarlyC.host.offset, ops._PlanBinsC.phi_bin_mem.offset]
     assert got == want
 
