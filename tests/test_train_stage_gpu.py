@@ -328,6 +328,19 @@ def test_in_launch_finishes_agree_with_the_separate_launches(monkeypatch):
     assert torch.equal(g1, g2)
 
 
+def test_consumer_side_coefficient_merge_agrees_with_the_finish_launches(monkeypatch):
+    """SN_TRAIN_MERGE (default on): the backward link merges the column-sum partials of its own BatchNorm in its prologue instead of reading
+    coefficients a finish launch wrote; same slicing and order, separately compiled: gradients agree to 1e-6 of the largest entry, the
+    forward (loss, running statistics) is untouched."""
+    from signnet_basisnet_amd import train_stage
+    monkeypatch.setattr(train_stage, "MERGE_COEF", False)
+    g0, l0, b0 = _train_step_grads(False, True, monkeypatch)
+    monkeypatch.setattr(train_stage, "MERGE_COEF", True)
+    g1, l1, b1 = _train_step_grads(False, True, monkeypatch)
+    assert l0 == l1 and all(torch.equal(x, y) for x, y in zip(b0, b1))
+    assert (g0 - g1).abs().max().item() <= 1e-6 * g0.abs().max().item()
+
+
 def test_reduce_jobs_entry_point_vs_torch():
     import ctypes as C
     from signnet_basisnet_amd import train_stage as T
